@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — TEPS of the boolean-vxm BFS on synthetic R-MAT graphs (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole BFS (the GrB_vxm frontier loop behind algo.BFS) from one of the 64
+Graph500-style roots of a synthetic R-MAT graph resident in HBM.  N=1 runs BASELINE.json
+configs[1] (RMAT scale-22, edge factor 16).  N>1 runs the same path on the column-slab
+partition (one process per GPU, frontier all-gather over RCCL each level) with weak scaling:
+scale = 22 + log2(N), i.e. the per-GPU edge count stays that of RMAT-22 (override: --scale).
+
+Rank 0 prints ONE JSON line; `value` = total traversed edges (sum over BFS runs of the
+out-degrees of reached vertices) / max-over-ranks wall time of the K steps.
+Extra objects: `roofline` (dominant kernel, HIP-event timed in a second pass over the same
+roots), `spmv_full_pass` (the north-star "RMAT-22 boolean SpMV" full-matrix pass) and
+`cpu_baseline` (the CPU oracle's BFS timed on this box's host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def pick_roots(A, want=64):
+    """First `want` vertex ids with out-degree > 0."""
+    roots, hi = [], 4096
+    n = A.nrows
+    while len(roots) < want:
+        rows, _, _ = A.extract(0, min(hi, n) - 1)
+        roots = np.unique(rows)[:want].tolist()
+        if hi >= n:
+            break
+        hi *= 4
+    return [int(r) for r in roots]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--scale", type=int, default=0, help="R-MAT scale (default 22 + log2(gpus))")
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--alpha", type=float, default=0.0, help="push->pull switch factor (0 = library default)")
+    ap.add_argument("--force-dir", type=int, default=0, help="0 auto, 1 push only, 2 pull only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+
+    from falkordb_amd import dist as fdist
+    from falkordb_amd import engine
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as td
+        td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    scale = args.scale or (22 + int(round(math.log2(world))))
+    seed = 0x5EED1234 + scale
+    ctx = engine.Context(local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    info = ctx.device_info()
+
+    # ---- synthetic input, resident in HBM before anything is timed ----------------------
+    t_build = time.time()
+    A_full = ctx.mat_rmat(scale, args.edge_factor, seed)
+    n, nnz = A_full.nrows, A_full.nvals
+    roots = pick_roots(A_full, 64)
+    if use_dist:
+        lo, hi, slab = fdist.slab_range(n, rank, world)
+        A = A_full.col_slab(lo, min(hi, n))
+        A_full.free()
+        At = A.transpose()
+    else:
+        A = A_full
+        At = A.transpose()
+    backend = fdist.HipSlabBackend(ctx, A, At, rank if use_dist else 0, world if use_dist else 1, dev)
+    plan = backend.plan
+    plan.tune(alpha=args.alpha, force_direction=args.force_dir)
+    ctx.sync()
+    t_build = time.time() - t_build
+
+    def run_one(src):
+        if use_dist:
+            backend.run(src)
+        else:
+            plan.run(src, -1, False)
+
+    # ---- untimed pass over every distinct root: per-root traversed-edge counts + warm-up --
+    edges_by_root = {}
+    stats_by_root = {}
+    for r in roots:
+        run_one(r)
+        st = plan.stats()
+        edges_by_root[r] = st["edges_traversed"]
+        stats_by_root[r] = st
+    if use_dist:
+        t = torch.tensor([edges_by_root[r] for r in roots], dtype=torch.int64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.SUM)  # slab-local out-degree sums -> global
+        for r, v in zip(roots, t.tolist()):
+            edges_by_root[r] = int(v)
+    for i in range(args.warmup):
+        run_one(roots[i % len(roots)])
+
+    # ---- timed region: exactly K steps ------------------------------------------------------
+    def fence():
+        if use_dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_one(roots[i % len(roots)])
+    fence()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_edges = sum(edges_by_root[roots[i % len(roots)]] for i in range(args.steps))
+    teps = total_edges / dt
+
+    # ---- roofline: per-kernel HIP-event timings over the same roots (second pass) ------------
+    roofline = None
+    spmv = None
+    if not args.no_roofline and not use_dist:
+        plan.profile(True)
+        for i in range(args.steps):
+            plan.run(roots[i % len(roots)], -1, False)
+        prof = plan.profile_read()
+        plan.profile(False)
+        steps = [p for p in prof if p["kernel"].startswith("bfs_step") and p["launches"]]
+        if steps:
+            dom = max(steps, key=lambda p: p["ms"])
+            per_launch_bytes = dom["alg_bytes"] / dom["launches"]
+            per_launch_ms = dom["ms"] / dom["launches"]
+            ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "alg_bytes_per_launch": int(per_launch_bytes), "avg_launch_us": round(per_launch_ms * 1e3, 2),
+                        "launches": int(dom["launches"]),
+                        "all_kernels": [{"kernel": p["kernel"], "ms_total": round(p["ms"], 4),
+                                         "launches": int(p["launches"]),
+                                         "GBps": round(p["alg_bytes"] / max(p["ms"], 1e-9) / 1e6, 2)} for p in prof]}
+        # the north-star full-matrix boolean SpMV pass (dense frontier, no mask, no early exit)
+        ms, ab = engine.bench_spmv(ctx, At, which=0, iters=20)
+        g = ab / (ms * 1e-3) / 1e9
+        spmv = {"kernel": "vxm_pull_kernel<full>", "avg_launch_us": round(ms * 1e3, 2), "alg_bytes": int(ab),
+                "achieved": round(g, 2), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(g / HBM_PEAK_GBS, 4)}
+
+    # ---- CPU baseline: the oracle's BFS on the same graph, bounded sample, rank 0 / N=1 only ----
+    cpu = None
+    if not args.no_cpu_baseline and not use_dist and rank == 0:
+        import oracle
+        rp, ci, _ = A.export_csr()
+        a = oracle.CSR(n, n, rp, ci)
+        e_cpu, t_cpu, k = 0, 0.0, 0
+        for r in roots:
+            t1 = time.perf_counter()
+            _, _, e = oracle.bfs(a, r, -1, want_parent=False)
+            t_cpu += time.perf_counter() - t1
+            e_cpu += e
+            k += 1
+            if t_cpu > args.cpu_seconds:
+                break
+        cpu = {"value": round(e_cpu / t_cpu, 1), "unit": "TEPS", "cores": 1, "kind": "port",
+               "sample": f"{k} of the 64 BFS roots on the same RMAT-{scale} graph, serial C oracle (oracle/oracle.c orc_bfs), "
+                         f"{t_cpu:.1f} s; CPU stand-in, not SuiteSparse:GraphBLAS (absent from this image)"}
+
+    if rank == 0:
+        st0 = stats_by_root[roots[0]]
+        out = {
+            "metric": "traversed edges/sec (TEPS) on BFS (boolean vxm frontier loop), synthetic R-MAT",
+            "value": round(teps, 1),
+            "unit": "TEPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"RMAT scale-{scale} BFS (boolean GrB_vxm frontier loop), edge factor {args.edge_factor}, "
+                            f"64 Graph500-style roots, directed, deduplicated",
+                "scale": scale, "vertices": int(n), "edges": int(nnz),
+                "parallelism": ("1 GPU" if world == 1 else f"column-slab x{world} + frontier all-gather (RCCL)"),
+                "direction": {0: "auto push/pull", 1: "push only", 2: "pull only"}[args.force_dir],
+                "device": info["name"], "build_seconds": round(t_build, 2),
+                "root0_levels": st0["levels"], "root0_push_levels": st0["push_levels"],
+                "root0_pull_levels": st0["pull_levels"],
+            },
+            "roofline": roofline,
+            "spmv_full_pass": spmv,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""Build libfgpu.so (HIP, gfx950) in-tree.
+
+hipcc cross-compiles without a GPU, so this runs both in the build container and on the
+GPU box.  Objects go to falkordb_amd/lib/obj, the library to falkordb_amd/lib/libfgpu.so
+(git-ignored, but shipped to the GPU box by gpurun).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libfgpu.so")
+SOURCES = ["ctx.hip", "prims.hip", "mat.hip", "bfs.hip", "spgemm.hip", "host.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a: str, b: str) -> bool:
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def _deps() -> list[str]:
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [
+        os.path.join(inc, f) for f in os.listdir(inc)
+    ]
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    deps = _deps()
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = [HIPCC, *FLAGS, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{r.stderr}")
+        return r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for err in ex.map(cc, jobs):
+                if verbose and err:
+                    print(err, file=sys.stderr)
+    objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES
+            if os.path.exists(os.path.join(CSRC, s))]
+    if force or jobs or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,966 @@
+// bfs.hip — boolean vxm over bitmap vectors and the level-synchronous BFS built on it.
+//
+// Replaces LAGr_BreadthFirstSearch_Extended as called by algo.BFS
+// (reference graph/src/runtime/functions/algo_procedures.rs:1079-1088; binding
+// graph/src/graph/graphblas/lagraphx_bindings.rs:585-594) and the GrB_vxm /
+// GrB_mxv it is built from (graphblas/mod.rs:11173-11193):
+//     q<!visited, replace> = q x A      (push, CSR of A)
+//     q<!visited, replace> = A' x q     (pull, CSR of A' = in-edges)
+//
+// MI355X design (no MFMA — this is HBM/L2-bound integer work):
+//  * every vector is an N-bit bitmap (512 KiB at scale 22, 8 MiB at scale 26): it lives in
+//    the 4 MiB-per-XCD L2s, so frontier tests never reach HBM and rowptr reads of a vertex
+//    block are contiguous;
+//  * push: 1024 consecutive vertices per workgroup, the out-edges of the active ones are
+//    concatenated through an LDS prefix sum and walked edge-parallel (coalesced colidx);
+//    rows >= HUB_DEG come from a static per-matrix chunk list so R-MAT hubs spread over CUs;
+//  * pull: one wavefront owns 64 consecutive destinations = one 64-bit output word.  The
+//    wave streams the contiguous colidx span of its 64 rows 256 B per load; ballot() of the
+//    frontier hits gives a 64-bit hit mask and every lane intersects it with its own row's
+//    [begin,end) window — no per-element owner search, no atomics, full-word stores;
+//  * the level loop is device-driven: a control block picks push/pull and raises `done`;
+//    the host only enqueues (step, commit, ctrl) triples and polls `done` every few levels.
+//  * multi-GPU: column-slab partition (rank owns destinations [lo,hi) and holds A[:,lo:hi)
+//    + A'[lo:hi,:]); the only exchange is an all-gather of the owned new-frontier words,
+//    issued by the host loop between step() and commit() (RCCL over xGMI).
+#include "common.hpp"
+
+namespace fgpu {
+
+constexpr int STAT_SLOTS = 256;
+
+struct BfsCtrl {
+    i32 level;       // level of the frontier in `cur` (source = 0)
+    i32 done;
+    i32 direction;   // direction of the NEXT step: 1 push, 2 pull
+    i32 max_level;   // <0 unlimited
+    u64 n_frontier;  // |cur| (global)
+    u64 m_frontier;  // sum of slab out-degrees over cur (local slab of A)
+    u64 reached;     // vertices reached so far incl. source (global)
+    u64 edges_traversed;  // sum over levels of m_frontier (local)
+    u64 visited_in_deg;   // sum of slab in-degrees of visited owned vertices (local)
+    u64 scanned_push, scanned_pull;
+    u32 push_levels, pull_levels;
+    u32 has_at, force_dir;
+    float alpha;
+    u32 pad;
+    u64 nnz_at;
+    // per-launch accumulators, spread over slots to keep same-address atomics off the critical path
+    u64 slot_count[STAT_SLOTS];
+    u64 slot_mf[STAT_SLOTS];
+    u64 slot_indeg[STAT_SLOTS];
+    u64 slot_scan[STAT_SLOTS];
+};
+
+struct BfsArgs {
+    CsrView A, At;
+    const u32* hubA;  u32 n_hubA;
+    const u32* hubAt; u32 n_hubAt;
+    u32 n;        // global vertex count
+    u32 lo, hi;   // owned destination range (hi <= n_pad)
+    u64* cur;         // global frontier bitmap (n_pad bits)
+    u64* nxt_local;   // owned slab of the next frontier (slab bits)
+    u64* nxt_global;  // all-gathered next frontier (n_pad bits); == nxt_local when single rank
+    u64* visited;     // global-indexed, only [lo,hi) maintained
+    i32* level;
+    u32* parent;      // nullable
+    BfsCtrl* ctrl;
+    u32 nw;           // u64 words in a global bitmap
+};
+
+__device__ __forceinline__ bool test_bit(const u64* bm, u32 v) {
+    return (((const u32*)bm)[v >> 5] >> (v & 31)) & 1u;
+}
+
+__device__ __forceinline__ u64 range_mask(u32 lo, u32 hi) {  // bits [lo,hi), 0 <= lo <= hi <= 64
+    u64 a = (hi >= 64) ? ~0ull : ((1ull << hi) - 1ull);
+    u64 b = (lo >= 64) ? ~0ull : ((1ull << lo) - 1ull);
+    return a & ~b;
+}
+
+// ---------------------------------------------------------------------------------
+// push: one workgroup expands 1024 consecutive source vertices
+// ---------------------------------------------------------------------------------
+constexpr u32 PUSH_VPB = 1024;
+
+template <bool PARENT>
+__device__ __forceinline__ void push_visit(const BfsArgs& a, const u64* __restrict__ mask, u32 u, u32 v) {
+    const u32 bit = 1u << (u & 31);
+    if (mask && ((((const u32*)mask)[u >> 5]) & bit)) return;
+    const u32 ul = u - a.lo;
+    u32* w = ((u32*)a.nxt_local) + (ul >> 5);
+    if (*w & bit) return;  // hint only: a stale read just costs a redundant atomic
+    u32 old = atomicOr(w, bit);
+    if (PARENT && !(old & bit)) a.parent[u] = v;
+}
+
+template <bool PARENT>
+__device__ void push_body(const BfsArgs& a, const u64* __restrict__ frontier, const u64* __restrict__ mask,
+                          u64* scanned_out) {
+    __shared__ u32 s_off[PUSH_VPB];
+    __shared__ u32 s_start[PUSH_VPB];
+    __shared__ u64 s_fw[PUSH_VPB / 64];
+    __shared__ u32 s_wave[4];
+    const u32 t = threadIdx.x;
+    const u32 nblk = (a.n + PUSH_VPB - 1) / PUSH_VPB;
+    const u32 nitems = nblk + a.n_hubA;
+    u64 scanned = 0;
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        if (item >= nblk) {
+            // hub chunk: (row, begin, end)
+            const u32 h = item - nblk;
+            const u32 row = a.hubA[3 * h], b = a.hubA[3 * h + 1], e = a.hubA[3 * h + 2];
+            if (!test_bit(frontier, row)) continue;
+            for (u32 i = b + t; i < e; i += 256) push_visit<PARENT>(a, mask, a.A.colidx[i], row);
+            if (t == 0) scanned += e - b;
+            continue;
+        }
+        const u32 base = item * PUSH_VPB;
+        u64 fw = 0;
+        if (t < PUSH_VPB / 64) {
+            u32 wi = (base >> 6) + t;
+            fw = (wi < a.nw) ? frontier[wi] : 0ull;
+            s_fw[t] = fw;
+        }
+        if (!__syncthreads_or(fw != 0ull)) continue;
+        // 4 consecutive vertices per thread
+        const u32 v0 = base + 4 * t;
+        const u32 nib = (u32)(s_fw[(4 * t) >> 6] >> ((4 * t) & 63)) & 0xFu;
+        u32 rp[5];
+        if (nib && v0 + 4 <= a.n) {
+            const uint4 q = *(const uint4*)(a.A.rowptr + v0);
+            rp[0] = q.x; rp[1] = q.y; rp[2] = q.z; rp[3] = q.w;
+            rp[4] = a.A.rowptr[v0 + 4];
+        } else if (nib) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) rp[j] = a.A.rowptr[(v0 + j <= a.n) ? (v0 + j) : a.n];
+        } else {
+            rp[0] = rp[1] = rp[2] = rp[3] = rp[4] = 0;
+        }
+        u32 deg[4], tsum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32 d = ((nib >> j) & 1u) ? (rp[j + 1] - rp[j]) : 0u;
+            if (d >= HUB_DEG) d = 0;  // expanded by the hub items
+            deg[j] = d;
+            tsum += d;
+        }
+        u32 total;
+        u32 ex;
+        {   // block exclusive scan of tsum
+            const u32 lane = lane_id();
+            u32 inc = tsum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                u32 y = __shfl_up(inc, d, 64);
+                if (lane >= (u32)d) inc += y;
+            }
+            if (lane == 63) s_wave[t >> 6] = inc;
+            __syncthreads();
+            u32 wbase = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32 x = s_wave[i];
+                if ((u32)i < (t >> 6)) wbase += x;
+                tot += x;
+            }
+            total = tot;
+            ex = wbase + inc - tsum;
+        }
+        {
+            uint4 o, s;
+            o.x = ex; o.y = ex + deg[0]; o.z = o.y + deg[1]; o.w = o.z + deg[2];
+            s.x = rp[0]; s.y = rp[1]; s.z = rp[2]; s.w = rp[3];
+            *(uint4*)(s_off + 4 * t) = o;
+            *(uint4*)(s_start + 4 * t) = s;
+        }
+        __syncthreads();
+        for (u32 e = t; e < total; e += 256) {
+            // last idx with s_off[idx] <= e
+            u32 lo = 0, hi = PUSH_VPB;
+#pragma unroll
+            for (int it = 0; it < 10; ++it) {
+                u32 mid = (lo + hi) >> 1;
+                if (s_off[mid] <= e) lo = mid; else hi = mid;
+            }
+            const u32 u = a.A.colidx[s_start[lo] + (e - s_off[lo])];
+            push_visit<PARENT>(a, mask, u, base + lo);
+        }
+        if (t == 0) scanned += total;
+        __syncthreads();
+    }
+    *scanned_out = scanned;
+}
+
+// ---------------------------------------------------------------------------------
+// pull: one wavefront per 64 consecutive destinations, flat streaming of the colidx span
+// ---------------------------------------------------------------------------------
+template <bool PARENT, bool EARLY_EXIT>
+__device__ void pull_body(const BfsArgs& a, const u64* __restrict__ frontier, const u64* __restrict__ mask,
+                          u64* __restrict__ out_words /* indexed by (v - lo) >> 6 */, u64* scanned_out) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 ngroups = (a.hi - a.lo + 63) >> 6;
+    const u32* __restrict__ f32 = (const u32*)frontier;
+    u64 scanned = 0;
+    for (u32 g = wave; g < ngroups; g += nwaves) {
+        const u32 v = a.lo + (g << 6) + lane;
+        const u64 mword = mask ? mask[(a.lo >> 6) + g] : 0ull;
+        if (mword == ~0ull) continue;
+        u32 rb = 0, re = 0;
+        const u32 vc = v < a.n ? v : a.n;
+        rb = a.At.rowptr[vc];
+        re = a.At.rowptr[(vc + 1 <= a.n) ? (vc + 1) : a.n];
+        const u32 s = __shfl(rb, 0, 64);
+        const u32 e = __shfl(re, 63, 64);
+        const u32 re0 = re;
+        bool need = (v < a.n) && !((mword >> lane) & 1ull) && (re > rb) && (re - rb < HUB_DEG);
+        // rows we do not need get an empty window; long ones let the stream jump over them
+        // an unvisited hub row shares this wave's output word with the hub items below, which
+        // publish with atomicOr: the wave must then OR its word in as well instead of storing it
+        const bool hub_here = __ballot((v < a.n) && !((mword >> lane) & 1ull) && (re - rb >= HUB_DEG)) != 0ull;
+        const bool skipper = !need && (re - rb) >= 128;
+        const bool any_skipper = __ballot(skipper) != 0ull;
+        if (!need) { re = rb; }
+        u64 pending = __ballot(need);
+        if (pending == 0ull) continue;
+        bool found = false;
+        u32 par = 0;
+        const u32 wb = need ? rb : 0xFFFFFFFFu, we = need ? re : 0u;  // my window
+        const u32 sb = rb, se = skipper ? re0 : rb;                    // skip window
+        u32 Q = s;
+        while (Q < e) {
+            if (any_skipper) {
+                u64 in = __ballot(skipper && sb <= Q && Q + 64 <= se);
+                if (in) {
+                    Q = __shfl(se, (int)__builtin_ctzll(in), 64);
+                    continue;
+                }
+            }
+            // 4 x 64 elements per trip
+            u32 c[4];
+            bool h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u32 q = Q + 64 * k + lane;
+                c[k] = (q < e) ? a.At.colidx[q] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                h[k] = (c[k] != 0xFFFFFFFFu) && ((f32[c[k] >> 5] >> (c[k] & 31)) & 1u);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u64 H = __ballot(h[k]);
+                if (H) {
+                    const u32 q0 = Q + 64 * k;
+                    // my window clipped to [q0, q0+64)
+                    u32 lo = wb > q0 ? wb - q0 : 0u;
+                    u32 hi = we > q0 ? we - q0 : 0u;
+                    if (lo > 64) lo = 64;
+                    if (hi > 64) hi = 64;
+                    const u64 mine = (hi > lo) ? (H & range_mask(lo, hi)) : 0ull;
+                    if (PARENT) {
+                        // parent = column held by the lane of my first hit
+                        int src = mine ? (int)__builtin_ctzll(mine) : (int)lane;
+                        u32 pc = __shfl(c[k], src, 64);
+                        if (mine && !found) par = pc;
+                    }
+                    if (mine) found = true;
+                }
+            }
+            {
+                u32 span = e - Q;
+                scanned += (lane == 0) ? (span < 256 ? span : 256) : 0;
+            }
+            Q += 256;
+            if (EARLY_EXIT) {
+                if (__ballot(need && !found) == 0ull) break;
+            }
+        }
+        const u64 word = __ballot(found);
+        if (lane == 0 && word) {
+            if (hub_here) {
+                atomicOr(((u32*)out_words) + 2 * g, (u32)word);
+                atomicOr(((u32*)out_words) + 2 * g + 1, (u32)(word >> 32));
+            } else {
+                out_words[g] = word;
+            }
+        }
+        if (PARENT && found) a.parent[v] = par;
+    }
+    // hub rows of At: one workgroup-sized chunk per item, whole workgroups of this launch
+    // pick them up after their wave groups (block-uniform loop)
+    {
+        __shared__ u32 s_hit[2];
+        for (u32 h = blockIdx.x; h < a.n_hubAt; h += gridDim.x) {
+            const u32 row = a.hubAt[3 * h], b = a.hubAt[3 * h + 1], e2 = a.hubAt[3 * h + 2];
+            if (row < a.lo || row >= a.hi || row >= a.n) continue;
+            if (mask && ((mask[row >> 6] >> (row & 63)) & 1ull)) continue;
+            if (threadIdx.x == 0) { s_hit[0] = 0; s_hit[1] = 0xFFFFFFFFu; }
+            __syncthreads();
+            bool hit = false;
+            u32 pc = 0xFFFFFFFFu;
+            for (u32 i = b + threadIdx.x; i < e2; i += 256) {
+                u32 c = a.At.colidx[i];
+                if ((f32[c >> 5] >> (c & 31)) & 1u) { hit = true; pc = c; if (EARLY_EXIT) break; }
+            }
+            if (hit) { s_hit[0] = 1; if (PARENT) atomicMin(&s_hit[1], pc); }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                scanned += e2 - b;
+                if (s_hit[0]) {
+                    const u32 rl = row - a.lo;
+                    u32 old = atomicOr(((u32*)out_words) + (rl >> 5), 1u << (rl & 31));
+                    if (PARENT && !(old & (1u << (rl & 31)))) a.parent[row] = s_hit[1];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // reduce scanned over the wave (lane 0 holds it)
+    *scanned_out = scanned;
+}
+
+// ---------------------------------------------------------------------------------
+// level kernels
+// ---------------------------------------------------------------------------------
+template <bool PARENT>
+__global__ __launch_bounds__(256) void bfs_step_kernel(BfsArgs a) {
+    BfsCtrl* c = a.ctrl;
+    if (c->done) return;
+    const int dir = c->direction;
+    u64 scanned = 0;
+    if (dir == 1) {
+        push_body<PARENT>(a, a.cur, a.visited, &scanned);
+        if (threadIdx.x == 0 && scanned)
+            atomicAdd((unsigned long long*)&c->slot_scan[blockIdx.x & (STAT_SLOTS - 1)], (unsigned long long)scanned);
+    } else {
+        pull_body<PARENT, true>(a, a.cur, a.visited, a.nxt_local, &scanned);
+        // lane 0 of each wave and thread 0 (hub items) hold partial sums
+        __shared__ unsigned long long s_acc;
+        if (threadIdx.x == 0) s_acc = 0;
+        __syncthreads();
+        if (scanned) atomicAdd(&s_acc, (unsigned long long)scanned);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_acc)
+            atomicAdd((unsigned long long*)&c->slot_scan[blockIdx.x & (STAT_SLOTS - 1)], s_acc);
+    }
+}
+
+// After the (all-)gather: adopt the new frontier, mark owned vertices, reset the local slab,
+// gather the statistics the control kernel needs.  One wavefront per 64-bit word.
+__global__ __launch_bounds__(256) void bfs_commit_kernel(BfsArgs a) {
+    BfsCtrl* c = a.ctrl;
+    if (c->done) return;
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const i32 newlevel = c->level + 1;
+    u64 cnt = 0, mf = 0, indeg = 0;
+    const u32 lo_w = a.lo >> 6, hi_w = (a.hi + 63) >> 6;
+    for (u32 w = wave; w < a.nw; w += nwaves) {
+        const u64 g = a.nxt_global[w];
+        const bool owned = (w >= lo_w && w < hi_w);
+        if (lane == 0) {
+            a.cur[w] = g;
+            if (owned) {
+                a.nxt_local[w - lo_w] = 0ull;  // also clears nxt_global when single-rank (same buffer)
+                if (g) a.visited[w] |= g;
+            }
+        }
+        if (g == 0ull) continue;
+        const u32 v = (w << 6) + lane;
+        if (((g >> lane) & 1ull) && v < a.n) {
+            cnt += 1;
+            mf += a.A.rowptr[v + 1] - a.A.rowptr[v];
+            if (owned) {
+                a.level[v] = newlevel;
+                if (a.At.rowptr) indeg += a.At.rowptr[v + 1] - a.At.rowptr[v];
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += __shfl_xor(cnt, d, 64);
+        mf += __shfl_xor(mf, d, 64);
+        indeg += __shfl_xor(indeg, d, 64);
+    }
+    __shared__ unsigned long long s_acc[3];
+    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0 && cnt) {
+        atomicAdd(&s_acc[0], (unsigned long long)cnt);
+        atomicAdd(&s_acc[1], (unsigned long long)mf);
+        atomicAdd(&s_acc[2], (unsigned long long)indeg);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_acc[0]) {
+        const u32 slot = blockIdx.x & (STAT_SLOTS - 1);
+        atomicAdd((unsigned long long*)&c->slot_count[slot], s_acc[0]);
+        atomicAdd((unsigned long long*)&c->slot_mf[slot], s_acc[1]);
+        atomicAdd((unsigned long long*)&c->slot_indeg[slot], s_acc[2]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bfs_ctrl_kernel(BfsCtrl* c) {
+    if (c->done) return;
+    __shared__ unsigned long long s[4];
+    if (threadIdx.x < 4) s[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 t = threadIdx.x;
+    if (t < STAT_SLOTS) {
+        if (c->slot_count[t]) atomicAdd(&s[0], (unsigned long long)c->slot_count[t]);
+        if (c->slot_mf[t]) atomicAdd(&s[1], (unsigned long long)c->slot_mf[t]);
+        if (c->slot_indeg[t]) atomicAdd(&s[2], (unsigned long long)c->slot_indeg[t]);
+        if (c->slot_scan[t]) atomicAdd(&s[3], (unsigned long long)c->slot_scan[t]);
+        c->slot_count[t] = 0; c->slot_mf[t] = 0; c->slot_indeg[t] = 0; c->slot_scan[t] = 0;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const int dir = c->direction;
+        if (dir == 1) { c->scanned_push += s[3]; c->push_levels += 1; }
+        else { c->scanned_pull += s[3]; c->pull_levels += 1; }
+        c->level += 1;
+        c->n_frontier = s[0];
+        c->m_frontier = s[1];
+        c->reached += s[0];
+        c->edges_traversed += s[1];
+        c->visited_in_deg += s[2];
+        bool done = (s[0] == 0) || (c->max_level >= 0 && c->level >= c->max_level);
+        c->done = done ? 1 : 0;
+        int nd = 1;
+        if (c->force_dir == 1 || !c->has_at) nd = 1;
+        else if (c->force_dir == 2) nd = 2;
+        else {
+            const u64 m_u = c->nnz_at > c->visited_in_deg ? c->nnz_at - c->visited_in_deg : 0;
+            nd = ((double)s[1] * (double)c->alpha > (double)m_u) ? 2 : 1;
+        }
+        c->direction = nd;
+    }
+}
+
+__global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u32 force_dir, float alpha,
+                                u64 nnz_at) {
+    // single thread: seed the source (arrays were memset by the host side of begin())
+    BfsCtrl* c = a.ctrl;
+    c->level = 0;
+    c->max_level = max_level;
+    c->n_frontier = 1;
+    const u64 mf = a.A.rowptr[src + 1] - a.A.rowptr[src];
+    c->m_frontier = mf;
+    c->reached = 1;
+    c->edges_traversed = mf;
+    c->has_at = has_at;
+    c->force_dir = force_dir;
+    c->alpha = alpha;
+    c->nnz_at = nnz_at;
+    a.cur[src >> 6] = 1ull << (src & 63);
+    u64 indeg = 0;
+    if (src >= a.lo && src < a.hi) {
+        a.visited[src >> 6] = 1ull << (src & 63);
+        a.level[src] = 0;
+        if (a.parent) a.parent[src] = src;
+        if (a.At.rowptr) indeg = a.At.rowptr[src + 1] - a.At.rowptr[src];
+    }
+    c->visited_in_deg = indeg;
+    c->done = (max_level == 0) ? 1 : 0;
+    int nd = 1;
+    if (force_dir == 2 && has_at) nd = 2;
+    else if (force_dir == 0 && has_at) {
+        const u64 m_u = nnz_at > indeg ? nnz_at - indeg : 0;
+        nd = ((double)mf * (double)alpha > (double)m_u) ? 2 : 1;
+    }
+    c->direction = nd;
+}
+
+// ---- standalone vxm kernels (fgpu_vxm, bench) ---------------------------------------
+__global__ __launch_bounds__(256) void vxm_push_kernel(BfsArgs a, const u64* frontier, const u64* mask) {
+    u64 scanned;
+    push_body<false>(a, frontier, mask, &scanned);
+}
+template <bool EARLY_EXIT>
+__global__ __launch_bounds__(256) void vxm_pull_kernel(BfsArgs a, const u64* frontier, const u64* mask, u64* out) {
+    u64 scanned;
+    pull_body<false, EARLY_EXIT>(a, frontier, mask, out, &scanned);
+}
+
+}  // namespace fgpu
+
+using namespace fgpu;
+
+// ===================================================================================
+// plan
+// ===================================================================================
+struct ProfSlot {
+    const char* name;
+    double ms = 0;
+    uint64_t launches = 0;
+    uint64_t alg_bytes = 0;
+};
+
+struct fgpu_bfs_plan {
+    fgpu_ctx* ctx = nullptr;
+    const fgpu_mat* A = nullptr;
+    const fgpu_mat* At = nullptr;
+    int rank = 0, nranks = 1;
+    u32 n = 0, slab = 0, lo = 0, hi = 0, nw = 0, slabw = 0;
+    u64 *cur = nullptr, *nxt_local = nullptr, *nxt_global = nullptr, *visited = nullptr;
+    bool external_bufs = false;
+    i32* level = nullptr;
+    u32* parent = nullptr;
+    BfsCtrl* ctrl = nullptr;
+    BfsCtrl* h_ctrl = nullptr;  // pinned
+    double alpha = 4.0, beta = 24.0;
+    int force_dir = 0;
+    bool want_parent = false;
+    bool profile = false;
+    std::vector<ProfSlot> prof;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    u32 grid = 0;
+};
+
+static BfsArgs make_args(fgpu_bfs_plan* p) {
+    BfsArgs a;
+    a.A = view_of(p->A);
+    if (p->At) a.At = view_of(p->At);
+    else { a.At.rowptr = nullptr; a.At.colidx = nullptr; a.At.hrows = nullptr; a.At.nvec = 0; a.At.nrows = 0; }
+    a.hubA = p->A->hub_chunks; a.n_hubA = p->A->n_hub_chunks;
+    a.hubAt = p->At ? p->At->hub_chunks : nullptr; a.n_hubAt = p->At ? p->At->n_hub_chunks : 0;
+    a.n = p->n; a.lo = p->lo; a.hi = p->hi;
+    a.cur = p->cur; a.nxt_local = p->nxt_local; a.nxt_global = p->nxt_global; a.visited = p->visited;
+    a.level = p->level;
+    a.parent = p->want_parent ? p->parent : nullptr;
+    a.ctrl = p->ctrl;
+    a.nw = p->nw;
+    return a;
+}
+
+extern "C" {
+
+fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
+    if (!p) return FGPU_OK;
+    fgpu_ctx* c = p->ctx;
+    c->dev_free(p->cur);
+    if (!p->external_bufs) {
+        if (p->nxt_local != p->nxt_global) c->dev_free(p->nxt_local);
+        c->dev_free(p->nxt_global);
+    }
+    c->dev_free(p->visited);
+    c->dev_free(p->level);
+    c->dev_free(p->parent);
+    c->dev_free(p->ctrl);
+    if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat* A, const fgpu_mat* At, int rank,
+                               int nranks) {
+    FGPU_REQUIRE(ctx && out && A, FGPU_NULL_POINTER, "fgpu_bfs_plan_create: NULL argument");
+    FGPU_REQUIRE(A->nrows == A->ncols, FGPU_DIM_MISMATCH, "BFS needs a square adjacency (%llu x %llu)",
+                 (unsigned long long)A->nrows, (unsigned long long)A->ncols);
+    FGPU_REQUIRE(!A->is_hyper() && (!At || !At->is_hyper()), FGPU_INVALID,
+                 "BFS needs non-hypersparse adjacency snapshots");
+    FGPU_REQUIRE(!At || (At->nrows == A->nrows && At->ncols == A->ncols), FGPU_DIM_MISMATCH,
+                 "At dims differ from A");
+    FGPU_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, FGPU_INVALID, "bad rank %d / %d", rank, nranks);
+    FGPU_REQUIRE(A->nrows >= 1, FGPU_INVALID, "empty graph");
+    fgpu_bfs_plan* p = new (std::nothrow) fgpu_bfs_plan();
+    FGPU_REQUIRE(p, FGPU_OOM, "out of host memory");
+    p->ctx = ctx; p->A = A; p->At = At; p->rank = rank; p->nranks = nranks;
+    p->n = (u32)A->nrows;
+    u64 per = (A->nrows + nranks - 1) / nranks;
+    per = (per + 4095) & ~4095ull;
+    p->slab = (u32)per;
+    p->slabw = p->slab / 64;
+    p->nw = p->slabw * nranks;
+    p->lo = p->slab * rank;
+    p->hi = p->lo + p->slab;
+    fgpu_info i = FGPU_OK;
+    const size_t wb = (size_t)p->nw * sizeof(u64);
+    do {
+        if ((i = ctx->dev_alloc((void**)&p->cur, wb)) != FGPU_OK) break;
+        if ((i = ctx->dev_alloc((void**)&p->nxt_global, wb)) != FGPU_OK) break;
+        if (nranks == 1) p->nxt_local = p->nxt_global;
+        else if ((i = ctx->dev_alloc((void**)&p->nxt_local, (size_t)p->slabw * sizeof(u64))) != FGPU_OK) break;
+        if ((i = ctx->dev_alloc((void**)&p->visited, wb)) != FGPU_OK) break;
+        if ((i = ctx->dev_alloc((void**)&p->level, (size_t)p->nw * 64 * sizeof(i32))) != FGPU_OK) break;
+        if ((i = ctx->dev_alloc((void**)&p->parent, (size_t)p->nw * 64 * sizeof(u32))) != FGPU_OK) break;
+        if ((i = ctx->dev_alloc((void**)&p->ctrl, sizeof(BfsCtrl))) != FGPU_OK) break;
+    } while (0);
+    if (i == FGPU_OK) {
+        hipError_t e = hipHostMalloc((void**)&p->h_ctrl, sizeof(BfsCtrl), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+        if (e == hipSuccess) e = hipMemsetAsync(p->nxt_global, 0, wb, ctx->stream);
+        if (e == hipSuccess && nranks > 1)
+            e = hipMemsetAsync(p->nxt_local, 0, (size_t)p->slabw * sizeof(u64), ctx->stream);
+        if (e != hipSuccess) { set_error("bfs plan setup failed: %s", hipGetErrorString(e)); i = FGPU_DEVICE; }
+    }
+    if (i != FGPU_OK) { fgpu_bfs_plan_free(p); return i; }
+    memset(p->h_ctrl, 0, sizeof(BfsCtrl));
+    p->grid = (u32)ctx->cus * 8;
+    p->prof = {{"bfs_step_push"}, {"bfs_step_pull"}, {"bfs_commit"}, {"bfs_ctrl"}};
+    *out = p;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_plan_tune(fgpu_bfs_plan* p, double alpha, double beta, int force_direction) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_plan_tune: NULL plan");
+    if (alpha > 0) p->alpha = alpha;
+    if (beta > 0) p->beta = beta;
+    FGPU_REQUIRE(force_direction >= 0 && force_direction <= 2, FGPU_INVALID, "force_direction must be 0/1/2");
+    FGPU_REQUIRE(force_direction != 2 || p->At, FGPU_INVALID, "pull needs At");
+    p->force_dir = force_direction;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_part_buffers(fgpu_bfs_plan* p, void** local_words, void** global_words, uint64_t* words_per_rank) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_part_buffers: NULL plan");
+    if (local_words) *local_words = p->nxt_local;
+    if (global_words) *global_words = p->nxt_global;
+    if (words_per_rank) *words_per_rank = p->slabw;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_part_set_buffers(fgpu_bfs_plan* p, void* local_words, void* global_words) {
+    FGPU_REQUIRE(p && local_words && global_words, FGPU_NULL_POINTER, "fgpu_bfs_part_set_buffers: NULL argument");
+    FGPU_REQUIRE(p->nranks == 1 ? true : local_words != global_words, FGPU_INVALID,
+                 "multi-rank plans need distinct local and global buffers");
+    fgpu_ctx* c = p->ctx;
+    if (!p->external_bufs) {
+        if (p->nxt_local != p->nxt_global) c->dev_free(p->nxt_local);
+        c->dev_free(p->nxt_global);
+    }
+    p->external_bufs = true;
+    p->nxt_local = (u64*)local_words;
+    p->nxt_global = (u64*)global_words;
+    if (p->nranks == 1) p->nxt_local = p->nxt_global;
+    FGPU_HIP(hipMemsetAsync(p->nxt_global, 0, (size_t)p->nw * sizeof(u64), c->stream));
+    if (p->nxt_local != p->nxt_global)
+        FGPU_HIP(hipMemsetAsync(p->nxt_local, 0, (size_t)p->slabw * sizeof(u64), c->stream));
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_part_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_part_begin: NULL plan");
+    FGPU_REQUIRE(src < p->n, FGPU_OUT_OF_BOUNDS, "BFS source %llu >= %u vertices", (unsigned long long)src, p->n);
+    fgpu_ctx* ctx = p->ctx;
+    const size_t wb = (size_t)p->nw * sizeof(u64);
+    FGPU_HIP(hipMemsetAsync(p->cur, 0, wb, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(p->visited, 0, wb, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(p->nxt_global, 0, wb, ctx->stream));
+    if (p->nxt_local != p->nxt_global)
+        FGPU_HIP(hipMemsetAsync(p->nxt_local, 0, (size_t)p->slabw * sizeof(u64), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(p->level + p->lo, 0xFF, (size_t)p->slab * sizeof(i32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(p->ctrl, 0, sizeof(BfsCtrl), ctx->stream));
+    i32 ml = max_level < 0 ? -1 : (max_level > 0x7FFFFFFF ? 0x7FFFFFFF : (i32)max_level);
+    BfsArgs a = make_args(p);
+    hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(1), 0, ctx->stream, a, (u32)src, ml, p->At ? 1u : 0u,
+                       (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+
+static fgpu_info timed_begin(fgpu_bfs_plan* p) {
+    if (p->profile) FGPU_HIP(hipEventRecord(p->ev0, p->ctx->stream));
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_part_step(fgpu_bfs_plan* p) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_part_step: NULL plan");
+    BfsArgs a = make_args(p);
+    if (p->want_parent)
+        hipLaunchKernelGGL(bfs_step_kernel<true>, dim3(p->grid), dim3(256), 0, p->ctx->stream, a);
+    else
+        hipLaunchKernelGGL(bfs_step_kernel<false>, dim3(p->grid), dim3(256), 0, p->ctx->stream, a);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_part_commit(fgpu_bfs_plan* p) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_part_commit: NULL plan");
+    BfsArgs a = make_args(p);
+    u32 grid = cdiv(p->nw, 4);
+    if (grid > p->grid * 2) grid = p->grid * 2;
+    hipLaunchKernelGGL(bfs_commit_kernel, dim3(grid), dim3(256), 0, p->ctx->stream, a);
+    FGPU_HIP(hipGetLastError());
+    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(256), 0, p->ctx->stream, p->ctrl);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+
+static fgpu_info fetch_ctrl(fgpu_bfs_plan* p) {
+    // header only (everything before the slot arrays)
+    FGPU_HIP(hipMemcpyAsync(p->h_ctrl, p->ctrl, offsetof(BfsCtrl, slot_count), hipMemcpyDeviceToHost,
+                            p->ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(p->ctx->stream));
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_part_done(fgpu_bfs_plan* p, int32_t* done, int32_t* level) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_part_done: NULL plan");
+    FGPU_TRY(fetch_ctrl(p));
+    if (done) *done = p->h_ctrl->done;
+    if (level) *level = p->h_ctrl->level;
+    return FGPU_OK;
+}
+
+// Profiled variant of one level: every kernel bracketed by events (slow; bench/roofline only).
+static fgpu_info profiled_level(fgpu_bfs_plan* p) {
+    fgpu_ctx* ctx = p->ctx;
+    FGPU_TRY(fetch_ctrl(p));
+    if (p->h_ctrl->done) return FGPU_OK;
+    const int dir = p->h_ctrl->direction;
+    const u64 sp0 = p->h_ctrl->scanned_push, sl0 = p->h_ctrl->scanned_pull;
+    const u64 nf = p->h_ctrl->n_frontier;
+    float ms = 0;
+    FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
+    FGPU_TRY(fgpu_bfs_part_step(p));
+    FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
+    FGPU_HIP(hipEventSynchronize(p->ev1));
+    FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    ProfSlot& s = p->prof[dir == 1 ? 0 : 1];
+    s.ms += ms; s.launches += 1;
+    // commit + ctrl
+    BfsArgs a = make_args(p);
+    u32 grid = cdiv(p->nw, 4);
+    if (grid > p->grid * 2) grid = p->grid * 2;
+    FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
+    hipLaunchKernelGGL(bfs_commit_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
+    FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
+    FGPU_HIP(hipEventSynchronize(p->ev1));
+    FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->prof[2].ms += ms; p->prof[2].launches += 1;
+    FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
+    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(256), 0, ctx->stream, p->ctrl);
+    FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
+    FGPU_HIP(hipEventSynchronize(p->ev1));
+    FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->prof[3].ms += ms; p->prof[3].launches += 1;
+    FGPU_TRY(fetch_ctrl(p));
+    // algorithmic bytes of the step: colidx scanned + rowptr pairs + bitmaps + output
+    const u64 scanned = dir == 1 ? (p->h_ctrl->scanned_push - sp0) : (p->h_ctrl->scanned_pull - sl0);
+    const u64 newf = p->h_ctrl->n_frontier;
+    u64 bytes;
+    if (dir == 1) bytes = 4 * scanned + 8 * nf + (u64)p->nw * 8 /*frontier bitmap*/ + newf / 8 + 1;
+    else bytes = 4 * scanned + 4ull * (p->hi - p->lo) /*rowptr*/ + (u64)p->slabw * 8 * 2 /*visited + out words*/;
+    s.alg_bytes += bytes;
+    p->prof[2].alg_bytes += (u64)p->nw * 8 * 3 + 4 * newf + 8 * newf;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_run(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, int want_parent) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_run: NULL plan");
+    FGPU_REQUIRE(p->nranks == 1, FGPU_INVALID,
+                 "fgpu_bfs_run drives single-rank plans; multi-rank plans are stepped by the host loop");
+    p->want_parent = want_parent != 0;
+    FGPU_TRY(fgpu_bfs_part_begin(p, src, max_level));
+    if (p->profile) {
+        for (;;) {
+            FGPU_TRY(profiled_level(p));
+            if (p->h_ctrl->done) break;
+        }
+        return FGPU_OK;
+    }
+    // enqueue levels blind in small batches; the kernels no-op once ctrl->done is raised
+    int batch = 6;
+    for (;;) {
+        for (int k = 0; k < batch; ++k) {
+            FGPU_TRY(fgpu_bfs_part_step(p));
+            FGPU_TRY(fgpu_bfs_part_commit(p));
+        }
+        FGPU_TRY(fetch_ctrl(p));
+        if (p->h_ctrl->done) break;
+        batch = 3;
+    }
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_fetch(fgpu_bfs_plan* p, int32_t* level, int64_t* parent) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_fetch: NULL plan");
+    fgpu_ctx* ctx = p->ctx;
+    const u32 lo = p->lo, hi = p->hi < p->n ? p->hi : p->n;
+    if (hi <= lo) return FGPU_OK;
+    std::vector<i32> lv;
+    const i32* lvp = level ? level + lo : nullptr;
+    if (level) {
+        FGPU_HIP(hipMemcpyAsync(level + lo, p->level + lo, (size_t)(hi - lo) * sizeof(i32), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    } else if (parent) {
+        lv.resize(hi - lo);
+        FGPU_HIP(hipMemcpyAsync(lv.data(), p->level + lo, (size_t)(hi - lo) * sizeof(i32), hipMemcpyDeviceToHost,
+                                ctx->stream));
+        lvp = lv.data();
+    }
+    std::vector<u32> par;
+    if (parent) {
+        FGPU_REQUIRE(p->want_parent, FGPU_INVALID, "the last run did not track parents");
+        par.resize(hi - lo);
+        FGPU_HIP(hipMemcpyAsync(par.data(), p->parent + lo, (size_t)(hi - lo) * sizeof(u32), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    }
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    if (parent)
+        for (u32 v = lo; v < hi; ++v) parent[v] = (lvp[v - lo] >= 0) ? (int64_t)par[v - lo] : -1;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_stats(fgpu_bfs_plan* p, uint64_t stats[8]) {
+    FGPU_REQUIRE(p && stats, FGPU_NULL_POINTER, "fgpu_bfs_stats: NULL argument");
+    FGPU_TRY(fetch_ctrl(p));
+    const BfsCtrl* c = p->h_ctrl;
+    stats[0] = (u64)c->level;
+    stats[1] = c->reached;
+    stats[2] = c->edges_traversed;
+    stats[3] = c->push_levels;
+    stats[4] = c->pull_levels;
+    stats[5] = c->scanned_push;
+    stats[6] = c->scanned_pull;
+    stats[7] = c->n_frontier;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_plan_profile(fgpu_bfs_plan* p, int enable) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_plan_profile: NULL plan");
+    p->profile = enable != 0;
+    for (auto& s : p->prof) { s.ms = 0; s.launches = 0; s.alg_bytes = 0; }
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_plan_profile_read(fgpu_bfs_plan* p, const char** names, double* ms, uint64_t* launches,
+                                     uint64_t* alg_bytes, int cap, int* n) {
+    FGPU_REQUIRE(p && n, FGPU_NULL_POINTER, "fgpu_bfs_plan_profile_read: NULL argument");
+    int k = 0;
+    for (auto& s : p->prof) {
+        if (k >= cap) break;
+        if (names) names[k] = s.name;
+        if (ms) ms[k] = s.ms;
+        if (launches) launches[k] = s.launches;
+        if (alg_bytes) alg_bytes[k] = s.alg_bytes;
+        ++k;
+    }
+    *n = k;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, uint64_t src, int64_t max_level,
+                   int32_t* level, int64_t* parent, uint64_t* edges_traversed) {
+    FGPU_REQUIRE(ctx && A && level, FGPU_NULL_POINTER, "fgpu_bfs: NULL argument");
+    fgpu_bfs_plan* p = nullptr;
+    FGPU_TRY(fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1));
+    fgpu_info i = fgpu_bfs_run(p, src, max_level, parent != nullptr);
+    if (i == FGPU_OK) i = fgpu_bfs_fetch(p, level, parent);
+    if (i == FGPU_OK && edges_traversed) {
+        uint64_t st[8];
+        i = fgpu_bfs_stats(p, st);
+        *edges_traversed = st[2];
+    }
+    fgpu_bfs_plan_free(p);
+    return i;
+}
+
+// ---- standalone vxm ------------------------------------------------------------------
+static void vxm_args(BfsArgs& a, const fgpu_mat* A, const fgpu_mat* At, u32 n, u64* out_words, u32 nw) {
+    memset(&a, 0, sizeof(a));
+    a.A = view_of(A);
+    if (At) a.At = view_of(At);
+    a.hubA = A->hub_chunks; a.n_hubA = A->n_hub_chunks;
+    a.hubAt = At ? At->hub_chunks : nullptr; a.n_hubAt = At ? At->n_hub_chunks : 0;
+    a.n = n; a.lo = 0; a.hi = nw * 64;
+    a.nxt_local = out_words; a.nxt_global = out_words;
+    a.nw = nw;
+}
+
+fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t* mask, const fgpu_mat* A,
+                   const fgpu_mat* At, int direction) {
+    FGPU_REQUIRE(ctx && w && f && A, FGPU_NULL_POINTER, "fgpu_vxm: NULL argument");
+    FGPU_REQUIRE(A->nrows == A->ncols, FGPU_DIM_MISMATCH, "fgpu_vxm: square matrices only");
+    FGPU_REQUIRE(!A->is_hyper() && (!At || !At->is_hyper()), FGPU_INVALID, "fgpu_vxm: non-hypersparse snapshots only");
+    FGPU_REQUIRE(direction >= 0 && direction <= 2 && (direction != 2 || At), FGPU_INVALID, "fgpu_vxm: bad direction");
+    const u32 n = (u32)A->nrows;
+    const u32 nw_user = (n + 63) / 64;
+    const u32 nw = ((n + 4095) & ~4095u) / 64;
+    DevBuf<u64> df, dm, dw;
+    FGPU_TRY(df.alloc(ctx, nw));
+    FGPU_TRY(dw.alloc(ctx, nw));
+    FGPU_HIP(hipMemsetAsync(df.p, 0, nw * sizeof(u64), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(dw.p, 0, nw * sizeof(u64), ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(df.p, f, nw_user * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    if (mask) {
+        FGPU_TRY(dm.alloc(ctx, nw));
+        FGPU_HIP(hipMemsetAsync(dm.p, 0, nw * sizeof(u64), ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(dm.p, mask, nw_user * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    }
+    BfsArgs a;
+    vxm_args(a, A, At, n, dw.p, nw);
+    const bool pull = (direction == 2);
+    const u32 grid = ctx->cus * 8;
+    if (pull)
+        hipLaunchKernelGGL(vxm_pull_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, a, (const u64*)df.p,
+                           (const u64*)(mask ? dm.p : nullptr), dw.p);
+    else
+        hipLaunchKernelGGL(vxm_push_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, (const u64*)df.p,
+                           (const u64*)(mask ? dm.p : nullptr));
+    FGPU_HIP(hipGetLastError());
+    FGPU_HIP(hipMemcpyAsync(w, dw.p, nw_user * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bench_spmv(fgpu_ctx* ctx, const fgpu_mat* A, int which, int iters, double* avg_ms,
+                          uint64_t* alg_bytes) {
+    FGPU_REQUIRE(ctx && A && avg_ms, FGPU_NULL_POINTER, "fgpu_bench_spmv: NULL argument");
+    FGPU_REQUIRE(A->nrows == A->ncols && !A->is_hyper(), FGPU_INVALID, "fgpu_bench_spmv: square non-hyper matrix");
+    FGPU_REQUIRE(which == 0 || which == 1, FGPU_INVALID, "fgpu_bench_spmv: which must be 0 (pull) or 1 (push)");
+    if (iters < 1) iters = 1;
+    const u32 n = (u32)A->nrows;
+    const u32 nw = ((n + 4095) & ~4095u) / 64;
+    DevBuf<u64> df, dw;
+    FGPU_TRY(df.alloc(ctx, nw));
+    FGPU_TRY(dw.alloc(ctx, nw));
+    // dense frontier: every vertex set (bits beyond n stay clear)
+    FGPU_HIP(hipMemsetAsync(df.p, 0, nw * sizeof(u64), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(df.p, 0xFF, (n / 64) * sizeof(u64), ctx->stream));
+    if (n % 64) {
+        u64 tail = (1ull << (n % 64)) - 1ull;
+        FGPU_HIP(hipMemcpyAsync(df.p + n / 64, &tail, sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    BfsArgs a;
+    // `A` plays the role of At for the pull kernel (the caller passes the matrix to stream)
+    vxm_args(a, A, A, n, dw.p, nw);
+    hipEvent_t e0, e1;
+    FGPU_HIP(hipEventCreate(&e0));
+    FGPU_HIP(hipEventCreate(&e1));
+    const u32 grid = ctx->cus * 8;
+    auto launch = [&]() {
+        if (which == 0)
+            hipLaunchKernelGGL(vxm_pull_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, a, (const u64*)df.p,
+                               (const u64*)nullptr, dw.p);
+        else
+            hipLaunchKernelGGL(vxm_push_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, (const u64*)df.p,
+                               (const u64*)nullptr);
+    };
+    FGPU_HIP(hipMemsetAsync(dw.p, 0, nw * sizeof(u64), ctx->stream));
+    launch();  // warm
+    FGPU_HIP(hipGetLastError());
+    FGPU_HIP(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters; ++i) launch();
+    FGPU_HIP(hipEventRecord(e1, ctx->stream));
+    FGPU_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    FGPU_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / iters;
+    // SURVEY.md §8d "one boolean pull / full pass": 4(N+1) + 4 nnz + N/8 + N/8
+    if (alg_bytes) *alg_bytes = 4ull * ((u64)n + 1) + 4ull * A->nnz + (u64)n / 8 + (u64)n / 8;
+    return FGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+// common.hpp — context, device pool, error plumbing and the device-side CSR view
+// shared by every translation unit of libfgpu.  gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/fgpu.h"
+
+namespace fgpu {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+constexpr int WAVE = 64;  // CDNA4 wavefront
+
+// ---- error plumbing ---------------------------------------------------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define FGPU_HIP(expr)                                                                  \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ::fgpu::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                              __FILE__, __LINE__);                                      \
+            return (_e == hipErrorOutOfMemory) ? FGPU_OOM : FGPU_DEVICE;                \
+        }                                                                               \
+    } while (0)
+
+#define FGPU_TRY(expr)                      \
+    do {                                    \
+        fgpu_info _i = (expr);              \
+        if (_i != FGPU_OK) return _i;       \
+    } while (0)
+
+#define FGPU_REQUIRE(cond, code, ...)       \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::fgpu::set_error(__VA_ARGS__); \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+}  // namespace fgpu
+
+// ---- context -----------------------------------------------------------------
+// One per process+device.  Owns a HIP stream, a size-class device pool (hipMalloc
+// is ~100 us; traversal calls must not pay it per hop) and the host allocator
+// hooks the caller handed to fgpu_init.
+struct fgpu_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    void* (*mal)(size_t) = nullptr;
+    void (*fre)(void*) = nullptr;
+    int cus = 0;
+    std::mutex mu;
+    std::multimap<size_t, void*> pool;  // free blocks by capacity
+    std::map<void*, size_t> live;       // capacity of live blocks
+    uint64_t bytes_in_use = 0, bytes_pooled = 0;
+    void* pinned = nullptr;  // small pinned staging block for control read-backs
+    size_t pinned_bytes = 0;
+
+    fgpu_info dev_alloc(void** p, size_t bytes);
+    void dev_free(void* p);
+    void* host_alloc(size_t bytes);
+    void host_free(void* p);
+    void trim();
+};
+
+namespace fgpu {
+
+// RAII device buffer from the ctx pool.
+template <typename T>
+struct DevBuf {
+    fgpu_ctx* ctx = nullptr;
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            ctx = o.ctx; p = o.p; n = o.n;
+            o.p = nullptr; o.n = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    fgpu_info alloc(fgpu_ctx* c, size_t count) {
+        release();
+        ctx = c;
+        n = count;
+        void* q = nullptr;
+        fgpu_info i = c->dev_alloc(&q, (count ? count : 1) * sizeof(T));
+        if (i != FGPU_OK) { n = 0; return i; }
+        p = (T*)q;
+        return FGPU_OK;
+    }
+    void release() {
+        if (p && ctx) ctx->dev_free(p);
+        p = nullptr; n = 0;
+    }
+    T* take() { T* q = p; p = nullptr; n = 0; return q; }
+};
+
+}  // namespace fgpu
+
+// ---- matrix snapshot -----------------------------------------------------------
+// Immutable CSR on device.  `hrows == nullptr`: rowptr has nrows+1 entries.
+// Hypersparse (delta layers, me): hrows = sorted ids of the nvec non-empty rows and
+// rowptr has nvec+1 entries; row lookups binary-search hrows.
+struct fgpu_mat {
+    fgpu_ctx* ctx = nullptr;
+    uint64_t nrows = 0, ncols = 0, nnz = 0;
+    uint32_t nvec = 0;          // number of stored rows (== nrows when not hyper)
+    uint32_t* rowptr = nullptr; // device
+    uint32_t* colidx = nullptr; // device
+    uint64_t* vals = nullptr;   // device, nullable (BOOL: pattern only)
+    uint32_t* hrows = nullptr;  // device, nullable
+    // static hub list for the push kernels (rows with degree >= HUB_DEG), device
+    uint32_t* hub_chunks = nullptr;  // triples (row, begin, end)
+    uint32_t n_hub_chunks = 0;
+    uint32_t max_deg = 0;
+    bool is_hyper() const { return hrows != nullptr; }
+};
+
+namespace fgpu {
+
+// POD view passed to kernels by value.
+struct CsrView {
+    const u32* rowptr;
+    const u32* colidx;
+    const u32* hrows;  // nullable
+    u32 nvec;
+    u32 nrows;
+};
+
+inline CsrView view_of(const fgpu_mat* m) {
+    CsrView v;
+    v.rowptr = m->rowptr;
+    v.colidx = m->colidx;
+    v.hrows = m->hrows;
+    v.nvec = m->nvec;
+    v.nrows = (u32)m->nrows;
+    return v;
+}
+
+// [begin,end) of row r in the view (device).
+__device__ __forceinline__ void row_range(const CsrView& a, u32 r, u32& b, u32& e) {
+    if (a.hrows == nullptr) {
+        if (r < a.nrows) { b = a.rowptr[r]; e = a.rowptr[r + 1]; }
+        else { b = 0; e = 0; }
+        return;
+    }
+    u32 lo = 0, hi = a.nvec;
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        if (a.hrows[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    if (lo < a.nvec && a.hrows[lo] == r) { b = a.rowptr[lo]; e = a.rowptr[lo + 1]; }
+    else { b = 0; e = 0; }
+}
+
+__device__ __forceinline__ u32 lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__host__ __device__ __forceinline__ u64 mix64(u64 z) {  // splitmix64 finalizer
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// ---- primitives (prims.hip) ------------------------------------------------------
+// Exclusive prefix sums on device; `total` (nullable device pointer) receives the sum.
+fgpu_info scan_u32(fgpu_ctx* ctx, const u32* in, u32* out, u64 n, u32* total_dev);
+fgpu_info scan_u32_to_u64(fgpu_ctx* ctx, const u32* in, u64* out, u64 n, u64* total_dev);
+// Sort every segment [off[s], off[s+1]) of `data` ascending and drop duplicates in
+// place; cnt[s] receives the number of unique keys left at the front of the segment.
+// `key_bound` = exclusive upper bound of the keys (bitmap path sizing).
+// `dirty` (nullable): segments with dirty[s]==0 are skipped (cnt[s] pre-filled by the caller).
+fgpu_info segsort_unique(fgpu_ctx* ctx, u32* data, const u64* off, u32 nseg, u32 key_bound,
+                         u32* cnt, const uint8_t* dirty);
+// Gather the unique prefixes into a dense CSR; rowptr = exclusive scan of cnt (nseg+1 entries).
+fgpu_info compact_segments(fgpu_ctx* ctx, const u32* data, const u64* off, const u32* rowptr,
+                           u32 nseg, u32* col_out);
+
+// ---- matrix helpers (mat.hip) ---------------------------------------------------
+fgpu_info mat_alloc(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, u64 nnz, bool with_vals,
+                    u32 nvec_hyper, bool hyper);
+// (m \ dm) U dp, pattern only, on device (K3/K6).
+fgpu_info mat_merge_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
+                           const fgpu_mat* dm, bool dm_masks_dp);
+// dense (nrows+1) rowptr of a possibly hypersparse matrix.
+fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp);
+fgpu_info mat_finalize(fgpu_mat* m);  // hub list, max degree (after rowptr/colidx are filled)
+// device COO (u32 rows / cols, n entries) -> CSR snapshot, duplicates collapsed.
+fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
+                              const u32* cols, u64 n);
+// read one u32 / u64 from device on the ctx stream (synchronises).
+fgpu_info read_u32(fgpu_ctx* ctx, const u32* dev, u32* host);
+fgpu_info read_u64(fgpu_ctx* ctx, const u64* dev, u64* host);
+
+constexpr u32 HUB_DEG = 4096;    // rows at least this long are expanded by the hub kernel
+constexpr u32 HUB_CHUNK = 4096;  // edges per hub work item
+
+}  // namespace fgpu

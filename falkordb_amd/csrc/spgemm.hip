@@ -1,0 +1,378 @@
+// spgemm.hip — ANY_PAIR (structural) sparse products and the CondTraverse expansion core.
+//
+// Reference call sites (graph/src/graph/graphblas/matrix.rs unless noted):
+//   Matrix::lmxm        :930-947   C = F x B, GrB_mxm(GxB_ANY_PAIR_BOOL), no mask
+//   Matrix::delta_lmxm  :1317-1402 (F x (m U dp)) with (F x dm) masked out of the F x m part
+//   expand_batch        runtime/ops/cond_traverse.rs:452-751 (F build :600-601, chain :602-605,
+//                       ascending (row, dest) read-out :644, dst label post-filter :647-651)
+//
+// The semiring never reads values, so a product row is the sorted union of the B-rows named
+// by the F-row.  Device formulation: (1) per F-entry degree + prefix sum = output upper bound
+// ("flops"), (2) one wavefront per F-entry copies its B-row coalesced into the row's segment,
+// (3) segments with more than one source go through segsort_unique (prims.hip), single-source
+// segments (hop 1 of every traversal) are already sorted and unique, (4) compaction to CSR.
+#include "common.hpp"
+
+namespace fgpu {
+
+__global__ void entry_deg_kernel(CsrView f, CsrView b, u32 nnzf, u32* __restrict__ deg) {
+    u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnzf) { if (e == nnzf) deg[e] = 0; return; }
+    u32 s = f.colidx[e], rb, re;
+    row_range(b, s, rb, re);
+    deg[e] = re - rb;
+}
+
+__global__ void gather_u64_kernel(const u64* __restrict__ eoff, const u32* __restrict__ frp, u32 k,
+                                  u64* __restrict__ roff, u32* __restrict__ maxlen) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > k) return;
+    roff[i] = eoff[frp[i]];
+    if (i < k) {
+        u32 len = frp[i + 1] - frp[i];
+        u32 m = len;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { u32 o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+        if (lane_id() == 0 && m > 1) atomicMax(maxlen, m);
+        else if (lane_id() == 0 && m == 1) atomicMax(maxlen, 1u);
+    }
+}
+
+// one wavefront per F entry: copy the B row it names into the product row's segment
+__global__ __launch_bounds__(256) void gather_rows_kernel(CsrView f, CsrView b, u32 nnzf,
+                                                         const u64* __restrict__ eoff, u32* __restrict__ tmp) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    for (u32 e = wave; e < nnzf; e += nwaves) {
+        u32 s = f.colidx[e], rb, re;
+        row_range(b, s, rb, re);
+        const u64 o = eoff[e];
+        u32 i = rb + lane;
+        // 4 x 64 per trip keeps several loads in flight for long rows
+        for (; i + 192 < re; i += 256) {
+            u32 x0 = b.colidx[i], x1 = b.colidx[i + 64], x2 = b.colidx[i + 128], x3 = b.colidx[i + 192];
+            u64 p = o + (i - rb);
+            tmp[p] = x0; tmp[p + 64] = x1; tmp[p + 128] = x2; tmp[p + 192] = x3;
+        }
+        for (; i < re; i += 64) tmp[o + (i - rb)] = b.colidx[i];
+    }
+}
+
+__global__ void seg_len_kernel(const u64* __restrict__ roff, u32 k, u32* __restrict__ cnt) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > k) return;
+    cnt[i] = (i < k) ? (u32)(roff[i + 1] - roff[i]) : 0u;
+}
+
+// keep entries whose column bit is set in `bitmap`
+__global__ __launch_bounds__(256) void bitmap_filter_fill_kernel(CsrView c, const u64* __restrict__ bitmap,
+                                                                u32 nrows, u32* __restrict__ tmp,
+                                                                u32* __restrict__ cnt) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32* __restrict__ b32 = (const u32*)bitmap;
+    for (u32 r = wave; r < nrows; r += nwaves) {
+        const u32 rb = c.rowptr[r], re = c.rowptr[r + 1];
+        u32 outn = 0;
+        for (u32 i0 = rb; i0 < re; i0 += 64) {
+            u32 i = i0 + lane, x = 0;
+            bool keep = false;
+            if (i < re) {
+                x = c.colidx[i];
+                keep = (b32[x >> 5] >> (x & 31)) & 1u;
+            }
+            u64 mask = __ballot(keep);
+            if (keep) tmp[rb + outn + __popcll(mask & ((1ull << lane) - 1ull))] = x;
+            outn += (u32)__popcll(mask);
+        }
+        if (lane == 0) cnt[r] = outn;
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_rows_kernel(const u32* __restrict__ tmp, const u32* __restrict__ srcoff,
+                                                          const u32* __restrict__ rowptr, u32 nrows,
+                                                          u32* __restrict__ col) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    for (u32 r = wave; r < nrows; r += nwaves) {
+        u32 s = srcoff[r], o = rowptr[r], c = rowptr[r + 1] - o;
+        for (u32 i = lane; i < c; i += 64) col[o + i] = tmp[s + i];
+    }
+}
+
+__global__ __launch_bounds__(256) void checksum_kernel(CsrView c, u32 nrows, unsigned long long* __restrict__ acc) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    u64 sum = 0;
+    for (u32 r = wave; r < nrows; r += nwaves) {
+        const u32 rb = c.rowptr[r], re = c.rowptr[r + 1];
+        for (u32 i = rb + lane; i < re; i += 64) sum += mix64(((u64)r << 32) | c.colidx[i]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0 && sum) atomicAdd(acc, (unsigned long long)sum);
+}
+
+static fgpu_info empty_dense(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols) {
+    fgpu_mat* o = nullptr;
+    FGPU_TRY(mat_alloc(ctx, &o, nrows, ncols, 0, false, 0, false));
+    hipError_t e = hipMemsetAsync(o->rowptr, 0, (nrows + 1) * sizeof(u32), ctx->stream);
+    if (e != hipSuccess) { fgpu_mat_free(o); set_error("memset failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+    *out = o;
+    return FGPU_OK;
+}
+
+// C = F x B (structural).  *flops (nullable) += sum_{(i,s) in F} deg_B(s).
+fgpu_info mxm_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* F, const fgpu_mat* B, u64* flops) {
+    FGPU_REQUIRE(F->ncols == B->nrows, FGPU_DIM_MISMATCH, "mxm: F is %llu x %llu but B is %llu x %llu",
+                 (unsigned long long)F->nrows, (unsigned long long)F->ncols, (unsigned long long)B->nrows,
+                 (unsigned long long)B->ncols);
+    const u64 k = F->nrows;
+    const u32 nnzf = (u32)F->nnz;
+    if (nnzf == 0 || B->nnz == 0) return empty_dense(ctx, out, k, B->ncols);
+    DevBuf<u32> frp, deg, cnt, rowptr, maxlen;
+    DevBuf<u64> eoff, roff, tot;
+    FGPU_TRY(dense_rowptr(ctx, F, frp));
+    FGPU_TRY(deg.alloc(ctx, (size_t)nnzf + 1));
+    FGPU_TRY(eoff.alloc(ctx, (size_t)nnzf + 1));
+    FGPU_TRY(tot.alloc(ctx, 1));
+    hipLaunchKernelGGL(entry_deg_kernel, dim3(cdiv((u64)nnzf + 1, 256)), dim3(256), 0, ctx->stream, view_of(F),
+                       view_of(B), nnzf, deg.p);
+    FGPU_HIP(hipGetLastError());
+    FGPU_TRY(scan_u32_to_u64(ctx, deg.p, eoff.p, (u64)nnzf + 1, tot.p));
+    FGPU_TRY(roff.alloc(ctx, k + 1));
+    FGPU_TRY(maxlen.alloc(ctx, 1));
+    FGPU_HIP(hipMemsetAsync(maxlen.p, 0, sizeof(u32), ctx->stream));
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(cdiv(k + 1, 256)), dim3(256), 0, ctx->stream, (const u64*)eoff.p,
+                       (const u32*)frp.p, (u32)k, roff.p, maxlen.p);
+    FGPU_HIP(hipGetLastError());
+    u64 T = 0;
+    FGPU_TRY(read_u64(ctx, tot.p, &T));
+    u32 ml = 0;
+    FGPU_TRY(read_u32(ctx, maxlen.p, &ml));
+    if (flops) *flops += T;
+    if (T == 0) return empty_dense(ctx, out, k, B->ncols);
+    FGPU_REQUIRE(T < (1ull << 33), FGPU_OOM,
+                 "mxm: %llu gathered entries exceed the per-call workspace; batch the source rows",
+                 (unsigned long long)T);
+    DevBuf<u32> tmp;
+    FGPU_TRY(tmp.alloc(ctx, T));
+    {
+        u32 grid = cdiv(nnzf, 4);
+        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(F), view_of(B), nnzf,
+                           (const u64*)eoff.p, tmp.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    FGPU_TRY(cnt.alloc(ctx, k + 1));
+    if (ml <= 1) {
+        hipLaunchKernelGGL(seg_len_kernel, dim3(cdiv(k + 1, 256)), dim3(256), 0, ctx->stream, (const u64*)roff.p,
+                           (u32)k, cnt.p);
+        FGPU_HIP(hipGetLastError());
+    } else {
+        FGPU_HIP(hipMemsetAsync(cnt.p, 0, (k + 1) * sizeof(u32), ctx->stream));
+        FGPU_TRY(segsort_unique(ctx, tmp.p, roff.p, (u32)k, (u32)B->ncols, cnt.p, nullptr));
+    }
+    FGPU_TRY(rowptr.alloc(ctx, k + 1));
+    FGPU_TRY(scan_u32(ctx, cnt.p, rowptr.p, k + 1, nullptr));
+    u32 nnz = 0;
+    FGPU_TRY(read_u32(ctx, rowptr.p + k, &nnz));
+    fgpu_mat* o = nullptr;
+    FGPU_TRY(mat_alloc(ctx, &o, k, B->ncols, nnz, false, 0, false));
+    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (k + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    fgpu_info i = compact_segments(ctx, tmp.p, roff.p, o->rowptr, (u32)k, o->colidx);
+    if (i != FGPU_OK) { fgpu_mat_free(o); return i; }
+    // hub lists are only needed by BFS; products skip mat_finalize (no extra sync per hop)
+    *out = o;
+    return FGPU_OK;
+}
+
+fgpu_info delta_lmxm_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* F, const fgpu_mat* m, const fgpu_mat* dp,
+                            const fgpu_mat* dm, u64* flops) {
+    const bool has_dp = dp && dp->nnz, has_dm = dm && dm->nnz;
+    if (!has_dp && !has_dm) return mxm_device(ctx, out, F, m, flops);  // hot path, matrix.rs:1333-1337
+    fgpu_mat *mask = nullptr, *acc = nullptr, *c = nullptr;
+    fgpu_info i = FGPU_OK;
+    if (has_dm) {
+        i = mxm_device(ctx, &mask, F, dm, nullptr);
+        if (i == FGPU_OK && mask->nnz == 0) { fgpu_mat_free(mask); mask = nullptr; }
+    }
+    if (i == FGPU_OK && has_dp) {
+        i = mxm_device(ctx, &acc, F, dp, flops);
+        if (i == FGPU_OK && acc->nnz == 0) { fgpu_mat_free(acc); acc = nullptr; }
+    }
+    if (i == FGPU_OK) i = mxm_device(ctx, &c, F, m, flops);
+    if (i == FGPU_OK && (mask || acc)) {
+        fgpu_mat* merged = nullptr;
+        // (F.m with MASK removed) U ACCUM — the accumulated dp product is not masked (matrix.rs:1382-1400)
+        i = mat_merge_device(ctx, &merged, c, acc, mask, false);
+        if (i == FGPU_OK) { fgpu_mat_free(c); c = merged; }
+    }
+    fgpu_mat_free(mask);
+    fgpu_mat_free(acc);
+    if (i != FGPU_OK) { fgpu_mat_free(c); return i; }
+    *out = c;
+    return FGPU_OK;
+}
+
+static fgpu_info filter_by_bitmap(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* c, const u64* bitmap_dev) {
+    const u64 nrows = c->nrows;
+    DevBuf<u32> tmp, cnt, rowptr;
+    FGPU_TRY(tmp.alloc(ctx, c->nnz));
+    FGPU_TRY(cnt.alloc(ctx, nrows + 1));
+    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream));
+    u32 grid = cdiv(nrows ? nrows : 1, 4);
+    if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+    if (nrows && c->nnz) {
+        hipLaunchKernelGGL(bitmap_filter_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(c), bitmap_dev,
+                           (u32)nrows, tmp.p, cnt.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    FGPU_TRY(rowptr.alloc(ctx, nrows + 1));
+    FGPU_TRY(scan_u32(ctx, cnt.p, rowptr.p, nrows + 1, nullptr));
+    u32 nnz = 0;
+    FGPU_TRY(read_u32(ctx, rowptr.p + nrows, &nnz));
+    fgpu_mat* o = nullptr;
+    FGPU_TRY(mat_alloc(ctx, &o, nrows, c->ncols, nnz, false, 0, false));
+    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    if (nnz) {
+        hipLaunchKernelGGL(compact_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const u32*)tmp.p,
+                           (const u32*)c->rowptr, (const u32*)o->rowptr, (u32)nrows, o->colidx);
+        FGPU_HIP(hipGetLastError());
+    }
+    *out = o;
+    return FGPU_OK;
+}
+
+// shared front half of fgpu_expand / fgpu_expand_count: result stays on device
+static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                               const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                               const uint64_t* dst_label_bitmap, fgpu_mat** result, u64* flops) {
+    FGPU_REQUIRE(nhops >= 1 && m, FGPU_INVALID, "expand: need at least one hop");
+    FGPU_REQUIRE(nsrc < 0xFFFFFFFFull, FGPU_INVALID, "expand: too many source rows");
+    for (int h = 0; h < nhops; ++h) {
+        FGPU_REQUIRE(m[h], FGPU_NULL_POINTER, "expand: hop %d base matrix is NULL", h);
+        FGPU_REQUIRE(!dp || !dp[h] || (dp[h]->nrows == m[h]->nrows && dp[h]->ncols == m[h]->ncols),
+                     FGPU_DIM_MISMATCH, "expand: hop %d dp dims differ from m", h);
+        FGPU_REQUIRE(!dm || !dm[h] || (dm[h]->nrows == m[h]->nrows && dm[h]->ncols == m[h]->ncols),
+                     FGPU_DIM_MISMATCH, "expand: hop %d dm dims differ from m", h);
+        FGPU_REQUIRE(h == 0 || m[h]->nrows == m[h - 1]->ncols, FGPU_DIM_MISMATCH,
+                     "expand: hop %d rows do not match hop %d columns", h, h - 1);
+    }
+    // F: one row per source, at most one entry per row (cond_traverse.rs:600-601)
+    const u64 ncols0 = m[0]->nrows;
+    std::vector<u32> rp(nsrc + 1), ci;
+    ci.reserve(nsrc);
+    rp[0] = 0;
+    for (u64 i = 0; i < nsrc; ++i) {
+        if (src_ids[i] != UINT64_MAX) {
+            FGPU_REQUIRE(src_ids[i] < ncols0, FGPU_OUT_OF_BOUNDS, "expand: source %llu = %llu >= %llu",
+                         (unsigned long long)i, (unsigned long long)src_ids[i], (unsigned long long)ncols0);
+            ci.push_back((u32)src_ids[i]);
+        }
+        rp[i + 1] = (u32)ci.size();
+    }
+    fgpu_mat* f = nullptr;
+    FGPU_TRY(mat_alloc(ctx, &f, nsrc, ncols0, ci.size(), false, 0, false));
+    hipError_t e = hipMemcpyAsync(f->rowptr, rp.data(), rp.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !ci.empty())
+        e = hipMemcpyAsync(f->colidx, ci.data(), ci.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { fgpu_mat_free(f); set_error("expand: source upload failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+    for (int h = 0; h < nhops; ++h) {
+        fgpu_mat* c = nullptr;
+        fgpu_info i = delta_lmxm_device(ctx, &c, f, m[h], dp ? dp[h] : nullptr, dm ? dm[h] : nullptr, flops);
+        fgpu_mat_free(f);
+        if (i != FGPU_OK) return i;
+        f = c;
+    }
+    if (dst_label_bitmap) {
+        const u64 nc = f->ncols, nw = (nc + 63) / 64;
+        DevBuf<u64> bm;
+        fgpu_info i = bm.alloc(ctx, nw + 1);
+        if (i == FGPU_OK) {
+            hipError_t e2 = hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+            if (e2 != hipSuccess) { set_error("expand: label bitmap upload failed: %s", hipGetErrorString(e2)); i = FGPU_DEVICE; }
+        }
+        fgpu_mat* c = nullptr;
+        if (i == FGPU_OK) i = filter_by_bitmap(ctx, &c, f, bm.p);
+        if (i == FGPU_OK) i = (hipStreamSynchronize(ctx->stream) == hipSuccess) ? FGPU_OK : FGPU_DEVICE;
+        fgpu_mat_free(f);
+        if (i != FGPU_OK) return i;
+        f = c;
+    }
+    *result = f;
+    return FGPU_OK;
+}
+
+}  // namespace fgpu
+
+using namespace fgpu;
+
+extern "C" {
+
+fgpu_info fgpu_mxm(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* b) {
+    FGPU_REQUIRE(ctx && c && f && b, FGPU_NULL_POINTER, "fgpu_mxm: NULL argument");
+    return mxm_device(ctx, c, f, b, nullptr);
+}
+
+fgpu_info fgpu_delta_lmxm(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* dp,
+                          const fgpu_mat* dm) {
+    FGPU_REQUIRE(ctx && c && f && m, FGPU_NULL_POINTER, "fgpu_delta_lmxm: NULL argument");
+    FGPU_REQUIRE(!dp || (dp->nrows == m->nrows && dp->ncols == m->ncols), FGPU_DIM_MISMATCH,
+                 "fgpu_delta_lmxm: dp dims differ from m");
+    FGPU_REQUIRE(!dm || (dm->nrows == m->nrows && dm->ncols == m->ncols), FGPU_DIM_MISMATCH,
+                 "fgpu_delta_lmxm: dm dims differ from m");
+    return delta_lmxm_device(ctx, c, f, m, dp, dm, nullptr);
+}
+
+fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                      const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                      const uint64_t* dst_label_bitmap, uint64_t** out_rowptr, uint64_t** out_dest,
+                      uint64_t* out_nnz, uint64_t* flops) {
+    FGPU_REQUIRE(ctx && out_rowptr && out_dest && out_nnz, FGPU_NULL_POINTER, "fgpu_expand: NULL argument");
+    FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand: NULL src_ids");
+    if (flops) *flops = 0;
+    fgpu_mat* r = nullptr;
+    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
+    uint64_t *vals = nullptr;
+    fgpu_info i = fgpu_mat_export_csr(ctx, r, out_rowptr, out_dest, &vals, out_nnz);
+    fgpu_mat_free(r);
+    return i;
+}
+
+fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                            const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                            const uint64_t* dst_label_bitmap, uint64_t* out_nnz, uint64_t* checksum,
+                            uint64_t* flops) {
+    FGPU_REQUIRE(ctx && out_nnz, FGPU_NULL_POINTER, "fgpu_expand_count: NULL argument");
+    FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_count: NULL src_ids");
+    if (flops) *flops = 0;
+    fgpu_mat* r = nullptr;
+    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
+    *out_nnz = r->nnz;
+    fgpu_info i = FGPU_OK;
+    if (checksum) {
+        *checksum = 0;
+        if (r->nnz) {
+            DevBuf<u64> acc;
+            i = acc.alloc(ctx, 1);
+            if (i == FGPU_OK) {
+                (void)hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream);
+                u32 grid = cdiv(r->nrows, 4);
+                if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+                hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(r),
+                                   (u32)r->nrows, (unsigned long long*)acc.p);
+                i = read_u64(ctx, acc.p, checksum);
+            }
+        }
+    }
+    fgpu_mat_free(r);
+    return i;
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+"""Thin Python handles over the C ABI (include/fgpu.h) — test / bench plumbing only.
+
+Everything of substance happens inside libfgpu.so; these classes own handles, convert numpy
+arrays to the plain pointers the ABI takes, and raise FgpuError on any non-zero fgpu_info.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import FgpuError, check, u64p, u8p, i32p, i64p
+
+U64 = np.uint64
+
+
+def _u64(x):
+    return np.ascontiguousarray(x, dtype=U64)
+
+
+def _p(a, t=u64p):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Context:
+    """fgpu_ctx: one per process+device (matrix::init analogue, matrix.rs:116-185)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _ffi.load()
+        self._h = C.c_void_p()
+        check(self.lib.fgpu_init(C.byref(self._h), device, None, None))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self.lib.fgpu_finalize(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.fgpu_sync(self._h))
+
+    def set_stream(self, stream_ptr: int | None):
+        check(self.lib.fgpu_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, wave = C.c_int32(), C.c_int32()
+        lds, hbm = C.c_int64(), C.c_int64()
+        check(self.lib.fgpu_device_info(self._h, name, C.byref(cus), C.byref(wave), C.byref(lds), C.byref(hbm)))
+        return {"name": name.value.decode(), "cus": cus.value, "wave": wave.value, "lds_bytes": lds.value,
+                "hbm_bytes": hbm.value}
+
+    def device_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self.lib.fgpu_device_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- helpers to pull caller-owned host buffers back into numpy ----
+    def _take(self, ptr, n, dtype=U64):
+        if not ptr or n == 0:
+            if ptr:
+                self.lib.fgpu_free(self._h, C.cast(ptr, C.c_void_p))
+            return np.zeros(0, dtype=dtype)
+        arr = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+        self.lib.fgpu_free(self._h, C.cast(ptr, C.c_void_p))
+        return arr
+
+    # ---- matrix factories ----
+    def mat_new(self, nrows, ncols) -> "Mat":
+        h = C.c_void_p()
+        check(self.lib.fgpu_mat_new(self._h, C.byref(h), nrows, ncols))
+        return Mat(self, h)
+
+    def mat_from_coo(self, nrows, ncols, rows, cols, vals=None) -> "Mat":
+        rows, cols = _u64(rows), _u64(cols)
+        v = _u64(vals) if vals is not None else None
+        h = C.c_void_p()
+        check(self.lib.fgpu_mat_from_coo(self._h, C.byref(h), nrows, ncols, _p(rows), _p(cols), _p(v), len(rows)))
+        return Mat(self, h)
+
+    def mat_from_csr(self, nrows, ncols, rowptr, colidx, vals=None, hyper_rows=None) -> "Mat":
+        rowptr, colidx = _u64(rowptr), _u64(colidx)
+        v = _u64(vals) if vals is not None else None
+        hr = _u64(hyper_rows) if hyper_rows is not None else None
+        h = C.c_void_p()
+        check(self.lib.fgpu_mat_from_csr(self._h, C.byref(h), nrows, ncols, len(colidx),
+                                         rowptr.ctypes.data_as(C.c_void_p), 64, colidx.ctypes.data_as(C.c_void_p), 64,
+                                         _p(v), _p(hr), len(hr) if hr is not None else 0))
+        return Mat(self, h)
+
+    def mat_rmat(self, scale, edge_factor=16, seed=None, a16=0, b16=0, c16=0) -> "Mat":
+        if seed is None:
+            seed = 0x5EED1234 + scale
+        h = C.c_void_p()
+        check(self.lib.fgpu_mat_rmat(self._h, C.byref(h), scale, edge_factor, seed, a16, b16, c16))
+        return Mat(self, h)
+
+
+class Mat:
+    """fgpu_mat: immutable device snapshot of one matrix layer."""
+
+    def __init__(self, ctx: Context, h):
+        self.ctx, self._h = ctx, h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def free(self):
+        if self._h:
+            self.ctx.lib.fgpu_mat_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.free()
+        except Exception:
+            pass
+
+    def _get(self, fn):
+        v = C.c_uint64()
+        check(fn(self._h, C.byref(v)))
+        return v.value
+
+    @property
+    def nrows(self):
+        return self._get(self.ctx.lib.fgpu_mat_nrows)
+
+    @property
+    def ncols(self):
+        return self._get(self.ctx.lib.fgpu_mat_ncols)
+
+    @property
+    def nvals(self):
+        return self._get(self.ctx.lib.fgpu_mat_nvals)
+
+    def export_csr(self):
+        lib = self.ctx.lib
+        rp, ci, vv = u64p(), u64p(), u64p()
+        nnz = C.c_uint64()
+        check(lib.fgpu_mat_export_csr(self.ctx._h, self._h, C.byref(rp), C.byref(ci), C.byref(vv), C.byref(nnz)))
+        nrows = self.nrows
+        rowptr = self.ctx._take(rp, nrows + 1)
+        colidx = self.ctx._take(ci, max(nnz.value, 1))[: nnz.value]
+        vals = self.ctx._take(vv, nnz.value) if vv else None
+        return rowptr, colidx, vals
+
+    def extract(self, min_row=0, max_row=2**64 - 1):
+        lib = self.ctx.lib
+        r, c, v = u64p(), u64p(), u64p()
+        n = C.c_uint64()
+        check(lib.fgpu_mat_extract(self.ctx._h, self._h, min_row, max_row, C.byref(r), C.byref(c), C.byref(v),
+                                   C.byref(n)))
+        rows = self.ctx._take(r, n.value)
+        cols = self.ctx._take(c, n.value)
+        vals = self.ctx._take(v, n.value) if v else None
+        return rows, cols, vals
+
+    def transpose(self) -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mat_transpose(self.ctx._h, C.byref(h), self._h))
+        return Mat(self.ctx, h)
+
+    def probe(self, rows, cols, want_vals=False):
+        rows, cols = _u64(rows), _u64(cols)
+        present = np.zeros(len(rows), dtype=np.uint8)
+        vals = np.zeros(len(rows), dtype=U64) if want_vals else None
+        check(self.ctx.lib.fgpu_mat_probe(self.ctx._h, self._h, _p(rows), _p(cols), len(rows), _p(present, u8p),
+                                          _p(vals)))
+        return (present, vals) if want_vals else present
+
+    def merge(self, dp: "Mat | None", dm: "Mat | None", dm_masks_dp=False) -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mat_merge(self.ctx._h, C.byref(h), self._h, dp._h if dp else None,
+                                          dm._h if dm else None, 1 if dm_masks_dp else 0))
+        return Mat(self.ctx, h)
+
+    def intersect(self, b: "Mat") -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mat_intersect(self.ctx._h, C.byref(h), self._h, b._h))
+        return Mat(self.ctx, h)
+
+    def intersect_nvals(self, b: "Mat") -> int:
+        v = C.c_uint64()
+        check(self.ctx.lib.fgpu_mat_intersect_nvals(self.ctx._h, self._h, b._h, C.byref(v)))
+        return v.value
+
+    def mxm(self, b: "Mat") -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mxm(self.ctx._h, C.byref(h), self._h, b._h))
+        return Mat(self.ctx, h)
+
+    def delta_lmxm(self, m: "Mat", dp: "Mat | None", dm: "Mat | None") -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_delta_lmxm(self.ctx._h, C.byref(h), self._h, m._h, dp._h if dp else None,
+                                           dm._h if dm else None))
+        return Mat(self.ctx, h)
+
+    def col_slab(self, lo, hi) -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mat_col_slab(self.ctx._h, C.byref(h), self._h, lo, hi))
+        return Mat(self.ctx, h)
+
+    def row_slab(self, lo, hi) -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mat_row_slab(self.ctx._h, C.byref(h), self._h, lo, hi))
+        return Mat(self.ctx, h)
+
+
+def _hop_arrays(mats):
+    arr = (C.c_void_p * len(mats))()
+    for i, m in enumerate(mats):
+        arr[i] = m._h if m is not None else None
+    return arr
+
+
+def expand(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
+    """fgpu_expand: the device core of CondTraverseOp::expand_batch.  Returns (rowptr, dest, flops)."""
+    src = _u64(src_ids)
+    nh = len(m)
+    am = _hop_arrays(m)
+    adp = _hop_arrays(dp) if dp is not None else None
+    adm = _hop_arrays(dm) if dm is not None else None
+    lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
+    rp, ci = u64p(), u64p()
+    nnz, flops = C.c_uint64(), C.c_uint64()
+    check(ctx.lib.fgpu_expand(ctx._h, _p(src), len(src), am, adp, adm, nh, _p(lab), C.byref(rp), C.byref(ci),
+                              C.byref(nnz), C.byref(flops)))
+    rowptr = ctx._take(rp, len(src) + 1)
+    dest = ctx._take(ci, max(nnz.value, 1))[: nnz.value]
+    return rowptr, dest, flops.value
+
+
+def expand_count(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
+    src = _u64(src_ids)
+    am = _hop_arrays(m)
+    adp = _hop_arrays(dp) if dp is not None else None
+    adm = _hop_arrays(dm) if dm is not None else None
+    lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
+    nnz, cs, flops = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    check(ctx.lib.fgpu_expand_count(ctx._h, _p(src), len(src), am, adp, adm, len(m), _p(lab), C.byref(nnz),
+                                    C.byref(cs), C.byref(flops)))
+    return nnz.value, cs.value, flops.value
+
+
+def vxm(ctx: Context, f_bits, mask_bits, A: Mat, At: Mat | None = None, direction=0):
+    f = _u64(f_bits)
+    mk = _u64(mask_bits) if mask_bits is not None else None
+    w = np.zeros(len(f), dtype=U64)
+    check(ctx.lib.fgpu_vxm(ctx._h, _p(w), _p(f), _p(mk), A._h, At._h if At else None, direction))
+    return w
+
+
+def bfs(ctx: Context, A: Mat, At: Mat | None, src: int, max_level: int = -1, want_parent: bool = True):
+    n = A.nrows
+    level = np.zeros(n, dtype=np.int32)
+    parent = np.zeros(n, dtype=np.int64) if want_parent else None
+    edges = C.c_uint64()
+    check(ctx.lib.fgpu_bfs(ctx._h, A._h, At._h if At else None, src, max_level, _p(level, i32p),
+                           _p(parent, i64p), C.byref(edges)))
+    return level, parent, edges.value
+
+
+class BfsPlan:
+    """fgpu_bfs_plan: resident BFS workspace (+ slab partition state for multi-rank runs)."""
+
+    def __init__(self, ctx: Context, A: Mat, At: Mat | None, rank=0, nranks=1):
+        self.ctx, self.A, self.At = ctx, A, At
+        self._h = C.c_void_p()
+        check(ctx.lib.fgpu_bfs_plan_create(ctx._h, C.byref(self._h), A._h, At._h if At else None, rank, nranks))
+        self.n = A.nrows
+
+    def free(self):
+        if self._h:
+            self.ctx.lib.fgpu_bfs_plan_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.free()
+        except Exception:
+            pass
+
+    def tune(self, alpha=0.0, beta=0.0, force_direction=0):
+        check(self.ctx.lib.fgpu_bfs_plan_tune(self._h, alpha, beta, force_direction))
+
+    def run(self, src, max_level=-1, want_parent=False):
+        check(self.ctx.lib.fgpu_bfs_run(self._h, src, max_level, 1 if want_parent else 0))
+
+    def fetch(self, want_parent=False):
+        level = np.zeros(self.n, dtype=np.int32)
+        parent = np.zeros(self.n, dtype=np.int64) if want_parent else None
+        check(self.ctx.lib.fgpu_bfs_fetch(self._h, _p(level, i32p), _p(parent, i64p)))
+        return level, parent
+
+    def stats(self):
+        s = np.zeros(8, dtype=U64)
+        check(self.ctx.lib.fgpu_bfs_stats(self._h, _p(s)))
+        keys = ["levels", "reached", "edges_traversed", "push_levels", "pull_levels", "scanned_push",
+                "scanned_pull", "last_frontier"]
+        return dict(zip(keys, (int(x) for x in s)))
+
+    def profile(self, enable=True):
+        check(self.ctx.lib.fgpu_bfs_plan_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        cap = 8
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        launches = (C.c_uint64 * cap)()
+        ab = (C.c_uint64 * cap)()
+        n = C.c_int()
+        check(self.ctx.lib.fgpu_bfs_plan_profile_read(self._h, names, ms, launches, ab, cap, C.byref(n)))
+        return [{"kernel": names[i].decode(), "ms": ms[i], "launches": launches[i], "alg_bytes": ab[i]}
+                for i in range(n.value)]
+
+    # ---- multi-rank stepping ----
+    def part_buffers(self):
+        lw, gw = C.c_void_p(), C.c_void_p()
+        wpr = C.c_uint64()
+        check(self.ctx.lib.fgpu_bfs_part_buffers(self._h, C.byref(lw), C.byref(gw), C.byref(wpr)))
+        return lw.value, gw.value, wpr.value
+
+    def part_set_buffers(self, local_ptr: int, global_ptr: int):
+        check(self.ctx.lib.fgpu_bfs_part_set_buffers(self._h, C.c_void_p(local_ptr), C.c_void_p(global_ptr)))
+
+    def part_begin(self, src, max_level=-1):
+        check(self.ctx.lib.fgpu_bfs_part_begin(self._h, src, max_level))
+
+    def part_step(self):
+        check(self.ctx.lib.fgpu_bfs_part_step(self._h))
+
+    def part_commit(self):
+        check(self.ctx.lib.fgpu_bfs_part_commit(self._h))
+
+    def part_done(self):
+        d, l = C.c_int32(), C.c_int32()
+        check(self.ctx.lib.fgpu_bfs_part_done(self._h, C.byref(d), C.byref(l)))
+        return bool(d.value), l.value
+
+
+def bench_spmv(ctx: Context, A: Mat, which=0, iters=20):
+    ms = C.c_double()
+    ab = C.c_uint64()
+    check(ctx.lib.fgpu_bench_spmv(ctx._h, A._h, which, iters, C.byref(ms), C.byref(ab)))
+    return ms.value, ab.value

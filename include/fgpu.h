@@ -1,0 +1,272 @@
+/*
+ * fgpu.h — C ABI of the MI355X-native traversal engine (device tier).
+ *
+ * This is the drop-in boundary for FalkorDB's sparse-linear-algebra hot path.
+ * In the reference the boundary is the `extern "C"` GraphBLAS/LAGraph symbol set
+ * bound by bindgen (graph/src/graph/graphblas/mod.rs:42-79) and consumed only
+ * through `Matrix<T>` (graph/src/graph/graphblas/matrix.rs).  Every entry point
+ * below names the reference call it replaces (file:line relative to
+ * /root/reference).  INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer would add beside graphblas/mod.rs.
+ *
+ * Conventions (mirroring SURVEY.md §8b):
+ *  - plain pointers and sizes only; no C++ / torch types cross this boundary;
+ *  - every call returns an fgpu_info (values 0/1/-2/-3/-102/-105 mirror
+ *    GrB_Info, graphblas/mod.rs:274-296); never aborts, never throws;
+ *  - fgpu_last_error() returns a thread-local message for the last failure;
+ *  - an fgpu_mat is an IMMUTABLE device-resident snapshot (the committed,
+ *    `wait()`ed state of a reference Matrix: CSR, sorted unique columns per
+ *    row, pattern-only for BOOL, +u64 values for UINT64 tensors);
+ *  - node ids must fit in 32 bits (the reference's Tensor::compound_key makes
+ *    the same demand, tensor.rs:154-163) and nnz per matrix must be < 2^32;
+ *  - outputs returned through `T**` are host buffers owned by the caller until
+ *    fgpu_free().
+ *  - There is NO CPU fallback: without a HIP device fgpu_init fails with
+ *    FGPU_DEVICE and nothing else can be called.
+ */
+#ifndef FGPU_H
+#define FGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fgpu_ctx fgpu_ctx; /* one per process+device (matrix::init, matrix.rs:116-185) */
+typedef struct fgpu_mat fgpu_mat; /* immutable device CSR snapshot of one matrix layer        */
+typedef struct fgpu_bfs_plan fgpu_bfs_plan; /* per-(A,At) BFS workspace + partition state       */
+
+typedef int32_t fgpu_info;
+#define FGPU_OK 0                  /* GrB_SUCCESS                */
+#define FGPU_NO_VALUE 1            /* GrB_NO_VALUE               */
+#define FGPU_NULL_POINTER (-2)     /* GrB_NULL_POINTER           */
+#define FGPU_INVALID (-3)          /* GrB_INVALID_VALUE          */
+#define FGPU_DIM_MISMATCH (-6)     /* GrB_DIMENSION_MISMATCH     */
+#define FGPU_OOM (-102)            /* GrB_OUT_OF_MEMORY          */
+#define FGPU_OUT_OF_BOUNDS (-105)  /* GrB_INDEX_OUT_OF_BOUNDS    */
+#define FGPU_DEVICE (-7002)        /* GxB_GPU_ERROR              */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* Replaces matrix::init -> GxB_init(GrB_NONBLOCKING, allocators) (matrix.rs:116-185).
+ * `mal`/`fre` (nullable) are the host allocator hooks used for every buffer
+ * handed back to the caller (the reference passes Redis' allocator). */
+fgpu_info fgpu_init(fgpu_ctx** ctx, int device, void* (*mal)(size_t), void (*fre)(void*));
+/* Replaces matrix::shutdown -> GrB_finalize (matrix.rs:214-221). */
+fgpu_info fgpu_finalize(fgpu_ctx* ctx);
+const char* fgpu_last_error(void);
+void fgpu_free(fgpu_ctx* ctx, void* p);
+/* Run all subsequent work of this ctx on an externally owned hipStream_t
+ * (plumbing for torch.distributed: pass torch.cuda.current_stream().cuda_stream).
+ * NULL restores the ctx's own stream. */
+fgpu_info fgpu_set_stream(fgpu_ctx* ctx, void* hip_stream);
+fgpu_info fgpu_sync(fgpu_ctx* ctx);
+/* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */
+fgpu_info fgpu_device_info(fgpu_ctx* ctx, char* name, int32_t* cus, int32_t* wave,
+                           int64_t* lds_bytes, int64_t* hbm_bytes);
+/* Bytes currently held by the ctx's device pool (GRAPH.MEMORY analogue, graph.rs:3935). */
+fgpu_info fgpu_device_bytes(fgpu_ctx* ctx, uint64_t* in_use, uint64_t* pooled);
+
+/* ---- matrices ----------------------------------------------------------- */
+
+/* Empty nrows x ncols matrix: Matrix::<bool>::new (matrix.rs:1214-1235). */
+fgpu_info fgpu_mat_new(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols);
+
+/* COO -> CSR with duplicate coordinates collapsed.
+ * vals == NULL : Matrix::<bool>::build -> GxB_Matrix_build_Scalar (matrix.rs:1281-1303;
+ *                dup-collapse pinned by matrix.rs:1686-1695).
+ * vals != NULL : Matrix::<u64>::build -> GrB_Matrix_build_UINT64(..., GxB_ANY_UINT64)
+ *                (matrix.rs:1186-1210); the LAST duplicate wins (a legal ANY). */
+fgpu_info fgpu_mat_from_coo(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols,
+                            const uint64_t* rows, const uint64_t* cols, const uint64_t* vals,
+                            uint64_t n);
+
+/* Host CSR (what GxB_unload_Matrix_into_Container yields: p, i, x [, h];
+ * matrix.rs:508-546) -> device snapshot.  rowptr has nvec+1 entries when
+ * `hyper_rows` (sorted non-empty row ids, nvec of them) is given, else
+ * nrows+1.  rowptr_bits / colidx_bits are 32 or 64.  Rows must already be
+ * sorted and unique (the state after Matrix::wait). */
+fgpu_info fgpu_mat_from_csr(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols,
+                            uint64_t nnz, const void* rowptr, int rowptr_bits,
+                            const void* colidx, int colidx_bits, const uint64_t* vals,
+                            const uint64_t* hyper_rows, uint64_t nvec);
+
+/* Synthetic Graph500 R-MAT adjacency generated ON DEVICE (bench/tests data):
+ * 2^scale vertices, edge_factor*2^scale raw edges, (a,b,c) quadrant probabilities
+ * as 16.16 fixed point (0 -> Graph500 defaults .57/.19/.19), counter-based
+ * splitmix64 keyed by `seed`, vertex ids scrambled by a fixed bijection, directed,
+ * self-loops dropped, duplicates collapsed.  Not a reference API. */
+fgpu_info fgpu_mat_rmat(fgpu_ctx* ctx, fgpu_mat** out, int scale, int edge_factor,
+                        uint64_t seed, uint32_t a16, uint32_t b16, uint32_t c16);
+
+fgpu_info fgpu_mat_free(fgpu_mat* m);                       /* Drop, matrix.rs:387-399 */
+fgpu_info fgpu_mat_nrows(const fgpu_mat* m, uint64_t* out);  /* GrB_Matrix_nrows */
+fgpu_info fgpu_mat_ncols(const fgpu_mat* m, uint64_t* out);  /* GrB_Matrix_ncols */
+fgpu_info fgpu_mat_nvals(const fgpu_mat* m, uint64_t* out);  /* GrB_Matrix_nvals, matrix.rs:722-729 */
+fgpu_info fgpu_mat_has_values(const fgpu_mat* m, int32_t* out);
+
+/* D2H export of the whole snapshot in CSR form (GxB_Container p/i/x):
+ * rowptr[nrows+1] (always full, hyper rows expanded), colidx[nnz], vals[nnz] or NULL. */
+fgpu_info fgpu_mat_export_csr(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t** rowptr,
+                              uint64_t** colidx, uint64_t** vals, uint64_t* nnz);
+/* Entries of rows [min_row, max_row] in ascending (row, col) order:
+ * matrix::Iter::new/next (matrix.rs:1471-1605). */
+fgpu_info fgpu_mat_extract(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t min_row, uint64_t max_row,
+                           uint64_t** rows, uint64_t** cols, uint64_t** vals, uint64_t* n);
+
+/* GrB_transpose full: Matrix::transpose (matrix.rs:633-662).  Pattern only when
+ * `a` is BOOL; values carried when UINT64. */
+fgpu_info fgpu_mat_transpose(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
+
+/* Batched point probes (K11): GrB_Matrix_extractElement_* / GxB_Matrix_isStoredElement
+ * (matrix.rs:731-737, 1158-1172, 1248-1262).  present[i] = 1 iff (rows[i], cols[i])
+ * is stored; vals (nullable) receives the u64 value (0 for BOOL). */
+fgpu_info fgpu_mat_probe(fgpu_ctx* ctx, const fgpu_mat* m, const uint64_t* rows,
+                         const uint64_t* cols, uint64_t n, uint8_t* present, uint64_t* vals);
+
+/* Delta merge (K3/K6): out = (m \ dm) U dp, dp's value wins on a shared coordinate
+ * (GrB_SECOND_UINT64) — VersionedMatrix::flush / extract (versioned_matrix.rs:609-620,
+ * 892-938), Tensor::flush (tensor.rs:702-751).  dp/dm may be NULL.
+ * `dm_masks_dp`: 0 => dp entries survive dm (extract / Tensor structure semantics,
+ * where the invariants make it moot), 1 => eWiseAdd<!dm>(m, dp) exactly as flush's
+ * (true,true) arm (mask applies to the whole union). */
+fgpu_info fgpu_mat_merge(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
+                         const fgpu_mat* dm, int dm_masks_dp);
+/* Pattern intersection (K7): eWiseMult ANY_PAIR (matrix.rs:876-896); values from `b`. */
+fgpu_info fgpu_mat_intersect(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, const fgpu_mat* b);
+/* intersection_nvals (matrix.rs:743-761). */
+fgpu_info fgpu_mat_intersect_nvals(fgpu_ctx* ctx, const fgpu_mat* a, const fgpu_mat* b,
+                                   uint64_t* out);
+
+/* ---- products (ANY_PAIR structural semiring) ------------------------------ */
+
+/* C = F x B, no mask: Matrix::lmxm -> GrB_mxm(GxB_ANY_PAIR_BOOL) (matrix.rs:930-947).
+ * The result is a new snapshot (the reference overwrites F in place; the caller
+ * frees the old F). */
+fgpu_info fgpu_mxm(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* b);
+
+/* C = (F x (m U dp)) with every (i,j) of (F x dm) removed from the F x m part —
+ * the exact algebra of Matrix::delta_lmxm (matrix.rs:1317-1402): dp results are
+ * NOT masked; the mask is row-level (any source of row i tombstoning j kills
+ * (i,j)).  dp / dm may be NULL or empty => plain lmxm. */
+fgpu_info fgpu_delta_lmxm(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* m,
+                          const fgpu_mat* dp, const fgpu_mat* dm);
+
+/* The device core of CondTraverseOp::expand_batch (cond_traverse.rs:452-751):
+ *   F[i, src_ids[i]] = 1 for i in [0,nsrc)  (src_ids[i] == UINT64_MAX => row i left empty:
+ *   a source that failed its label pre-filter, cond_traverse.rs:561-589);
+ *   F <- delta_lmxm(F; m[h], dp[h], dm[h]) for h in [0,nhops);
+ *   entries whose dest lacks a bit in `dst_label_bitmap` (nullable, ncols bits,
+ *   LSB-first in 64-bit words) are dropped (cond_traverse.rs:644-651);
+ *   output CSR over the nsrc rows, dest ascending & unique per row
+ *   (= the ascending (row_i, dest) stream of F.iter, cond_traverse.rs:644).
+ * dp[h] / dm[h] may be NULL.  flops (nullable) receives sum over hops of
+ * sum_{(i,s) in F_h} deg_{m U dp}(s) — the traversed-edge count used for TEPS. */
+fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                      const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                      const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                      uint64_t** out_rowptr, uint64_t** out_dest, uint64_t* out_nnz,
+                      uint64_t* flops);
+
+/* Same as fgpu_expand but the result stays on device and only its size and an
+ * order-independent checksum come back (full-size configs whose output would not
+ * fit a host buffer): checksum = sum over entries of
+ * mix64((row << 32) | dest) mod 2^64. */
+fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                            const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                            const fgpu_mat* const* dm, int nhops,
+                            const uint64_t* dst_label_bitmap, uint64_t* out_nnz,
+                            uint64_t* checksum, uint64_t* flops);
+
+/* ---- boolean vxm / BFS (K9) ---------------------------------------------- */
+
+/* w<!mask, replace> = f x A over the boolean (ANY_PAIR) semiring, vectors as
+ * ncols-/nrows-bit bitmaps (LSB-first 64-bit words, HOST pointers; copied in/out).
+ * This is GrB_vxm (graphblas/mod.rs:11173) in the form LAGraph's BFS issues it.
+ * mask may be NULL.  `At` (nullable) enables the pull direction; `direction`:
+ * 0 = auto, 1 = push over A, 2 = pull over At (full pass, no early exit). */
+fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t* mask,
+                   const fgpu_mat* A, const fgpu_mat* At, int direction);
+
+/* Level-synchronous BFS: replaces LAGr_BreadthFirstSearch_Extended(level, parent, G,
+ * src, max_level, -1, false) as called by algo.BFS (algo_procedures.rs:1079-1088;
+ * binding lagraphx_bindings.rs:585-594).  level[n] (int32, -1 = unreached, source = 0),
+ * parent[n] (nullable, int64, -1 = none, parent[src] = src) are HOST arrays.
+ * max_level < 0 => unlimited.  At may be NULL (push only).  edges_traversed
+ * (nullable) = sum of out-degrees of reached vertices (TEPS numerator). */
+fgpu_info fgpu_bfs(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, uint64_t src,
+                   int64_t max_level, int32_t* level, int64_t* parent,
+                   uint64_t* edges_traversed);
+
+/* Plan API: keeps the BFS workspace resident so repeated searches (bench steps,
+ * many roots) pay no allocation, and results can stay on device.
+ * Column-slab partition for multi-GPU: rank `rank` of `nranks`
+ * owns destination vertices [rank*slab, (rank+1)*slab), slab = ceil(n/nranks)
+ * rounded up to 4096; A / At passed here are the rank's slab (A restricted to the
+ * owned columns, At restricted to the owned rows, both with GLOBAL ids).
+ * nranks == 1 is the plain single-GPU case. */
+fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** plan, const fgpu_mat* A,
+                               const fgpu_mat* At, int rank, int nranks);
+fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* plan);
+/* Tunables: alpha/beta of the push<->pull switch (Beamer), 0 keeps defaults;
+ * force_direction 0 auto / 1 push only / 2 pull only. */
+fgpu_info fgpu_bfs_plan_tune(fgpu_bfs_plan* plan, double alpha, double beta, int force_direction);
+/* Run one whole BFS on a single-rank plan; results stay on device. */
+fgpu_info fgpu_bfs_run(fgpu_bfs_plan* plan, uint64_t src, int64_t max_level, int want_parent);
+/* Copy results of the last run to host (either pointer may be NULL). */
+fgpu_info fgpu_bfs_fetch(fgpu_bfs_plan* plan, int32_t* level, int64_t* parent);
+/* Stats of the last run: stats[0]=levels, [1]=reached vertices (incl. source),
+ * [2]=edges traversed (sum outdeg of reached), [3]=push levels, [4]=pull levels,
+ * [5]=edges scanned by push kernels, [6]=edges scanned by pull kernels. */
+fgpu_info fgpu_bfs_stats(fgpu_bfs_plan* plan, uint64_t stats[8]);
+
+/* Multi-rank stepping (driven by the host loop that owns the collective):
+ *   begin(src) ; repeat { step() ; <allgather slab words> ; commit() } until done.
+ * local_words / global_words are DEVICE pointers owned by the plan:
+ *   local  = this rank's new-frontier slab: slab/64 bitmap words + 2 stat words
+ *            (count, sum of out-degrees) => `words_per_rank` uint64 each;
+ *   global = nranks * words_per_rank, the allgather destination. */
+fgpu_info fgpu_bfs_part_buffers(fgpu_bfs_plan* plan, void** local_words, void** global_words,
+                                uint64_t* words_per_rank);
+/* Let the caller own the exchange buffers instead (e.g. torch tensors handed to
+ * torch.distributed.all_gather_into_tensor): local = words_per_rank uint64, global =
+ * nranks * words_per_rank uint64, both DEVICE memory that outlives the plan's use.  Both are
+ * zeroed by the call. */
+fgpu_info fgpu_bfs_part_set_buffers(fgpu_bfs_plan* plan, void* local_words, void* global_words);
+fgpu_info fgpu_bfs_part_begin(fgpu_bfs_plan* plan, uint64_t src, int64_t max_level);
+fgpu_info fgpu_bfs_part_step(fgpu_bfs_plan* plan);
+fgpu_info fgpu_bfs_part_commit(fgpu_bfs_plan* plan);
+/* Non-blocking-ish poll of the device control block (one small D2H): done != 0 when
+ * the last committed frontier was empty or max_level was reached. */
+fgpu_info fgpu_bfs_part_done(fgpu_bfs_plan* plan, int32_t* done, int32_t* level);
+
+/* Build this rank's column slab of a full matrix: out = A[:, lo:hi) (global ids
+ * kept), and its transpose restricted to rows [lo,hi).  Used to shard a replicated
+ * or host-loaded adjacency. */
+fgpu_info fgpu_mat_col_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo,
+                            uint64_t hi);
+fgpu_info fgpu_mat_row_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo,
+                            uint64_t hi);
+
+/* ---- measurement hooks (bench.py; not reference APIs) --------------------- */
+
+/* Time `iters` launches of one named kernel with HIP events on the ctx stream.
+ * which: 0 = full-pass boolean pull SpMV over At (dense frontier, no mask, no early
+ * exit — the "RMAT-22 boolean SpMV" roofline case), 1 = push over A with a dense
+ * frontier.  Returns avg ms per launch and algorithmic bytes per launch
+ * (SURVEY.md §8d formulas). */
+fgpu_info fgpu_bench_spmv(fgpu_ctx* ctx, const fgpu_mat* A, int which, int iters,
+                          double* avg_ms, uint64_t* alg_bytes);
+/* Per-kernel accumulated HIP-event timings of a plan (enabled by
+ * fgpu_bfs_plan_profile(plan,1)): names[i] (static strings), ms[i], launches[i],
+ * alg_bytes[i]; returns count in *n (<= cap). */
+fgpu_info fgpu_bfs_plan_profile(fgpu_bfs_plan* plan, int enable);
+fgpu_info fgpu_bfs_plan_profile_read(fgpu_bfs_plan* plan, const char** names, double* ms,
+                                     uint64_t* launches, uint64_t* alg_bytes, int cap, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGPU_H */

@@ -1,0 +1,162 @@
+"""GPU parity: matrix builders / transposes / probes / merges vs the CPU oracle (bit-exact).
+
+Each test names the reference behaviour it pins (file:line relative to /root/reference).
+All calls go through the C ABI (include/fgpu.h)."""
+import numpy as np
+import pytest
+
+import oracle
+from falkordb_amd import engine
+
+pytestmark = pytest.mark.gpu
+U64 = np.uint64
+
+
+def rand_coo(rng, nrows, ncols, n):
+    return rng.integers(0, nrows, n, dtype=np.uint64), rng.integers(0, ncols, n, dtype=np.uint64)
+
+
+def assert_same(mat, ref: oracle.CSR):
+    rp, ci, _ = mat.export_csr()
+    assert mat.nrows == ref.nrows and mat.ncols == ref.ncols
+    assert mat.nvals == ref.nnz
+    np.testing.assert_array_equal(rp, ref.rowptr)
+    np.testing.assert_array_equal(ci, ref.colidx)
+
+
+def test_build_collapses_duplicates(ctx):
+    # matrix.rs:1686-1695: duplicate coordinates collapse to one entry
+    m = ctx.mat_from_coo(4, 4, [0, 0, 0, 3, 3], [1, 1, 2, 0, 0])
+    assert m.nvals == 3
+    r, c, _ = m.extract()
+    assert list(zip(r.tolist(), c.tolist())) == [(0, 1), (0, 2), (3, 0)]
+
+
+@pytest.mark.parametrize("nrows,ncols,n", [(1, 1, 1), (7, 5, 0), (64, 64, 500), (1000, 3000, 20000),
+                                           (100000, 100000, 300000)])
+def test_from_coo_host_path(ctx, nrows, ncols, n):
+    rng = np.random.default_rng(nrows * 31 + n)
+    r, c = rand_coo(rng, nrows, ncols, n)
+    assert_same(ctx.mat_from_coo(nrows, ncols, r, c), oracle.build_csr(nrows, ncols, r, c))
+
+
+def test_from_coo_device_path_skewed(ctx):
+    # >= 2^20 tuples go through the device histogram / segsort path, incl. a hub row (bitmap class)
+    rng = np.random.default_rng(7)
+    n = (1 << 21) + 12345
+    nrows = ncols = 50000
+    r, c = rand_coo(rng, nrows, ncols, n)
+    r[:200000] = 17          # hub row with > 4096 unique columns
+    r[200000:200300] = 18    # LDS class (65..4096)
+    assert_same(ctx.mat_from_coo(nrows, ncols, r, c), oracle.build_csr(nrows, ncols, r, c))
+
+
+def test_hypersparse_delta_layer(ctx):
+    # delta layers are pinned hypersparse (versioned_matrix.rs Delta::new); few rows of a huge matrix
+    n = 1 << 22
+    r = np.array([5, 5, 4000000, 123456], dtype=U64)
+    c = np.array([9, 3, 1, 77], dtype=U64)
+    m = ctx.mat_from_coo(n, n, r, c)
+    assert m.nvals == 4
+    rows, cols, _ = m.extract()
+    assert list(zip(rows.tolist(), cols.tolist())) == [(5, 3), (5, 9), (123456, 77), (4000000, 1)]
+    rows, cols, _ = m.extract(6, 123456)
+    assert list(zip(rows.tolist(), cols.tolist())) == [(123456, 77)]
+    p = m.probe([5, 5, 6, 4000000], [3, 4, 3, 1])
+    assert p.tolist() == [1, 0, 0, 1]
+
+
+def test_u64_build_and_probe_values(ctx):
+    # Matrix::<u64>::build (matrix.rs:1186-1210) + extractElement_UINT64 (:1158-1172)
+    m = ctx.mat_from_coo(10, 10, [1, 1, 2, 1], [3, 4, 0, 3], vals=[100, 200, 300, 111])
+    assert m.nvals == 3
+    p, v = m.probe([1, 1, 2, 0], [3, 4, 0, 0], want_vals=True)
+    assert p.tolist() == [1, 1, 1, 0]
+    assert v[1] == 200 and v[2] == 300 and v[0] in (100, 111)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_transpose(ctx, seed):
+    rng = np.random.default_rng(seed)
+    r, c = rand_coo(rng, 3000, 2000, 40000)
+    a = oracle.build_csr(3000, 2000, r, c)
+    assert_same(ctx.mat_from_coo(3000, 2000, r, c).transpose(), oracle.transpose(a))
+
+
+def test_from_csr_roundtrip_and_validation(ctx):
+    rng = np.random.default_rng(3)
+    r, c = rand_coo(rng, 500, 500, 5000)
+    a = oracle.build_csr(500, 500, r, c)
+    assert_same(ctx.mat_from_csr(500, 500, a.rowptr, a.colidx), a)
+    bad = a.colidx.copy()
+    if len(bad) > 1:
+        row0 = int(np.argmax(np.diff(a.rowptr) >= 2))
+        s = int(a.rowptr[row0])
+        bad[s], bad[s + 1] = bad[s + 1], bad[s]
+        with pytest.raises(engine.FgpuError) as e:
+            ctx.mat_from_csr(500, 500, a.rowptr, bad)
+        assert e.value.code == -3
+
+
+def test_probe_random(ctx):
+    rng = np.random.default_rng(11)
+    r, c = rand_coo(rng, 2000, 2000, 30000)
+    a = oracle.build_csr(2000, 2000, r, c)
+    m = ctx.mat_from_coo(2000, 2000, r, c)
+    pr, pc = rand_coo(rng, 2000, 2000, 5000)
+    pr[:1000], pc[:1000] = r[:1000], c[:1000]
+    s = a.to_set()
+    want = np.array([(int(x), int(y)) in s for x, y in zip(pr, pc)], dtype=np.uint8)
+    np.testing.assert_array_equal(m.probe(pr, pc), want)
+
+
+@pytest.mark.parametrize("masks_dp", [False, True])
+def test_merge_delta_layers(ctx, masks_dp):
+    # (m \ dm) U dp: VersionedMatrix::extract / flush (versioned_matrix.rs:609-620, 892-938)
+    rng = np.random.default_rng(5)
+    n = 4000
+    r, c = rand_coo(rng, n, n, 60000)
+    pr, pc = rand_coo(rng, n, n, 900)
+    k = 700
+    dr = np.concatenate([r[:k], pr[:50]])
+    dc = np.concatenate([c[:k], pc[:50]])
+    m, dp, dm = (oracle.build_csr(n, n, r, c), oracle.build_csr(n, n, pr, pc), oracle.build_csr(n, n, dr, dc))
+    got = ctx.mat_from_coo(n, n, r, c).merge(ctx.mat_from_coo(n, n, pr, pc), ctx.mat_from_coo(n, n, dr, dc),
+                                             dm_masks_dp=masks_dp)
+    assert_same(got, oracle.merge(m, dp, dm, masks_dp))
+
+
+def test_intersect(ctx):
+    rng = np.random.default_rng(6)
+    n = 3000
+    r, c = rand_coo(rng, n, n, 50000)
+    r2 = np.concatenate([r[:10000], rng.integers(0, n, 10000, dtype=np.uint64)])
+    c2 = np.concatenate([c[:10000], rng.integers(0, n, 10000, dtype=np.uint64)])
+    sa, sb = oracle.build_csr(n, n, r, c).to_set(), oracle.build_csr(n, n, r2, c2).to_set()
+    inter = sorted(sa & sb)
+    A, B = ctx.mat_from_coo(n, n, r, c), ctx.mat_from_coo(n, n, r2, c2)
+    assert A.intersect_nvals(B) == len(inter)
+    rows, cols, _ = A.intersect(B).extract()
+    assert list(zip(rows.tolist(), cols.tolist())) == inter
+
+
+@pytest.mark.parametrize("scale", [10, 14])
+def test_rmat_matches_numpy_generator(ctx, scale):
+    assert_same(ctx.mat_rmat(scale), oracle.rmat_csr(scale))
+
+
+def test_slabs(ctx):
+    a = oracle.rmat_csr(12)
+    A = ctx.mat_rmat(12)
+    lo, hi = 1024, 3072
+    rp, ci, _ = A.col_slab(lo, hi).export_csr()
+    rows, cols = a.pairs()
+    keep = (cols >= lo) & (cols < hi)
+    ref = oracle.build_csr(a.nrows, a.ncols, rows[keep], cols[keep])
+    np.testing.assert_array_equal(rp, ref.rowptr)
+    np.testing.assert_array_equal(ci, ref.colidx)
+    rp, ci, _ = A.row_slab(lo, hi).export_csr()
+    keep = (rows >= lo) & (rows < hi)
+    ref = oracle.build_csr(a.nrows, a.ncols, rows[keep], cols[keep])
+    np.testing.assert_array_equal(rp, ref.rowptr)
+    np.testing.assert_array_equal(ci, ref.colidx)

@@ -1,0 +1,189 @@
+"""GPU parity: ANY_PAIR products, CondTraverse expansion core and BFS vs the CPU oracle.
+Bit-exact (integer/structural work): identical CSR arrays, identical level vectors; parents
+are checked for validity because LAGraph's ANY monoid leaves the choice open."""
+import numpy as np
+import pytest
+
+import oracle
+from falkordb_amd import engine
+
+pytestmark = pytest.mark.gpu
+U64 = np.uint64
+
+
+def up(ctx, a: oracle.CSR):
+    return ctx.mat_from_csr(a.nrows, a.ncols, a.rowptr, a.colidx)
+
+
+def assert_same(mat, ref: oracle.CSR):
+    rp, ci, _ = mat.export_csr()
+    assert mat.nvals == ref.nnz
+    np.testing.assert_array_equal(rp, ref.rowptr)
+    np.testing.assert_array_equal(ci, ref.colidx)
+
+
+def f_matrix(k, n, srcs):
+    rows = np.arange(k, dtype=U64)
+    return oracle.build_csr(k, n, rows, np.asarray(srcs, dtype=U64))
+
+
+@pytest.mark.parametrize("scale,k", [(10, 64), (14, 1024), (16, 5000)])
+def test_lmxm_single_and_multi_source(ctx, scale, k):
+    # Matrix::lmxm (matrix.rs:930-947): hop 1 (one source per row) then hop 2 (multi-source rows)
+    a = oracle.rmat_csr(scale)
+    n = a.nrows
+    rng = np.random.default_rng(scale)
+    f = f_matrix(k, n, rng.integers(0, n, k))
+    A, F = up(ctx, a), up(ctx, f)
+    c1_ref, _ = oracle.mxm(f, a)
+    C1 = F.mxm(A)
+    assert_same(C1, c1_ref)
+    c2_ref, _ = oracle.mxm(c1_ref, a)
+    assert_same(C1.mxm(A), c2_ref)
+
+
+def test_lmxm_hub_rows_hit_bitmap_class(ctx):
+    # a product row far above 4096 gathered entries exercises the global-bitmap sort class
+    a = oracle.rmat_csr(15)
+    deg = np.diff(a.rowptr).astype(np.int64)
+    hubs = np.argsort(-deg)[:8]
+    f = oracle.build_csr(2, a.nrows, np.repeat(np.arange(2, dtype=U64), 4), hubs.astype(U64))
+    c1, _ = oracle.mxm(f, a)
+    c2, _ = oracle.mxm(c1, a)
+    A = up(ctx, a)
+    assert_same(up(ctx, f).mxm(A).mxm(A), c2)
+
+
+def _delta_layers(a: oracle.CSR, rng, n_dm, n_dp):
+    rows, cols = a.pairs()
+    pick = rng.choice(len(rows), n_dm, replace=False)
+    dm = oracle.build_csr(a.nrows, a.ncols, rows[pick], cols[pick])
+    pr = rng.integers(0, a.nrows, n_dp, dtype=np.uint64)
+    pc = rng.integers(0, a.ncols, n_dp, dtype=np.uint64)
+    dp = oracle.build_csr(a.nrows, a.ncols, pr, pc)
+    return dp, dm
+
+
+@pytest.mark.parametrize("n_dm,n_dp", [(0, 50), (50, 0), (300, 300)])
+def test_delta_lmxm_all_branches(ctx, n_dm, n_dp):
+    # Matrix::delta_lmxm (matrix.rs:1317-1402) incl. the row-level mask quirk on hop 2
+    a = oracle.rmat_csr(12)
+    rng = np.random.default_rng(n_dm * 7 + n_dp)
+    dp, dm = _delta_layers(a, rng, n_dm, n_dp)
+    k = 700
+    f = f_matrix(k, a.nrows, rng.integers(0, a.nrows, k))
+    A, DP, DM, F = up(ctx, a), up(ctx, dp), up(ctx, dm), up(ctx, f)
+    h1_ref, _ = oracle.delta_lmxm(f, a, dp, dm)
+    H1 = F.delta_lmxm(A, DP, DM)
+    assert_same(H1, h1_ref)
+    h2_ref, _ = oracle.delta_lmxm(h1_ref, a, dp, dm)
+    assert_same(H1.delta_lmxm(A, DP, DM), h2_ref)
+
+
+def test_expand_chain_with_label_filter_and_skipped_rows(ctx):
+    # expand_batch core (cond_traverse.rs:452-751): skipped sources leave empty rows, 3 hops,
+    # dst-label bitmap post-filter, ascending (row, dest)
+    a = oracle.rmat_csr(11)
+    n = a.nrows
+    rng = np.random.default_rng(42)
+    dp, dm = _delta_layers(a, rng, 100, 100)
+    k = 300
+    src = rng.integers(0, n, k).astype(U64)
+    src[::7] = np.uint64(2**64 - 1)
+    valid = src != np.uint64(2**64 - 1)
+    f = oracle.build_csr(k, n, np.arange(k, dtype=U64)[valid], src[valid])
+    label_ids = np.nonzero((oracle.mix64(np.arange(n, dtype=U64)) % np.uint64(3)) == 0)[0]
+    label = oracle.bits_from_ids(n, label_ids)
+    A, DP, DM = up(ctx, a), up(ctx, dp), up(ctx, dm)
+    c, flops_ref = f, 0
+    for _ in range(3):
+        c, fl = oracle.delta_lmxm(c, a, dp, dm)
+        flops_ref += fl
+    rows, cols = c.pairs()
+    keep = np.isin(cols, label_ids)
+    ref = oracle.build_csr(k, n, rows[keep], cols[keep])
+    rp, dest, flops = engine.expand(ctx, src, [A, A, A], [DP, DP, DP], [DM, DM, DM], label)
+    np.testing.assert_array_equal(rp, ref.rowptr)
+    np.testing.assert_array_equal(dest, ref.colidx)
+    assert flops == flops_ref
+    nnz, cs, fl2 = engine.expand_count(ctx, src, [A, A, A], [DP, DP, DP], [DM, DM, DM], label)
+    assert nnz == ref.nnz and cs == oracle.checksum(ref) and fl2 == flops_ref
+
+
+def check_bfs(a: oracle.CSR, level, parent, src, ref_level):
+    np.testing.assert_array_equal(level, ref_level)
+    if parent is None:
+        return
+    assert parent[src] == src
+    reached = np.nonzero(level > 0)[0]
+    p = parent[reached]
+    assert np.all(p >= 0)
+    assert np.all(level[p] + 1 == level[reached])          # parent sits one level up
+    s = a.to_set() if a.nnz < 2_000_000 else None
+    if s is not None:
+        assert all((int(pp), int(v)) in s for pp, v in zip(p, reached))  # and the edge exists
+    assert np.all(parent[level < 0] == -1)
+
+
+@pytest.mark.parametrize("force", [0, 1, 2])
+@pytest.mark.parametrize("scale", [8, 13, 16])
+def test_bfs_levels_and_parents(ctx, scale, force):
+    a = oracle.rmat_csr(scale)
+    A = up(ctx, a)
+    At = A.transpose()
+    deg = np.diff(a.rowptr)
+    roots = np.nonzero(deg > 0)[0][:3]
+    plan = engine.BfsPlan(ctx, A, At)
+    plan.tune(force_direction=force)
+    for src in roots:
+        ref_level, _, ref_edges = oracle.bfs(a, int(src), -1)
+        plan.run(int(src), -1, want_parent=True)
+        level, parent = plan.fetch(want_parent=True)
+        check_bfs(a, level, parent, int(src), ref_level)
+        st = plan.stats()
+        assert st["edges_traversed"] == ref_edges
+        assert st["reached"] == int(np.count_nonzero(ref_level >= 0))
+
+
+@pytest.mark.parametrize("max_level", [0, 1, 2, 3])
+def test_bfs_max_level(ctx, max_level):
+    a = oracle.rmat_csr(12)
+    A = up(ctx, a)
+    src = int(np.argmax(np.diff(a.rowptr)))
+    ref_level, _, _ = oracle.bfs(a, src, max_level)
+    level, parent, _ = engine.bfs(ctx, A, A.transpose(), src, max_level, want_parent=True)
+    check_bfs(a, level, parent, src, ref_level)
+
+
+def test_bfs_push_only_without_transpose(ctx):
+    a = oracle.rmat_csr(12)
+    A = up(ctx, a)
+    src = int(np.argmax(np.diff(a.rowptr)))
+    ref_level, _, ref_edges = oracle.bfs(a, src, -1)
+    level, parent, edges = engine.bfs(ctx, A, None, src, -1, want_parent=False)
+    np.testing.assert_array_equal(level, ref_level)
+    assert edges == ref_edges
+
+
+def test_bfs_chain_graph_many_levels(ctx):
+    # a path 0->1->...->299: 299 levels, exercises the blind level batching and termination
+    n = 300
+    a = oracle.build_csr(n, n, np.arange(n - 1, dtype=U64), np.arange(1, n, dtype=U64))
+    A = up(ctx, a)
+    level, _, _ = engine.bfs(ctx, A, A.transpose(), 0, -1, want_parent=False)
+    np.testing.assert_array_equal(level, np.arange(n, dtype=np.int32))
+
+
+@pytest.mark.parametrize("direction", [1, 2])
+def test_vxm_masked(ctx, direction):
+    a = oracle.rmat_csr(13)
+    n = a.nrows
+    rng = np.random.default_rng(direction)
+    f = oracle.bits_from_ids(n, rng.choice(n, 500, replace=False))
+    mask = oracle.bits_from_ids(n, rng.choice(n, n // 3, replace=False))
+    A = up(ctx, a)
+    At = A.transpose()
+    for mk in (None, mask):
+        want = oracle.vxm(a, f, mk)
+        got = engine.vxm(ctx, f, mk, A, At, direction)
+        np.testing.assert_array_equal(got, want)
