@@ -27,7 +27,7 @@
 
 namespace fgpu {
 
-constexpr int STAT_SLOTS = 256;
+constexpr int STAT_SLOTS = 64;
 
 struct BfsCtrl {
     i32 level;       // level of the frontier in `cur` (source = 0)
@@ -43,8 +43,9 @@ struct BfsCtrl {
     u32 push_levels, pull_levels;
     u32 has_at, force_dir;
     float alpha;
-    u32 pad;
+    u32 rot;         // fused single-rank path: cur = bm[rot%3], nxt = bm[(rot+1)%3], zeroed = bm[(rot+2)%3]
     u64 nnz_at;
+    u64 n_total;     // != 0 selects the fused path's m_u estimate (vertex count)
     // per-launch accumulators, spread over slots to keep same-address atomics off the critical path
     u64 slot_count[STAT_SLOTS];
     u64 slot_mf[STAT_SLOTS];
@@ -66,6 +67,7 @@ struct BfsArgs {
     u32* parent;      // nullable
     BfsCtrl* ctrl;
     u32 nw;           // u64 words in a global bitmap
+    u64* bm[3];       // fused single-rank path: rotating frontier bitmaps
 };
 
 __device__ __forceinline__ bool test_bit(const u64* bm, u32 v) {
@@ -323,6 +325,344 @@ __device__ void pull_body(const BfsArgs& a, const u64* __restrict__ frontier, co
     *scanned_out = scanned;
 }
 
+
+// ---------------------------------------------------------------------------------
+// fused single-rank level kernel: discovery, visited/level/parent update, next frontier and
+// statistics in ONE launch (no commit pass).  Frontier bitmaps rotate through three buffers:
+// this level reads bm[rot], ORs into bm[rot+1] (zeroed by the previous level) and zeroes
+// bm[rot+2] for the next one.
+// ---------------------------------------------------------------------------------
+struct LevelAcc { u64 count, mf, scanned; };
+
+template <bool PARENT>
+__device__ __forceinline__ void fused_visit(const BfsArgs& a, u32* __restrict__ vis32, u32* __restrict__ nxt32,
+                                            i32 newlevel, u32 u, u32 v, LevelAcc& acc) {
+    const u32 bit = 1u << (u & 31);
+    const u32 w = u >> 5;
+    if (vis32[w] & bit) return;  // possibly stale: worst case one redundant atomic
+    const u32 old = atomicOr(&vis32[w], bit);
+    if (old & bit) return;
+    a.level[u] = newlevel;
+    if (PARENT) a.parent[u] = v;
+    atomicOr(&nxt32[w], bit);
+    acc.count += 1;
+    acc.mf += a.A.rowptr[u + 1] - a.A.rowptr[u];
+}
+
+template <bool PARENT>
+__device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, u64* __restrict__ visited,
+                           u64* __restrict__ nxt, i32 newlevel, LevelAcc& acc) {
+    __shared__ u32 s_off[PUSH_VPB];
+    __shared__ u32 s_start[PUSH_VPB];
+    __shared__ u64 s_fw[PUSH_VPB / 64];
+    __shared__ u32 s_wave[4];
+    u32* __restrict__ vis32 = (u32*)visited;
+    u32* __restrict__ nxt32 = (u32*)nxt;
+    const u32 t = threadIdx.x;
+    const u32 nblk = (a.n + PUSH_VPB - 1) / PUSH_VPB;
+    const u32 nitems = nblk + a.n_hubA;
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        if (item >= nblk) {
+            const u32 h = item - nblk;
+            const u32 row = a.hubA[3 * h], b = a.hubA[3 * h + 1], e = a.hubA[3 * h + 2];
+            if (!test_bit(frontier, row)) continue;
+            for (u32 i = b + t; i < e; i += 256) fused_visit<PARENT>(a, vis32, nxt32, newlevel, a.A.colidx[i], row, acc);
+            if (t == 0) acc.scanned += e - b;
+            continue;
+        }
+        const u32 base = item * PUSH_VPB;
+        u64 fw = 0;
+        if (t < PUSH_VPB / 64) {
+            u32 wi = (base >> 6) + t;
+            fw = (wi < a.nw) ? frontier[wi] : 0ull;
+            s_fw[t] = fw;
+        }
+        if (!__syncthreads_or(fw != 0ull)) continue;
+        const u32 v0 = base + 4 * t;
+        const u32 nib = (u32)(s_fw[(4 * t) >> 6] >> ((4 * t) & 63)) & 0xFu;
+        u32 rp[5];
+        if (nib && v0 + 4 <= a.n) {
+            const uint4 q = *(const uint4*)(a.A.rowptr + v0);
+            rp[0] = q.x; rp[1] = q.y; rp[2] = q.z; rp[3] = q.w;
+            rp[4] = a.A.rowptr[v0 + 4];
+        } else if (nib) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) rp[j] = a.A.rowptr[(v0 + j <= a.n) ? (v0 + j) : a.n];
+        } else {
+            rp[0] = rp[1] = rp[2] = rp[3] = rp[4] = 0;
+        }
+        u32 deg[4], tsum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32 d = ((nib >> j) & 1u) ? (rp[j + 1] - rp[j]) : 0u;
+            if (d >= HUB_DEG) d = 0;
+            deg[j] = d;
+            tsum += d;
+        }
+        u32 total, ex;
+        {
+            const u32 lane = lane_id();
+            u32 inc = tsum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                u32 y = __shfl_up(inc, d, 64);
+                if (lane >= (u32)d) inc += y;
+            }
+            if (lane == 63) s_wave[t >> 6] = inc;
+            __syncthreads();
+            u32 wbase = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32 x = s_wave[i];
+                if ((u32)i < (t >> 6)) wbase += x;
+                tot += x;
+            }
+            total = tot;
+            ex = wbase + inc - tsum;
+        }
+        {
+            uint4 o, st;
+            o.x = ex; o.y = ex + deg[0]; o.z = o.y + deg[1]; o.w = o.z + deg[2];
+            st.x = rp[0]; st.y = rp[1]; st.z = rp[2]; st.w = rp[3];
+            *(uint4*)(s_off + 4 * t) = o;
+            *(uint4*)(s_start + 4 * t) = st;
+        }
+        __syncthreads();
+        // 4 edges per thread per trip: four independent (search -> colidx -> visited) chains in flight
+        for (u32 e0 = t; e0 < total; e0 += 1024) {
+            u32 own[4], u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 e = e0 + 256 * k;
+                u32 lo = 0, hi = PUSH_VPB;
+#pragma unroll
+                for (int it = 0; it < 10; ++it) {
+                    u32 mid = (lo + hi) >> 1;
+                    if (s_off[mid] <= e) lo = mid; else hi = mid;
+                }
+                own[k] = lo;
+                u[k] = (e < total) ? a.A.colidx[s_start[lo] + (e - s_off[lo])] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (u[k] != 0xFFFFFFFFu) fused_visit<PARENT>(a, vis32, nxt32, newlevel, u[k], base + own[k], acc);
+        }
+        if (t == 0) acc.scanned += total;
+        __syncthreads();
+    }
+}
+
+constexpr int PULL_A = 4;  // in-neighbours probed per row before the cooperative phase
+constexpr int PULL_R = 4;  // 64-row words per wavefront trip (memory-level parallelism: the level is
+                           // latency-bound, so one wave keeps 4 x (rowptr, 4 colidx, 4 probes) in flight)
+
+template <bool PARENT>
+__device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u64* __restrict__ visited,
+                           u64* __restrict__ nxt, i32 newlevel, LevelAcc& acc) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwords = (a.n + 63) >> 6;
+    const u32 nsuper = (nwords + PULL_R - 1) / PULL_R;
+    const u32* __restrict__ f32 = (const u32*)frontier;
+    const u32* __restrict__ col = a.At.colidx;
+    for (u32 G = wave; G < nsuper; G += nwaves) {
+        u64 mword[PULL_R];
+        bool live = false;
+#pragma unroll
+        for (int r = 0; r < PULL_R; ++r) {
+            const u32 g = G * PULL_R + r;
+            mword[r] = (g < nwords) ? visited[g] : ~0ull;
+            live |= (mword[r] != ~0ull);
+        }
+        if (!live) continue;
+        u32 rb[PULL_R], re[PULL_R];
+#pragma unroll
+        for (int r = 0; r < PULL_R; ++r) {
+            const u32 v = ((G * PULL_R + r) << 6) + lane;
+            const u32 vc = v < a.n ? v : a.n;
+            const bool want = (mword[r] != ~0ull);
+            rb[r] = want ? a.At.rowptr[vc] : 0u;
+            re[r] = want ? a.At.rowptr[(vc + 1 <= a.n) ? (vc + 1) : a.n] : 0u;
+        }
+        bool need[PULL_R], found[PULL_R];
+        u32 par[PULL_R];
+        u32 c[PULL_R][PULL_A];
+#pragma unroll
+        for (int r = 0; r < PULL_R; ++r) {
+            const u32 v = ((G * PULL_R + r) << 6) + lane;
+            const u32 deg = re[r] - rb[r];
+            need[r] = (v < a.n) && !((mword[r] >> lane) & 1ull) && deg > 0;
+            found[r] = false;
+            par[r] = 0;
+#pragma unroll
+            for (int j = 0; j < PULL_A; ++j) c[r][j] = (need[r] && (u32)j < deg) ? col[rb[r] + j] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int r = 0; r < PULL_R; ++r) {
+#pragma unroll
+            for (int j = 0; j < PULL_A; ++j) {
+                const u32 x = c[r][j];
+                const bool h = (x != 0xFFFFFFFFu) && ((f32[x >> 5] >> (x & 31)) & 1u);
+                if (h && !found[r]) { found[r] = true; par[r] = x; }
+            }
+            if (need[r]) {
+                const u32 deg = re[r] - rb[r];
+                acc.scanned += deg < (u32)PULL_A ? deg : (u32)PULL_A;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PULL_R; ++r) {
+            const u32 g = G * PULL_R + r;
+            if (g >= nwords) continue;  // wave-uniform
+            const u32 v = (g << 6) + lane;
+            const u32 deg = re[r] - rb[r];
+            const bool hub_here = __ballot(need[r] && deg >= HUB_DEG) != 0ull;
+            // phase B: rows still open are scanned by the whole wave, 256 coalesced elements per trip
+            u64 pend = __ballot(need[r] && !found[r] && deg > (u32)PULL_A && deg < HUB_DEG);
+            while (pend) {
+                const int l = (int)__builtin_ctzll(pend);
+                pend &= pend - 1ull;
+                const u32 b0 = __shfl(rb[r], l, 64) + PULL_A;
+                const u32 e0 = __shfl(re[r], l, 64);
+                bool hit = false;
+                u32 hc = 0;
+                for (u32 q = b0; q < e0; q += 256) {
+                    u32 x[4];
+                    bool hh[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        u32 qq = q + 64 * k + lane;
+                        x[k] = (qq < e0) ? col[qq] : 0xFFFFFFFFu;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        hh[k] = (x[k] != 0xFFFFFFFFu) && ((f32[x[k] >> 5] >> (x[k] & 31)) & 1u);
+                    u64 any = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const u64 H = __ballot(hh[k]);
+                        if (H && !any) {
+                            any = H;
+                            hc = __shfl(x[k], (int)__builtin_ctzll(H), 64);
+                        }
+                    }
+                    if (lane == 0) acc.scanned += (e0 - q < 256u) ? (e0 - q) : 256u;
+                    if (any) { hit = true; break; }
+                }
+                if ((int)lane == l && hit) { found[r] = true; par[r] = hc; }
+            }
+            const u64 neww = __ballot(found[r]);
+            if (neww == 0ull) continue;
+            u64 won = neww;
+            if (hub_here) {
+                // hub items publish into the same words with atomics
+                u32 o0 = 0, o1 = 0;
+                if (lane == 0) {
+                    o0 = atomicOr(((u32*)visited) + 2 * g, (u32)neww);
+                    o1 = atomicOr(((u32*)visited) + 2 * g + 1, (u32)(neww >> 32));
+                    atomicOr(((u32*)nxt) + 2 * g, (u32)neww);
+                    atomicOr(((u32*)nxt) + 2 * g + 1, (u32)(neww >> 32));
+                }
+                o0 = __shfl(o0, 0, 64);
+                o1 = __shfl(o1, 0, 64);
+                won = neww & ~(((u64)o1 << 32) | o0);
+            } else if (lane == 0) {
+                visited[g] = mword[r] | neww;
+                nxt[g] = neww;
+            }
+            if ((won >> lane) & 1ull) {
+                a.level[v] = newlevel;
+                if (PARENT) a.parent[v] = par[r];
+                acc.count += 1;
+                acc.mf += a.A.rowptr[v + 1] - a.A.rowptr[v];
+            }
+        }
+    }
+    // hub rows of A' (>= HUB_DEG in-edges): chunks spread over workgroups
+    {
+        __shared__ u32 s_hit[2];
+        __shared__ u32 s_skip;
+        u32* __restrict__ vis32 = (u32*)visited;
+        u32* __restrict__ nxt32 = (u32*)nxt;
+        for (u32 h = blockIdx.x; h < a.n_hubAt; h += gridDim.x) {
+            const u32 row = a.hubAt[3 * h], b = a.hubAt[3 * h + 1], e2 = a.hubAt[3 * h + 2];
+            // visited may change under us (other waves publish): one thread samples it for the block
+            if (threadIdx.x == 0) {
+                s_hit[0] = 0;
+                s_hit[1] = 0xFFFFFFFFu;
+                s_skip = (row >= a.n) || ((vis32[row >> 5] >> (row & 31)) & 1u);
+            }
+            __syncthreads();
+            if (s_skip) { __syncthreads(); continue; }
+            bool hit = false;
+            u32 pc = 0xFFFFFFFFu;
+            for (u32 i = b + threadIdx.x; i < e2; i += 256) {
+                u32 x = col[i];
+                if ((f32[x >> 5] >> (x & 31)) & 1u) { hit = true; pc = x; break; }
+            }
+            if (hit) { s_hit[0] = 1; if (PARENT) atomicMin(&s_hit[1], pc); }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                acc.scanned += e2 - b;
+                if (s_hit[0]) {
+                    const u32 bit = 1u << (row & 31);
+                    const u32 old = atomicOr(&vis32[row >> 5], bit);
+                    if (!(old & bit)) {
+                        a.level[row] = newlevel;
+                        if (PARENT) a.parent[row] = s_hit[1];
+                        atomicOr(&nxt32[row >> 5], bit);
+                        acc.count += 1;
+                        acc.mf += a.A.rowptr[row + 1] - a.A.rowptr[row];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <bool PARENT>
+__global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
+    BfsCtrl* c = a.ctrl;
+    if (c->done) return;
+    const u32 rot = c->rot;
+    const u64* cur = a.bm[rot % 3];
+    u64* nxt = a.bm[(rot + 1) % 3];
+    u64* zr = a.bm[(rot + 2) % 3];
+    const i32 newlevel = c->level + 1;
+    const int dir = c->direction;
+    for (u32 w = blockIdx.x * 256 + threadIdx.x; w < a.nw; w += gridDim.x * 256) zr[w] = 0ull;
+    LevelAcc acc = {0, 0, 0};
+    if (dir == 1) push_fused<PARENT>(a, cur, a.visited, nxt, newlevel, acc);
+    else pull_fused<PARENT>(a, cur, a.visited, nxt, newlevel, acc);
+    // block reduction of the per-thread statistics, one atomic triple per workgroup
+    u64 cnt = acc.count, mf = acc.mf, sc = acc.scanned;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += __shfl_xor(cnt, d, 64);
+        mf += __shfl_xor(mf, d, 64);
+        sc += __shfl_xor(sc, d, 64);
+    }
+    __shared__ unsigned long long s_acc[3];
+    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane_id() == 0 && (cnt | sc)) {
+        atomicAdd(&s_acc[0], (unsigned long long)cnt);
+        atomicAdd(&s_acc[1], (unsigned long long)mf);
+        atomicAdd(&s_acc[2], (unsigned long long)sc);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_acc[0] | s_acc[2])) {
+        const u32 slot = blockIdx.x & (STAT_SLOTS - 1);
+        if (s_acc[0]) {
+            atomicAdd((unsigned long long*)&c->slot_count[slot], s_acc[0]);
+            atomicAdd((unsigned long long*)&c->slot_mf[slot], s_acc[1]);
+        }
+        if (s_acc[2]) atomicAdd((unsigned long long*)&c->slot_scan[slot], s_acc[2]);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // level kernels
 // ---------------------------------------------------------------------------------
@@ -404,20 +744,26 @@ __global__ __launch_bounds__(256) void bfs_commit_kernel(BfsArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void bfs_ctrl_kernel(BfsCtrl* c) {
-    if (c->done) return;
-    __shared__ unsigned long long s[4];
-    if (threadIdx.x < 4) s[threadIdx.x] = 0;
-    __syncthreads();
+__global__ __launch_bounds__(64) void bfs_ctrl_kernel(BfsCtrl* c) {
+    // one wavefront: lane t owns stat slot t; all loads issued before anything depends on them
     const u32 t = threadIdx.x;
-    if (t < STAT_SLOTS) {
-        if (c->slot_count[t]) atomicAdd(&s[0], (unsigned long long)c->slot_count[t]);
-        if (c->slot_mf[t]) atomicAdd(&s[1], (unsigned long long)c->slot_mf[t]);
-        if (c->slot_indeg[t]) atomicAdd(&s[2], (unsigned long long)c->slot_indeg[t]);
-        if (c->slot_scan[t]) atomicAdd(&s[3], (unsigned long long)c->slot_scan[t]);
-        c->slot_count[t] = 0; c->slot_mf[t] = 0; c->slot_indeg[t] = 0; c->slot_scan[t] = 0;
+    const i32 was_done = c->done;
+    const int dir_in = c->direction;
+    u64 v0 = c->slot_count[t], v1 = c->slot_mf[t], v2 = c->slot_indeg[t], v3 = c->slot_scan[t];
+    if (was_done) return;
+    if (v0) c->slot_count[t] = 0;
+    if (v1) c->slot_mf[t] = 0;
+    if (v2) c->slot_indeg[t] = 0;
+    if (v3) c->slot_scan[t] = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        v0 += __shfl_xor(v0, d, 64);
+        v1 += __shfl_xor(v1, d, 64);
+        v2 += __shfl_xor(v2, d, 64);
+        v3 += __shfl_xor(v3, d, 64);
     }
-    __syncthreads();
+    const u64 s[4] = {v0, v1, v2, v3};
+    (void)dir_in;
     if (t == 0) {
         const int dir = c->direction;
         if (dir == 1) { c->scanned_push += s[3]; c->push_levels += 1; }
@@ -428,13 +774,20 @@ __global__ __launch_bounds__(256) void bfs_ctrl_kernel(BfsCtrl* c) {
         c->reached += s[0];
         c->edges_traversed += s[1];
         c->visited_in_deg += s[2];
+        c->rot += 1;
         bool done = (s[0] == 0) || (c->max_level >= 0 && c->level >= c->max_level);
         c->done = done ? 1 : 0;
         int nd = 1;
         if (c->force_dir == 1 || !c->has_at) nd = 1;
         else if (c->force_dir == 2) nd = 2;
         else {
-            const u64 m_u = c->nnz_at > c->visited_in_deg ? c->nnz_at - c->visited_in_deg : 0;
+            u64 m_u;
+            if (c->n_total) {  // fused path: in-degree not tracked, estimate from the unvisited share
+                const double un = (double)(c->n_total > c->reached ? c->n_total - c->reached : 0);
+                m_u = (u64)((double)c->nnz_at * un / (double)c->n_total);
+            } else {
+                m_u = c->nnz_at > c->visited_in_deg ? c->nnz_at - c->visited_in_deg : 0;
+            }
             nd = ((double)s[1] * (double)c->alpha > (double)m_u) ? 2 : 1;
         }
         c->direction = nd;
@@ -442,7 +795,7 @@ __global__ __launch_bounds__(256) void bfs_ctrl_kernel(BfsCtrl* c) {
 }
 
 __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u32 force_dir, float alpha,
-                                u64 nnz_at) {
+                                u64 nnz_at, u64 n_total) {
     // single thread: seed the source (arrays were memset by the host side of begin())
     BfsCtrl* c = a.ctrl;
     c->level = 0;
@@ -456,7 +809,9 @@ __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u
     c->force_dir = force_dir;
     c->alpha = alpha;
     c->nnz_at = nnz_at;
-    a.cur[src >> 6] = 1ull << (src & 63);
+    c->n_total = n_total;
+    c->rot = 0;
+    a.cur[src >> 6] = 1ull << (src & 63);  // fused path: a.cur == bm[0]
     u64 indeg = 0;
     if (src >= a.lo && src < a.hi) {
         a.visited[src >> 6] = 1ull << (src & 63);
@@ -508,11 +863,12 @@ struct fgpu_bfs_plan {
     u32 n = 0, slab = 0, lo = 0, hi = 0, nw = 0, slabw = 0;
     u64 *cur = nullptr, *nxt_local = nullptr, *nxt_global = nullptr, *visited = nullptr;
     bool external_bufs = false;
+    u64* bm_block = nullptr;  // single-rank fused path: [bm0 | bm1 | bm2 | visited] in one allocation
     i32* level = nullptr;
     u32* parent = nullptr;
     BfsCtrl* ctrl = nullptr;
     BfsCtrl* h_ctrl = nullptr;  // pinned
-    double alpha = 4.0, beta = 24.0;
+    double alpha = 32.0, beta = 24.0;
     int force_dir = 0;
     bool want_parent = false;
     bool profile = false;
@@ -521,7 +877,7 @@ struct fgpu_bfs_plan {
     u32 grid = 0;
 };
 
-static BfsArgs make_args(fgpu_bfs_plan* p) {
+static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
     BfsArgs a;
     a.A = view_of(p->A);
     if (p->At) a.At = view_of(p->At);
@@ -534,6 +890,15 @@ static BfsArgs make_args(fgpu_bfs_plan* p) {
     a.parent = p->want_parent ? p->parent : nullptr;
     a.ctrl = p->ctrl;
     a.nw = p->nw;
+    if (p->bm_block && fused) {
+        a.bm[0] = p->bm_block;
+        a.bm[1] = p->bm_block + p->nw;
+        a.bm[2] = p->bm_block + 2 * (size_t)p->nw;
+        a.visited = p->bm_block + 3 * (size_t)p->nw;
+        a.cur = a.bm[0];
+    } else {
+        a.bm[0] = a.bm[1] = a.bm[2] = nullptr;
+    }
     return a;
 }
 
@@ -543,6 +908,7 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     if (!p) return FGPU_OK;
     fgpu_ctx* c = p->ctx;
     c->dev_free(p->cur);
+    c->dev_free(p->bm_block);
     if (!p->external_bufs) {
         if (p->nxt_local != p->nxt_global) c->dev_free(p->nxt_local);
         c->dev_free(p->nxt_global);
@@ -591,6 +957,7 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
         if ((i = ctx->dev_alloc((void**)&p->level, (size_t)p->nw * 64 * sizeof(i32))) != FGPU_OK) break;
         if ((i = ctx->dev_alloc((void**)&p->parent, (size_t)p->nw * 64 * sizeof(u32))) != FGPU_OK) break;
         if ((i = ctx->dev_alloc((void**)&p->ctrl, sizeof(BfsCtrl))) != FGPU_OK) break;
+        if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->bm_block, 4 * wb)) != FGPU_OK) break;
     } while (0);
     if (i == FGPU_OK) {
         hipError_t e = hipHostMalloc((void**)&p->h_ctrl, sizeof(BfsCtrl), hipHostMallocDefault);
@@ -603,7 +970,16 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
     }
     if (i != FGPU_OK) { fgpu_bfs_plan_free(p); return i; }
     memset(p->h_ctrl, 0, sizeof(BfsCtrl));
-    p->grid = (u32)ctx->cus * 8;
+    {
+        // one launch serves both directions (picked on device): size the grid for the larger of
+        // push items (1024-vertex blocks + hub chunks) and pull trips (4 waves x PULL_R words)
+        u64 push_items = ((u64)p->n + PUSH_VPB - 1) / PUSH_VPB + A->n_hub_chunks;
+        u64 pull_blocks = (((u64)p->n + 63) / 64 + PULL_R * 4 - 1) / (PULL_R * 4);
+        u64 g = push_items > pull_blocks ? push_items : pull_blocks;
+        if (g < (u64)ctx->cus * 4) g = (u64)ctx->cus * 4;
+        if (g > 65536) g = 65536;
+        p->grid = (u32)g;
+    }
     p->prof = {{"bfs_step_push"}, {"bfs_step_pull"}, {"bfs_commit"}, {"bfs_ctrl"}};
     *out = p;
     return FGPU_OK;
@@ -661,7 +1037,34 @@ fgpu_info fgpu_bfs_part_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level)
     i32 ml = max_level < 0 ? -1 : (max_level > 0x7FFFFFFF ? 0x7FFFFFFF : (i32)max_level);
     BfsArgs a = make_args(p);
     hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(1), 0, ctx->stream, a, (u32)src, ml, p->At ? 1u : 0u,
-                       (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull);
+                       (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull, 0ull);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+
+// single-rank fused path ----------------------------------------------------------------
+static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) {
+    FGPU_REQUIRE(src < p->n, FGPU_OUT_OF_BOUNDS, "BFS source %llu >= %u vertices", (unsigned long long)src, p->n);
+    fgpu_ctx* ctx = p->ctx;
+    FGPU_HIP(hipMemsetAsync(p->bm_block, 0, 4 * (size_t)p->nw * sizeof(u64), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(p->level, 0xFF, (size_t)p->n * sizeof(i32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(p->ctrl, 0, sizeof(BfsCtrl), ctx->stream));
+    i32 ml = max_level < 0 ? -1 : (max_level > 0x7FFFFFFF ? 0x7FFFFFFF : (i32)max_level);
+    BfsArgs a = make_args(p, true);
+    hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(1), 0, ctx->stream, a, (u32)src, ml, p->At ? 1u : 0u,
+                       (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull, (u64)p->n);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+
+static fgpu_info fused_level(fgpu_bfs_plan* p) {
+    BfsArgs a = make_args(p, true);
+    if (p->want_parent)
+        hipLaunchKernelGGL(bfs_fused_kernel<true>, dim3(p->grid), dim3(256), 0, p->ctx->stream, a);
+    else
+        hipLaunchKernelGGL(bfs_fused_kernel<false>, dim3(p->grid), dim3(256), 0, p->ctx->stream, a);
+    FGPU_HIP(hipGetLastError());
+    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(64), 0, p->ctx->stream, p->ctrl);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
@@ -689,7 +1092,7 @@ fgpu_info fgpu_bfs_part_commit(fgpu_bfs_plan* p) {
     if (grid > p->grid * 2) grid = p->grid * 2;
     hipLaunchKernelGGL(bfs_commit_kernel, dim3(grid), dim3(256), 0, p->ctx->stream, a);
     FGPU_HIP(hipGetLastError());
-    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(256), 0, p->ctx->stream, p->ctrl);
+    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(64), 0, p->ctx->stream, p->ctrl);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
@@ -710,47 +1113,42 @@ fgpu_info fgpu_bfs_part_done(fgpu_bfs_plan* p, int32_t* done, int32_t* level) {
     return FGPU_OK;
 }
 
-// Profiled variant of one level: every kernel bracketed by events (slow; bench/roofline only).
+// Profiled variant of one fused level: every kernel bracketed by HIP events (bench/roofline only).
 static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     fgpu_ctx* ctx = p->ctx;
     FGPU_TRY(fetch_ctrl(p));
     if (p->h_ctrl->done) return FGPU_OK;
     const int dir = p->h_ctrl->direction;
     const u64 sp0 = p->h_ctrl->scanned_push, sl0 = p->h_ctrl->scanned_pull;
-    const u64 nf = p->h_ctrl->n_frontier;
+    const u64 nf = p->h_ctrl->n_frontier, reached0 = p->h_ctrl->reached;
     float ms = 0;
+    BfsArgs a = make_args(p, true);
     FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
-    FGPU_TRY(fgpu_bfs_part_step(p));
+    if (p->want_parent)
+        hipLaunchKernelGGL(bfs_fused_kernel<true>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(bfs_fused_kernel<false>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
     FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
     FGPU_HIP(hipEventSynchronize(p->ev1));
     FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     ProfSlot& s = p->prof[dir == 1 ? 0 : 1];
     s.ms += ms; s.launches += 1;
-    // commit + ctrl
-    BfsArgs a = make_args(p);
-    u32 grid = cdiv(p->nw, 4);
-    if (grid > p->grid * 2) grid = p->grid * 2;
     FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
-    hipLaunchKernelGGL(bfs_commit_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
-    FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
-    FGPU_HIP(hipEventSynchronize(p->ev1));
-    FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
-    p->prof[2].ms += ms; p->prof[2].launches += 1;
-    FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
-    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(256), 0, ctx->stream, p->ctrl);
+    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(64), 0, ctx->stream, p->ctrl);
     FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
     FGPU_HIP(hipEventSynchronize(p->ev1));
     FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     p->prof[3].ms += ms; p->prof[3].launches += 1;
     FGPU_TRY(fetch_ctrl(p));
-    // algorithmic bytes of the step: colidx scanned + rowptr pairs + bitmaps + output
+    // algorithmic bytes of the level (bitmap form): colidx actually examined,
+    // rowptr pairs of the rows touched, the bitmaps streamed, level (+ out-degree) of new vertices
     const u64 scanned = dir == 1 ? (p->h_ctrl->scanned_push - sp0) : (p->h_ctrl->scanned_pull - sl0);
     const u64 newf = p->h_ctrl->n_frontier;
+    const u64 unvisited = p->n > reached0 ? p->n - reached0 : 0;
     u64 bytes;
-    if (dir == 1) bytes = 4 * scanned + 8 * nf + (u64)p->nw * 8 /*frontier bitmap*/ + newf / 8 + 1;
-    else bytes = 4 * scanned + 4ull * (p->hi - p->lo) /*rowptr*/ + (u64)p->slabw * 8 * 2 /*visited + out words*/;
+    if (dir == 1) bytes = 4 * scanned + 8 * nf + (u64)p->nw * 8 * 2 + 12 * newf;
+    else bytes = 4 * scanned + 8 * unvisited + (u64)p->nw * 8 * 2 + 12 * newf;
     s.alg_bytes += bytes;
-    p->prof[2].alg_bytes += (u64)p->nw * 8 * 3 + 4 * newf + 8 * newf;
     return FGPU_OK;
 }
 
@@ -759,7 +1157,7 @@ fgpu_info fgpu_bfs_run(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, int wa
     FGPU_REQUIRE(p->nranks == 1, FGPU_INVALID,
                  "fgpu_bfs_run drives single-rank plans; multi-rank plans are stepped by the host loop");
     p->want_parent = want_parent != 0;
-    FGPU_TRY(fgpu_bfs_part_begin(p, src, max_level));
+    FGPU_TRY(fused_begin(p, src, max_level));
     if (p->profile) {
         for (;;) {
             FGPU_TRY(profiled_level(p));
@@ -770,10 +1168,7 @@ fgpu_info fgpu_bfs_run(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, int wa
     // enqueue levels blind in small batches; the kernels no-op once ctrl->done is raised
     int batch = 6;
     for (;;) {
-        for (int k = 0; k < batch; ++k) {
-            FGPU_TRY(fgpu_bfs_part_step(p));
-            FGPU_TRY(fgpu_bfs_part_commit(p));
-        }
+        for (int k = 0; k < batch; ++k) FGPU_TRY(fused_level(p));
         FGPU_TRY(fetch_ctrl(p));
         if (p->h_ctrl->done) break;
         batch = 3;
