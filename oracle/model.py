@@ -1,0 +1,444 @@
+"""Pure-Python restatement of the reference's Delta-matrix layer and traversal operators.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): small cases, obvious code, one reference
+citation per method (file:line relative to /root/reference).
+
+    VersionedMatrix   graph/src/graph/graphblas/versioned_matrix.rs  ("Delta_Matrix")
+    Tensor (read)     graph/src/graph/graphblas/tensor.rs:154-319, 841-943
+    Graph             graph/src/graph/graph.rs (traversal-facing parts only)
+    expand_batch      graph/src/runtime/ops/cond_traverse.rs:452-751
+    expand_into_row   graph/src/runtime/ops/expand_into.rs:121-258
+    algo_bfs          graph/src/runtime/functions/algo_procedures.rs:1021-1160
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import CSR, bfs as _bfs, build_csr, delta_lmxm, empty
+
+# ---- fold policy (versioned_matrix.rs:140-188) -------------------------------------------------
+WRITE_FOLD_K = 20_500_000
+READ_FOLD_K = 82_000
+MIN_FOLD_DELTA = 256
+U64_MAX = (1 << 64) - 1
+
+
+def _sat_mul(a, b):
+    return min(a * b, U64_MAX)
+
+
+def fold_balance(delta_nvals, tx_added, base_nvals, k):
+    """versioned_matrix.rs:175-188"""
+    return (tx_added > 0 and delta_nvals >= MIN_FOLD_DELTA
+            and (_sat_mul(delta_nvals, 2) >= base_nvals or _sat_mul(delta_nvals, delta_nvals) >= _sat_mul(k, tx_added)))
+
+
+def should_fold(delta_nvals, tx_added, base_nvals):       # versioned_matrix.rs:152-158 (dup / write path)
+    return fold_balance(delta_nvals, tx_added, base_nvals, WRITE_FOLD_K)
+
+
+def should_fold_read(delta_nvals, tx_added, base_nvals):  # versioned_matrix.rs:164-170 (wait / read path)
+    return fold_balance(delta_nvals, tx_added, base_nvals, READ_FOLD_K)
+
+
+def delta_dominates_base(delta_nvals, base_nvals):        # versioned_matrix.rs:195-200
+    return delta_nvals >= MIN_FOLD_DELTA and _sat_mul(delta_nvals, 2) >= base_nvals
+
+
+class Delta:
+    """One delta layer + the fold bookkeeping (versioned_matrix.rs:214-478)."""
+
+    def __init__(self, entries=None):
+        self.layer = dict(entries or {})   # (i, j) -> value
+        self.count = len(self.layer)       # approximate nvals, maintained without materializing
+        self.tx_nvals = 0
+        self.fold = False
+        self.pending = False               # Matrix::has_pending of the layer
+
+    def new_version(self, fold):           # :337-349
+        d = Delta(self.layer)
+        d.count = self.count
+        d.tx_nvals = self.count
+        d.fold = fold
+        d.pending = self.pending
+        return d
+
+    def is_synced(self):
+        return not self.pending
+
+    def resync(self):                      # :355-358
+        self.pending = False
+        self.count = len(self.layer)
+
+    def latch(self, decision):             # :360-367
+        if decision:
+            self.fold = True
+
+    def fold_decision(self, policy, base):  # :369-377
+        return self.fold or policy(self.count, max(self.count - self.tx_nvals, 0), base)
+
+    def take_fold(self):                   # :383-385
+        f, self.fold = self.fold, False
+        return f and len(self.layer) > 0
+
+    def clear(self):                       # :387-398
+        self.layer = {}
+        self.count = 0
+        self.tx_nvals = 0
+        self.fold = False
+        self.pending = False
+
+    def insert(self, i, j, value=True):    # :429-437 (count moves whether or not the key existed)
+        self.layer[(i, j)] = value
+        self.count += 1
+        self.pending = True
+
+    def erase(self, i, j):                 # :414-422
+        self.layer.pop((i, j), None)
+        self.count = max(self.count - 1, 0)
+        self.pending = True
+
+
+class VersionedMatrix:
+    """VersionedMatrix<bool>: base m + pending adds dp + tombstones dm (versioned_matrix.rs:480-1079).
+    Invariants: dp ∩ m = ∅, dm ⊆ m, dp ∩ dm = ∅."""
+
+    def __init__(self, nrows, ncols, m=None):
+        self.nrows, self.ncols = nrows, ncols
+        self.m = set(m or ())
+        self.dp = Delta()
+        self.dm = Delta()
+        self.needs_flush = False
+
+    @classmethod
+    def from_matrix(cls, nrows, ncols, entries):    # :877-890
+        return cls(nrows, ncols, entries)
+
+    def wait(self):                                 # :545-556
+        if self.dp.is_synced() and self.dm.is_synced():
+            return
+        self.dp.resync()
+        self.dm.resync()
+        base = len(self.m)
+        self.dp.latch(self.dp.fold_decision(should_fold_read, base))
+        self.dm.latch(self.dm.fold_decision(should_fold_read, base))
+
+    def wait_all(self):                             # :562-566
+        self.dp.pending = False
+        self.dm.pending = False
+
+    def nvals(self):                                # :629-632
+        self.wait()
+        return len(self.m) + len(self.dp.layer) - len(self.dm.layer)
+
+    def extract(self):                              # :609-620  pattern(m) \ dm U pattern(dp)
+        self.wait()
+        return (self.m - set(self.dm.layer)) | set(self.dp.layer)
+
+    def get(self, i, j):                            # :819-835
+        self.wait()
+        if (i, j) in self.m:
+            return None if (i, j) in self.dm.layer else True
+        return self.dp.layer.get((i, j))
+
+    def iter(self, min_row=0, max_row=U64_MAX):     # :647-654 + Iter :1116-1253 (3-way sorted merge)
+        self.wait()
+        return sorted(e for e in self.extract() if min_row <= e[0] <= max_row)
+
+    def flush(self):                                # :892-938
+        if not self.needs_flush:
+            return
+        self.wait_all()
+        fold_dp = self.dp.take_fold()
+        fold_dm = self.dm.take_fold()
+        if fold_dp and fold_dm:
+            self.m = (self.m | set(self.dp.layer)) - set(self.dm.layer)   # eWiseAdd<!dm>(m, dp), :905-911
+        elif fold_dp:
+            self.m = self.m | set(self.dp.layer)
+        elif fold_dm:
+            self.m = self.m - set(self.dm.layer)                          # select(!dm, m)
+        if fold_dp:
+            self.dp.clear()
+        if fold_dm:
+            self.dm.clear()
+        self.needs_flush = False
+
+    def set(self, i, j, value=True):                # :844-857
+        self.flush()
+        if (i, j) in self.m:
+            self.dm.erase(i, j)
+        else:
+            self.dp.insert(i, j)
+
+    def remove(self, i, j):                         # :780-791
+        self.flush()
+        if (i, j) in self.m:
+            self.dm.insert(i, j)
+        else:
+            self.dp.erase(i, j)
+
+    def remove_mask(self, mask):                    # :799-816   dm U= mask ∩ m ; dp \= mask
+        self.flush()
+        mask = set(mask)
+        for e in mask & self.m:
+            self.dm.layer[e] = True
+        self.dm.resync()                            # tombstone_masked resyncs (:439-447)
+        for e in mask:
+            self.dp.layer.pop(e, None)
+        self.dp.resync()                            # remove_all resyncs (:451-458)
+
+    def set_all(self, entries, new=False):          # :1006-1035
+        self.flush()
+        self.dm.pending = False                     # dm.wait()
+        if len(self.dm.layer) == 0:
+            for (i, j) in entries:
+                if not new and (i, j) in self.m:
+                    continue
+                self.dp.insert(i, j)
+        else:
+            for (i, j) in entries:
+                self.set(i, j, True)
+
+    def dup(self):                                  # :1038-1051
+        base = len(self.m)
+        fold_dp = self.dp.fold_decision(should_fold, base)
+        fold_dm = self.dm.fold_decision(should_fold, base)
+        v = VersionedMatrix(self.nrows, self.ncols, self.m)
+        v.dp = self.dp.new_version(fold_dp)
+        v.dm = self.dm.new_version(fold_dm)
+        v.needs_flush = fold_dp or fold_dm
+        return v
+
+    def fold_oversized(self):                       # :953-965
+        base = len(self.m)
+        odp = delta_dominates_base(self.dp.count, base)
+        odm = delta_dominates_base(self.dm.count, base)
+        if odp or odm:
+            self.dp.latch(odp)
+            self.dm.latch(odm)
+            self.needs_flush = True
+            self.flush()
+
+    # layers as CSR for the products
+    def layers(self):
+        self.wait()
+        return (_csr(self.nrows, self.ncols, self.m), _csr(self.nrows, self.ncols, self.dp.layer),
+                _csr(self.nrows, self.ncols, self.dm.layer))
+
+
+def _csr(nrows, ncols, pairs) -> CSR:
+    pairs = list(pairs)
+    if not pairs:
+        return empty(nrows, ncols)
+    a = np.asarray(pairs, dtype=np.uint64)
+    return build_csr(nrows, ncols, a[:, 0], a[:, 1])
+
+
+MULTI_EDGE = U64_MAX  # tensor.rs:207
+
+
+class Tensor:
+    """Read side of a per-relationship-type Tensor (tensor.rs:184-319, 841-943): forward u64 layers
+    whose value is the inline edge id or MULTI_EDGE, multi-edge ids in `me`, bool transpose `mt`."""
+
+    def __init__(self, nrows, ncols, m=None, dp=None, dm=None, me=None):
+        self.nrows, self.ncols = nrows, ncols
+        self.m = dict(m or {})       # (s, d) -> id | MULTI_EDGE
+        self.dp = dict(dp or {})
+        self.dm = set(dm or ())
+        self.me = {k: sorted(v) for k, v in (me or {}).items()}  # (s, d) -> ascending edge ids
+
+    def eff_get(self, s, d):         # tensor.rs:286-299
+        if (s, d) in self.dp:
+            return self.dp[(s, d)]
+        if (s, d) in self.dm:
+            return None
+        return self.m.get((s, d))
+
+    def get(self, s, d):             # tensor.rs:307-319 -> ascending edge ids
+        v = self.eff_get(s, d)
+        if v is None:
+            return []
+        if v == MULTI_EDGE:
+            return list(self.me.get((s, d), []))
+        return [v]
+
+    def structure(self):             # (pattern(m) \ dm) U pattern(dp); mt is its transpose (tensor.rs:886-888)
+        return (set(self.m) - self.dm) | set(self.dp)
+
+    def fwd_layers(self):            # fwd_m / fwd_dp / fwd_dm (tensor.rs:841-856) as patterns
+        return (_csr(self.nrows, self.ncols, self.m), _csr(self.nrows, self.ncols, self.dp),
+                _csr(self.nrows, self.ncols, self.dm))
+
+
+class Graph:
+    """The traversal-facing slice of graph.rs: adjacency, node-label matrix, per-type tensors."""
+
+    def __init__(self, node_cap):
+        self.n = node_cap
+        self.adjacency = VersionedMatrix(node_cap, node_cap)    # graph.rs:2251
+        self.node_labels = set()                                # (node, label_id)   graph.rs:1057-1066
+        self.tensors: list[Tensor] = []                         # relationship_matrices  graph.rs:2256
+        self.label_ids: dict[str, int] = {}
+        self.type_ids: dict[str, int] = {}
+        self.deleted_nodes: set[int] = set()
+
+    def add_label(self, name):
+        return self.label_ids.setdefault(name, len(self.label_ids))
+
+    def add_type(self, name):
+        if name not in self.type_ids:
+            self.type_ids[name] = len(self.tensors)
+            self.tensors.append(Tensor(self.n, self.n))
+        return self.type_ids[name]
+
+    def node_has_label_id(self, node, lid):     # graph.rs:1057-1066
+        return (node, lid) in self.node_labels
+
+    def resolve_label_ids(self, labels):        # graph.rs:2554-2559: unknown label -> None (no rows)
+        out = []
+        for l in labels:
+            if l not in self.label_ids:
+                return None
+            out.append(self.label_ids[l])
+        return out
+
+    def traversal_layers(self, types):
+        """Matrix choice of expand_batch (cond_traverse.rs:478-505): [] -> adjacency; one type -> that
+        Tensor's forward layers; several -> materialized union with clean deltas
+        (build_relationship_matrix_unrestricted, graph.rs:2520-2549).  Unknown type -> None."""
+        if not types:
+            return self.adjacency.layers()
+        ids = []
+        for t in types:
+            if t not in self.type_ids:
+                return None
+            ids.append(self.type_ids[t])
+        if len(ids) == 1:
+            return self.tensors[ids[0]].fwd_layers()
+        u = set()
+        for i in ids:
+            u |= self.tensors[i].structure()
+        return _csr(self.n, self.n, u), empty(self.n, self.n), empty(self.n, self.n)
+
+    def build_adjacency_matrix(self, types) -> CSR:   # graph.rs:3870-3894
+        if not types:
+            return _csr(self.n, self.n, self.adjacency.extract())
+        u = set()
+        for t in types:
+            if t in self.type_ids:
+                u |= self.tensors[self.type_ids[t]].structure()
+        return _csr(self.n, self.n, u)
+
+    def get_src_dest_relationships(self, s, d, types):   # graph.rs:1797-1837 (ids in type order)
+        ids = []
+        tids = [self.type_ids[t] for t in types if t in self.type_ids] if types else range(len(self.tensors))
+        for t in tids:
+            ids.extend(self.tensors[t].get(s, d))
+        return ids
+
+
+def expand_batch(g: Graph, src_values, types, src_labels=(), dst_labels=(), chain=(), optional=False,
+                 to_bound=None, bind_relationship=False):
+    """CondTraverseOp::expand_batch (cond_traverse.rs:452-751), SURVEY Appendix A.2.
+
+    src_values[i]: node id (int) or None (bound to a non-node, e.g. NULL).  chain: sequence of
+    (types, dst_labels) for the fused hops.  Returns (rows, null_rows): rows = list of
+    (active_row_index, dest[, edge_id]) in emission order; null_rows = unmatched active rows that an
+    optional traverse null-pads (appended after the matches, :737-747).  Returns None when the
+    batched path bails to the per-row fallback (non-node source on a non-optional traverse)."""
+    k = len(src_values)
+    hops = [(types, dst_labels)] + [tuple(h) for h in chain]
+    layers = []
+    for ht, _ in hops:
+        l = g.traversal_layers(list(ht))
+        if l is None:                                # unknown type: no_match (:485-490)
+            return ([], list(range(k)) if optional else [])
+        layers.append(l)
+    last_dst = g.resolve_label_ids(list(hops[-1][1]))
+    src_lids = g.resolve_label_ids(list(src_labels))
+    if last_dst is None or src_lids is None:
+        return ([], list(range(k)) if optional else [])
+    rows, cols = [], []
+    for i, v in enumerate(src_values):
+        if v is None:                                # bound to a non-Node (:566-575)
+            if optional:
+                continue
+            return None
+        if not all(g.node_has_label_id(v, l) for l in src_lids):   # :580-586
+            continue
+        rows.append(i)
+        cols.append(v)
+    if not rows:
+        return ([], list(range(k)) if optional else [])
+    f = build_csr(k, g.n, rows, cols)                # :600-601
+    for (m, dp, dm) in layers:                       # :602-605
+        f, _ = delta_lmxm(f, m, dp, dm)
+    out = []
+    matched = [False] * k
+    fr, fc = f.pairs()
+    for i, d in zip(fr.tolist(), fc.tolist()):       # ascending (row, col)  (:644)
+        if not all(g.node_has_label_id(d, l) for l in last_dst):   # :647-651
+            continue
+        if to_bound is not None and to_bound[i] is not None and to_bound[i] != d:   # :657-661
+            continue
+        if bind_relationship and len(hops) == 1:     # :663-695 representative edge, first type with an id
+            ids = g.get_src_dest_relationships(src_values[i], d, list(types))
+            if not ids:
+                continue
+            out.append((i, d, ids[0]))
+        else:
+            out.append((i, d))
+        matched[i] = True
+    nulls = [i for i in range(k) if not matched[i]] if optional else []
+    return out, nulls
+
+
+def expand_into_row(g: Graph, src, dst, types, bidirectional=False, emit_relationship=True, used_edges=()):
+    """ExpandIntoOp::expand_row (expand_into.rs:121-258), SURVEY Appendix A.5: edge ids connecting the
+    two bound endpoints, scanning the type tensors in order, ids ascending per type; without
+    emit_relationship only the first surviving id per (src, dst) pair is kept."""
+    pairs = [(src, dst)]
+    if bidirectional and src != dst:
+        pairs.append((dst, src))
+    out = []
+    tids = [g.type_ids[t] for t in types if t in g.type_ids] if types else list(range(len(g.tensors)))
+    for (s, d) in pairs:
+        got = []
+        for t in tids:
+            for e in g.tensors[t].get(s, d):
+                if e in used_edges:
+                    continue
+                got.append((s, d, e))
+        if not emit_relationship:
+            got = got[:1]
+        out.extend(got)
+    return out
+
+
+def algo_bfs(g: Graph, source, max_depth=-1, rel_type=None, want_edges=False):
+    """algo.BFS (algo_procedures.rs:1021-1160), SURVEY Appendix A.6.  Returns None for "no row",
+    else (nodes, edges): nodes ascending by id, excluding the source and deleted nodes."""
+    if source is None or g.n == 0:
+        return None
+    if source in g.deleted_nodes:
+        raise ValueError("Source node not found in graph")
+    types = [rel_type] if rel_type is not None else []
+    adj = g.build_adjacency_matrix(types)
+    level, parent, _ = _bfs(adj, source, -1 if max_depth < 0 else max_depth, want_parent=True)
+    nodes, edges = [], []
+    for v in range(g.n):
+        if level[v] < 0 or v == source or v in g.deleted_nodes:
+            continue
+        if want_edges:
+            p = int(parent[v])
+            if p in g.deleted_nodes:
+                continue
+            nodes.append(v)
+            ids = g.get_src_dest_relationships(p, v, types)
+            if ids:
+                edges.append(ids[0])
+        else:
+            nodes.append(v)
+    if not nodes:
+        return None
+    return nodes, edges

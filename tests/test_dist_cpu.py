@@ -1,0 +1,125 @@
+"""CPU, world_size 2, gloo: the multi-GPU BFS control flow (falkordb_amd.dist.run_levels: column-slab
+partition, one frontier all-gather per level, device-side termination) driven with an oracle-backed
+stand-in for the HIP step kernels.  The HIP backend itself is covered on the GPU by
+tests/test_gpu_dist.py (two slab plans on one device)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+import oracle
+from falkordb_amd import dist as fdist
+
+U64 = np.uint64
+
+
+class OracleSlabBackend:
+    """Same contract as dist.HipSlabBackend, numpy inside: rank owns destinations [lo, hi)."""
+
+    def __init__(self, a: oracle.CSR, rank, nranks):
+        self.n = a.nrows
+        self.rank, self.nranks = rank, nranks
+        self.lo, self.hi, self.slab = fdist.slab_range(self.n, rank, nranks)
+        rows, cols = a.pairs()
+        keep = (cols >= self.lo) & (cols < self.hi)
+        self.a_slab = oracle.build_csr(self.n, self.n, rows[keep], cols[keep])   # A[:, lo:hi)
+        self.words_per_rank = self.slab // 64
+        self.local = torch.zeros(self.words_per_rank, dtype=torch.int64)
+        self.glob = torch.zeros(self.words_per_rank * nranks, dtype=torch.int64)
+        self.level = np.full(self.n, -1, dtype=np.int32)
+
+    def begin(self, src, max_level=-1):
+        npad = self.words_per_rank * self.nranks * 64
+        self.cur = np.zeros(npad // 64, dtype=U64)
+        self.cur[src >> 6] = U64(1) << U64(src & 63)
+        self.visited = self.cur.copy()
+        self.level[:] = -1
+        if self.lo <= src < self.hi:
+            self.level[src] = 0
+        self.lvl, self.max_level, self.is_done = 0, max_level, (max_level == 0)
+
+    def step(self):
+        if self.is_done:
+            return
+        nw = (self.n + 63) // 64
+        w = oracle.vxm(self.a_slab, self.cur[:nw], self.visited[:nw])     # q<!visited> = q x A[:, slab]
+        full = np.zeros(len(self.cur), dtype=U64)
+        full[:nw] = w
+        lo_w = self.lo // 64
+        self.local.copy_(torch.from_numpy(full[lo_w:lo_w + self.words_per_rank].view(np.int64).copy()))
+
+    def commit(self):
+        if self.is_done:
+            return
+        g = self.glob.numpy().view(U64).copy()
+        new_ids = oracle.ids_from_bits(g, self.n)
+        self.cur = g
+        self.visited = self.visited | g
+        self.lvl += 1
+        own = new_ids[(new_ids >= self.lo) & (new_ids < self.hi)].astype(np.int64)
+        self.level[own] = self.lvl
+        self.local.zero_()
+        self.is_done = (len(new_ids) == 0) or (self.max_level >= 0 and self.lvl >= self.max_level)
+
+    def done(self):
+        return self.is_done, self.lvl
+
+
+def _worker(rank, world, port, scale, srcs, max_level, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a = oracle.rmat_csr(scale)
+        be = OracleSlabBackend(a, rank, world)
+        out = []
+        for src in srcs:
+            nlev = fdist.run_levels(be, lambda: td.all_gather_into_tensor(be.glob, be.local), src, max_level,
+                                    first_batch=2, batch=1)
+            lv = torch.from_numpy(be.level.copy())
+            td.all_reduce(lv, op=td.ReduceOp.MAX)      # owners hold the levels, everyone else -1
+            out.append((nlev, lv.numpy()))
+        if rank == 0:
+            q.put(out)
+    finally:
+        td.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("max_level", [-1, 2])
+def test_two_rank_slab_bfs_matches_single_process_oracle(max_level):
+    scale = 10
+    a = oracle.rmat_csr(scale)
+    srcs = [int(np.argmax(np.diff(a.rowptr))), 3]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, scale, srcs, max_level, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for src, (nlev, level) in zip(srcs, out):
+        ref, _, _ = oracle.bfs(a, src, max_level)
+        np.testing.assert_array_equal(level, ref)
+
+
+def test_slab_range_matches_plan_rounding():
+    # slab = ceil(n / nranks) rounded up to 4096 (bfs.hip fgpu_bfs_plan_create)
+    assert fdist.slab_range(1 << 22, 0, 1) == (0, 1 << 22, 1 << 22)
+    assert fdist.slab_range(1 << 22, 3, 8) == (3 * (1 << 19), 4 * (1 << 19), 1 << 19)
+    lo, hi, slab = fdist.slab_range(1000, 1, 2)
+    assert slab == 4096 and (lo, hi) == (4096, 8192)

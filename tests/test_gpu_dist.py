@@ -1,0 +1,85 @@
+"""GPU: the multi-rank (column-slab) BFS kernels, exercised on ONE device by running `nranks` slab
+plans side by side and doing the frontier all-gather by hand (device copies into each plan's
+gather buffer).  The control flow is falkordb_amd.dist.run_levels — the same loop bench.py runs
+over RCCL — so this pins the partitioned step / commit kernels against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from falkordb_amd import dist as fdist
+from falkordb_amd import engine
+
+pytestmark = pytest.mark.gpu
+
+
+class Gang:
+    """`nranks` HipSlabBackends on one GPU stepping in lock-step (a stand-in for one rank per GPU)."""
+
+    def __init__(self, ctx, A, nranks, dev):
+        self.backs = []
+        n = A.nrows
+        for r in range(nranks):
+            lo, hi, _ = fdist.slab_range(n, r, nranks)
+            a_slab = A.col_slab(lo, min(hi, n))
+            self.backs.append(fdist.HipSlabBackend(ctx, a_slab, a_slab.transpose(), r, nranks, dev))
+        self.nranks = nranks
+
+    def begin(self, src, max_level=-1):
+        for b in self.backs:
+            b.begin(src, max_level)
+
+    def step(self):
+        for b in self.backs:
+            b.step()
+
+    def gather(self):
+        wpr = self.backs[0].words_per_rank
+        for dst in self.backs:
+            for r, src in enumerate(self.backs):
+                dst.glob[r * wpr:(r + 1) * wpr].copy_(src.local)
+
+    def commit(self):
+        for b in self.backs:
+            b.commit()
+
+    def done(self):
+        res = [b.done() for b in self.backs]
+        assert len(set(res)) == 1, f"ranks disagree on termination: {res}"
+        return res[0]
+
+    def levels(self, n):
+        out = np.full(n, -1, dtype=np.int32)
+        for b in self.backs:
+            lv, _ = b.plan.fetch()
+            own = lv >= 0
+            out[own] = lv[own]
+        return out
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 4])
+@pytest.mark.parametrize("force", [0, 1, 2])
+def test_slab_partitioned_bfs_matches_oracle(ctx, nranks, force):
+    scale = 14
+    a = oracle.rmat_csr(scale)
+    A = ctx.mat_rmat(scale)
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        ctx.set_stream(s.cuda_stream)
+        try:
+            gang = Gang(ctx, A, nranks, dev)
+            for b in gang.backs:
+                b.plan.tune(force_direction=force)
+            for src in [int(np.argmax(np.diff(a.rowptr))), 5]:
+                for max_level in (-1, 2):
+                    fdist.run_levels(gang, gang.gather, src, max_level)
+                    ref, _, _ = oracle.bfs(a, src, max_level)
+                    np.testing.assert_array_equal(gang.levels(a.nrows), ref)
+                    if max_level < 0:
+                        # slab-local out-degree sums add up to the global traversed-edge count
+                        edges = sum(b.plan.stats()["edges_traversed"] for b in gang.backs)
+                        assert edges == int(np.diff(a.rowptr)[ref >= 0].sum())
+        finally:
+            torch.cuda.synchronize()
+            ctx.set_stream(None)
