@@ -34,6 +34,8 @@ class Gang:
             b.step()
 
     def gather(self):
+        if self.nranks == 1:
+            return  # single-rank plans step in place: local IS the global buffer
         wpr = self.backs[0].words_per_rank
         for dst in self.backs:
             for r, src in enumerate(self.backs):
