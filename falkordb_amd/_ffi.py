@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfgpu.so")
+LIB_PATH = os.environ.get("FGPU_LIB") or os.path.join(_HERE, "lib", "libfgpu.so")
 
 FGPU_OK = 0
 FGPU_NO_VALUE = 1
@@ -37,6 +37,9 @@ SIGNATURES = {
     "fgpu_free": (None, [vp, vp]),
     "fgpu_set_stream": (C.c_int32, [vp, vp]),
     "fgpu_sync": (C.c_int32, [vp]),
+    "fgpu_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int64]),
+    "fgpu_mat_build_tiles": (C.c_int32, [vp, vp, C.c_int, C.c_int, C.c_int]),
+    "fgpu_mat_tiles_info": (C.c_int32, [vp, u64p]),
     "fgpu_device_info": (C.c_int32, [vp, C.c_char_p, i32p, i32p, i64p, i64p]),
     "fgpu_device_bytes": (C.c_int32, [vp, u64p, u64p]),
     "fgpu_mat_new": (C.c_int32, [vp, vpp, C.c_uint64, C.c_uint64]),

@@ -1276,7 +1276,8 @@ fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t
     FGPU_REQUIRE(ctx && w && f && A, FGPU_NULL_POINTER, "fgpu_vxm: NULL argument");
     FGPU_REQUIRE(A->nrows == A->ncols, FGPU_DIM_MISMATCH, "fgpu_vxm: square matrices only");
     FGPU_REQUIRE(!A->is_hyper() && (!At || !At->is_hyper()), FGPU_INVALID, "fgpu_vxm: non-hypersparse snapshots only");
-    FGPU_REQUIRE(direction >= 0 && direction <= 2 && (direction != 2 || At), FGPU_INVALID, "fgpu_vxm: bad direction");
+    FGPU_REQUIRE(direction >= 0 && direction <= 3 && (direction < 2 || At), FGPU_INVALID, "fgpu_vxm: bad direction");
+    if (direction == 3 && !At->tiles) FGPU_TRY(tiles_build(ctx, const_cast<fgpu_mat*>(At), 0, 0, 0));
     const u32 n = (u32)A->nrows;
     const u32 nw_user = (n + 63) / 64;
     const u32 nw = ((n + 4095) & ~4095u) / 64;
@@ -1295,7 +1296,9 @@ fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t
     vxm_args(a, A, At, n, dw.p, nw);
     const bool pull = (direction == 2);
     const u32 grid = ctx->cus * 8;
-    if (pull)
+    if (direction == 3)
+        FGPU_TRY(tiles_mxv(ctx, At->tiles, df.p, nw, mask ? dm.p : nullptr, dw.p, false));
+    else if (pull)
         hipLaunchKernelGGL(vxm_pull_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, a, (const u64*)df.p,
                            (const u64*)(mask ? dm.p : nullptr), dw.p);
     else
@@ -1311,7 +1314,9 @@ fgpu_info fgpu_bench_spmv(fgpu_ctx* ctx, const fgpu_mat* A, int which, int iters
                           uint64_t* alg_bytes) {
     FGPU_REQUIRE(ctx && A && avg_ms, FGPU_NULL_POINTER, "fgpu_bench_spmv: NULL argument");
     FGPU_REQUIRE(A->nrows == A->ncols && !A->is_hyper(), FGPU_INVALID, "fgpu_bench_spmv: square non-hyper matrix");
-    FGPU_REQUIRE(which == 0 || which == 1, FGPU_INVALID, "fgpu_bench_spmv: which must be 0 (pull) or 1 (push)");
+    FGPU_REQUIRE(which >= 0 && which <= 2, FGPU_INVALID,
+                 "fgpu_bench_spmv: which must be 0 (CSR pull), 1 (CSR push) or 2 (LDS-tiled pull)");
+    if (which == 2 && !A->tiles) FGPU_TRY(tiles_build(ctx, const_cast<fgpu_mat*>(A), 0, 0, 0));
     if (iters < 1) iters = 1;
     const u32 n = (u32)A->nrows;
     const u32 nw = ((n + 4095) & ~4095u) / 64;
@@ -1334,7 +1339,9 @@ fgpu_info fgpu_bench_spmv(fgpu_ctx* ctx, const fgpu_mat* A, int which, int iters
     FGPU_HIP(hipEventCreate(&e1));
     const u32 grid = ctx->cus * 8;
     auto launch = [&]() {
-        if (which == 0)
+        if (which == 2)
+            (void)tiles_mxv(ctx, A->tiles, df.p, nw, nullptr, dw.p, true);
+        else if (which == 0)
             hipLaunchKernelGGL(vxm_pull_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, a, (const u64*)df.p,
                                (const u64*)nullptr, dw.p);
         else

@@ -56,8 +56,17 @@ const char* get_error();
 // One per process+device.  Owns a HIP stream, a size-class device pool (hipMalloc
 // is ~100 us; traversal calls must not pay it per hop) and the host allocator
 // hooks the caller handed to fgpu_init.
+struct fgpu_options {  // fgpu_set_option
+    int tiled_u = 4;           // items in flight per wavefront of the tiled kernel
+    int tiled_nt = 0;          // nontemporal entry loads
+    int tiled_threads = 1024;  // its workgroup size
+    int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)
+    int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
+};
+
 struct fgpu_ctx {
     int device = 0;
+    fgpu_options opt;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     void* (*mal)(size_t) = nullptr;
@@ -121,6 +130,8 @@ struct DevBuf {
 // Immutable CSR on device.  `hrows == nullptr`: rowptr has nrows+1 entries.
 // Hypersparse (delta layers, me): hrows = sorted ids of the nvec non-empty rows and
 // rowptr has nvec+1 entries; row lookups binary-search hrows.
+struct fgpu_tiles;  // tiled.hip: LDS-staged frontier-tile edge layout (acceleration index)
+
 struct fgpu_mat {
     fgpu_ctx* ctx = nullptr;
     uint64_t nrows = 0, ncols = 0, nnz = 0;
@@ -133,7 +144,24 @@ struct fgpu_mat {
     uint32_t* hub_chunks = nullptr;  // triples (row, begin, end)
     uint32_t n_hub_chunks = 0;
     uint32_t max_deg = 0;
+    fgpu_tiles* tiles = nullptr;  // built on demand by fgpu_mat_build_tiles; owned by the matrix
     bool is_hyper() const { return hrows != nullptr; }
+};
+
+// Column-tiled edge layout of a matrix M for y = M (x) x over the boolean semiring with the x tile
+// staged in LDS (tiled.hip).  Tile c holds the entries whose column lies in
+// [c << tile_bits, (c+1) << tile_bits); inside a tile entries are grouped by 64 consecutive rows
+// (one output word) and cut into items of at most 64*vec*k entries.
+struct fgpu_tiles {
+    fgpu_ctx* ctx = nullptr;
+    uint32_t tile_bits = 0, ntiles = 0, ngroups = 0, nitems = 0;
+    uint32_t vec = 4, k = 1;         // entries per lane per load, loads per lane per item
+    uint64_t nentries = 0;           // padded
+    uint32_t* item_off = nullptr;    // nitems + 1
+    uint32_t* item_group = nullptr;  // nitems
+    uint32_t* entries = nullptr;     // packed: bits 0..25 column - tile base (bit tile_bits = pad), 26..31 row & 63
+    uint32_t* tile_item = nullptr;   // ntiles + 1 (device)
+    uint64_t* row_has = nullptr;     // ngroups words: bit set = row has at least one entry
 };
 
 namespace fgpu {
@@ -215,6 +243,12 @@ fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncol
 // read one u32 / u64 from device on the ctx stream (synchronises).
 fgpu_info read_u32(fgpu_ctx* ctx, const u32* dev, u32* host);
 fgpu_info read_u64(fgpu_ctx* ctx, const u64* dev, u64* host);
+
+void tiles_release(fgpu_tiles* t);
+// tiled.hip: build the LDS-tile layout of `m` (0 = automatic parameter) / run out = m (x) x & ~mask
+fgpu_info tiles_build(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k);
+fgpu_info tiles_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 x_words64, const u64* mask_dev,
+                    u64* out_dev, bool zero_out);
 
 constexpr u32 HUB_DEG = 4096;    // rows at least this long are expanded by the hub kernel
 constexpr u32 HUB_CHUNK = 4096;  // edges per hub work item

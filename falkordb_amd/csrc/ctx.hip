@@ -140,6 +140,7 @@ fgpu_info fgpu_init(fgpu_ctx** out, int device, void* (*mal)(size_t), void (*fre
     c->mal = mal;
     c->fre = fre;
     c->cus = prop.multiProcessorCount;
+    c->opt.lds_limit = (int)prop.sharedMemPerBlock;
     hipError_t se = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
@@ -183,6 +184,28 @@ fgpu_info fgpu_set_stream(fgpu_ctx* ctx, void* hip_stream) {
     // drain work queued on the previous stream so pooled blocks stay stream-ordered
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
+    FGPU_REQUIRE(ctx && name, FGPU_NULL_POINTER, "fgpu_set_option: NULL argument");
+    if (!strcmp(name, "tiled_u")) {
+        FGPU_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, FGPU_INVALID,
+                     "tiled_u must be 1, 2, 4 or 8");
+        ctx->opt.tiled_u = (int)value;
+    } else if (!strcmp(name, "tiled_nt")) {
+        ctx->opt.tiled_nt = value != 0;
+    } else if (!strcmp(name, "tiled_threads")) {
+        FGPU_REQUIRE(value == 256 || value == 512 || value == 1024, FGPU_INVALID,
+                     "tiled_threads must be 256, 512 or 1024");
+        ctx->opt.tiled_threads = (int)value;
+    } else if (!strcmp(name, "tiled_wgs")) {
+        FGPU_REQUIRE(value >= 0 && value <= 65536, FGPU_INVALID, "tiled_wgs out of range");
+        ctx->opt.tiled_wgs = (int)value;
+    } else {
+        set_error("fgpu_set_option: unknown option '%s'", name);
+        return FGPU_INVALID;
+    }
     return FGPU_OK;
 }
 

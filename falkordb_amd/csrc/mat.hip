@@ -27,6 +27,7 @@ static void mat_release(fgpu_mat* m) {
         c->dev_free(m->hrows);
         c->dev_free(m->hub_chunks);
     }
+    tiles_release(m->tiles);
     delete m;
 }
 

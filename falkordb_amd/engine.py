@@ -52,6 +52,9 @@ class Context:
     def set_stream(self, stream_ptr: int | None):
         check(self.lib.fgpu_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
+    def set_option(self, name: str, value: int):
+        check(self.lib.fgpu_set_option(self._h, name.encode(), int(value)))
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus, wave = C.c_int32(), C.c_int32()
@@ -206,6 +209,16 @@ class Mat:
         check(self.ctx.lib.fgpu_delta_lmxm(self.ctx._h, C.byref(h), self._h, m._h, dp._h if dp else None,
                                            dm._h if dm else None))
         return Mat(self.ctx, h)
+
+    def build_tiles(self, tile_bits=0, vec=0, k=0):
+        check(self.ctx.lib.fgpu_mat_build_tiles(self.ctx._h, self._h, tile_bits, vec, k))
+        return self.tiles_info()
+
+    def tiles_info(self):
+        s = np.zeros(8, dtype=U64)
+        check(self.ctx.lib.fgpu_mat_tiles_info(self._h, _p(s)))
+        keys = ["tile_bits", "tiles", "groups", "items", "entries", "vec", "k", "bytes"]
+        return dict(zip(keys, (int(x) for x in s)))
 
     def col_slab(self, lo, hi) -> "Mat":
         h = C.c_void_p()

@@ -63,6 +63,10 @@ void fgpu_free(fgpu_ctx* ctx, void* p);
  * NULL restores the ctx's own stream. */
 fgpu_info fgpu_set_stream(fgpu_ctx* ctx, void* hip_stream);
 fgpu_info fgpu_sync(fgpu_ctx* ctx);
+/* Engine tunables (the analogue of GrB_Global_set_INT32, matrix.rs:151-159): "tiled_u" (items in
+ * flight per wavefront of the LDS-tiled vxm: 1/2/4/8), "tiled_threads" (256/512/1024),
+ * "tiled_wgs" (grid of that kernel, 0 = fill the CUs), "tiled_nt" (nontemporal entry loads). */
+fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
 /* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */
 fgpu_info fgpu_device_info(fgpu_ctx* ctx, char* name, int32_t* cus, int32_t* wave,
                            int64_t* lds_bytes, int64_t* hbm_bytes);
@@ -140,6 +144,16 @@ fgpu_info fgpu_mat_intersect(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, c
 fgpu_info fgpu_mat_intersect_nvals(fgpu_ctx* ctx, const fgpu_mat* a, const fgpu_mat* b,
                                    uint64_t* out);
 
+/* Acceleration index for the dense-frontier vxm (tiled.hip): regroup the entries of `m` by column
+ * tile of 2^tile_bits ids so the kernel can stage the frontier tile in LDS and stream packed 4-byte
+ * entries from HBM.  tile_bits / vec / k == 0 pick defaults (2^20-id tiles = 128 KiB of LDS).
+ * Logically const: the matrix content is unchanged; the index is owned and freed by the matrix.
+ * No reference counterpart (GraphBLAS keeps its own internal formats, matrix.rs:405-426). */
+fgpu_info fgpu_mat_build_tiles(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k);
+/* info[0]=tile_bits [1]=tiles [2]=64-row groups [3]=items [4]=padded entries [5]=vec [6]=k
+ * [7]=device bytes of the index.  FGPU_NO_VALUE when the matrix has no tiles. */
+fgpu_info fgpu_mat_tiles_info(const fgpu_mat* m, uint64_t info[8]);
+
 /* ---- products (ANY_PAIR structural semiring) ------------------------------ */
 
 /* C = F x B, no mask: Matrix::lmxm -> GrB_mxm(GxB_ANY_PAIR_BOOL) (matrix.rs:930-947).
@@ -186,7 +200,8 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
  * ncols-/nrows-bit bitmaps (LSB-first 64-bit words, HOST pointers; copied in/out).
  * This is GrB_vxm (graphblas/mod.rs:11173) in the form LAGraph's BFS issues it.
  * mask may be NULL.  `At` (nullable) enables the pull direction; `direction`:
- * 0 = auto, 1 = push over A, 2 = pull over At (full pass, no early exit). */
+ * 0 = auto, 1 = push over A, 2 = pull over At's CSR (full pass, no early exit),
+ * 3 = pull over At's LDS-tile layout (built on first use, fgpu_mat_build_tiles). */
 fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t* mask,
                    const fgpu_mat* A, const fgpu_mat* At, int direction);
 
@@ -253,9 +268,9 @@ fgpu_info fgpu_mat_row_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, ui
 /* ---- measurement hooks (bench.py; not reference APIs) --------------------- */
 
 /* Time `iters` launches of one named kernel with HIP events on the ctx stream.
- * which: 0 = full-pass boolean pull SpMV over At (dense frontier, no mask, no early
- * exit — the "RMAT-22 boolean SpMV" roofline case), 1 = push over A with a dense
- * frontier.  Returns avg ms per launch and algorithmic bytes per launch
+ * which: 0 = full-pass boolean pull SpMV over the CSR of the matrix passed (dense frontier, no
+ * mask, no early exit), 1 = push over A with a dense frontier, 2 = the same full pass as 0 over
+ * the LDS-tile layout (the "RMAT-22 boolean SpMV" roofline case).  Returns avg ms per launch and algorithmic bytes per launch
  * (SURVEY.md §8d formulas). */
 fgpu_info fgpu_bench_spmv(fgpu_ctx* ctx, const fgpu_mat* A, int which, int iters,
                           double* avg_ms, uint64_t* alg_bytes);

@@ -52,10 +52,10 @@ class Gang:
 
     def levels(self, n):
         out = np.full(n, -1, dtype=np.int32)
-        for b in self.backs:
-            lv, _ = b.plan.fetch()
-            own = lv >= 0
-            out[own] = lv[own]
+        for r, b in enumerate(self.backs):
+            lv, _ = b.plan.fetch()  # only the rank's own slab [lo, hi) is filled in
+            lo, hi, _ = fdist.slab_range(n, r, self.nranks)
+            out[lo:min(hi, n)] = lv[lo:min(hi, n)]
         return out
 
 

@@ -1,0 +1,99 @@
+"""GPU: the LDS-tiled boolean vxm (tiled.hip) against the CPU oracle and against the CSR pull kernel.
+
+Small tile widths force many column tiles, padding, multi-item hub groups and partially filled
+last tiles on graphs the oracle finishes in seconds; the RMAT-22 case (BASELINE.json configs[1])
+is checked through the CSR kernel of the same library, itself pinned on the oracle here."""
+import numpy as np
+import pytest
+
+import oracle
+from falkordb_amd import engine
+
+pytestmark = pytest.mark.gpu
+
+
+def up(ctx, a):
+    return ctx.mat_from_csr(a.nrows, a.ncols, a.rowptr, a.colidx)
+
+
+@pytest.mark.parametrize("tile_bits,vec,k", [(0, 0, 0), (7, 1, 1), (9, 2, 2), (10, 4, 1), (12, 4, 2), (11, 1, 2),
+                                             (13, 2, 1), (8, 4, 2)])
+def test_tiled_vxm_matches_oracle(ctx, tile_bits, vec, k):
+    a = oracle.rmat_csr(13)
+    n = a.nrows
+    rng = np.random.default_rng(tile_bits * 100 + vec * 10 + k)
+    A = up(ctx, a)
+    At = A.transpose()
+    info = At.build_tiles(tile_bits, vec, k)
+    assert info["entries"] >= a.nnz and info["entries"] % info["vec"] == 0
+    try:
+        for u in (1, 2, 4, 8):
+            ctx.set_option("tiled_u", u)
+            ctx.set_option("tiled_nt", u == 2)
+            for nf in (1, 37, 500, n // 2, n):
+                f = oracle.bits_from_ids(n, rng.choice(n, nf, replace=False))
+                mask = oracle.bits_from_ids(n, rng.choice(n, n // 3, replace=False))
+                for mk in (None, mask):
+                    want = oracle.vxm(a, f, mk)
+                    for _ in range(3):  # repeated: a timing-dependent hazard once hid behind a single pass
+                        got = engine.vxm(ctx, f, mk, A, At, 3)
+                        np.testing.assert_array_equal(got, want)
+    finally:
+        ctx.set_option("tiled_u", 4)
+        ctx.set_option("tiled_nt", 0)
+
+
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+def test_tiled_vxm_workgroup_shapes(ctx, threads):
+    a = oracle.rmat_csr(12)
+    n = a.nrows
+    A = up(ctx, a)
+    At = A.transpose()
+    At.build_tiles(9, 2, 2)
+    ctx.set_option("tiled_threads", threads)
+    try:
+        for wgs in (0, 3, 17):
+            ctx.set_option("tiled_wgs", wgs)
+            f = oracle.bits_from_ids(n, np.arange(0, n, 3))
+            np.testing.assert_array_equal(engine.vxm(ctx, f, None, A, At, 3), oracle.vxm(a, f, None))
+    finally:
+        ctx.set_option("tiled_threads", 1024)
+        ctx.set_option("tiled_wgs", 0)
+
+
+def test_tiled_vxm_ragged_and_empty(ctx):
+    # n not a multiple of 64, empty rows, one hub row longer than any item, an all-empty matrix
+    n = 1000
+    rows = np.concatenate([np.full(900, 7), np.arange(0, 200, 2), [999]]).astype(np.uint64)
+    cols = np.concatenate([np.arange(900) + 50, np.arange(0, 200, 2) + 1, [0]]).astype(np.uint64)
+    a = oracle.build_csr(n, n, rows, cols)  # a[u, v]: edge u -> v
+    A = up(ctx, a)
+    At = A.transpose()
+    At.build_tiles(8, 4, 1)  # 900-entry hub row: four 256-entry items
+    rng = np.random.default_rng(5)
+    for nf in (1, 10, 400, n):
+        f = oracle.bits_from_ids(n, rng.choice(n, nf, replace=False))
+        np.testing.assert_array_equal(engine.vxm(ctx, f, None, A, At, 3), oracle.vxm(a, f, None))
+    e = ctx.mat_new(256, 256)  # empty (stored hypersparse): the index builds and is empty
+    info = e.build_tiles(7, 1, 1)
+    assert info["items"] == 0 and info["tiles"] == 2
+
+
+def test_tiled_full_pass_rmat22_matches_csr_pull(ctx):
+    """BASELINE.json configs[1] size: both layouts must produce the same next-frontier words, and a
+    dense frontier must reach exactly the vertices with an in-edge."""
+    A = ctx.mat_rmat(22)
+    At = A.transpose()
+    n = A.nrows
+    info = At.build_tiles()
+    assert info["tiles"] == 4 and info["tile_bits"] == 20
+    rng = np.random.default_rng(22)
+    f = oracle.bits_from_ids(n, rng.choice(n, n // 5, replace=False))
+    mask = oracle.bits_from_ids(n, rng.choice(n, n // 2, replace=False))
+    for mk in (None, mask):
+        np.testing.assert_array_equal(engine.vxm(ctx, f, mk, A, At, 3), engine.vxm(ctx, f, mk, A, At, 2))
+    full = oracle.bits_from_ids(n, np.arange(n))
+    got = engine.vxm(ctx, full, None, A, At, 3)
+    rp, _, _ = At.export_csr()
+    has_in = np.diff(rp.astype(np.int64)) > 0
+    np.testing.assert_array_equal(oracle.ids_from_bits(got, n), np.nonzero(has_in)[0])
