@@ -71,6 +71,8 @@ SIGNATURES = {
     "fgpu_bfs_plan_free": (C.c_int32, [vp]),
     "fgpu_bfs_plan_tune": (C.c_int32, [vp, C.c_double, C.c_double, C.c_int]),
     "fgpu_bfs_run": (C.c_int32, [vp, C.c_uint64, C.c_int64, C.c_int]),
+    "fgpu_bfs_run_async": (C.c_int32, [vp, C.c_uint64, C.c_int64, C.c_int, C.c_int]),
+    "fgpu_bfs_wait": (C.c_int32, [vp]),
     "fgpu_bfs_fetch": (C.c_int32, [vp, i32p, i64p]),
     "fgpu_bfs_stats": (C.c_int32, [vp, u64p]),
     "fgpu_bfs_part_buffers": (C.c_int32, [vp, vpp, vpp, u64p]),

@@ -28,6 +28,10 @@
 namespace fgpu {
 
 constexpr int STAT_SLOTS = 64;
+constexpr unsigned QSHARDS = 8;          // the frontier queue is appended in 8 independent segments
+constexpr unsigned QCAP = 1u << 16;      // capacity of a frontier queue (vertex ids), all segments
+constexpr unsigned QSEG = QCAP / QSHARDS;
+constexpr unsigned long long QGATE = 1ull << 17;  // a level appends only when it can discover at most this many
 
 struct BfsCtrl {
     i32 level;       // level of the frontier in `cur` (source = 0)
@@ -51,6 +55,15 @@ struct BfsCtrl {
     u64 slot_mf[STAT_SLOTS];
     u64 slot_indeg[STAT_SLOTS];
     u64 slot_scan[STAT_SLOTS];
+    // fused single-rank path: next-frontier queue, hub census and the end-of-level ticket
+    u32 hubs[2];       // hub vertices (out-degree >= HUB_DEG) in the current / next frontier
+    u32 use_queue;     // the current frontier is completely listed in queue[rot & 1]
+    u32 q_open;        // this level appends its discoveries to queue[(rot + 1) & 1]
+    u32 qmax;          // longest shard of the current queue
+    u32 qchunk;        // queue entries expanded per workgroup this level (power of two, 4..1024)
+    u32 tick_top;
+    u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
+    u32 tick[64];
 };
 
 struct BfsArgs {
@@ -68,6 +81,8 @@ struct BfsArgs {
     BfsCtrl* ctrl;
     u32 nw;           // u64 words in a global bitmap
     u64* bm[3];       // fused single-rank path: rotating frontier bitmaps
+    u32* queue[2];    // fused single-rank path: vertex-id lists of small frontiers (QCAP entries each)
+    u32* host_done;   // fused single-rank path: pinned host word, set to 0x80000000 | levels when the search ends
 };
 
 __device__ __forceinline__ bool test_bit(const u64* bm, u32 v) {
@@ -334,68 +349,148 @@ __device__ void pull_body(const BfsArgs& a, const u64* __restrict__ frontier, co
 // ---------------------------------------------------------------------------------
 struct LevelAcc { u64 count, mf, scanned; };
 
-template <bool PARENT>
-__device__ __forceinline__ void fused_visit(const BfsArgs& a, u32* __restrict__ vis32, u32* __restrict__ nxt32,
-                                            i32 newlevel, u32 u, u32 v, LevelAcc& acc) {
-    const u32 bit = 1u << (u & 31);
-    const u32 w = u >> 5;
-    if (vis32[w] & bit) return;  // possibly stale: worst case one redundant atomic
-    const u32 old = atomicOr(&vis32[w], bit);
-    if (old & bit) return;
-    a.level[u] = newlevel;
-    if (PARENT) a.parent[u] = v;
-    atomicOr(&nxt32[w], bit);
+// Per-wavefront view of the NEXT frontier's queue.  Small frontiers (the first and last levels of
+// every BFS) are walked from the queue instead of scanning the whole bitmap.  A level appends only
+// when the control step found it light (q_open: at most QGATE edges to examine), so the returning
+// atomics below never pile up on one word; a workgroup appends to segment blockIdx & 7.
+struct QueueCtx {
+    u32* q;     // this workgroup's segment of the next queue
+    u32* qlen;  // its length counter
+    u32* hubs;
+    bool open;  // level-uniform
+};
+
+// must be reached by all 64 lanes together
+__device__ __forceinline__ void queue_append(QueueCtx& qc, bool won, u32 v) {
+    if (!qc.open) return;
+    const u64 m = __ballot(won);
+    if (m == 0ull) return;
+    const u32 lane = lane_id();
+    const u32 cnt = (u32)__popcll(m);
+    const int leader = (int)__builtin_ctzll(m);
+    u32 base = 0;
+    if ((int)lane == leader) base = atomicAdd(qc.qlen, cnt);
+    base = __shfl(base, leader, 64);
+    if (won) {
+        const u32 idx = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+        if (idx < QSEG) qc.q[idx] = v;
+    }
+}
+
+__device__ __forceinline__ void note_discovery(const BfsArgs& a, QueueCtx& qc, u32 u, LevelAcc& acc) {
+    const u32 deg = a.A.rowptr[u + 1] - a.A.rowptr[u];
     acc.count += 1;
-    acc.mf += a.A.rowptr[u + 1] - a.A.rowptr[u];
+    acc.mf += deg;
+    if (deg >= HUB_DEG) {  // rare; returning form so the count has landed before the block's ticket
+        const u32 r = atomicAdd(qc.hubs, 1u);
+        asm volatile("" ::"v"(r));
+    }
 }
 
 template <bool PARENT>
-__device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, u64* __restrict__ visited,
-                           u64* __restrict__ nxt, i32 newlevel, LevelAcc& acc) {
+__device__ __forceinline__ bool fused_visit(const BfsArgs& a, u32* __restrict__ vis32, u32* __restrict__ nxt32,
+                                            i32 newlevel, u32 u, u32 v, QueueCtx& qc, LevelAcc& acc) {
+    const u32 bit = 1u << (u & 31);
+    const u32 w = u >> 5;
+    if (vis32[w] & bit) return false;  // possibly stale: worst case one redundant atomic
+    const u32 old = atomicOr(&vis32[w], bit);
+    if (old & bit) return false;
+    a.level[u] = newlevel;
+    if (PARENT) a.parent[u] = v;
+    atomicOr(&nxt32[w], bit);
+    note_discovery(a, qc, u, acc);
+    return true;
+}
+
+// Push level.  `qcur` != nullptr: the frontier is the list qcur[0 .. qn) (queue mode, work
+// proportional to the frontier); else it is the bitmap `frontier` (1024 consecutive vertices per
+// item).  Hub rows (>= HUB_DEG out-edges) come from the static chunk list in both modes, and only
+// when the level's hub census says the frontier holds one.
+template <bool PARENT>
+__device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, const u32* __restrict__ qcur,
+                           const u32* __restrict__ qcur_len, u32 qmax, u32 qchunk, bool hubs_present,
+                           u64* __restrict__ visited,
+                           u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc) {
     __shared__ u32 s_off[PUSH_VPB];
     __shared__ u32 s_start[PUSH_VPB];
+    __shared__ u32 s_vid[PUSH_VPB];
     __shared__ u64 s_fw[PUSH_VPB / 64];
     __shared__ u32 s_wave[4];
     u32* __restrict__ vis32 = (u32*)visited;
     u32* __restrict__ nxt32 = (u32*)nxt;
     const u32 t = threadIdx.x;
-    const u32 nblk = (a.n + PUSH_VPB - 1) / PUSH_VPB;
-    const u32 nitems = nblk + a.n_hubA;
+    const bool qmode = qcur != nullptr;
+    // queue mode: item = (chunk, segment); segments shorter than the longest one skip their tail chunks
+    // (a chunk holds `qchunk` entries: few when the frontier's rows are long, so that a handful of
+    // near-hub vertices does not land on one workgroup)
+    const u32 nblk = qmode ? QSHARDS * ((qmax + qchunk - 1) / qchunk) : (a.n + PUSH_VPB - 1) / PUSH_VPB;
+    const u32 nitems = nblk + (hubs_present ? a.n_hubA : 0u);
     for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
         if (item >= nblk) {
             const u32 h = item - nblk;
             const u32 row = a.hubA[3 * h], b = a.hubA[3 * h + 1], e = a.hubA[3 * h + 2];
             if (!test_bit(frontier, row)) continue;
-            for (u32 i = b + t; i < e; i += 256) fused_visit<PARENT>(a, vis32, nxt32, newlevel, a.A.colidx[i], row, acc);
+            for (u32 i0 = b; i0 < e; i0 += 256) {  // block-uniform trip count: queue_append needs whole waves
+                const u32 i = i0 + t;
+                const bool ok = i < e;
+                const u32 u = ok ? a.A.colidx[i] : 0u;
+                const bool won = ok && fused_visit<PARENT>(a, vis32, nxt32, newlevel, u, row, qc, acc);
+                queue_append(qc, won, u);
+            }
             if (t == 0) acc.scanned += e - b;
             continue;
         }
-        const u32 base = item * PUSH_VPB;
-        u64 fw = 0;
-        if (t < PUSH_VPB / 64) {
-            u32 wi = (base >> 6) + t;
-            fw = (wi < a.nw) ? frontier[wi] : 0ull;
-            s_fw[t] = fw;
-        }
-        if (!__syncthreads_or(fw != 0ull)) continue;
-        const u32 v0 = base + 4 * t;
-        const u32 nib = (u32)(s_fw[(4 * t) >> 6] >> ((4 * t) & 63)) & 0xFu;
-        u32 rp[5];
-        if (nib && v0 + 4 <= a.n) {
-            const uint4 q = *(const uint4*)(a.A.rowptr + v0);
-            rp[0] = q.x; rp[1] = q.y; rp[2] = q.z; rp[3] = q.w;
-            rp[4] = a.A.rowptr[v0 + 4];
-        } else if (nib) {
+        u32 vid[4], rb[4], re[4];
+        if (qmode) {
+            const u32 seg = item % QSHARDS, chunk = item / QSHARDS;
+            const u32 qn = qcur_len[seg * 16];
+            if (chunk * qchunk >= qn) continue;  // block-uniform
+            const u32 s0 = chunk * qchunk + 4 * t;
+            const u32 send = (chunk + 1) * qchunk < qn ? (chunk + 1) * qchunk : qn;
+            const u32* __restrict__ qs = qcur + seg * QSEG;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) rp[j] = a.A.rowptr[(v0 + j <= a.n) ? (v0 + j) : a.n];
+            for (int j = 0; j < 4; ++j) vid[j] = (s0 + j < send) ? qs[s0 + j] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = vid[j] != 0xFFFFFFFFu;
+                rb[j] = ok ? a.A.rowptr[vid[j]] : 0u;
+                re[j] = ok ? a.A.rowptr[vid[j] + 1] : 0u;
+            }
         } else {
-            rp[0] = rp[1] = rp[2] = rp[3] = rp[4] = 0;
+            const u32 base = item * PUSH_VPB;
+            u64 fw = 0;
+            if (t < PUSH_VPB / 64) {
+                u32 wi = (base >> 6) + t;
+                fw = (wi < a.nw) ? frontier[wi] : 0ull;
+                s_fw[t] = fw;
+            }
+            if (!__syncthreads_or(fw != 0ull)) continue;
+            const u32 v0 = base + 4 * t;
+            const u32 nib = (u32)(s_fw[(4 * t) >> 6] >> ((4 * t) & 63)) & 0xFu;
+            u32 rp[5];
+            if (nib && v0 + 4 <= a.n) {
+                const uint4 q = *(const uint4*)(a.A.rowptr + v0);
+                rp[0] = q.x; rp[1] = q.y; rp[2] = q.z; rp[3] = q.w;
+                rp[4] = a.A.rowptr[v0 + 4];
+            } else if (nib) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) rp[j] = a.A.rowptr[(v0 + j <= a.n) ? (v0 + j) : a.n];
+            } else {
+                rp[0] = rp[1] = rp[2] = rp[3] = rp[4] = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = (nib >> j) & 1u;
+                vid[j] = v0 + j;
+                rb[j] = on ? rp[j] : 0u;
+                re[j] = on ? rp[j + 1] : 0u;
+            }
         }
         u32 deg[4], tsum = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            u32 d = ((nib >> j) & 1u) ? (rp[j + 1] - rp[j]) : 0u;
-            if (d >= HUB_DEG) d = 0;
+            u32 d = re[j] - rb[j];
+            if (d >= HUB_DEG) d = 0;  // expanded by the hub items
             deg[j] = d;
             tsum += d;
         }
@@ -421,19 +516,22 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
             ex = wbase + inc - tsum;
         }
         {
-            uint4 o, st;
+            uint4 o, st, vv;
             o.x = ex; o.y = ex + deg[0]; o.z = o.y + deg[1]; o.w = o.z + deg[2];
-            st.x = rp[0]; st.y = rp[1]; st.z = rp[2]; st.w = rp[3];
+            st.x = rb[0]; st.y = rb[1]; st.z = rb[2]; st.w = rb[3];
+            vv.x = vid[0]; vv.y = vid[1]; vv.z = vid[2]; vv.w = vid[3];
             *(uint4*)(s_off + 4 * t) = o;
             *(uint4*)(s_start + 4 * t) = st;
+            *(uint4*)(s_vid + 4 * t) = vv;
         }
         __syncthreads();
-        // 4 edges per thread per trip: four independent (search -> colidx -> visited) chains in flight
-        for (u32 e0 = t; e0 < total; e0 += 1024) {
+        // 4 edges per thread per trip: four independent (search -> colidx -> visited) chains in flight;
+        // the trip count is block-uniform so the queue appends see whole wavefronts
+        for (u32 e00 = 0; e00 < total; e00 += 1024) {
             u32 own[4], u[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const u32 e = e0 + 256 * k;
+                const u32 e = e00 + t + 256 * k;
                 u32 lo = 0, hi = PUSH_VPB;
 #pragma unroll
                 for (int it = 0; it < 10; ++it) {
@@ -444,8 +542,11 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
                 u[k] = (e < total) ? a.A.colidx[s_start[lo] + (e - s_off[lo])] : 0xFFFFFFFFu;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (u[k] != 0xFFFFFFFFu) fused_visit<PARENT>(a, vis32, nxt32, newlevel, u[k], base + own[k], acc);
+            for (int k = 0; k < 4; ++k) {
+                const bool won = (u[k] != 0xFFFFFFFFu) &&
+                                 fused_visit<PARENT>(a, vis32, nxt32, newlevel, u[k], s_vid[own[k]], qc, acc);
+                queue_append(qc, won, u[k]);
+            }
         }
         if (t == 0) acc.scanned += total;
         __syncthreads();
@@ -458,7 +559,7 @@ constexpr int PULL_R = 4;  // 64-row words per wavefront trip (memory-level para
 
 template <bool PARENT>
 __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u64* __restrict__ visited,
-                           u64* __restrict__ nxt, i32 newlevel, LevelAcc& acc) {
+                           u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
@@ -571,12 +672,13 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
                 visited[g] = mword[r] | neww;
                 nxt[g] = neww;
             }
-            if ((won >> lane) & 1ull) {
+            const bool mine = (won >> lane) & 1ull;
+            if (mine) {
                 a.level[v] = newlevel;
                 if (PARENT) a.parent[v] = par[r];
-                acc.count += 1;
-                acc.mf += a.A.rowptr[v + 1] - a.A.rowptr[v];
+                note_discovery(a, qc, v, acc);
             }
+            queue_append(qc, mine, v);
         }
     }
     // hub rows of A' (>= HUB_DEG in-edges): chunks spread over workgroups
@@ -612,14 +714,100 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
                         a.level[row] = newlevel;
                         if (PARENT) a.parent[row] = s_hit[1];
                         atomicOr(&nxt32[row >> 5], bit);
-                        acc.count += 1;
-                        acc.mf += a.A.rowptr[row + 1] - a.A.rowptr[row];
+                        note_discovery(a, qc, row, acc);
+                        if (qc.open) {
+                            const u32 idx = atomicAdd(qc.qlen, 1u);
+                            if (idx < QSEG) qc.q[idx] = row;
+                        }
                     }
                 }
             }
             __syncthreads();
         }
     }
+}
+
+// End-of-level control, run by the first wavefront of the LAST workgroup to finish (ticket below):
+// sums the statistic slots, advances level / rotation / queue, applies the push<->pull rule and
+// raises `done`.  Same arithmetic as bfs_ctrl_kernel (the multi-rank path keeps that kernel).
+__device__ void fused_ctrl(BfsCtrl* c, u32* host_done) {
+    const u32 t = threadIdx.x;  // 0..63
+    u64 v0 = __hip_atomic_load(&c->slot_count[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 v1 = __hip_atomic_load(&c->slot_mf[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 v3 = __hip_atomic_load(&c->slot_scan[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v0) c->slot_count[t] = 0;
+    if (v1) c->slot_mf[t] = 0;
+    if (v3) c->slot_scan[t] = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        v0 += __shfl_xor(v0, d, 64);
+        v1 += __shfl_xor(v1, d, 64);
+        v3 += __shfl_xor(v3, d, 64);
+    }
+    const u32 rot = c->rot;
+    // lanes 0..7: lengths of the segments appended this level
+    u32 ql = 0;
+    if (t < QSHARDS) {
+        ql = __hip_atomic_load(&c->qlen[(rot + 1) & 1][t * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c->qlen[rot & 1][t * 16] = 0;  // the old current queue is the next level's append target
+    }
+    u32 qn = ql, qmx = ql;
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) {
+        qn += __shfl_xor(qn, d, 64);
+        const u32 o = __shfl_xor(qmx, d, 64);
+        qmx = o > qmx ? o : qmx;
+    }
+    if (t != 0) return;
+    if (c->direction == 1) { c->scanned_push += v3; c->push_levels += 1; }
+    else { c->scanned_pull += v3; c->pull_levels += 1; }
+    c->level += 1;
+    c->n_frontier = v0;
+    c->m_frontier = v1;
+    c->reached += v0;
+    c->edges_traversed += v1;
+    c->rot = rot + 1;
+    // queue[(rot+1)&1] becomes the current one; it lists the whole frontier iff this level appended
+    // and no segment overflowed
+    c->use_queue = (c->q_open && v0 == (u64)qn && qmx <= QSEG) ? 1u : 0u;
+    c->qmax = qmx;
+    {   // aim at ~8K edges per workgroup
+        const u64 avg = v0 ? (v1 / v0) : 1;
+        u32 ch = PUSH_VPB;
+        while (ch > 4 && (u64)ch * (avg ? avg : 1) > 8192ull) ch >>= 1;
+        c->qchunk = ch;
+    }
+    c->hubs[rot & 1] = 0;
+    const bool done = (v0 == 0) || (c->max_level >= 0 && c->level >= c->max_level);
+    c->done = done ? 1 : 0;
+    if (done && host_done)  // the host polls this word instead of paying a D2H copy + stream sync
+        __hip_atomic_store(host_done, 0x80000000u | (u32)c->level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int nd = 1;
+    if (c->force_dir == 1 || !c->has_at) nd = 1;
+    else if (c->force_dir == 2) nd = 2;
+    else {
+        const double un = (double)(c->n_total > c->reached ? c->n_total - c->reached : 0);
+        const u64 m_u = (u64)((double)c->nnz_at * un / (double)c->n_total);
+        nd = ((double)v1 * (double)c->alpha > (double)m_u) ? 2 : 1;
+    }
+    c->direction = nd;
+    // the next level may append its discoveries only if it is light: a push examines m_frontier
+    // edges, a pull can discover at most the unvisited vertices
+    const u64 unv = c->n_total > c->reached ? c->n_total - c->reached : 0;
+    c->q_open = ((nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u;
+}
+
+// One ticket per workgroup, sharded over 64 counters so no word sees more than grid/64 arrivals;
+// returns true in exactly one workgroup of the launch, after every other one has arrived.
+__device__ __forceinline__ bool take_ticket(BfsCtrl* c) {
+    const u32 s = blockIdx.x & 63u;
+    const u32 expect = (gridDim.x + 63u - s) >> 6;
+    if (atomicAdd(&c->tick[s], 1u) + 1u != expect) return false;
+    c->tick[s] = 0;
+    const u32 nshards = gridDim.x < 64u ? gridDim.x : 64u;
+    if (atomicAdd(&c->tick_top, 1u) + 1u != nshards) return false;
+    c->tick_top = 0;
+    return true;
 }
 
 template <bool PARENT>
@@ -632,10 +820,21 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
     u64* zr = a.bm[(rot + 2) % 3];
     const i32 newlevel = c->level + 1;
     const int dir = c->direction;
+    const u32 use_q = c->use_queue;
+    const u32 qmax = c->qmax, qchunk = c->qchunk;
+    const bool hubs_present = c->hubs[rot & 1] != 0;
     for (u32 w = blockIdx.x * 256 + threadIdx.x; w < a.nw; w += gridDim.x * 256) zr[w] = 0ull;
     LevelAcc acc = {0, 0, 0};
-    if (dir == 1) push_fused<PARENT>(a, cur, a.visited, nxt, newlevel, acc);
-    else pull_fused<PARENT>(a, cur, a.visited, nxt, newlevel, acc);
+    QueueCtx qc;
+    qc.q = a.queue[(rot + 1) & 1] + (blockIdx.x % QSHARDS) * QSEG;
+    qc.qlen = &c->qlen[(rot + 1) & 1][(blockIdx.x % QSHARDS) * 16];
+    qc.hubs = &c->hubs[(rot + 1) & 1];
+    qc.open = c->q_open != 0;
+    if (dir == 1)
+        push_fused<PARENT>(a, cur, use_q ? a.queue[rot & 1] : nullptr, &c->qlen[rot & 1][0], qmax, qchunk, hubs_present,
+                           a.visited, nxt, newlevel, qc, acc);
+    else
+        pull_fused<PARENT>(a, cur, a.visited, nxt, newlevel, qc, acc);
     // block reduction of the per-thread statistics, one atomic triple per workgroup
     u64 cnt = acc.count, mf = acc.mf, sc = acc.scanned;
 #pragma unroll
@@ -645,6 +844,7 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
         sc += __shfl_xor(sc, d, 64);
     }
     __shared__ unsigned long long s_acc[3];
+    __shared__ u32 s_last;
     if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
     __syncthreads();
     if (lane_id() == 0 && (cnt | sc)) {
@@ -652,15 +852,21 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
         atomicAdd(&s_acc[1], (unsigned long long)mf);
         atomicAdd(&s_acc[2], (unsigned long long)sc);
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && (s_acc[0] | s_acc[2])) {
+    __syncthreads();  // also drains every wave's outstanding queue / hub atomics (vmcnt(0) before the barrier)
+    if (threadIdx.x == 0) {
         const u32 slot = blockIdx.x & (STAT_SLOTS - 1);
+        // returning atomics whose results are consumed: the sums have landed before the ticket is taken
+        unsigned long long r0 = 0, r1 = 0, r2 = 0;
         if (s_acc[0]) {
-            atomicAdd((unsigned long long*)&c->slot_count[slot], s_acc[0]);
-            atomicAdd((unsigned long long*)&c->slot_mf[slot], s_acc[1]);
+            r0 = atomicAdd((unsigned long long*)&c->slot_count[slot], s_acc[0]);
+            r1 = atomicAdd((unsigned long long*)&c->slot_mf[slot], s_acc[1]);
         }
-        if (s_acc[2]) atomicAdd((unsigned long long*)&c->slot_scan[slot], s_acc[2]);
+        if (s_acc[2]) r2 = atomicAdd((unsigned long long*)&c->slot_scan[slot], s_acc[2]);
+        asm volatile("" ::"v"(r0), "v"(r1), "v"(r2));
+        s_last = take_ticket(c) ? 1u : 0u;
     }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done);
 }
 
 // ---------------------------------------------------------------------------------
@@ -812,6 +1018,15 @@ __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u
     c->n_total = n_total;
     c->rot = 0;
     a.cur[src >> 6] = 1ull << (src & 63);  // fused path: a.cur == bm[0]
+    if (a.queue[0]) {  // fused path: the source is the whole level-0 queue
+        a.queue[0][0] = src;
+        c->qlen[0][0] = 1;
+        c->qmax = 1;
+        c->qchunk = PUSH_VPB;
+        c->use_queue = 1;
+        c->hubs[0] = (mf >= HUB_DEG) ? 1u : 0u;
+        c->q_open = 1;  // patched below once the first direction is known
+    }
     u64 indeg = 0;
     if (src >= a.lo && src < a.hi) {
         a.visited[src >> 6] = 1ull << (src & 63);
@@ -828,6 +1043,67 @@ __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u
         nd = ((double)mf * (double)alpha > (double)m_u) ? 2 : 1;
     }
     c->direction = nd;
+    if (a.queue[0]) c->q_open = ((nd == 1 ? mf : n_total) <= QGATE) ? 1u : 0u;
+}
+
+// Fused single-rank path: ONE launch clears the workspace and seeds the source (replaces three
+// memsets + bfs_init_kernel).  Every word is written by exactly one thread, which also applies the
+// seed value if the source falls into its word; workgroup 0 owns the control block.
+__global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at,
+                                                             u32 force_dir, float alpha, u64 nnz_at) {
+    const u32 tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    // level[]: -1 everywhere, 0 at the source (n_pad is a multiple of 4096)
+    const u32 nq = (a.nw * 64) >> 2;
+    uint4* lv4 = (uint4*)a.level;
+    for (u32 i = tid; i < nq; i += nth) {
+        uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (i == (src >> 2)) {
+            const u32 k = src & 3;
+            if (k == 0) v.x = 0; else if (k == 1) v.y = 0; else if (k == 2) v.z = 0; else v.w = 0;
+        }
+        lv4[i] = v;
+    }
+    // bm[0] | bm[1] | bm[2] | visited are one allocation of 4 * nw words
+    u64* bm = a.bm[0];
+    const u32 sw = src >> 6;
+    const u64 sbit = 1ull << (src & 63);
+    for (u32 i = tid; i < 4 * a.nw; i += nth) bm[i] = (i == sw || i == 3 * a.nw + sw) ? sbit : 0ull;
+    if (a.parent && tid == 0) a.parent[src] = src;
+    if (blockIdx.x != 0) return;
+    BfsCtrl* c = a.ctrl;
+    u32* cw = (u32*)c;
+    for (u32 i = threadIdx.x; i < sizeof(BfsCtrl) / 4; i += 256) cw[i] = 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const u64 mf = a.A.rowptr[src + 1] - a.A.rowptr[src];
+    c->max_level = max_level;
+    c->n_frontier = 1;
+    c->m_frontier = mf;
+    c->reached = 1;
+    c->edges_traversed = mf;
+    c->has_at = has_at;
+    c->force_dir = force_dir;
+    c->alpha = alpha;
+    c->nnz_at = nnz_at;
+    c->n_total = a.n;
+    a.queue[0][0] = src;
+    c->qlen[0][0] = 1;
+    c->qmax = 1;
+    c->qchunk = PUSH_VPB;
+    c->use_queue = 1;
+    c->hubs[0] = (mf >= HUB_DEG) ? 1u : 0u;
+    c->done = (max_level == 0) ? 1 : 0;
+    if (max_level == 0 && a.host_done)
+        __hip_atomic_store(a.host_done, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int nd = 1;
+    if (force_dir == 2 && has_at) nd = 2;
+    else if (force_dir == 0 && has_at) {
+        const u64 indeg = a.At.rowptr[src + 1] - a.At.rowptr[src];
+        const u64 m_u = nnz_at > indeg ? nnz_at - indeg : 0;
+        nd = ((double)mf * (double)alpha > (double)m_u) ? 2 : 1;
+    }
+    c->direction = nd;
+    c->q_open = ((nd == 1 ? mf : (u64)a.n) <= QGATE) ? 1u : 0u;
 }
 
 // ---- standalone vxm kernels (fgpu_vxm, bench) ---------------------------------------
@@ -864,6 +1140,10 @@ struct fgpu_bfs_plan {
     u64 *cur = nullptr, *nxt_local = nullptr, *nxt_global = nullptr, *visited = nullptr;
     bool external_bufs = false;
     u64* bm_block = nullptr;  // single-rank fused path: [bm0 | bm1 | bm2 | visited] in one allocation
+    u32* queue_block = nullptr;  // single-rank fused path: two frontier queues of QCAP ids
+    u32* h_done = nullptr;       // pinned host word the last level writes (host view)
+    u32* d_done = nullptr;       // the same word as the device sees it
+    int enqueued = 0;            // levels enqueued since the last begin
     i32* level = nullptr;
     u32* parent = nullptr;
     BfsCtrl* ctrl = nullptr;
@@ -874,7 +1154,8 @@ struct fgpu_bfs_plan {
     bool profile = false;
     std::vector<ProfSlot> prof;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    u32 grid = 0;
+    u32 grid = 0;   // multi-rank step kernel
+    u32 fgrid = 0;  // fused single-rank level kernel: every workgroup resident at once
 };
 
 static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
@@ -896,8 +1177,13 @@ static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
         a.bm[2] = p->bm_block + 2 * (size_t)p->nw;
         a.visited = p->bm_block + 3 * (size_t)p->nw;
         a.cur = a.bm[0];
+        a.queue[0] = p->queue_block;
+        a.queue[1] = p->queue_block + QCAP;
+        a.host_done = p->d_done;
     } else {
         a.bm[0] = a.bm[1] = a.bm[2] = nullptr;
+        a.queue[0] = a.queue[1] = nullptr;
+        a.host_done = nullptr;
     }
     return a;
 }
@@ -909,6 +1195,7 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     fgpu_ctx* c = p->ctx;
     c->dev_free(p->cur);
     c->dev_free(p->bm_block);
+    c->dev_free(p->queue_block);
     if (!p->external_bufs) {
         if (p->nxt_local != p->nxt_global) c->dev_free(p->nxt_local);
         c->dev_free(p->nxt_global);
@@ -918,6 +1205,7 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->parent);
     c->dev_free(p->ctrl);
     if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
+    if (p->h_done) (void)hipHostFree(p->h_done);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -958,9 +1246,15 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
         if ((i = ctx->dev_alloc((void**)&p->parent, (size_t)p->nw * 64 * sizeof(u32))) != FGPU_OK) break;
         if ((i = ctx->dev_alloc((void**)&p->ctrl, sizeof(BfsCtrl))) != FGPU_OK) break;
         if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->bm_block, 4 * wb)) != FGPU_OK) break;
+        if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->queue_block, 2 * (size_t)QCAP * sizeof(u32))) != FGPU_OK) break;
     } while (0);
     if (i == FGPU_OK) {
         hipError_t e = hipHostMalloc((void**)&p->h_ctrl, sizeof(BfsCtrl), hipHostMallocDefault);
+        if (e == hipSuccess && nranks == 1) {
+            e = hipHostMalloc((void**)&p->h_done, 64, hipHostMallocMapped);
+            if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->d_done, p->h_done, 0);
+            if (e == hipSuccess) *(volatile u32*)p->h_done = 0;
+        }
         if (e == hipSuccess) e = hipEventCreate(&p->ev0);
         if (e == hipSuccess) e = hipEventCreate(&p->ev1);
         if (e == hipSuccess) e = hipMemsetAsync(p->nxt_global, 0, wb, ctx->stream);
@@ -979,6 +1273,11 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
         if (g < (u64)ctx->cus * 4) g = (u64)ctx->cus * 4;
         if (g > 65536) g = 65536;
         p->grid = (u32)g;
+        // one resident round: the hardware admits 7 of these 256-thread workgroups per CU at this
+        // SGPR count (MI355X_MICROARCH.md "Residency"), a grid just above that runs a near-empty second round
+        u64 fg = (u64)ctx->cus * (u64)ctx->opt.bfs_wgs_per_cu;
+        if (fg > g) fg = g;
+        p->fgrid = (u32)fg;
     }
     p->prof = {{"bfs_step_push"}, {"bfs_step_pull"}, {"bfs_commit"}, {"bfs_ctrl"}};
     *out = p;
@@ -1046,13 +1345,12 @@ fgpu_info fgpu_bfs_part_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level)
 static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) {
     FGPU_REQUIRE(src < p->n, FGPU_OUT_OF_BOUNDS, "BFS source %llu >= %u vertices", (unsigned long long)src, p->n);
     fgpu_ctx* ctx = p->ctx;
-    FGPU_HIP(hipMemsetAsync(p->bm_block, 0, 4 * (size_t)p->nw * sizeof(u64), ctx->stream));
-    FGPU_HIP(hipMemsetAsync(p->level, 0xFF, (size_t)p->n * sizeof(i32), ctx->stream));
-    FGPU_HIP(hipMemsetAsync(p->ctrl, 0, sizeof(BfsCtrl), ctx->stream));
     i32 ml = max_level < 0 ? -1 : (max_level > 0x7FFFFFFF ? 0x7FFFFFFF : (i32)max_level);
     BfsArgs a = make_args(p, true);
-    hipLaunchKernelGGL(bfs_init_kernel, dim3(1), dim3(1), 0, ctx->stream, a, (u32)src, ml, p->At ? 1u : 0u,
-                       (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull, (u64)p->n);
+    *(volatile u32*)p->h_done = 0;
+    p->enqueued = 0;
+    hipLaunchKernelGGL(bfs_fused_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream, a, (u32)src, ml,
+                       p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
@@ -1060,11 +1358,9 @@ static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) 
 static fgpu_info fused_level(fgpu_bfs_plan* p) {
     BfsArgs a = make_args(p, true);
     if (p->want_parent)
-        hipLaunchKernelGGL(bfs_fused_kernel<true>, dim3(p->grid), dim3(256), 0, p->ctx->stream, a);
+        hipLaunchKernelGGL(bfs_fused_kernel<true>, dim3(p->fgrid), dim3(256), 0, p->ctx->stream, a);
     else
-        hipLaunchKernelGGL(bfs_fused_kernel<false>, dim3(p->grid), dim3(256), 0, p->ctx->stream, a);
-    FGPU_HIP(hipGetLastError());
-    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(64), 0, p->ctx->stream, p->ctrl);
+        hipLaunchKernelGGL(bfs_fused_kernel<false>, dim3(p->fgrid), dim3(256), 0, p->ctx->stream, a);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
@@ -1125,20 +1421,14 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     BfsArgs a = make_args(p, true);
     FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
     if (p->want_parent)
-        hipLaunchKernelGGL(bfs_fused_kernel<true>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(bfs_fused_kernel<true>, dim3(p->fgrid), dim3(256), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(bfs_fused_kernel<false>, dim3(p->grid), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(bfs_fused_kernel<false>, dim3(p->fgrid), dim3(256), 0, ctx->stream, a);
     FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
     FGPU_HIP(hipEventSynchronize(p->ev1));
     FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     ProfSlot& s = p->prof[dir == 1 ? 0 : 1];
     s.ms += ms; s.launches += 1;
-    FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
-    hipLaunchKernelGGL(bfs_ctrl_kernel, dim3(1), dim3(64), 0, ctx->stream, p->ctrl);
-    FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
-    FGPU_HIP(hipEventSynchronize(p->ev1));
-    FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
-    p->prof[3].ms += ms; p->prof[3].launches += 1;
     FGPU_TRY(fetch_ctrl(p));
     // algorithmic bytes of the level (bitmap form): colidx actually examined,
     // rowptr pairs of the rows touched, the bitmaps streamed, level (+ out-degree) of new vertices
@@ -1152,28 +1442,61 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     return FGPU_OK;
 }
 
+fgpu_info fgpu_bfs_run_async(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, int want_parent, int levels) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_run_async: NULL plan");
+    FGPU_REQUIRE(p->nranks == 1, FGPU_INVALID,
+                 "fgpu_bfs_run drives single-rank plans; multi-rank plans are stepped by the host loop");
+    FGPU_REQUIRE(!p->profile, FGPU_INVALID, "a profiled plan runs synchronously (fgpu_bfs_run)");
+    p->want_parent = want_parent != 0;
+    FGPU_TRY(fused_begin(p, src, max_level));
+    if (levels <= 0) levels = 10;
+    // levels are enqueued blind; the kernels no-op once ctrl->done is raised
+    for (int k = 0; k < levels; ++k) FGPU_TRY(fused_level(p));
+    p->enqueued = levels;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_wait(fgpu_bfs_plan* p) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_wait: NULL plan");
+    FGPU_REQUIRE(p->nranks == 1 && p->enqueued > 0, FGPU_INVALID, "fgpu_bfs_wait: no search in flight");
+    volatile u32* flag = (volatile u32*)p->h_done;
+    for (;;) {
+        // the last level raises the pinned flag; poll it, and look at the stream now and then so a
+        // search that needs more levels than were enqueued (or a failed launch) is noticed
+        for (u32 spin = 0; (*flag & 0x80000000u) == 0; ++spin) {
+            if ((spin & 0x3FFu) == 0x3FFu) {
+                hipError_t q = hipStreamQuery(p->ctx->stream);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) {
+                    set_error("BFS stream failed: %s", hipGetErrorString(q));
+                    return FGPU_DEVICE;
+                }
+            }
+        }
+        if (*flag & 0x80000000u) return FGPU_OK;
+        if (*flag & 0x80000000u) return FGPU_OK;
+        FGPU_TRY(fetch_ctrl(p));  // stream drained without the flag: not done yet (or it raced the poll)
+        if (p->h_ctrl->done) return FGPU_OK;
+        for (int k = 0; k < 4; ++k) FGPU_TRY(fused_level(p));
+        p->enqueued += 4;
+    }
+}
+
 fgpu_info fgpu_bfs_run(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, int want_parent) {
     FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_run: NULL plan");
     FGPU_REQUIRE(p->nranks == 1, FGPU_INVALID,
                  "fgpu_bfs_run drives single-rank plans; multi-rank plans are stepped by the host loop");
-    p->want_parent = want_parent != 0;
-    FGPU_TRY(fused_begin(p, src, max_level));
     if (p->profile) {
+        p->want_parent = want_parent != 0;
+        FGPU_TRY(fused_begin(p, src, max_level));
         for (;;) {
             FGPU_TRY(profiled_level(p));
             if (p->h_ctrl->done) break;
         }
         return FGPU_OK;
     }
-    // enqueue levels blind in small batches; the kernels no-op once ctrl->done is raised
-    int batch = 6;
-    for (;;) {
-        for (int k = 0; k < batch; ++k) FGPU_TRY(fused_level(p));
-        FGPU_TRY(fetch_ctrl(p));
-        if (p->h_ctrl->done) break;
-        batch = 3;
-    }
-    return FGPU_OK;
+    FGPU_TRY(fgpu_bfs_run_async(p, src, max_level, want_parent, 8));
+    return fgpu_bfs_wait(p);
 }
 
 fgpu_info fgpu_bfs_fetch(fgpu_bfs_plan* p, int32_t* level, int64_t* parent) {

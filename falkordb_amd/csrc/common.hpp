@@ -61,6 +61,7 @@ struct fgpu_options {  // fgpu_set_option
     int tiled_nt = 0;          // nontemporal entry loads
     int tiled_threads = 1024;  // its workgroup size
     int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)
+    int bfs_wgs_per_cu = 6;    // grid of the fused BFS level kernel, workgroups per CU
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
 };
 

@@ -193,6 +193,9 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         FGPU_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, FGPU_INVALID,
                      "tiled_u must be 1, 2, 4 or 8");
         ctx->opt.tiled_u = (int)value;
+    } else if (!strcmp(name, "bfs_wgs_per_cu")) {
+        FGPU_REQUIRE(value >= 1 && value <= 64, FGPU_INVALID, "bfs_wgs_per_cu out of range");
+        ctx->opt.bfs_wgs_per_cu = (int)value;
     } else if (!strcmp(name, "tiled_nt")) {
         ctx->opt.tiled_nt = value != 0;
     } else if (!strcmp(name, "tiled_threads")) {

@@ -312,6 +312,12 @@ class BfsPlan:
     def run(self, src, max_level=-1, want_parent=False):
         check(self.ctx.lib.fgpu_bfs_run(self._h, src, max_level, 1 if want_parent else 0))
 
+    def run_async(self, src, max_level=-1, want_parent=False, levels=0):
+        check(self.ctx.lib.fgpu_bfs_run_async(self._h, src, max_level, 1 if want_parent else 0, levels))
+
+    def wait(self):
+        check(self.ctx.lib.fgpu_bfs_wait(self._h))
+
     def fetch(self, want_parent=False):
         level = np.zeros(self.n, dtype=np.int32)
         parent = np.zeros(self.n, dtype=np.int64) if want_parent else None

@@ -230,6 +230,13 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* plan);
 fgpu_info fgpu_bfs_plan_tune(fgpu_bfs_plan* plan, double alpha, double beta, int force_direction);
 /* Run one whole BFS on a single-rank plan; results stay on device. */
 fgpu_info fgpu_bfs_run(fgpu_bfs_plan* plan, uint64_t src, int64_t max_level, int want_parent);
+/* The same search without the final host wait: clears the workspace, seeds `src` and enqueues
+ * `levels` (<= 0: 10) level kernels on the ctx stream; kernels past the last level are no-ops.
+ * fgpu_bfs_wait() returns once the search has ended (it enqueues more levels if `levels` was too
+ * few).  Two plans over the same matrices let the host enqueue search i+1 while search i runs. */
+fgpu_info fgpu_bfs_run_async(fgpu_bfs_plan* plan, uint64_t src, int64_t max_level, int want_parent,
+                             int levels);
+fgpu_info fgpu_bfs_wait(fgpu_bfs_plan* plan);
 /* Copy results of the last run to host (either pointer may be NULL). */
 fgpu_info fgpu_bfs_fetch(fgpu_bfs_plan* plan, int32_t* level, int64_t* parent);
 /* Stats of the last run: stats[0]=levels, [1]=reached vertices (incl. source),

@@ -174,6 +174,45 @@ def test_bfs_chain_graph_many_levels(ctx):
     np.testing.assert_array_equal(level, np.arange(n, dtype=np.int32))
 
 
+def test_bfs_async_pipeline_two_plans(ctx):
+    """run_async / wait: two plans alternate so search i+1 is enqueued while search i runs; `levels`
+    smaller than the search depth exercises the enqueue-more path of wait()."""
+    a = oracle.rmat_csr(14)
+    A = up(ctx, a)
+    At = A.transpose()
+    roots = [int(r) for r in np.nonzero(np.diff(a.rowptr) > 0)[0][:6]]
+    plans = [engine.BfsPlan(ctx, A, At), engine.BfsPlan(ctx, A, At)]
+    for levels in (0, 2, 12):
+        refs = {}
+        for i, src in enumerate(roots):
+            plans[i % 2].run_async(src, -1, False, levels)
+            if i > 0:
+                prev = roots[i - 1]
+                plans[(i - 1) % 2].wait()
+                lv, _ = plans[(i - 1) % 2].fetch()
+                refs.setdefault(prev, oracle.bfs(a, prev, -1)[0])
+                np.testing.assert_array_equal(lv, refs[prev])
+        plans[(len(roots) - 1) % 2].wait()
+        lv, _ = plans[(len(roots) - 1) % 2].fetch()
+        np.testing.assert_array_equal(lv, oracle.bfs(a, roots[-1], -1)[0])
+
+
+def test_bfs_hub_source_and_isolated_source(ctx):
+    # the queue / hub-census path: a source that is itself a hub row (>= 4096 out-edges), and one
+    # with no out-edges at all (the search ends after level 0)
+    n = 6000
+    rows = np.concatenate([np.zeros(5000, dtype=U64), np.arange(1, 5001, dtype=U64)])
+    cols = np.concatenate([np.arange(1, 5001, dtype=U64), (np.arange(1, 5001, dtype=U64) % 900) + 5001])
+    a = oracle.build_csr(n, n, rows, cols)
+    A = up(ctx, a)
+    At = A.transpose()
+    for src in (0, 5999, 17):
+        ref, _, ref_edges = oracle.bfs(a, src, -1)
+        level, parent, edges = engine.bfs(ctx, A, At, src, -1, want_parent=True)
+        check_bfs(a, level, parent, src, ref)
+        assert edges == ref_edges
+
+
 @pytest.mark.parametrize("direction", [1, 2])
 def test_vxm_masked(ctx, direction):
     a = oracle.rmat_csr(13)
