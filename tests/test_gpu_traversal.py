@@ -226,3 +226,46 @@ def test_vxm_masked(ctx, direction):
         want = oracle.vxm(a, f, mk)
         got = engine.vxm(ctx, f, mk, A, At, direction)
         np.testing.assert_array_equal(got, want)
+
+
+def test_bfs_rmat22_properties(ctx):
+    """BASELINE.json configs[1] at full size, through size-independent properties (the serial oracle takes
+    seconds per root here): level(src) = 0; along every edge level[v] <= level[u] + 1 for reached u;
+    every reached v != src has an in-neighbour one level up (checked through the returned parents);
+    reached count and traversed-edge count agree with the level vector; the async two-plan path agrees
+    with the synchronous one."""
+    A = ctx.mat_rmat(22)
+    At = A.transpose()
+    rp, ci, _ = A.export_csr()
+    rp = rp.astype(np.int64)
+    ci = ci.astype(np.int64)
+    deg = np.diff(rp)
+    n = A.nrows
+    src_of_edge = np.repeat(np.arange(n, dtype=np.int64), deg)
+    plan = engine.BfsPlan(ctx, A, At)
+    plan2 = engine.BfsPlan(ctx, A, At)
+    for src in [int(np.nonzero(deg > 0)[0][0]), int(np.argmax(deg))]:
+        plan.run(src, -1, want_parent=True)
+        level, parent = plan.fetch(want_parent=True)
+        st = plan.stats()
+        reached = level >= 0
+        assert level[src] == 0 and parent[src] == src
+        assert st["reached"] == int(reached.sum())
+        assert st["edges_traversed"] == int(deg[reached].sum())
+        lu, lv = level[src_of_edge], level[ci]
+        live = lu >= 0
+        assert (lv[live] >= 0).all() and (lv[live] <= lu[live] + 1).all()
+        others = reached.copy()
+        others[src] = False
+        p = parent[others]
+        assert (level[p] + 1 == level[others]).all()
+        # the parent edge exists: binary search parent's row for the child
+        child = np.nonzero(others)[0]
+        lo, hi = rp[p], rp[p + 1]
+        pos = np.array([np.searchsorted(ci[a:b], c) for a, b, c in zip(lo[:2000], hi[:2000], child[:2000])])
+        assert (ci[lo[:2000] + pos] == child[:2000]).all()
+        assert (parent[~reached] == -1).all()
+        plan2.run_async(src, -1, False, 4)
+        plan2.wait()
+        lv2, _ = plan2.fetch()
+        np.testing.assert_array_equal(lv2, level)
