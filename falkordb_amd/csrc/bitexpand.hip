@@ -1,0 +1,398 @@
+// bitexpand.hip — bit-parallel k-hop expansion for the CondTraverse core when products get dense.
+//
+// The reference evaluates F·A₁·A₂… with GrB_mxm(ANY_PAIR) per hop (Matrix::delta_lmxm,
+// graph/src/graph/graphblas/matrix.rs:1317-1402, driven by expand_batch,
+// graph/src/runtime/ops/cond_traverse.rs:602-605).  On R-MAT graphs the second / third hop of a
+// 1024-row batch touches billions of entries that collapse onto a few hundred million distinct
+// (row, dest) pairs: gathering and sorting them (spgemm.hip) is bound by that "flops" volume.
+// The same set algebra has a transposed form with one BIT per source row:
+//
+//     X[v] = { i : (i, v) in F }                 W = ceil(nsrc / 64) words per vertex
+//     Y[v] = OR_{u in A'[v,:]} X[u]              one pull over the in-edges per hop
+//     Y[v] &= ~X[u] for (u, v) in dm ;  Y[v] |= X[u] for (u, v) in dp
+//
+// which is exactly (F·m)<¬(F·dm)> ∪ (F·dp) read column-wise, including the reference's row-level
+// mask quirk (bit i of (X·dm)[v] is set iff ANY source of row i has a tombstoned edge to v).  A hop
+// streams the transposed matrix once (4 B / entry) and gathers one X row (8·W bytes, a full cache
+// line at W = 16) per entry: HBM-bound, independent of how many duplicates the product contains.
+// The result is converted back to the ascending (row_i, dest) CSR the operator emits
+// (cond_traverse.rs:644) by a 64×64 bit transposition per (64 vertices, word): ballot per source bit.
+#include "common.hpp"
+
+namespace fgpu {
+
+constexpr u32 BP_ITEM = 256;    // entries of A' per work item
+constexpr u32 BP_VCHUNK = 4096; // vertices per emission chunk (64 blocks of 64)
+
+// ---------------------------------------------------------------------------------
+// transpose cache + item list
+// ---------------------------------------------------------------------------------
+__global__ void bp_item_count_kernel(const u32* __restrict__ rowptr, u32 nrows, u32* __restrict__ cnt) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    cnt[r] = (r < nrows) ? (rowptr[r + 1] - rowptr[r] + BP_ITEM - 1) / BP_ITEM : 0u;
+}
+
+__global__ void bp_item_fill_kernel(const u32* __restrict__ rowptr, u32 nrows, const u32* __restrict__ off,
+                                    u32* __restrict__ items) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const u32 b = rowptr[r], e = rowptr[r + 1];
+    const u32 n = (e - b + BP_ITEM - 1) / BP_ITEM;
+    const u32 split = n > 1 ? 0x80000000u : 0u;
+    u32 o = off[r];
+    for (u32 k = 0; k < n; ++k, ++o) {
+        const u32 ib = b + k * BP_ITEM;
+        const u32 ie = ib + BP_ITEM < e ? ib + BP_ITEM : e;
+        items[3 * o] = r;
+        items[3 * o + 1] = ib;
+        items[3 * o + 2] = ie | split;  // nnz < 2^31 is checked by the caller
+    }
+}
+
+// pattern transpose of `m`, built once per snapshot and owned by it (the reference keeps the same
+// thing per relationship type: Tensor::matrix_t, tensor.rs:886-888)
+static fgpu_info transposed_with_items(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat** out) {
+    fgpu_mat* mm = const_cast<fgpu_mat*>(m);
+    if (!mm->tcache) {
+        fgpu_mat* t = nullptr;
+        FGPU_TRY(mat_transpose_pattern(ctx, &t, m));
+        mm->tcache = t;
+    }
+    fgpu_mat* t = mm->tcache;
+    if (!t->bp_items && t->nnz) {
+        FGPU_REQUIRE(!t->is_hyper(), FGPU_INVALID, "bit-parallel expansion needs a non-hypersparse transpose");
+        const u32 nrows = (u32)t->nrows;
+        DevBuf<u32> cnt, off;
+        FGPU_TRY(cnt.alloc(ctx, (size_t)nrows + 1));
+        FGPU_TRY(off.alloc(ctx, (size_t)nrows + 1));
+        hipLaunchKernelGGL(bp_item_count_kernel, dim3(cdiv((u64)nrows + 1, 256)), dim3(256), 0, ctx->stream,
+                           (const u32*)t->rowptr, nrows, cnt.p);
+        FGPU_HIP(hipGetLastError());
+        FGPU_TRY(scan_u32(ctx, cnt.p, off.p, (u64)nrows + 1, nullptr));
+        u32 n = 0;
+        FGPU_TRY(read_u32(ctx, off.p + nrows, &n));
+        FGPU_TRY(ctx->dev_alloc((void**)&t->bp_items, (size_t)(n ? n : 1) * 3 * sizeof(u32)));
+        hipLaunchKernelGGL(bp_item_fill_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream,
+                           (const u32*)t->rowptr, nrows, (const u32*)off.p, t->bp_items);
+        FGPU_HIP(hipGetLastError());
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        t->n_bp_items = n;
+    }
+    *out = t;
+    return FGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// F -> X
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bp_scatter_csr_kernel(CsrView f, u32 nrows, u32 ws, u64* __restrict__ x) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    for (u32 i = wave; i < nrows; i += nwaves) {
+        const u32 b = f.rowptr[i], e = f.rowptr[i + 1];
+        const u64 bit = 1ull << (i & 63);
+        for (u32 q = b + lane; q < e; q += 64)
+            atomicOr((unsigned long long*)&x[(size_t)f.colidx[q] * ws + (i >> 6)], (unsigned long long)bit);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// one hop: Y[v] = OR over in-neighbours u of X[u]
+//   ws  = words per vertex row (power of two <= 64, or a multiple of 64)
+//   LN  = lanes per neighbour = min(ws, 64); 64 / LN neighbours are gathered per load
+// ---------------------------------------------------------------------------------
+template <int LN>
+__global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __restrict__ items, u32 nitems, u32 ws,
+                                                     const u64* __restrict__ x, u64* __restrict__ y) {
+    constexpr int SLOTS = 64 / LN;
+    const u32 lane = lane_id();
+    const u32 wl = lane % LN, slot = lane / LN;
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwb = ws / LN;  // word blocks per row (1 unless ws > 64)
+    for (u32 it = wave; it < nitems; it += nwaves) {
+        const u32 v = items[3 * it], b = items[3 * it + 1];
+        const u32 e3 = items[3 * it + 2];
+        const u32 e = e3 & 0x7FFFFFFFu;
+        const bool split = (e3 >> 31) != 0;
+        for (u32 wb = 0; wb < nwb; ++wb) {
+            const u32 wo = wb * LN + wl;
+            u64 acc = 0ull;
+            // 4 gathers in flight per lane
+            for (u32 q0 = b; q0 < e; q0 += 4 * SLOTS) {
+                u32 u[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 q = q0 + k * SLOTS + slot;
+                    u[k] = (q < e) ? at.colidx[q] : 0xFFFFFFFFu;
+                }
+                u64 xv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[k] = (u[k] != 0xFFFFFFFFu) ? x[(size_t)u[k] * ws + wo] : 0ull;
+                acc |= (xv[0] | xv[1]) | (xv[2] | xv[3]);
+            }
+#pragma unroll
+            for (int d = LN; d < 64; d <<= 1) acc |= __shfl_xor(acc, d, 64);
+            if (slot == 0 && acc) {
+                u64* dst = &y[(size_t)v * ws + wo];
+                if (split) atomicOr((unsigned long long*)dst, (unsigned long long)acc);
+                else *dst = acc;
+            }
+        }
+    }
+}
+
+// delta layers (hypersparse, a handful of entries): Y[v] &= ~X[u] for dm, Y[v] |= X[u] for dp
+template <bool IS_DM>
+__global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 w, u32 ws, const u64* __restrict__ x,
+                                                      u64* __restrict__ y) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    for (u32 r = wave; r < d.nvec; r += nwaves) {
+        const u32 u = d.hrows ? d.hrows[r] : r;
+        const u32 b = d.rowptr[r], e = d.rowptr[r + 1];
+        for (u32 q = b; q < e; ++q) {
+            const u32 v = d.colidx[q];
+            for (u32 k = lane; k < w; k += 64) {
+                const u64 xv = x[(size_t)u * ws + k];
+                if (xv == 0ull) continue;
+                if (IS_DM) atomicAnd((unsigned long long*)&y[(size_t)v * ws + k], (unsigned long long)~xv);
+                else atomicOr((unsigned long long*)&y[(size_t)v * ws + k], (unsigned long long)xv);
+            }
+        }
+    }
+}
+
+// traversed-edge count of a hop: sum_v popcount(X[v]) * deg(v)
+__global__ __launch_bounds__(256) void bp_flops_kernel(CsrView a, u32 w, u32 ws, const u64* __restrict__ x,
+                                                      unsigned long long* __restrict__ out) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    u64 sum = 0;
+    for (u32 r0 = wave * 64; r0 < a.nvec; r0 += nwaves * 64) {
+        const u32 r = r0 + lane;
+        if (r >= a.nvec) continue;
+        const u32 deg = a.rowptr[r + 1] - a.rowptr[r];
+        if (deg == 0) continue;
+        const u32 v = a.hrows ? a.hrows[r] : r;
+        u32 pc = 0;
+        for (u32 k = 0; k < w; ++k) pc += (u32)__popcll(x[(size_t)v * ws + k]);
+        sum += (u64)pc * deg;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0 && sum) atomicAdd(out, (unsigned long long)sum);
+}
+
+// ---------------------------------------------------------------------------------
+// Y -> CSR over the source rows.  A wavefront owns (chunk of 4096 vertices, word w): per block of
+// 64 vertices lane l holds word w of vertex v0 + l; ballot over bit b = the 64-vertex mask of source
+// row 64 w + b.  Pass 1 counts per (row, chunk); a flat exclusive scan of cnt[row][chunk] IS the
+// CSR position of every (row, chunk) run, so pass 2 writes ascending dest ids with no sort.
+// ---------------------------------------------------------------------------------
+template <bool EMIT>
+__global__ __launch_bounds__(256) void bp_rows_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws, u32 nchunks,
+                                                     const u64* __restrict__ label, u32* __restrict__ cnt,
+                                                     const u64* __restrict__ off, u32* __restrict__ col) {
+    const u32 lane = lane_id();
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 total = nchunks * w;
+    for (u32 t = wave; t < total; t += nwaves) {
+        const u32 c = t / w, wi = t % w;
+        const u32 row = wi * 64 + lane;  // the source row this lane accounts for
+        u32 mycnt = 0;
+        u64 mypos = 0;
+        if (EMIT) mypos = off[(size_t)row * nchunks + c];
+        for (u32 vb = 0; vb < BP_VCHUNK / 64; ++vb) {
+            const u32 v0 = c * BP_VCHUNK + vb * 64;
+            if (v0 >= n) break;
+            const u32 v = v0 + lane;
+            u64 word = (v < n) ? y[(size_t)v * ws + wi] : 0ull;
+            if (label) {
+                const u64 lw = label[v0 >> 6];
+                if (!((lw >> lane) & 1ull)) word = 0ull;
+            }
+            if (__ballot(word != 0ull) == 0ull) continue;
+            const u32 lo = (u32)word, hi = (u32)(word >> 32);
+#pragma unroll 4
+            for (u32 bbit = 0; bbit < 64; ++bbit) {
+                const u32 half = bbit < 32 ? lo : hi;
+                const u64 m = __ballot((half >> (bbit & 31)) & 1u);
+                if (m == 0ull) continue;  // wave-uniform
+                const u32 pc = (u32)__popcll(m);
+                if (EMIT) {
+                    // position of row (64 wi + bbit) lives in lane bbit
+                    const u32 plo = (u32)__builtin_amdgcn_readlane((int)(u32)mypos, (int)bbit);
+                    const u32 phi = (u32)__builtin_amdgcn_readlane((int)(u32)(mypos >> 32), (int)bbit);
+                    const u64 p = ((u64)phi << 32) | plo;
+                    if ((m >> lane) & 1ull) col[p + (u32)__popcll(m & ((1ull << lane) - 1ull))] = v;
+                    if (lane == bbit) mypos += pc;
+                } else {
+                    if (lane == bbit) mycnt += pc;
+                }
+            }
+        }
+        if (!EMIT) cnt[(size_t)row * nchunks + c] = mycnt;
+    }
+}
+
+__global__ void bp_rowptr_kernel(const u64* __restrict__ off, u32 k, u32 nchunks, u32* __restrict__ rowptr) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= k) rowptr[i] = (u32)off[(size_t)i * nchunks];
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+static u32 pow2_ceil(u32 x) {
+    u32 p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+static void bp_layout(BitState& s, u32 n, u32 nsrc) {
+    s.n = n; s.nsrc = nsrc;
+    s.w = (nsrc + 63) / 64;
+    if (s.w == 0) s.w = 1;
+    s.ws = s.w <= 64 ? pow2_ceil(s.w) : ((s.w + 63) / 64) * 64;
+}
+
+static fgpu_info bp_alloc_zero(fgpu_ctx* ctx, DevBuf<u64>& buf, const BitState& s) {
+    const size_t words = (size_t)s.n * s.ws;
+    FGPU_TRY(buf.alloc(ctx, words));
+    FGPU_HIP(hipMemsetAsync(buf.p, 0, words * sizeof(u64), ctx->stream));
+    return FGPU_OK;
+}
+
+fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f) {
+    FGPU_REQUIRE(!f->is_hyper(), FGPU_INVALID, "bit-parallel expansion: F must not be hypersparse");
+    bp_layout(s, (u32)f->ncols, (u32)f->nrows);
+    FGPU_TRY(bp_alloc_zero(ctx, s.x, s));
+    if (f->nnz) {
+        u32 grid = cdiv(f->nrows, 4);
+        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        hipLaunchKernelGGL(bp_scatter_csr_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(f), (u32)f->nrows,
+                           s.ws, s.x.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    return FGPU_OK;
+}
+
+static fgpu_info bp_flops(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* a, u64* flops) {
+    if (!a || a->nnz == 0) return FGPU_OK;
+    DevBuf<u64> acc;
+    FGPU_TRY(acc.alloc(ctx, 1));
+    FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream));
+    u32 grid = cdiv(a->nvec ? a->nvec : 1, 256);
+    if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+    hipLaunchKernelGGL(bp_flops_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(a), s.w, s.ws,
+                       (const u64*)s.x.p, (unsigned long long*)acc.p);
+    FGPU_HIP(hipGetLastError());
+    u64 v = 0;
+    FGPU_TRY(read_u64(ctx, acc.p, &v));
+    *flops += v;
+    return FGPU_OK;
+}
+
+// one delta_lmxm in bit form: s.x <- ((X·m) & ~(X·dm)) | (X·dp)
+fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops) {
+    FGPU_REQUIRE(m->nrows == s.n, FGPU_DIM_MISMATCH, "bit-parallel hop: matrix has %llu rows, frontier %u",
+                 (unsigned long long)m->nrows, s.n);
+    FGPU_REQUIRE(m->nnz < 0x7FFFFFFFull, FGPU_INVALID, "bit-parallel hop: nnz must be < 2^31");
+    if (flops) {
+        FGPU_TRY(bp_flops(ctx, s, m, flops));
+        if (dp && dp->nnz) FGPU_TRY(bp_flops(ctx, s, dp, flops));
+    }
+    BitState o;
+    bp_layout(o, (u32)m->ncols, s.nsrc);
+    FGPU_TRY(bp_alloc_zero(ctx, o.x, o));
+    if (m->nnz) {
+        const fgpu_mat* t = nullptr;
+        FGPU_TRY(transposed_with_items(ctx, m, &t));
+        const u32 nitems = t->n_bp_items;
+        u32 grid = cdiv(nitems ? nitems : 1, 4);
+        if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+        const u32 ln = s.ws < 64 ? s.ws : 64;
+#define BP_LAUNCH(LN)                                                                                                   \
+    hipLaunchKernelGGL(bp_pull_kernel<LN>, dim3(grid), dim3(256), 0, ctx->stream, view_of(t), (const u32*)t->bp_items, \
+                       nitems, s.ws, (const u64*)s.x.p, o.x.p)
+        switch (ln) {
+            case 1: BP_LAUNCH(1); break;
+            case 2: BP_LAUNCH(2); break;
+            case 4: BP_LAUNCH(4); break;
+            case 8: BP_LAUNCH(8); break;
+            case 16: BP_LAUNCH(16); break;
+            case 32: BP_LAUNCH(32); break;
+            default: BP_LAUNCH(64); break;
+        }
+#undef BP_LAUNCH
+        FGPU_HIP(hipGetLastError());
+    }
+    if (dm && dm->nnz) {
+        u32 grid = cdiv(dm->nvec ? dm->nvec : 1, 4);
+        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, view_of(dm), s.w, s.ws,
+                           (const u64*)s.x.p, o.x.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    if (dp && dp->nnz) {
+        u32 grid = cdiv(dp->nvec ? dp->nvec : 1, 4);
+        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, view_of(dp), s.w, s.ws,
+                           (const u64*)s.x.p, o.x.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    s.x = std::move(o.x);
+    s.n = o.n;
+    return FGPU_OK;
+}
+
+// X -> CSR snapshot with nsrc rows (dest ascending per row); `label_dev` (nullable) = destination
+// label bitmap applied on the way out (cond_traverse.rs:647-651)
+fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out) {
+    const u32 nchunks = cdiv(s.n ? s.n : 1, BP_VCHUNK);
+    const u32 krows = s.w * 64;  // counted rows (>= nsrc; the tail rows are empty)
+    const size_t ncnt = (size_t)krows * nchunks;
+    DevBuf<u32> cnt;
+    DevBuf<u64> off;
+    FGPU_TRY(cnt.alloc(ctx, ncnt + 1));
+    FGPU_TRY(off.alloc(ctx, ncnt + 1));
+    FGPU_HIP(hipMemsetAsync(cnt.p + ncnt, 0, sizeof(u32), ctx->stream));
+    const u32 total = nchunks * s.w;
+    u32 grid = cdiv(total, 4);
+    if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+    hipLaunchKernelGGL(bp_rows_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n, s.w, s.ws,
+                       nchunks, label_dev, cnt.p, (const u64*)nullptr, (u32*)nullptr);
+    FGPU_HIP(hipGetLastError());
+    FGPU_TRY(scan_u32_to_u64(ctx, cnt.p, off.p, ncnt + 1, nullptr));
+    u64 nnz = 0;
+    FGPU_TRY(read_u64(ctx, off.p + ncnt, &nnz));
+    FGPU_REQUIRE(nnz < 0xFFFFFFFFull, FGPU_OOM,
+                 "expand: %llu result entries exceed the 32-bit row-pointer space; batch the source rows",
+                 (unsigned long long)nnz);
+    fgpu_mat* o = nullptr;
+    FGPU_TRY(mat_alloc(ctx, &o, s.nsrc, s.n, nnz, false, 0, false));
+    // rows >= nsrc are empty, so off[nsrc * nchunks] == nnz already
+    hipLaunchKernelGGL(bp_rowptr_kernel, dim3(cdiv((u64)s.nsrc + 1, 256)), dim3(256), 0, ctx->stream,
+                       (const u64*)off.p, s.nsrc, nchunks, o->rowptr);
+    if (nnz) {
+        hipLaunchKernelGGL(bp_rows_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n, s.w,
+                           s.ws, nchunks, label_dev, (u32*)nullptr, (const u64*)off.p, o->colidx);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        fgpu_mat_free(o);
+        set_error("bit-parallel emission failed: %s", hipGetErrorString(e));
+        return FGPU_DEVICE;
+    }
+    *out = o;
+    return FGPU_OK;
+}
+
+}  // namespace fgpu

@@ -61,6 +61,7 @@ struct fgpu_options {  // fgpu_set_option
     int tiled_nt = 0;          // nontemporal entry loads
     int tiled_threads = 1024;  // its workgroup size
     int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)
+    int expand_mode = 0;       // 0 auto, 1 sorted-CSR products only, 2 bit-parallel from the first hop
     int bfs_wgs_per_cu = 6;    // grid of the fused BFS level kernel, workgroups per CU
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
 };
@@ -146,6 +147,11 @@ struct fgpu_mat {
     uint32_t n_hub_chunks = 0;
     uint32_t max_deg = 0;
     fgpu_tiles* tiles = nullptr;  // built on demand by fgpu_mat_build_tiles; owned by the matrix
+    // bit-parallel expansion (bitexpand.hip): cached pattern transpose of this matrix, and (on that
+    // transpose) its rows cut into items of <= 256 entries
+    fgpu_mat* tcache = nullptr;
+    uint32_t* bp_items = nullptr;  // triples (row, begin, end | split << 31)
+    uint32_t n_bp_items = 0;
     bool is_hyper() const { return hrows != nullptr; }
 };
 
@@ -237,6 +243,7 @@ fgpu_info mat_merge_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, con
                            const fgpu_mat* dm, bool dm_masks_dp);
 // dense (nrows+1) rowptr of a possibly hypersparse matrix.
 fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp);
+fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 fgpu_info mat_finalize(fgpu_mat* m);  // hub list, max degree (after rowptr/colidx are filled)
 // device COO (u32 rows / cols, n entries) -> CSR snapshot, duplicates collapsed.
 fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
@@ -250,6 +257,18 @@ void tiles_release(fgpu_tiles* t);
 fgpu_info tiles_build(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k);
 fgpu_info tiles_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 x_words64, const u64* mask_dev,
                     u64* out_dev, bool zero_out);
+
+// ---- bit-parallel expansion (bitexpand.hip) ------------------------------------------
+struct BitState {
+    DevBuf<u64> x;  // n rows of `ws` words: bit i of row v set <=> (i, v) in F
+    u32 n = 0;      // vertices (rows of X)
+    u32 nsrc = 0;   // source rows of F
+    u32 w = 0;      // words in use per vertex
+    u32 ws = 0;     // row stride in words (power of two <= 64, or a multiple of 64)
+};
+fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f);
+fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops);
+fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out);
 
 constexpr u32 HUB_DEG = 4096;    // rows at least this long are expanded by the hub kernel
 constexpr u32 HUB_CHUNK = 4096;  // edges per hub work item

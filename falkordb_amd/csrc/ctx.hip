@@ -196,6 +196,9 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "bfs_wgs_per_cu")) {
         FGPU_REQUIRE(value >= 1 && value <= 64, FGPU_INVALID, "bfs_wgs_per_cu out of range");
         ctx->opt.bfs_wgs_per_cu = (int)value;
+    } else if (!strcmp(name, "expand_mode")) {
+        FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "expand_mode must be 0 (auto), 1 (sorted CSR) or 2 (bit-parallel)");
+        ctx->opt.expand_mode = (int)value;
     } else if (!strcmp(name, "tiled_nt")) {
         ctx->opt.tiled_nt = value != 0;
     } else if (!strcmp(name, "tiled_threads")) {

@@ -28,6 +28,8 @@ static void mat_release(fgpu_mat* m) {
         c->dev_free(m->hub_chunks);
     }
     tiles_release(m->tiles);
+    if (c) c->dev_free(m->bp_items);
+    if (m->tcache) mat_release(m->tcache);
     delete m;
 }
 
@@ -481,6 +483,21 @@ using namespace fgpu;
 // ===================================================================================
 // C ABI
 // ===================================================================================
+namespace fgpu {
+// pattern-only transpose on device (values, if any, are ignored)
+fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
+    if (a->nnz == 0) return fgpu_mat_new(ctx, out, a->ncols, a->nrows);
+    DevBuf<u32> rows, cols;
+    FGPU_TRY(rows.alloc(ctx, a->nnz));
+    FGPU_TRY(cols.alloc(ctx, a->nnz));
+    u32 grid = cdiv(a->nvec, 4);
+    if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+    hipLaunchKernelGGL(csr_to_coo_t_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(a), rows.p, cols.p);
+    FGPU_HIP(hipGetLastError());
+    return mat_from_device_coo(ctx, out, a->ncols, a->nrows, rows.p, cols.p, a->nnz);
+}
+}  // namespace fgpu
+
 extern "C" {
 
 fgpu_info fgpu_mat_free(fgpu_mat* m) {
@@ -768,15 +785,7 @@ fgpu_info fgpu_mat_transpose(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
         }
         return fgpu_mat_from_coo(ctx, out, a->ncols, a->nrows, rows.data(), cols.data(), vv.data(), a->nnz);
     }
-    if (a->nnz == 0) return fgpu_mat_new(ctx, out, a->ncols, a->nrows);
-    DevBuf<u32> rows, cols;
-    FGPU_TRY(rows.alloc(ctx, a->nnz));
-    FGPU_TRY(cols.alloc(ctx, a->nnz));
-    u32 grid = cdiv(a->nvec, 4);
-    if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-    hipLaunchKernelGGL(csr_to_coo_t_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(a), rows.p, cols.p);
-    FGPU_HIP(hipGetLastError());
-    return mat_from_device_coo(ctx, out, a->ncols, a->nrows, rows.p, cols.p, a->nnz);
+    return mat_transpose_pattern(ctx, out, a);
 }
 
 // ---- probes ------------------------------------------------------------------------

@@ -117,6 +117,40 @@ __global__ __launch_bounds__(256) void checksum_kernel(CsrView c, u32 nrows, uns
     if (lane == 0 && sum) atomicAdd(acc, (unsigned long long)sum);
 }
 
+// sum_{(i,s) in F} deg_B(s): the entries a sorted-CSR product would gather (exact, one small pass)
+static fgpu_info mxm_flops(fgpu_ctx* ctx, const fgpu_mat* F, const fgpu_mat* B, u64* T) {
+    *T = 0;
+    const u32 nnzf = (u32)F->nnz;
+    if (nnzf == 0 || B->nnz == 0) return FGPU_OK;
+    DevBuf<u32> deg;
+    DevBuf<u64> eoff, tot;
+    FGPU_TRY(deg.alloc(ctx, (size_t)nnzf + 1));
+    FGPU_TRY(eoff.alloc(ctx, (size_t)nnzf + 1));
+    FGPU_TRY(tot.alloc(ctx, 1));
+    hipLaunchKernelGGL(entry_deg_kernel, dim3(cdiv((u64)nnzf + 1, 256)), dim3(256), 0, ctx->stream, view_of(F),
+                       view_of(B), nnzf, deg.p);
+    FGPU_HIP(hipGetLastError());
+    FGPU_TRY(scan_u32_to_u64(ctx, deg.p, eoff.p, (u64)nnzf + 1, tot.p));
+    return read_u64(ctx, tot.p, T);
+}
+
+// long rows (dense k-hop results: ~5e5 entries per row): one workgroup per row
+__global__ __launch_bounds__(256) void checksum_rows_kernel(CsrView c, u32 nrows, unsigned long long* __restrict__ acc) {
+    __shared__ unsigned long long s_sum;
+    u64 sum = 0;
+    for (u32 r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const u32 rb = c.rowptr[r], re = c.rowptr[r + 1];
+        for (u32 i = rb + threadIdx.x; i < re; i += 256) sum += mix64(((u64)r << 32) | c.colidx[i]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    if (lane_id() == 0 && sum) atomicAdd(&s_sum, (unsigned long long)sum);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(acc, s_sum);
+}
+
 static fgpu_info empty_dense(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols) {
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, nrows, ncols, 0, false, 0, false));
@@ -283,12 +317,55 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         e = hipMemcpyAsync(f->colidx, ci.data(), ci.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { fgpu_mat_free(f); set_error("expand: source upload failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+    // Hops run on the sorted-CSR products until a hop's gather volume T makes the bit-parallel form
+    // cheaper (bitexpand.hip): it costs one pass over A' gathering max(64, 8 W) bytes per entry,
+    // whatever T is; the CSR product moves ~T entries several times.  Once dense, stay dense.
+    const int mode = ctx->opt.expand_mode;
+    bool bits = false;
+    BitState bs;
     for (int h = 0; h < nhops; ++h) {
+        const fgpu_mat* mh = m[h];
+        const fgpu_mat* dph = dp ? dp[h] : nullptr;
+        const fgpu_mat* dmh = dm ? dm[h] : nullptr;
+        if (!bits && mode != 1 && !mh->is_hyper() && mh->nnz && mh->nnz < 0x7FFFFFFFull && f->nnz) {
+            const u64 w = (nsrc + 63) / 64;
+            const u64 row_bytes = w * 8 > 64 ? w * 8 : 64;
+            const u64 mem = 2ull * (mh->nrows > mh->ncols ? mh->nrows : mh->ncols) * (w <= 64 ? 2 * w : w + 64) * 8;
+            bool go = (mode == 2);
+            if (mode == 0 && mem < (64ull << 30)) {
+                u64 T = 0;
+                fgpu_info i = mxm_flops(ctx, f, mh, &T);
+                if (i != FGPU_OK) { fgpu_mat_free(f); return i; }
+                // measured on RMAT-22 / 1024 rows: a sorted-CSR hop costs ~0.16 ns per gathered entry
+                // (6 ms at T = 36 M), a bit hop ~2.7 ms per 65 M matrix entries at 128 B rows
+                go = T * 512 > mh->nnz * row_bytes;
+            }
+            if (go) {
+                fgpu_info i = bp_from_csr(ctx, bs, f);
+                fgpu_mat_free(f);
+                f = nullptr;
+                if (i != FGPU_OK) return i;
+                bits = true;
+            }
+        }
+        if (bits) {
+            FGPU_TRY(bp_hop(ctx, bs, mh, dph, dmh, flops));
+            continue;
+        }
         fgpu_mat* c = nullptr;
-        fgpu_info i = delta_lmxm_device(ctx, &c, f, m[h], dp ? dp[h] : nullptr, dm ? dm[h] : nullptr, flops);
+        fgpu_info i = delta_lmxm_device(ctx, &c, f, mh, dph, dmh, flops);
         fgpu_mat_free(f);
         if (i != FGPU_OK) return i;
         f = c;
+    }
+    if (bits) {
+        DevBuf<u64> bm;
+        if (dst_label_bitmap) {
+            const u64 nw = ((u64)bs.n + 63) / 64;
+            FGPU_TRY(bm.alloc(ctx, nw + 1));
+            FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        }
+        return bp_to_csr(ctx, bs, dst_label_bitmap ? bm.p : nullptr, result);
     }
     if (dst_label_bitmap) {
         const u64 nc = f->ncols, nw = (nc + 63) / 64;
@@ -363,10 +440,16 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
             i = acc.alloc(ctx, 1);
             if (i == FGPU_OK) {
                 (void)hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream);
-                u32 grid = cdiv(r->nrows, 4);
-                if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-                hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(r),
-                                   (u32)r->nrows, (unsigned long long*)acc.p);
+                if (r->nnz / r->nrows >= 1024) {
+                    u32 grid = (u32)r->nrows < (u32)ctx->cus * 8 ? (u32)r->nrows : (u32)ctx->cus * 8;
+                    hipLaunchKernelGGL(checksum_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(r),
+                                       (u32)r->nrows, (unsigned long long*)acc.p);
+                } else {
+                    u32 grid = cdiv(r->nrows, 4);
+                    if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+                    hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(r),
+                                       (u32)r->nrows, (unsigned long long*)acc.p);
+                }
                 i = read_u64(ctx, acc.p, checksum);
             }
         }

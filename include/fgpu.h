@@ -65,7 +65,9 @@ fgpu_info fgpu_set_stream(fgpu_ctx* ctx, void* hip_stream);
 fgpu_info fgpu_sync(fgpu_ctx* ctx);
 /* Engine tunables (the analogue of GrB_Global_set_INT32, matrix.rs:151-159): "tiled_u" (items in
  * flight per wavefront of the LDS-tiled vxm: 1/2/4/8), "tiled_threads" (256/512/1024),
- * "tiled_wgs" (grid of that kernel, 0 = fill the CUs), "tiled_nt" (nontemporal entry loads). */
+ * "tiled_wgs" (grid of that kernel, 0 = fill the CUs), "tiled_nt" (nontemporal entry loads),
+ * "expand_mode" (fgpu_expand: 0 = pick per hop, 1 = sorted-CSR products only, 2 = bit-parallel from the
+ * first hop), "bfs_wgs_per_cu" (grid of the fused BFS level kernel). */
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
 /* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */
 fgpu_info fgpu_device_info(fgpu_ctx* ctx, char* name, int32_t* cus, int32_t* wave,

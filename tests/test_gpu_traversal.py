@@ -110,6 +110,67 @@ def test_expand_chain_with_label_filter_and_skipped_rows(ctx):
     assert nnz == ref.nnz and cs == oracle.checksum(ref) and fl2 == flops_ref
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("k", [1, 64, 65, 300, 1100, 4200])
+def test_expand_modes_match_oracle(ctx, mode, k):
+    """fgpu_expand through both product forms (sorted CSR / bit-parallel, bitexpand.hip) and the per-hop
+    automatic choice: identical (rowptr, dest), flops and checksum, with delta layers (row-level mask
+    quirk included), skipped source rows, repeated sources and a destination-label filter.  k spans one
+    word, a word boundary, a padded row stride (1100 -> 18 words -> 32) and a stride beyond one
+    wavefront (4200 -> 66 words -> 128)."""
+    a = oracle.rmat_csr(10)
+    n = a.nrows
+    rng = np.random.default_rng(1000 * mode + k)
+    dp, dm = _delta_layers(a, rng, 60, 60)
+    src = rng.integers(0, n, k).astype(U64)   # repeats on purpose
+    if k > 8:
+        src[::5] = np.uint64(2**64 - 1)
+    valid = src != np.uint64(2**64 - 1)
+    f = oracle.build_csr(k, n, np.arange(k, dtype=U64)[valid], src[valid])
+    label_ids = np.nonzero((oracle.mix64(np.arange(n, dtype=U64)) % np.uint64(4)) != 0)[0]
+    label = oracle.bits_from_ids(n, label_ids)
+    A, DP, DM = up(ctx, a), up(ctx, dp), up(ctx, dm)
+    ctx.set_option("expand_mode", mode)
+    try:
+        for hops, with_delta, with_label in [(1, True, False), (2, False, True), (3, True, True)]:
+            c, flops_ref = f, 0
+            for _ in range(hops):
+                c, fl = oracle.delta_lmxm(c, a, dp if with_delta else None, dm if with_delta else None)
+                flops_ref += fl
+            if with_label:
+                rows, cols = c.pairs()
+                keep = np.isin(cols, label_ids)
+                c = oracle.build_csr(k, n, rows[keep], cols[keep])
+            mats = [A] * hops
+            dps = [DP] * hops if with_delta else None
+            dms = [DM] * hops if with_delta else None
+            rp, dest, flops = engine.expand(ctx, src, mats, dps, dms, label if with_label else None)
+            np.testing.assert_array_equal(rp, c.rowptr)
+            np.testing.assert_array_equal(dest, c.colidx)
+            assert flops == flops_ref
+            nnz, cs, _ = engine.expand_count(ctx, src, mats, dps, dms, label if with_label else None)
+            assert nnz == c.nnz and cs == oracle.checksum(c)
+    finally:
+        ctx.set_option("expand_mode", 0)
+
+
+def test_expand_rmat22_three_hops_both_forms_agree(ctx):
+    """Full-size graph (BASELINE.json configs[1]/[2] shape): 512 sources, 3 hops — the sorted-CSR chain
+    and the bit-parallel chain must give the same result size, order-independent checksum and flops."""
+    A = ctx.mat_rmat(22)
+    n = A.nrows
+    src = np.random.default_rng(3).choice(n, 512, replace=False).astype(U64)
+    out = {}
+    try:
+        for mode in (1, 2, 0):
+            ctx.set_option("expand_mode", mode)
+            out[mode] = engine.expand_count(ctx, src, [A, A, A])
+    finally:
+        ctx.set_option("expand_mode", 0)
+    assert out[1] == out[2] == out[0]
+    assert out[1][0] > 10_000_000
+
+
 def check_bfs(a: oracle.CSR, level, parent, src, ref_level):
     np.testing.assert_array_equal(level, ref_level)
     if parent is None:

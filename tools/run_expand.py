@@ -8,12 +8,14 @@ scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 hops = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 nbatches = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx = engine.Context(0)
+ctx.set_option("expand_mode", mode)
 t0 = time.time()
 A = ctx.mat_rmat(scale)
 ctx.sync()
 n = A.nrows
-print(f"rmat-{scale}: n={n} nnz={A.nvals} build {time.time()-t0:.2f}s", flush=True)
+print(f"rmat-{scale}: n={n} nnz={A.nvals} build {time.time()-t0:.2f}s  expand_mode={mode} batch={batch}", flush=True)
 rng = np.random.default_rng(7)
 for b in range(nbatches):
     src = rng.choice(n, batch, replace=False).astype(np.uint64)
