@@ -33,6 +33,21 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(kernel, scale):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/traffic.json, written by tools/prof_bench.sh + tools/pmc_summary.py: FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM).  PMC needs rocprofv3 around the process, so it is not
+    collected live; null when no profile of this workload is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t.get(f"rmat{scale}", {}).get(kernel)
+        return int(e["hbm_bytes_per_dispatch"]) if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def pick_roots(A, want=64):
     """First `want` vertex ids with out-degree > 0."""
     roots, hi = [], 4096
@@ -185,16 +200,20 @@ def main():
             plan.run(roots[i % len(roots)], -1, False)
         prof = plan.profile_read()
         plan.profile(False)
-        steps = [p for p in prof if p["kernel"].startswith("bfs_step") and p["launches"]]
+        steps = [p for p in prof if p["launches"]]
         if steps:
             dom = max(steps, key=lambda p: p["ms"])
             per_launch_bytes = dom["alg_bytes"] / dom["launches"]
             per_launch_ms = dom["ms"] / dom["launches"]
             ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            kname = dom["kernel"].split(" (")[0]
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": pmc_traffic(kname, scale),
                         "alg_bytes_per_launch": int(per_launch_bytes), "avg_launch_us": round(per_launch_ms * 1e3, 2),
                         "launches": int(dom["launches"]),
+                        "timing": "HIP events on the ctx stream around each launch of the profiled pass "
+                                  "(same roots as the timed region)",
                         "all_kernels": [{"kernel": p["kernel"], "ms_total": round(p["ms"], 4),
                                          "launches": int(p["launches"]),
                                          "GBps": round(p["alg_bytes"] / max(p["ms"], 1e-9) / 1e6, 2)} for p in prof]}
@@ -206,6 +225,7 @@ def main():
         ms0, _ = engine.bench_spmv(ctx, At, which=0, iters=10)
         spmv = {"kernel": "tiled_mxv_kernel", "avg_launch_us": round(ms * 1e3, 2), "alg_bytes": int(ab),
                 "achieved": round(g, 2), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(g / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic("tiled_mxv_kernel", scale),
                 "layout": {k: tinfo[k] for k in ("tile_bits", "tiles", "items", "entries", "vec", "k", "bytes")},
                 "csr_pull_us": round(ms0 * 1e3, 2), "csr_pull_GBps": round(ab / (ms0 * 1e-3) / 1e9, 2)}
 

@@ -810,7 +810,9 @@ __device__ __forceinline__ bool take_ticket(BfsCtrl* c) {
     return true;
 }
 
-template <bool PARENT>
+// DIRHINT only names the launch for profilers (0 = blind level loop; 1 / 2 = the profiled pass knows the
+// level is a push / pull); the direction taken is always the control block's.
+template <bool PARENT, int DIRHINT>
 __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
     BfsCtrl* c = a.ctrl;
     if (c->done) return;
@@ -1279,7 +1281,7 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
         if (fg > g) fg = g;
         p->fgrid = (u32)fg;
     }
-    p->prof = {{"bfs_step_push"}, {"bfs_step_pull"}, {"bfs_commit"}, {"bfs_ctrl"}};
+    p->prof = {{"bfs_fused_kernel<false, 1> (push level)"}, {"bfs_fused_kernel<false, 2> (pull level)"}};
     *out = p;
     return FGPU_OK;
 }
@@ -1358,9 +1360,9 @@ static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) 
 static fgpu_info fused_level(fgpu_bfs_plan* p) {
     BfsArgs a = make_args(p, true);
     if (p->want_parent)
-        hipLaunchKernelGGL(bfs_fused_kernel<true>, dim3(p->fgrid), dim3(256), 0, p->ctx->stream, a);
+        hipLaunchKernelGGL((bfs_fused_kernel<true, 0>), dim3(p->fgrid), dim3(256), 0, p->ctx->stream, a);
     else
-        hipLaunchKernelGGL(bfs_fused_kernel<false>, dim3(p->fgrid), dim3(256), 0, p->ctx->stream, a);
+        hipLaunchKernelGGL((bfs_fused_kernel<false, 0>), dim3(p->fgrid), dim3(256), 0, p->ctx->stream, a);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
@@ -1420,10 +1422,13 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     float ms = 0;
     BfsArgs a = make_args(p, true);
     FGPU_HIP(hipEventRecord(p->ev0, ctx->stream));
-    if (p->want_parent)
-        hipLaunchKernelGGL(bfs_fused_kernel<true>, dim3(p->fgrid), dim3(256), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(bfs_fused_kernel<false>, dim3(p->fgrid), dim3(256), 0, ctx->stream, a);
+    if (p->want_parent) {
+        if (dir == 1) hipLaunchKernelGGL((bfs_fused_kernel<true, 1>), dim3(p->fgrid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((bfs_fused_kernel<true, 2>), dim3(p->fgrid), dim3(256), 0, ctx->stream, a);
+    } else {
+        if (dir == 1) hipLaunchKernelGGL((bfs_fused_kernel<false, 1>), dim3(p->fgrid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((bfs_fused_kernel<false, 2>), dim3(p->fgrid), dim3(256), 0, ctx->stream, a);
+    }
     FGPU_HIP(hipEventRecord(p->ev1, ctx->stream));
     FGPU_HIP(hipEventSynchronize(p->ev1));
     FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));

@@ -24,7 +24,7 @@ rows = []
 for k, d in res.items():
     f = d.get("FETCH_SIZE", 0.0) * 1024
     w = d.get("WRITE_SIZE", 0.0) * 1024
-    rows.append({"kernel": k[:90], "fetch_bytes_raw": round(f), "fetch_bytes_x2": round(2 * f), "write_bytes": round(w),
+    rows.append({"kernel": k[:160], "fetch_bytes_raw": round(f), "fetch_bytes_x2": round(2 * f), "write_bytes": round(w),
                  "hbm_bytes_per_dispatch": round(2 * f + w), "dispatches": d.get("dispatches_FETCH_SIZE", 0)})
 rows.sort(key=lambda r: -r["hbm_bytes_per_dispatch"])
 for r in rows[:12]:
