@@ -58,6 +58,8 @@ SIGNATURES = {
     "fgpu_mat_transpose": (C.c_int32, [vp, vpp, vp]),
     "fgpu_mat_probe": (C.c_int32, [vp, vp, u64p, u64p, C.c_uint64, u8p, u64p]),
     "fgpu_mat_merge": (C.c_int32, [vp, vpp, vp, vp, vp, C.c_int]),
+    "fgpu_mat_merge_pattern": (C.c_int32, [vp, vpp, vp, vp, vp, C.c_int]),
+    "fgpu_mat_resize": (C.c_int32, [vp, vpp, vp, C.c_uint64, C.c_uint64]),
     "fgpu_mat_intersect": (C.c_int32, [vp, vpp, vp, vp]),
     "fgpu_mat_intersect_nvals": (C.c_int32, [vp, vp, vp, u64p]),
     "fgpu_mxm": (C.c_int32, [vp, vpp, vp, vp]),

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libfgpu.so")
-SOURCES = ["ctx.hip", "prims.hip", "mat.hip", "bfs.hip", "spgemm.hip", "tiled.hip", "bitexpand.hip"]
+SOURCES = ["ctx.hip", "prims.hip", "mat.hip", "bfs.hip", "spgemm.hip", "tiled.hip", "bitexpand.hip", "merge.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -69,5 +69,32 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(LIBDIR, "libfalkor_host.so")
+HOST_SOURCES = ["matrix.cpp", "versioned_matrix.cpp", "tensor.cpp", "graph.cpp", "capi.cpp"]
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """libfalkor_host.so: the C++ host layer (falkordb_amd/host/) above the C ABI.  It links against
+    libfgpu.so only through include/fgpu.h (rpath $ORIGIN, both libraries live in falkordb_amd/lib)."""
+    build_lib(force=False, verbose=verbose)
+    srcs = [os.path.join(HOST_DIR, f) for f in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, "host.hpp")] + [
+        os.path.join(os.path.dirname(HERE), "include", f) for f in ("fgpu.h", "falkor_host.h")]
+    if not force and os.path.exists(HOST_LIB) and not any(_newer(d, HOST_LIB) for d in deps):
+        return HOST_LIB
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, *srcs,
+           "-L" + LIBDIR, "-lfgpu", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host layer build failed:\n{r.stderr}")
+    if verbose and r.stderr:
+        print(r.stderr, file=sys.stderr)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -63,6 +63,7 @@ struct fgpu_options {  // fgpu_set_option
     int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)
     int expand_mode = 0;       // 0 auto, 1 sorted-CSR products only, 2 bit-parallel from the first hop
     int bfs_wgs_per_cu = 6;    // grid of the fused BFS level kernel, workgroups per CU
+    int merge_mode = 0;        // Delta merge: 0 entry-parallel (merge.hip), 1 one wavefront per row (pattern only)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
 };
 
@@ -241,6 +242,14 @@ fgpu_info mat_alloc(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, u64 nnz
 // (m \ dm) U dp, pattern only, on device (K3/K6).
 fgpu_info mat_merge_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
                            const fgpu_mat* dm, bool dm_masks_dp);
+// The same merge walked entry-parallel, pattern or UINT64 values (dp's value wins), optionally onto
+// new dims (entries at or past them are dropped): merge.hip.
+fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
+                            const fgpu_mat* dm, bool dm_masks_dp, u64 out_nrows, u64 out_ncols,
+                            bool pattern_only);
+fgpu_info mat_from_device_coo_vals(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
+                                   const u32* cols, const u64* vals, u64 n);
+fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 // dense (nrows+1) rowptr of a possibly hypersparse matrix.
 fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp);
 fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);

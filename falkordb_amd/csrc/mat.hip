@@ -542,17 +542,25 @@ fgpu_info fgpu_mat_from_coo(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint6
                      "fgpu_mat_from_coo: tuple %llu = (%llu, %llu) outside %llu x %llu", (unsigned long long)i,
                      (unsigned long long)rows[i], (unsigned long long)cols[i], (unsigned long long)nrows,
                      (unsigned long long)ncols);
-    const u64 DEVICE_BUILD_MIN = 1u << 20;
-    if (!vals && n >= DEVICE_BUILD_MIN) {
-        // big pattern builds: narrow on host, sort/dedup on device
+    // Builds of >= DEVICE_BUILD_MIN tuples (valued or not) are sorted / deduplicated on the device; only a
+    // short host-provided tuple list is ordered on the host while it is being marshalled for upload
+    // (a kernel chain over nrows-sized histograms would cost more than the whole upload).
+    const u64 DEVICE_BUILD_MIN = 4096;
+    if (n >= DEVICE_BUILD_MIN) {
         std::vector<u32> r32(n), c32(n);
         for (u64 i = 0; i < n; ++i) { r32[i] = (u32)rows[i]; c32[i] = (u32)cols[i]; }
         DevBuf<u32> dr, dc;
+        DevBuf<u64> dv;
         FGPU_TRY(dr.alloc(ctx, n));
         FGPU_TRY(dc.alloc(ctx, n));
         FGPU_HIP(hipMemcpyAsync(dr.p, r32.data(), n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
         FGPU_HIP(hipMemcpyAsync(dc.p, c32.data(), n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+        if (vals) {
+            FGPU_TRY(dv.alloc(ctx, n));
+            FGPU_HIP(hipMemcpyAsync(dv.p, vals, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        }
         FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        if (vals) return mat_from_device_coo_vals(ctx, out, nrows, ncols, dr.p, dc.p, dv.p, n);
         return mat_from_device_coo(ctx, out, nrows, ncols, dr.p, dc.p, n);
     }
     // host path: stable sort by (row, col); duplicates collapse, last value wins
@@ -773,18 +781,7 @@ fgpu_info fgpu_mat_extract(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t min_row, u
 // ---- transpose ---------------------------------------------------------------------
 fgpu_info fgpu_mat_transpose(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
     FGPU_REQUIRE(ctx && out && a, FGPU_NULL_POINTER, "fgpu_mat_transpose: NULL argument");
-    if (a->vals) {
-        // values ride along on the host path (UINT64 transposes are write-path only in the reference)
-        std::vector<u32> rp, ci, hr;
-        std::vector<u64> vv;
-        FGPU_TRY(download_mat(ctx, a, rp, ci, vv, hr));
-        std::vector<u64> rows(a->nnz), cols(a->nnz);
-        for (u32 i = 0; i < a->nvec; ++i) {
-            u64 r = a->is_hyper() ? hr[i] : i;
-            for (u32 p = rp[i]; p < rp[i + 1]; ++p) { rows[p] = ci[p]; cols[p] = r; }
-        }
-        return fgpu_mat_from_coo(ctx, out, a->ncols, a->nrows, rows.data(), cols.data(), vv.data(), a->nnz);
-    }
+    if (a->vals) return mat_transpose_vals(ctx, out, a);
     return mat_transpose_pattern(ctx, out, a);
 }
 
@@ -913,38 +910,9 @@ fgpu_info fgpu_mat_merge(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const
                  "fgpu_mat_merge: dp dims differ from m");
     FGPU_REQUIRE(!dm || (dm->nrows == m->nrows && dm->ncols == m->ncols), FGPU_DIM_MISMATCH,
                  "fgpu_mat_merge: dm dims differ from m");
-    if (m->vals || (dp && dp->vals)) {
-        // UINT64 layers (Tensor::flush, tensor.rs:702-751): host merge, dp value wins (GrB_SECOND_UINT64)
-        std::vector<u32> rp, ci, hr, drp, dci, dhr, mrp, mci, mhr;
-        std::vector<u64> vv, dvv, mvv;
-        FGPU_TRY(download_mat(ctx, m, rp, ci, vv, hr));
-        if (dp) FGPU_TRY(download_mat(ctx, dp, drp, dci, dvv, dhr));
-        if (dm) FGPU_TRY(download_mat(ctx, dm, mrp, mci, mvv, mhr));
-        std::map<std::pair<u64, u64>, u64> acc;
-        for (u32 i = 0; i < m->nvec; ++i) {
-            u64 r = m->is_hyper() ? hr[i] : i;
-            for (u32 p = rp[i]; p < rp[i + 1]; ++p) acc[{r, ci[p]}] = m->vals ? vv[p] : 1;
-        }
-        auto erase_dm = [&]() {
-            if (!dm) return;
-            for (u32 i = 0; i < dm->nvec; ++i) {
-                u64 r = dm->is_hyper() ? mhr[i] : i;
-                for (u32 p = mrp[i]; p < mrp[i + 1]; ++p) acc.erase({r, mci[p]});
-            }
-        };
-        if (!dm_masks_dp) erase_dm();
-        if (dp)
-            for (u32 i = 0; i < dp->nvec; ++i) {
-                u64 r = dp->is_hyper() ? dhr[i] : i;
-                for (u32 p = drp[i]; p < drp[i + 1]; ++p) acc[{r, dci[p]}] = dp->vals ? dvv[p] : 1;
-            }
-        if (dm_masks_dp) erase_dm();
-        std::vector<u64> rows, cols, vals;
-        rows.reserve(acc.size()); cols.reserve(acc.size()); vals.reserve(acc.size());
-        for (auto& kv : acc) { rows.push_back(kv.first.first); cols.push_back(kv.first.second); vals.push_back(kv.second); }
-        return fgpu_mat_from_coo(ctx, out, m->nrows, m->ncols, rows.data(), cols.data(), vals.data(), rows.size());
-    }
-    return mat_merge_device(ctx, out, m, dp, dm, dm_masks_dp != 0);
+    if (ctx->opt.merge_mode == 1 && !m->vals && !(dp && dp->vals))
+        return mat_merge_device(ctx, out, m, dp, dm, dm_masks_dp != 0);  // one wavefront per row (A/B timing)
+    return mat_merge_entries(ctx, out, m, dp, dm, dm_masks_dp != 0, m->nrows, m->ncols, false);
 }
 
 static fgpu_info intersect_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, const fgpu_mat* b, uint64_t* nvals) {

@@ -189,6 +189,17 @@ class Mat:
                                           dm._h if dm else None, 1 if dm_masks_dp else 0))
         return Mat(self.ctx, h)
 
+    def merge_pattern(self, dp: "Mat | None", dm: "Mat | None", dm_masks_dp=False) -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mat_merge_pattern(self.ctx._h, C.byref(h), self._h, dp._h if dp else None,
+                                                  dm._h if dm else None, 1 if dm_masks_dp else 0))
+        return Mat(self.ctx, h)
+
+    def resize(self, nrows, ncols) -> "Mat":
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mat_resize(self.ctx._h, C.byref(h), self._h, nrows, ncols))
+        return Mat(self.ctx, h)
+
     def intersect(self, b: "Mat") -> "Mat":
         h = C.c_void_p()
         check(self.ctx.lib.fgpu_mat_intersect(self.ctx._h, C.byref(h), self._h, b._h))

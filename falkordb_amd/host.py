@@ -1,0 +1,416 @@
+"""ctypes handles over libfalkor_host.so (include/falkor_host.h) — the C++ host layer that mirrors
+FalkorDB's Matrix / VersionedMatrix / Tensor / Graph slice and the CondTraverse / ExpandInto / algo.BFS
+operators above the device C ABI.  Test and embedding plumbing only; nothing is computed here."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfalkor_host.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "falkor_host.h")
+_lib = None
+
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+
+
+class HostError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"falkor_host error {code}: {msg}")
+        self.code = code
+
+
+def declared_symbols():
+    """Function names declared in include/falkor_host.h."""
+    with open(HEADER) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fh_[a-z0-9_]+)\s*\(", src)))
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            from . import build
+            build.build_host()
+        L = C.CDLL(LIB_PATH)
+        L.fh_last_error.restype = C.c_char_p
+        L.fh_free.argtypes = [C.c_void_p]
+        L.fh_free.restype = None
+        for name in declared_symbols():
+            fn = getattr(L, name)  # raises if the library lacks a declared symbol
+            if name not in ("fh_last_error", "fh_free", "fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free"):
+                fn.restype = C.c_int
+        for name in ("fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ck(code, allow=(0,)):
+    if code not in allow:
+        raise HostError(code, (load().fh_last_error() or b"").decode())
+    return code
+
+
+def _u64(x):
+    return np.ascontiguousarray(x, dtype=np.uint64)
+
+
+def _p(a):
+    return a.ctypes.data_as(u64p)
+
+
+def _take(ptr, n, dtype=np.uint64):
+    L = load()
+    if not ptr:
+        return np.zeros(0, dtype=dtype)
+    out = np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dtype, copy=True)
+    L.fh_free(C.cast(ptr, C.c_void_p))
+    return out
+
+
+def should_fold(d, tx, base):
+    return bool(load().fh_should_fold(C.c_uint64(d), C.c_uint64(tx), C.c_uint64(base)))
+
+
+def should_fold_read(d, tx, base):
+    return bool(load().fh_should_fold_read(C.c_uint64(d), C.c_uint64(tx), C.c_uint64(base)))
+
+
+def delta_dominates_base(d, base):
+    return bool(load().fh_delta_dominates_base(C.c_uint64(d), C.c_uint64(base)))
+
+
+def compound_key(src, dst):
+    k = C.c_uint64()
+    _ck(load().fh_compound_key(C.c_uint64(src), C.c_uint64(dst), C.byref(k)))
+    return k.value
+
+
+class Context:
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        _ck(self.L.fh_init(C.byref(self.h), device))
+
+    def close(self):
+        if self.h:
+            self.L.fh_finalize(self.h)
+            self.h = C.c_void_p()
+
+
+class Matrix:
+    BOOL, UINT64 = 0, 1
+
+    def __init__(self, ctx, typ=0, nrows=0, ncols=0, _h=None):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = _h if _h is not None else C.c_void_p()
+        if _h is None:
+            _ck(self.L.fh_mat_new(ctx.h, C.byref(self.h), typ, C.c_uint64(nrows), C.c_uint64(ncols)))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.L.fh_mat_free(self.h)
+        except Exception:
+            pass
+
+    def _wrap(self, h):
+        return Matrix(self.ctx, _h=h)
+
+    def build(self, rows, cols, vals=None):
+        r, c = _u64(rows), _u64(cols)
+        v = _u64(vals) if vals is not None else None
+        _ck(self.L.fh_mat_build(self.h, _p(r), _p(c), _p(v) if v is not None else None, C.c_uint64(len(r))))
+
+    def set(self, i, j, v=1):
+        _ck(self.L.fh_mat_set(self.h, C.c_uint64(i), C.c_uint64(j), C.c_uint64(v)))
+
+    def remove(self, i, j):
+        _ck(self.L.fh_mat_remove(self.h, C.c_uint64(i), C.c_uint64(j)))
+
+    def get(self, i, j):
+        v = C.c_uint64()
+        code = _ck(self.L.fh_mat_get(self.h, C.c_uint64(i), C.c_uint64(j), C.byref(v)), allow=(0, 1))
+        return None if code == 1 else v.value
+
+    def nvals(self):
+        v = C.c_uint64()
+        _ck(self.L.fh_mat_nvals(self.h, C.byref(v)))
+        return v.value
+
+    def dims(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _ck(self.L.fh_mat_dims(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def pending(self):
+        v = C.c_int()
+        _ck(self.L.fh_mat_pending(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def wait(self):
+        _ck(self.L.fh_mat_wait(self.h))
+
+    def iter(self, min_row=0, max_row=2**64 - 1):
+        r, c, v = u64p(), u64p(), u64p()
+        n = C.c_uint64()
+        _ck(self.L.fh_mat_iter(self.h, C.c_uint64(min_row), C.c_uint64(max_row), C.byref(r), C.byref(c), C.byref(v),
+                               C.byref(n)))
+        return list(zip(_take(r, n.value).tolist(), _take(c, n.value).tolist(), _take(v, n.value).tolist()))
+
+    def _unary(self, fn, *args):
+        h = C.c_void_p()
+        _ck(fn(self.h, *args, C.byref(h)))
+        return self._wrap(h)
+
+    def dup(self):
+        return self._unary(self.L.fh_mat_dup)
+
+    def transpose(self):
+        return self._unary(self.L.fh_mat_transpose)
+
+    def grown(self, nrows, ncols):
+        return self._unary(self.L.fh_mat_grown, C.c_uint64(nrows), C.c_uint64(ncols))
+
+    def resize(self, nrows, ncols):
+        _ck(self.L.fh_mat_resize(self.h, C.c_uint64(nrows), C.c_uint64(ncols)))
+
+    def lmxm(self, b):
+        _ck(self.L.fh_mat_lmxm(self.h, b.h))
+
+    def rmxm(self, b):
+        _ck(self.L.fh_mat_rmxm(self.h, b.h))
+
+    def delta_lmxm(self, m, dp, dm):
+        _ck(self.L.fh_mat_delta_lmxm(self.h, m.h, dp.h, dm.h))
+
+    def intersection_nvals(self, b):
+        v = C.c_uint64()
+        _ck(self.L.fh_mat_intersection_nvals(self.h, b.h, C.byref(v)))
+        return v.value
+
+
+class VersionedMatrix:
+    def __init__(self, ctx, nrows=0, ncols=0, _h=None):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = _h if _h is not None else C.c_void_p()
+        if _h is None:
+            _ck(self.L.fh_vm_new(ctx.h, C.byref(self.h), C.c_uint64(nrows), C.c_uint64(ncols)))
+
+    @classmethod
+    def from_coo(cls, ctx, nrows, ncols, rows, cols):
+        r, c = _u64(rows), _u64(cols)
+        h = C.c_void_p()
+        _ck(ctx.L.fh_vm_from_coo(ctx.h, C.byref(h), C.c_uint64(nrows), C.c_uint64(ncols), _p(r), _p(c),
+                                 C.c_uint64(len(r))))
+        return cls(ctx, _h=h)
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.L.fh_vm_free(self.h)
+        except Exception:
+            pass
+
+    def set(self, i, j, _v=True):
+        _ck(self.L.fh_vm_set(self.h, C.c_uint64(i), C.c_uint64(j)))
+
+    def remove(self, i, j):
+        _ck(self.L.fh_vm_remove(self.h, C.c_uint64(i), C.c_uint64(j)))
+
+    def get(self, i, j):
+        return True if _ck(self.L.fh_vm_get(self.h, C.c_uint64(i), C.c_uint64(j)), allow=(0, 1)) == 0 else None
+
+    def nvals(self):
+        v = C.c_uint64()
+        _ck(self.L.fh_vm_nvals(self.h, C.byref(v)))
+        return v.value
+
+    def iter(self, min_row=0, max_row=2**64 - 1):
+        r, c = u64p(), u64p()
+        n = C.c_uint64()
+        _ck(self.L.fh_vm_iter(self.h, C.c_uint64(min_row), C.c_uint64(max_row), C.byref(r), C.byref(c), C.byref(n)))
+        return list(zip(_take(r, n.value).tolist(), _take(c, n.value).tolist()))
+
+    def set_all(self, entries, new=False):
+        e = list(entries)
+        r, c = _u64([x[0] for x in e]), _u64([x[1] for x in e])
+        _ck(self.L.fh_vm_set_all(self.h, _p(r), _p(c), C.c_uint64(len(e)), 1 if new else 0))
+
+    def remove_mask(self, entries):
+        e = list(entries)
+        r, c = _u64([x[0] for x in e]), _u64([x[1] for x in e])
+        _ck(self.L.fh_vm_remove_mask(self.h, _p(r), _p(c), C.c_uint64(len(e))))
+
+    def dup(self):
+        h = C.c_void_p()
+        _ck(self.L.fh_vm_dup(self.h, C.byref(h)))
+        return VersionedMatrix(self.ctx, _h=h)
+
+    def transpose(self):
+        h = C.c_void_p()
+        _ck(self.L.fh_vm_transpose(self.h, C.byref(h)))
+        return VersionedMatrix(self.ctx, _h=h)
+
+    def wait(self):
+        _ck(self.L.fh_vm_wait(self.h))
+
+    def flush(self):
+        _ck(self.L.fh_vm_flush(self.h))
+
+    def fold_oversized(self):
+        _ck(self.L.fh_vm_fold_oversized(self.h))
+
+    def extract(self):
+        h = C.c_void_p()
+        _ck(self.L.fh_vm_extract(self.h, C.byref(h)))
+        return Matrix(self.ctx, _h=h)
+
+    def state(self):
+        s = (C.c_uint64 * 4)()
+        _ck(self.L.fh_vm_state(self.h, s))
+        return {"m": s[0], "dp": s[1], "dm": s[2], "needs_flush": bool(s[3])}
+
+
+def cond_spec(src_labels=(), hops=((), ()), optional=False, bind=False, emit=False, bidir=False, siblings=False,
+              attrs=False):
+    """hops: sequence of (types, dst_labels); hop 0 is the operator's own pattern, the rest the fused chain."""
+    parts = ["src=" + ",".join(src_labels)]
+    for types, labels in hops:
+        parts.append("hop=" + ",".join(types) + "|" + ",".join(labels))
+    for k, v in (("optional", optional), ("bind", bind), ("emit", emit), ("bidir", bidir), ("siblings", siblings),
+                 ("attrs", attrs)):
+        parts.append(f"{k}={1 if v else 0}")
+    return ";".join(parts).encode()
+
+
+class Graph:
+    def __init__(self, ctx, node_cap):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = C.c_void_p()
+        self.n = node_cap
+        _ck(self.L.fh_graph_new(ctx.h, C.byref(self.h), C.c_uint64(node_cap)))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.L.fh_graph_free(self.h)
+        except Exception:
+            pass
+
+    def add_label(self, name):
+        v = C.c_uint64()
+        _ck(self.L.fh_graph_add_label(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def add_type(self, name):
+        v = C.c_uint64()
+        _ck(self.L.fh_graph_add_type(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def label_node(self, node, label_id):
+        _ck(self.L.fh_graph_label_node(self.h, C.c_uint64(node), C.c_uint64(label_id)))
+
+    def delete_node(self, node):
+        _ck(self.L.fh_graph_delete_node(self.h, C.c_uint64(node)))
+
+    def create_edge(self, type_id, src, dst, edge_id):
+        _ck(self.L.fh_graph_create_edge(self.h, C.c_uint64(type_id), C.c_uint64(src), C.c_uint64(dst),
+                                        C.c_uint64(edge_id)))
+
+    def create_edges(self, type_id, srcs, dsts, ids):
+        s, d, i = _u64(srcs), _u64(dsts), _u64(ids)
+        _ck(self.L.fh_graph_create_edges(self.h, C.c_uint64(type_id), _p(s), _p(d), _p(i), C.c_uint64(len(s))))
+
+    def delete_edge(self, type_id, src, dst, edge_id):
+        _ck(self.L.fh_graph_delete_edge(self.h, C.c_uint64(type_id), C.c_uint64(src), C.c_uint64(dst),
+                                        C.c_uint64(edge_id)))
+
+    def commit(self):
+        _ck(self.L.fh_graph_commit(self.h))
+
+    def node_has_label(self, node, label_id):
+        return _ck(self.L.fh_graph_node_has_label(self.h, C.c_uint64(node), C.c_uint64(label_id)), allow=(0, 1)) == 0
+
+    def tensor_get(self, type_id, src, dst):
+        p, n = u64p(), C.c_uint64()
+        _ck(self.L.fh_tensor_get(self.h, C.c_uint64(type_id), C.c_uint64(src), C.c_uint64(dst), C.byref(p),
+                                 C.byref(n)))
+        return _take(p, n.value).tolist()
+
+    def tensor_edge_count(self, type_id):
+        v = C.c_uint64()
+        _ck(self.L.fh_tensor_edge_count(self.h, C.c_uint64(type_id), C.byref(v)))
+        return v.value
+
+    def tensor_iter_edges(self, type_id):
+        s, d, i = u64p(), u64p(), u64p()
+        n = C.c_uint64()
+        _ck(self.L.fh_tensor_iter_edges(self.h, C.c_uint64(type_id), C.byref(s), C.byref(d), C.byref(i), C.byref(n)))
+        return list(zip(_take(s, n.value).tolist(), _take(d, n.value).tolist(), _take(i, n.value).tolist()))
+
+    def tensor_state(self, type_id):
+        s = (C.c_uint64 * 5)()
+        _ck(self.L.fh_tensor_state(self.h, C.c_uint64(type_id), s))
+        return {"m": s[0], "dp": s[1], "dm": s[2], "multi_pairs": s[3], "mt": s[4]}
+
+    # ---- operators -----------------------------------------------------------------------------
+    def cond_traverse_batch(self, spec, src, to_bound=None):
+        """src / to_bound: node id, None = bound to NULL / non-node (src) or unbound (to_bound).
+        Returns None when the batched path bails to the per-row one, else (rows, null_rows, flops) with
+        rows = [(active_row, dest[, edge])]."""
+        k = len(src)
+        s = np.asarray([(-2 if v is None else v) for v in src], dtype=np.int64)
+        tb = None if to_bound is None else np.asarray([(-1 if v is None else v) for v in to_bound], dtype=np.int64)
+        batched = C.c_int()
+        orow, odst, onull = u64p(), u64p(), u64p()
+        oedge = i64p()
+        n, nn, fl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _ck(self.L.fh_cond_traverse_batch(self.h, spec, s.ctypes.data_as(i64p),
+                                          tb.ctypes.data_as(i64p) if tb is not None else None, C.c_uint64(k),
+                                          C.byref(batched), C.byref(orow), C.byref(odst), C.byref(oedge), C.byref(n),
+                                          C.byref(onull), C.byref(nn), C.byref(fl)))
+        rows, dst = _take(orow, n.value).tolist(), _take(odst, n.value).tolist()
+        edge = _take(oedge, n.value, np.int64).tolist()
+        nulls = _take(onull, nn.value).tolist()
+        if not batched.value:
+            return None
+        out = [(r, d) if e < 0 else (r, d, e) for r, d, e in zip(rows, dst, edge)]
+        return out, nulls, fl.value
+
+    def cond_traverse_row(self, spec, from_id=None, to_id=None, transposed=False):
+        f, t, e = u64p(), u64p(), u64p()
+        n = C.c_uint64()
+        _ck(self.L.fh_cond_traverse_row(self.h, spec, C.c_int64(-1 if from_id is None else from_id),
+                                        C.c_int64(-1 if to_id is None else to_id), 1 if transposed else 0,
+                                        C.byref(f), C.byref(t), C.byref(e), C.byref(n)))
+        return list(zip(_take(f, n.value).tolist(), _take(t, n.value).tolist(), _take(e, n.value).tolist()))
+
+    def expand_into(self, types, srcs, dsts, bidirectional=False, emit_relationship=True, batched=True):
+        s, d = _u64(srcs), _u64(dsts)
+        orow, osrc, odst, oedge = u64p(), u64p(), u64p(), u64p()
+        n = C.c_uint64()
+        _ck(self.L.fh_expand_into(self.h, ",".join(types).encode(), 1 if bidirectional else 0,
+                                  1 if emit_relationship else 0, 1 if batched else 0, _p(s), _p(d),
+                                  C.c_uint64(len(s)), C.byref(orow), C.byref(osrc), C.byref(odst), C.byref(oedge),
+                                  C.byref(n)))
+        return list(zip(_take(orow, n.value).tolist(), _take(osrc, n.value).tolist(),
+                        _take(odst, n.value).tolist(), _take(oedge, n.value).tolist()))
+
+    def algo_bfs(self, source, max_depth=-1, rel_type=None, want_edges=False):
+        has = C.c_int()
+        nodes, edges = u64p(), u64p()
+        nn, ne = C.c_uint64(), C.c_uint64()
+        _ck(self.L.fh_algo_bfs(self.h, C.c_int64(-1 if source is None else source), C.c_int64(max_depth),
+                               rel_type.encode() if rel_type is not None else None, 1 if want_edges else 0,
+                               C.byref(has), C.byref(nodes), C.byref(nn), C.byref(edges), C.byref(ne)))
+        nv, ev = _take(nodes, nn.value).tolist(), _take(edges, ne.value).tolist()
+        return (nv, ev) if has.value else None

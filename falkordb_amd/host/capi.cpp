@@ -1,0 +1,376 @@
+// capi.cpp — C surface of the host layer (include/falkor_host.h): handles, error codes, array hand-off.
+#include <stdlib.h>
+#include <string.h>
+
+#include <sstream>
+
+#include "../../include/falkor_host.h"
+#include "host.hpp"
+
+using namespace falkor;
+
+struct fh_ctx { Context c; explicit fh_ctx(int d) : c(d) {} };
+struct fh_mat { Matrix m; };
+struct fh_vm { VersionedMatrix v; };
+struct fh_graph { Graph g; fh_graph(Context& c, u64 n) : g(c, n) {} };
+
+static thread_local std::string g_err;
+
+template <class F>
+static int guard(F f) {
+    try {
+        return f();
+    } catch (const GrbError& e) {
+        g_err = e.what();
+        return e.info ? (int)e.info : -1;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return FGPU_INVALID;
+    }
+}
+
+static uint64_t* hand(const std::vector<u64>& v) {
+    uint64_t* p = (uint64_t*)malloc((v.size() ? v.size() : 1) * sizeof(uint64_t));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(uint64_t));
+    return p;
+}
+
+static std::vector<std::string> split(const std::string& s, char sep) {
+    std::vector<std::string> out;
+    std::string cur;
+    std::istringstream in(s);
+    while (std::getline(in, cur, sep))
+        if (!cur.empty()) out.push_back(cur);
+    return out;
+}
+
+static CondTraverseOp parse_spec(const char* spec) {
+    CondTraverseOp op;
+    for (auto& kv : split(spec ? spec : "", ';')) {
+        auto eq = kv.find('=');
+        if (eq == std::string::npos) continue;
+        std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+        if (k == "src") op.src_labels = split(v, ',');
+        else if (k == "hop") {
+            Hop h;
+            auto bar = v.find('|');
+            h.types = split(v.substr(0, bar), ',');
+            if (bar != std::string::npos) h.dst_labels = split(v.substr(bar + 1), ',');
+            op.hops.push_back(h);
+        } else if (k == "optional") op.optional = v == "1";
+        else if (k == "bind") op.bind_relationship = v == "1";
+        else if (k == "emit") op.emit_relationship = v == "1";
+        else if (k == "bidir") op.bidirectional = v == "1";
+        else if (k == "siblings") op.has_sibling_edges = v == "1";
+        else if (k == "attrs") op.has_inline_attrs = v == "1";
+    }
+    if (op.hops.empty()) op.hops.push_back(Hop{});
+    return op;
+}
+
+extern "C" {
+
+const char* fh_last_error(void) { return g_err.c_str(); }
+void fh_free(void* p) { free(p); }
+
+int fh_init(fh_ctx** ctx, int device) {
+    return guard([&] { *ctx = new fh_ctx(device); return 0; });
+}
+void fh_finalize(fh_ctx* ctx) { delete ctx; }
+
+int fh_should_fold(uint64_t d, uint64_t tx, uint64_t base) { return should_fold(d, tx, base) ? 1 : 0; }
+int fh_should_fold_read(uint64_t d, uint64_t tx, uint64_t base) { return should_fold_read(d, tx, base) ? 1 : 0; }
+int fh_delta_dominates_base(uint64_t d, uint64_t base) { return delta_dominates_base(d, base) ? 1 : 0; }
+int fh_compound_key(uint64_t src, uint64_t dst, uint64_t* key) {
+    return guard([&] { *key = compound_key(src, dst); return 0; });
+}
+
+// ---- Matrix ----------------------------------------------------------------------------------------
+int fh_mat_new(fh_ctx* ctx, fh_mat** out, int type, uint64_t nrows, uint64_t ncols) {
+    return guard([&] { *out = new fh_mat{Matrix(ctx->c, type ? Type::UInt64 : Type::Bool, nrows, ncols)}; return 0; });
+}
+void fh_mat_free(fh_mat* m) { delete m; }
+int fh_mat_build(fh_mat* m, const uint64_t* rows, const uint64_t* cols, const uint64_t* vals, uint64_t n) {
+    return guard([&] {
+        std::vector<u64> r(rows, rows + n), c(cols, cols + n), v;
+        if (vals) v.assign(vals, vals + n);
+        m->m.build(r, c, vals ? &v : nullptr);
+        return 0;
+    });
+}
+int fh_mat_set(fh_mat* m, uint64_t i, uint64_t j, uint64_t v) { return guard([&] { m->m.set_element(i, j, v); return 0; }); }
+int fh_mat_remove(fh_mat* m, uint64_t i, uint64_t j) { return guard([&] { m->m.remove_element(i, j); return 0; }); }
+int fh_mat_get(fh_mat* m, uint64_t i, uint64_t j, uint64_t* v) {
+    return guard([&] {
+        auto x = m->m.get(i, j);
+        if (!x) return 1;
+        if (v) *v = *x;
+        return 0;
+    });
+}
+int fh_mat_nvals(fh_mat* m, uint64_t* out) { return guard([&] { *out = m->m.nvals(); return 0; }); }
+int fh_mat_dims(fh_mat* m, uint64_t* nrows, uint64_t* ncols) {
+    *nrows = m->m.nrows();
+    *ncols = m->m.ncols();
+    return 0;
+}
+int fh_mat_pending(fh_mat* m, int* out) { *out = m->m.pending() ? 1 : 0; return 0; }
+int fh_mat_wait(fh_mat* m) { return guard([&] { m->m.wait(); return 0; }); }
+int fh_mat_iter(fh_mat* m, uint64_t min_row, uint64_t max_row, uint64_t** rows, uint64_t** cols, uint64_t** vals,
+                uint64_t* n) {
+    return guard([&] {
+        auto es = m->m.iter(min_row, max_row);
+        std::vector<u64> r, c, v;
+        for (auto& e : es) { r.push_back(e.row); c.push_back(e.col); v.push_back(e.val); }
+        *rows = hand(r);
+        *cols = hand(c);
+        if (vals) *vals = hand(v);
+        *n = es.size();
+        return 0;
+    });
+}
+int fh_mat_dup(fh_mat* m, fh_mat** out) { return guard([&] { *out = new fh_mat{m->m.dup()}; return 0; }); }
+int fh_mat_transpose(fh_mat* m, fh_mat** out) { return guard([&] { *out = new fh_mat{m->m.transpose()}; return 0; }); }
+int fh_mat_grown(fh_mat* m, uint64_t nrows, uint64_t ncols, fh_mat** out) {
+    return guard([&] { *out = new fh_mat{m->m.grown(nrows, ncols)}; return 0; });
+}
+int fh_mat_resize(fh_mat* m, uint64_t nrows, uint64_t ncols) { return guard([&] { m->m.resize(nrows, ncols); return 0; }); }
+int fh_mat_lmxm(fh_mat* self, fh_mat* b) { return guard([&] { self->m.lmxm(b->m); return 0; }); }
+int fh_mat_rmxm(fh_mat* self, fh_mat* b) { return guard([&] { self->m.rmxm(b->m); return 0; }); }
+int fh_mat_delta_lmxm(fh_mat* self, fh_mat* m, fh_mat* dp, fh_mat* dm) {
+    return guard([&] { self->m.delta_lmxm(m->m, dp->m, dm->m); return 0; });
+}
+int fh_mat_intersection_nvals(fh_mat* a, fh_mat* b, uint64_t* out) {
+    return guard([&] { *out = a->m.intersection_nvals(b->m); return 0; });
+}
+
+// ---- VersionedMatrix ------------------------------------------------------------------------------------
+int fh_vm_new(fh_ctx* ctx, fh_vm** out, uint64_t nrows, uint64_t ncols) {
+    return guard([&] { *out = new fh_vm{VersionedMatrix(ctx->c, nrows, ncols)}; return 0; });
+}
+int fh_vm_from_coo(fh_ctx* ctx, fh_vm** out, uint64_t nrows, uint64_t ncols, const uint64_t* rows,
+                   const uint64_t* cols, uint64_t n) {
+    return guard([&] {
+        Matrix m(ctx->c, Type::Bool, nrows, ncols);
+        m.build(std::vector<u64>(rows, rows + n), std::vector<u64>(cols, cols + n));
+        *out = new fh_vm{VersionedMatrix::from_matrix(m)};
+        return 0;
+    });
+}
+void fh_vm_free(fh_vm* v) { delete v; }
+int fh_vm_set(fh_vm* v, uint64_t i, uint64_t j) { return guard([&] { v->v.set(i, j, true); return 0; }); }
+int fh_vm_remove(fh_vm* v, uint64_t i, uint64_t j) { return guard([&] { v->v.remove(i, j); return 0; }); }
+int fh_vm_get(fh_vm* v, uint64_t i, uint64_t j) { return guard([&] { return v->v.get(i, j) ? 0 : 1; }); }
+int fh_vm_nvals(fh_vm* v, uint64_t* out) { return guard([&] { *out = v->v.nvals(); return 0; }); }
+int fh_vm_iter(fh_vm* v, uint64_t min_row, uint64_t max_row, uint64_t** rows, uint64_t** cols, uint64_t* n) {
+    return guard([&] {
+        auto es = v->v.iter(min_row, max_row);
+        std::vector<u64> r, c;
+        for (auto& e : es) { r.push_back(e.row); c.push_back(e.col); }
+        *rows = hand(r);
+        *cols = hand(c);
+        *n = es.size();
+        return 0;
+    });
+}
+int fh_vm_set_all(fh_vm* v, const uint64_t* rows, const uint64_t* cols, uint64_t n, int is_new) {
+    return guard([&] {
+        std::vector<std::pair<u64, u64>> e(n);
+        for (u64 k = 0; k < n; ++k) e[k] = {rows[k], cols[k]};
+        v->v.set_all(e, is_new != 0);
+        return 0;
+    });
+}
+int fh_vm_remove_mask(fh_vm* v, const uint64_t* rows, const uint64_t* cols, uint64_t n) {
+    return guard([&] {
+        Matrix mask(v->v.m().ctx(), Type::Bool, v->v.nrows(), v->v.ncols());
+        mask.build(std::vector<u64>(rows, rows + n), std::vector<u64>(cols, cols + n));
+        v->v.remove_mask(mask);
+        return 0;
+    });
+}
+int fh_vm_dup(fh_vm* v, fh_vm** out) { return guard([&] { *out = new fh_vm{v->v.dup()}; return 0; }); }
+int fh_vm_wait(fh_vm* v) { return guard([&] { v->v.wait(); return 0; }); }
+int fh_vm_flush(fh_vm* v) { return guard([&] { v->v.flush(); return 0; }); }
+int fh_vm_fold_oversized(fh_vm* v) { return guard([&] { v->v.fold_oversized(); return 0; }); }
+int fh_vm_extract(fh_vm* v, fh_mat** out) { return guard([&] { *out = new fh_mat{v->v.extract()}; return 0; }); }
+int fh_vm_transpose(fh_vm* v, fh_vm** out) { return guard([&] { *out = new fh_vm{v->v.transpose()}; return 0; }); }
+int fh_vm_state(fh_vm* v, uint64_t out[4]) {
+    return guard([&] {
+        out[0] = v->v.m().nvals();
+        out[1] = v->v.dp().nvals();
+        out[2] = v->v.dm().nvals();
+        out[3] = v->v.needs_flush() ? 1 : 0;
+        return 0;
+    });
+}
+
+// ---- Graph ------------------------------------------------------------------------------------------------
+int fh_graph_new(fh_ctx* ctx, fh_graph** out, uint64_t node_cap) {
+    return guard([&] { *out = new fh_graph(ctx->c, node_cap); return 0; });
+}
+void fh_graph_free(fh_graph* g) { delete g; }
+int fh_graph_add_label(fh_graph* g, const char* name, uint64_t* id) { return guard([&] { *id = g->g.add_label(name); return 0; }); }
+int fh_graph_add_type(fh_graph* g, const char* name, uint64_t* id) { return guard([&] { *id = g->g.add_type(name); return 0; }); }
+int fh_graph_label_node(fh_graph* g, uint64_t node, uint64_t label_id) { return guard([&] { g->g.label_node(node, label_id); return 0; }); }
+int fh_graph_delete_node(fh_graph* g, uint64_t node) { return guard([&] { g->g.delete_node(node); return 0; }); }
+int fh_graph_create_edge(fh_graph* g, uint64_t type_id, uint64_t src, uint64_t dst, uint64_t edge_id) {
+    return guard([&] { g->g.create_edge(type_id, src, dst, edge_id); return 0; });
+}
+int fh_graph_create_edges(fh_graph* g, uint64_t type_id, const uint64_t* srcs, const uint64_t* dsts,
+                          const uint64_t* ids, uint64_t n) {
+    return guard([&] {
+        g->g.create_edges(type_id, std::vector<u64>(srcs, srcs + n), std::vector<u64>(dsts, dsts + n),
+                          std::vector<u64>(ids, ids + n));
+        return 0;
+    });
+}
+int fh_graph_delete_edge(fh_graph* g, uint64_t type_id, uint64_t src, uint64_t dst, uint64_t edge_id) {
+    return guard([&] { g->g.delete_edge(type_id, src, dst, edge_id); return 0; });
+}
+int fh_graph_commit(fh_graph* g) {
+    return guard([&] {
+        g->g.fold_oversized_deltas();
+        g->g.new_version();
+        return 0;
+    });
+}
+int fh_graph_node_has_label(fh_graph* g, uint64_t node, uint64_t label_id) {
+    return guard([&] { return g->g.node_has_label_id(node, label_id) ? 0 : 1; });
+}
+int fh_tensor_get(fh_graph* g, uint64_t type_id, uint64_t src, uint64_t dst, uint64_t** ids, uint64_t* n) {
+    return guard([&] {
+        auto v = g->g.relationship_tensors().at(type_id).get(src, dst);
+        *ids = hand(v);
+        *n = v.size();
+        return 0;
+    });
+}
+int fh_tensor_edge_count(fh_graph* g, uint64_t type_id, uint64_t* out) {
+    return guard([&] { *out = g->g.relationship_tensors().at(type_id).edge_count(); return 0; });
+}
+int fh_tensor_iter_edges(fh_graph* g, uint64_t type_id, uint64_t** srcs, uint64_t** dsts, uint64_t** ids, uint64_t* n) {
+    return guard([&] {
+        auto es = g->g.relationship_tensors().at(type_id).iter_edges();
+        std::vector<u64> s, d, i;
+        for (auto& e : es) { s.push_back(e.row); d.push_back(e.col); i.push_back(e.val); }
+        *srcs = hand(s);
+        *dsts = hand(d);
+        *ids = hand(i);
+        *n = es.size();
+        return 0;
+    });
+}
+int fh_tensor_state(fh_graph* g, uint64_t type_id, uint64_t out[5]) {
+    return guard([&] {
+        const Tensor& t = g->g.relationship_tensors().at(type_id);
+        t.wait_fwd();
+        out[0] = t.fwd_m().nvals();
+        out[1] = t.fwd_dp().nvals();
+        out[2] = t.fwd_dm().nvals();
+        out[3] = t.multi_pairs();
+        out[4] = t.matrix_t().nvals();
+        return 0;
+    });
+}
+
+// ---- operators -----------------------------------------------------------------------------------------------
+static Value to_value(int64_t x) {
+    if (x >= 0) return Value::node((u64)x);
+    if (x == -2) return Value::null();
+    return Value{};
+}
+
+int fh_cond_traverse_eligible(const char* spec) { return parse_spec(spec).batched_eligible() ? 1 : 0; }
+
+int fh_cond_traverse_batch(fh_graph* g, const char* spec, const int64_t* src, const int64_t* to_bound, uint64_t k,
+                           int* batched, uint64_t** out_row, uint64_t** out_dest, int64_t** out_edge, uint64_t* n,
+                           uint64_t** null_rows, uint64_t* n_null, uint64_t* flops) {
+    return guard([&] {
+        CondTraverseOp op = parse_spec(spec);
+        std::vector<Value> s(k), tb(k);
+        for (u64 i = 0; i < k; ++i) {
+            s[i] = to_value(src[i]);
+            if (to_bound) tb[i] = to_value(to_bound[i]);
+        }
+        std::vector<ExpandedRow> rows;
+        std::vector<u64> nulls;
+        u64 fl = 0;
+        bool ok = op.expand_batch(g->g, s, to_bound ? &tb : nullptr, rows, nulls, &fl);
+        *batched = ok ? 1 : 0;
+        std::vector<u64> r, d;
+        int64_t* e = (int64_t*)malloc((rows.size() ? rows.size() : 1) * sizeof(int64_t));
+        for (size_t i = 0; i < rows.size(); ++i) {
+            r.push_back(rows[i].active_row);
+            d.push_back(rows[i].dest);
+            e[i] = rows[i].edge ? (int64_t)*rows[i].edge : -1;
+        }
+        *out_row = hand(r);
+        *out_dest = hand(d);
+        *out_edge = e;
+        *n = rows.size();
+        *null_rows = hand(nulls);
+        *n_null = nulls.size();
+        if (flops) *flops = fl;
+        return 0;
+    });
+}
+
+int fh_cond_traverse_row(fh_graph* g, const char* spec, int64_t from_id, int64_t to_id, int transposed,
+                         uint64_t** out_from, uint64_t** out_to, uint64_t** out_edge, uint64_t* n) {
+    return guard([&] {
+        CondTraverseOp op = parse_spec(spec);
+        std::vector<std::array<u64, 3>> out;
+        op.expand_row(g->g, from_id >= 0 ? std::optional<u64>((u64)from_id) : std::nullopt,
+                      to_id >= 0 ? std::optional<u64>((u64)to_id) : std::nullopt, transposed != 0, {}, out);
+        std::vector<u64> f, t, e;
+        for (auto& x : out) { f.push_back(x[0]); t.push_back(x[1]); e.push_back(x[2]); }
+        *out_from = hand(f);
+        *out_to = hand(t);
+        *out_edge = hand(e);
+        *n = out.size();
+        return 0;
+    });
+}
+
+int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_relationship, int batched,
+                   const uint64_t* srcs, const uint64_t* dsts, uint64_t k, uint64_t** out_row, uint64_t** out_src,
+                   uint64_t** out_dst, uint64_t** out_edge, uint64_t* n) {
+    return guard([&] {
+        ExpandIntoOp op;
+        op.types = split(types ? types : "", ',');
+        op.bidirectional = bidirectional != 0;
+        op.emit_relationship = emit_relationship != 0;
+        std::vector<std::vector<std::array<u64, 3>>> per_row(k);
+        if (batched) {
+            op.expand_batch(g->g, std::vector<u64>(srcs, srcs + k), std::vector<u64>(dsts, dsts + k), per_row);
+        } else {
+            for (u64 i = 0; i < k; ++i) per_row[i] = op.expand_row(g->g, srcs[i], dsts[i]);
+        }
+        std::vector<u64> r, s, d, e;
+        for (u64 i = 0; i < k; ++i)
+            for (auto& x : per_row[i]) { r.push_back(i); s.push_back(x[0]); d.push_back(x[1]); e.push_back(x[2]); }
+        *out_row = hand(r);
+        *out_src = hand(s);
+        *out_dst = hand(d);
+        *out_edge = hand(e);
+        *n = r.size();
+        return 0;
+    });
+}
+
+int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges, int* has_row,
+                uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges) {
+    return guard([&] {
+        BfsResult r = algo_bfs(g->g, source >= 0 ? std::optional<u64>((u64)source) : std::nullopt, max_depth,
+                               rel_type ? std::optional<std::string>(rel_type) : std::nullopt, want_edges != 0);
+        *has_row = r.has_row ? 1 : 0;
+        *nodes = hand(r.nodes);
+        *n_nodes = r.nodes.size();
+        *edges = hand(r.edges);
+        *n_edges = r.edges.size();
+        return 0;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,446 @@
+// graph.cpp — the traversal-facing slice of graph.rs plus the operators that sit on it:
+// CondTraverseOp::expand_batch / expand_row, ExpandIntoOp, algo.BFS.
+#include <algorithm>
+
+#include "host.hpp"
+
+namespace falkor {
+
+// ---- Graph ------------------------------------------------------------------------------------------
+Graph::Graph(Context& ctx, u64 node_cap, u64 label_cap)
+    : ctx_(&ctx), n_(node_cap), adj_(ctx, node_cap, node_cap), labels_(ctx, node_cap, label_cap) {}
+
+LabelId Graph::add_label(const std::string& name) {
+    auto it = label_ids_.find(name);
+    if (it != label_ids_.end()) return it->second;
+    LabelId id = label_ids_.size();
+    if (id >= labels_.ncols()) labels_.resize(labels_.nrows(), labels_.ncols() * 2);
+    label_ids_[name] = id;
+    return id;
+}
+
+u64 Graph::add_type(const std::string& name) {
+    auto it = type_ids_.find(name);
+    if (it != type_ids_.end()) return it->second;
+    u64 id = tensors_.size();
+    tensors_.emplace_back(*ctx_, n_, n_);
+    type_ids_[name] = id;
+    return id;
+}
+
+std::optional<LabelId> Graph::label_id(const std::string& name) const {
+    auto it = label_ids_.find(name);
+    if (it == label_ids_.end()) return std::nullopt;
+    return it->second;
+}
+std::optional<u64> Graph::type_id(const std::string& name) const {
+    auto it = type_ids_.find(name);
+    if (it == type_ids_.end()) return std::nullopt;
+    return it->second;
+}
+
+void Graph::create_edge(u64 type, u64 src, u64 dst, u64 edge_id) {
+    tensors_.at(type).set_all_from_slices({src}, {dst}, {edge_id});
+    adj_.set_all({{src, dst}}, false);   // two edges may share one pair: NEW = false
+}
+
+void Graph::delete_edge(u64 type, u64 src, u64 dst, u64 edge_id) {
+    auto emptied = tensors_.at(type).remove_all({{edge_id, src, dst}});
+    if (emptied.empty()) return;
+    for (auto& t : tensors_)
+        if (t.eff_get(src, dst)) return;   // another type still connects the pair
+    adj_.remove(src, dst);
+}
+
+void Graph::create_edges(u64 type, const std::vector<u64>& srcs, const std::vector<u64>& dsts,
+                         const std::vector<u64>& ids) {
+    tensors_.at(type).set_all_from_slices(srcs, dsts, ids);
+    std::vector<std::pair<u64, u64>> pairs(srcs.size());
+    for (size_t k = 0; k < srcs.size(); ++k) pairs[k] = {srcs[k], dsts[k]};
+    adj_.set_all(pairs, false);
+}
+
+void Graph::new_version() {
+    adj_ = adj_.dup();
+    labels_ = labels_.dup();
+    for (auto& t : tensors_) t = t.dup();
+}
+
+void Graph::fold_oversized_deltas() {
+    adj_.fold_oversized();
+    labels_.fold_oversized();
+    for (auto& t : tensors_) t.fold_oversized();
+}
+
+bool Graph::node_has_label_id(u64 node, LabelId l) const { return labels_.get(node, l).has_value(); }
+
+std::optional<std::vector<LabelId>> Graph::resolve_label_ids(const std::vector<std::string>& labels) const {
+    std::vector<LabelId> out;
+    for (auto& l : labels) {
+        auto id = label_id(l);
+        if (!id) return std::nullopt;
+        out.push_back(*id);
+    }
+    return out;
+}
+
+std::vector<u64> Graph::label_bitmap(const std::vector<LabelId>& ids) const {
+    const u64 words = (n_ + 63) / 64;
+    std::vector<u64> bits(words, ~0ull);
+    if (n_ % 64) bits[words - 1] = (1ull << (n_ % 64)) - 1;
+    if (ids.empty()) return bits;
+    // the label matrix is node x label: its transpose has one row per label = the node set of that label
+    VersionedMatrix lt = labels_.transpose();
+    for (LabelId l : ids) {
+        std::vector<u64> has(words, 0);
+        for (auto& e : lt.iter(l, l)) has[e.col >> 6] |= 1ull << (e.col & 63);
+        for (u64 w = 0; w < words; ++w) bits[w] &= has[w];
+    }
+    return bits;
+}
+
+Matrix Graph::build_relationship_matrix_unrestricted(const std::vector<u64>& type_ids) const {
+    // graph.rs:2520-2549: the first type's extract, then for every further type
+    //   m<!dm_t> U= pattern(m_t) ; m U= pattern(dp_t)
+    if (type_ids.empty()) return adj_.extract();
+    Matrix m = tensors_.at(type_ids[0]).extract();
+    for (size_t k = 1; k < type_ids.size(); ++k) {
+        const Tensor& t = tensors_.at(type_ids[k]);
+        t.wait_fwd();
+        m.set_pattern(&t.fwd_dm(), t.fwd_m(), Descriptor::C);
+        m.set_pattern(nullptr, t.fwd_dp(), Descriptor::None);
+    }
+    return m;
+}
+
+Matrix Graph::build_adjacency_matrix(const std::vector<std::string>& types) const {
+    if (types.empty()) return adj_.extract();                       // graph.rs:3874-3876
+    if (types.size() == 1) {
+        auto id = type_id(types[0]);
+        return id ? tensors_[*id].extract() : Matrix(*ctx_, Type::Bool, n_, n_);
+    }
+    Matrix result(*ctx_, Type::Bool, n_, n_);
+    for (auto& t : types)
+        if (auto id = type_id(t)) {
+            Matrix e = tensors_[*id].extract();
+            result.element_wise_add(nullptr, nullptr, &e, Descriptor::None);
+        }
+    return result;
+}
+
+std::vector<u64> Graph::get_src_dest_relationships(u64 src, u64 dst, const std::vector<u64>& type_ids) const {
+    std::vector<u64> out;
+    for (u64 t : type_ids) {
+        auto ids = tensors_.at(t).get(src, dst);
+        out.insert(out.end(), ids.begin(), ids.end());
+    }
+    return out;
+}
+
+// ---- CondTraverse -------------------------------------------------------------------------------------
+bool CondTraverseOp::batched_eligible() const {
+    // cond_traverse.rs:308-316
+    return !emit_relationship && !bidirectional && !has_sibling_edges && (hops.size() > 1 || !has_inline_attrs);
+}
+
+namespace {
+struct HopLayers {
+    // keeps temporaries (materialized unions) alive for the duration of the call
+    std::vector<Matrix> owned;
+    std::vector<const fgpu_mat*> m, dp, dm;
+};
+
+// Matrix choice per hop (cond_traverse.rs:478-505): no type -> adjacency; one type -> that tensor's forward
+// layers; several -> materialized union with clean deltas.  Returns false for an unknown type.
+bool hop_layers(const Graph& g, const std::vector<Hop>& hops, HopLayers& hl, std::vector<std::vector<u64>>& type_ids) {
+    for (auto& h : hops) {
+        std::vector<u64> ids;
+        for (auto& t : h.types) {
+            auto id = g.type_id(t);
+            if (!id) return false;
+            ids.push_back(*id);
+        }
+        type_ids.push_back(ids);
+        if (ids.empty()) {
+            const VersionedMatrix& a = g.adjacency_matrix();
+            a.wait();
+            hl.m.push_back(a.m().snapshot());
+            hl.dp.push_back(a.dp().nvals() ? a.dp().snapshot() : nullptr);
+            hl.dm.push_back(a.dm().nvals() ? a.dm().snapshot() : nullptr);
+        } else if (ids.size() == 1) {
+            const Tensor& t = g.relationship_tensors()[ids[0]];
+            t.wait_fwd();
+            hl.m.push_back(t.fwd_m().snapshot());
+            hl.dp.push_back(t.fwd_dp().nvals() ? t.fwd_dp().snapshot() : nullptr);
+            hl.dm.push_back(t.fwd_dm().nvals() ? t.fwd_dm().snapshot() : nullptr);
+        } else {
+            hl.owned.push_back(g.build_relationship_matrix_unrestricted(ids));
+            hl.m.push_back(hl.owned.back().snapshot());
+            hl.dp.push_back(nullptr);
+            hl.dm.push_back(nullptr);
+        }
+    }
+    return true;
+}
+}  // namespace
+
+bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src, const std::vector<Value>* to_bound,
+                                  std::vector<ExpandedRow>& rows, std::vector<u64>& null_rows, u64* flops) const {
+    rows.clear();
+    null_rows.clear();
+    if (flops) *flops = 0;
+    const u64 k = src.size();
+    auto no_match = [&]() {
+        if (optional)
+            for (u64 i = 0; i < k; ++i) null_rows.push_back(i);
+        return true;
+    };
+    HopLayers hl;
+    std::vector<std::vector<u64>> type_ids;
+    if (!hop_layers(g, hops, hl, type_ids)) return no_match();          // unknown type (:485-490)
+    auto last_dst = g.resolve_label_ids(hops.back().dst_labels);
+    auto src_lids = g.resolve_label_ids(src_labels);
+    if (!last_dst || !src_lids) return no_match();                      // unknown label
+
+    // F[i, src_i] = 1 for bound Node sources passing ALL source labels (:556-601)
+    std::vector<u64> src_ids(k, ~0ull);
+    std::vector<u64> cand_rows, cand_nodes;
+    for (u64 i = 0; i < k; ++i) {
+        if (src[i].kind != Value::Node) {
+            if (optional) continue;
+            return false;                                               // per-row fallback (:566-575)
+        }
+        cand_rows.push_back(i);
+        cand_nodes.push_back(src[i].id);
+    }
+    std::vector<uint8_t> ok(cand_rows.size(), 1);
+    if (!src_lids->empty() && !cand_rows.empty()) {
+        // node_has_label_id for every (row, label) in one batch of probes per layer of the label matrix
+        const VersionedMatrix& lab = g.node_labels_matrix();
+        lab.wait();
+        for (LabelId l : *src_lids) {
+            std::vector<u64> cols(cand_nodes.size(), l);
+            std::vector<uint8_t> in_m, in_dm, in_dp;
+            lab.m().probe(cand_nodes, cols, in_m, nullptr);
+            lab.dm().probe(cand_nodes, cols, in_dm, nullptr);
+            lab.dp().probe(cand_nodes, cols, in_dp, nullptr);
+            for (size_t c = 0; c < cand_nodes.size(); ++c)
+                if (!((in_m[c] && !in_dm[c]) || (!in_m[c] && in_dp[c]))) ok[c] = 0;
+        }
+    }
+    bool any = false;
+    for (size_t c = 0; c < cand_rows.size(); ++c)
+        if (ok[c]) { src_ids[cand_rows[c]] = cand_nodes[c]; any = true; }
+    if (!any) return no_match();
+
+    std::vector<u64> bitmap;
+    if (!last_dst->empty()) bitmap = g.label_bitmap(*last_dst);         // dst label filter of the LAST hop (:647-651)
+
+    fgpu_ctx* ctx = g.ctx().raw();
+    u64 *rowptr = nullptr, *dest = nullptr, nnz = 0, fl = 0;
+    check(fgpu_expand(ctx, src_ids.data(), k, hl.m.data(), hl.dp.data(), hl.dm.data(), (int)hops.size(),
+                      bitmap.empty() ? nullptr : bitmap.data(), &rowptr, &dest, &nnz, &fl),
+          "CondTraverse::expand_batch");
+    if (flops) *flops = fl;
+
+    std::vector<uint8_t> matched(k, 0);
+    const bool want_edge = bind_relationship && hops.size() == 1;
+    std::vector<u64> es, ed;   // pairs needing a representative edge
+    for (u64 i = 0; i < k; ++i) {
+        for (u64 p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            const u64 d = dest[p];
+            if (to_bound && (*to_bound)[i].kind == Value::Node && (*to_bound)[i].id != d) continue;   // :657-661
+            rows.push_back(ExpandedRow{i, d, std::nullopt});
+            if (want_edge) { es.push_back(src_ids[i]); ed.push_back(d); }
+        }
+    }
+    fgpu_free(ctx, rowptr);
+    fgpu_free(ctx, dest);
+    if (want_edge) {
+        // representative edge: first id found scanning the types in order (:663-695), batched per type
+        std::vector<u64> tids = type_ids[0];
+        if (tids.empty())
+            for (u64 t = 0; t < g.relationship_tensors().size(); ++t) tids.push_back(t);
+        std::vector<std::optional<u64>> rep(rows.size());
+        for (u64 t : tids) {
+            std::vector<std::vector<u64>> ids;
+            g.relationship_tensors()[t].get_batch(es, ed, ids);
+            for (size_t r = 0; r < rows.size(); ++r)
+                if (!rep[r] && !ids[r].empty()) rep[r] = ids[r][0];
+        }
+        std::vector<ExpandedRow> kept;
+        for (size_t r = 0; r < rows.size(); ++r) {
+            if (!rep[r]) continue;                                       // no edge: the pair is dropped
+            rows[r].edge = rep[r];
+            kept.push_back(rows[r]);
+        }
+        rows.swap(kept);
+    }
+    for (auto& r : rows) matched[r.active_row] = 1;
+    if (optional)
+        for (u64 i = 0; i < k; ++i)
+            if (!matched[i]) null_rows.push_back(i);
+    return true;
+}
+
+void CondTraverseOp::expand_row(const Graph& g, std::optional<u64> from_id, std::optional<u64> to_id, bool transposed,
+                                const std::vector<u64>& used_edges, std::vector<std::array<u64, 3>>& out) const {
+    const Hop& h = hops.at(0);
+    std::vector<u64> tids;
+    for (auto& t : h.types) {
+        auto id = g.type_id(t);
+        if (!id) return;                                                 // state.no_match
+        tids.push_back(*id);
+    }
+    auto src_l = g.resolve_label_ids(src_labels);
+    auto dst_l = g.resolve_label_ids(h.dst_labels);
+    if (!src_l || !dst_l) return;
+    // matrix coordinates: (src, dst) of the stored direction; `transposed` swaps the pattern's endpoints
+    std::optional<u64> msrc = transposed ? to_id : from_id;
+    std::optional<u64> mdst = transposed ? from_id : to_id;
+    const std::vector<LabelId>& msrc_l = transposed ? *dst_l : *src_l;
+    const std::vector<LabelId>& mdst_l = transposed ? *src_l : *dst_l;
+    std::vector<std::pair<u64, u64>> pairs;
+    auto fwd_rows = [&](u64 lo, u64 hi) {
+        std::vector<Entry> es;
+        if (tids.empty()) es = g.adjacency_matrix().iter(lo, hi);
+        else if (tids.size() == 1) es = g.relationship_tensors()[tids[0]].structural_iter(lo, hi);
+        else es = g.build_relationship_matrix_unrestricted(tids).iter(lo, hi);
+        return es;
+    };
+    if (!msrc && mdst) {
+        // only the matrix destination is bound: walk its incoming pairs over the transposed structure
+        std::vector<Entry> es;
+        if (tids.size() == 1) es = g.relationship_tensors()[tids[0]].matrix_t().iter(*mdst, *mdst);
+        else {
+            Matrix a = tids.empty() ? g.adjacency_matrix().extract() : g.build_relationship_matrix_unrestricted(tids);
+            es = a.transpose().iter(*mdst, *mdst);
+        }
+        for (auto& e : es) pairs.push_back({e.col, e.row});
+    } else {
+        for (auto& e : fwd_rows(msrc ? *msrc : 0, msrc ? *msrc : ~0ull))
+            if (!mdst || *mdst == e.col) pairs.push_back({e.row, e.col});
+    }
+    std::vector<u64> scan = tids;
+    if (scan.empty())
+        for (u64 t = 0; t < g.relationship_tensors().size(); ++t) scan.push_back(t);
+    for (auto& pr : pairs) {                                             // process_pairs (:978-1117)
+        const u64 s = pr.first, d = pr.second;
+        bool okl = true;
+        for (LabelId l : msrc_l) okl = okl && g.node_has_label_id(s, l);
+        for (LabelId l : mdst_l) okl = okl && g.node_has_label_id(d, l);
+        if (!okl) continue;
+        const u64 from_node = transposed ? d : s, to_node = transposed ? s : d;
+        bool first_only = !emit_relationship;
+        for (u64 t : scan) {
+            bool done = false;
+            for (u64 id : g.relationship_tensors()[t].get(s, d)) {
+                if (std::find(used_edges.begin(), used_edges.end(), id) != used_edges.end()) continue;
+                out.push_back({from_node, to_node, id});
+                if (first_only) { done = true; break; }
+            }
+            if (done) break;
+        }
+    }
+}
+
+// ---- ExpandInto ---------------------------------------------------------------------------------------
+static std::vector<u64> resolve_types(const Graph& g, const std::vector<std::string>& types) {
+    std::vector<u64> tids;
+    if (types.empty()) {
+        for (u64 t = 0; t < g.relationship_tensors().size(); ++t) tids.push_back(t);
+        return tids;
+    }
+    for (auto& t : types)
+        if (auto id = g.type_id(t)) tids.push_back(*id);
+    return tids;
+}
+
+std::vector<std::array<u64, 3>> ExpandIntoOp::expand_row(const Graph& g, u64 src, u64 dst,
+                                                         const std::vector<u64>& used_edges) const {
+    std::vector<std::array<u64, 3>> out;
+    std::vector<std::pair<u64, u64>> pairs{{src, dst}};
+    if (bidirectional && src != dst) pairs.push_back({dst, src});
+    auto tids = resolve_types(g, types);
+    for (auto& pr : pairs) {
+        size_t before = out.size();
+        for (u64 t : tids)
+            for (u64 e : g.relationship_tensors()[t].get(pr.first, pr.second)) {
+                if (std::find(used_edges.begin(), used_edges.end(), e) != used_edges.end()) continue;
+                out.push_back({pr.first, pr.second, e});
+            }
+        if (!emit_relationship && out.size() > before + 1) out.resize(before + 1);   // one representative per pair
+    }
+    return out;
+}
+
+void ExpandIntoOp::expand_batch(const Graph& g, const std::vector<u64>& srcs, const std::vector<u64>& dsts,
+                                std::vector<std::vector<std::array<u64, 3>>>& out) const {
+    const size_t k = srcs.size();
+    out.assign(k, {});
+    auto tids = resolve_types(g, types);
+    // probe list: (src, dst) of every row, then (dst, src) of the rows that also look backwards
+    std::vector<u64> ps(srcs), pd(dsts);
+    std::vector<size_t> back_row;
+    if (bidirectional)
+        for (size_t i = 0; i < k; ++i)
+            if (srcs[i] != dsts[i]) { ps.push_back(dsts[i]); pd.push_back(srcs[i]); back_row.push_back(i); }
+    std::vector<std::vector<std::vector<u64>>> per_type(tids.size());
+    for (size_t t = 0; t < tids.size(); ++t) g.relationship_tensors()[tids[t]].get_batch(ps, pd, per_type[t]);
+    auto emit = [&](size_t row, size_t probe) {
+        size_t before = out[row].size();
+        for (size_t t = 0; t < tids.size(); ++t)
+            for (u64 e : per_type[t][probe]) out[row].push_back({ps[probe], pd[probe], e});
+        if (!emit_relationship && out[row].size() > before + 1) out[row].resize(before + 1);
+    };
+    for (size_t i = 0; i < k; ++i) emit(i, i);
+    for (size_t b = 0; b < back_row.size(); ++b) emit(back_row[b], k + b);
+}
+
+// ---- algo.BFS --------------------------------------------------------------------------------------------
+BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
+                   const std::optional<std::string>& rel_type, bool want_edges) {
+    BfsResult res;
+    const u64 n = g.node_cap();
+    if (!source || n == 0) return res;                                   // NULL source / empty graph: no row
+    if (g.is_node_deleted(*source)) throw GrbError(FGPU_INVALID, "Source node not found in graph");
+    std::vector<std::string> types;
+    if (rel_type) types.push_back(*rel_type);
+    Matrix adj = g.build_adjacency_matrix(types);                        // graph.rs:3870-3894
+    Matrix adj_t = adj.transpose();
+    std::vector<int32_t> level(n);
+    std::vector<int64_t> parent(want_edges ? n : 0);
+    check(fgpu_bfs(g.ctx().raw(), adj.snapshot(), adj_t.snapshot(), *source, max_depth < 0 ? -1 : max_depth,
+                   level.data(), want_edges ? parent.data() : nullptr, nullptr),
+          "LAGr_BreadthFirstSearch");
+    std::vector<u64> ps, pd;
+    for (u64 v = 0; v < n; ++v) {
+        if (level[v] < 0 || v == *source || g.is_node_deleted(v)) continue;
+        if (want_edges) {
+            u64 p = (u64)parent[v];
+            if (g.is_node_deleted(p)) continue;
+            ps.push_back(p);
+            pd.push_back(v);
+        }
+        res.nodes.push_back(v);
+    }
+    if (want_edges && !res.nodes.empty()) {
+        // edges[k] = first id of get_src_dest_relationships(parent, child, types), batched per type
+        std::vector<u64> tids;
+        if (rel_type) { if (auto id = g.type_id(*rel_type)) tids.push_back(*id); }
+        else for (u64 t = 0; t < g.relationship_tensors().size(); ++t) tids.push_back(t);
+        std::vector<std::optional<u64>> rep(ps.size());
+        for (u64 t : tids) {
+            std::vector<std::vector<u64>> ids;
+            g.relationship_tensors()[t].get_batch(ps, pd, ids);
+            for (size_t r = 0; r < ps.size(); ++r)
+                if (!rep[r] && !ids[r].empty()) rep[r] = ids[r][0];
+        }
+        for (auto& e : rep)
+            if (e) res.edges.push_back(*e);
+    }
+    res.has_row = !res.nodes.empty();
+    return res;
+}
+
+}  // namespace falkor

@@ -1,0 +1,123 @@
+/*
+ * falkor_host.h — C surface of the C++ host layer (falkordb_amd/host/, libfalkor_host.so).
+ *
+ * The host layer is the C++17 stand-in for the Rust code that sits between FalkorDB's execution-plan
+ * operators and the GraphBLAS boundary (Matrix<T>, VersionedMatrix, Tensor, the traversal slice of Graph,
+ * CondTraverseOp::expand_batch, ExpandIntoOp, algo.BFS).  It calls the device engine only through
+ * include/fgpu.h.  This header flattens it to plain C so that tests (ctypes) and embedders can drive it;
+ * every function names the reference method it forwards to (file:line relative to
+ * /root/reference/graph/src).  Return value: 0 ok, 1 = GrB_NO_VALUE where noted, negative = fgpu_info;
+ * fh_last_error() holds the message.  Out arrays are malloc'ed and released with fh_free().
+ */
+#ifndef FALKOR_HOST_H
+#define FALKOR_HOST_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fh_ctx fh_ctx;     /* matrix::init context                         graphblas/matrix.rs:116-221 */
+typedef struct fh_mat fh_mat;     /* Matrix<bool> / Matrix<u64>                   graphblas/matrix.rs */
+typedef struct fh_vm fh_vm;       /* VersionedMatrix<bool> (Delta_Matrix)         graphblas/versioned_matrix.rs */
+typedef struct fh_graph fh_graph; /* traversal-facing slice of Graph              graph/graph.rs */
+
+int fh_init(fh_ctx** ctx, int device);
+void fh_finalize(fh_ctx* ctx);
+const char* fh_last_error(void);
+void fh_free(void* p);
+
+/* fold policy — versioned_matrix.rs:152-200 (pure integer arithmetic; needs no device) */
+int fh_should_fold(uint64_t delta_nvals, uint64_t tx_added, uint64_t base_nvals);
+int fh_should_fold_read(uint64_t delta_nvals, uint64_t tx_added, uint64_t base_nvals);
+int fh_delta_dominates_base(uint64_t delta_nvals, uint64_t base_nvals);
+/* tensor.rs:154-163; returns -3 when an id needs more than 32 bits */
+int fh_compound_key(uint64_t src, uint64_t dst, uint64_t* key);
+
+/* ---- Matrix<T>: type 0 = bool, 1 = u64 ------------------------------------------------------------ */
+int fh_mat_new(fh_ctx* ctx, fh_mat** out, int type, uint64_t nrows, uint64_t ncols);   /* matrix.rs:1151, 1214 */
+void fh_mat_free(fh_mat* m);
+int fh_mat_build(fh_mat* m, const uint64_t* rows, const uint64_t* cols, const uint64_t* vals, uint64_t n); /* :1186, :1281 */
+int fh_mat_set(fh_mat* m, uint64_t i, uint64_t j, uint64_t v);                         /* :1174, :1264 */
+int fh_mat_remove(fh_mat* m, uint64_t i, uint64_t j);                                  /* :664 */
+int fh_mat_get(fh_mat* m, uint64_t i, uint64_t j, uint64_t* v);                        /* :1158, :1248; 1 = NO_VALUE */
+int fh_mat_nvals(fh_mat* m, uint64_t* out);                                            /* :722 */
+int fh_mat_dims(fh_mat* m, uint64_t* nrows, uint64_t* ncols);
+int fh_mat_pending(fh_mat* m, int* out);                                               /* :764 */
+int fh_mat_wait(fh_mat* m);                                                            /* :781 */
+int fh_mat_iter(fh_mat* m, uint64_t min_row, uint64_t max_row, uint64_t** rows, uint64_t** cols,
+                uint64_t** vals, uint64_t* n);                                         /* Iter :1471-1605 */
+int fh_mat_dup(fh_mat* m, fh_mat** out);                                               /* :370 */
+int fh_mat_transpose(fh_mat* m, fh_mat** out);                                         /* :633 */
+int fh_mat_grown(fh_mat* m, uint64_t nrows, uint64_t ncols, fh_mat** out);             /* :664-704 */
+int fh_mat_resize(fh_mat* m, uint64_t nrows, uint64_t ncols);                          /* :576 */
+int fh_mat_lmxm(fh_mat* self, fh_mat* b);                                              /* :930 */
+int fh_mat_rmxm(fh_mat* self, fh_mat* b);                                              /* :951 */
+int fh_mat_delta_lmxm(fh_mat* self, fh_mat* m, fh_mat* dp, fh_mat* dm);                /* :1317 */
+int fh_mat_intersection_nvals(fh_mat* a, fh_mat* b, uint64_t* out);                    /* :743 */
+
+/* ---- VersionedMatrix<bool> ---------------------------------------------------------------------- */
+int fh_vm_new(fh_ctx* ctx, fh_vm** out, uint64_t nrows, uint64_t ncols);               /* versioned_matrix.rs:494 */
+int fh_vm_from_coo(fh_ctx* ctx, fh_vm** out, uint64_t nrows, uint64_t ncols, const uint64_t* rows,
+                   const uint64_t* cols, uint64_t n);                                  /* from_matrix :877 */
+void fh_vm_free(fh_vm* v);
+int fh_vm_set(fh_vm* v, uint64_t i, uint64_t j);                                       /* :844 */
+int fh_vm_remove(fh_vm* v, uint64_t i, uint64_t j);                                    /* :780 */
+int fh_vm_get(fh_vm* v, uint64_t i, uint64_t j);                                       /* :819; 0 present, 1 NO_VALUE */
+int fh_vm_nvals(fh_vm* v, uint64_t* out);                                              /* :629 */
+int fh_vm_iter(fh_vm* v, uint64_t min_row, uint64_t max_row, uint64_t** rows, uint64_t** cols, uint64_t* n); /* :647 */
+int fh_vm_set_all(fh_vm* v, const uint64_t* rows, const uint64_t* cols, uint64_t n, int is_new);   /* :1006 */
+int fh_vm_remove_mask(fh_vm* v, const uint64_t* rows, const uint64_t* cols, uint64_t n);           /* :799 */
+int fh_vm_dup(fh_vm* v, fh_vm** out);                                                  /* :1038 */
+int fh_vm_wait(fh_vm* v);                                                              /* :545 */
+int fh_vm_flush(fh_vm* v);                                                             /* :892 */
+int fh_vm_fold_oversized(fh_vm* v);                                                    /* :953 */
+int fh_vm_extract(fh_vm* v, fh_mat** out);                                             /* :609 */
+int fh_vm_transpose(fh_vm* v, fh_vm** out);                                            /* :1070 */
+/* out[0..2] = nvals of m, dp, dm; out[3] = needs_flush */
+int fh_vm_state(fh_vm* v, uint64_t out[4]);
+
+/* ---- Graph slice ------------------------------------------------------------------------------------ */
+int fh_graph_new(fh_ctx* ctx, fh_graph** out, uint64_t node_cap);
+void fh_graph_free(fh_graph* g);
+int fh_graph_add_label(fh_graph* g, const char* name, uint64_t* id);
+int fh_graph_add_type(fh_graph* g, const char* name, uint64_t* id);
+int fh_graph_label_node(fh_graph* g, uint64_t node, uint64_t label_id);
+int fh_graph_delete_node(fh_graph* g, uint64_t node);
+int fh_graph_create_edge(fh_graph* g, uint64_t type_id, uint64_t src, uint64_t dst, uint64_t edge_id);
+int fh_graph_create_edges(fh_graph* g, uint64_t type_id, const uint64_t* srcs, const uint64_t* dsts,
+                          const uint64_t* ids, uint64_t n);   /* Tensor::set_all_from_slices + adjacency set_all */
+int fh_graph_delete_edge(fh_graph* g, uint64_t type_id, uint64_t src, uint64_t dst, uint64_t edge_id);
+/* MVCC commit of every matrix: dup() (fold decision) then fold_oversized, as mvcc_graph.rs:161-180 does */
+int fh_graph_commit(fh_graph* g);
+int fh_graph_node_has_label(fh_graph* g, uint64_t node, uint64_t label_id);            /* graph.rs:1057; 0 yes, 1 no */
+int fh_tensor_get(fh_graph* g, uint64_t type_id, uint64_t src, uint64_t dst, uint64_t** ids, uint64_t* n); /* tensor.rs:307 */
+int fh_tensor_edge_count(fh_graph* g, uint64_t type_id, uint64_t* out);                /* tensor.rs:955 */
+int fh_tensor_iter_edges(fh_graph* g, uint64_t type_id, uint64_t** srcs, uint64_t** dsts, uint64_t** ids,
+                         uint64_t* n);                                                  /* tensor.rs:973 */
+/* out[0..2] = nvals of fwd m, dp, dm; out[3] = multi pairs; out[4] = nvals of mt (effective) */
+int fh_tensor_state(fh_graph* g, uint64_t type_id, uint64_t out[5]);
+
+/* ---- operators ---------------------------------------------------------------------------------------
+ * `spec` is "key=value;..." with keys: src=<labels,>  hop=<types,>|<dst labels,> (repeatable: hop 0 then the
+ * fused chain)  optional= bind= emit= bidir= siblings= attrs= (0/1).
+ * src[i] / to_bound[i]: node id, -1 = unbound, -2 = bound to NULL / a non-node. */
+int fh_cond_traverse_batch(fh_graph* g, const char* spec, const int64_t* src, const int64_t* to_bound,
+                           uint64_t k, int* batched, uint64_t** out_row, uint64_t** out_dest,
+                           int64_t** out_edge, uint64_t* n, uint64_t** null_rows, uint64_t* n_null,
+                           uint64_t* flops);                                            /* cond_traverse.rs:452-751 */
+int fh_cond_traverse_eligible(const char* spec);                                       /* cond_traverse.rs:308-316 */
+int fh_cond_traverse_row(fh_graph* g, const char* spec, int64_t from_id, int64_t to_id, int transposed,
+                         uint64_t** out_from, uint64_t** out_to, uint64_t** out_edge, uint64_t* n); /* :758-1117 */
+/* types: comma list ("" = all).  batched != 0 runs the whole input through one set of device probes. */
+int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_relationship, int batched,
+                   const uint64_t* srcs, const uint64_t* dsts, uint64_t k, uint64_t** out_row,
+                   uint64_t** out_src, uint64_t** out_dst, uint64_t** out_edge, uint64_t* n);  /* expand_into.rs:121-258 */
+/* source < 0 = NULL; rel_type NULL = all types */
+int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges,
+                int* has_row, uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges); /* algo_procedures.rs:1021-1160 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FALKOR_HOST_H */

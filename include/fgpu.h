@@ -67,7 +67,8 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * flight per wavefront of the LDS-tiled vxm: 1/2/4/8), "tiled_threads" (256/512/1024),
  * "tiled_wgs" (grid of that kernel, 0 = fill the CUs), "tiled_nt" (nontemporal entry loads),
  * "expand_mode" (fgpu_expand: 0 = pick per hop, 1 = sorted-CSR products only, 2 = bit-parallel from the
- * first hop), "bfs_wgs_per_cu" (grid of the fused BFS level kernel). */
+ * first hop), "bfs_wgs_per_cu" (grid of the fused BFS level kernel), "merge_mode" (fgpu_mat_merge:
+ * 0 = entry-parallel, 1 = one wavefront per row, pattern layers only). */
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
 /* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */
 fgpu_info fgpu_device_info(fgpu_ctx* ctx, char* name, int32_t* cus, int32_t* wave,
@@ -140,6 +141,17 @@ fgpu_info fgpu_mat_probe(fgpu_ctx* ctx, const fgpu_mat* m, const uint64_t* rows,
  * (true,true) arm (mask applies to the whole union). */
 fgpu_info fgpu_mat_merge(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
                          const fgpu_mat* dm, int dm_masks_dp);
+/* The same merge with the values dropped: out = pattern((m \ dm) U dp), a BOOL snapshot in one pass —
+ * Tensor::extract (tensor.rs:838-850), Matrix::set_pattern = GrB_Matrix_apply(GxB_ONE_BOOL)
+ * (matrix.rs:906-924), and with dp = dm = NULL the plain structure copy of a UINT64 layer that
+ * build_relationship_matrix_unrestricted / build_adjacency_matrix start from (graph.rs:2520-2549, 3870-3894). */
+fgpu_info fgpu_mat_merge_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
+                                 const fgpu_mat* dm, int dm_masks_dp);
+/* GrB_Matrix_resize (Matrix::resize, matrix.rs:576-598; the `grown` re-emit of tensor.rs:613-667):
+ * a new snapshot of `a` at nrows x ncols; every entry keeps its coordinate and value, entries at or
+ * past the new dims are dropped (grown fixture: matrix.rs:1617-1672). */
+fgpu_info fgpu_mat_resize(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t nrows,
+                          uint64_t ncols);
 /* Pattern intersection (K7): eWiseMult ANY_PAIR (matrix.rs:876-896); values from `b`. */
 fgpu_info fgpu_mat_intersect(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, const fgpu_mat* b);
 /* intersection_nvals (matrix.rs:743-761). */

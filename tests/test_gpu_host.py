@@ -1,0 +1,651 @@
+"""GPU parity of the C++ host layer (libfalkor_host.so -> libfgpu.so): Matrix<T>, VersionedMatrix, Tensor,
+the Graph slice and the CondTraverse / ExpandInto / algo.BFS operators, replayed against
+  * the reference's own fixtures (tests/golden/*.json, generated from /root/reference), and
+  * the pure-Python oracle state machines (oracle/model.py), op for op.
+Every case cites the reference test or method it mirrors (file:line relative to /root/reference)."""
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import model
+from falkordb_amd import host
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+PINS = gold("rust_unit_pins.json")
+
+
+@pytest.fixture(scope="module")
+def hctx():
+    c = host.Context(0)
+    yield c
+    c.close()
+
+
+# ---- Matrix<T> (graphblas/matrix.rs unit tests) -----------------------------------------------------
+def test_matrix_build_collapses_duplicates(hctx):          # matrix.rs:1686-1695
+    p = PINS["dup_collapse"]
+    m = host.Matrix(hctx, host.Matrix.BOOL, 4, 4)
+    m.build(p["rows"], p["cols"])
+    want = sorted(set(zip(p["rows"], p["cols"])))
+    assert m.nvals() == len(want)
+    assert [(r, c) for r, c, _ in m.iter()] == want
+    assert all(v == 1 for _, _, v in m.iter())               # bool build is iso / pattern-only (:1709-1775)
+
+
+@pytest.mark.parametrize("shape", [(64, 48, 64, 96), (64, 48, 128, 48), (64, 48, 128, 96), (64, 48, 73, 55),
+                                   (64, 48, 64, 48)])
+def test_grown_preserves_every_entry(hctx, shape):         # matrix.rs:1617-1672
+    r0, c0, r1, c1 = shape
+    coords = [(i, (7 * i) % 48) for i in range(64)] + [(i, (11 * i + 3) % 48) for i in range(64)]
+    vals = {rc: 1000 + k for k, rc in enumerate(coords)}     # later duplicate wins
+    u = host.Matrix(hctx, host.Matrix.UINT64, r0, c0)
+    u.build([c[0] for c in coords], [c[1] for c in coords], [1000 + k for k in range(len(coords))])
+    g = u.grown(r1, c1)
+    assert g.dims() == (r1, c1)
+    assert {(r, c): v for r, c, v in g.iter()} == vals
+    assert u.dims() == (r0, c0) and u.nvals() == len(vals)   # the source is untouched
+    b = host.Matrix(hctx, host.Matrix.BOOL, r0, c0)
+    b.build([c[0] for c in coords], [c[1] for c in coords])
+    gb = b.grown(r1, c1)
+    assert sorted((r, c) for r, c, _ in gb.iter()) == sorted(vals)
+    assert all(v == 1 for _, _, v in gb.iter())              # bool stays pattern
+
+
+def test_resize_shrink_drops_entries_past_the_new_dims(hctx):   # matrix.rs:576-598
+    m = host.Matrix(hctx, host.Matrix.UINT64, 10, 10)
+    m.build([0, 3, 9, 9, 5], [0, 9, 2, 9, 5], [10, 11, 12, 13, 14])
+    m.resize(9, 6)
+    assert m.dims() == (9, 6)
+    assert m.iter() == [(0, 0, 10), (5, 5, 14)]
+
+
+def test_matrix_pending_tuples_and_wait(hctx):             # matrix.rs:764-804, 1174-1184, 664-676
+    m = host.Matrix(hctx, host.Matrix.UINT64, 8, 8)
+    assert not m.pending() and m.nvals() == 0
+    m.set(1, 2, 77)
+    m.set(1, 3, 5)
+    m.set(1, 2, 78)                                          # last write wins
+    assert m.pending()
+    assert m.get(1, 2) == 78 and not m.pending()             # extractElement finishes pending work
+    m.remove(1, 3)
+    m.remove(6, 6)                                           # removing an absent entry is a no-op
+    assert m.get(1, 3) is None and m.get(6, 6) is None
+    assert m.nvals() == 1
+    d = m.dup()
+    d.set(0, 0, 1)
+    assert d.nvals() == 2 and m.nvals() == 1                 # dup is a deep copy (:370-385)
+    with pytest.raises(host.HostError):
+        m.set(8, 0, 1)                                       # GrB_INDEX_OUT_OF_BOUNDS
+
+
+def test_matrix_products_match_the_oracle(hctx):           # matrix.rs:930-968, 1317-1402
+    rng = np.random.default_rng(5)
+    a = oracle.rmat_csr(9)
+    n = a.nrows
+    ar, ac = a.pairs()
+    A = host.Matrix(hctx, host.Matrix.BOOL, n, n)
+    A.build(ar, ac)
+    fr = np.arange(40, dtype=np.uint64)
+    fc = rng.integers(0, n, 40).astype(np.uint64)
+    f = oracle.build_csr(40, n, fr, fc)
+    F = host.Matrix(hctx, host.Matrix.BOOL, 40, n)
+    F.build(fr, fc)
+    F.lmxm(A)
+    want, _ = oracle.mxm(f, a)
+    assert [(r, c) for r, c, _ in F.iter()] == sorted(want.to_set())
+    # rmxm: self = b * self
+    G = host.Matrix(hctx, host.Matrix.BOOL, n, n)
+    G.build(ar, ac)
+    F2 = host.Matrix(hctx, host.Matrix.BOOL, 40, n)
+    F2.build(fr, fc)
+    G.rmxm(F2)
+    assert [(r, c) for r, c, _ in G.iter()] == sorted(want.to_set())
+    # delta_lmxm with non-empty dp / dm
+    dm_idx = rng.choice(a.nnz, 200, replace=False)
+    dmr, dmc = ar[dm_idx], ac[dm_idx]
+    dpr, dpc = rng.integers(0, n, 300).astype(np.uint64), rng.integers(0, n, 300).astype(np.uint64)
+    DP = host.Matrix(hctx, host.Matrix.BOOL, n, n); DP.build(dpr, dpc)
+    DM = host.Matrix(hctx, host.Matrix.BOOL, n, n); DM.build(dmr, dmc)
+    F3 = host.Matrix(hctx, host.Matrix.BOOL, 40, n); F3.build(fr, fc)
+    F3.delta_lmxm(A, DP, DM)
+    w, _ = oracle.delta_lmxm(f, a, oracle.build_csr(n, n, dpr, dpc), oracle.build_csr(n, n, dmr, dmc))
+    assert [(r, c) for r, c, _ in F3.iter()] == sorted(w.to_set())
+    assert A.intersection_nvals(DM) == len(set(zip(dmr.tolist(), dmc.tolist())))
+
+
+def test_transpose_carries_values(hctx):                   # matrix.rs:633-662
+    rng = np.random.default_rng(11)
+    n = 6000
+    r = rng.integers(0, n, n).astype(np.uint64)
+    c = rng.integers(0, 50, n).astype(np.uint64)
+    v = rng.integers(0, 1 << 62, n).astype(np.uint64)
+    m = host.Matrix(hctx, host.Matrix.UINT64, n, 50)
+    m.build(r, c, v)
+    want = {}
+    for a, b, x in zip(r.tolist(), c.tolist(), v.tolist()):
+        want[(b, a)] = x                                     # last duplicate wins
+    t = m.transpose()
+    assert t.dims() == (50, n)
+    assert {(a, b): x for a, b, x in t.iter()} == want
+
+
+# ---- VersionedMatrix (graphblas/versioned_matrix.rs unit tests) -----------------------------------------
+def lcg_next(state):                                       # versioned_matrix.rs:1380-1385
+    p = PINS["lcg_model"]
+    state = (state * p["mul"] + p["add"]) & ((1 << 64) - 1)
+    return state, state >> p["shift"]
+
+
+def check_invariants(v: host.VersionedMatrix, ref: set):   # versioned_matrix.rs:1345-1377
+    it = v.iter()
+    assert it == sorted(ref)
+    assert v.nvals() == len(ref)
+    ext = v.extract()
+    assert [(r, c) for r, c, _ in ext.iter()] == sorted(ref)
+    st = v.state()
+    assert st["m"] + st["dp"] - st["dm"] == len(ref)         # dp & m = {}, dm subset of m
+
+
+def test_delta_invariants_hold_across_mutation_sequences(hctx):   # versioned_matrix.rs:1399-1472
+    p = PINS["lcg_model"]
+    dim = p["dim"]
+    v = host.VersionedMatrix(hctx, dim, dim)
+    o = model.VersionedMatrix(dim, dim)
+    ref = set()
+    rng = p["seed"]
+    key = lambda r: ((r % 24) * 7, (r // 24 % 24) * 11)
+
+    def rnd():
+        nonlocal rng
+        rng, out = lcg_next(rng)
+        return out
+
+    folded = False
+    for step in range(p["steps"]):
+        op = rnd() % 16
+        if op == 0:
+            batch = [key(rnd()) for _ in range(16)]
+            v.set_all(batch, new=False); o.set_all(batch, new=False)
+            ref.update(batch)
+        elif op == 1:
+            batch = sorted({key(rnd()) for _ in range(16)})
+            v.remove_mask(batch); o.remove_mask(batch)
+            ref.difference_update(batch)
+        elif op == 2:
+            v = v.dup(); o = o.dup()
+        elif op == 3:
+            v.wait(); o.wait()
+        elif op == 4:
+            v.fold_oversized(); o.fold_oversized()
+        elif 5 <= op <= 8:
+            k = key(rnd())
+            v.remove(*k); o.remove(*k)
+            ref.discard(k)
+        else:
+            k = key(rnd())
+            v.set(*k); o.set(k[0], k[1], True)
+            ref.add(k)
+        if step % p["check_stride"] == 0:
+            check_invariants(v, ref)                         # reads go through wait() (fold decisions latch there)
+            assert o.iter() == sorted(ref) and o.nvals() == len(ref)   # the same reads on the oracle
+            # layer for layer the same state as the oracle state machine (fold decisions included)
+            o.wait_all()
+            st = v.state()
+            assert (st["m"], st["dp"], st["dm"]) == (len(o.m), len(o.dp.layer), len(o.dm.layer)), step
+            assert st["needs_flush"] == o.needs_flush
+            folded = folded or st["m"] > 0
+    check_invariants(v, ref)
+    assert folded, "no fold ever happened: the `m` branches of set/remove were never taken"
+
+
+def test_folded_entry_deleted_and_re_added_stays_out_of_dp(hctx):  # versioned_matrix.rs:1481-1523
+    p = PINS["refold_probe"]
+    DIM, filler = p["dim"], p["filler"]
+    v = host.VersionedMatrix(hctx, DIM, DIM)
+    v.set_all([(i % DIM, (i // DIM + 1) % DIM) for i in range(filler)], new=False)
+    probe = tuple(p["probe"])
+    v.set(*probe)
+    v = v.dup()
+    v.set(*p["trigger"])
+    v.wait()
+    st = v.state()
+    assert st["m"] == filler + 1 and st["dp"] == 1           # the dup's latched fold ran before the first mutation
+    v.remove(*probe)
+    assert v.get(*probe) is None
+    st = v.state()
+    assert st["dm"] == 1
+    v.set(*probe)
+    assert v.get(*probe) is True
+    st = v.state()
+    assert st["dm"] == 0 and st["dp"] == 1                   # un-deleted, NOT re-added to dp
+    assert v.nvals() == p["final_nvals"] == filler + 2
+
+
+def test_versioned_matrix_transpose_and_from_matrix(hctx):   # versioned_matrix.rs:877-890, 1070-1079
+    rows, cols = [0, 0, 3, 5, 5], [1, 4, 3, 0, 2]
+    v = host.VersionedMatrix.from_coo(hctx, 6, 7, rows, cols)
+    v.set(2, 6)
+    v.remove(0, 4)
+    live = (set(zip(rows, cols)) | {(2, 6)}) - {(0, 4)}
+    assert v.iter() == sorted(live)
+    t = v.transpose()
+    assert t.iter() == sorted((c, r) for r, c in live)
+    assert t.state()["dp"] == 1 and t.state()["dm"] == 1
+
+
+# ---- Tensor state machine (graphblas/tensor.rs:72-108; tests at :1340-1669) ---------------------------------
+class TensorModel:
+    """(src, dst) -> sorted edge ids; the observable behaviour every layer state must reproduce."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def add(self, s, d, e):
+        self.pairs.setdefault((s, d), [])
+        if e not in self.pairs[(s, d)]:
+            self.pairs[(s, d)].append(e)
+            self.pairs[(s, d)].sort()
+
+    def remove(self, s, d, e):
+        ids = self.pairs.get((s, d), [])
+        if e in ids:
+            ids.remove(e)
+            if not ids:
+                del self.pairs[(s, d)]
+
+    def edges(self):
+        return sorted((s, d, e) for (s, d), ids in self.pairs.items() for e in ids)
+
+
+def check_tensor(g: host.Graph, t, mdl: TensorModel, n):
+    assert sorted(g.tensor_iter_edges(t)) == mdl.edges()
+    assert g.tensor_edge_count(t) == len(mdl.edges())
+    st = g.tensor_state(t)
+    assert st["multi_pairs"] == sum(1 for ids in mdl.pairs.values() if len(ids) > 1)
+    assert st["mt"] == len(mdl.pairs)                        # mt mirrors the effective forward structure
+    for (s, d), ids in mdl.pairs.items():
+        assert g.tensor_get(t, s, d) == ids
+
+
+@pytest.mark.parametrize("commits", list(itertools.product([False, True], repeat=5)),
+                         ids=lambda c: "".join("C" if x else "-" for x in c))
+def test_multiple_edges_lifecycle_ids(hctx, commits):      # tests/flow/test_multiple_edges.py:11-96
+    steps = gold("multiple_edges.json")["steps"]
+    g = host.Graph(hctx, 2)
+    t = g.add_type("R")
+    mdl = TensorModel()
+    assert g.tensor_get(t, 0, 1) == steps[0]["ids"]
+    for st, commit in zip(steps[1:], commits):
+        if st["op"] == "add":
+            g.create_edge(t, 0, 1, st["id"]); mdl.add(0, 1, st["id"])
+        else:
+            g.delete_edge(t, 0, 1, st["id"]); mdl.remove(0, 1, st["id"])
+        assert g.tensor_get(t, 0, 1) == st["ids"], (st, commits)
+        check_tensor(g, t, mdl, 2)
+        # the pair is in the adjacency matrix exactly while it holds an edge
+        rows = g.cond_traverse_batch(host.cond_spec(hops=[([], [])]), [0])[0]
+        assert [d for _, d in rows] == ([1] if st["ids"] else [])
+        if commit:
+            g.commit()
+            assert g.tensor_get(t, 0, 1) == st["ids"], ("after commit", st, commits)
+            check_tensor(g, t, mdl, 2)
+
+
+def test_tensor_random_walk_matches_the_pair_model(hctx):  # tensor.rs:1340-1669 (promote / demote / cancel / fold)
+    rng = np.random.default_rng(2024)
+    n = 12
+    g = host.Graph(hctx, n)
+    t = g.add_type("R")
+    mdl = TensorModel()
+    next_id = 0
+    live = []
+    for step in range(400):
+        op = rng.integers(0, 10)
+        if op < 5 or not live:
+            k = int(rng.integers(1, 5))
+            s = rng.integers(0, 4, k).tolist()
+            d = rng.integers(0, 4, k).tolist()
+            ids = list(range(next_id, next_id + k))
+            next_id += k
+            g.create_edges(t, s, d, ids)
+            for a, b, e in zip(s, d, ids):
+                mdl.add(a, b, e)
+                live.append((a, b, e))
+        elif op < 9:
+            a, b, e = live.pop(int(rng.integers(0, len(live))))
+            g.delete_edge(t, a, b, e)
+            mdl.remove(a, b, e)
+        else:
+            g.commit()
+        if step % 7 == 0:
+            check_tensor(g, t, mdl, n)
+    check_tensor(g, t, mdl, n)
+    # the adjacency matrix tracks pairs with >= 1 edge
+    rows, _, _ = g.cond_traverse_batch(host.cond_spec(hops=[([], [])]), list(range(n)))
+    assert sorted(rows) == sorted(mdl.pairs)
+
+
+def test_bulk_delete_folds_tombstones_at_commit(hctx):     # tensor.rs:1590-1669 (delete-all folds tombstones)
+    n = 2000
+    g = host.Graph(hctx, n)
+    t = g.add_type("R")
+    s = np.arange(n - 1)
+    g.create_edges(t, s, s + 1, np.arange(n - 1))
+    g.commit()                                               # dp dominates an empty base: folded into m
+    st = g.tensor_state(t)
+    assert (st["m"], st["dp"], st["dm"]) == (n - 1, 0, 0)
+    for i in range(0, n - 1):
+        g.delete_edge(t, i, i + 1, i)
+    st = g.tensor_state(t)
+    assert (st["m"], st["dp"], st["dm"]) == (n - 1, 0, n - 1)
+    assert g.tensor_edge_count(t) == 0
+    g.commit()                                               # escape hatch: 2|dm| >= |m|
+    st = g.tensor_state(t)
+    assert (st["m"], st["dp"], st["dm"]) == (0, 0, 0)
+    assert g.tensor_iter_edges(t) == []
+
+
+# ---- social graph known answers through the operators (tests/flow/social) ----------------------------------
+def social(hctx, commit):
+    s = gold("social.json")
+    names = [p["name"] for p in s["persons"]] + s["countries"]
+    ids = {n: i for i, n in enumerate(names)}
+    g = host.Graph(hctx, len(names))
+    lp, lc = g.add_label("person"), g.add_label("country")
+    for p in s["persons"]:
+        g.label_node(ids[p["name"]], lp)
+    for c in s["countries"]:
+        g.label_node(ids[c], lc)
+    tf, tv = g.add_type("friend"), g.add_type("visited")
+    eid = 0
+    for a, b, _purpose in s["visits"]:
+        g.create_edge(tv, ids[a], ids[b], eid); eid += 1
+    if commit:
+        g.commit()
+    for a, b in s["friends"]:
+        g.create_edge(tf, ids[a], ids[b], eid); eid += 1
+    if commit:
+        g.commit()
+    return s, g, ids, names
+
+
+@pytest.mark.parametrize("commit", [False, True], ids=["pending-deltas", "committed"])
+def test_social_queries(hctx, commit):                     # social_queries.py:57-80
+    s, g, ids, names = social(hctx, commit)
+    roi = ids["Roi Lipman"]
+    one = host.cond_spec(src_labels=["person"], hops=[(["friend"], ["person"])])
+    rows, nulls, _ = g.cond_traverse_batch(one, [roi])
+    assert sorted(names[d] for _, d in rows) == sorted(r[0] for r in s["queries"]["my_friends_query"]["expected"])
+    mids = [d for _, d in rows]
+    rows2, _, _ = g.cond_traverse_batch(host.cond_spec(hops=[(["friend"], ["person"])]), mids)
+    fof = [names[d] for _, d in rows2]
+    assert sorted(fof) == sorted(r[0] for r in s["queries"]["friends_of_friends_query"]["expected"])
+    # anonymous unlabeled intermediate: ONE fused CondTraverse with a chain (fuse_anonymous_traverse.rs:83-188)
+    fused = host.cond_spec(src_labels=["person"], hops=[(["friend"], []), (["friend"], ["person"])])
+    rows3, _, flops = g.cond_traverse_batch(fused, [roi])
+    assert sorted(names[d] for _, d in rows3) == sorted(set(fof))
+    assert flops > 0
+    # visited Netherlands and single
+    attrs = {p["name"]: p for p in s["persons"]}
+    singles = [ids[n] for n in fof if attrs[n]["status"] == "single"]
+    rows4, _, _ = g.cond_traverse_batch(host.cond_spec(hops=[(["visited"], ["country"])]), singles)
+    got = sorted({names[singles[i]] for i, d in rows4 if names[d] == "Netherlands"})
+    assert got == [r[0] for r in s["queries"]["friends_of_friends_visited_netherlands_and_single_query"]["expected"]]
+    # relation counts
+    want = dict(map(tuple, s["queries"]["relation_type_counts"]["expected"]))
+    assert g.tensor_edge_count(0) == want["friend"] and g.tensor_edge_count(1) == want["visited"]
+
+
+# ---- algo.BFS known answers (tests/flow/test_bfs.py:10-25, 63-213) ------------------------------------------
+def bfs5(hctx, commit):
+    b = gold("bfs5.json")
+    ids = {n: i for i, n in enumerate(b["nodes"])}
+    g = host.Graph(hctx, len(ids))
+    for eid, (s, d, t) in enumerate(b["edges"]):
+        g.create_edge(g.add_type(t), ids[s], ids[d], eid)
+    if commit:
+        g.commit()
+    return b, g, ids
+
+
+@pytest.mark.parametrize("commit", [False, True], ids=["pending-deltas", "committed"])
+def test_algo_bfs_known_answers(hctx, commit):
+    b, g, ids = bfs5(hctx, commit)
+    names = b["nodes"]
+    dst_of = {eid: d for eid, (s, d, t) in enumerate(b["edges"])}
+    for case in b["cases"]:
+        res = g.algo_bfs(ids[case["src"]], case["depth"], case["type"], want_edges="edges_dst" in case)
+        if case["nodes"] is None:
+            assert res is None, case
+            continue
+        nodes, edges = res
+        assert nodes == sorted(nodes)                        # ascending index of the level vector
+        assert sorted(names[v] for v in nodes) == sorted(case["nodes"]), case
+        if "edges_dst" in case:
+            assert sorted(dst_of[e] for e in edges) == sorted(case["edges_dst"]), case
+    assert g.algo_bfs(None) is None                          # NULL source: no row
+    g.delete_node(ids[b["cases"][0]["src"]])
+    with pytest.raises(host.HostError):                      # deleted source: error (algo_procedures.rs:1058-1064)
+        g.algo_bfs(ids[b["cases"][0]["src"]])
+
+
+# ---- ExpandInto known answers (tests/flow/test_expand_into.py:17-95) ----------------------------------------
+@pytest.mark.parametrize("case", gold("expand_into.json")["cases"], ids=lambda c: c["name"])
+@pytest.mark.parametrize("batched", [False, True], ids=["per-row", "batched"])
+def test_expand_into_known_answers(hctx, case, batched):
+    g = host.Graph(hctx, case["nodes"])
+    for eid, (s, d, t) in enumerate(case["edges"]):
+        g.create_edge(g.add_type(t), s, d, eid)
+    a, b = case["a"], case["b"]
+    if "count_named_edge" in case:
+        named = g.expand_into(case["types"], [a], [b], emit_relationship=True, batched=batched)
+        anon = g.expand_into(case["types"], [a], [b], emit_relationship=False, batched=batched)
+        assert len(named) == case["count_named_edge"] and len(anon) == case["count_pairs"]
+    if "two_hop_rows" in case:
+        spec = host.cond_spec(hops=[(["R"], []), ([], [])])
+        rows, _, _ = g.cond_traverse_batch(spec, [a], to_bound=[b])
+        assert len(rows) == case["two_hop_rows"]
+        if "expected_count" in case:
+            assert case["varlen_trails"] * len(rows) == case["expected_count"]
+
+
+# ---- operators on a random R-MAT graph with labels and dirty deltas vs the oracle --------------------------
+def build_random(hctx, scale=9, seed=3):
+    rng = np.random.default_rng(seed)
+    a = oracle.rmat_csr(scale)
+    n = a.nrows
+    er, ec = a.pairs()
+    g = host.Graph(hctx, n)
+    og = model.Graph(n)
+    labels = ["P", "Q"]
+    lids = [g.add_label(l) for l in labels]
+    for l in labels:
+        og.add_label(l)
+    for v in range(n):
+        for k, lid in enumerate(lids):
+            if (oracle.mix64(np.uint64(v * 7 + k))) % np.uint64(3 + k) == 0:
+                g.label_node(v, lid)
+                og.node_labels.add((v, lid))
+    types = ["A", "B"]
+    tids = [g.add_type(t) for t in types]
+    for t in types:
+        og.add_type(t)
+    split = rng.integers(0, 2, len(er))
+    eid = 0
+    per_type = {0: {}, 1: {}}
+    for k in (0, 1):
+        sel = np.nonzero(split == k)[0]
+        s, d = er[sel], ec[sel]
+        ids = np.arange(eid, eid + len(sel))
+        eid += len(sel)
+        g.create_edges(tids[k], s, d, ids)
+        for x, y, e in zip(s.tolist(), d.tolist(), ids.tolist()):
+            per_type[k][(x, y)] = [e]
+    g.commit()   # everything so far lands in the committed bases (dp dominates the empty base)
+    # a second transaction: extra parallel edges (promotions), fresh pairs (dp) and deletions (dm)
+    for k in (0, 1):
+        keys = list(per_type[k])
+        for j in rng.choice(len(keys), 60, replace=False):
+            x, y = keys[j]
+            g.create_edge(tids[k], x, y, eid)
+            per_type[k][(x, y)].append(eid); eid += 1
+        for _ in range(80):
+            x, y = int(rng.integers(0, n)), int(rng.integers(0, n))
+            if (x, y) in per_type[k]:
+                continue
+            g.create_edge(tids[k], x, y, eid)
+            per_type[k][(x, y)] = [eid]; eid += 1
+        for j in rng.choice(len(keys), 120, replace=False):
+            x, y = keys[j]
+            for e in list(per_type[k].get((x, y), [])):
+                g.delete_edge(tids[k], x, y, e)
+            per_type[k].pop((x, y), None)
+    # mirror the final state into the oracle graph (as committed layers: the oracle's operators read
+    # only the effective state, which is what must agree)
+    for k in (0, 1):
+        for (x, y), es in per_type[k].items():
+            og.tensors[k].m[(x, y)] = es[0] if len(es) == 1 else model.MULTI_EDGE
+            if len(es) > 1:
+                og.tensors[k].me[(x, y)] = sorted(es)
+            og.adjacency.m.add((x, y))
+    return g, og, n, per_type
+
+
+@pytest.fixture(scope="module")
+def rnd_graph(hctx):
+    return build_random(hctx)
+
+
+CASES = [
+    dict(types=["A"], src_labels=[], dst_labels=[], chain=[]),
+    dict(types=[], src_labels=["P"], dst_labels=["Q"], chain=[]),
+    dict(types=["A", "B"], src_labels=[], dst_labels=["P"], chain=[]),
+    dict(types=["A"], src_labels=["P"], dst_labels=[], chain=[(["B"], ["Q"])]),
+    dict(types=[], src_labels=[], dst_labels=[], chain=[([], []), (["A"], ["P"])]),
+    dict(types=["B"], src_labels=[], dst_labels=[], chain=[], bind=True),
+    dict(types=[], src_labels=["Q"], dst_labels=["P"], chain=[], bind=True),
+    dict(types=["A"], src_labels=[], dst_labels=[], chain=[], optional=True),
+    dict(types=["Nope"], src_labels=[], dst_labels=[], chain=[], optional=True),
+    dict(types=["A"], src_labels=["NoSuchLabel"], dst_labels=[], chain=[]),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: json.dumps(c, separators=(",", ":"))[:60])
+def test_expand_batch_matches_the_oracle(rnd_graph, case):   # cond_traverse.rs:452-751
+    g, og, n, _ = rnd_graph
+    rng = np.random.default_rng(17)
+    src = rng.integers(0, n, 200).tolist()
+    hops = [(case["types"], case["dst_labels"])] + [tuple(h) for h in case["chain"]]
+    spec = host.cond_spec(src_labels=case["src_labels"], hops=hops, optional=case.get("optional", False),
+                          bind=case.get("bind", False))
+    got = g.cond_traverse_batch(spec, src)
+    want = model.expand_batch(og, src, case["types"], src_labels=case["src_labels"], dst_labels=case["dst_labels"],
+                              chain=case["chain"], optional=case.get("optional", False),
+                              bind_relationship=case.get("bind", False))
+    assert got is not None
+    rows, nulls, flops = got
+    assert rows == want[0]                                   # emission order: ascending (row, dest)
+    assert nulls == want[1]
+
+
+def test_expand_batch_to_bound_and_null_sources(rnd_graph):  # cond_traverse.rs:566-575, 657-661
+    g, og, n, _ = rnd_graph
+    src = [5, None, 9, 300, 17]
+    spec = host.cond_spec(hops=[(["A"], [])])
+    assert g.cond_traverse_batch(spec, src) is None          # non-node source, not optional: per-row fallback
+    assert model.expand_batch(og, src, ["A"]) is None
+    spec_o = host.cond_spec(hops=[(["A"], [])], optional=True)
+    rows, nulls, _ = g.cond_traverse_batch(spec_o, src)
+    want = model.expand_batch(og, src, ["A"], optional=True)
+    assert (rows, nulls) == want
+    full, _, _ = g.cond_traverse_batch(spec, [5, 9, 300, 17])
+    tb = [None, full[0][1] if full else 0, None, 1]
+    rows, _, _ = g.cond_traverse_batch(spec, [5, 9, 300, 17], to_bound=tb)
+    assert rows == model.expand_batch(og, [5, 9, 300, 17], ["A"], to_bound=tb)[0]
+
+
+def test_expand_row_fallback_matches_brute_force(rnd_graph):   # cond_traverse.rs:758-1117
+    g, og, n, per_type = rnd_graph
+    a = per_type[0]
+    srcs = sorted({s for s, _ in a})[:10]
+    spec = host.cond_spec(hops=[(["A"], [])], emit=True)
+    for s in srcs:
+        got = g.cond_traverse_row(spec, from_id=s)
+        want = sorted((s, d, e) for (x, d), es in a.items() if x == s for e in es)
+        assert sorted(got) == want
+    # only the destination bound: walked over the transposed structure
+    dsts = sorted({d for _, d in a})[:10]
+    for d in dsts:
+        got = g.cond_traverse_row(spec, to_id=d)
+        want = sorted((x, d, e) for (x, y), es in a.items() if y == d for e in es)
+        assert sorted(got) == want
+    # anonymous edge: one representative (the smallest id of the first type that has one) per pair
+    anon = host.cond_spec(hops=[(["A"], [])], emit=False)
+    for s in srcs[:4]:
+        got = g.cond_traverse_row(anon, from_id=s)
+        want = sorted((s, d, es[0]) for (x, d), es in a.items() if x == s)
+        assert sorted(got) == want
+
+
+def test_expand_into_batch_matches_the_oracle(rnd_graph):    # expand_into.rs:121-258
+    g, og, n, per_type = rnd_graph
+    rng = np.random.default_rng(23)
+    pairs = list(per_type[0])[:150] + list(per_type[1])[:150] + \
+        [(int(x), int(y)) for x, y in rng.integers(0, n, (100, 2))]
+    srcs, dsts = [p[0] for p in pairs], [p[1] for p in pairs]
+    for types, bidir, emit in [(["A"], False, True), (["A", "B"], True, True), ([], True, False), (["B"], False, False)]:
+        got = g.expand_into(types, srcs, dsts, bidirectional=bidir, emit_relationship=emit, batched=True)
+        want = []
+        for i, (s, d) in enumerate(pairs):
+            want += [(i,) + t for t in model.expand_into_row(og, s, d, types, bidirectional=bidir,
+                                                             emit_relationship=emit)]
+        assert got == want
+        sample = list(range(0, len(pairs), 37))
+        one = g.expand_into(types, [srcs[i] for i in sample], [dsts[i] for i in sample], bidirectional=bidir,
+                            emit_relationship=emit, batched=False)
+        want1 = []
+        for j, i in enumerate(sample):
+            want1 += [(j,) + t for t in model.expand_into_row(og, srcs[i], dsts[i], types, bidirectional=bidir,
+                                                              emit_relationship=emit)]
+        assert one == want1
+
+
+def test_algo_bfs_matches_the_oracle_on_rmat(rnd_graph):     # algo_procedures.rs:1021-1160
+    g, og, n, per_type = rnd_graph
+    deg = {}
+    for (s, d) in og.adjacency.m:
+        deg[s] = deg.get(s, 0) + 1
+    src = max(deg, key=deg.get)
+    for rel, depth in [(None, -1), ("A", -1), ("B", 2), (None, 1)]:
+        got = g.algo_bfs(src, depth, rel, want_edges=True)
+        want = model.algo_bfs(og, src, depth, rel, want_edges=True)
+        assert (got is None) == (want is None)
+        if got is None:
+            continue
+        assert got[0] == want[0]                             # same reachable set, ascending
+        assert len(got[1]) == len(want[1])
+        # parents are ANY-valid: every edge returned must end at its node and start one level up
+        types = [rel] if rel else []
+        adj = og.build_adjacency_matrix(types)
+        level, _, _ = oracle.bfs(adj, src, depth, want_parent=False)
+        by_edge = {}
+        for k in ((0, 1) if rel is None else (og.type_ids[rel],)):
+            for (s, d), es in per_type[k].items():
+                for e in es:
+                    by_edge[e] = (s, d)
+        for v, e in zip(got[0], got[1]):
+            s, d = by_edge[e]
+            assert d == v and level[s] + 1 == level[v]

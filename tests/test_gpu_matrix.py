@@ -126,6 +126,101 @@ def test_merge_delta_layers(ctx, masks_dp):
     assert_same(got, oracle.merge(m, dp, dm, masks_dp))
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_merge_rmat_hub_rows_both_kernels(ctx, mode):
+    # the entry-parallel merge (merge.hip) and the wavefront-per-row one agree with the oracle on a skewed graph
+    a = oracle.rmat_csr(14)
+    n = a.nrows
+    rng = np.random.default_rng(9)
+    ar, ac = a.pairs()
+    kill = rng.choice(a.nnz, a.nnz // 50, replace=False)
+    hub = int(np.argmax(np.diff(a.rowptr.astype(np.int64))))
+    hub_cols = a.row(hub)
+    dr = np.concatenate([ar[kill], np.full(len(hub_cols) // 2, hub, dtype=np.uint64)])
+    dc = np.concatenate([ac[kill], hub_cols[::2][:len(hub_cols) // 2]])
+    pr, pc = rand_coo(rng, n, n, 5000)
+    pr = np.concatenate([pr, np.full(3000, hub, dtype=np.uint64)])
+    pc = np.concatenate([pc, rng.integers(0, n, 3000, dtype=np.uint64)])
+    ctx.set_option("merge_mode", mode)
+    try:
+        for masks_dp in (False, True):
+            got = ctx.mat_rmat(14).merge(ctx.mat_from_coo(n, n, pr, pc), ctx.mat_from_coo(n, n, dr, dc),
+                                         dm_masks_dp=masks_dp)
+            assert_same(got, oracle.merge(a, oracle.build_csr(n, n, pr, pc), oracle.build_csr(n, n, dr, dc), masks_dp))
+        assert_same(ctx.mat_rmat(14).merge(None, None), a)
+        assert_same(ctx.mat_new(n, n).merge(ctx.mat_from_coo(n, n, pr, pc), None), oracle.build_csr(n, n, pr, pc))
+    finally:
+        ctx.set_option("merge_mode", 0)
+
+
+@pytest.mark.parametrize("n_tuples", [900, 40000])
+def test_merge_u64_layers_dp_value_wins(ctx, n_tuples):
+    # Tensor::flush (tensor.rs:741-797): new_m<!dm> = m (+) dp with GrB_SECOND_UINT64 — on device, both the
+    # short-list and the device COO builder (>= 4096 tuples) feeding it
+    rng = np.random.default_rng(n_tuples)
+    n = 3000
+    r, c = rand_coo(rng, n, n, n_tuples)
+    v = rng.integers(0, 1 << 63, n_tuples, dtype=np.uint64)
+    pr = np.concatenate([r[:n_tuples // 10], rng.integers(0, n, n_tuples // 5, dtype=np.uint64)])
+    pc = np.concatenate([c[:n_tuples // 10], rng.integers(0, n, n_tuples // 5, dtype=np.uint64)])
+    pv = rng.integers(0, 1 << 63, len(pr), dtype=np.uint64)
+    dr, dc = r[n_tuples // 20:n_tuples // 4], c[n_tuples // 20:n_tuples // 4]
+    base, add = {}, {}
+    for a, b, x in zip(r.tolist(), c.tolist(), v.tolist()):
+        base[(a, b)] = x
+    for a, b, x in zip(pr.tolist(), pc.tolist(), pv.tolist()):
+        add[(a, b)] = x
+    dead = set(zip(dr.tolist(), dc.tolist()))
+    M, DP, DM = ctx.mat_from_coo(n, n, r, c, v), ctx.mat_from_coo(n, n, pr, pc, pv), ctx.mat_from_coo(n, n, dr, dc)
+    for masks_dp in (False, True):
+        want = {k: x for k, x in base.items() if k not in dead}
+        want.update({k: x for k, x in add.items() if not (masks_dp and k in dead)})
+        rows, cols, vals = M.merge(DP, DM, dm_masks_dp=masks_dp).extract()
+        assert vals is not None
+        got = dict(zip(zip(rows.tolist(), cols.tolist()), vals.tolist()))
+        assert got == want
+        assert list(zip(rows.tolist(), cols.tolist())) == sorted(want)
+        # the same merge with the values dropped (Tensor::extract, tensor.rs:838-850)
+        prow, pcol, pval = M.merge_pattern(DP, DM, dm_masks_dp=masks_dp).extract()
+        assert pval is None and list(zip(prow.tolist(), pcol.tolist())) == sorted(want)
+    # a BOOL layer merged into a valued one carries the iso value 1
+    rows, cols, vals = M.merge(ctx.mat_from_coo(n, n, [7], [9]), None).extract()
+    got = dict(zip(zip(rows.tolist(), cols.tolist()), vals.tolist()))
+    assert got[(7, 9)] == 1
+
+
+def test_u64_transpose_on_device(ctx):
+    rng = np.random.default_rng(77)
+    n = 5000
+    r, c = rand_coo(rng, n, 300, 50000)
+    v = rng.integers(0, 1 << 63, 50000, dtype=np.uint64)
+    want = {}
+    for a, b, x in zip(r.tolist(), c.tolist(), v.tolist()):
+        want[(b, a)] = x
+    rows, cols, vals = ctx.mat_from_coo(n, 300, r, c, v).transpose().extract()
+    assert dict(zip(zip(rows.tolist(), cols.tolist()), vals.tolist())) == want
+    assert list(zip(rows.tolist(), cols.tolist())) == sorted(want)
+
+
+def test_resize_grow_and_shrink(ctx):
+    # GrB_Matrix_resize: grow keeps every (i, j, v) (matrix.rs:1617-1672), shrink drops what falls outside
+    a = oracle.rmat_csr(12)
+    A = ctx.mat_rmat(12)
+    G = A.resize(a.nrows + 1000, a.ncols + 77)
+    assert (G.nrows, G.ncols) == (a.nrows + 1000, a.ncols + 77)
+    rows, cols, _ = G.extract()
+    ar, ac = a.pairs()
+    np.testing.assert_array_equal(rows, ar)
+    np.testing.assert_array_equal(cols, ac)
+    S = A.resize(1500, 2200)
+    keep = (ar < 1500) & (ac < 2200)
+    assert_same(S, oracle.build_csr(1500, 2200, ar[keep], ac[keep]))
+    # hypersparse delta layer grows too
+    H = ctx.mat_from_coo(1 << 20, 1 << 20, [5, 900000], [6, 7]).resize((1 << 20) + 5, 1 << 21)
+    rows, cols, _ = H.extract()
+    assert list(zip(rows.tolist(), cols.tolist())) == [(5, 6), (900000, 7)]
+
+
 def test_intersect(ctx):
     rng = np.random.default_rng(6)
     n = 3000
