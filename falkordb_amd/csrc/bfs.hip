@@ -1574,16 +1574,30 @@ fgpu_info fgpu_bfs_plan_profile_read(fgpu_bfs_plan* p, const char** names, doubl
 fgpu_info fgpu_bfs(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, uint64_t src, int64_t max_level,
                    int32_t* level, int64_t* parent, uint64_t* edges_traversed) {
     FGPU_REQUIRE(ctx && A && level, FGPU_NULL_POINTER, "fgpu_bfs: NULL argument");
+    // a hypersparse snapshot (an adjacency with few populated rows, or an empty one) is re-emitted with a
+    // dense row-pointer array for the level kernels; plans themselves only take the dense form
+    fgpu_mat *dA = nullptr, *dAt = nullptr;
+    fgpu_info i = FGPU_OK;
+    if (A->is_hyper()) {
+        i = mat_merge_entries(ctx, &dA, A, nullptr, nullptr, false, A->nrows, A->ncols, true);
+        A = dA;
+    }
+    if (i == FGPU_OK && At && At->is_hyper()) {
+        i = mat_merge_entries(ctx, &dAt, At, nullptr, nullptr, false, At->nrows, At->ncols, true);
+        At = dAt;
+    }
     fgpu_bfs_plan* p = nullptr;
-    FGPU_TRY(fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1));
-    fgpu_info i = fgpu_bfs_run(p, src, max_level, parent != nullptr);
+    if (i == FGPU_OK) i = fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1);
+    if (i == FGPU_OK) i = fgpu_bfs_run(p, src, max_level, parent != nullptr);
     if (i == FGPU_OK) i = fgpu_bfs_fetch(p, level, parent);
     if (i == FGPU_OK && edges_traversed) {
         uint64_t st[8];
         i = fgpu_bfs_stats(p, st);
         *edges_traversed = st[2];
     }
-    fgpu_bfs_plan_free(p);
+    if (p) fgpu_bfs_plan_free(p);
+    if (dA) fgpu_mat_free(dA);
+    if (dAt) fgpu_mat_free(dAt);
     return i;
 }
 

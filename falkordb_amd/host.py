@@ -362,6 +362,15 @@ class Graph:
         _ck(self.L.fh_tensor_state(self.h, C.c_uint64(type_id), s))
         return {"m": s[0], "dp": s[1], "dm": s[2], "multi_pairs": s[3], "mt": s[4]}
 
+    def layer(self, type_id, which):
+        """Raw (row, col, val) entries of one layer: type_id None = adjacency; which in 'm', 'dp', 'dm'."""
+        r, c, v = u64p(), u64p(), u64p()
+        n = C.c_uint64()
+        _ck(self.L.fh_graph_layer_iter(self.h, C.c_int64(-1 if type_id is None else type_id),
+                                       {"m": 0, "dp": 1, "dm": 2}[which], C.byref(r), C.byref(c), C.byref(v),
+                                       C.byref(n)))
+        return list(zip(_take(r, n.value).tolist(), _take(c, n.value).tolist(), _take(v, n.value).tolist()))
+
     # ---- operators -----------------------------------------------------------------------------
     def cond_traverse_batch(self, spec, src, to_bound=None):
         """src / to_bound: node id, None = bound to NULL / non-node (src) or unbound (to_bound).

@@ -274,6 +274,30 @@ int fh_tensor_state(fh_graph* g, uint64_t type_id, uint64_t out[5]) {
     });
 }
 
+int fh_graph_layer_iter(fh_graph* g, int64_t type_id, int which, uint64_t** rows, uint64_t** cols, uint64_t** vals,
+                        uint64_t* n) {
+    return guard([&] {
+        const Matrix* m;
+        if (type_id < 0) {
+            const VersionedMatrix& a = g->g.adjacency_matrix();
+            a.wait();
+            m = which == 0 ? &a.m() : which == 1 ? &a.dp() : &a.dm();
+        } else {
+            const Tensor& t = g->g.relationship_tensors().at((size_t)type_id);
+            t.wait_fwd();
+            m = which == 0 ? &t.fwd_m() : which == 1 ? &t.fwd_dp() : &t.fwd_dm();
+        }
+        auto es = m->iter(0, ~0ull);
+        std::vector<u64> r, c, v;
+        for (auto& e : es) { r.push_back(e.row); c.push_back(e.col); v.push_back(e.val); }
+        *rows = hand(r);
+        *cols = hand(c);
+        *vals = hand(v);
+        *n = es.size();
+        return 0;
+    });
+}
+
 // ---- operators -----------------------------------------------------------------------------------------------
 static Value to_value(int64_t x) {
     if (x >= 0) return Value::node((u64)x);

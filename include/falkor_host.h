@@ -98,6 +98,10 @@ int fh_tensor_iter_edges(fh_graph* g, uint64_t type_id, uint64_t** srcs, uint64_
 /* out[0..2] = nvals of fwd m, dp, dm; out[3] = multi pairs; out[4] = nvals of mt (effective) */
 int fh_tensor_state(fh_graph* g, uint64_t type_id, uint64_t out[5]);
 
+/* Raw layer dump for tests: type_id < 0 = the adjacency matrix; which 0 = m, 1 = dp, 2 = dm. */
+int fh_graph_layer_iter(fh_graph* g, int64_t type_id, int which, uint64_t** rows, uint64_t** cols,
+                        uint64_t** vals, uint64_t* n);
+
 /* ---- operators ---------------------------------------------------------------------------------------
  * `spec` is "key=value;..." with keys: src=<labels,>  hop=<types,>|<dst labels,> (repeatable: hop 0 then the
  * fused chain)  optional= bind= emit= bidir= siblings= attrs= (0/1).
