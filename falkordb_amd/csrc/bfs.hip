@@ -1225,6 +1225,8 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
                  "At dims differ from A");
     FGPU_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, FGPU_INVALID, "bad rank %d / %d", rank, nranks);
     FGPU_REQUIRE(A->nrows >= 1, FGPU_INVALID, "empty graph");
+    FGPU_TRY(mat_ensure_finalized(A));   // hub lists of snapshots that came out of a merge
+    if (At) FGPU_TRY(mat_ensure_finalized(At));
     fgpu_bfs_plan* p = new (std::nothrow) fgpu_bfs_plan();
     FGPU_REQUIRE(p, FGPU_OOM, "out of host memory");
     p->ctx = ctx; p->A = A; p->At = At; p->rank = rank; p->nranks = nranks;
@@ -1620,6 +1622,8 @@ fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t
     FGPU_REQUIRE(!A->is_hyper() && (!At || !At->is_hyper()), FGPU_INVALID, "fgpu_vxm: non-hypersparse snapshots only");
     FGPU_REQUIRE(direction >= 0 && direction <= 3 && (direction < 2 || At), FGPU_INVALID, "fgpu_vxm: bad direction");
     if (direction == 3 && !At->tiles) FGPU_TRY(tiles_build(ctx, const_cast<fgpu_mat*>(At), 0, 0, 0));
+    FGPU_TRY(mat_ensure_finalized(A));
+    if (At) FGPU_TRY(mat_ensure_finalized(At));
     const u32 n = (u32)A->nrows;
     const u32 nw_user = (n + 63) / 64;
     const u32 nw = ((n + 4095) & ~4095u) / 64;

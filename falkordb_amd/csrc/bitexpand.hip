@@ -86,15 +86,47 @@ static fgpu_info transposed_with_items(fgpu_ctx* ctx, const fgpu_mat* m, const f
 // ---------------------------------------------------------------------------------
 // F -> X
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bp_scatter_csr_kernel(CsrView f, u32 nrows, u32 ws, u64* __restrict__ x) {
-    const u32 lane = lane_id();
-    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const u32 nwaves = (gridDim.x * 256) >> 6;
-    for (u32 i = wave; i < nrows; i += nwaves) {
-        const u32 b = f.rowptr[i], e = f.rowptr[i + 1];
-        const u64 bit = 1ull << (i & 63);
-        for (u32 q = b + lane; q < e; q += 64)
-            atomicOr((unsigned long long*)&x[(size_t)f.colidx[q] * ws + (i >> 6)], (unsigned long long)bit);
+// Entry-parallel: F has few rows (a batch of <= a few thousand sources) but after a hop or two its rows hold
+// up to ~10^6 entries each, so one wavefront per row leaves most of the chip idle behind the hub rows.  Every
+// lane takes one entry and finds its row in the (L1-resident) row-pointer array.
+__global__ __launch_bounds__(256) void bp_scatter_csr_kernel(CsrView f, u32 nrows, u32 nnz, u32 ws,
+                                                            u64* __restrict__ x) {
+    for (u32 q = blockIdx.x * 256 + threadIdx.x; q < nnz; q += gridDim.x * 256) {
+        u32 lo = 0, hi = nrows - 1;   // largest i with rowptr[i] <= q
+        while (lo < hi) {
+            u32 mid = (lo + hi + 1) >> 1;
+            if (f.rowptr[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        atomicOr((unsigned long long*)&x[(size_t)f.colidx[q] * ws + (lo >> 6)], 1ull << (lo & 63));
+    }
+}
+
+// nnz and the order-independent checksum of the result (sum of mix64((row << 32) | dest)) straight from the
+// bit state — fgpu_expand_count needs no CSR.  One lane per (vertex, word).
+__global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws,
+                                                      const u64* __restrict__ label,
+                                                      unsigned long long* __restrict__ acc) {
+    u64 cnt = 0, sum = 0;
+    const u64 total = (u64)n * w;
+    for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < total; t += (u64)gridDim.x * 256) {
+        const u32 v = (u32)(t / w), k = (u32)(t % w);
+        if (label && !((label[v >> 6] >> (v & 63)) & 1ull)) continue;
+        u64 bits = y[(size_t)v * ws + k];
+        cnt += (u64)__popcll(bits);
+        while (bits) {
+            const u32 b = (u32)__builtin_ctzll(bits);
+            bits &= bits - 1;
+            sum += mix64(((u64)(k * 64 + b) << 32) | v);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += __shfl_xor(cnt, d, 64);
+        sum += __shfl_xor(sum, d, 64);
+    }
+    if (lane_id() == 0 && cnt) {
+        atomicAdd(&acc[0], (unsigned long long)cnt);
+        atomicAdd(&acc[1], (unsigned long long)sum);
     }
 }
 
@@ -274,12 +306,29 @@ fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f) {
     bp_layout(s, (u32)f->ncols, (u32)f->nrows);
     FGPU_TRY(bp_alloc_zero(ctx, s.x, s));
     if (f->nnz) {
-        u32 grid = cdiv(f->nrows, 4);
-        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        u32 grid = cdiv(f->nnz, 256);
+        if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
         hipLaunchKernelGGL(bp_scatter_csr_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(f), (u32)f->nrows,
-                           s.ws, s.x.p);
+                           (u32)f->nnz, s.ws, s.x.p);
         FGPU_HIP(hipGetLastError());
     }
+    return FGPU_OK;
+}
+
+fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum) {
+    DevBuf<u64> acc;
+    FGPU_TRY(acc.alloc(ctx, 2));
+    FGPU_HIP(hipMemsetAsync(acc.p, 0, 2 * sizeof(u64), ctx->stream));
+    const u64 total = (u64)s.n * s.w;
+    if (total) {
+        u32 grid = cdiv(total, 256);
+        if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+        hipLaunchKernelGGL(bp_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n, s.w, s.ws,
+                           label_dev, (unsigned long long*)acc.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    FGPU_TRY(read_u64(ctx, acc.p, nnz));
+    FGPU_TRY(read_u64(ctx, acc.p + 1, checksum));
     return FGPU_OK;
 }
 

@@ -147,6 +147,8 @@ struct fgpu_mat {
     uint32_t* hub_chunks = nullptr;  // triples (row, begin, end)
     uint32_t n_hub_chunks = 0;
     uint32_t max_deg = 0;
+    bool finalized = false;       // hub list / max_deg computed (mat_finalize); merges leave it to the first BFS plan
+    uint32_t* wordrow = nullptr;  // merge.hip: stored-row index of entry 64 w, for w in [0, ceil(nnz/64)] (lazy, owned)
     fgpu_tiles* tiles = nullptr;  // built on demand by fgpu_mat_build_tiles; owned by the matrix
     // bit-parallel expansion (bitexpand.hip): cached pattern transpose of this matrix, and (on that
     // transpose) its rows cut into items of <= 256 entries
@@ -254,6 +256,7 @@ fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp);
 fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 fgpu_info mat_finalize(fgpu_mat* m);  // hub list, max degree (after rowptr/colidx are filled)
+fgpu_info mat_ensure_finalized(const fgpu_mat* m);  // lazily, for snapshots produced by the merge kernels
 // device COO (u32 rows / cols, n entries) -> CSR snapshot, duplicates collapsed.
 fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
                               const u32* cols, u64 n);
@@ -278,6 +281,8 @@ struct BitState {
 fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f);
 fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops);
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out);
+// nnz + order-independent checksum of the result read straight from the bit state (fgpu_expand_count)
+fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum);
 
 constexpr u32 HUB_DEG = 4096;    // rows at least this long are expanded by the hub kernel
 constexpr u32 HUB_CHUNK = 4096;  // edges per hub work item

@@ -26,6 +26,7 @@ static void mat_release(fgpu_mat* m) {
         c->dev_free(m->vals);
         c->dev_free(m->hrows);
         c->dev_free(m->hub_chunks);
+        c->dev_free(m->wordrow);
     }
     tiles_release(m->tiles);
     if (c) c->dev_free(m->bp_items);
@@ -93,6 +94,7 @@ fgpu_info mat_finalize(fgpu_mat* m) {
     fgpu_ctx* ctx = m->ctx;
     m->max_deg = 0;
     m->n_hub_chunks = 0;
+    m->finalized = true;
     if (m->nnz == 0 || m->nvec == 0) return FGPU_OK;
     // every hub chunk holds >= 1 edge and at most nnz / HUB_CHUNK + (#hub rows) chunks exist
     u32 cap = (u32)(m->nnz / HUB_CHUNK + m->nnz / HUB_DEG + 1);
@@ -115,6 +117,11 @@ fgpu_info mat_finalize(fgpu_mat* m) {
                                 hipMemcpyDeviceToDevice, ctx->stream));
     }
     return FGPU_OK;
+}
+
+fgpu_info mat_ensure_finalized(const fgpu_mat* m) {
+    if (m->finalized) return FGPU_OK;
+    return mat_finalize(const_cast<fgpu_mat*>(m));
 }
 
 // ---------------------------------------------------------------------------------

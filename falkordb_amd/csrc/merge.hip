@@ -9,8 +9,13 @@
 // The same machinery serves GrB_Matrix_resize (Matrix::resize / grown, matrix.rs:576-598,
 // tensor.rs:613-667): entries at or past the new dims are dropped, rows are extended.
 //
-// Every layer is walked ENTRY-parallel (one lane per stored entry, 64 consecutive entries per
-// wavefront), so R-MAT hub rows cost no more than any other 64 entries:
+// Every layer is walked ENTRY-parallel (one lane per stored entry, 64 consecutive entries = one "word"
+// per wavefront step), so R-MAT hub rows cost no more than any other 64 entries:
+//   0. wordrow : stored-row index of the first entry of every word (cached on the snapshot: it only
+//                depends on the row pointers) — a lane finds its row with a 1-3 step search between
+//                wordrow[w] and wordrow[w+1] instead of a log2(nrows) search
+//      rowbits : one bit per row "dp or dm stores something in this row"; with 0.1 % deltas 99 % of
+//                the base entries skip every delta lookup after one cached load
 //   1. mark    : keep bit per entry (ballot -> one 64-bit word per wavefront step)
 //   2. scan    : exclusive prefix of the per-word popcounts
 //   3. rowlen  : out_len[r] = kept(m row r) + kept(dp row r)  ->  scan  -> out rowptr
@@ -22,15 +27,14 @@
 
 namespace fgpu {
 
-struct Layer {        // dense-rowptr CSR view of one layer
-    const u32* rp;    // nrows_layer + 1
-    const u32* col;
+struct Layer {        // one layer: the (possibly hypersparse) CSR view, its values and its wordrow index
+    CsrView v;
     const u64* val;   // nullable
-    u32 nrows;
+    const u32* wordrow;
     u32 nnz;
 };
 
-// largest r in [lo, hi] with rp[r] <= p (rows may be empty: equal row pointers)
+// largest i in [lo, hi] with rp[i] <= p (rows may be empty: equal row pointers)
 __device__ __forceinline__ u32 row_of(const u32* __restrict__ rp, u32 lo, u32 hi, u32 p) {
     while (lo < hi) {
         u32 mid = (lo + hi + 1) >> 1;
@@ -48,11 +52,11 @@ __device__ __forceinline__ u32 lower_bound_col(const u32* __restrict__ col, u32 
 }
 
 __device__ __forceinline__ bool layer_has(const Layer& l, u32 r, u32 c) {
-    if (r >= l.nrows) return false;
-    u32 b = l.rp[r], e = l.rp[r + 1];
+    u32 b, e;
+    row_range(l.v, r, b, e);
     if (b == e) return false;
-    u32 p = lower_bound_col(l.col, b, e, c);
-    return p < e && l.col[p] == c;
+    u32 p = lower_bound_col(l.v.colidx, b, e, c);
+    return p < e && l.v.colidx[p] == c;
 }
 
 // kept entries before position p of a layer: ks[p >> 6] + popcount(kb[p >> 6] below bit p & 63)
@@ -62,39 +66,55 @@ __device__ __forceinline__ u32 kept_before(const u64* __restrict__ kb, const u32
     return ks[p >> 6] + (u32)__popcll(s ? (w & ((1ull << s) - 1ull)) : 0ull);
 }
 
-// rows of the 64 entries [base, base+64) of `x`: scalar search for the wave's row window, then a
-// short per-lane search inside it.
-__device__ __forceinline__ u32 lane_row(const Layer& x, u32 base, u32 p, bool valid) {
-    u32 last = base + 63 < x.nnz ? base + 63 : x.nnz - 1;
-    u32 rlo = row_of(x.rp, 0, x.nrows - 1, base);
-    u32 rhi = row_of(x.rp, rlo, x.nrows - 1, last);
-    return valid ? row_of(x.rp, rlo, rhi, p) : rlo;
+// stored-row index of the first entry of each 64-entry word; wordrow[nwords] = last stored row
+__global__ void wordrow_kernel(const u32* __restrict__ rp, u32 nvec, u32 nwords, u32* __restrict__ wordrow) {
+    u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > nwords) return;
+    wordrow[w] = w < nwords ? row_of(rp, 0, nvec - 1, w << 6) : nvec - 1;
+}
+
+__global__ void rowbits_kernel(CsrView d, u32* __restrict__ bits) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.nvec) return;
+    if (d.rowptr[i] == d.rowptr[i + 1]) return;
+    u32 r = d.hrows ? d.hrows[i] : i;
+    atomicOr(&bits[r >> 5], 1u << (r & 31));
+}
+
+// stored-row index and row id of entry p = (w << 6) + lane of layer x
+__device__ __forceinline__ void lane_row(const Layer& x, u32 w, u32 p, bool valid, u32& i, u32& r) {
+    const u32 ilo = x.wordrow[w], ihi = x.wordrow[w + 1];
+    i = valid ? row_of(x.v.rowptr, ilo, ihi, p) : ilo;
+    r = x.v.hrows ? x.v.hrows[i] : i;
 }
 
 // IS_M: x = m, other = dp (a coordinate also stored in dp is dropped from m: dp's value wins),
 //       and dm always masks m.   !IS_M: x = dp, masked by dm only when dm_masks_dp.
 template <bool IS_M>
 __global__ __launch_bounds__(256) void merge_mark_kernel(Layer x, Layer other, Layer dm, bool has_other, bool has_dm,
-                                                        bool dm_masks_dp, u32 out_nrows, u32 out_ncols,
-                                                        u64* __restrict__ kb, u32* __restrict__ kc) {
+                                                        bool dm_masks_dp, const u32* __restrict__ rowbits,
+                                                        u32 out_nrows, u32 out_ncols, u64* __restrict__ kb,
+                                                        u32* __restrict__ kc) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
     const u32 nwords = (x.nnz + 63) >> 6;
     for (u32 w = wave; w < nwords; w += nwaves) {
-        const u32 base = __builtin_amdgcn_readfirstlane(w << 6);
-        const u32 p = base + lane;
+        const u32 p = (w << 6) + lane;
         const bool valid = p < x.nnz;
-        const u32 r = lane_row(x, base, p, valid);
+        u32 i, r;
+        lane_row(x, w, p, valid, i, r);
         bool keep = false;
         if (valid) {
-            const u32 c = x.col[p];
+            const u32 c = x.v.colidx[p];
             keep = r < out_nrows && c < out_ncols;
-            if (IS_M) {
-                if (keep && has_dm) keep = !layer_has(dm, r, c);
-                if (keep && has_other) keep = !layer_has(other, r, c);
-            } else {
-                if (keep && dm_masks_dp && has_dm) keep = !layer_has(dm, r, c);
+            if (keep && rowbits && ((rowbits[r >> 5] >> (r & 31)) & 1u)) {
+                if (IS_M) {
+                    if (has_dm) keep = !layer_has(dm, r, c);
+                    if (keep && has_other) keep = !layer_has(other, r, c);
+                } else {
+                    if (dm_masks_dp && has_dm) keep = !layer_has(dm, r, c);
+                }
             }
         }
         const u64 mask = __ballot(keep);
@@ -105,19 +125,21 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(Layer x, Layer other, L
     }
 }
 
-__global__ void merge_rowlen_kernel(Layer m, Layer dp, bool has_dp, const u64* __restrict__ kbm,
-                                    const u32* __restrict__ ksm, const u64* __restrict__ kbp,
-                                    const u32* __restrict__ ksp, u32 out_nrows, u32* __restrict__ len) {
+__global__ void merge_rowlen_kernel(Layer m, Layer dp, bool has_dp, const u32* __restrict__ rowbits,
+                                    const u64* __restrict__ kbm, const u32* __restrict__ ksm,
+                                    const u64* __restrict__ kbp, const u32* __restrict__ ksp, u32 out_nrows,
+                                    u32* __restrict__ len) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > out_nrows) return;
     u32 n = 0;
     if (r < out_nrows) {
-        if (r < m.nrows && m.nnz) {
-            u32 b = m.rp[r], e = m.rp[r + 1];
+        u32 b, e;
+        if (m.nnz) {
+            row_range(m.v, r, b, e);
             if (b != e) n += kept_before(kbm, ksm, e) - kept_before(kbm, ksm, b);
         }
-        if (has_dp && r < dp.nrows) {
-            u32 b = dp.rp[r], e = dp.rp[r + 1];
+        if (has_dp && ((rowbits[r >> 5] >> (r & 31)) & 1u)) {
+            row_range(dp.v, r, b, e);
             if (b != e) n += kept_before(kbp, ksp, e) - kept_before(kbp, ksp, b);
         }
     }
@@ -126,6 +148,7 @@ __global__ void merge_rowlen_kernel(Layer m, Layer dp, bool has_dp, const u64* _
 
 template <bool IS_M>
 __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other, bool has_other,
+                                                           const u32* __restrict__ rowbits,
                                                            const u64* __restrict__ kbx, const u32* __restrict__ ksx,
                                                            const u64* __restrict__ kbo, const u32* __restrict__ kso,
                                                            const u32* __restrict__ out_rp, u32* __restrict__ out_col,
@@ -135,21 +158,21 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other
     const u32 nwaves = (gridDim.x * 256) >> 6;
     const u32 nwords = (x.nnz + 63) >> 6;
     for (u32 w = wave; w < nwords; w += nwaves) {
-        const u32 base = __builtin_amdgcn_readfirstlane(w << 6);
         const u64 mask = kbx[w];
         if (mask == 0) continue;
-        const u32 p = base + lane;
-        const bool valid = p < x.nnz;
-        const u32 r = lane_row(x, base, p, valid);
-        if (!((mask >> lane) & 1ull)) continue;
-        const u32 c = x.col[p];
+        const u32 p = (w << 6) + lane;
+        if (!((mask >> lane) & 1ull)) continue;   // kept entries are valid entries
+        u32 i, r;
+        lane_row(x, w, p, true, i, r);
+        const u32 c = x.v.colidx[p];
         const u32 own = ksx[w] + (u32)__popcll(lane ? (mask & ((1ull << lane) - 1ull)) : 0ull) -
-                        kept_before(kbx, ksx, x.rp[r]);
+                        kept_before(kbx, ksx, x.v.rowptr[i]);
         u32 cross = 0;
-        if (has_other && r < other.nrows) {
-            u32 b = other.rp[r], e = other.rp[r + 1];
+        if (has_other && (!IS_M || !rowbits || ((rowbits[r >> 5] >> (r & 31)) & 1u))) {
+            u32 b, e;
+            row_range(other.v, r, b, e);
             if (b != e) {
-                u32 q = lower_bound_col(other.col, b, e, c);
+                u32 q = lower_bound_col(other.v.colidx, b, e, c);
                 cross = kept_before(kbo, kso, q) - kept_before(kbo, kso, b);
             }
         }
@@ -159,18 +182,29 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other
     }
 }
 
-// dense-rowptr view of a (possibly hypersparse) matrix; `tmp` keeps the expanded row pointers alive
-static fgpu_info layer_of(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& tmp, Layer& l) {
-    l.col = a->colidx;
+// the wordrow index of a snapshot: built on first use, owned (and freed) by the matrix
+static fgpu_info layer_of(fgpu_ctx* ctx, const fgpu_mat* a, Layer& l) {
+    l.v = view_of(a);
     l.val = a->vals;
-    l.nrows = (u32)a->nrows;
     l.nnz = (u32)a->nnz;
-    if (!a->is_hyper()) {
-        l.rp = a->rowptr;
-        return FGPU_OK;
+    l.wordrow = nullptr;
+    if (a->nnz == 0) return FGPU_OK;
+    fgpu_mat* aa = const_cast<fgpu_mat*>(a);
+    if (!aa->wordrow) {
+        const u32 nwords = (u32)((a->nnz + 63) >> 6);
+        u32* wr = nullptr;
+        FGPU_TRY(ctx->dev_alloc((void**)&wr, ((size_t)nwords + 1) * sizeof(u32)));
+        hipLaunchKernelGGL(wordrow_kernel, dim3(cdiv((u64)nwords + 1, 256)), dim3(256), 0, ctx->stream,
+                           (const u32*)a->rowptr, a->nvec, nwords, wr);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            ctx->dev_free(wr);
+            set_error("wordrow launch failed: %s", hipGetErrorString(e));
+            return FGPU_DEVICE;
+        }
+        aa->wordrow = wr;
     }
-    FGPU_TRY(dense_rowptr(ctx, a, tmp));
-    l.rp = tmp.p;
+    l.wordrow = aa->wordrow;
     return FGPU_OK;
 }
 
@@ -198,31 +232,45 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
                             bool dm_masks_dp, u64 out_nrows, u64 out_ncols, bool pattern_only) {
     const bool has_dp = dp && dp->nnz, has_dm = dm && dm->nnz;
     const bool with_vals = !pattern_only && (m->vals != nullptr || (dp && dp->vals != nullptr));
-    DevBuf<u32> trm, trp, trd;
     Layer lm{}, lp{}, ld{};
-    FGPU_TRY(layer_of(ctx, m, trm, lm));
-    if (has_dp) FGPU_TRY(layer_of(ctx, dp, trp, lp));
-    if (has_dm) FGPU_TRY(layer_of(ctx, dm, trd, ld));
+    FGPU_TRY(layer_of(ctx, m, lm));
+    if (has_dp) FGPU_TRY(layer_of(ctx, dp, lp));
+    if (has_dm) FGPU_TRY(layer_of(ctx, dm, ld));
+    // rows touched by a delta layer
+    DevBuf<u32> rowbits;
+    const u64 max_rows = m->nrows > out_nrows ? m->nrows : out_nrows;
+    if (has_dp || has_dm) {
+        const size_t nb = (size_t)(max_rows >> 5) + 2;
+        FGPU_TRY(rowbits.alloc(ctx, nb));
+        FGPU_HIP(hipMemsetAsync(rowbits.p, 0, nb * sizeof(u32), ctx->stream));
+        if (has_dp)
+            hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream, lp.v, rowbits.p);
+        if (has_dm)
+            hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dm->nvec, 256)), dim3(256), 0, ctx->stream, ld.v, rowbits.p);
+        FGPU_HIP(hipGetLastError());
+    }
     Keep km, kp;
     FGPU_TRY(km.alloc(ctx, lm.nnz));
     FGPU_TRY(kp.alloc(ctx, has_dp ? lp.nnz : 0));
     if (lm.nnz) {
         hipLaunchKernelGGL(merge_mark_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream, lm, lp,
-                           ld, has_dp, has_dm, dm_masks_dp, (u32)out_nrows, (u32)out_ncols, km.kb.p, km.ks.p);
+                           ld, has_dp, has_dm, dm_masks_dp, (const u32*)rowbits.p, (u32)out_nrows, (u32)out_ncols,
+                           km.kb.p, km.ks.p);
         FGPU_HIP(hipGetLastError());
     }
     FGPU_TRY(scan_u32(ctx, km.ks.p, km.ks.p, ((u64)(lm.nnz + 63) >> 6) + 1, nullptr));
     if (has_dp) {
         hipLaunchKernelGGL(merge_mark_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream, lp, lm,
-                           ld, lm.nnz != 0, has_dm, dm_masks_dp, (u32)out_nrows, (u32)out_ncols, kp.kb.p, kp.ks.p);
+                           ld, lm.nnz != 0, has_dm, dm_masks_dp, (const u32*)rowbits.p, (u32)out_nrows,
+                           (u32)out_ncols, kp.kb.p, kp.ks.p);
         FGPU_HIP(hipGetLastError());
         FGPU_TRY(scan_u32(ctx, kp.ks.p, kp.ks.p, ((u64)(lp.nnz + 63) >> 6) + 1, nullptr));
     }
     DevBuf<u32> orp;
     FGPU_TRY(orp.alloc(ctx, out_nrows + 1));
     hipLaunchKernelGGL(merge_rowlen_kernel, dim3(cdiv(out_nrows + 1, 256)), dim3(256), 0, ctx->stream, lm, lp, has_dp,
-                       (const u64*)km.kb.p, (const u32*)km.ks.p, (const u64*)kp.kb.p, (const u32*)kp.ks.p,
-                       (u32)out_nrows, orp.p);
+                       (const u32*)rowbits.p, (const u64*)km.kb.p, (const u32*)km.ks.p, (const u64*)kp.kb.p,
+                       (const u32*)kp.ks.p, (u32)out_nrows, orp.p);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY(scan_u32(ctx, orp.p, orp.p, out_nrows + 1, nullptr));
     u32 nnz = 0;
@@ -233,23 +281,24 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
                                   ctx->stream);
     if (e == hipSuccess && lm.nnz && nnz) {
         hipLaunchKernelGGL(merge_scatter_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream, lm,
-                           lp, has_dp, (const u64*)km.kb.p, (const u32*)km.ks.p, (const u64*)kp.kb.p,
-                           (const u32*)kp.ks.p, (const u32*)o->rowptr, o->colidx, o->vals);
+                           lp, has_dp, (const u32*)rowbits.p, (const u64*)km.kb.p, (const u32*)km.ks.p,
+                           (const u64*)kp.kb.p, (const u32*)kp.ks.p, (const u32*)o->rowptr, o->colidx, o->vals);
         e = hipGetLastError();
     }
     if (e == hipSuccess && has_dp && nnz) {
         hipLaunchKernelGGL(merge_scatter_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream, lp,
-                           lm, lm.nnz != 0, (const u64*)kp.kb.p, (const u32*)kp.ks.p, (const u64*)km.kb.p,
-                           (const u32*)km.ks.p, (const u32*)o->rowptr, o->colidx, o->vals);
+                           lm, lm.nnz != 0, (const u32*)rowbits.p, (const u64*)kp.kb.p, (const u32*)kp.ks.p,
+                           (const u64*)km.kb.p, (const u32*)km.ks.p, (const u32*)o->rowptr, o->colidx, o->vals);
         e = hipGetLastError();
     }
-    fgpu_info i = FGPU_OK;
+    // the scratch buffers above go back to the pool when this returns: the kernels reading them must be done
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        set_error("merge launch failed: %s", hipGetErrorString(e));
-        i = FGPU_DEVICE;
+        set_error("merge failed: %s", hipGetErrorString(e));
+        fgpu_mat_free(o);
+        return FGPU_DEVICE;
     }
-    if (i == FGPU_OK) i = mat_finalize(o);
-    if (i != FGPU_OK) { fgpu_mat_free(o); return i; }
+    // hub list / max degree are computed when a BFS plan first needs them (mat_ensure_finalized)
     *out = o;
     return FGPU_OK;
 }
@@ -260,13 +309,12 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
 // ---------------------------------------------------------------------------------------
 // COO build with values: the LAST duplicate of a coordinate wins (a legal GxB_ANY_UINT64 choice,
 // matrix.rs:1186-1210, made deterministic): win[pos] = max tuple index, then vals[pos] = in[win].
-__global__ void coo_winner_kernel(const u32* __restrict__ rows, const u32* __restrict__ cols, u64 n, Layer a,
-                                  u32* __restrict__ win) {
+__global__ void coo_winner_kernel(const u32* __restrict__ rows, const u32* __restrict__ cols, u64 n,
+                                  const u32* __restrict__ rp, const u32* __restrict__ col, u32* __restrict__ win) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         u32 r = rows[i], c = cols[i];
         if (r == 0xFFFFFFFFu) continue;  // tuple dropped by the generator (mat_from_device_coo's ROW_INVALID)
-        u32 b = a.rp[r], e = a.rp[r + 1];
-        u32 p = lower_bound_col(a.col, b, e, c);
+        u32 p = lower_bound_col(col, rp[r], rp[r + 1], c);
         atomicMax(&win[p], (u32)i);
     }
 }
@@ -279,7 +327,7 @@ __global__ void coo_take_winner_kernel(const u32* __restrict__ win, const u64* _
 fgpu_info mat_from_device_coo_vals(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
                                    const u32* cols, const u64* vals, u64 n) {
     fgpu_mat* a = nullptr;
-    FGPU_TRY(mat_from_device_coo(ctx, &a, nrows, ncols, rows, cols, n));
+    FGPU_TRY(mat_from_device_coo(ctx, &a, nrows, ncols, rows, cols, n));   // dense row pointers
     fgpu_info i = FGPU_OK;
     do {
         if ((i = ctx->dev_alloc((void**)&a->vals, (size_t)(a->nnz ? a->nnz : 1) * sizeof(u64))) != FGPU_OK) break;
@@ -288,9 +336,8 @@ fgpu_info mat_from_device_coo_vals(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64
         if ((i = win.alloc(ctx, a->nnz)) != FGPU_OK) break;
         hipError_t e = hipMemsetAsync(win.p, 0, a->nnz * sizeof(u32), ctx->stream);
         if (e == hipSuccess) {
-            Layer la{a->rowptr, a->colidx, nullptr, (u32)a->nrows, (u32)a->nnz};
-            hipLaunchKernelGGL(coo_winner_kernel, dim3(ctx->cus * 16), dim3(256), 0, ctx->stream, rows, cols, n, la,
-                               win.p);
+            hipLaunchKernelGGL(coo_winner_kernel, dim3(ctx->cus * 16), dim3(256), 0, ctx->stream, rows, cols, n,
+                               (const u32*)a->rowptr, (const u32*)a->colidx, win.p);
             hipLaunchKernelGGL(coo_take_winner_kernel, dim3(cdiv(a->nnz, 256)), dim3(256), 0, ctx->stream,
                                (const u32*)win.p, vals, (u32)a->nnz, a->vals);
             e = hipGetLastError();
@@ -306,21 +353,21 @@ fgpu_info mat_from_device_coo_vals(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64
     return FGPU_OK;
 }
 
-// transpose with values: structure from the pattern transpose, then every entry (r, c, v) of `a`
-// is dropped at (c, r) of the result.
-__global__ __launch_bounds__(256) void transpose_vals_kernel(Layer a, Layer t, u64* __restrict__ tvals) {
+// transpose with values: structure from the pattern transpose (dense row pointers), then every entry
+// (r, c, v) of `a` is dropped at (c, r) of the result.
+__global__ __launch_bounds__(256) void transpose_vals_kernel(Layer a, const u32* __restrict__ trp,
+                                                            const u32* __restrict__ tcol, u64* __restrict__ tvals) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
     const u32 nwords = (a.nnz + 63) >> 6;
     for (u32 w = wave; w < nwords; w += nwaves) {
-        const u32 base = __builtin_amdgcn_readfirstlane(w << 6);
-        const u32 p = base + lane;
-        const bool valid = p < a.nnz;
-        const u32 r = lane_row(a, base, p, valid);
-        if (!valid) continue;
-        const u32 c = a.col[p];
-        u32 q = lower_bound_col(t.col, t.rp[c], t.rp[c + 1], r);
+        const u32 p = (w << 6) + lane;
+        if (p >= a.nnz) continue;
+        u32 i, r;
+        lane_row(a, w, p, true, i, r);
+        const u32 c = a.v.colidx[p];
+        u32 q = lower_bound_col(tcol, trp[c], trp[c + 1], r);
         tvals[q] = a.val[p];
     }
 }
@@ -336,11 +383,10 @@ fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
         }
         if ((i = ctx->dev_alloc((void**)&t->vals, (size_t)(t->nnz ? t->nnz : 1) * sizeof(u64))) != FGPU_OK) break;
         if (a->nnz == 0) break;
-        DevBuf<u32> tra;
-        Layer la{}, lt{t->rowptr, t->colidx, nullptr, (u32)t->nrows, (u32)t->nnz};
-        if ((i = layer_of(ctx, a, tra, la)) != FGPU_OK) break;
-        hipLaunchKernelGGL(transpose_vals_kernel, dim3(entry_grid(ctx, la.nnz)), dim3(256), 0, ctx->stream, la, lt,
-                           t->vals);
+        Layer la{};
+        if ((i = layer_of(ctx, a, la)) != FGPU_OK) break;
+        hipLaunchKernelGGL(transpose_vals_kernel, dim3(entry_grid(ctx, la.nnz)), dim3(256), 0, ctx->stream, la,
+                           (const u32*)t->rowptr, (const u32*)t->colidx, t->vals);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {

@@ -134,21 +134,22 @@ static fgpu_info mxm_flops(fgpu_ctx* ctx, const fgpu_mat* F, const fgpu_mat* B, 
     return read_u64(ctx, tot.p, T);
 }
 
-// long rows (dense k-hop results: ~5e5 entries per row): one workgroup per row
-__global__ __launch_bounds__(256) void checksum_rows_kernel(CsrView c, u32 nrows, unsigned long long* __restrict__ acc) {
-    __shared__ unsigned long long s_sum;
+// entry-parallel form for results with few, very long rows (dense k-hop results: ~10^6 entries per row):
+// each lane takes one entry and finds its row in the short row-pointer array
+__global__ __launch_bounds__(256) void checksum_entries_kernel(CsrView c, u32 nrows, u32 nnz,
+                                                              unsigned long long* __restrict__ acc) {
     u64 sum = 0;
-    for (u32 r = blockIdx.x; r < nrows; r += gridDim.x) {
-        const u32 rb = c.rowptr[r], re = c.rowptr[r + 1];
-        for (u32 i = rb + threadIdx.x; i < re; i += 256) sum += mix64(((u64)r << 32) | c.colidx[i]);
+    for (u32 q = blockIdx.x * 256 + threadIdx.x; q < nnz; q += gridDim.x * 256) {
+        u32 lo = 0, hi = nrows - 1;
+        while (lo < hi) {
+            u32 mid = (lo + hi + 1) >> 1;
+            if (c.rowptr[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        sum += mix64(((u64)lo << 32) | c.colidx[q]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-    if (threadIdx.x == 0) s_sum = 0;
-    __syncthreads();
-    if (lane_id() == 0 && sum) atomicAdd(&s_sum, (unsigned long long)sum);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_sum) atomicAdd(acc, s_sum);
+    if (lane_id() == 0 && sum) atomicAdd(acc, (unsigned long long)sum);
 }
 
 static fgpu_info empty_dense(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols) {
@@ -243,7 +244,7 @@ fgpu_info delta_lmxm_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* F, co
     if (i == FGPU_OK && (mask || acc)) {
         fgpu_mat* merged = nullptr;
         // (F.m with MASK removed) U ACCUM — the accumulated dp product is not masked (matrix.rs:1382-1400)
-        i = mat_merge_device(ctx, &merged, c, acc, mask, false);
+        i = mat_merge_entries(ctx, &merged, c, acc, mask, false, c->nrows, c->ncols, true);
         if (i == FGPU_OK) { fgpu_mat_free(c); c = merged; }
     }
     fgpu_mat_free(mask);
@@ -285,7 +286,9 @@ static fgpu_info filter_by_bitmap(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat*
 // shared front half of fgpu_expand / fgpu_expand_count: result stays on device
 static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
                                const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
-                               const uint64_t* dst_label_bitmap, fgpu_mat** result, u64* flops) {
+                               const uint64_t* dst_label_bitmap, fgpu_mat** result, u64* flops,
+                               u64* count_only = nullptr /* [0] nnz, [1] checksum: no CSR is built when the
+                                                            chain ends in bit form */) {
     FGPU_REQUIRE(nhops >= 1 && m, FGPU_INVALID, "expand: need at least one hop");
     FGPU_REQUIRE(nsrc < 0xFFFFFFFFull, FGPU_INVALID, "expand: too many source rows");
     for (int h = 0; h < nhops; ++h) {
@@ -338,7 +341,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 if (i != FGPU_OK) { fgpu_mat_free(f); return i; }
                 // measured on RMAT-22 / 1024 rows: a sorted-CSR hop costs ~0.16 ns per gathered entry
                 // (6 ms at T = 36 M), a bit hop ~2.7 ms per 65 M matrix entries at 128 B rows
-                go = T * 512 > mh->nnz * row_bytes;
+                go = T * 1024 > mh->nnz * row_bytes;
             }
             if (go) {
                 fgpu_info i = bp_from_csr(ctx, bs, f);
@@ -364,6 +367,10 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
             const u64 nw = ((u64)bs.n + 63) / 64;
             FGPU_TRY(bm.alloc(ctx, nw + 1));
             FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (count_only) {
+            *result = nullptr;
+            return bp_count(ctx, bs, dst_label_bitmap ? bm.p : nullptr, &count_only[0], &count_only[1]);
         }
         return bp_to_csr(ctx, bs, dst_label_bitmap ? bm.p : nullptr, result);
     }
@@ -430,7 +437,13 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
     FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_count: NULL src_ids");
     if (flops) *flops = 0;
     fgpu_mat* r = nullptr;
-    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
+    u64 cnt[2] = {0, 0};
+    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops, cnt));
+    if (!r) {   // the chain ended in bit form: counted there, no CSR was materialized
+        *out_nnz = cnt[0];
+        if (checksum) *checksum = cnt[1];
+        return FGPU_OK;
+    }
     *out_nnz = r->nnz;
     fgpu_info i = FGPU_OK;
     if (checksum) {
@@ -440,10 +453,11 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
             i = acc.alloc(ctx, 1);
             if (i == FGPU_OK) {
                 (void)hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream);
-                if (r->nnz / r->nrows >= 1024) {
-                    u32 grid = (u32)r->nrows < (u32)ctx->cus * 8 ? (u32)r->nrows : (u32)ctx->cus * 8;
-                    hipLaunchKernelGGL(checksum_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(r),
-                                       (u32)r->nrows, (unsigned long long*)acc.p);
+                if (r->nnz / r->nrows >= 1024 && r->nnz < 0xFFFFFFFFull) {
+                    u32 grid = cdiv(r->nnz, 256);
+                    if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+                    hipLaunchKernelGGL(checksum_entries_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(r),
+                                       (u32)r->nrows, (u32)r->nnz, (unsigned long long*)acc.p);
                 } else {
                     u32 grid = cdiv(r->nrows, 4);
                     if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;

@@ -372,7 +372,7 @@ class Graph:
         return list(zip(_take(r, n.value).tolist(), _take(c, n.value).tolist(), _take(v, n.value).tolist()))
 
     # ---- operators -----------------------------------------------------------------------------
-    def cond_traverse_batch(self, spec, src, to_bound=None):
+    def cond_traverse_batch(self, spec, src, to_bound=None, as_arrays=False):
         """src / to_bound: node id, None = bound to NULL / non-node (src) or unbound (to_bound).
         Returns None when the batched path bails to the per-row one, else (rows, null_rows, flops) with
         rows = [(active_row, dest[, edge])]."""
@@ -387,6 +387,10 @@ class Graph:
                                           tb.ctypes.data_as(i64p) if tb is not None else None, C.c_uint64(k),
                                           C.byref(batched), C.byref(orow), C.byref(odst), C.byref(oedge), C.byref(n),
                                           C.byref(onull), C.byref(nn), C.byref(fl)))
+        if as_arrays:   # numpy views of the result columns (no per-row Python objects)
+            res = (_take(orow, n.value), _take(odst, n.value), _take(oedge, n.value, np.int64))
+            nulls = _take(onull, nn.value)
+            return (res, nulls, fl.value) if batched.value else None
         rows, dst = _take(orow, n.value).tolist(), _take(odst, n.value).tolist()
         edge = _take(oedge, n.value, np.int64).tolist()
         nulls = _take(onull, nn.value).tolist()

@@ -317,20 +317,16 @@ int fh_cond_traverse_batch(fh_graph* g, const char* spec, const int64_t* src, co
             s[i] = to_value(src[i]);
             if (to_bound) tb[i] = to_value(to_bound[i]);
         }
-        std::vector<ExpandedRow> rows;
+        ExpandedRows rows;
         std::vector<u64> nulls;
         u64 fl = 0;
         bool ok = op.expand_batch(g->g, s, to_bound ? &tb : nullptr, rows, nulls, &fl);
         *batched = ok ? 1 : 0;
-        std::vector<u64> r, d;
         int64_t* e = (int64_t*)malloc((rows.size() ? rows.size() : 1) * sizeof(int64_t));
-        for (size_t i = 0; i < rows.size(); ++i) {
-            r.push_back(rows[i].active_row);
-            d.push_back(rows[i].dest);
-            e[i] = rows[i].edge ? (int64_t)*rows[i].edge : -1;
-        }
-        *out_row = hand(r);
-        *out_dest = hand(d);
+        if (rows.edge.empty()) memset(e, 0xFF, (rows.size() ? rows.size() : 1) * sizeof(int64_t));   // -1: none
+        else memcpy(e, rows.edge.data(), rows.size() * sizeof(int64_t));
+        *out_row = hand(rows.active_row);
+        *out_dest = hand(rows.dest);
         *out_edge = e;
         *n = rows.size();
         *null_rows = hand(nulls);

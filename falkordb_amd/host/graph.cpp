@@ -185,7 +185,7 @@ bool hop_layers(const Graph& g, const std::vector<Hop>& hops, HopLayers& hl, std
 }  // namespace
 
 bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src, const std::vector<Value>* to_bound,
-                                  std::vector<ExpandedRow>& rows, std::vector<u64>& null_rows, u64* flops) const {
+                                  ExpandedRows& rows, std::vector<u64>& null_rows, u64* flops) const {
     rows.clear();
     null_rows.clear();
     if (flops) *flops = 0;
@@ -245,13 +245,15 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
 
     std::vector<uint8_t> matched(k, 0);
     const bool want_edge = bind_relationship && hops.size() == 1;
-    std::vector<u64> es, ed;   // pairs needing a representative edge
+    rows.active_row.reserve(nnz);
+    rows.dest.reserve(nnz);
     for (u64 i = 0; i < k; ++i) {
+        const bool pinned = to_bound && (*to_bound)[i].kind == Value::Node;
         for (u64 p = rowptr[i]; p < rowptr[i + 1]; ++p) {
             const u64 d = dest[p];
-            if (to_bound && (*to_bound)[i].kind == Value::Node && (*to_bound)[i].id != d) continue;   // :657-661
-            rows.push_back(ExpandedRow{i, d, std::nullopt});
-            if (want_edge) { es.push_back(src_ids[i]); ed.push_back(d); }
+            if (pinned && (*to_bound)[i].id != d) continue;                          // :657-661
+            rows.active_row.push_back(i);
+            rows.dest.push_back(d);
         }
     }
     fgpu_free(ctx, rowptr);
@@ -261,25 +263,34 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
         std::vector<u64> tids = type_ids[0];
         if (tids.empty())
             for (u64 t = 0; t < g.relationship_tensors().size(); ++t) tids.push_back(t);
-        std::vector<std::optional<u64>> rep(rows.size());
+        const size_t n = rows.dest.size();
+        std::vector<u64> es(n);
+        for (size_t r = 0; r < n; ++r) es[r] = src_ids[rows.active_row[r]];
+        std::vector<std::optional<u64>> rep(n);
         for (u64 t : tids) {
             std::vector<std::vector<u64>> ids;
-            g.relationship_tensors()[t].get_batch(es, ed, ids);
-            for (size_t r = 0; r < rows.size(); ++r)
+            g.relationship_tensors()[t].get_batch(es, rows.dest, ids);
+            for (size_t r = 0; r < n; ++r)
                 if (!rep[r] && !ids[r].empty()) rep[r] = ids[r][0];
         }
-        std::vector<ExpandedRow> kept;
-        for (size_t r = 0; r < rows.size(); ++r) {
-            if (!rep[r]) continue;                                       // no edge: the pair is dropped
-            rows[r].edge = rep[r];
-            kept.push_back(rows[r]);
+        size_t o = 0;
+        rows.edge.resize(n);
+        for (size_t r = 0; r < n; ++r) {
+            if (!rep[r]) continue;                                                   // no edge: the pair is dropped
+            rows.active_row[o] = rows.active_row[r];
+            rows.dest[o] = rows.dest[r];
+            rows.edge[o] = *rep[r];
+            ++o;
         }
-        rows.swap(kept);
+        rows.active_row.resize(o);
+        rows.dest.resize(o);
+        rows.edge.resize(o);
     }
-    for (auto& r : rows) matched[r.active_row] = 1;
-    if (optional)
+    if (optional) {
+        for (u64 r : rows.active_row) matched[r] = 1;
         for (u64 i = 0; i < k; ++i)
             if (!matched[i]) null_rows.push_back(i);
+    }
     return true;
 }
 

@@ -311,10 +311,15 @@ struct Hop {                               // one (types, dst labels) step; hop 
     std::vector<std::string> dst_labels;
 };
 
-struct ExpandedRow {
-    u64 active_row;     // index into the input batch (the emitter gathers the parent columns by it)
-    u64 dest;
-    std::optional<u64> edge;
+// Result columns of expand_batch, in emission order: the emitter gathers the parent columns by `active_row`
+// and appends `dest` as a NodeIds column (+ `edge` as RelIds when a representative edge was bound),
+// cond_traverse.rs:700-735.
+struct ExpandedRows {
+    std::vector<u64> active_row;   // index into the input batch
+    std::vector<u64> dest;
+    std::vector<u64> edge;         // empty unless bind_relationship
+    size_t size() const { return dest.size(); }
+    void clear() { active_row.clear(); dest.clear(); edge.clear(); }
 };
 
 // CondTraverseOp (runtime/ops/cond_traverse.rs).  Only the matrix path and its eligibility rule are
@@ -332,7 +337,7 @@ struct CondTraverseOp {
     // (a non-node source on a non-optional traverse, :566-575); otherwise fills `rows` in emission order
     // and `null_rows` with the active rows an OPTIONAL traverse null-pads (:737-747).
     bool expand_batch(const Graph& g, const std::vector<Value>& src, const std::vector<Value>* to_bound,
-                      std::vector<ExpandedRow>& rows, std::vector<u64>& null_rows, u64* flops = nullptr) const;
+                      ExpandedRows& rows, std::vector<u64>& null_rows, u64* flops = nullptr) const;
     // expand_row + process_pairs (cond_traverse.rs:758-974, 978-1117) without attribute filters: the pairs
     // of one source (or, transposed, one destination) with label checks and per-pair edge lookup.
     void expand_row(const Graph& g, std::optional<u64> from_id, std::optional<u64> to_id, bool transposed,

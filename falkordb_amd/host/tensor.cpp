@@ -141,10 +141,15 @@ void Tensor::set_all_from_slices(const std::vector<u64>& srcs, const std::vector
             w_masked.push_back(masked[k] ? committed() : std::nullopt);
         }
     }
-    // Write phase (tensor.rs:429-454)
+    // Write phase (tensor.rs:429-454).  mt.set(d, s) of every written pair goes out as one set_all: the same
+    // per-entry body with its probe of mt's committed base hoisted into one batch.
+    {
+        std::vector<std::pair<u64, u64>> back(w_src.size());
+        for (size_t i = 0; i < w_src.size(); ++i) back[i] = {w_dst[i], w_src[i]};
+        mt_.set_all(back, false);
+    }
     for (size_t i = 0; i < w_src.size(); ++i) {
         const u64 s = w_src[i], d = w_dst[i], id = w_id[i];
-        mt_.set(d, s, true);
         if (w_masked[i]) {
             dm_.erase(s, d);
             if (*w_masked[i] == id) {              // cancel to clean: committed value restored

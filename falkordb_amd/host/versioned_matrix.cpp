@@ -219,20 +219,25 @@ void VersionedMatrix::remove_mask(const Matrix& mask) {
 void VersionedMatrix::set_all(const std::vector<std::pair<u64, u64>>& entries, bool is_new) {
     flush();
     dm_.wait();
-    if (dm_.nvals() == 0) {
-        // one device probe of the committed base for the whole batch instead of a get per entry
-        std::vector<uint8_t> in_m;
-        if (!is_new) {
-            std::vector<u64> r(entries.size()), c(entries.size());
-            for (size_t k = 0; k < entries.size(); ++k) { r[k] = entries[k].first; c[k] = entries[k].second; }
-            m_.probe(r, c, in_m, nullptr);
-        }
+    // one device probe of the committed base for the whole batch instead of a get per entry: `m` is never
+    // pending and no entry of this call changes it, so the answers are those the per-entry calls would see
+    const bool dm_empty = dm_.nvals() == 0;
+    std::vector<uint8_t> in_m;
+    if (!(dm_empty && is_new)) {
+        std::vector<u64> r(entries.size()), c(entries.size());
+        for (size_t k = 0; k < entries.size(); ++k) { r[k] = entries[k].first; c[k] = entries[k].second; }
+        m_.probe(r, c, in_m, nullptr);
+    }
+    if (dm_empty) {
         for (size_t k = 0; k < entries.size(); ++k) {
             if (!is_new && in_m[k]) continue;   // keeps dp & m = {}
             dp_.insert(entries[k].first, entries[k].second);
         }
     } else {
-        for (auto& e : entries) set(e.first, e.second, true);
+        for (size_t k = 0; k < entries.size(); ++k) {   // the body of set(), probe hoisted
+            if (in_m[k]) dm_.erase(entries[k].first, entries[k].second);
+            else dp_.insert(entries[k].first, entries[k].second);
+        }
     }
 }
 

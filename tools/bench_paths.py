@@ -1,0 +1,153 @@
+"""Secondary hot-path measurements (one JSON line each; bench.py stays the BFS headline):
+
+  merge   Delta merge (m \\ dm) U dp on RMAT-<scale> with 0.1 % pending adds + 0.1 % tombstones
+          (SURVEY §8d config 5 "merge GB/s"; K6): entry-parallel kernel vs the wavefront-per-row one,
+          pattern and UINT64 layers
+  expand  k-hop CondTraverse core (fgpu_expand_count) on RMAT-<scale>, 1024-row batches, clean and dirty
+          layers
+  host    CondTraverseOp::expand_batch through the C++ host layer vs the bare fgpu_expand call
+
+usage: python tools/bench_paths.py [merge|expand|host|all] [scale]
+"""
+import json
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+
+from falkordb_amd import engine
+
+
+def timed(ctx, fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    ctx.sync()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fn()
+        ctx.sync()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), r
+
+
+def deltas(ctx, A, frac, rng, valued=False):
+    n, nnz = A.nrows, A.nvals
+    k = max(1, int(nnz * frac))
+    # tombstones: k existing entries; pending adds: k random coordinates
+    rows, cols, _ = A.extract(0, min(n - 1, 1 << 16))
+    pick = rng.choice(len(rows), min(k, len(rows)), replace=False)
+    dm = ctx.mat_from_coo(n, n, rows[pick], cols[pick])
+    pr = rng.integers(0, n, k, dtype=np.uint64)
+    pc = rng.integers(0, n, k, dtype=np.uint64)
+    dp = ctx.mat_from_coo(n, n, pr, pc, rng.integers(0, 1 << 40, k, dtype=np.uint64) if valued else None)
+    return dp, dm
+
+
+def bench_merge(ctx, scale):
+    rng = np.random.default_rng(1)
+    A = ctx.mat_rmat(scale)
+    n, nnz = A.nrows, A.nvals
+    dp, dm = deltas(ctx, A, 0.001, rng)
+    for mode in (0, 1):
+        ctx.set_option("merge_mode", mode)
+        dt, out = timed(ctx, lambda: A.merge(dp, dm))
+        b_alg = 4 * (nnz + dp.nvals + dm.nvals) + 4 * out.nvals + 8 * (n + 1)
+        print(json.dumps({"path": "delta_merge", "layers": "bool", "kernel": ["entry-parallel", "row-wave"][mode],
+                          "scale": scale, "nnz_m": nnz, "nnz_dp": dp.nvals, "nnz_dm": dm.nvals,
+                          "nnz_out": out.nvals, "ms": round(dt * 1e3, 3), "alg_bytes": b_alg,
+                          "GBps": round(b_alg / dt / 1e9, 1), "frac_hbm": round(b_alg / dt / 8e12, 4)}), flush=True)
+    ctx.set_option("merge_mode", 0)
+    # UINT64 layers (Tensor::flush): values ride along, 8 B per entry each way
+    rp, ci, _ = A.export_csr()
+    r = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp).astype(np.int64))
+    V = ctx.mat_from_coo(n, n, r, ci, np.arange(len(ci), dtype=np.uint64))
+    del r, ci, rp
+    dpv, dmv = deltas(ctx, A, 0.001, rng, valued=True)
+    dt, out = timed(ctx, lambda: V.merge(dpv, dmv), reps=3)
+    b_alg = 12 * (nnz + dpv.nvals) + 4 * dmv.nvals + 12 * out.nvals + 8 * (n + 1)
+    print(json.dumps({"path": "delta_merge", "layers": "u64", "kernel": "entry-parallel", "scale": scale,
+                      "nnz_m": nnz, "nnz_out": out.nvals, "ms": round(dt * 1e3, 3), "alg_bytes": b_alg,
+                      "GBps": round(b_alg / dt / 1e9, 1), "frac_hbm": round(b_alg / dt / 8e12, 4)}), flush=True)
+    dt, out = timed(ctx, lambda: V.merge_pattern(dpv, dmv), reps=3)
+    print(json.dumps({"path": "tensor_extract", "kernel": "entry-parallel", "scale": scale, "nnz_out": out.nvals,
+                      "ms": round(dt * 1e3, 3)}), flush=True)
+    dt, out = timed(ctx, lambda: A.transpose(), reps=3)
+    print(json.dumps({"path": "transpose", "layers": "bool", "scale": scale, "ms": round(dt * 1e3, 3)}), flush=True)
+
+
+def bench_expand(ctx, scale, hops=3, batch=1024, nbatches=3):
+    rng = np.random.default_rng(7)
+    A = ctx.mat_rmat(scale)
+    n, nnz = A.nrows, A.nvals
+    dp, dm = deltas(ctx, A, 0.001, rng)
+    for name, layers in (("clean", ([A] * hops, None, None)), ("dirty-0.1%", ([A] * hops, [dp] * hops, [dm] * hops))):
+        tot_t, tot_f, tot_n = 0.0, 0, 0
+        for b in range(nbatches + 1):
+            src = rng.choice(n, batch, replace=False).astype(np.uint64)
+            ctx.sync()
+            t0 = time.perf_counter()
+            out_nnz, cs, flops = engine.expand_count(ctx, src, *layers)
+            dt = time.perf_counter() - t0
+            if b == 0:
+                continue  # warm-up (transpose cache, pools)
+            tot_t += dt; tot_f += flops; tot_n += out_nnz
+        print(json.dumps({"path": "khop_expand", "layers": name, "scale": scale, "hops": hops, "batch_rows": batch,
+                          "batches": nbatches, "ms_per_batch": round(tot_t / nbatches * 1e3, 3),
+                          "flops_per_batch": tot_f // nbatches, "out_nnz_per_batch": tot_n // nbatches,
+                          "GTEPS": round(tot_f / tot_t / 1e9, 2),
+                          "alg_bytes_per_batch": int((4 * tot_f + 4 * tot_n) // nbatches),
+                          "GBps": round((4 * tot_f + 4 * tot_n) / tot_t / 1e9, 1)}), flush=True)
+
+
+def bench_host(scale):
+    """expand_batch through libfalkor_host.so (label probes, layer waits, result hand-off) vs bare fgpu_expand."""
+    from falkordb_amd import host
+    hc = host.Context(0)
+    ctx = engine.Context(0)
+    A = ctx.mat_rmat(scale)
+    n = A.nrows
+    rp, ci, _ = A.export_csr()
+    r = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp).astype(np.int64))
+    g = host.Graph(hc, n)
+    t = g.add_type("KNOWS")
+    lp = g.add_label("P")
+    t0 = time.perf_counter()
+    g.create_edges(t, r, ci, np.arange(len(ci), dtype=np.uint64))
+    g.commit()
+    build = time.perf_counter() - t0
+    rng = np.random.default_rng(3)
+    src = rng.choice(n, 1024, replace=False).astype(np.uint64)
+    spec = host.cond_spec(hops=[(["KNOWS"], []), (["KNOWS"], [])])
+    srcl = src.tolist()
+    for _ in range(2):
+        (rows, _, _), nulls, flops = g.cond_traverse_batch(spec, srcl, as_arrays=True)
+    t0 = time.perf_counter()
+    (rows, _, _), nulls, flops = g.cond_traverse_batch(spec, srcl, as_arrays=True)
+    t_host = time.perf_counter() - t0
+    for _ in range(2):
+        rowptr, dest, fl = engine.expand(ctx, src, [A, A])
+    t0 = time.perf_counter()
+    rowptr, dest, fl = engine.expand(ctx, src, [A, A])
+    t_raw = time.perf_counter() - t0
+    assert len(rows) == len(dest) and fl == flops
+    print(json.dumps({"path": "host_expand_batch", "scale": scale, "hops": 2, "batch_rows": 1024, "rows_out": len(rows),
+                      "flops": flops, "ms_host_layer": round(t_host * 1e3, 3), "ms_bare_fgpu_expand": round(t_raw * 1e3, 3),
+                      "graph_load_s": round(build, 2),
+                      "note": "host figure = C++ expand_batch + result hand-off as three arrays"}), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    scale = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if what in ("merge", "all"):
+        c = engine.Context(0)
+        bench_merge(c, scale or 22)
+        c.close()
+    if what in ("expand", "all"):
+        c = engine.Context(0)
+        bench_expand(c, scale or 24)
+        c.close()
+    if what in ("host", "all"):
+        bench_host(scale or 18)
