@@ -144,7 +144,7 @@ def main():
 
     def run_pipelined(srcs):
         for i, src in enumerate(srcs):
-            plans[i % 2].run_async(src, -1, False, 10)
+            plans[i % 2].run_async(src, -1, False, 0)   # levels=0: one more than this plan's previous search took
             if i > 0:
                 plans[(i - 1) % 2].wait()
         if srcs:

@@ -1133,6 +1133,72 @@ struct ProfSlot {
     uint64_t alg_bytes = 0;
 };
 
+// ---------------------------------------------------------------------------------
+// hub-first in-neighbour order for the pull levels (acceleration index on A', like the LDS tiles)
+// ---------------------------------------------------------------------------------
+// A pull row stops at its first in-neighbour found in the frontier.  The frontier of the heavy levels is
+// where the high out-degree vertices are, so a copy of A''s column ids with every row reordered by
+// descending out-degree class (floor(log2(outdeg + 1)); ids ascending inside a class) makes the first
+// probes hit far more often.  Levels are unchanged (any in-neighbour in the frontier proves the level);
+// the parent is "any valid parent", as LAGraph's ANY monoid allows.  Rows of >= HUB_DEG
+// entries keep their order: they are scanned cooperatively by whole workgroups.
+__global__ void pull_key_kernel(const u32* __restrict__ col, u32 nnz, const u32* __restrict__ out_rowptr, u32 n_out,
+                                u32 idbits, u32* __restrict__ keys) {
+    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < nnz; p += gridDim.x * 256) {
+        const u32 x = col[p];
+        const u32 deg = x < n_out ? out_rowptr[x + 1] - out_rowptr[x] : 0u;
+        keys[p] = ((u32)__clz(deg + 1u) << idbits) | x;   // clz: 31 for deg 0 ... small for hubs
+    }
+}
+__global__ void pull_unkey_kernel(u32* __restrict__ keys, u32 nnz, u32 mask) {
+    for (u32 p = blockIdx.x * 256 + threadIdx.x; p < nnz; p += gridDim.x * 256) keys[p] &= mask;
+}
+__global__ void pull_seg_kernel(const u32* __restrict__ rowptr, u32 nrows, u64* __restrict__ off,
+                                uint8_t* __restrict__ dirty) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    off[r] = rowptr[r];
+    if (r < nrows) {
+        const u32 len = rowptr[r + 1] - rowptr[r];
+        dirty[r] = (len > 1 && len < HUB_DEG) ? 1 : 0;
+    }
+}
+
+static fgpu_info ensure_pull_order(fgpu_ctx* ctx, const fgpu_mat* At, const fgpu_mat* A) {
+    fgpu_mat* t = const_cast<fgpu_mat*>(At);
+    if (t->pull_col || At->nnz == 0 || At->nnz >= 0xFFFFFFFFull) return FGPU_OK;
+    u32 idbits = 1;
+    while (idbits < 32 && (1ull << idbits) < At->ncols) ++idbits;
+    if (idbits > 27) return FGPU_OK;   // 5 class bits + id must fit a 32-bit sort key
+    const u32 nnz = (u32)At->nnz, nrows = (u32)At->nrows;
+    u32* keys = nullptr;
+    FGPU_TRY(ctx->dev_alloc((void**)&keys, (size_t)nnz * sizeof(u32)));
+    DevBuf<u64> off;
+    DevBuf<uint8_t> dirty;
+    DevBuf<u32> cnt;
+    fgpu_info i = off.alloc(ctx, (size_t)nrows + 1);
+    if (i == FGPU_OK) i = dirty.alloc(ctx, (size_t)nrows + 1);
+    if (i == FGPU_OK) i = cnt.alloc(ctx, (size_t)nrows + 1);
+    if (i == FGPU_OK) {
+        const u32 grid = ctx->cus * 16;
+        hipLaunchKernelGGL(pull_key_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const u32*)At->colidx, nnz,
+                           (const u32*)A->rowptr, (u32)A->nrows, idbits, keys);
+        hipLaunchKernelGGL(pull_seg_kernel, dim3(cdiv((u64)nrows + 1, 256)), dim3(256), 0, ctx->stream,
+                           (const u32*)At->rowptr, nrows, off.p, dirty.p);
+        i = segsort_unique(ctx, keys, off.p, nrows, 0xFFFFFFFFu, cnt.p, dirty.p);
+        if (i == FGPU_OK) {
+            hipLaunchKernelGGL(pull_unkey_kernel, dim3(grid), dim3(256), 0, ctx->stream, keys, nnz,
+                               idbits >= 32 ? 0xFFFFFFFFu : ((1u << idbits) - 1u));
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { set_error("pull order build failed: %s", hipGetErrorString(e)); i = FGPU_DEVICE; }
+        }
+    }
+    if (i != FGPU_OK) { ctx->dev_free(keys); return i; }
+    t->pull_col = keys;
+    return FGPU_OK;
+}
+
 struct fgpu_bfs_plan {
     fgpu_ctx* ctx = nullptr;
     const fgpu_mat* A = nullptr;
@@ -1146,6 +1212,7 @@ struct fgpu_bfs_plan {
     u32* h_done = nullptr;       // pinned host word the last level writes (host view)
     u32* d_done = nullptr;       // the same word as the device sees it
     int enqueued = 0;            // levels enqueued since the last begin
+    int last_levels = 0;         // levels the previous search of this plan took (sizes the next blind batch)
     i32* level = nullptr;
     u32* parent = nullptr;
     BfsCtrl* ctrl = nullptr;
@@ -1163,7 +1230,10 @@ struct fgpu_bfs_plan {
 static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
     BfsArgs a;
     a.A = view_of(p->A);
-    if (p->At) a.At = view_of(p->At);
+    if (p->At) {
+        a.At = view_of(p->At);
+        if (p->At->pull_col && p->ctx->opt.bfs_hub_first) a.At.colidx = p->At->pull_col;
+    }
     else { a.At.rowptr = nullptr; a.At.colidx = nullptr; a.At.hrows = nullptr; a.At.nvec = 0; a.At.nrows = 0; }
     a.hubA = p->A->hub_chunks; a.n_hubA = p->A->n_hub_chunks;
     a.hubAt = p->At ? p->At->hub_chunks : nullptr; a.n_hubAt = p->At ? p->At->n_hub_chunks : 0;
@@ -1227,6 +1297,7 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
     FGPU_REQUIRE(A->nrows >= 1, FGPU_INVALID, "empty graph");
     FGPU_TRY(mat_ensure_finalized(A));   // hub lists of snapshots that came out of a merge
     if (At) FGPU_TRY(mat_ensure_finalized(At));
+    if (At && ctx->opt.bfs_hub_first) FGPU_TRY(ensure_pull_order(ctx, At, A));
     fgpu_bfs_plan* p = new (std::nothrow) fgpu_bfs_plan();
     FGPU_REQUIRE(p, FGPU_OOM, "out of host memory");
     p->ctx = ctx; p->A = A; p->At = At; p->rank = rank; p->nranks = nranks;
@@ -1456,8 +1527,10 @@ fgpu_info fgpu_bfs_run_async(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, 
     FGPU_REQUIRE(!p->profile, FGPU_INVALID, "a profiled plan runs synchronously (fgpu_bfs_run)");
     p->want_parent = want_parent != 0;
     FGPU_TRY(fused_begin(p, src, max_level));
-    if (levels <= 0) levels = 10;
-    // levels are enqueued blind; the kernels no-op once ctrl->done is raised
+    // levels are enqueued blind; the kernels no-op once ctrl->done is raised (a no-op level still costs
+    // ~4.6 us), so the default is one more than the plan's previous search needed: R-MAT searches from
+    // different roots differ by at most a level, and fgpu_bfs_wait tops up when the guess was short
+    if (levels <= 0) levels = p->last_levels ? p->last_levels + 1 : 10;
     for (int k = 0; k < levels; ++k) FGPU_TRY(fused_level(p));
     p->enqueued = levels;
     return FGPU_OK;
@@ -1480,10 +1553,15 @@ fgpu_info fgpu_bfs_wait(fgpu_bfs_plan* p) {
                 }
             }
         }
-        if (*flag & 0x80000000u) return FGPU_OK;
-        if (*flag & 0x80000000u) return FGPU_OK;
+        if (*flag & 0x80000000u) {
+            p->last_levels = (int)(*flag & 0x7FFFFFFFu);
+            return FGPU_OK;
+        }
         FGPU_TRY(fetch_ctrl(p));  // stream drained without the flag: not done yet (or it raced the poll)
-        if (p->h_ctrl->done) return FGPU_OK;
+        if (p->h_ctrl->done) {
+            p->last_levels = (int)p->h_ctrl->level;
+            return FGPU_OK;
+        }
         for (int k = 0; k < 4; ++k) FGPU_TRY(fused_level(p));
         p->enqueued += 4;
     }

@@ -63,6 +63,7 @@ struct fgpu_options {  // fgpu_set_option
     int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)
     int expand_mode = 0;       // 0 auto, 1 sorted-CSR products only, 2 bit-parallel from the first hop
     int bfs_wgs_per_cu = 6;    // grid of the fused BFS level kernel, workgroups per CU
+    int bfs_hub_first = 1;     // pull levels read A' rows reordered hub-first (bfs.hip ensure_pull_order)
     int merge_mode = 0;        // Delta merge: 0 entry-parallel (merge.hip), 1 one wavefront per row (pattern only)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
 };
@@ -148,6 +149,7 @@ struct fgpu_mat {
     uint32_t n_hub_chunks = 0;
     uint32_t max_deg = 0;
     bool finalized = false;       // hub list / max_deg computed (mat_finalize); merges leave it to the first BFS plan
+    uint32_t* pull_col = nullptr; // bfs.hip: column ids with every row reordered hub-first, for the pull levels (lazy, owned)
     uint32_t* wordrow = nullptr;  // merge.hip: stored-row index of entry 64 w, for w in [0, ceil(nnz/64)] (lazy, owned)
     fgpu_tiles* tiles = nullptr;  // built on demand by fgpu_mat_build_tiles; owned by the matrix
     // bit-parallel expansion (bitexpand.hip): cached pattern transpose of this matrix, and (on that

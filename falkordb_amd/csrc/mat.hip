@@ -27,6 +27,7 @@ static void mat_release(fgpu_mat* m) {
         c->dev_free(m->hrows);
         c->dev_free(m->hub_chunks);
         c->dev_free(m->wordrow);
+        c->dev_free(m->pull_col);
     }
     tiles_release(m->tiles);
     if (c) c->dev_free(m->bp_items);
