@@ -1054,17 +1054,10 @@ __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u
 __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at,
                                                              u32 force_dir, float alpha, u64 nnz_at) {
     const u32 tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
-    // level[]: -1 everywhere, 0 at the source (n_pad is a multiple of 4096)
-    const u32 nq = (a.nw * 64) >> 2;
-    uint4* lv4 = (uint4*)a.level;
-    for (u32 i = tid; i < nq; i += nth) {
-        uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (i == (src >> 2)) {
-            const u32 k = src & 3;
-            if (k == 0) v.x = 0; else if (k == 1) v.y = 0; else if (k == 2) v.z = 0; else v.w = 0;
-        }
-        lv4[i] = v;
-    }
+    // level[] is NOT cleared: level[v] is meaningful exactly where the visited bitmap has v set (the on-device
+    // result is the pair); fgpu_bfs_fetch masks the rest to -1 on its way out (bfs_mask_levels_kernel).
+    // Clearing 4 N bytes per search was 5 of the begin kernel's 6 us at scale 22.
+    if (tid == 0) a.level[src] = 0;
     // bm[0] | bm[1] | bm[2] | visited are one allocation of 4 * nw words
     u64* bm = a.bm[0];
     const u32 sw = src >> 6;
@@ -1106,6 +1099,12 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     }
     c->direction = nd;
     c->q_open = ((nd == 1 ? mf : (u64)a.n) <= QGATE) ? 1u : 0u;
+}
+
+// level[v] = -1 wherever the search did not reach v (fused single-rank path, see bfs_fused_begin_kernel)
+__global__ void bfs_mask_levels_kernel(i32* __restrict__ level, const u64* __restrict__ visited, u32 n_pad) {
+    for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n_pad; v += gridDim.x * 256)
+        if (!((visited[v >> 6] >> (v & 63)) & 1ull)) level[v] = -1;
 }
 
 // ---- standalone vxm kernels (fgpu_vxm, bench) ---------------------------------------
@@ -1212,6 +1211,7 @@ struct fgpu_bfs_plan {
     u32* h_done = nullptr;       // pinned host word the last level writes (host view)
     u32* d_done = nullptr;       // the same word as the device sees it
     int enqueued = 0;            // levels enqueued since the last begin
+    bool levels_masked = false;  // level[] already holds -1 for unreached vertices (set by fgpu_bfs_fetch)
     int last_levels = 0;         // levels the previous search of this plan took (sizes the next blind batch)
     i32* level = nullptr;
     u32* parent = nullptr;
@@ -1400,6 +1400,7 @@ fgpu_info fgpu_bfs_part_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level)
     FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_part_begin: NULL plan");
     FGPU_REQUIRE(src < p->n, FGPU_OUT_OF_BOUNDS, "BFS source %llu >= %u vertices", (unsigned long long)src, p->n);
     fgpu_ctx* ctx = p->ctx;
+    p->levels_masked = true;   // bfs_init_kernel clears level[] itself on this path
     const size_t wb = (size_t)p->nw * sizeof(u64);
     FGPU_HIP(hipMemsetAsync(p->cur, 0, wb, ctx->stream));
     FGPU_HIP(hipMemsetAsync(p->visited, 0, wb, ctx->stream));
@@ -1424,6 +1425,7 @@ static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) 
     BfsArgs a = make_args(p, true);
     *(volatile u32*)p->h_done = 0;
     p->enqueued = 0;
+    p->levels_masked = false;
     hipLaunchKernelGGL(bfs_fused_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream, a, (u32)src, ml,
                        p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull);
     FGPU_HIP(hipGetLastError());
@@ -1589,6 +1591,12 @@ fgpu_info fgpu_bfs_fetch(fgpu_bfs_plan* p, int32_t* level, int64_t* parent) {
     fgpu_ctx* ctx = p->ctx;
     const u32 lo = p->lo, hi = p->hi < p->n ? p->hi : p->n;
     if (hi <= lo) return FGPU_OK;
+    if (p->nranks == 1 && p->bm_block && !p->levels_masked) {
+        hipLaunchKernelGGL(bfs_mask_levels_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream, p->level,
+                           (const u64*)(p->bm_block + 3 * (size_t)p->nw), p->nw * 64);
+        FGPU_HIP(hipGetLastError());
+        p->levels_masked = true;
+    }
     std::vector<i32> lv;
     const i32* lvp = level ? level + lo : nullptr;
     if (level) {

@@ -315,6 +315,30 @@ fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f) {
     return FGPU_OK;
 }
 
+// U |= X (same layout): the DISTINCT union over the hops of a variable-length pattern
+__global__ void bp_or_kernel(u64* __restrict__ u, const u64* __restrict__ x, u64 words) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < words; i += (u64)gridDim.x * 256) {
+        const u64 v = x[i];
+        if (v) u[i] |= v;
+    }
+}
+
+fgpu_info bp_accumulate(fgpu_ctx* ctx, BitState& u, const BitState& x) {
+    if (u.x.p == nullptr) {
+        bp_layout(u, x.n, x.nsrc);
+        FGPU_TRY(bp_alloc_zero(ctx, u.x, u));
+    }
+    FGPU_REQUIRE(u.n == x.n && u.ws == x.ws, FGPU_DIM_MISMATCH, "bit-state union: layouts differ");
+    const u64 words = (u64)x.n * x.ws;
+    if (words) {
+        u32 grid = cdiv(words, 256);
+        if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+        hipLaunchKernelGGL(bp_or_kernel, dim3(grid), dim3(256), 0, ctx->stream, u.x.p, (const u64*)x.x.p, words);
+        FGPU_HIP(hipGetLastError());
+    }
+    return FGPU_OK;
+}
+
 fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum) {
     DevBuf<u64> acc;
     FGPU_TRY(acc.alloc(ctx, 2));

@@ -285,6 +285,8 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out);
 // nnz + order-independent checksum of the result read straight from the bit state (fgpu_expand_count)
 fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum);
+// u |= x (u is allocated, zeroed, on first use): DISTINCT union over the hops of a [*1..k] pattern
+fgpu_info bp_accumulate(fgpu_ctx* ctx, BitState& u, const BitState& x);
 
 constexpr u32 HUB_DEG = 4096;    // rows at least this long are expanded by the hub kernel
 constexpr u32 HUB_CHUNK = 4096;  // edges per hub work item

@@ -283,25 +283,8 @@ static fgpu_info filter_by_bitmap(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat*
     return FGPU_OK;
 }
 
-// shared front half of fgpu_expand / fgpu_expand_count: result stays on device
-static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
-                               const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
-                               const uint64_t* dst_label_bitmap, fgpu_mat** result, u64* flops,
-                               u64* count_only = nullptr /* [0] nnz, [1] checksum: no CSR is built when the
-                                                            chain ends in bit form */) {
-    FGPU_REQUIRE(nhops >= 1 && m, FGPU_INVALID, "expand: need at least one hop");
-    FGPU_REQUIRE(nsrc < 0xFFFFFFFFull, FGPU_INVALID, "expand: too many source rows");
-    for (int h = 0; h < nhops; ++h) {
-        FGPU_REQUIRE(m[h], FGPU_NULL_POINTER, "expand: hop %d base matrix is NULL", h);
-        FGPU_REQUIRE(!dp || !dp[h] || (dp[h]->nrows == m[h]->nrows && dp[h]->ncols == m[h]->ncols),
-                     FGPU_DIM_MISMATCH, "expand: hop %d dp dims differ from m", h);
-        FGPU_REQUIRE(!dm || !dm[h] || (dm[h]->nrows == m[h]->nrows && dm[h]->ncols == m[h]->ncols),
-                     FGPU_DIM_MISMATCH, "expand: hop %d dm dims differ from m", h);
-        FGPU_REQUIRE(h == 0 || m[h]->nrows == m[h - 1]->ncols, FGPU_DIM_MISMATCH,
-                     "expand: hop %d rows do not match hop %d columns", h, h - 1);
-    }
-    // F: one row per source, at most one entry per row (cond_traverse.rs:600-601)
-    const u64 ncols0 = m[0]->nrows;
+// F: one row per source, at most one entry per row (cond_traverse.rs:600-601); UINT64_MAX = row left empty
+static fgpu_info upload_sources(fgpu_ctx* ctx, fgpu_mat** out, const uint64_t* src_ids, uint64_t nsrc, u64 ncols0) {
     std::vector<u32> rp(nsrc + 1), ci;
     ci.reserve(nsrc);
     rp[0] = 0;
@@ -320,6 +303,35 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         e = hipMemcpyAsync(f->colidx, ci.data(), ci.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { fgpu_mat_free(f); set_error("expand: source upload failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+    *out = f;
+    return FGPU_OK;
+}
+
+static fgpu_info check_hops(const fgpu_mat* const* m, const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                            uint64_t nsrc) {
+    FGPU_REQUIRE(nhops >= 1 && m, FGPU_INVALID, "expand: need at least one hop");
+    FGPU_REQUIRE(nsrc < 0xFFFFFFFFull, FGPU_INVALID, "expand: too many source rows");
+    for (int h = 0; h < nhops; ++h) {
+        FGPU_REQUIRE(m[h], FGPU_NULL_POINTER, "expand: hop %d base matrix is NULL", h);
+        FGPU_REQUIRE(!dp || !dp[h] || (dp[h]->nrows == m[h]->nrows && dp[h]->ncols == m[h]->ncols),
+                     FGPU_DIM_MISMATCH, "expand: hop %d dp dims differ from m", h);
+        FGPU_REQUIRE(!dm || !dm[h] || (dm[h]->nrows == m[h]->nrows && dm[h]->ncols == m[h]->ncols),
+                     FGPU_DIM_MISMATCH, "expand: hop %d dm dims differ from m", h);
+        FGPU_REQUIRE(h == 0 || m[h]->nrows == m[h - 1]->ncols, FGPU_DIM_MISMATCH,
+                     "expand: hop %d rows do not match hop %d columns", h, h - 1);
+    }
+    return FGPU_OK;
+}
+
+// shared front half of fgpu_expand / fgpu_expand_count: result stays on device
+static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                               const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                               const uint64_t* dst_label_bitmap, fgpu_mat** result, u64* flops,
+                               u64* count_only = nullptr /* [0] nnz, [1] checksum: no CSR is built when the
+                                                            chain ends in bit form */) {
+    FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
+    fgpu_mat* f = nullptr;
+    FGPU_TRY(upload_sources(ctx, &f, src_ids, nsrc, m[0]->nrows));
     // Hops run on the sorted-CSR products until a hop's gather volume T makes the bit-parallel form
     // cheaper (bitexpand.hip): it costs one pass over A' gathering max(64, 8 W) bytes per entry,
     // whatever T is; the CSR product moves ~T entries several times.  Once dense, stay dense.
@@ -470,6 +482,52 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
     }
     fgpu_mat_free(r);
     return i;
+}
+
+fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                             const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                             const uint64_t* dst_label_bitmap, uint64_t* hop_nnz, uint64_t* hop_checksum,
+                             uint64_t* union_nnz, uint64_t* union_checksum, uint64_t* flops) {
+    FGPU_REQUIRE(ctx && hop_nnz, FGPU_NULL_POINTER, "fgpu_expand_levels: NULL argument");
+    FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_levels: NULL src_ids");
+    FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
+    for (int h = 0; h < nhops; ++h)
+        FGPU_REQUIRE(!m[h]->is_hyper() && m[h]->nnz < 0x7FFFFFFFull, FGPU_INVALID,
+                     "fgpu_expand_levels: hop %d needs a non-hypersparse base matrix with nnz < 2^31", h);
+    if (flops) *flops = 0;
+    if (union_nnz) *union_nnz = 0;
+    if (union_checksum) *union_checksum = 0;
+    fgpu_mat* f = nullptr;
+    FGPU_TRY(upload_sources(ctx, &f, src_ids, nsrc, m[0]->nrows));
+    // the whole chain runs in bit form (one bit per source row): every hop is one pass over the cached
+    // transpose whatever the frontier size, and the union over the hops is a word-wise OR
+    BitState bs, un;
+    fgpu_info i = bp_from_csr(ctx, bs, f);
+    fgpu_mat_free(f);
+    if (i != FGPU_OK) return i;
+    DevBuf<u64> bm;
+    const u64* label_dev = nullptr;
+    for (int h = 0; h < nhops; ++h) {
+        FGPU_TRY(bp_hop(ctx, bs, m[h], dp ? dp[h] : nullptr, dm ? dm[h] : nullptr, flops));
+        if (dst_label_bitmap && h == 0) {   // the destination label applies to every reported set
+            const u64 nw = ((u64)bs.n + 63) / 64;
+            FGPU_TRY(bm.alloc(ctx, nw + 1));
+            FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            label_dev = bm.p;
+        }
+        u64 n = 0, cs = 0;
+        FGPU_TRY(bp_count(ctx, bs, label_dev, &n, &cs));
+        hop_nnz[h] = n;
+        if (hop_checksum) hop_checksum[h] = cs;
+        if (union_nnz || union_checksum) FGPU_TRY(bp_accumulate(ctx, un, bs));
+    }
+    if (union_nnz || union_checksum) {
+        u64 n = 0, cs = 0;
+        FGPU_TRY(bp_count(ctx, un, label_dev, &n, &cs));
+        if (union_nnz) *union_nnz = n;
+        if (union_checksum) *union_checksum = cs;
+    }
+    return FGPU_OK;
 }
 
 }  // extern "C"

@@ -278,6 +278,22 @@ def expand_count(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=No
     return nnz.value, cs.value, flops.value
 
 
+def expand_levels(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
+    """fgpu_expand_levels: per-hop (nnz, checksum) of the chain and the DISTINCT union over the hops."""
+    src = _u64(src_ids)
+    nh = len(m)
+    am = _hop_arrays(m)
+    adp = _hop_arrays(dp) if dp is not None else None
+    adm = _hop_arrays(dm) if dm is not None else None
+    lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
+    hn, hc = np.zeros(nh, dtype=U64), np.zeros(nh, dtype=U64)
+    un, uc, fl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    check(ctx.lib.fgpu_expand_levels(ctx._h, _p(src), len(src), am, adp, adm, nh, _p(lab), _p(hn), _p(hc),
+                                     C.byref(un), C.byref(uc), C.byref(fl)))
+    return {"hop_nnz": hn.tolist(), "hop_checksum": hc.tolist(), "union_nnz": un.value,
+            "union_checksum": uc.value, "flops": fl.value}
+
+
 def vxm(ctx: Context, f_bits, mask_bits, A: Mat, At: Mat | None = None, direction=0):
     f = _u64(f_bits)
     mk = _u64(mask_bits) if mask_bits is not None else None

@@ -209,6 +209,21 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
                             const uint64_t* dst_label_bitmap, uint64_t* out_nnz,
                             uint64_t* checksum, uint64_t* flops);
 
+/* Variable-length reachability core (BASELINE config 5).  The reference evaluates
+ * `[*1..k]` with a per-row DFS (CondVarLenTraverseOp, cond_var_len_traverse.rs:81-128); its DISTINCT
+ * end-point set and the per-hop frontiers are set algebra over the same layers: ONE chain of `nhops` hops
+ * (each hop a delta_lmxm, quirk included) evaluated once in bit form (one bit per source row),
+ *   hop_nnz[h] / hop_checksum[h] : size / checksum of F x A_1 .. A_{h+1}  (walks of exactly h+1 hops),
+ *   union_nnz / union_checksum   : the DISTINCT (row, dest) pairs reached by 1..nhops hops
+ *                                  (= MATCH (a)-[*1..k]->(b) RETURN DISTINCT a, b; also the pruning set for the DFS).
+ * hop_checksum / union_* / flops are nullable; checksum as in fgpu_expand_count; the destination-label
+ * bitmap (nullable) filters every reported set.  Base matrices must be non-hypersparse with nnz < 2^31. */
+fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                             const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                             const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                             uint64_t* hop_nnz, uint64_t* hop_checksum, uint64_t* union_nnz,
+                             uint64_t* union_checksum, uint64_t* flops);
+
 /* ---- boolean vxm / BFS (K9) ---------------------------------------------- */
 
 /* w<!mask, replace> = f x A over the boolean (ANY_PAIR) semiring, vectors as

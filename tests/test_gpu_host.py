@@ -409,6 +409,51 @@ def test_social_queries(hctx, commit):                     # social_queries.py:5
     assert g.tensor_edge_count(0) == want["friend"] and g.tensor_edge_count(1) == want["visited"]
 
 
+# ---- BASELINE config 1: LDBC-SNB-SF0.1-shaped 2-hop MATCH through the whole stack ----------------------------
+def test_ldbc_shaped_two_hop_match_count(hctx):
+    """`MATCH (a:Person)-[:KNOWS]->()-[:KNOWS]->(c) RETURN count(c)` (bench row "two-hop",
+    bench/src/falkorbench/queries.py:184) on a stand-in with SF0.1's shape (the LDBC dataset is not available
+    offline): ~1.5 k Person nodes among other nodes, ~18 k directed KNOWS edges with a power-law
+    degree distribution, plus a second relationship type that must not leak into the result.  The fused
+    CondTraverse chain runs through libfalkor_host -> fgpu_expand in batches of 1024 rows (batch.rs:81)."""
+    rng = np.random.default_rng(2026)
+    n_person, n_other = 1536, 512
+    n = n_person + n_other
+    e = oracle.rmat_edges(11, edge_factor=9, seed=0xD0C)       # 2048-vertex R-MAT, ~18 k raw edges
+    keep = (e[0] < n_person) & (e[1] < n_person)
+    ks, kd = e[0][keep], e[1][keep]
+    g = host.Graph(hctx, n)
+    og = model.Graph(n)
+    lp = g.add_label("Person"); og.add_label("Person")
+    for v in range(n_person):
+        g.label_node(v, lp); og.node_labels.add((v, lp))
+    tk, tl = g.add_type("KNOWS"), g.add_type("LIKES")
+    og.add_type("KNOWS"); og.add_type("LIKES")
+    g.create_edges(tk, ks, kd, np.arange(len(ks)))
+    ls, ld = rng.integers(0, n, 4000), rng.integers(0, n, 4000)
+    g.create_edges(tl, ls, ld, np.arange(len(ks), len(ks) + 4000))
+    g.commit()
+    pairs = {}
+    for s_, d_, i_ in zip(ks.tolist(), kd.tolist(), range(len(ks))):
+        pairs.setdefault((s_, d_), []).append(i_)
+    for p_, es in pairs.items():
+        og.tensors[0].m[p_] = es[0] if len(es) == 1 else model.MULTI_EDGE
+        if len(es) > 1:
+            og.tensors[0].me[p_] = es
+        og.adjacency.m.add(p_)
+    spec = host.cond_spec(src_labels=["Person"], hops=[(["KNOWS"], []), (["KNOWS"], [])])
+    sources = list(range(n))                                     # the label scan feeds every node id
+    count, want = 0, 0
+    for b in range(0, n, 1024):
+        batch = sources[b:b + 1024]
+        (rows, dest, _), nulls, flops = g.cond_traverse_batch(spec, batch, as_arrays=True)
+        count += len(dest)
+        ref = model.expand_batch(og, batch, ["KNOWS"], src_labels=["Person"], chain=[(["KNOWS"], [])])[0]
+        want += len(ref)
+        assert list(zip(rows.tolist(), dest.tolist())) == ref
+    assert count == want > 10000
+
+
 # ---- algo.BFS known answers (tests/flow/test_bfs.py:10-25, 63-213) ------------------------------------------
 def bfs5(hctx, commit):
     b = gold("bfs5.json")

@@ -154,6 +154,51 @@ def test_expand_modes_match_oracle(ctx, mode, k):
         ctx.set_option("expand_mode", 0)
 
 
+@pytest.mark.parametrize("k,with_delta,with_label", [(1, False, False), (70, True, False), (300, True, True),
+                                                     (1100, False, True)])
+def test_expand_levels_per_hop_sets_and_distinct_union(ctx, k, with_delta, with_label):
+    """fgpu_expand_levels (variable-length [*1..4] core, SURVEY §8f-1 / BASELINE config 5): per-hop result of the
+    delta_lmxm chain and the DISTINCT union over the hops, against the oracle's chain of products."""
+    a = oracle.rmat_csr(10)
+    n = a.nrows
+    rng = np.random.default_rng(77 + k)
+    dp, dm = _delta_layers(a, rng, 50, 50)
+    src = rng.integers(0, n, k).astype(U64)
+    if k > 8:
+        src[::7] = np.uint64(2**64 - 1)
+    valid = src != np.uint64(2**64 - 1)
+    f = oracle.build_csr(k, n, np.arange(k, dtype=U64)[valid], src[valid])
+    label_ids = np.nonzero((oracle.mix64(np.arange(n, dtype=U64)) % np.uint64(3)) != 0)[0]
+    label = oracle.bits_from_ids(n, label_ids)
+    A, DP, DM = up(ctx, a), up(ctx, dp), up(ctx, dm)
+    hops = 4
+    got = engine.expand_levels(ctx, src, [A] * hops, [DP] * hops if with_delta else None,
+                               [DM] * hops if with_delta else None, label if with_label else None)
+    c, union, flops_ref = f, set(), 0
+    for h in range(hops):
+        c, fl = oracle.delta_lmxm(c, a, dp if with_delta else None, dm if with_delta else None)
+        flops_ref += fl
+        rows, cols = c.pairs()
+        if with_label:
+            keep = np.isin(cols, label_ids)
+            rows, cols = rows[keep], cols[keep]
+        shown = oracle.build_csr(k, n, rows, cols)
+        assert got["hop_nnz"][h] == shown.nnz, f"hop {h + 1}"
+        assert got["hop_checksum"][h] == oracle.checksum(shown), f"hop {h + 1}"
+        union |= set(zip(rows.tolist(), cols.tolist()))
+    assert got["flops"] == flops_ref
+    u = oracle.build_csr(k, n, [r for r, _ in union], [c_ for _, c_ in union])
+    assert got["union_nnz"] == len(union) and got["union_checksum"] == oracle.checksum(u)
+    if not with_delta and not with_label:
+        # clean layers: the DISTINCT [*1..4] end points of one source = BFS levels 1..4 (+ the source itself
+        # when it lies on a cycle of length <= 4)
+        for i in np.nonzero(valid)[0][:5]:
+            level, _, _ = oracle.bfs(a, int(src[i]), 4, want_parent=False)
+            reach = {int(v) for v in np.nonzero((level >= 1) & (level <= 4))[0]}
+            mine = {c_ for r, c_ in union if r == i}
+            assert mine - {int(src[i])} == reach - {int(src[i])}
+
+
 def test_expand_rmat22_three_hops_both_forms_agree(ctx):
     """Full-size graph (BASELINE.json configs[1]/[2] shape): 512 sources, 3 hops — the sorted-CSR chain
     and the bit-parallel chain must give the same result size, order-independent checksum and flops."""

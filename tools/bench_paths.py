@@ -7,7 +7,10 @@
           layers
   host    CondTraverseOp::expand_batch through the C++ host layer vs the bare fgpu_expand call
 
-usage: python tools/bench_paths.py [merge|expand|host|all] [scale]
+  reach   [*1..4] DISTINCT reachability (fgpu_expand_levels) with dirty layers, device fold, folded rerun
+          (SURVEY §8d config 5 stand-in)
+
+usage: python tools/bench_paths.py [merge|expand|reach|host|all] [scale]
 """
 import json
 import sys
@@ -101,6 +104,33 @@ def bench_expand(ctx, scale, hops=3, batch=1024, nbatches=3):
                           "GBps": round((4 * tot_f + 4 * tot_n) / tot_t / 1e9, 1)}), flush=True)
 
 
+def bench_reach(ctx, scale=19, edge_factor=38, hops=4, batch=1024):
+    """BASELINE config 5 stand-in (LDBC SF100 is not available offline): ~0.5 M vertices / ~20 M edges,
+    [*1..4] DISTINCT reachability of 1024 sources with dirty layers, the Delta fold on device, then the same
+    query on the folded base."""
+    rng = np.random.default_rng(5)
+    A = ctx.mat_rmat(scale, edge_factor)
+    n, nnz = A.nrows, A.nvals
+    dp, dm = deltas(ctx, A, 0.001, rng)
+    src = rng.choice(n, batch, replace=False).astype(np.uint64)
+    for name, m, p_, d_ in (("dirty-0.1%", A, dp, dm), ("folded", None, None, None)):
+        if m is None:
+            dt_fold, m = timed(ctx, lambda: A.merge(dp, dm), reps=3)
+            b_alg = 4 * (nnz + dp.nvals + dm.nvals) + 4 * m.nvals + 8 * (n + 1)
+            print(json.dumps({"path": "delta_fold", "scale": scale, "nnz_m": nnz, "nnz_out": m.nvals,
+                              "ms": round(dt_fold * 1e3, 3), "GBps": round(b_alg / dt_fold / 1e9, 1)}), flush=True)
+        args = ([m] * hops, [p_] * hops if p_ else None, [d_] * hops if d_ else None)
+        engine.expand_levels(ctx, src, *args)   # warm-up: transpose cache
+        ctx.sync()
+        t0 = time.perf_counter()
+        r = engine.expand_levels(ctx, src, *args)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"path": "varlen_reach", "layers": name, "scale": scale, "edges": m.nvals, "hops": hops,
+                          "batch_rows": batch, "ms": round(dt * 1e3, 3), "hop_nnz": r["hop_nnz"],
+                          "distinct_1_to_k": r["union_nnz"], "flops": r["flops"],
+                          "GTEPS": round(r["flops"] / dt / 1e9, 2)}), flush=True)
+
+
 def bench_host(scale):
     """expand_batch through libfalkor_host.so (label probes, layer waits, result hand-off) vs bare fgpu_expand."""
     from falkordb_amd import host
@@ -148,6 +178,10 @@ if __name__ == "__main__":
     if what in ("expand", "all"):
         c = engine.Context(0)
         bench_expand(c, scale or 24)
+        c.close()
+    if what in ("reach", "all"):
+        c = engine.Context(0)
+        bench_reach(c, scale or 19)
         c.close()
     if what in ("host", "all"):
         bench_host(scale or 18)
