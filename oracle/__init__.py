@@ -29,11 +29,46 @@ U64 = np.uint64
 _p64 = ctypes.POINTER(ctypes.c_uint64)
 
 
+_OMP_PATH = os.path.join(_HERE, "_build", "liboracle_omp.so")
+_omp = None
+
+
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_LIB_PATH):
-        subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
+    stale = force
+    for src, lib_path in (("oracle.c", _LIB_PATH), ("oracle_omp.c", _OMP_PATH)):
+        s = os.path.join(_HERE, src)
+        if not os.path.exists(lib_path) or os.path.getmtime(s) > os.path.getmtime(lib_path):
+            stale = True
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "all"] + (["-B"] if force else []), check=True, capture_output=True)
     return _LIB_PATH
+
+
+def omp_lib():
+    global _omp
+    if _omp is None:
+        build()
+        L = ctypes.CDLL(_OMP_PATH)
+        L.orc_bfs_omp.restype = ctypes.c_uint64
+        L.orc_omp_threads.restype = ctypes.c_int
+        _omp = L
+    return _omp
+
+
+def omp_threads() -> int:
+    return int(omp_lib().orc_omp_threads())
+
+
+def bfs_omp(a: "CSR", at: "CSR | None", src: int, max_level: int = -1, threads: int = 0, alpha: float = 15.0):
+    """Multi-threaded CPU stand-in for LAGraph's push/pull BFS (oracle_omp.c): bench.py's cpu_baseline.
+    Returns (level int32[n], edges_traversed)."""
+    level = np.zeros(a.nrows, dtype=np.int32)
+    e = omp_lib().orc_bfs_omp(ctypes.c_uint64(a.nrows), _ptr(a.rowptr), _ptr(a.colidx),
+                              _ptr(at.rowptr) if at is not None else None,
+                              _ptr(at.colidx) if at is not None else None, ctypes.c_uint64(src),
+                              ctypes.c_int64(max_level), level.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                              ctypes.c_int(threads), ctypes.c_double(alpha))
+    return level, int(e)
 
 
 def lib():
