@@ -84,6 +84,11 @@ SIGNATURES = {
     "fgpu_bfs_part_step": (C.c_int32, [vp]),
     "fgpu_bfs_part_commit": (C.c_int32, [vp]),
     "fgpu_bfs_part_done": (C.c_int32, [vp, i32p, i32p]),
+    "fgpu_bfs_slab_set_buffers": (C.c_int32, [vp, vp, vp, vp]),
+    "fgpu_bfs_slab_set_degrees": (C.c_int32, [vp, vp]),
+    "fgpu_bfs_slab_begin": (C.c_int32, [vp, C.c_uint64, C.c_int64, C.c_int]),
+    "fgpu_bfs_slab_level": (C.c_int32, [vp, C.POINTER(C.c_int)]),
+    "fgpu_mat_row_degrees": (C.c_int32, [vp, vp, vp]),
     "fgpu_mat_col_slab": (C.c_int32, [vp, vpp, vp, C.c_uint64, C.c_uint64]),
     "fgpu_mat_row_slab": (C.c_int32, [vp, vpp, vp, C.c_uint64, C.c_uint64]),
     "fgpu_bench_spmv": (C.c_int32, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), u64p]),

@@ -83,6 +83,12 @@ struct BfsArgs {
     u64* bm[3];       // fused single-rank path: rotating frontier bitmaps
     u32* queue[2];    // fused single-rank path: vertex-id lists of small frontiers (QCAP entries each)
     u32* host_done;   // fused single-rank path: pinned host word, set to 0x80000000 | levels when the search ends
+    // fused slab path (multi-rank v2: ONE level kernel + ONE frontier all-gather per level, no commit pass):
+    u32 slab_mode;    // != 0: cur = nxt_global (the gathered bitmap); discoveries go to slab_nxt, slab_zero is cleared
+    u32 slabw;        // u64 words of the owned slab
+    u64* slab_nxt;    // this level's send buffer (slabw words), indexed with the GLOBAL word index minus lo / 64
+    u64* slab_zero;   // the other send buffer: zeroed for the next level
+    const u32* gdeg;  // nullable: global out-degree of every vertex (a column slab only knows its own share)
 };
 
 __device__ __forceinline__ bool test_bit(const u64* bm, u32 v) {
@@ -347,7 +353,7 @@ __device__ void pull_body(const BfsArgs& a, const u64* __restrict__ frontier, co
 // this level reads bm[rot], ORs into bm[rot+1] (zeroed by the previous level) and zeroes
 // bm[rot+2] for the next one.
 // ---------------------------------------------------------------------------------
-struct LevelAcc { u64 count, mf, scanned; };
+struct LevelAcc { u64 count, mf, scanned, seen; };
 
 // Per-wavefront view of the NEXT frontier's queue.  Small frontiers (the first and last levels of
 // every BFS) are walked from the queue instead of scanning the whole bitmap.  A level appends only
@@ -378,10 +384,10 @@ __device__ __forceinline__ void queue_append(QueueCtx& qc, bool won, u32 v) {
 }
 
 __device__ __forceinline__ void note_discovery(const BfsArgs& a, QueueCtx& qc, u32 u, LevelAcc& acc) {
-    const u32 deg = a.A.rowptr[u + 1] - a.A.rowptr[u];
+    const u32 rowdeg = a.A.rowptr[u + 1] - a.A.rowptr[u];
     acc.count += 1;
-    acc.mf += deg;
-    if (deg >= HUB_DEG) {  // rare; returning form so the count has landed before the block's ticket
+    acc.mf += a.gdeg ? a.gdeg[u] : rowdeg;   // slab plans: the owner accounts the vertex's GLOBAL out-degree
+    if (rowdeg >= HUB_DEG) {  // rare; returning form so the count has landed before the block's ticket
         const u32 r = atomicAdd(qc.hubs, 1u);
         asm volatile("" ::"v"(r));
     }
@@ -563,11 +569,15 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
-    const u32 nwords = (a.n + 63) >> 6;
+    // a slab plan only owns (and only holds in-edges of) the destinations [lo, hi): words [lo/64, hi/64)
+    const u32 nwords_all = (a.n + 63) >> 6;
+    const u32 w_lo = a.slab_mode ? (a.lo >> 6) : 0u;
+    const u32 w_hi_raw = a.slab_mode ? ((a.hi + 63) >> 6) : nwords_all;
+    const u32 nwords = w_hi_raw < nwords_all ? w_hi_raw : nwords_all;
     const u32 nsuper = (nwords + PULL_R - 1) / PULL_R;
     const u32* __restrict__ f32 = (const u32*)frontier;
     const u32* __restrict__ col = a.At.colidx;
-    for (u32 G = wave; G < nsuper; G += nwaves) {
+    for (u32 G = w_lo / PULL_R + wave; G < nsuper; G += nwaves) {
         u64 mword[PULL_R];
         bool live = false;
 #pragma unroll
@@ -730,19 +740,55 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
 // End-of-level control, run by the first wavefront of the LAST workgroup to finish (ticket below):
 // sums the statistic slots, advances level / rotation / queue, applies the push<->pull rule and
 // raises `done`.  Same arithmetic as bfs_ctrl_kernel (the multi-rank path keeps that kernel).
-__device__ void fused_ctrl(BfsCtrl* c, u32* host_done) {
+__device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
     const u32 t = threadIdx.x;  // 0..63
     u64 v0 = __hip_atomic_load(&c->slot_count[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v1 = __hip_atomic_load(&c->slot_mf[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v3 = __hip_atomic_load(&c->slot_scan[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 v2 = slab ? __hip_atomic_load(&c->slot_indeg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     if (v0) c->slot_count[t] = 0;
     if (v1) c->slot_mf[t] = 0;
     if (v3) c->slot_scan[t] = 0;
+    if (v2) c->slot_indeg[t] = 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         v0 += __shfl_xor(v0, d, 64);
         v1 += __shfl_xor(v1, d, 64);
         v3 += __shfl_xor(v3, d, 64);
+        v2 += __shfl_xor(v2, d, 64);
+    }
+    if (slab) {
+        // Slab plans (one rank of a multi-GPU search): every counter here is LOCAL — the vertices this rank
+        // discovered (v0), their global out-degrees (v1) — except v2 = |frontier just consumed|, popcounted
+        // from the gathered bitmap and therefore identical on every rank.  Termination uses v2 only, so all
+        // ranks stop at the same launch; the direction of the next level is this rank's own Beamer rule on its
+        // own share (a rank's push work ~ sum of the global degrees of ITS discoveries when ids are scrambled,
+        // its pull work ~ its unvisited share of A' rows).  Either direction yields the same owned bits.
+        if (t != 0) return;
+        if (c->direction == 1) { c->scanned_push += v3; c->push_levels += 1; }
+        else { c->scanned_pull += v3; c->pull_levels += 1; }
+        c->level += 1;
+        c->n_frontier = v2;
+        c->m_frontier = v1;
+        c->reached += v0;
+        c->edges_traversed += v1;
+        c->rot += 1;
+        const bool done = (v2 == 0) || (c->max_level >= 0 && c->level >= c->max_level);
+        c->done = done ? 1 : 0;
+        if (done && host_done)
+            __hip_atomic_store(host_done, 0x80000000u | (u32)c->level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        int nd = 1;
+        if (c->force_dir == 1 || !c->has_at) nd = 1;
+        else if (c->force_dir == 2) nd = 2;
+        else {
+            const double un = (double)(c->n_total > c->reached ? c->n_total - c->reached : 0);
+            const u64 m_u = (u64)((double)c->nnz_at * un / (double)(c->n_total ? c->n_total : 1));
+            nd = ((double)v1 * (double)c->alpha > (double)m_u) ? 2 : 1;
+        }
+        c->direction = nd;
+        c->use_queue = 0;
+        c->q_open = 0;
+        return;
     }
     const u32 rot = c->rot;
     // lanes 0..7: lengths of the segments appended this level
@@ -817,58 +863,69 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
     BfsCtrl* c = a.ctrl;
     if (c->done) return;
     const u32 rot = c->rot;
-    const u64* cur = a.bm[rot % 3];
-    u64* nxt = a.bm[(rot + 1) % 3];
-    u64* zr = a.bm[(rot + 2) % 3];
+    const bool slab = a.slab_mode != 0;
+    // slab plans read the frontier the all-gather just delivered and write their owned words of the next one
+    // into this level's send buffer (pointer pre-offset so that GLOBAL word indices work)
+    const u64* cur = slab ? a.nxt_global : a.bm[rot % 3];
+    u64* nxt = slab ? (a.slab_nxt - (a.lo >> 6)) : a.bm[(rot + 1) % 3];
+    u64* zr = slab ? a.slab_zero : a.bm[(rot + 2) % 3];
     const i32 newlevel = c->level + 1;
     const int dir = c->direction;
-    const u32 use_q = c->use_queue;
+    const u32 use_q = slab ? 0u : c->use_queue;
     const u32 qmax = c->qmax, qchunk = c->qchunk;
-    const bool hubs_present = c->hubs[rot & 1] != 0;
-    for (u32 w = blockIdx.x * 256 + threadIdx.x; w < a.nw; w += gridDim.x * 256) zr[w] = 0ull;
-    LevelAcc acc = {0, 0, 0};
+    // a slab plan cannot census hubs (other ranks discover them): it always walks its hub chunk list
+    const bool hubs_present = slab || c->hubs[rot & 1] != 0;
+    const u32 zwords = slab ? a.slabw : a.nw;
+    for (u32 w = blockIdx.x * 256 + threadIdx.x; w < zwords; w += gridDim.x * 256) zr[w] = 0ull;
+    LevelAcc acc = {0, 0, 0, 0};
+    if (slab)   // |frontier| from the gathered bitmap: the one statistic every rank sees identically
+        for (u32 w = blockIdx.x * 256 + threadIdx.x; w < a.nw; w += gridDim.x * 256)
+            acc.seen += (u64)__popcll(cur[w]);
     QueueCtx qc;
     qc.q = a.queue[(rot + 1) & 1] + (blockIdx.x % QSHARDS) * QSEG;
     qc.qlen = &c->qlen[(rot + 1) & 1][(blockIdx.x % QSHARDS) * 16];
     qc.hubs = &c->hubs[(rot + 1) & 1];
-    qc.open = c->q_open != 0;
+    qc.open = !slab && c->q_open != 0;
     if (dir == 1)
         push_fused<PARENT>(a, cur, use_q ? a.queue[rot & 1] : nullptr, &c->qlen[rot & 1][0], qmax, qchunk, hubs_present,
                            a.visited, nxt, newlevel, qc, acc);
     else
         pull_fused<PARENT>(a, cur, a.visited, nxt, newlevel, qc, acc);
     // block reduction of the per-thread statistics, one atomic triple per workgroup
-    u64 cnt = acc.count, mf = acc.mf, sc = acc.scanned;
+    u64 cnt = acc.count, mf = acc.mf, sc = acc.scanned, sn = acc.seen;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         cnt += __shfl_xor(cnt, d, 64);
         mf += __shfl_xor(mf, d, 64);
         sc += __shfl_xor(sc, d, 64);
+        sn += __shfl_xor(sn, d, 64);
     }
-    __shared__ unsigned long long s_acc[3];
+    __shared__ unsigned long long s_acc[4];
     __shared__ u32 s_last;
-    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
     __syncthreads();
-    if (lane_id() == 0 && (cnt | sc)) {
+    if (lane_id() == 0 && (cnt | sc | sn)) {
         atomicAdd(&s_acc[0], (unsigned long long)cnt);
         atomicAdd(&s_acc[1], (unsigned long long)mf);
         atomicAdd(&s_acc[2], (unsigned long long)sc);
+        atomicAdd(&s_acc[3], (unsigned long long)sn);
     }
     __syncthreads();  // also drains every wave's outstanding queue / hub atomics (vmcnt(0) before the barrier)
     if (threadIdx.x == 0) {
         const u32 slot = blockIdx.x & (STAT_SLOTS - 1);
         // returning atomics whose results are consumed: the sums have landed before the ticket is taken
-        unsigned long long r0 = 0, r1 = 0, r2 = 0;
+        unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         if (s_acc[0]) {
             r0 = atomicAdd((unsigned long long*)&c->slot_count[slot], s_acc[0]);
             r1 = atomicAdd((unsigned long long*)&c->slot_mf[slot], s_acc[1]);
         }
         if (s_acc[2]) r2 = atomicAdd((unsigned long long*)&c->slot_scan[slot], s_acc[2]);
-        asm volatile("" ::"v"(r0), "v"(r1), "v"(r2));
+        if (s_acc[3]) r3 = atomicAdd((unsigned long long*)&c->slot_indeg[slot], s_acc[3]);
+        asm volatile("" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3));
         s_last = take_ticket(c) ? 1u : 0u;
     }
     __syncthreads();
-    if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done);
+    if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done, slab);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1101,6 +1158,48 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     c->q_open = ((nd == 1 ? mf : (u64)a.n) <= QGATE) ? 1u : 0u;
 }
 
+// Fused slab path: clear the rank's workspace, seed the source into every rank's copy of the gathered
+// frontier (no collective needed for level 0) and, on the owner, into visited / level / the statistics.
+__global__ __launch_bounds__(256) void bfs_slab_begin_kernel(BfsArgs a, u64* send0, u64* send1, u32 src,
+                                                            i32 max_level, u32 has_at, u32 force_dir, float alpha,
+                                                            u64 nnz_at) {
+    const u32 tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    const bool owned = src >= a.lo && src < a.hi;
+    const u32 sw = src >> 6;
+    const u64 sbit = 1ull << (src & 63);
+    for (u32 i = tid; i < a.nw; i += nth) {
+        a.nxt_global[i] = (i == sw) ? sbit : 0ull;
+        a.visited[i] = (owned && i == sw) ? sbit : 0ull;
+    }
+    for (u32 i = tid; i < a.slabw; i += nth) { send0[i] = 0ull; send1[i] = 0ull; }
+    if (tid == 0 && owned) {
+        a.level[src] = 0;
+        if (a.parent) a.parent[src] = src;
+    }
+    if (blockIdx.x != 0) return;
+    BfsCtrl* c = a.ctrl;
+    u32* cw = (u32*)c;
+    for (u32 i = threadIdx.x; i < sizeof(BfsCtrl) / 4; i += 256) cw[i] = 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const u64 mf = a.gdeg ? a.gdeg[src] : (u64)(a.A.rowptr[src + 1] - a.A.rowptr[src]);
+    c->max_level = max_level;
+    c->n_frontier = 1;
+    c->m_frontier = mf;
+    c->reached = owned ? 1 : 0;            // local: the owner accounts a vertex
+    c->edges_traversed = owned ? mf : 0;
+    c->has_at = has_at;
+    c->force_dir = force_dir;
+    c->alpha = alpha;
+    c->nnz_at = nnz_at;
+    const u32 own_hi = a.hi < a.n ? a.hi : a.n;
+    c->n_total = own_hi > a.lo ? own_hi - a.lo : 0;   // owned vertices: the rank-local share the direction rule uses
+    c->done = (max_level == 0) ? 1 : 0;
+    if (max_level == 0 && a.host_done)
+        __hip_atomic_store(a.host_done, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    c->direction = (force_dir == 2 && has_at) ? 2 : 1;   // a one-vertex frontier is pushed
+}
+
 // level[v] = -1 wherever the search did not reach v (fused single-rank path, see bfs_fused_begin_kernel)
 __global__ void bfs_mask_levels_kernel(i32* __restrict__ level, const u64* __restrict__ visited, u32 n_pad) {
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n_pad; v += gridDim.x * 256)
@@ -1212,6 +1311,10 @@ struct fgpu_bfs_plan {
     u32* d_done = nullptr;       // the same word as the device sees it
     int enqueued = 0;            // levels enqueued since the last begin
     bool levels_masked = false;  // level[] already holds -1 for unreached vertices (set by fgpu_bfs_fetch)
+    const u64* mask_visited = nullptr;  // the visited bitmap fgpu_bfs_fetch masks level[] with (fused paths)
+    u64* slab_send[2] = {nullptr, nullptr};  // fused slab path: double-buffered send slabs (caller-owned)
+    const u32* gdeg = nullptr;               // fused slab path: global out-degrees (caller-owned, nullable)
+    u32 launch = 0;                          // fused slab path: level launches since begin
     int last_levels = 0;         // levels the previous search of this plan took (sizes the next blind batch)
     i32* level = nullptr;
     u32* parent = nullptr;
@@ -1243,6 +1346,7 @@ static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
     a.parent = p->want_parent ? p->parent : nullptr;
     a.ctrl = p->ctrl;
     a.nw = p->nw;
+    a.slab_mode = 0; a.slabw = p->slabw; a.slab_nxt = nullptr; a.slab_zero = nullptr; a.gdeg = nullptr;
     if (p->bm_block && fused) {
         a.bm[0] = p->bm_block;
         a.bm[1] = p->bm_block + p->nw;
@@ -1325,7 +1429,7 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
     } while (0);
     if (i == FGPU_OK) {
         hipError_t e = hipHostMalloc((void**)&p->h_ctrl, sizeof(BfsCtrl), hipHostMallocDefault);
-        if (e == hipSuccess && nranks == 1) {
+        if (e == hipSuccess) {
             e = hipHostMalloc((void**)&p->h_done, 64, hipHostMallocMapped);
             if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->d_done, p->h_done, 0);
             if (e == hipSuccess) *(volatile u32*)p->h_done = 0;
@@ -1417,6 +1521,73 @@ fgpu_info fgpu_bfs_part_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level)
     return FGPU_OK;
 }
 
+// fused slab path (multi-rank v2) ----------------------------------------------------------
+fgpu_info fgpu_bfs_slab_set_buffers(fgpu_bfs_plan* p, void* send0, void* send1, void* global_words) {
+    FGPU_REQUIRE(p && send0 && send1 && global_words, FGPU_NULL_POINTER, "fgpu_bfs_slab_set_buffers: NULL argument");
+    FGPU_REQUIRE(send0 != send1 && send0 != global_words && send1 != global_words, FGPU_INVALID,
+                 "fgpu_bfs_slab_set_buffers: the three buffers must be distinct");
+    fgpu_ctx* c = p->ctx;
+    if (!p->external_bufs) {
+        if (p->nxt_local != p->nxt_global) c->dev_free(p->nxt_local);
+        c->dev_free(p->nxt_global);
+    }
+    p->external_bufs = true;
+    p->nxt_global = (u64*)global_words;
+    p->nxt_local = p->nxt_global;
+    p->slab_send[0] = (u64*)send0;
+    p->slab_send[1] = (u64*)send1;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_slab_set_degrees(fgpu_bfs_plan* p, const uint32_t* global_out_degrees) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_slab_set_degrees: NULL plan");
+    p->gdeg = global_out_degrees;
+    return FGPU_OK;
+}
+
+static BfsArgs slab_args(fgpu_bfs_plan* p) {
+    BfsArgs a = make_args(p);
+    a.slab_mode = 1;
+    a.slabw = p->slabw;
+    a.slab_nxt = p->slab_send[p->launch & 1];
+    a.slab_zero = p->slab_send[(p->launch + 1) & 1];
+    a.gdeg = p->gdeg;
+    a.host_done = p->d_done;
+    return a;
+}
+
+fgpu_info fgpu_bfs_slab_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, int want_parent) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_slab_begin: NULL plan");
+    FGPU_REQUIRE(p->slab_send[0] && p->slab_send[1], FGPU_INVALID, "fgpu_bfs_slab_begin: call fgpu_bfs_slab_set_buffers first");
+    FGPU_REQUIRE(src < p->n, FGPU_OUT_OF_BOUNDS, "BFS source %llu >= %u vertices", (unsigned long long)src, p->n);
+    fgpu_ctx* ctx = p->ctx;
+    i32 ml = max_level < 0 ? -1 : (max_level > 0x7FFFFFFF ? 0x7FFFFFFF : (i32)max_level);
+    p->want_parent = want_parent != 0;
+    p->launch = 0;
+    p->levels_masked = false;
+    p->mask_visited = p->visited;
+    *(volatile u32*)p->h_done = 0;
+    BfsArgs a = slab_args(p);
+    hipLaunchKernelGGL(bfs_slab_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream, a, p->slab_send[0],
+                       p->slab_send[1], (u32)src, ml, p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha,
+                       p->At ? p->At->nnz : 0ull);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_slab_level(fgpu_bfs_plan* p, int* send_index) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_slab_level: NULL plan");
+    BfsArgs a = slab_args(p);
+    if (p->want_parent)
+        hipLaunchKernelGGL((bfs_fused_kernel<true, 0>), dim3(p->fgrid), dim3(256), 0, p->ctx->stream, a);
+    else
+        hipLaunchKernelGGL((bfs_fused_kernel<false, 0>), dim3(p->fgrid), dim3(256), 0, p->ctx->stream, a);
+    FGPU_HIP(hipGetLastError());
+    if (send_index) *send_index = (int)(p->launch & 1);
+    p->launch += 1;
+    return FGPU_OK;
+}
+
 // single-rank fused path ----------------------------------------------------------------
 static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) {
     FGPU_REQUIRE(src < p->n, FGPU_OUT_OF_BOUNDS, "BFS source %llu >= %u vertices", (unsigned long long)src, p->n);
@@ -1426,6 +1597,7 @@ static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) 
     *(volatile u32*)p->h_done = 0;
     p->enqueued = 0;
     p->levels_masked = false;
+    p->mask_visited = p->bm_block + 3 * (size_t)p->nw;
     hipLaunchKernelGGL(bfs_fused_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream, a, (u32)src, ml,
                        p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull);
     FGPU_HIP(hipGetLastError());
@@ -1591,9 +1763,9 @@ fgpu_info fgpu_bfs_fetch(fgpu_bfs_plan* p, int32_t* level, int64_t* parent) {
     fgpu_ctx* ctx = p->ctx;
     const u32 lo = p->lo, hi = p->hi < p->n ? p->hi : p->n;
     if (hi <= lo) return FGPU_OK;
-    if (p->nranks == 1 && p->bm_block && !p->levels_masked) {
+    if (p->mask_visited && !p->levels_masked) {
         hipLaunchKernelGGL(bfs_mask_levels_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream, p->level,
-                           (const u64*)(p->bm_block + 3 * (size_t)p->nw), p->nw * 64);
+                           p->mask_visited, p->nw * 64);
         FGPU_HIP(hipGetLastError());
         p->levels_masked = true;
     }

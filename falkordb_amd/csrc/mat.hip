@@ -397,6 +397,11 @@ __global__ void compact32_kernel(const u32* __restrict__ tmp, const u64* __restr
     }
 }
 
+__global__ void row_degree_kernel(const u32* __restrict__ rowptr, u32 nrows, u32* __restrict__ deg) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrows) deg[r] = rowptr[r + 1] - rowptr[r];
+}
+
 // dense rowptr for a (possibly hypersparse) view
 __global__ void dense_rowptr_len_kernel(CsrView a, u32* __restrict__ len) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -975,6 +980,19 @@ fgpu_info fgpu_mat_intersect_nvals(fgpu_ctx* ctx, const fgpu_mat* a, const fgpu_
 }
 
 // ---- slabs (multi-GPU sharding helpers) ----------------------------------------------
+fgpu_info fgpu_mat_row_degrees(fgpu_ctx* ctx, const fgpu_mat* a, uint32_t* out_dev) {
+    FGPU_REQUIRE(ctx && a && out_dev, FGPU_NULL_POINTER, "fgpu_mat_row_degrees: NULL argument");
+    DevBuf<u32> rp;
+    FGPU_TRY(dense_rowptr(ctx, a, rp));
+    if (a->nrows) {
+        hipLaunchKernelGGL(row_degree_kernel, dim3(cdiv(a->nrows, 256)), dim3(256), 0, ctx->stream,
+                           (const u32*)rp.p, (u32)a->nrows, out_dev);
+        FGPU_HIP(hipGetLastError());
+    }
+    FGPU_HIP(hipStreamSynchronize(ctx->stream));   // `rp` may return to the pool
+    return FGPU_OK;
+}
+
 fgpu_info fgpu_mat_col_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo, uint64_t hi) {
     FGPU_REQUIRE(ctx && out && a, FGPU_NULL_POINTER, "fgpu_mat_col_slab: NULL argument");
     FGPU_REQUIRE(!a->is_hyper() && !a->vals, FGPU_INVALID, "fgpu_mat_col_slab: needs a non-hypersparse pattern matrix");

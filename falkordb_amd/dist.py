@@ -1,12 +1,14 @@
 """Multi-GPU BFS driver: column-slab partition + one frontier all-gather per level.
 
 SURVEY.md §8e / BASELINE.json north_star: rank r owns destination vertices
-[r*slab, (r+1)*slab) and holds A[:, slab] (push) and A'[slab, :] (pull); every level each
-rank computes the new-frontier bits of its own slab (libfgpu step kernel), the slabs are
-all-gathered over RCCL/xGMI (`all_gather_into_tensor`: equal 1-D slabs, so the gathered buffer
-IS the global frontier bitmap), and the commit kernel adopts it.  Direction choice is
-rank-local (either direction yields the same owned bits); termination is decided from the
-global frontier population, identical on every rank, so no extra collective is needed.
+[r*slab, (r+1)*slab) and holds A[:, slab] (push) and A'[slab, :] (pull).  A column slab only ever
+discovers vertices it owns, so a level is ONE kernel per rank (libfgpu fgpu_bfs_slab_level: discovery,
+visited / level / parent update and the rank's owned words of the next frontier) followed by ONE
+collective: the equal 1-D slabs are all-gathered over RCCL/xGMI (`all_gather_into_tensor`), and the
+gathered buffer IS the global frontier bitmap the next level reads.  Termination is decided from the
+population of that bitmap (identical on every rank); the push / pull choice is rank-local (either
+direction yields the same owned bits), so no other collective is needed.  Levels are enqueued blind in
+batches; the host looks at the device control block once per batch.
 
 The level loop is generic over a `backend` (begin / step / commit / done) and a `gather`
 callable so that tests can drive the exact same control flow on CPU with gloo
@@ -42,40 +44,75 @@ def run_levels(backend, gather: Callable[[], None], src: int, max_level: int = -
 
 
 class HipSlabBackend:
-    """Product backend: libfgpu plan stepping on this rank's slab, buffers owned by torch."""
+    """Product backend, fused slab path: ONE level kernel + ONE all-gather per level (fgpu_bfs_slab_*).
+    Buffers are torch tensors so torch.distributed can use them directly.  `protocol="stepped"` selects the
+    older step / gather / commit kernels (kept for comparison and as a second implementation in the tests)."""
 
-    def __init__(self, ctx, A_slab, At_slab, rank: int, nranks: int, device):
+    def __init__(self, ctx, A_slab, At_slab, rank: int, nranks: int, device, protocol: str = "fused"):
         import torch
         from .engine import BfsPlan
 
         self.torch = torch
+        self.protocol = protocol
+        self.last_levels = 0
         self.plan = BfsPlan(ctx, A_slab, At_slab, rank, nranks)
         _, _, wpr = self.plan.part_buffers()
         self.words_per_rank = int(wpr)
-        # torch owns the exchange buffers so torch.distributed can use them directly
-        self.local = torch.zeros(self.words_per_rank, dtype=torch.int64, device=device)
-        self.glob = torch.zeros(self.words_per_rank * nranks, dtype=torch.int64, device=device)
         self.nranks = nranks
-        if nranks > 1:
-            self.plan.part_set_buffers(self.local.data_ptr(), self.glob.data_ptr())
-        else:
-            self.plan.part_set_buffers(self.glob.data_ptr(), self.glob.data_ptr())
+        self.glob = torch.zeros(self.words_per_rank * nranks, dtype=torch.int64, device=device)
+        if protocol == "stepped":
+            self.local = torch.zeros(self.words_per_rank, dtype=torch.int64, device=device)
+            if nranks > 1:
+                self.plan.part_set_buffers(self.local.data_ptr(), self.glob.data_ptr())
+            else:
+                self.plan.part_set_buffers(self.glob.data_ptr(), self.glob.data_ptr())
+            return
+        self.send = torch.zeros(2, self.words_per_rank, dtype=torch.int64, device=device)
+        self.send_index = 0
+        self.plan.slab_set_buffers(self.send[0].data_ptr(), self.send[1].data_ptr(), self.glob.data_ptr())
+        # global out-degrees: every rank's column slab knows its own share of each row; the sum over ranks is
+        # the degree the owner accounts at discovery (TEPS numerator) and feeds its push / pull rule with
+        self.deg = torch.zeros(int(A_slab.nrows), dtype=torch.int32, device=device)
+        A_slab.row_degrees(self.deg.data_ptr())
+        if nranks > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(self.deg, op=torch.distributed.ReduceOp.SUM)
+        self.plan.slab_set_degrees(self.deg.data_ptr())
+
+    def set_degrees(self, deg):
+        """Single-process gangs (tests): install the summed degree vector by hand."""
+        self.deg = deg
+        self.plan.slab_set_degrees(deg.data_ptr())
+
+    def send_buffer(self):
+        return self.local if self.protocol == "stepped" else self.send[self.send_index]
 
     def begin(self, src, max_level=-1):
-        self.plan.part_begin(src, max_level)
+        if self.protocol == "stepped":
+            self.plan.part_begin(src, max_level)
+        else:
+            self.plan.slab_begin(src, max_level, False)
 
     def step(self):
-        self.plan.part_step()
+        if self.protocol == "stepped":
+            self.plan.part_step()
+        else:
+            self.send_index = self.plan.slab_level()
 
     def commit(self):
-        self.plan.part_commit()
+        if self.protocol == "stepped":
+            self.plan.part_commit()
 
     def done(self):
         return self.plan.part_done()
 
     def gather(self):
         if self.nranks > 1:
-            self.torch.distributed.all_gather_into_tensor(self.glob, self.local)
+            self.torch.distributed.all_gather_into_tensor(self.glob, self.send_buffer())
+        elif self.protocol != "stepped":
+            self.glob.copy_(self.send_buffer())   # one rank: the "gather" is a device copy
 
     def run(self, src, max_level=-1):
-        return run_levels(self, self.gather, src, max_level)
+        # first blind batch = what the previous search needed (+1); R-MAT roots differ by a level at most
+        first = max(4, self.last_levels + 1) if self.last_levels else 6
+        self.last_levels = run_levels(self, self.gather, src, max_level, first_batch=first, batch=2)
+        return self.last_levels

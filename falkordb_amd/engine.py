@@ -231,6 +231,10 @@ class Mat:
         keys = ["tile_bits", "tiles", "groups", "items", "entries", "vec", "k", "bytes"]
         return dict(zip(keys, (int(x) for x in s)))
 
+    def row_degrees(self, out_dev_ptr: int):
+        """deg[r] = stored entries of row r, written to DEVICE memory (uint32[nrows], e.g. a torch int32 tensor)."""
+        check(self.ctx.lib.fgpu_mat_row_degrees(self.ctx._h, self._h, C.c_void_p(out_dev_ptr)))
+
     def col_slab(self, lo, hi) -> "Mat":
         h = C.c_void_p()
         check(self.ctx.lib.fgpu_mat_col_slab(self.ctx._h, C.byref(h), self._h, lo, hi))
@@ -390,6 +394,22 @@ class BfsPlan:
 
     def part_commit(self):
         check(self.ctx.lib.fgpu_bfs_part_commit(self._h))
+
+    # ---- fused slab path (multi-rank v2: one kernel + one all-gather per level) ----
+    def slab_set_buffers(self, send0_ptr: int, send1_ptr: int, global_ptr: int):
+        check(self.ctx.lib.fgpu_bfs_slab_set_buffers(self._h, C.c_void_p(send0_ptr), C.c_void_p(send1_ptr),
+                                                     C.c_void_p(global_ptr)))
+
+    def slab_set_degrees(self, deg_ptr: int | None):
+        check(self.ctx.lib.fgpu_bfs_slab_set_degrees(self._h, C.c_void_p(deg_ptr or 0)))
+
+    def slab_begin(self, src, max_level=-1, want_parent=False):
+        check(self.ctx.lib.fgpu_bfs_slab_begin(self._h, src, max_level, 1 if want_parent else 0))
+
+    def slab_level(self) -> int:
+        idx = C.c_int()
+        check(self.ctx.lib.fgpu_bfs_slab_level(self._h, C.byref(idx)))
+        return idx.value
 
     def part_done(self):
         d, l = C.c_int32(), C.c_int32()

@@ -294,6 +294,29 @@ fgpu_info fgpu_bfs_part_commit(fgpu_bfs_plan* plan);
  * the last committed frontier was empty or max_level was reached. */
 fgpu_info fgpu_bfs_part_done(fgpu_bfs_plan* plan, int32_t* done, int32_t* level);
 
+/* Fused slab path (multi-rank v2): ONE level kernel and ONE frontier all-gather per level — no commit pass,
+ * no control kernel.  The rank owns destinations [lo, hi) exactly as above; because a column slab only ever
+ * discovers vertices it owns, the level kernel updates visited / level / parent at discovery and writes its
+ * owned words of the next frontier into a send buffer; the host all-gathers that buffer into `global_words`
+ * (nranks * words_per_rank uint64 = the global frontier bitmap) and launches the next level.  Everything a
+ * level needs from other ranks is that bitmap: termination comes from its population (identical on all
+ * ranks), the push / pull choice is each rank's own.
+ *   set_buffers : send0 / send1 (words_per_rank uint64 each, double-buffered) and global_words, caller-owned
+ *                 DEVICE memory (torch tensors handed to all_gather_into_tensor);
+ *   set_degrees : optional global out-degree of every vertex (uint32[n], device) so that the owner accounts a
+ *                 vertex's whole out-degree in edges_traversed (a column slab holds only its share);
+ *   begin       : clears the workspace and seeds `src` on every rank (no collective for level 0);
+ *   level       : enqueues one level; *send_index (0/1) = the send buffer to all-gather next;
+ *   fgpu_bfs_part_done / _stats / _fetch work as for the stepped path (reached / edges_traversed are the
+ *   rank's own share: sum them over ranks). */
+fgpu_info fgpu_bfs_slab_set_buffers(fgpu_bfs_plan* plan, void* send0, void* send1, void* global_words);
+fgpu_info fgpu_bfs_slab_set_degrees(fgpu_bfs_plan* plan, const uint32_t* global_out_degrees);
+fgpu_info fgpu_bfs_slab_begin(fgpu_bfs_plan* plan, uint64_t src, int64_t max_level, int want_parent);
+fgpu_info fgpu_bfs_slab_level(fgpu_bfs_plan* plan, int* send_index);
+/* deg[r] = stored entries of row r (DEVICE uint32[nrows]); summed over the ranks' column slabs it is the global
+ * out-degree vector fgpu_bfs_slab_set_degrees takes. */
+fgpu_info fgpu_mat_row_degrees(fgpu_ctx* ctx, const fgpu_mat* a, uint32_t* out_dev);
+
 /* Build this rank's column slab of a full matrix: out = A[:, lo:hi) (global ids
  * kept), and its transpose restricted to rows [lo,hi).  Used to shard a replicated
  * or host-loaded adjacency. */

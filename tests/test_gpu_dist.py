@@ -16,14 +16,22 @@ pytestmark = pytest.mark.gpu
 class Gang:
     """`nranks` HipSlabBackends on one GPU stepping in lock-step (a stand-in for one rank per GPU)."""
 
-    def __init__(self, ctx, A, nranks, dev):
+    def __init__(self, ctx, A, nranks, dev, protocol="fused"):
         self.backs = []
+        self.protocol = protocol
         n = A.nrows
         for r in range(nranks):
             lo, hi, _ = fdist.slab_range(n, r, nranks)
             a_slab = A.col_slab(lo, min(hi, n))
-            self.backs.append(fdist.HipSlabBackend(ctx, a_slab, a_slab.transpose(), r, nranks, dev))
+            self.backs.append(fdist.HipSlabBackend(ctx, a_slab, a_slab.transpose(), r, nranks, dev, protocol))
         self.nranks = nranks
+        if protocol == "fused":
+            # what torch.distributed.all_reduce does across processes: slab-local row degrees -> global
+            total = self.backs[0].deg.clone()
+            for b in self.backs[1:]:
+                total += b.deg
+            for b in self.backs:
+                b.set_degrees(total)
 
     def begin(self, src, max_level=-1):
         for b in self.backs:
@@ -34,12 +42,12 @@ class Gang:
             b.step()
 
     def gather(self):
-        if self.nranks == 1:
-            return  # single-rank plans step in place: local IS the global buffer
+        if self.nranks == 1 and self.protocol == "stepped":
+            return  # single-rank stepped plans work in place: local IS the global buffer
         wpr = self.backs[0].words_per_rank
         for dst in self.backs:
             for r, src in enumerate(self.backs):
-                dst.glob[r * wpr:(r + 1) * wpr].copy_(src.local)
+                dst.glob[r * wpr:(r + 1) * wpr].copy_(src.send_buffer())
 
     def commit(self):
         for b in self.backs:
@@ -59,9 +67,10 @@ class Gang:
         return out
 
 
+@pytest.mark.parametrize("protocol", ["fused", "stepped"])
 @pytest.mark.parametrize("nranks", [1, 2, 4])
 @pytest.mark.parametrize("force", [0, 1, 2])
-def test_slab_partitioned_bfs_matches_oracle(ctx, nranks, force):
+def test_slab_partitioned_bfs_matches_oracle(ctx, nranks, force, protocol):
     scale = 14
     a = oracle.rmat_csr(scale)
     A = ctx.mat_rmat(scale)
@@ -70,7 +79,7 @@ def test_slab_partitioned_bfs_matches_oracle(ctx, nranks, force):
     with torch.cuda.stream(s):
         ctx.set_stream(s.cuda_stream)
         try:
-            gang = Gang(ctx, A, nranks, dev)
+            gang = Gang(ctx, A, nranks, dev, protocol)
             for b in gang.backs:
                 b.plan.tune(force_direction=force)
             for src in [int(np.argmax(np.diff(a.rowptr))), 5]:
@@ -82,6 +91,8 @@ def test_slab_partitioned_bfs_matches_oracle(ctx, nranks, force):
                         # slab-local out-degree sums add up to the global traversed-edge count
                         edges = sum(b.plan.stats()["edges_traversed"] for b in gang.backs)
                         assert edges == int(np.diff(a.rowptr)[ref >= 0].sum())
+                        if protocol == "fused":   # the owner accounts a vertex: shares add up to the total
+                            assert sum(b.plan.stats()["reached"] for b in gang.backs) == int((ref >= 0).sum())
         finally:
             torch.cuda.synchronize()
             ctx.set_stream(None)
