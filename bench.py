@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (fgpu_set_option)")
     args = ap.parse_args()
 
@@ -93,9 +94,12 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1
+    # --force-dist: drive the multi-rank code path (process group, column slab, slab backend, collectives)
+    # with world_size 1 — a smoke test of the N > 1 path on a 1-GPU box, not a benchmark configuration
+    use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as td
         td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
