@@ -57,7 +57,7 @@ const char* get_error();
 // is ~100 us; traversal calls must not pay it per hop) and the host allocator
 // hooks the caller handed to fgpu_init.
 struct fgpu_options {  // fgpu_set_option
-    int tiled_u = 4;           // items in flight per wavefront of the tiled kernel
+    int tiled_u = 8;           // items in flight per wavefront of the tiled kernel (8 KiB of entries per wave)
     int tiled_nt = 0;          // nontemporal entry loads
     int tiled_threads = 1024;  // its workgroup size
     int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)

@@ -16,10 +16,10 @@
 // wavefronts; a wavefront owns whole items, ORs hit bits into a per-lane 64-bit accumulator,
 // reduces it across the wave with DPP and publishes one atomicOr per item.
 //
-// Entry packing (32 bit, the same 4 B/entry as a CSR column index):
-//   bits  0..25  column - (tile << tile_bits)   (bit `tile_bits` set = padding entry; it probes
-//                the zero word kept behind the staged tile, so padding needs no branch)
-//   bits 26..31  row & 63
+// Entry packing: see pack_entry below (32 bit, the same 4 B/entry as a CSR column index).  Inside a
+// (tile, 64-row group) slot the entries of rows 0..31 come first, padded to a multiple of `vec`, then
+// those of rows 32..63, padded likewise: the `vec` entries a lane loads at once always belong to the same
+// half of the output word, so the half is selected once per load instead of once per entry.
 #include "common.hpp"
 
 namespace fgpu {
@@ -60,6 +60,17 @@ void tiles_release(fgpu_tiles* t) {
 // branching around the load, which keeps every load of a trip in flight together
 constexpr u32 PAD_HEAD = 4;
 
+// Packed entry (one per stored element, 4 B as in CSR): the three fields sit where the probe needs them so that
+// each costs ONE instruction to extract —
+//   bits  2..17  byte offset of the frontier word inside the LDS tile   (e & 0x3FFFC  -> ds_read_b32 address)
+//   bits 18..22  bit inside that word                                   (e >> 18      -> v_bfe_u32 offset, low 5 bits used)
+//   bits 26..31  row inside the 64-row group                            (e >> 26      -> shift amount, bit 31 = upper half)
+// The kernel is VALU-issue bound (a wave64 instruction holds a 16-lane SIMD for 4 cycles), so instructions per
+// entry, not bytes, set its speed.  A padding entry addresses the zero word kept past the tile.
+__host__ __device__ __forceinline__ u32 pack_entry(u32 col_in_tile, u32 row_in_group) {
+    return ((col_in_tile >> 5) << 2) | ((col_in_tile & 31u) << 18) | (row_in_group << 26);
+}
+
 __device__ __forceinline__ u32 lower_bound_col(const u32* __restrict__ col, u32 lo, u32 hi, u64 key) {
     while (lo < hi) {
         const u32 mid = lo + ((hi - lo) >> 1);
@@ -89,9 +100,10 @@ __global__ __launch_bounds__(256) void tiles_count_kernel(CsrView a, u32 nrows, 
         u32 lo = rb;
         for (u32 c = 0; c < ntiles; ++c) {
             const u32 hi = (c + 1 == ntiles) ? re : lower_bound_col(a.colidx, lo, re, (u64)(c + 1) << tile_bits);
-            const u32 total = wave_sum_u32(hi - lo);
+            const u32 total_lo = wave_sum_u32(lane < 32 ? hi - lo : 0u);
+            const u32 total_hi = wave_sum_u32(lane < 32 ? 0u : hi - lo);
             if (lane == 0) {
-                const u32 padded = (total + vec - 1) / vec * vec;
+                const u32 padded = (total_lo + vec - 1) / vec * vec + (total_hi + vec - 1) / vec * vec;
                 cnt_e[(size_t)c * ngroups + g] = padded;
                 cnt_i[(size_t)c * ngroups + g] = (padded + cap - 1) / cap;
             }
@@ -101,13 +113,14 @@ __global__ __launch_bounds__(256) void tiles_count_kernel(CsrView a, u32 nrows, 
 }
 
 __global__ __launch_bounds__(256) void tiles_fill_kernel(CsrView a, u32 nrows, u32 ngroups, u32 tile_bits, u32 ntiles,
-                                                        u32 cap, const u64* __restrict__ eoff,
+                                                        u32 vec, u32 cap, const u64* __restrict__ eoff,
                                                         const u32* __restrict__ ioff, u32* __restrict__ entries,
                                                         u32* __restrict__ item_off, u32* __restrict__ item_group) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
-    const u32 pad = 1u << tile_bits;
+    const u32 pad_lo = pack_entry(1u << tile_bits, 0);    // probes the zero word past the tile: never a hit
+    const u32 pad_hi = pack_entry(1u << tile_bits, 32);   // the same, carrying the upper-half flag
     for (u32 g = wave; g < ngroups; g += nwaves) {
         const u32 r = (g << 6) + lane;
         u32 rb = 0, re = 0;
@@ -123,13 +136,16 @@ __global__ __launch_bounds__(256) void tiles_fill_kernel(CsrView a, u32 nrows, u
                 if (lane >= (u32)d) inc += y;
             }
             const u32 total = __shfl(inc, 63, 64);
+            const u32 total_lo = __shfl(inc, 31, 64);                 // entries of rows 0..31
+            const u32 lo_padded = (total_lo + vec - 1) / vec * vec;   // rows 32..63 start on a `vec` boundary
             const size_t slot = (size_t)c * ngroups + g;
             const u32 base = (u32)eoff[slot] + PAD_HEAD;
             const u32 padded = (u32)(eoff[slot + 1] - eoff[slot]);
-            const u32 pos = base + inc - cnt;
+            const u32 pos = base + inc - cnt + (lane < 32 ? 0u : lo_padded - total_lo);
             const u32 cbase = c << tile_bits;
-            for (u32 j = 0; j < cnt; ++j) entries[pos + j] = (a.colidx[lo + j] - cbase) | (lane << 26);
-            for (u32 j = total + lane; j < padded; j += 64) entries[base + j] = pad;
+            for (u32 j = 0; j < cnt; ++j) entries[pos + j] = pack_entry(a.colidx[lo + j] - cbase, lane);
+            for (u32 j = total_lo + lane; j < lo_padded; j += 64) entries[base + j] = pad_lo;
+            for (u32 j = lo_padded + (total - total_lo) + lane; j < padded; j += 64) entries[base + j] = pad_hi;
             const u32 ib = ioff[slot], ni = ioff[slot + 1] - ib;
             for (u32 kk = lane; kk < ni; kk += 64) {
                 item_off[ib + kk] = base + kk * cap;
@@ -149,7 +165,7 @@ __global__ void tiles_finish_kernel(const u32* __restrict__ ioff, const u64* __r
         const size_t n = (size_t)ntiles * ngroups;
         item_off[ioff[n]] = (u32)eoff[n] + PAD_HEAD;
     }
-    if (c < PAD_HEAD) entries[c] = 1u << tile_bits;
+    if (c < PAD_HEAD) entries[c] = pack_entry(1u << tile_bits, 0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -168,6 +184,35 @@ __device__ __forceinline__ u32 wave_or_u32(u32 v) {
     v = dpp_or_row(v);
     return (u32)__builtin_amdgcn_readlane((int)v, 0) | (u32)__builtin_amdgcn_readlane((int)v, 16) |
            (u32)__builtin_amdgcn_readlane((int)v, 32) | (u32)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// OR-reduction of N (power of two, <= 16) per-lane values over a fully active wavefront, all at once.
+// Reduce-scatter over the low log2(N) lane bits — at the step for bit b a lane keeps the values whose index
+// has bit b equal to its own lane bit and ORs in its partner's copies of them — then a plain butterfly over the
+// remaining lane bits.  Afterwards every lane L holds the complete OR of value (L mod N).
+// Cost ~ 3 N + 2 (6 - log2 N) + ... instructions against ~15 N for N independent reductions.
+template <int N>
+__device__ __forceinline__ u32 wave_or_many(u32 (&v)[N], u32 lane) {
+    int n = N;
+#pragma unroll
+    for (int b = 0; (1 << b) < N; ++b) {
+        const bool up = (lane >> b) & 1u;
+        n >>= 1;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            if (i < n) {
+                // values 2i (bit b of its index = 0 after renumbering) and 2i+1 (bit = 1)
+                const u32 keep = up ? v[2 * i + 1] : v[2 * i];
+                const u32 send = up ? v[2 * i] : v[2 * i + 1];
+                v[i] = keep | (u32)__shfl_xor((int)send, 1 << b, 64);
+            }
+        }
+    }
+    u32 r = v[0];
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+        if ((1 << b) >= N) r |= (u32)__shfl_xor((int)r, 1 << b, 64);
+    return r;
 }
 
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
@@ -277,30 +322,44 @@ __global__ __launch_bounds__(1024) void tiled_mxv_kernel(TilesView t, const u64*
 #pragma unroll
                     for (int k = 0; k < K; ++k) asm volatile("" : "+v"(d[u][k]));
                 }
+                // two 32-bit accumulators per item, 32-bit shifts only: on gfx950 a v_lshlrev_b64 result
+                // read by a DPP instruction two wait states later came back wrong under multi-wave
+                // occupancy (measured; see DESIGN.md "gfx950 findings").  Per entry: v_and (LDS address),
+                // ds_read_b32, v_lshrrev, v_bfe_u32 (hit), v_lshrrev (row), v_lshl_or_b32; per load of V
+                // entries: one compare + two selects + two ORs for the half of the output word.
+                u32 acc[2 * U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    // two 32-bit accumulators, 32-bit shifts only: on gfx950 a v_lshlrev_b64 result
-                    // read by a DPP instruction two wait states later came back wrong under
-                    // multi-wave occupancy (measured; see DESIGN.md "gfx950 findings")
                     u32 acc_lo = 0, acc_hi = 0;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         u32 ee[V];
                         unpack<V>(d[u][k], ee);
+                        u32 part = 0;
 #pragma unroll
                         for (int jj = 0; jj < V; ++jj) {
-                            const u32 w = xs[(ee[jj] & 0x03FFFFFFu) >> 5];
-                            const u32 hit = (w >> (ee[jj] & 31u)) & 1u;
-                            const u32 bit = hit << ((ee[jj] >> 26) & 31u);
-                            const bool upper = (ee[jj] >> 31) != 0u;
-                            acc_lo |= upper ? 0u : bit;
-                            acc_hi |= upper ? bit : 0u;
+                            const u32 e = ee[jj];
+                            const u32 w = *(const u32*)((const char*)xs + (e & 0x3FFFCu));
+                            const u32 hit = __builtin_amdgcn_ubfe(w, e >> 18, 1u);   // offset = low 5 bits
+                            part = (hit << ((e >> 26) & 31u)) | part;                // one v_lshl_or_b32
                         }
+                        // the V entries of one load share their half of the output word (layout guarantee)
+                        const bool upper = (i32)ee[0] < 0;
+                        acc_lo |= upper ? 0u : part;
+                        acc_hi |= upper ? part : 0u;
                     }
-                    // empty / skipped items carry only padding entries: their word is 0
-                    const u32 lo = wave_or_u32(acc_lo);
-                    const u32 hi = wave_or_u32(acc_hi);
-                    const bool mine = lane == j0 + (u32)u;
+                    acc[2 * u] = acc_lo;       // empty / skipped items carry only padding entries: 0
+                    acc[2 * u + 1] = acc_hi;
+                }
+                // OR-reduce the 2U accumulators over the wavefront TOGETHER: a reduce-scatter (each step
+                // halves the values a lane carries while doubling the lanes they cover) instead of 2U
+                // independent 6-step reductions; lane L ends up with accumulator (L mod 2U) complete.
+                const u32 full = wave_or_many<2 * U>(acc, lane);
+                {   // item j0+u's halves are accumulators 2u and 2u+1: park them in lane j0+u
+                    const u32 u_of_lane = lane - j0;
+                    const bool mine = u_of_lane < (u32)U;
+                    const u32 lo = (u32)__shfl((int)full, (int)((2 * u_of_lane) & (2 * U - 1)), 64);
+                    const u32 hi = (u32)__shfl((int)full, (int)((2 * u_of_lane + 1) & (2 * U - 1)), 64);
                     res_lo = mine ? lo : res_lo;
                     res_hi = mine ? hi : res_hi;
                 }
@@ -433,7 +492,7 @@ fgpu_info tiles_build(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k)
         if ((info = ctx->dev_alloc((void**)&t->item_off, ((size_t)total_i + 1) * sizeof(u32))) != FGPU_OK) break;
         if ((info = ctx->dev_alloc((void**)&t->item_group, ((size_t)total_i + 1) * sizeof(u32))) != FGPU_OK) break;
         hipLaunchKernelGGL(tiles_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, mv, (u32)m->nrows, ngroups,
-                           (u32)tile_bits, ntiles, cap, (const u64*)eoff.p, (const u32*)ioff.p, t->entries, t->item_off,
+                           (u32)tile_bits, ntiles, (u32)vec, cap, (const u64*)eoff.p, (const u32*)ioff.p, t->entries, t->item_off,
                            t->item_group);
         if (hipGetLastError() != hipSuccess) { set_error("tiles_fill launch failed"); info = FGPU_DEVICE; break; }
         hipLaunchKernelGGL(tiles_finish_kernel, dim3(cdiv((u64)ntiles + 1, 64)), dim3(64), 0, ctx->stream,
