@@ -114,10 +114,48 @@ def rust_unit_pins():
     }
 
 
+def load_imdb():
+    """tests/flow/imdb: 284 movies + 1 300-odd actors from the csv files, loaded exactly as imdb_utils.py does
+    (CREATE lists the actors first, then the movies: node ids follow that order; one `act` edge per csv row whose
+    movie exists), and the expected results of the traversal-only queries of imdb_queries.py."""
+    import types
+    d = os.path.join(REF, "tests/flow/imdb")
+    movies = [r[0] for r in csv.reader(open(os.path.join(d, "resources/movies.csv")))]
+    movie_set = set(movies)
+    actors, seen, edges = [], set(), []
+    for r in csv.reader(open(os.path.join(d, "resources/actors.csv"))):
+        name, movie = r[0], r[2]
+        if name not in seen:
+            seen.add(name)
+            actors.append(name)
+        if movie in movie_set:
+            edges.append([name, movie])
+    # imdb_queries.py does `from imdb import QueryInfo`: give it a stand-in that just records the fields
+    stub = types.ModuleType("imdb")
+
+    class QueryInfo:
+        def __init__(self, query=None, description=None, expected_result=None, reversible=True, **kw):
+            self.query, self.description, self.expected_result = query, description, expected_result
+    stub.QueryInfo = QueryInfo
+    sys.modules["imdb"] = stub
+    spec = importlib.util.spec_from_file_location("imdb_queries", os.path.join(d, "imdb_queries.py"))
+    iq = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(iq)
+    q = iq.IMDBQueries()
+    want = ["number_of_actors_query", "actors_played_with_nicolas_cage_query",
+            "actors_played_in_movie_straight_outta_compton_query", "how_many_movies_cameron_diaz_played_query",
+            "grand_budapest_hotel_cast_and_their_other_roles"]
+    queries = {w: {"query": " ".join(getattr(q, w).query.split()), "expected": getattr(q, w).expected_result}
+               for w in want}
+    return {"source": "tests/flow/imdb/resources/{movies,actors}.csv + imdb_queries.py (imdb_utils.py load order)",
+            "actors": actors, "movies": movies, "act": edges, "queries": queries}
+
+
 def main():
     assert os.path.isdir(REF), "run in the build container (needs /root/reference)"
     for name, obj in [("social.json", load_social()), ("bfs5.json", bfs5()), ("expand_into.json", expand_into()),
-                      ("multiple_edges.json", multiple_edges()), ("rust_unit_pins.json", rust_unit_pins())]:
+                      ("multiple_edges.json", multiple_edges()), ("rust_unit_pins.json", rust_unit_pins()),
+                      ("imdb.json", load_imdb())]:
         with open(os.path.join(OUT, name), "w") as f:
             json.dump(obj, f, indent=1, sort_keys=True)
         print("wrote", name)

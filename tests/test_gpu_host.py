@@ -409,6 +409,47 @@ def test_social_queries(hctx, commit):                     # social_queries.py:5
     assert g.tensor_edge_count(0) == want["friend"] and g.tensor_edge_count(1) == want["visited"]
 
 
+# ---- imdb fixture known answers through the operators (tests/flow/imdb, imdb_queries.py) ------------------------
+@pytest.mark.parametrize("commit", [False, True], ids=["pending-deltas", "committed"])
+def test_imdb_known_answers(hctx, commit):
+    d = gold("imdb.json")
+    names = d["actors"] + d["movies"]
+    ida = {n: i for i, n in enumerate(d["actors"])}
+    idm = {n: len(d["actors"]) + i for i, n in enumerate(d["movies"])}
+    g = host.Graph(hctx, len(names))
+    la, lm = g.add_label("actor"), g.add_label("movie")
+    for n in d["actors"]:
+        g.label_node(ida[n], la)
+    for n in d["movies"]:
+        g.label_node(idm[n], lm)
+    t = g.add_type("act")
+    g.create_edges(t, [ida[a] for a, _ in d["act"]], [idm[m] for _, m in d["act"]], list(range(len(d["act"]))))
+    if commit:
+        g.commit()
+    q = d["queries"]
+    fwd = host.cond_spec(src_labels=["actor"], hops=[(["act"], ["movie"])])
+    # (a:actor)-[:act]->(m) with only m bound: the per-row path over the transposed structure (cond_traverse.rs:840-870)
+    cast_of = lambda m: sorted({f for f, _, _ in g.cond_traverse_row(fwd, to_id=m)})
+    rows, _, _ = g.cond_traverse_batch(fwd, [ida["Nicolas Cage"]])
+    got = sorted([names[a], names[m]] for _, m in rows for a in cast_of(m))
+    assert got == q["actors_played_with_nicolas_cage_query"]["expected"]
+    assert sorted(names[a] for a in cast_of(idm["Straight Outta Compton"])) == \
+        sorted(r[0] for r in q["actors_played_in_movie_straight_outta_compton_query"]["expected"])
+    rows, _, _ = g.cond_traverse_batch(fwd, [ida["Cameron Diaz"]])
+    assert [["Cameron Diaz", len(rows)]] == q["how_many_movies_cameron_diaz_played_query"]["expected"]
+    gbh = idm["The Grand Budapest Hotel"]
+    cast = cast_of(gbh)
+    opt = host.cond_spec(hops=[(["act"], ["movie"])], optional=True)
+    rows, nulls, _ = g.cond_traverse_batch(opt, cast)
+    assert nulls == []                                        # everyone played in GBH itself
+    got = [[names[cast[i]], names[m]] for i, m in rows if m != gbh]
+    matched = {i for i, m in rows if m != gbh}
+    got += [[names[cast[i]], None] for i in range(len(cast)) if i not in matched]   # WHERE m <> h leaves the NULL row
+    key = lambda r: (r[0], r[1] or "")
+    assert sorted(got, key=key) == sorted(q["grand_budapest_hotel_cast_and_their_other_roles"]["expected"], key=key)
+    assert g.tensor_edge_count(t) == len(d["act"])
+
+
 # ---- BASELINE config 1: LDBC-SNB-SF0.1-shaped 2-hop MATCH through the whole stack ----------------------------
 def test_ldbc_shaped_two_hop_match_count(hctx):
     """`MATCH (a:Person)-[:KNOWS]->()-[:KNOWS]->(c) RETURN count(c)` (bench row "two-hop",
