@@ -90,19 +90,30 @@ static fgpu_info transposed_with_items(fgpu_ctx* ctx, const fgpu_mat* m, const f
 // up to ~10^6 entries each, so one wavefront per row leaves most of the chip idle behind the hub rows.  Every
 // lane takes one entry and finds its row in the (L1-resident) row-pointer array.
 __global__ __launch_bounds__(256) void bp_scatter_csr_kernel(CsrView f, u32 nrows, u32 nnz, u32 ws,
-                                                            u64* __restrict__ x) {
+                                                            u64* __restrict__ x, uint8_t* __restrict__ xflag) {
     for (u32 q = blockIdx.x * 256 + threadIdx.x; q < nnz; q += gridDim.x * 256) {
         u32 lo = 0, hi = nrows - 1;   // largest i with rowptr[i] <= q
         while (lo < hi) {
             u32 mid = (lo + hi + 1) >> 1;
             if (f.rowptr[mid] <= q) lo = mid; else hi = mid - 1;
         }
-        atomicOr((unsigned long long*)&x[(size_t)f.colidx[q] * ws + (lo >> 6)], 1ull << (lo & 63));
+        const u32 col = f.colidx[q];
+        atomicOr((unsigned long long*)&x[(size_t)col * ws + (lo >> 6)], 1ull << (lo & 63));
+        xflag[col] = 1;
     }
+}
+
+__global__ void bp_flag_count_kernel(const uint8_t* __restrict__ flag, u32 n, unsigned long long* __restrict__ out) {
+    u32 c = 0;
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += flag[i] != 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (lane_id() == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
 // nnz and the order-independent checksum of the result (sum of mix64((row << 32) | dest)) straight from the
 // bit state — fgpu_expand_count needs no CSR.  One lane per (vertex, word).
+template <bool WITH_SUM>   // the checksum hashes every set bit (VALU-bound: ~35 instructions per result entry)
 __global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws,
                                                       const u64* __restrict__ label,
                                                       unsigned long long* __restrict__ acc) {
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y
         if (label && !((label[v >> 6] >> (v & 63)) & 1ull)) continue;
         u64 bits = y[(size_t)v * ws + k];
         cnt += (u64)__popcll(bits);
-        while (bits) {
+        while (WITH_SUM && bits) {
             const u32 b = (u32)__builtin_ctzll(bits);
             bits &= bits - 1;
             sum += mix64(((u64)(k * 64 + b) << 32) | v);
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y
     }
     if (lane_id() == 0 && cnt) {
         atomicAdd(&acc[0], (unsigned long long)cnt);
-        atomicAdd(&acc[1], (unsigned long long)sum);
+        if (WITH_SUM) atomicAdd(&acc[1], (unsigned long long)sum);
     }
 }
 
@@ -135,9 +146,14 @@ __global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y
 //   ws  = words per vertex row (power of two <= 64, or a multiple of 64)
 //   LN  = lanes per neighbour = min(ws, 64); 64 / LN neighbours are gathered per load
 // ---------------------------------------------------------------------------------
-template <int LN>
+// SPARSE: the frontier rows X[u] are mostly zero (the hop right after the switch from the sorted-CSR products:
+// a few 10^4 non-zero rows among 10^7 vertices).  A byte flag per vertex ("X[u] has a bit set", written by
+// whoever wrote X) is probed first — 64 neighbours per wavefront step, one byte each — and only flagged
+// neighbours pay the 8 W-byte row gather.  Every variant writes the flags of Y for the next hop.
+template <int LN, bool SPARSE>
 __global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __restrict__ items, u32 nitems, u32 ws,
-                                                     const u64* __restrict__ x, u64* __restrict__ y) {
+                                                     const u64* __restrict__ x, const uint8_t* __restrict__ xflag,
+                                                     u64* __restrict__ y, uint8_t* __restrict__ yflag) {
     constexpr int SLOTS = 64 / LN;
     const u32 lane = lane_id();
     const u32 wl = lane % LN, slot = lane / LN;
@@ -149,21 +165,44 @@ __global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __r
         const u32 e3 = items[3 * it + 2];
         const u32 e = e3 & 0x7FFFFFFFu;
         const bool split = (e3 >> 31) != 0;
+        bool any = false;
         for (u32 wb = 0; wb < nwb; ++wb) {
             const u32 wo = wb * LN + wl;
             u64 acc = 0ull;
-            // 4 gathers in flight per lane
-            for (u32 q0 = b; q0 < e; q0 += 4 * SLOTS) {
-                u32 u[4];
+            if (SPARSE) {
+                for (u32 q0 = b; q0 < e; q0 += 64) {
+                    const u32 q = q0 + lane;
+                    const u32 un = (q < e) ? at.colidx[q] : 0u;
+                    u64 live = __ballot((q < e) && xflag[un] != 0);
+                    while (live) {   // wave-uniform: SLOTS flagged neighbours per trip
+                        u32 src = 0;
+                        bool on = false;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const u32 q = q0 + k * SLOTS + slot;
-                    u[k] = (q < e) ? at.colidx[q] : 0xFFFFFFFFu;
+                        for (int sl = 0; sl < SLOTS; ++sl) {
+                            if (live) {
+                                const u32 idx = (u32)__builtin_ctzll(live);
+                                live &= live - 1ull;
+                                if ((int)slot == sl) { src = idx; on = true; }
+                            }
+                        }
+                        const u32 uu = (u32)__shfl((int)un, (int)src, 64);
+                        if (on) acc |= x[(size_t)uu * ws + wo];
+                    }
                 }
-                u64 xv[4];
+            } else {
+                // 4 gathers in flight per lane
+                for (u32 q0 = b; q0 < e; q0 += 4 * SLOTS) {
+                    u32 u[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) xv[k] = (u[k] != 0xFFFFFFFFu) ? x[(size_t)u[k] * ws + wo] : 0ull;
-                acc |= (xv[0] | xv[1]) | (xv[2] | xv[3]);
+                    for (int k = 0; k < 4; ++k) {
+                        const u32 q = q0 + k * SLOTS + slot;
+                        u[k] = (q < e) ? at.colidx[q] : 0xFFFFFFFFu;
+                    }
+                    u64 xv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xv[k] = (u[k] != 0xFFFFFFFFu) ? x[(size_t)u[k] * ws + wo] : 0ull;
+                    acc |= (xv[0] | xv[1]) | (xv[2] | xv[3]);
+                }
             }
 #pragma unroll
             for (int d = LN; d < 64; d <<= 1) acc |= __shfl_xor(acc, d, 64);
@@ -172,27 +211,38 @@ __global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __r
                 if (split) atomicOr((unsigned long long*)dst, (unsigned long long)acc);
                 else *dst = acc;
             }
+            any |= __ballot(acc != 0ull) != 0ull;   // any word of the row, whichever lane holds it
         }
+        if (any && lane == 0) yflag[v] = 1;   // "maybe non-zero": benign races, never cleared within a hop
     }
 }
 
-// delta layers (hypersparse, a handful of entries): Y[v] &= ~X[u] for dm, Y[v] |= X[u] for dp
+// delta layers: Y[v] &= ~X[u] for (u, v) in dm, Y[v] |= X[u] for (u, v) in dp.  Entry-parallel — a delta layer
+// built on the device has a dense row-pointer array (one slot per vertex, almost all empty), and a wavefront
+// per stored row spent its time walking 16 M empty rows: LN lanes take one entry, its row comes from a binary
+// search over the row pointers.
 template <bool IS_DM>
-__global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 w, u32 ws, const u64* __restrict__ x,
-                                                      u64* __restrict__ y) {
-    const u32 lane = lane_id();
-    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const u32 nwaves = (gridDim.x * 256) >> 6;
-    for (u32 r = wave; r < d.nvec; r += nwaves) {
-        const u32 u = d.hrows ? d.hrows[r] : r;
-        const u32 b = d.rowptr[r], e = d.rowptr[r + 1];
-        for (u32 q = b; q < e; ++q) {
-            const u32 v = d.colidx[q];
-            for (u32 k = lane; k < w; k += 64) {
-                const u64 xv = x[(size_t)u * ws + k];
-                if (xv == 0ull) continue;
-                if (IS_DM) atomicAnd((unsigned long long*)&y[(size_t)v * ws + k], (unsigned long long)~xv);
-                else atomicOr((unsigned long long*)&y[(size_t)v * ws + k], (unsigned long long)xv);
+__global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w, u32 ws, u32 ln,
+                                                      const u64* __restrict__ x, u64* __restrict__ y,
+                                                      uint8_t* __restrict__ yflag) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    const u32 per = nth / ln;             // entries in flight per sweep
+    const u32 sub = t % ln;
+    for (u32 q = t / ln; q < nnz; q += per) {
+        u32 lo = 0, hi = d.nvec - 1;      // largest stored row i with rowptr[i] <= q
+        while (lo < hi) {
+            const u32 mid = (lo + hi + 1) >> 1;
+            if (d.rowptr[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        const u32 u = d.hrows ? d.hrows[lo] : lo;
+        const u32 v = d.colidx[q];
+        for (u32 k = sub; k < w; k += ln) {
+            const u64 xv = x[(size_t)u * ws + k];
+            if (xv == 0ull) continue;
+            if (IS_DM) atomicAnd((unsigned long long*)&y[(size_t)v * ws + k], (unsigned long long)~xv);
+            else {
+                atomicOr((unsigned long long*)&y[(size_t)v * ws + k], (unsigned long long)xv);
+                yflag[v] = 1;
             }
         }
     }
@@ -301,17 +351,39 @@ static fgpu_info bp_alloc_zero(fgpu_ctx* ctx, DevBuf<u64>& buf, const BitState& 
     return FGPU_OK;
 }
 
+static fgpu_info bp_alloc_flags(fgpu_ctx* ctx, BitState& s) {
+    FGPU_TRY(s.flag.alloc(ctx, (size_t)s.n + 1));
+    FGPU_HIP(hipMemsetAsync(s.flag.p, 0, (size_t)s.n + 1, ctx->stream));
+    return FGPU_OK;
+}
+
+static fgpu_info bp_count_flags(fgpu_ctx* ctx, BitState& s) {
+    DevBuf<u64> acc;
+    FGPU_TRY(acc.alloc(ctx, 1));
+    FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream));
+    if (s.n) {
+        u32 grid = cdiv(s.n, 256);
+        if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
+        hipLaunchKernelGGL(bp_flag_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*)s.flag.p, s.n,
+                           (unsigned long long*)acc.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    return read_u64(ctx, acc.p, &s.nz_rows);
+}
+
 fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f) {
     FGPU_REQUIRE(!f->is_hyper(), FGPU_INVALID, "bit-parallel expansion: F must not be hypersparse");
     bp_layout(s, (u32)f->ncols, (u32)f->nrows);
     FGPU_TRY(bp_alloc_zero(ctx, s.x, s));
+    FGPU_TRY(bp_alloc_flags(ctx, s));
     if (f->nnz) {
         u32 grid = cdiv(f->nnz, 256);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
         hipLaunchKernelGGL(bp_scatter_csr_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(f), (u32)f->nrows,
-                           (u32)f->nnz, s.ws, s.x.p);
+                           (u32)f->nnz, s.ws, s.x.p, s.flag.p);
         FGPU_HIP(hipGetLastError());
     }
+    s.nz_rows = f->nnz < f->ncols ? f->nnz : f->ncols;   // an upper bound is all the next hop needs
     return FGPU_OK;
 }
 
@@ -347,12 +419,16 @@ fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* 
     if (total) {
         u32 grid = cdiv(total, 256);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-        hipLaunchKernelGGL(bp_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n, s.w, s.ws,
-                           label_dev, (unsigned long long*)acc.p);
+        if (checksum)
+            hipLaunchKernelGGL(bp_count_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n,
+                               s.w, s.ws, label_dev, (unsigned long long*)acc.p);
+        else
+            hipLaunchKernelGGL(bp_count_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n,
+                               s.w, s.ws, label_dev, (unsigned long long*)acc.p);
         FGPU_HIP(hipGetLastError());
     }
     FGPU_TRY(read_u64(ctx, acc.p, nnz));
-    FGPU_TRY(read_u64(ctx, acc.p + 1, checksum));
+    if (checksum) FGPU_TRY(read_u64(ctx, acc.p + 1, checksum));
     return FGPU_OK;
 }
 
@@ -384,6 +460,7 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
     BitState o;
     bp_layout(o, (u32)m->ncols, s.nsrc);
     FGPU_TRY(bp_alloc_zero(ctx, o.x, o));
+    FGPU_TRY(bp_alloc_flags(ctx, o));
     if (m->nnz) {
         const fgpu_mat* t = nullptr;
         FGPU_TRY(transposed_with_items(ctx, m, &t));
@@ -391,9 +468,19 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
         u32 grid = cdiv(nitems ? nitems : 1, 4);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
         const u32 ln = s.ws < 64 ? s.ws : 64;
+        // fewer than 1 row in 8 flagged: probing a byte per neighbour first beats gathering 8 W-byte rows
+        const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n;
 #define BP_LAUNCH(LN)                                                                                                   \
-    hipLaunchKernelGGL(bp_pull_kernel<LN>, dim3(grid), dim3(256), 0, ctx->stream, view_of(t), (const u32*)t->bp_items, \
-                       nitems, s.ws, (const u64*)s.x.p, o.x.p)
+    do {                                                                                                                \
+        if (sparse)                                                                                                     \
+            hipLaunchKernelGGL((bp_pull_kernel<LN, true>), dim3(grid), dim3(256), 0, ctx->stream, view_of(t),         \
+                               (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const uint8_t*)s.flag.p,     \
+                               o.x.p, o.flag.p);                                                                        \
+        else                                                                                                            \
+            hipLaunchKernelGGL((bp_pull_kernel<LN, false>), dim3(grid), dim3(256), 0, ctx->stream, view_of(t),        \
+                               (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const uint8_t*)s.flag.p,     \
+                               o.x.p, o.flag.p);                                                                        \
+    } while (0)
         switch (ln) {
             case 1: BP_LAUNCH(1); break;
             case 2: BP_LAUNCH(2); break;
@@ -406,21 +493,28 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
 #undef BP_LAUNCH
         FGPU_HIP(hipGetLastError());
     }
-    if (dm && dm->nnz) {
-        u32 grid = cdiv(dm->nvec ? dm->nvec : 1, 4);
-        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-        hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, view_of(dm), s.w, s.ws,
-                           (const u64*)s.x.p, o.x.p);
-        FGPU_HIP(hipGetLastError());
+    {
+        u32 ln = 1;                               // lanes per delta entry: a power of two covering the row words
+        while (ln < s.w && ln < 64) ln <<= 1;
+        if (dm && dm->nnz) {
+            u32 grid = cdiv((u64)dm->nnz * ln, 256);
+            if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+            hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, view_of(dm), (u32)dm->nnz,
+                               s.w, s.ws, ln, (const u64*)s.x.p, o.x.p, o.flag.p);
+            FGPU_HIP(hipGetLastError());
+        }
+        if (dp && dp->nnz) {
+            u32 grid = cdiv((u64)dp->nnz * ln, 256);
+            if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+            hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, view_of(dp), (u32)dp->nnz,
+                               s.w, s.ws, ln, (const u64*)s.x.p, o.x.p, o.flag.p);
+            FGPU_HIP(hipGetLastError());
+        }
     }
-    if (dp && dp->nnz) {
-        u32 grid = cdiv(dp->nvec ? dp->nvec : 1, 4);
-        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-        hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, view_of(dp), s.w, s.ws,
-                           (const u64*)s.x.p, o.x.p);
-        FGPU_HIP(hipGetLastError());
-    }
+    FGPU_TRY(bp_count_flags(ctx, o));
     s.x = std::move(o.x);
+    s.flag = std::move(o.flag);
+    s.nz_rows = o.nz_rows;
     s.n = o.n;
     return FGPU_OK;
 }

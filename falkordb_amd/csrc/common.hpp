@@ -279,6 +279,8 @@ struct BitState {
     u32 nsrc = 0;   // source rows of F
     u32 w = 0;      // words in use per vertex
     u32 ws = 0;     // row stride in words (power of two <= 64, or a multiple of 64)
+    DevBuf<uint8_t> flag;  // one byte per vertex: != 0 => row v may hold a set bit (lets a hop skip empty rows)
+    u64 nz_rows = 0;       // number of flagged rows (what decides the sparse / dense form of the next hop)
 };
 fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f);
 fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops);

@@ -328,7 +328,8 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                                const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
                                const uint64_t* dst_label_bitmap, fgpu_mat** result, u64* flops,
                                u64* count_only = nullptr /* [0] nnz, [1] checksum: no CSR is built when the
-                                                            chain ends in bit form */) {
+                                                            chain ends in bit form */,
+                               bool want_checksum = true) {
     FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
     fgpu_mat* f = nullptr;
     FGPU_TRY(upload_sources(ctx, &f, src_ids, nsrc, m[0]->nrows));
@@ -382,7 +383,8 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         }
         if (count_only) {
             *result = nullptr;
-            return bp_count(ctx, bs, dst_label_bitmap ? bm.p : nullptr, &count_only[0], &count_only[1]);
+            return bp_count(ctx, bs, dst_label_bitmap ? bm.p : nullptr, &count_only[0],
+                            want_checksum ? &count_only[1] : nullptr);
         }
         return bp_to_csr(ctx, bs, dst_label_bitmap ? bm.p : nullptr, result);
     }
@@ -450,7 +452,7 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
     if (flops) *flops = 0;
     fgpu_mat* r = nullptr;
     u64 cnt[2] = {0, 0};
-    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops, cnt));
+    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops, cnt, checksum != nullptr));
     if (!r) {   // the chain ended in bit form: counted there, no CSR was materialized
         *out_nnz = cnt[0];
         if (checksum) *checksum = cnt[1];
@@ -516,14 +518,14 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
             label_dev = bm.p;
         }
         u64 n = 0, cs = 0;
-        FGPU_TRY(bp_count(ctx, bs, label_dev, &n, &cs));
+        FGPU_TRY(bp_count(ctx, bs, label_dev, &n, hop_checksum ? &cs : nullptr));
         hop_nnz[h] = n;
         if (hop_checksum) hop_checksum[h] = cs;
         if (union_nnz || union_checksum) FGPU_TRY(bp_accumulate(ctx, un, bs));
     }
     if (union_nnz || union_checksum) {
         u64 n = 0, cs = 0;
-        FGPU_TRY(bp_count(ctx, un, label_dev, &n, &cs));
+        FGPU_TRY(bp_count(ctx, un, label_dev, &n, union_checksum ? &cs : nullptr));
         if (union_nnz) *union_nnz = n;
         if (union_checksum) *union_checksum = cs;
     }

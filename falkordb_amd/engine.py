@@ -270,7 +270,9 @@ def expand(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
     return rowptr, dest, flops.value
 
 
-def expand_count(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
+def expand_count(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None, want_checksum=True):
+    """fgpu_expand_count: (nnz, checksum, flops) of the k-hop result without materialising it on the host;
+    want_checksum=False skips the per-entry hashing (count only: `RETURN count(c)`), checksum comes back 0."""
     src = _u64(src_ids)
     am = _hop_arrays(m)
     adp = _hop_arrays(dp) if dp is not None else None
@@ -278,7 +280,7 @@ def expand_count(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=No
     lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
     nnz, cs, flops = C.c_uint64(), C.c_uint64(), C.c_uint64()
     check(ctx.lib.fgpu_expand_count(ctx._h, _p(src), len(src), am, adp, adm, len(m), _p(lab), C.byref(nnz),
-                                    C.byref(cs), C.byref(flops)))
+                                    C.byref(cs) if want_checksum else None, C.byref(flops)))
     return nnz.value, cs.value, flops.value
 
 

@@ -85,18 +85,22 @@ def bench_expand(ctx, scale, hops=3, batch=1024, nbatches=3):
     A = ctx.mat_rmat(scale)
     n, nnz = A.nrows, A.nvals
     dp, dm = deltas(ctx, A, 0.001, rng)
-    for name, layers in (("clean", ([A] * hops, None, None)), ("dirty-0.1%", ([A] * hops, [dp] * hops, [dm] * hops))):
+    for name, layers, cs in (("clean", ([A] * hops, None, None), True),
+                             ("clean", ([A] * hops, None, None), False),
+                             ("dirty-0.1%", ([A] * hops, [dp] * hops, [dm] * hops), True),
+                             ("dirty-0.1%", ([A] * hops, [dp] * hops, [dm] * hops), False)):
         tot_t, tot_f, tot_n = 0.0, 0, 0
         for b in range(nbatches + 1):
             src = rng.choice(n, batch, replace=False).astype(np.uint64)
             ctx.sync()
             t0 = time.perf_counter()
-            out_nnz, cs, flops = engine.expand_count(ctx, src, *layers)
+            out_nnz, _, flops = engine.expand_count(ctx, src, *layers, want_checksum=cs)
             dt = time.perf_counter() - t0
             if b == 0:
                 continue  # warm-up (transpose cache, pools)
             tot_t += dt; tot_f += flops; tot_n += out_nnz
-        print(json.dumps({"path": "khop_expand", "layers": name, "scale": scale, "hops": hops, "batch_rows": batch,
+        print(json.dumps({"path": "khop_expand", "layers": name, "result": "count + checksum" if cs else "count only",
+                          "scale": scale, "hops": hops, "batch_rows": batch,
                           "batches": nbatches, "ms_per_batch": round(tot_t / nbatches * 1e3, 3),
                           "flops_per_batch": tot_f // nbatches, "out_nnz_per_batch": tot_n // nbatches,
                           "GTEPS": round(tot_f / tot_t / 1e9, 2),
