@@ -559,6 +559,7 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
     }
 }
 
+typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int PULL_A = 4;  // in-neighbours probed per row before the cooperative phase
 constexpr int PULL_R = 4;  // 64-row words per wavefront trip (memory-level parallelism: the level is
                            // latency-bound, so one wave keeps 4 x (rowptr, 4 colidx, 4 probes) in flight)
@@ -577,6 +578,7 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
     const u32 nsuper = (nwords + PULL_R - 1) / PULL_R;
     const u32* __restrict__ f32 = (const u32*)frontier;
     const u32* __restrict__ col = a.At.colidx;
+    const u32 at_nnz = a.At.rowptr[a.n];
     for (u32 G = w_lo / PULL_R + wave; G < nsuper; G += nwaves) {
         u64 mword[PULL_R];
         bool live = false;
@@ -606,17 +608,40 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
             need[r] = (v < a.n) && !((mword[r] >> lane) & 1ull) && deg > 0;
             found[r] = false;
             par[r] = 0;
+            // the level is bound by the CU's address rate (one divergent lane-address per clock), not by bytes:
+            // the row's first four in-neighbours come in ONE dword-aligned 16 B load instead of four
+            const bool tail = rb[r] + PULL_A > at_nnz;   // last rows of the array: 16 B would overrun it
+            const u32x4_a4 q4 = *(const u32x4_a4*)(col + ((need[r] && !tail) ? rb[r] : 0u));
 #pragma unroll
-            for (int j = 0; j < PULL_A; ++j) c[r][j] = (need[r] && (u32)j < deg) ? col[rb[r] + j] : 0xFFFFFFFFu;
+            for (int j = 0; j < PULL_A; ++j) c[r][j] = (need[r] && !tail && (u32)j < deg) ? q4[j] : 0xFFFFFFFFu;
+            if (__ballot(need[r] && tail)) {
+#pragma unroll
+                for (int j = 0; j < PULL_A; ++j)
+                    if (need[r] && tail && (u32)j < deg) c[r][j] = col[rb[r] + j];
+            }
+        }
+        // ... and the frontier probes stop at the first hit: two rounds of two (hub-first order makes the first
+        // in-neighbour the likely parent), the second round only for rows still open
+#pragma unroll
+        for (int half = 0; half < PULL_A; half += 2) {
+            bool h[PULL_R][2];
+#pragma unroll
+            for (int r = 0; r < PULL_R; ++r) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32 x = c[r][half + j];
+                    h[r][j] = (x != 0xFFFFFFFFu) && !found[r] && ((f32[x >> 5] >> (x & 31)) & 1u);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PULL_R; ++r) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (h[r][j] && !found[r]) { found[r] = true; par[r] = c[r][half + j]; }
+            }
         }
 #pragma unroll
         for (int r = 0; r < PULL_R; ++r) {
-#pragma unroll
-            for (int j = 0; j < PULL_A; ++j) {
-                const u32 x = c[r][j];
-                const bool h = (x != 0xFFFFFFFFu) && ((f32[x >> 5] >> (x & 31)) & 1u);
-                if (h && !found[r]) { found[r] = true; par[r] = x; }
-            }
             if (need[r]) {
                 const u32 deg = re[r] - rb[r];
                 acc.scanned += deg < (u32)PULL_A ? deg : (u32)PULL_A;
@@ -628,40 +653,59 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
             if (g >= nwords) continue;  // wave-uniform
             const u32 v = (g << 6) + lane;
             const u32 deg = re[r] - rb[r];
-            const bool hub_here = __ballot(need[r] && deg >= HUB_DEG) != 0ull;
-            // phase B: rows still open are scanned by the whole wave, 256 coalesced elements per trip
+            // a word that holds a hub row (visited or not) is published with atomics: the hub section of a
+            // workgroup that ran ahead may already have set that row's visited AND next-frontier bits, and a
+            // plain store of this wave's word would wipe the hub out of the next frontier
+            const bool hub_here = __ballot(v < a.n && deg >= HUB_DEG) != 0ull;
+            // phase B: rows still open are scanned by the whole wave — FOUR rows per trip, 64 coalesced
+            // elements each (most open rows are shorter than that; four independent gathers and probes in
+            // flight instead of one row's 256).  Slot state is wave-uniform and lives in SGPRs (v_readlane).
             u64 pend = __ballot(need[r] && !found[r] && deg > (u32)PULL_A && deg < HUB_DEG);
             while (pend) {
-                const int l = (int)__builtin_ctzll(pend);
-                pend &= pend - 1ull;
-                const u32 b0 = __shfl(rb[r], l, 64) + PULL_A;
-                const u32 e0 = __shfl(re[r], l, 64);
-                bool hit = false;
-                u32 hc = 0;
-                for (u32 q = b0; q < e0; q += 256) {
+                int sl[4];
+                u32 sb[4], se[4], shc[4];
+                bool shit[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sl[k] = -1; sb[k] = 0; se[k] = 0; shit[k] = false; shc[k] = 0;
+                    if (pend) {
+                        sl[k] = (int)__builtin_ctzll(pend);
+                        pend &= pend - 1ull;
+                        sb[k] = (u32)__builtin_amdgcn_readlane((int)rb[r], sl[k]) + PULL_A;
+                        se[k] = (u32)__builtin_amdgcn_readlane((int)re[r], sl[k]);
+                    }
+                }
+                for (;;) {
+                    bool more = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) more |= (!shit[k] && sb[k] < se[k]);
+                    if (!more) break;
                     u32 x[4];
                     bool hh[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        u32 qq = q + 64 * k + lane;
-                        x[k] = (qq < e0) ? col[qq] : 0xFFFFFFFFu;
+                        const u32 qq = sb[k] + lane;
+                        x[k] = (!shit[k] && qq < se[k]) ? col[qq] : 0xFFFFFFFFu;
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         hh[k] = (x[k] != 0xFFFFFFFFu) && ((f32[x[k] >> 5] >> (x[k] & 31)) & 1u);
-                    u64 any = 0;
+                    u32 sc = 0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
+                        if (!shit[k] && sb[k] < se[k]) sc += (se[k] - sb[k] < 64u) ? (se[k] - sb[k]) : 64u;
                         const u64 H = __ballot(hh[k]);
-                        if (H && !any) {
-                            any = H;
-                            hc = __shfl(x[k], (int)__builtin_ctzll(H), 64);
+                        if (H) {
+                            shit[k] = true;
+                            shc[k] = (u32)__builtin_amdgcn_readlane((int)x[k], (int)__builtin_ctzll(H));
                         }
+                        sb[k] += 64;
                     }
-                    if (lane == 0) acc.scanned += (e0 - q < 256u) ? (e0 - q) : 256u;
-                    if (any) { hit = true; break; }
+                    if (lane == 0) acc.scanned += sc;
                 }
-                if ((int)lane == l && hit) { found[r] = true; par[r] = hc; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((int)lane == sl[k] && shit[k]) { found[r] = true; par[r] = shc[k]; }
             }
             const u64 neww = __ballot(found[r]);
             if (neww == 0ull) continue;

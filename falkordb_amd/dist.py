@@ -1,4 +1,5 @@
-"""Multi-GPU BFS driver: column-slab partition + one frontier all-gather per level.
+"""Multi-GPU drivers.  BFS: column-slab partition + one frontier all-gather per level.  k-hop MATCH: source
+rows sharded, layers replicated, no data-path collective (expand_sharded, end of file).
 
 SURVEY.md §8e / BASELINE.json north_star: rank r owns destination vertices
 [r*slab, (r+1)*slab) and holds A[:, slab] (push) and A'[slab, :] (pull).  A column slab only ever
@@ -116,3 +117,84 @@ class HipSlabBackend:
         first = max(4, self.last_levels + 1) if self.last_levels else 6
         self.last_levels = run_levels(self, self.gather, src, max_level, first_batch=first, batch=2)
         return self.last_levels
+
+
+# ---------------------------------------------------------------------------------------------------
+# k-hop MATCH across ranks (last bullet): the source rows of F are independent units, the
+# layers are replicated (RMAT-26 is 4.3 GB of 288), so a batch is split by rows, every rank runs the whole
+# chain on its share with NO data-path collective, and only the results travel (to the rank that talks to
+# the client).  `expand_local(src_ids) -> (rowptr, dest, flops)` is engine.expand bound to this rank's
+# context and layer handles; the CPU tests bind the oracle instead.
+
+def shard_rows(nrows: int, rank: int, nranks: int) -> tuple[int, int]:
+    """Contiguous, sizes differing by at most one; rank order = row order, so concatenation keeps the
+    ascending (row, dest) order CondTraverseOp::expand_batch iterates in (cond_traverse.rs:612-640)."""
+    base, extra = divmod(nrows, nranks)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _gather_varlen(t, group=None):
+    """All ranks' 1-D int64 tensors, concatenated in rank order (RCCL has no all-gather-v: sizes first, then one
+    padded all_gather_into_tensor)."""
+    import torch
+    import torch.distributed as td
+
+    world = td.get_world_size(group)
+    sizes = torch.zeros(world, dtype=torch.int64, device=t.device)
+    mine = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    td.all_gather_into_tensor(sizes, mine, group=group)
+    sizes = sizes.tolist()
+    cap = max(max(sizes), 1)
+    pad = torch.zeros(cap, dtype=torch.int64, device=t.device)
+    pad[:t.numel()] = t
+    allb = torch.empty(world * cap, dtype=torch.int64, device=t.device)
+    td.all_gather_into_tensor(allb, pad, group=group)
+    return torch.cat([allb[r * cap:r * cap + sizes[r]] for r in range(world)])
+
+
+def expand_sharded(expand_local, src_ids, rank: int, nranks: int, device="cpu", collect: bool = True):
+    """One CondTraverse batch over `nranks` GPUs.  Returns (rowptr[nsrc+1], dest, flops) of the WHOLE batch on
+    every rank when `collect`, else this rank's share plus the batch totals (nnz, flops) — the
+    `RETURN count(c)` shape, where only two integers cross xGMI."""
+    import numpy as np
+    import torch
+    import torch.distributed as td
+
+    src_ids = np.ascontiguousarray(src_ids, dtype=np.uint64)
+    lo, hi = shard_rows(len(src_ids), rank, nranks)
+    if hi > lo:
+        rowptr, dest, flops = expand_local(src_ids[lo:hi])
+    else:       # more ranks than rows: this rank only takes part in the collectives
+        rowptr, dest, flops = np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.uint64), 0
+    rowptr = np.asarray(rowptr, dtype=np.uint64)
+    dest = np.asarray(dest, dtype=np.uint64)
+    if nranks == 1:
+        return (rowptr, dest, int(flops)) if collect else (rowptr, dest, int(len(dest)), int(flops))
+    tot = torch.tensor([len(dest), int(flops)], dtype=torch.int64, device=device)
+    td.all_reduce(tot, op=td.ReduceOp.SUM)
+    if not collect:
+        return rowptr, dest, int(tot[0]), int(tot[1])
+    counts = torch.from_numpy(np.diff(rowptr.astype(np.int64))).to(device)
+    counts = _gather_varlen(counts).cpu().numpy()
+    dest_all = _gather_varlen(torch.from_numpy(dest.view(np.int64)).to(device)).cpu().numpy().view(np.uint64)
+    rp = np.zeros(len(src_ids) + 1, dtype=np.uint64)
+    np.cumsum(counts, out=rp[1:].view(np.int64))
+    return rp, dest_all, int(tot[1])
+
+
+def expand_count_sharded(count_local, src_ids, rank: int, nranks: int, device="cpu"):
+    """`RETURN count(c)` over ranks: `count_local(src_ids) -> (nnz, flops)` is engine.expand_count on this rank's
+    share (nothing is materialised); the batch totals are one 16-byte all-reduce."""
+    import numpy as np
+    import torch
+    import torch.distributed as td
+
+    src_ids = np.ascontiguousarray(src_ids, dtype=np.uint64)
+    lo, hi = shard_rows(len(src_ids), rank, nranks)
+    nnz, flops = count_local(src_ids[lo:hi]) if hi > lo else (0, 0)
+    if nranks == 1:
+        return int(nnz), int(flops)
+    tot = torch.tensor([int(nnz), int(flops)], dtype=torch.int64, device=device)
+    td.all_reduce(tot, op=td.ReduceOp.SUM)
+    return int(tot[0]), int(tot[1])

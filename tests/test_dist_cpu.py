@@ -123,3 +123,76 @@ def test_slab_range_matches_plan_rounding():
     assert fdist.slab_range(1 << 22, 3, 8) == (3 * (1 << 19), 4 * (1 << 19), 1 << 19)
     lo, hi, slab = fdist.slab_range(1000, 1, 2)
     assert slab == 4096 and (lo, hi) == (4096, 8192)
+
+
+# ---- k-hop MATCH: source rows sharded over ranks, layers replicated -------------------------
+
+def _oracle_expand(a, dp, dm, hops):
+    n = a.nrows
+
+    def run(src):
+        k = len(src)
+        c = oracle.build_csr(k, n, np.arange(k, dtype=U64), np.asarray(src, dtype=U64))
+        flops = 0
+        for _ in range(hops):
+            c, fl = oracle.delta_lmxm(c, a, dp, dm)
+            flops += fl
+        return c.rowptr.astype(U64), c.colidx.astype(U64), flops
+    return run
+
+
+def _expand_inputs(scale, nsrc):
+    a = oracle.rmat_csr(scale)
+    n = a.nrows
+    rng = np.random.default_rng(11)
+    rows, cols = a.pairs()
+    pick = rng.choice(len(rows), 60, replace=False)
+    dm = oracle.build_csr(n, n, rows[pick], cols[pick])
+    dp = oracle.build_csr(n, n, rng.integers(0, n, 60).astype(U64), rng.integers(0, n, 60).astype(U64))
+    src = rng.integers(0, n, nsrc).astype(U64)
+    return a, dp, dm, src
+
+
+def _expand_worker(rank, world, port, scale, nsrc, hops, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, dp, dm, src = _expand_inputs(scale, nsrc)
+        run = _oracle_expand(a, dp, dm, hops)
+        rp, dest, flops = fdist.expand_sharded(run, src, rank, world)
+        _, _, nnz_tot, flops_tot = fdist.expand_sharded(run, src, rank, world, collect=False)
+        if rank == 1:   # every rank holds the whole result; check the non-zero one
+            q.put((rp, dest, flops, nnz_tot, flops_tot))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("nsrc", [37, 1])
+def test_two_rank_sharded_expand_matches_single_process_oracle(nsrc):
+    scale, hops = 9, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_expand_worker, args=(r, 2, port, scale, nsrc, hops, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rp, dest, flops, nnz_tot, flops_tot = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, dp, dm, src = _expand_inputs(scale, nsrc)
+    rp_ref, dest_ref, flops_ref = _oracle_expand(a, dp, dm, hops)(src)
+    np.testing.assert_array_equal(rp, rp_ref)
+    np.testing.assert_array_equal(dest, dest_ref)
+    assert flops == flops_ref == flops_tot and nnz_tot == len(dest_ref)
+
+
+def test_shard_rows_cover_batch_in_order():
+    for nrows in (0, 1, 7, 1024, 1025):
+        for nranks in (1, 2, 8):
+            spans = [fdist.shard_rows(nrows, r, nranks) for r in range(nranks)]
+            assert spans[0][0] == 0 and spans[-1][1] == nrows
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(nranks - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

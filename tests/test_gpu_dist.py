@@ -96,3 +96,36 @@ def test_slab_partitioned_bfs_matches_oracle(ctx, nranks, force, protocol):
         finally:
             torch.cuda.synchronize()
             ctx.set_stream(None)
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3])
+def test_row_sharded_expand_concatenates_to_the_whole_batch(ctx, nranks):
+    """k-hop MATCH over ranks: shard the source rows with dist.shard_rows, run every share
+    through fgpu_expand on replicated layers, concatenate in rank order == one fgpu_expand of the whole batch
+    == the oracle's delta_lmxm chain."""
+    a = oracle.rmat_csr(12)
+    n = a.nrows
+    rng = np.random.default_rng(3)
+    rows, cols = a.pairs()
+    pick = rng.choice(len(rows), 200, replace=False)
+    dm = oracle.build_csr(n, n, rows[pick], cols[pick])
+    dp = oracle.build_csr(n, n, rng.integers(0, n, 200).astype(np.uint64), rng.integers(0, n, 200).astype(np.uint64))
+    up = lambda m: ctx.mat_from_csr(m.nrows, m.ncols, m.rowptr, m.colidx)
+    A, DP, DM = up(a), up(dp), up(dm)
+    src = rng.integers(0, n, 257).astype(np.uint64)
+    local = lambda s: engine.expand(ctx, s, [A, A], [DP, DP], [DM, DM])
+    parts = []
+    for r in range(nranks):
+        lo, hi = fdist.shard_rows(len(src), r, nranks)
+        parts.append(fdist.expand_sharded(local, src[lo:hi], 0, 1))
+    counts = np.concatenate([np.diff(p[0].astype(np.int64)) for p in parts])
+    dest = np.concatenate([p[1] for p in parts])
+    flops = sum(p[2] for p in parts)
+    c = oracle.build_csr(len(src), n, np.arange(len(src), dtype=np.uint64), src)
+    flops_ref = 0
+    for _ in range(2):
+        c, fl = oracle.delta_lmxm(c, a, dp, dm)
+        flops_ref += fl
+    np.testing.assert_array_equal(np.concatenate([[0], np.cumsum(counts)]), c.rowptr)
+    np.testing.assert_array_equal(dest, c.colidx)
+    assert flops == flops_ref

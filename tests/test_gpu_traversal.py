@@ -375,3 +375,34 @@ def test_bfs_rmat22_properties(ctx):
         plan2.wait()
         lv2, _ = plan2.fetch()
         np.testing.assert_array_equal(lv2, level)
+
+
+def test_bfs_rmat22_directions_agree_over_repeated_runs(ctx):
+    """Race regression: in a pull level the hub section of a workgroup that ran ahead sets a hub row's visited
+    and next-frontier bits; the wave that owns the row's 64-bit word must then OR its own discoveries in, not
+    store them (a plain store dropped the hub from the next frontier and ~50 of its children were never
+    reached, a few runs in a hundred).  Push-only levels are the reference (atomics only); auto and pull-only
+    searches must reproduce them on every repetition, and max_level searches must be their truncation."""
+    A = ctx.mat_rmat(22)
+    At = A.transpose()
+    rp, _, _ = A.export_csr()
+    deg = np.diff(rp.astype(np.int64))
+    roots = np.nonzero(deg > 0)[0][:10].tolist()
+    ref_plan = engine.BfsPlan(ctx, A, At)
+    ref_plan.tune(force_direction=1)
+    plans = {0: engine.BfsPlan(ctx, A, At), 2: engine.BfsPlan(ctx, A, At)}
+    plans[2].tune(force_direction=2)
+    for src in roots:
+        ref_plan.run(src)
+        ref = ref_plan.fetch()[0].copy()
+        nlev = ref_plan.stats()["levels"]
+        for force, plan in plans.items():
+            for rep in range(4 if force == 0 else 2):
+                plan.run(src)
+                np.testing.assert_array_equal(plan.fetch()[0], ref, err_msg=f"root {src} force {force} rep {rep}")
+                st = plan.stats()
+                assert st["reached"] == int((ref >= 0).sum())
+                assert st["edges_traversed"] == int(deg[ref >= 0].sum())
+        for k in (nlev - 2, nlev - 1):
+            plans[0].run(src, k)
+            np.testing.assert_array_equal(plans[0].fetch()[0], np.where((ref >= 0) & (ref <= k), ref, -1))

@@ -80,7 +80,10 @@ def bench_merge(ctx, scale):
     print(json.dumps({"path": "transpose", "layers": "bool", "scale": scale, "ms": round(dt * 1e3, 3)}), flush=True)
 
 
-def bench_expand(ctx, scale, hops=3, batch=1024, nbatches=3):
+def bench_expand(ctx, scale, hops=3, batch=1024, nbatches=3, rank=0, nranks=1, device="cpu"):
+    """Under torch.distributed.run (WORLD_SIZE > 1) the batch is `batch` rows PER RANK, sharded by
+    dist.expand_count_sharded over replicated layers (weak scaling, no data-path collective)."""
+    from falkordb_amd import dist as fdist
     rng = np.random.default_rng(7)
     A = ctx.mat_rmat(scale)
     n, nnz = A.nrows, A.nvals
@@ -91,16 +94,22 @@ def bench_expand(ctx, scale, hops=3, batch=1024, nbatches=3):
                              ("dirty-0.1%", ([A] * hops, [dp] * hops, [dm] * hops), False)):
         tot_t, tot_f, tot_n = 0.0, 0, 0
         for b in range(nbatches + 1):
-            src = rng.choice(n, batch, replace=False).astype(np.uint64)
+            src = rng.choice(n, batch * nranks, replace=False).astype(np.uint64)
             ctx.sync()
+            if nranks > 1:
+                import torch.distributed as td
+                td.barrier()
             t0 = time.perf_counter()
-            out_nnz, _, flops = engine.expand_count(ctx, src, *layers, want_checksum=cs)
+            out_nnz, flops = fdist.expand_count_sharded(
+                lambda s_: engine.expand_count(ctx, s_, *layers, want_checksum=cs)[::2], src, rank, nranks, device)
             dt = time.perf_counter() - t0
             if b == 0:
                 continue  # warm-up (transpose cache, pools)
             tot_t += dt; tot_f += flops; tot_n += out_nnz
+        if rank:
+            continue
         print(json.dumps({"path": "khop_expand", "layers": name, "result": "count + checksum" if cs else "count only",
-                          "scale": scale, "hops": hops, "batch_rows": batch,
+                          "n_gpus": nranks, "scale": scale, "hops": hops, "batch_rows": batch * nranks,
                           "batches": nbatches, "ms_per_batch": round(tot_t / nbatches * 1e3, 3),
                           "flops_per_batch": tot_f // nbatches, "out_nnz_per_batch": tot_n // nbatches,
                           "GTEPS": round(tot_f / tot_t / 1e9, 2),
@@ -180,9 +189,25 @@ if __name__ == "__main__":
         bench_merge(c, scale or 22)
         c.close()
     if what in ("expand", "all"):
-        c = engine.Context(0)
-        bench_expand(c, scale or 24)
+        import os
+        world, rank, dev = int(os.environ.get("WORLD_SIZE", "1")), 0, "cpu"
+        if world > 1:    # python -m torch.distributed.run --nproc-per-node N tools/bench_paths.py expand 24
+            import torch
+            import torch.distributed as td
+            rank = int(os.environ["RANK"])
+            local = int(os.environ.get("LOCAL_RANK", rank))
+            torch.cuda.set_device(local)
+            dev = torch.device("cuda", local)
+            td.init_process_group("nccl", device_id=dev)
+            c = engine.Context(local)
+        else:
+            c = engine.Context(0)
+        bench_expand(c, scale or 24, rank=rank, nranks=world, device=dev)
         c.close()
+        if world > 1:
+            td.destroy_process_group()
+        if what == "expand":
+            sys.exit(0)
     if what in ("reach", "all"):
         c = engine.Context(0)
         bench_reach(c, scale or 19)
