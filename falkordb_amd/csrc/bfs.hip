@@ -33,6 +33,9 @@ constexpr unsigned QCAP = 1u << 16;      // capacity of a frontier queue (vertex
 constexpr unsigned QSEG = QCAP / QSHARDS;
 constexpr unsigned long long QGATE = 1ull << 17;  // a level appends only when it can discover at most this many
 
+struct StatSlot { u64 count, mf, indeg, scan; u64 pad[12]; };
+constexpr unsigned TICK_PAD = 32;   // u32 words between ticket counters (128 B)
+
 struct BfsCtrl {
     i32 level;       // level of the frontier in `cur` (source = 0)
     i32 done;
@@ -50,26 +53,30 @@ struct BfsCtrl {
     u32 rot;         // fused single-rank path: cur = bm[rot%3], nxt = bm[(rot+1)%3], zeroed = bm[(rot+2)%3]
     u64 nnz_at;
     u64 n_total;     // != 0 selects the fused path's m_u estimate (vertex count)
-    // per-launch accumulators, spread over slots to keep same-address atomics off the critical path
-    u64 slot_count[STAT_SLOTS];
-    u64 slot_mf[STAT_SLOTS];
-    u64 slot_indeg[STAT_SLOTS];
-    u64 slot_scan[STAT_SLOTS];
+    // per-launch accumulators, spread over slots to keep same-address atomics off the critical path; one slot per
+    // 128 B: atomics to different words of ONE line serialise at the memory side just like same-address ones
+    // (tools/micro/levelfloor.hip: 1792 workgroups' arrivals on 64 packed counters cost 8.6 us per launch, 0.6 us
+    // with a line per counter)
+    StatSlot slot[STAT_SLOTS];
     // fused single-rank path: next-frontier queue, hub census and the end-of-level ticket
-    u32 hubs[2];       // hub vertices (out-degree >= HUB_DEG) in the current / next frontier
+    u32 hubs[2];       // hub vertices (out-degree >= PUSH_HUB_DEG) in the current / next frontier
     u32 use_queue;     // the current frontier is completely listed in queue[rot & 1]
     u32 q_open;        // this level appends its discoveries to queue[(rot + 1) & 1]
     u32 qmax;          // longest shard of the current queue
     u32 qchunk;        // queue entries expanded per workgroup this level (power of two, 4..1024)
+    u32 nact;          // workgroups that take part in the next fused launch (0 = the whole grid): a light queue-mode
+                       // level runs on a few dozen, the rest return at once and skip the end-of-level ticket
     u32 tick_top;
     u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
-    u32 tick[64];
+    u32 tick_pad[31];
+    u32 tick[64 * TICK_PAD];
 };
 
 struct BfsArgs {
     CsrView A, At;
     const u32* hubA;  u32 n_hubA;
     const u32* hubAt; u32 n_hubAt;
+    const u32* hubP;  u32 n_hubP;   // A's finer list (PUSH_HUB_DEG / PUSH_HUB_CHUNK): fused push levels
     u32 n;        // global vertex count
     u32 lo, hi;   // owned destination range (hi <= n_pad)
     u64* cur;         // global frontier bitmap (n_pad bits)
@@ -353,7 +360,7 @@ __device__ void pull_body(const BfsArgs& a, const u64* __restrict__ frontier, co
 // this level reads bm[rot], ORs into bm[rot+1] (zeroed by the previous level) and zeroes
 // bm[rot+2] for the next one.
 // ---------------------------------------------------------------------------------
-struct LevelAcc { u64 count, mf, scanned, seen; };
+struct LevelAcc { u64 count, mf, scanned, seen; u32 hub; };
 
 // Per-wavefront view of the NEXT frontier's queue.  Small frontiers (the first and last levels of
 // every BFS) are walked from the queue instead of scanning the whole bitmap.  A level appends only
@@ -387,10 +394,10 @@ __device__ __forceinline__ void note_discovery(const BfsArgs& a, QueueCtx& qc, u
     const u32 rowdeg = a.A.rowptr[u + 1] - a.A.rowptr[u];
     acc.count += 1;
     acc.mf += a.gdeg ? a.gdeg[u] : rowdeg;   // slab plans: the owner accounts the vertex's GLOBAL out-degree
-    if (rowdeg >= HUB_DEG) {  // rare; returning form so the count has landed before the block's ticket
-        const u32 r = atomicAdd(qc.hubs, 1u);
-        asm volatile("" ::"v"(r));
-    }
+    // census for the NEXT launch: kept in a register and published once per workgroup at the end of the level —
+    // thousands of same-address atomics or write-through stores (every discovered row >= 1024) serialise at the
+    // memory side (a heavy level went from 80 to 120 us with a per-discovery atomic, to 350 us with a store)
+    acc.hub |= (rowdeg >= PUSH_HUB_DEG) ? 1u : 0u;
 }
 
 template <bool PARENT>
@@ -410,13 +417,13 @@ __device__ __forceinline__ bool fused_visit(const BfsArgs& a, u32* __restrict__ 
 
 // Push level.  `qcur` != nullptr: the frontier is the list qcur[0 .. qn) (queue mode, work
 // proportional to the frontier); else it is the bitmap `frontier` (1024 consecutive vertices per
-// item).  Hub rows (>= HUB_DEG out-edges) come from the static chunk list in both modes, and only
+// item).  Hub rows (>= PUSH_HUB_DEG out-edges) come from the static fine chunk list in both modes, and only
 // when the level's hub census says the frontier holds one.
 template <bool PARENT>
 __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, const u32* __restrict__ qcur,
                            const u32* __restrict__ qcur_len, u32 qmax, u32 qchunk, bool hubs_present,
                            u64* __restrict__ visited,
-                           u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc) {
+                           u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc, u32 nwg) {
     __shared__ u32 s_off[PUSH_VPB];
     __shared__ u32 s_start[PUSH_VPB];
     __shared__ u32 s_vid[PUSH_VPB];
@@ -430,22 +437,7 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
     // (a chunk holds `qchunk` entries: few when the frontier's rows are long, so that a handful of
     // near-hub vertices does not land on one workgroup)
     const u32 nblk = qmode ? QSHARDS * ((qmax + qchunk - 1) / qchunk) : (a.n + PUSH_VPB - 1) / PUSH_VPB;
-    const u32 nitems = nblk + (hubs_present ? a.n_hubA : 0u);
-    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
-        if (item >= nblk) {
-            const u32 h = item - nblk;
-            const u32 row = a.hubA[3 * h], b = a.hubA[3 * h + 1], e = a.hubA[3 * h + 2];
-            if (!test_bit(frontier, row)) continue;
-            for (u32 i0 = b; i0 < e; i0 += 256) {  // block-uniform trip count: queue_append needs whole waves
-                const u32 i = i0 + t;
-                const bool ok = i < e;
-                const u32 u = ok ? a.A.colidx[i] : 0u;
-                const bool won = ok && fused_visit<PARENT>(a, vis32, nxt32, newlevel, u, row, qc, acc);
-                queue_append(qc, won, u);
-            }
-            if (t == 0) acc.scanned += e - b;
-            continue;
-        }
+    for (u32 item = blockIdx.x; item < nblk; item += nwg) {
         u32 vid[4], rb[4], re[4];
         if (qmode) {
             const u32 seg = item % QSHARDS, chunk = item / QSHARDS;
@@ -496,7 +488,7 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             u32 d = re[j] - rb[j];
-            if (d >= HUB_DEG) d = 0;  // expanded by the hub items
+            if (d >= PUSH_HUB_DEG) d = 0;  // expanded by the hub items
             deg[j] = d;
             tsum += d;
         }
@@ -556,6 +548,42 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
         }
         if (t == 0) acc.scanned += total;
         __syncthreads();
+    }
+    // Hub rows (>= PUSH_HUB_DEG): this workgroup's share of the static chunk list is TESTED in parallel (a thread per
+    // item: one round of loads instead of a dependent triple + bit probe per item in sequence — the list has tens of
+    // thousands of items at RMAT-22 and a level that holds a single hub walks all of it), then only the chunks whose
+    // row is in the frontier are expanded, one workgroup trip each.
+    if (hubs_present && a.n_hubP) {
+        __shared__ u32 s_act[256];
+        __shared__ u32 s_nact;
+        const u32 first = (blockIdx.x + nwg - nblk % nwg) % nwg;   // items follow the regular ones
+        for (u32 h0 = first; h0 < a.n_hubP; h0 += nwg * 256) {   // block-uniform
+            if (t == 0) s_nact = 0;
+            __syncthreads();
+            const u32 hmine = h0 + t * nwg;
+            if (hmine < a.n_hubP && test_bit(frontier, a.hubP[3 * hmine])) s_act[atomicAdd(&s_nact, 1u)] = hmine;
+            __syncthreads();
+            const u32 na = s_nact;
+            for (u32 ia = 0; ia < na; ++ia) {
+                const u32 h = s_act[ia];
+                const u32 row = a.hubP[3 * h], b = a.hubP[3 * h + 1], e = a.hubP[3 * h + 2];
+                // one trip: PUSH_HUB_CHUNK = 256 threads x 4 edges, all four gathers / visits in flight together
+                u32 u[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 i = b + t + 256 * k;
+                    u[k] = (i < e) ? a.A.colidx[i] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {   // whole waves reach queue_append
+                    const bool won = (u[k] != 0xFFFFFFFFu) &&
+                                     fused_visit<PARENT>(a, vis32, nxt32, newlevel, u[k], row, qc, acc);
+                    queue_append(qc, won, u[k]);
+                }
+                if (t == 0) acc.scanned += e - b;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -786,14 +814,14 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
 // raises `done`.  Same arithmetic as bfs_ctrl_kernel (the multi-rank path keeps that kernel).
 __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
     const u32 t = threadIdx.x;  // 0..63
-    u64 v0 = __hip_atomic_load(&c->slot_count[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u64 v1 = __hip_atomic_load(&c->slot_mf[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u64 v3 = __hip_atomic_load(&c->slot_scan[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u64 v2 = slab ? __hip_atomic_load(&c->slot_indeg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    if (v0) c->slot_count[t] = 0;
-    if (v1) c->slot_mf[t] = 0;
-    if (v3) c->slot_scan[t] = 0;
-    if (v2) c->slot_indeg[t] = 0;
+    u64 v0 = __hip_atomic_load(&c->slot[t].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 v1 = __hip_atomic_load(&c->slot[t].mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 v3 = __hip_atomic_load(&c->slot[t].scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 v2 = slab ? __hip_atomic_load(&c->slot[t].indeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    if (v0) c->slot[t].count = 0;
+    if (v1) c->slot[t].mf = 0;
+    if (v3) c->slot[t].scan = 0;
+    if (v2) c->slot[t].indeg = 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         v0 += __shfl_xor(v0, d, 64);
@@ -885,16 +913,23 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
     // edges, a pull can discover at most the unvisited vertices
     const u64 unv = c->n_total > c->reached ? c->n_total - c->reached : 0;
     c->q_open = ((nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u;
+    // workgroups the next launch needs: twice its work items (queue chunks + one per 1024 hub-row edges), at least 64
+    u32 na = 0;
+    if (nd == 1 && c->use_queue && !done) {
+        const u64 items = (u64)QSHARDS * ((qmx + c->qchunk - 1) / c->qchunk) + v1 / PUSH_HUB_CHUNK + 1;
+        na = items * 2 < 64 ? 64u : (items * 2 > 60000ull ? 0u : (u32)(items * 2));
+    }
+    c->nact = na;
 }
 
 // One ticket per workgroup, sharded over 64 counters so no word sees more than grid/64 arrivals;
 // returns true in exactly one workgroup of the launch, after every other one has arrived.
-__device__ __forceinline__ bool take_ticket(BfsCtrl* c) {
+__device__ __forceinline__ bool take_ticket(BfsCtrl* c, u32 nwg) {
     const u32 s = blockIdx.x & 63u;
-    const u32 expect = (gridDim.x + 63u - s) >> 6;
-    if (atomicAdd(&c->tick[s], 1u) + 1u != expect) return false;
-    c->tick[s] = 0;
-    const u32 nshards = gridDim.x < 64u ? gridDim.x : 64u;
+    const u32 expect = (nwg + 63u - s) >> 6;
+    if (atomicAdd(&c->tick[s * TICK_PAD], 1u) + 1u != expect) return false;
+    c->tick[s * TICK_PAD] = 0;
+    const u32 nshards = nwg < 64u ? nwg : 64u;
     if (atomicAdd(&c->tick_top, 1u) + 1u != nshards) return false;
     c->tick_top = 0;
     return true;
@@ -906,6 +941,11 @@ template <bool PARENT, int DIRHINT>
 __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
     BfsCtrl* c = a.ctrl;
     if (c->done) return;
+    // a light level (queue-mode push over a few thousand edges) is run by c->nact workgroups only: the end-of-level
+    // ticket costs ~9 us with 7 workgroups per CU arriving and < 1 us with a few dozen (tools/micro/levelfloor.hip)
+    u32 nwg = c->nact;
+    if (nwg == 0 || nwg > gridDim.x) nwg = gridDim.x;
+    if (blockIdx.x >= nwg) return;
     const u32 rot = c->rot;
     const bool slab = a.slab_mode != 0;
     // slab plans read the frontier the all-gather just delivered and write their owned words of the next one
@@ -920,10 +960,10 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
     // a slab plan cannot census hubs (other ranks discover them): it always walks its hub chunk list
     const bool hubs_present = slab || c->hubs[rot & 1] != 0;
     const u32 zwords = slab ? a.slabw : a.nw;
-    for (u32 w = blockIdx.x * 256 + threadIdx.x; w < zwords; w += gridDim.x * 256) zr[w] = 0ull;
-    LevelAcc acc = {0, 0, 0, 0};
+    for (u32 w = blockIdx.x * 256 + threadIdx.x; w < zwords; w += nwg * 256) zr[w] = 0ull;
+    LevelAcc acc = {0, 0, 0, 0, 0};
     if (slab)   // |frontier| from the gathered bitmap: the one statistic every rank sees identically
-        for (u32 w = blockIdx.x * 256 + threadIdx.x; w < a.nw; w += gridDim.x * 256)
+        for (u32 w = blockIdx.x * 256 + threadIdx.x; w < a.nw; w += nwg * 256)
             acc.seen += (u64)__popcll(cur[w]);
     QueueCtx qc;
     qc.q = a.queue[(rot + 1) & 1] + (blockIdx.x % QSHARDS) * QSEG;
@@ -932,7 +972,7 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
     qc.open = !slab && c->q_open != 0;
     if (dir == 1)
         push_fused<PARENT>(a, cur, use_q ? a.queue[rot & 1] : nullptr, &c->qlen[rot & 1][0], qmax, qchunk, hubs_present,
-                           a.visited, nxt, newlevel, qc, acc);
+                           a.visited, nxt, newlevel, qc, acc, nwg);
     else
         pull_fused<PARENT>(a, cur, a.visited, nxt, newlevel, qc, acc);
     // block reduction of the per-thread statistics, one atomic triple per workgroup
@@ -946,8 +986,11 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
     }
     __shared__ unsigned long long s_acc[4];
     __shared__ u32 s_last;
+    __shared__ u32 s_hub;
     if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_hub = 0;
     __syncthreads();
+    if (__ballot(acc.hub != 0) != 0ull && lane_id() == 0) s_hub = 1;
     if (lane_id() == 0 && (cnt | sc | sn)) {
         atomicAdd(&s_acc[0], (unsigned long long)cnt);
         atomicAdd(&s_acc[1], (unsigned long long)mf);
@@ -960,13 +1003,14 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
         // returning atomics whose results are consumed: the sums have landed before the ticket is taken
         unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         if (s_acc[0]) {
-            r0 = atomicAdd((unsigned long long*)&c->slot_count[slot], s_acc[0]);
-            r1 = atomicAdd((unsigned long long*)&c->slot_mf[slot], s_acc[1]);
+            r0 = atomicAdd((unsigned long long*)&c->slot[slot].count, s_acc[0]);
+            r1 = atomicAdd((unsigned long long*)&c->slot[slot].mf, s_acc[1]);
         }
-        if (s_acc[2]) r2 = atomicAdd((unsigned long long*)&c->slot_scan[slot], s_acc[2]);
-        if (s_acc[3]) r3 = atomicAdd((unsigned long long*)&c->slot_indeg[slot], s_acc[3]);
+        if (s_acc[2]) r2 = atomicAdd((unsigned long long*)&c->slot[slot].scan, s_acc[2]);
+        if (s_acc[3]) r3 = atomicAdd((unsigned long long*)&c->slot[slot].indeg, s_acc[3]);
         asm volatile("" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3));
-        s_last = take_ticket(c) ? 1u : 0u;
+        if (s_hub) *qc.hubs = 1u;   // read by the next launch
+        s_last = take_ticket(c, nwg) ? 1u : 0u;
     }
     __syncthreads();
     if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done, slab);
@@ -984,7 +1028,7 @@ __global__ __launch_bounds__(256) void bfs_step_kernel(BfsArgs a) {
     if (dir == 1) {
         push_body<PARENT>(a, a.cur, a.visited, &scanned);
         if (threadIdx.x == 0 && scanned)
-            atomicAdd((unsigned long long*)&c->slot_scan[blockIdx.x & (STAT_SLOTS - 1)], (unsigned long long)scanned);
+            atomicAdd((unsigned long long*)&c->slot[blockIdx.x & (STAT_SLOTS - 1)].scan, (unsigned long long)scanned);
     } else {
         pull_body<PARENT, true>(a, a.cur, a.visited, a.nxt_local, &scanned);
         // lane 0 of each wave and thread 0 (hub items) hold partial sums
@@ -994,7 +1038,7 @@ __global__ __launch_bounds__(256) void bfs_step_kernel(BfsArgs a) {
         if (scanned) atomicAdd(&s_acc, (unsigned long long)scanned);
         __syncthreads();
         if (threadIdx.x == 0 && s_acc)
-            atomicAdd((unsigned long long*)&c->slot_scan[blockIdx.x & (STAT_SLOTS - 1)], s_acc);
+            atomicAdd((unsigned long long*)&c->slot[blockIdx.x & (STAT_SLOTS - 1)].scan, s_acc);
     }
 }
 
@@ -1047,9 +1091,9 @@ __global__ __launch_bounds__(256) void bfs_commit_kernel(BfsArgs a) {
     __syncthreads();
     if (threadIdx.x == 0 && s_acc[0]) {
         const u32 slot = blockIdx.x & (STAT_SLOTS - 1);
-        atomicAdd((unsigned long long*)&c->slot_count[slot], s_acc[0]);
-        atomicAdd((unsigned long long*)&c->slot_mf[slot], s_acc[1]);
-        atomicAdd((unsigned long long*)&c->slot_indeg[slot], s_acc[2]);
+        atomicAdd((unsigned long long*)&c->slot[slot].count, s_acc[0]);
+        atomicAdd((unsigned long long*)&c->slot[slot].mf, s_acc[1]);
+        atomicAdd((unsigned long long*)&c->slot[slot].indeg, s_acc[2]);
     }
 }
 
@@ -1058,12 +1102,12 @@ __global__ __launch_bounds__(64) void bfs_ctrl_kernel(BfsCtrl* c) {
     const u32 t = threadIdx.x;
     const i32 was_done = c->done;
     const int dir_in = c->direction;
-    u64 v0 = c->slot_count[t], v1 = c->slot_mf[t], v2 = c->slot_indeg[t], v3 = c->slot_scan[t];
+    u64 v0 = c->slot[t].count, v1 = c->slot[t].mf, v2 = c->slot[t].indeg, v3 = c->slot[t].scan;
     if (was_done) return;
-    if (v0) c->slot_count[t] = 0;
-    if (v1) c->slot_mf[t] = 0;
-    if (v2) c->slot_indeg[t] = 0;
-    if (v3) c->slot_scan[t] = 0;
+    if (v0) c->slot[t].count = 0;
+    if (v1) c->slot[t].mf = 0;
+    if (v2) c->slot[t].indeg = 0;
+    if (v3) c->slot[t].scan = 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         v0 += __shfl_xor(v0, d, 64);
@@ -1127,7 +1171,7 @@ __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u
         c->qmax = 1;
         c->qchunk = PUSH_VPB;
         c->use_queue = 1;
-        c->hubs[0] = (mf >= HUB_DEG) ? 1u : 0u;
+        c->hubs[0] = (mf >= PUSH_HUB_DEG) ? 1u : 0u;
         c->q_open = 1;  // patched below once the first direction is known
     }
     u64 indeg = 0;
@@ -1187,7 +1231,7 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     c->qmax = 1;
     c->qchunk = PUSH_VPB;
     c->use_queue = 1;
-    c->hubs[0] = (mf >= HUB_DEG) ? 1u : 0u;
+    c->hubs[0] = (mf >= PUSH_HUB_DEG) ? 1u : 0u;
     c->done = (max_level == 0) ? 1 : 0;
     if (max_level == 0 && a.host_done)
         __hip_atomic_store(a.host_done, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1200,6 +1244,10 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     }
     c->direction = nd;
     c->q_open = ((nd == 1 ? mf : (u64)a.n) <= QGATE) ? 1u : 0u;
+    {   // level 1 expands one vertex: a few dozen workgroups unless it is a hub
+        const u64 items = (u64)QSHARDS + mf / PUSH_HUB_CHUNK + 1;
+        c->nact = (nd != 1) ? 0u : (items * 2 < 64 ? 64u : (items * 2 > 60000ull ? 0u : (u32)(items * 2)));
+    }
 }
 
 // Fused slab path: clear the rank's workspace, seed the source into every rank's copy of the gathered
@@ -1242,6 +1290,7 @@ __global__ __launch_bounds__(256) void bfs_slab_begin_kernel(BfsArgs a, u64* sen
     if (max_level == 0 && a.host_done)
         __hip_atomic_store(a.host_done, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     c->direction = (force_dir == 2 && has_at) ? 2 : 1;   // a one-vertex frontier is pushed
+    c->nact = 0;   // slab plans always run the whole grid (the frontier is global, there is no queue)
 }
 
 // level[v] = -1 wherever the search did not reach v (fused single-rank path, see bfs_fused_begin_kernel)
@@ -1383,6 +1432,7 @@ static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
     }
     else { a.At.rowptr = nullptr; a.At.colidx = nullptr; a.At.hrows = nullptr; a.At.nvec = 0; a.At.nrows = 0; }
     a.hubA = p->A->hub_chunks; a.n_hubA = p->A->n_hub_chunks;
+    a.hubP = p->A->push_chunks; a.n_hubP = p->A->n_push_chunks;
     a.hubAt = p->At ? p->At->hub_chunks : nullptr; a.n_hubAt = p->At ? p->At->n_hub_chunks : 0;
     a.n = p->n; a.lo = p->lo; a.hi = p->hi;
     a.cur = p->cur; a.nxt_local = p->nxt_local; a.nxt_global = p->nxt_global; a.visited = p->visited;
@@ -1490,7 +1540,7 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
     {
         // one launch serves both directions (picked on device): size the grid for the larger of
         // push items (1024-vertex blocks + hub chunks) and pull trips (4 waves x PULL_R words)
-        u64 push_items = ((u64)p->n + PUSH_VPB - 1) / PUSH_VPB + A->n_hub_chunks;
+        u64 push_items = ((u64)p->n + PUSH_VPB - 1) / PUSH_VPB + A->n_push_chunks;
         u64 pull_blocks = (((u64)p->n + 63) / 64 + PULL_R * 4 - 1) / (PULL_R * 4);
         u64 g = push_items > pull_blocks ? push_items : pull_blocks;
         if (g < (u64)ctx->cus * 4) g = (u64)ctx->cus * 4;
@@ -1688,7 +1738,7 @@ fgpu_info fgpu_bfs_part_commit(fgpu_bfs_plan* p) {
 
 static fgpu_info fetch_ctrl(fgpu_bfs_plan* p) {
     // header only (everything before the slot arrays)
-    FGPU_HIP(hipMemcpyAsync(p->h_ctrl, p->ctrl, offsetof(BfsCtrl, slot_count), hipMemcpyDeviceToHost,
+    FGPU_HIP(hipMemcpyAsync(p->h_ctrl, p->ctrl, offsetof(BfsCtrl, slot), hipMemcpyDeviceToHost,
                             p->ctx->stream));
     FGPU_HIP(hipStreamSynchronize(p->ctx->stream));
     return FGPU_OK;
@@ -1911,6 +1961,7 @@ static void vxm_args(BfsArgs& a, const fgpu_mat* A, const fgpu_mat* At, u32 n, u
     a.A = view_of(A);
     if (At) a.At = view_of(At);
     a.hubA = A->hub_chunks; a.n_hubA = A->n_hub_chunks;
+    a.hubP = A->push_chunks; a.n_hubP = A->n_push_chunks;
     a.hubAt = At ? At->hub_chunks : nullptr; a.n_hubAt = At ? At->n_hub_chunks : 0;
     a.n = n; a.lo = 0; a.hi = nw * 64;
     a.nxt_local = out_words; a.nxt_global = out_words;

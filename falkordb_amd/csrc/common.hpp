@@ -147,6 +147,10 @@ struct fgpu_mat {
     // static hub list for the push kernels (rows with degree >= HUB_DEG), device
     uint32_t* hub_chunks = nullptr;  // triples (row, begin, end)
     uint32_t n_hub_chunks = 0;
+    // finer list for the fused push levels (rows >= PUSH_HUB_DEG in PUSH_HUB_CHUNK-edge items): a frontier of a
+    // few hundred near-hub rows must spread over the whole chip, not over frontier/4 workgroups
+    uint32_t* push_chunks = nullptr;
+    uint32_t n_push_chunks = 0;
     uint32_t max_deg = 0;
     bool finalized = false;       // hub list / max_deg computed (mat_finalize); merges leave it to the first BFS plan
     uint32_t* pull_col = nullptr; // bfs.hip: column ids with every row reordered hub-first, for the pull levels (lazy, owned)
@@ -292,5 +296,7 @@ fgpu_info bp_accumulate(fgpu_ctx* ctx, BitState& u, const BitState& x);
 
 constexpr u32 HUB_DEG = 4096;    // rows at least this long are expanded by the hub kernel
 constexpr u32 HUB_CHUNK = 4096;  // edges per hub work item
+constexpr u32 PUSH_HUB_DEG = 1024;    // fused push levels: rows at least this long come from push_chunks ...
+constexpr u32 PUSH_HUB_CHUNK = 1024;  // ... in items of one workgroup trip (256 threads x 4 edges)
 
 }  // namespace fgpu

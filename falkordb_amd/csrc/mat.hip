@@ -26,6 +26,7 @@ static void mat_release(fgpu_mat* m) {
         c->dev_free(m->vals);
         c->dev_free(m->hrows);
         c->dev_free(m->hub_chunks);
+        c->dev_free(m->push_chunks);
         c->dev_free(m->wordrow);
         c->dev_free(m->pull_col);
     }
@@ -67,7 +68,7 @@ fail:
 // max degree + static hub chunk list (rows with >= HUB_DEG entries).
 __global__ void hub_scan_kernel(const u32* __restrict__ rowptr, u32 nvec, u32* __restrict__ max_deg,
                                 u32* __restrict__ n_chunks, u32* __restrict__ chunks, u32 cap,
-                                const u32* __restrict__ hrows) {
+                                const u32* __restrict__ hrows, u32 HUB_DEG, u32 HUB_CHUNK) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     u32 deg = 0, b = 0;
     if (r < nvec) { b = rowptr[r]; deg = rowptr[r + 1] - b; }
@@ -91,32 +92,40 @@ __global__ void hub_scan_kernel(const u32* __restrict__ rowptr, u32 nvec, u32* _
     }
 }
 
-fgpu_info mat_finalize(fgpu_mat* m) {
+static fgpu_info build_hub_list(fgpu_mat* m, u32 deg_min, u32 chunk, u32** out, u32* n_out) {
     fgpu_ctx* ctx = m->ctx;
-    m->max_deg = 0;
-    m->n_hub_chunks = 0;
-    m->finalized = true;
-    if (m->nnz == 0 || m->nvec == 0) return FGPU_OK;
-    // every hub chunk holds >= 1 edge and at most nnz / HUB_CHUNK + (#hub rows) chunks exist
-    u32 cap = (u32)(m->nnz / HUB_CHUNK + m->nnz / HUB_DEG + 1);
+    // every hub chunk holds >= 1 edge and at most nnz / chunk + (#hub rows) chunks exist
+    u32 cap = (u32)(m->nnz / chunk + m->nnz / deg_min + 1);
     DevBuf<u32> meta, chunks;
     FGPU_TRY(meta.alloc(ctx, 2));
     FGPU_TRY(chunks.alloc(ctx, (size_t)cap * 3));
     FGPU_HIP(hipMemsetAsync(meta.p, 0, 2 * sizeof(u32), ctx->stream));
     hipLaunchKernelGGL(hub_scan_kernel, dim3(cdiv(m->nvec, 256)), dim3(256), 0, ctx->stream, m->rowptr, m->nvec,
-                       meta.p, meta.p + 1, chunks.p, cap, m->hrows);
+                       meta.p, meta.p + 1, chunks.p, cap, m->hrows, deg_min, chunk);
     FGPU_HIP(hipGetLastError());
     u32 h[2];
     FGPU_HIP(hipMemcpyAsync(ctx->pinned, meta.p, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
     FGPU_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(h, ctx->pinned, sizeof(h));
     m->max_deg = h[0];
-    m->n_hub_chunks = h[1] < cap ? h[1] : cap;
-    if (m->n_hub_chunks) {
-        FGPU_TRY(ctx->dev_alloc((void**)&m->hub_chunks, (size_t)m->n_hub_chunks * 3 * sizeof(u32)));
-        FGPU_HIP(hipMemcpyAsync(m->hub_chunks, chunks.p, (size_t)m->n_hub_chunks * 3 * sizeof(u32),
-                                hipMemcpyDeviceToDevice, ctx->stream));
+    *n_out = h[1] < cap ? h[1] : cap;
+    if (*n_out) {
+        FGPU_TRY(ctx->dev_alloc((void**)out, (size_t)*n_out * 3 * sizeof(u32)));
+        FGPU_HIP(hipMemcpyAsync(*out, chunks.p, (size_t)*n_out * 3 * sizeof(u32), hipMemcpyDeviceToDevice,
+                                ctx->stream));
     }
+    return FGPU_OK;
+}
+
+fgpu_info mat_finalize(fgpu_mat* m) {
+    m->max_deg = 0;
+    m->n_hub_chunks = 0;
+    m->n_push_chunks = 0;
+    m->finalized = true;
+    if (m->nnz == 0 || m->nvec == 0) return FGPU_OK;
+    FGPU_TRY(build_hub_list(m, HUB_DEG, HUB_CHUNK, &m->hub_chunks, &m->n_hub_chunks));
+    if (m->max_deg >= PUSH_HUB_DEG)
+        FGPU_TRY(build_hub_list(m, PUSH_HUB_DEG, PUSH_HUB_CHUNK, &m->push_chunks, &m->n_push_chunks));
     return FGPU_OK;
 }
 
