@@ -247,13 +247,27 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
     const bool want_edge = bind_relationship && hops.size() == 1;
     rows.active_row.reserve(nnz);
     rows.dest.reserve(nnz);
-    for (u64 i = 0; i < k; ++i) {
-        const bool pinned = to_bound && (*to_bound)[i].kind == Value::Node;
-        for (u64 p = rowptr[i]; p < rowptr[i + 1]; ++p) {
-            const u64 d = dest[p];
-            if (pinned && (*to_bound)[i].id != d) continue;                          // :657-661
-            rows.active_row.push_back(i);
-            rows.dest.push_back(d);
+    bool any_pinned = false;
+    if (to_bound)
+        for (u64 i = 0; i < k && !any_pinned; ++i) any_pinned = (*to_bound)[i].kind == Value::Node;
+    if (!any_pinned) {
+        // nothing to filter: the device result IS the (row, dest) stream — one block copy and one run per row
+        // (the per-entry loop below was 10 of the 16 ms of a 4.9 M-row batch)
+        rows.dest.assign(dest, dest + nnz);
+        for (u64 i = 0; i < k; ++i) rows.active_row.insert(rows.active_row.end(), rowptr[i + 1] - rowptr[i], i);
+    } else {
+        for (u64 i = 0; i < k; ++i) {
+            const bool pinned = (*to_bound)[i].kind == Value::Node;
+            if (!pinned) {
+                rows.dest.insert(rows.dest.end(), dest + rowptr[i], dest + rowptr[i + 1]);
+                rows.active_row.insert(rows.active_row.end(), rowptr[i + 1] - rowptr[i], i);
+                continue;
+            }
+            for (u64 p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                if ((*to_bound)[i].id != dest[p]) continue;                              // :657-661
+                rows.active_row.push_back(i);
+                rows.dest.push_back(dest[p]);
+            }
         }
     }
     fgpu_free(ctx, rowptr);
