@@ -63,6 +63,8 @@ struct fgpu_options {  // fgpu_set_option
     int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)
     int expand_mode = 0;       // 0 auto, 1 sorted-CSR products only, 2 bit-parallel from the first hop
     int bfs_wgs_per_cu = 6;    // grid of the fused BFS level kernel, workgroups per CU
+    int bfs_tiny = 2;          // consecutive tiny BFS levels in one single-workgroup launch (bfs_tiny_kernel): 0 off, 1 on,
+                               // 2 = when the plan's previous search took more than 12 levels
     int bfs_hub_first = 1;     // pull levels read A' rows reordered hub-first (bfs.hip ensure_pull_order)
     int merge_mode = 0;        // Delta merge: 0 entry-parallel (merge.hip), 1 one wavefront per row (pattern only)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)

@@ -68,7 +68,8 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * "tiled_wgs" (grid of that kernel, 0 = fill the CUs), "tiled_nt" (nontemporal entry loads),
  * "expand_mode" (fgpu_expand: 0 = pick per hop, 1 = sorted-CSR products only, 2 = bit-parallel from the
  * first hop), "bfs_wgs_per_cu" (grid of the fused BFS level kernel), "merge_mode" (fgpu_mat_merge:
- * 0 = entry-parallel, 1 = one wavefront per row, pattern layers only), "bfs_hub_first" (1 = BFS plans
+ * 0 = entry-parallel, 1 = one wavefront per row, pattern layers only), "bfs_tiny" (consecutive tiny BFS levels in one single-workgroup launch: 0 off, 1 on,
+ * 2 = when the plan's previous search took more than 12 levels), "bfs_hub_first" (1 = BFS plans
  * read the pull direction from a copy of At whose rows are reordered by descending out-degree class). */
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
 /* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */

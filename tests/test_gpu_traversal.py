@@ -406,3 +406,40 @@ def test_bfs_rmat22_directions_agree_over_repeated_runs(ctx):
         for k in (nlev - 2, nlev - 1):
             plans[0].run(src, k)
             np.testing.assert_array_equal(plans[0].fetch()[0], np.where((ref >= 0) & (ref <= k), ref, -1))
+
+
+@pytest.mark.parametrize("tiny", [0, 1, 2])
+def test_bfs_tiny_kernel_modes(ctx, tiny):
+    """bfs_tiny_kernel (consecutive tiny levels in one single-workgroup launch; option bfs_tiny: off / on / when the
+    previous search was deep): a 3000-level path, and R-MAT searches whose first and last levels are tiny, every
+    search run three times so that the history-sized blind sequences are exercised; levels, parents, max_level."""
+    ctx.set_option("bfs_tiny", tiny)
+    try:
+        n = 3000
+        path = oracle.build_csr(n, n, np.arange(n - 1, dtype=U64), np.arange(1, n, dtype=U64))
+        P = up(ctx, path)
+        plan = engine.BfsPlan(ctx, P, P.transpose())
+        for rep in range(3):
+            plan.run(0, -1, want_parent=True)
+            level, parent = plan.fetch(want_parent=True)
+            np.testing.assert_array_equal(level, np.arange(n, dtype=np.int32))
+            np.testing.assert_array_equal(parent[1:], np.arange(n - 1))
+            st = plan.stats()
+            assert st["levels"] == n and st["reached"] == n and st["edges_traversed"] == n - 1
+        plan.run(0, 1234)
+        level, _ = plan.fetch()
+        np.testing.assert_array_equal(level, np.where(np.arange(n) <= 1234, np.arange(n), -1))
+        a = oracle.rmat_csr(15)
+        A = ctx.mat_rmat(15)
+        plan = engine.BfsPlan(ctx, A, A.transpose())
+        deg = np.diff(a.rowptr)
+        for src in [int(np.argmax(deg)), int(np.nonzero(deg == 1)[0][0]), 7]:
+            for max_level in (-1, 1, 3):
+                ref, _, _ = oracle.bfs(a, src, max_level)
+                for rep in range(3):
+                    plan.run(src, max_level, want_parent=True)
+                    level, parent = plan.fetch(want_parent=True)
+                    np.testing.assert_array_equal(level, ref)
+                    check_bfs(a, level, parent, src, ref)
+    finally:
+        ctx.set_option("bfs_tiny", 2)

@@ -10,9 +10,9 @@ for r in rows:
     if 'bfs_init' in n or 'fused_begin' in n:
         if cur: seqs.append(cur)
         cur = [('B', round(d, 1), round((st - last_end) / 1000, 1) if last_end else 0)]; last_end = en
-    elif cur is not None and ('fused' in n or 'ctrl' in n or 'step' in n or 'commit' in n):
+    elif cur is not None and ('fused' in n or 'ctrl' in n or 'step' in n or 'commit' in n or 'tiny' in n):
         gap = (st - last_end) / 1000 if last_end else 0
-        cur.append(('P' if ('fused' in n and ', 1>' in n) else 'L' if ('fused' in n and ', 2>' in n) else 'F' if 'fused' in n else 'c' if 'ctrl' in n else 'S' if 'step' in n else 'M', round(d, 1), round(gap, 1)))
+        cur.append(('T' if 'tiny' in n else 'P' if ('fused' in n and ', 1>' in n) else 'L' if ('fused' in n and ', 2>' in n) else 'F' if 'fused' in n else 'c' if 'ctrl' in n else 'S' if 'step' in n else 'M', round(d, 1), round(gap, 1)))
         last_end = en
 seqs.append(cur)
 lo = int(sys.argv[2]) if len(sys.argv) > 2 else 80
