@@ -88,13 +88,34 @@ __device__ __forceinline__ void lane_row(const Layer& x, u32 w, u32 p, bool vali
     r = x.v.hrows ? x.v.hrows[i] : i;
 }
 
+// CLEAN words: no row from the first entry's row to the next word's first row is touched by dp or dm (one or two
+// rowbits words, a lane each, one ballot).  Such a word's 64 entries are all kept and move by ONE offset
+// (out_rowptr[r0] - rowptr[i0]: nothing is inserted or removed between its rows, empty rows included), so mark is a
+// constant and scatter a shifted copy — ~10 instructions per word-lane against ~120 for the per-entry path, which
+// is what bounds this kernel (VALU issue, not bytes).  With 0.1 % deltas on R-MAT-22 about 80 % of the words are clean.
+__device__ __forceinline__ bool word_clean(const Layer& x, u32 w, const u32* __restrict__ rowbits, u32 lane) {
+    if (!rowbits) return true;
+    const u32 ilo = x.wordrow[w], ihi = x.wordrow[w + 1];
+    const u32 rlo = x.v.hrows ? x.v.hrows[ilo] : ilo;
+    const u32 rhi = x.v.hrows ? x.v.hrows[ihi] : ihi;
+    const u32 b0 = rlo >> 5, b1 = rhi >> 5;
+    if (b1 - b0 >= 64u) return false;   // a long run of rows (the last word of a layer): per-entry path
+    u32 v = 0;
+    if (lane <= b1 - b0) {
+        v = rowbits[b0 + lane];
+        if (lane == 0) v &= ~0u << (rlo & 31);
+        if (lane == b1 - b0) v &= (rhi & 31) == 31 ? ~0u : ((1u << ((rhi & 31) + 1)) - 1u);
+    }
+    return __ballot(v != 0) == 0ull;
+}
+
 // IS_M: x = m, other = dp (a coordinate also stored in dp is dropped from m: dp's value wins),
 //       and dm always masks m.   !IS_M: x = dp, masked by dm only when dm_masks_dp.
 template <bool IS_M>
 __global__ __launch_bounds__(256) void merge_mark_kernel(Layer x, Layer other, Layer dm, bool has_other, bool has_dm,
                                                         bool dm_masks_dp, const u32* __restrict__ rowbits,
                                                         u32 out_nrows, u32 out_ncols, u64* __restrict__ kb,
-                                                        u32* __restrict__ kc) {
+                                                        u32* __restrict__ kc, bool clip) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
@@ -102,6 +123,14 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(Layer x, Layer other, L
     for (u32 w = wave; w < nwords; w += nwaves) {
         const u32 p = (w << 6) + lane;
         const bool valid = p < x.nnz;
+        if (IS_M && !clip && word_clean(x, w, rowbits, lane)) {   // wave-uniform
+            const u64 all = __ballot(valid);
+            if (lane == 0) {
+                kb[w] = all;
+                kc[w] = (u32)__popcll(all);
+            }
+            continue;
+        }
         u32 i, r;
         lane_row(x, w, p, valid, i, r);
         bool keep = false;
@@ -152,7 +181,7 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other
                                                            const u64* __restrict__ kbx, const u32* __restrict__ ksx,
                                                            const u64* __restrict__ kbo, const u32* __restrict__ kso,
                                                            const u32* __restrict__ out_rp, u32* __restrict__ out_col,
-                                                           u64* __restrict__ out_val) {
+                                                           u64* __restrict__ out_val, bool clip) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
@@ -161,6 +190,16 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other
         const u64 mask = kbx[w];
         if (mask == 0) continue;
         const u32 p = (w << 6) + lane;
+        if (IS_M && !clip && word_clean(x, w, rowbits, lane)) {   // wave-uniform: a shifted copy
+            const u32 i0 = x.wordrow[w];
+            const u32 r0 = x.v.hrows ? x.v.hrows[i0] : i0;
+            const u32 shift = out_rp[r0] - x.v.rowptr[i0];
+            if (p < x.nnz) {
+                out_col[p + shift] = x.v.colidx[p];
+                if (out_val) out_val[p + shift] = x.val ? x.val[p] : 1ull;
+            }
+            continue;
+        }
         if (!((mask >> lane) & 1ull)) continue;   // kept entries are valid entries
         u32 i, r;
         lane_row(x, w, p, true, i, r);
@@ -232,6 +271,8 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
                             bool dm_masks_dp, u64 out_nrows, u64 out_ncols, bool pattern_only) {
     const bool has_dp = dp && dp->nnz, has_dm = dm && dm->nnz;
     const bool with_vals = !pattern_only && (m->vals != nullptr || (dp && dp->vals != nullptr));
+    // entries at or past the new dims are dropped only when the result is smaller than m (Matrix::resize shrinking)
+    const bool clip = out_nrows < m->nrows || out_ncols < m->ncols || (dp && (out_nrows < dp->nrows || out_ncols < dp->ncols));
     Layer lm{}, lp{}, ld{};
     FGPU_TRY(layer_of(ctx, m, lm));
     if (has_dp) FGPU_TRY(layer_of(ctx, dp, lp));
@@ -255,14 +296,14 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     if (lm.nnz) {
         hipLaunchKernelGGL(merge_mark_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream, lm, lp,
                            ld, has_dp, has_dm, dm_masks_dp, (const u32*)rowbits.p, (u32)out_nrows, (u32)out_ncols,
-                           km.kb.p, km.ks.p);
+                           km.kb.p, km.ks.p, clip);
         FGPU_HIP(hipGetLastError());
     }
     FGPU_TRY(scan_u32(ctx, km.ks.p, km.ks.p, ((u64)(lm.nnz + 63) >> 6) + 1, nullptr));
     if (has_dp) {
         hipLaunchKernelGGL(merge_mark_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream, lp, lm,
                            ld, lm.nnz != 0, has_dm, dm_masks_dp, (const u32*)rowbits.p, (u32)out_nrows,
-                           (u32)out_ncols, kp.kb.p, kp.ks.p);
+                           (u32)out_ncols, kp.kb.p, kp.ks.p, clip);
         FGPU_HIP(hipGetLastError());
         FGPU_TRY(scan_u32(ctx, kp.ks.p, kp.ks.p, ((u64)(lp.nnz + 63) >> 6) + 1, nullptr));
     }
@@ -282,13 +323,13 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     if (e == hipSuccess && lm.nnz && nnz) {
         hipLaunchKernelGGL(merge_scatter_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream, lm,
                            lp, has_dp, (const u32*)rowbits.p, (const u64*)km.kb.p, (const u32*)km.ks.p,
-                           (const u64*)kp.kb.p, (const u32*)kp.ks.p, (const u32*)o->rowptr, o->colidx, o->vals);
+                           (const u64*)kp.kb.p, (const u32*)kp.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip);
         e = hipGetLastError();
     }
     if (e == hipSuccess && has_dp && nnz) {
         hipLaunchKernelGGL(merge_scatter_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream, lp,
                            lm, lm.nnz != 0, (const u32*)rowbits.p, (const u64*)kp.kb.p, (const u32*)kp.ks.p,
-                           (const u64*)km.kb.p, (const u32*)km.ks.p, (const u32*)o->rowptr, o->colidx, o->vals);
+                           (const u64*)km.kb.p, (const u32*)km.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip);
         e = hipGetLastError();
     }
     // the scratch buffers above go back to the pool when this returns: the kernels reading them must be done
