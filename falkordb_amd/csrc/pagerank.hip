@@ -1,0 +1,287 @@
+// pagerank.hip — algo.pageRank's numeric core: LAGr_PageRank (LAGraph v1.x, called from
+// graph/src/runtime/functions/algo_procedures.rs:741-752 with damping 0.85, tol 1e-4, itermax 100) over the
+// adjacency matrix, the first floating-point semiring of the path (plus_second FP32).
+//
+// LAGraph is not vendored in the reference tree; the algorithm restated (the tests hold a numpy twin of it):
+//     r = 1/n;  d = max(1/damping, out_degree / damping);  sinks = vertices without out-edges
+//     repeat (iters < itermax and rdiff > tol):
+//         teleport = (1 - damping)/n + (damping/n) * sum(r[sinks])
+//         t = r;  w = t ./ d;  r = teleport + A' (+.second) w;  rdiff = sum |t - r|
+// All arithmetic FP32 like the reference's GrB_FP32 vectors.  The summation ORDER is GraphBLAS-internal there and
+// lane / block order here, so results agree to FP32 rounding, not bit for bit: the tests state the tolerance.
+//
+// `active` (nullable bitmap) restricts the graph to the induced subgraph of the flagged vertices — what
+// algo.pageRank does with a label that does not cover every node (build_compact_adj_from_tensors,
+// algo_procedures.rs:725-733): n = |active|, edges with an inactive endpoint do not exist, inactive scores = 0.
+//
+// One iteration = three passes: (1) elementwise w = r/d + block partials of the sink mass, (2) the pull
+// SpMV over CSR(A') — a wavefront per 64 rows: every lane sums its row's first 8 in-neighbours, longer rows are
+// finished by the whole wave, rows >= HUB_DEG by the static hub chunk list with float atomics — fused with the
+// |t - r| partials, (3) fixed-order reductions of the partials (deterministic apart from the hub atomics).
+// Bytes per iteration: 4 nnz (column ids) + gathers of w (16 MB at RMAT-22, L2 / MALL resident) + 6 n-vectors.
+#include "common.hpp"
+
+namespace fgpu {
+
+constexpr int PR_A = 8;   // in-neighbours a lane sums alone before the wave takes the row over
+
+__device__ __forceinline__ bool pr_active(const u64* __restrict__ act, u32 v) {
+    return !act || ((act[v >> 6] >> (v & 63)) & 1ull);
+}
+
+// out-degree inside the active subgraph (only launched when `active` is given)
+__global__ void pr_degree_kernel(CsrView a, const u64* __restrict__ act, u32 n, u32* __restrict__ deg) {
+    const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    u32 d = 0;
+    if (pr_active(act, v)) {
+        u32 b, e;
+        row_range(a, v, b, e);
+        for (u32 i = b; i < e; ++i) d += pr_active(act, a.colidx[i]) ? 1u : 0u;
+    }
+    deg[v] = d;
+}
+
+__global__ void pr_init_kernel(CsrView a, const u64* __restrict__ act, const u32* __restrict__ deg_in, u32 n,
+                               float r0, float damping, float* __restrict__ r, float* __restrict__ d,
+                               unsigned char* __restrict__ sink) {
+    const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const bool on = pr_active(act, v);
+    u32 dg;
+    if (deg_in) dg = deg_in[v];
+    else { u32 b, e; row_range(a, v, b, e); dg = e - b; }
+    r[v] = on ? r0 : 0.0f;
+    const float dmin = 1.0f / damping;
+    const float dv = (float)dg / damping;
+    d[v] = dv > dmin ? dv : dmin;
+    sink[v] = (on && dg == 0) ? 1 : 0;
+}
+
+__device__ __forceinline__ float block_sum_256(float x, float* s_red) {
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) x += __shfl_xor(x, k, 64);
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    const float tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return tot;
+}
+
+// w = t ./ d (0 for inactive vertices) and the per-block sink mass
+__global__ __launch_bounds__(256) void pr_prep_kernel(const float* __restrict__ t, const float* __restrict__ d,
+                                                     const unsigned char* __restrict__ sink,
+                                                     const u64* __restrict__ act, u32 n, float* __restrict__ w,
+                                                     float* __restrict__ part) {
+    __shared__ float s_red[4];
+    const u32 v = blockIdx.x * 256 + threadIdx.x;
+    float rs = 0.0f;
+    if (v < n) {
+        const float tv = t[v];
+        w[v] = pr_active(act, v) ? tv / d[v] : 0.0f;
+        rs = sink[v] ? tv : 0.0f;
+    }
+    const float tot = block_sum_256(rs, s_red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// out[0] = base + scale * sum(part[0..np))  — one workgroup, fixed order
+__global__ __launch_bounds__(256) void pr_reduce_kernel(const float* __restrict__ part, u32 np, float base, float scale,
+                                                       float* __restrict__ out) {
+    __shared__ float s_red[4];
+    float x = 0.0f;
+    for (u32 i = threadIdx.x; i < np; i += 256) x += part[i];
+    const float tot = block_sum_256(x, s_red);
+    if (threadIdx.x == 0) out[0] = base + scale * tot;
+}
+
+// r[v] = teleport + sum_{u in in(v)} w[u]   (rows < HUB_DEG; hub rows get teleport only, the chunks add the rest)
+__global__ __launch_bounds__(256) void pr_spmv_kernel(CsrView at, const u64* __restrict__ act, u32 n,
+                                                     const float* __restrict__ w, const float* __restrict__ tele,
+                                                     const float* __restrict__ t, float* __restrict__ r,
+                                                     float* __restrict__ part) {
+    __shared__ float s_red[4];
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwords = (n + 63) >> 6;
+    const float tp = tele[0];
+    const u32* __restrict__ col = at.colidx;
+    float diff = 0.0f;
+    for (u32 g = wave; g < nwords; g += nwaves) {
+        const u32 v = (g << 6) + lane;
+        const u32 vc = v < n ? v : n;
+        const u32 rb = at.rowptr[vc];
+        const u32 re = at.rowptr[vc + 1 <= n ? vc + 1 : n];
+        const bool on = v < n && pr_active(act, v);
+        const u32 deg = on ? re - rb : 0u;
+        const bool hub = deg >= HUB_DEG;
+        float acc = 0.0f;
+        if (!hub) {
+            u32 c[PR_A];
+#pragma unroll
+            for (int j = 0; j < PR_A; ++j) c[j] = ((u32)j < deg) ? col[rb + j] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < PR_A; ++j) acc += (c[j] != 0xFFFFFFFFu) ? w[c[j]] : 0.0f;
+        }
+        // rows longer than PR_A (and shorter than HUB_DEG): the wave sums the rest, 64 coalesced elements per trip
+        u64 pend = __ballot(!hub && deg > (u32)PR_A);
+        while (pend) {
+            const int l = (int)__builtin_ctzll(pend);
+            pend &= pend - 1ull;
+            const u32 b0 = (u32)__builtin_amdgcn_readlane((int)rb, l) + PR_A;
+            const u32 e0 = (u32)__builtin_amdgcn_readlane((int)re, l);
+            float s = 0.0f;
+            for (u32 q = b0 + lane; q < e0; q += 64) s += w[col[q]];
+#pragma unroll
+            for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k, 64);
+            if ((int)lane == l) acc += s;
+        }
+        if (v < n) {
+            const float rv = on ? tp + acc : 0.0f;
+            r[v] = rv;
+            if (!hub) diff += fabsf(t[v] - rv);
+        }
+    }
+    const float tot = block_sum_256(diff, s_red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// hub rows of A' (>= HUB_DEG in-neighbours): one workgroup per chunk of the static list, float atomics into r
+__global__ __launch_bounds__(256) void pr_hub_kernel(const u32* __restrict__ hub, u32 n_hub, const u32* __restrict__ col,
+                                                    const u64* __restrict__ act, const float* __restrict__ w,
+                                                    float* __restrict__ r) {
+    __shared__ float s_red[4];
+    for (u32 h = blockIdx.x; h < n_hub; h += gridDim.x) {
+        const u32 row = hub[3 * h], b = hub[3 * h + 1], e = hub[3 * h + 2];
+        if (!pr_active(act, row)) continue;   // block-uniform
+        float s = 0.0f;
+        for (u32 i = b + threadIdx.x; i < e; i += 256) s += w[col[i]];
+        const float tot = block_sum_256(s, s_red);
+        if (threadIdx.x == 0) atomicAdd(&r[row], tot);
+    }
+}
+
+// |t - r| of the hub rows, once their chunks have landed (a row appears once per chunk: only its first chunk counts)
+__global__ __launch_bounds__(256) void pr_hub_diff_kernel(const u32* __restrict__ hub, u32 n_hub,
+                                                         const u32* __restrict__ rowptr, const float* __restrict__ t,
+                                                         const float* __restrict__ r, float* __restrict__ part) {
+    __shared__ float s_red[4];
+    float x = 0.0f;
+    for (u32 h = threadIdx.x; h < n_hub; h += 256) {
+        const u32 row = hub[3 * h];
+        if (hub[3 * h + 1] == rowptr[row]) x += fabsf(t[row] - r[row]);
+    }
+    const float tot = block_sum_256(x, s_red);
+    if (threadIdx.x == 0) part[0] = tot;
+}
+
+}  // namespace fgpu
+
+using namespace fgpu;
+
+extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, const uint64_t* active_bitmap,
+                                   float damping, float tol, int32_t itermax, float* centrality, int32_t* iters) {
+    FGPU_REQUIRE(ctx && A && centrality, FGPU_NULL_POINTER, "fgpu_pagerank: NULL argument");
+    FGPU_REQUIRE(A->nrows == A->ncols, FGPU_DIM_MISMATCH, "fgpu_pagerank: adjacency must be square");
+    FGPU_REQUIRE(!At || (At->nrows == A->nrows && At->ncols == A->ncols), FGPU_DIM_MISMATCH,
+                 "fgpu_pagerank: transpose has different dimensions");
+    FGPU_REQUIRE(damping > 0.0f && damping <= 1.0f, FGPU_INVALID, "fgpu_pagerank: damping out of (0, 1]");
+    const u32 n = (u32)A->nrows;
+    if (iters) *iters = 0;
+    if (n == 0) return FGPU_OK;
+    // dense row pointers are indexed directly below: hypersparse inputs are densified, a missing transpose is built
+    fgpu_mat *dA = nullptr, *dAt = nullptr;
+    fgpu_info info = FGPU_OK;
+    if (A->is_hyper()) {
+        info = mat_merge_entries(ctx, &dA, A, nullptr, nullptr, false, A->nrows, A->ncols, true);
+        A = dA;
+    }
+    if (info == FGPU_OK && !At) {
+        info = fgpu_mat_transpose(ctx, &dAt, A);
+        At = dAt;
+    } else if (info == FGPU_OK && At->is_hyper()) {
+        info = mat_merge_entries(ctx, &dAt, At, nullptr, nullptr, false, At->nrows, At->ncols, true);
+        At = dAt;
+    }
+    auto run = [&]() -> fgpu_info {
+        FGPU_TRY(mat_ensure_finalized(At));
+        const u32 nb = cdiv(n, 256);
+        const u32 grid = (u32)ctx->cus * 8 < cdiv(cdiv(n, 64), 4) ? (u32)ctx->cus * 8 : cdiv(cdiv(n, 64), 4);
+        DevBuf<u64> act;
+        DevBuf<u32> deg;
+        DevBuf<float> r, t, w, d, part, part2, scal;
+        DevBuf<unsigned char> sink;
+        u64 n_act = n;
+        if (active_bitmap) {
+            const size_t words = ((size_t)n + 63) / 64;
+            n_act = 0;
+            for (size_t k = 0; k < words; ++k) {
+                u64 x = active_bitmap[k];
+                if (k == words - 1 && (n & 63)) x &= (1ull << (n & 63)) - 1ull;
+                n_act += (u64)__builtin_popcountll(x);
+            }
+            FGPU_TRY(act.alloc(ctx, words));
+            FGPU_HIP(hipMemcpyAsync(act.p, active_bitmap, words * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            FGPU_TRY(deg.alloc(ctx, n));
+            hipLaunchKernelGGL(pr_degree_kernel, dim3(nb), dim3(256), 0, ctx->stream, view_of(A), (const u64*)act.p, n,
+                               deg.p);
+            FGPU_HIP(hipGetLastError());
+        }
+        FGPU_TRY(r.alloc(ctx, n));
+        FGPU_TRY(t.alloc(ctx, n));
+        FGPU_TRY(w.alloc(ctx, n));
+        FGPU_TRY(d.alloc(ctx, n));
+        FGPU_TRY(sink.alloc(ctx, n));
+        FGPU_TRY(part.alloc(ctx, nb));
+        FGPU_TRY(part2.alloc(ctx, (size_t)grid + 1));
+        FGPU_TRY(scal.alloc(ctx, 2));
+        if (n_act == 0) {
+            memset(centrality, 0, (size_t)n * sizeof(float));
+            return FGPU_OK;
+        }
+        const float fn = (float)n_act;
+        hipLaunchKernelGGL(pr_init_kernel, dim3(nb), dim3(256), 0, ctx->stream, view_of(A), (const u64*)act.p,
+                           (const u32*)deg.p, n, 1.0f / fn, damping, r.p, d.p, sink.p);
+        FGPU_HIP(hipGetLastError());
+        const float teleport0 = (1.0f - damping) / fn, damp_over_n = damping / fn;
+        const CsrView vat = view_of(At);
+        float rdiff = 1.0f;
+        int it = 0;
+        float* rp = r.p;   // current scores
+        float* tp = t.p;   // previous scores
+        for (; it < itermax && rdiff > tol; ++it) {
+            float* tmp = tp; tp = rp; rp = tmp;   // t = old r
+            hipLaunchKernelGGL(pr_prep_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const float*)tp,
+                               (const float*)d.p, (const unsigned char*)sink.p, (const u64*)act.p, n, w.p, part.p);
+            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)part.p, nb,
+                               teleport0, damp_over_n, scal.p);
+            hipLaunchKernelGGL(pr_spmv_kernel, dim3(grid), dim3(256), 0, ctx->stream, vat, (const u64*)act.p, n,
+                               (const float*)w.p, (const float*)scal.p, (const float*)tp, rp, part2.p + 1);
+            if (At->n_hub_chunks) {
+                const u32 hg = At->n_hub_chunks < (u32)ctx->cus * 8 ? At->n_hub_chunks : (u32)ctx->cus * 8;
+                hipLaunchKernelGGL(pr_hub_kernel, dim3(hg), dim3(256), 0, ctx->stream, (const u32*)At->hub_chunks,
+                                   At->n_hub_chunks, (const u32*)At->colidx, (const u64*)act.p, (const float*)w.p, rp);
+                hipLaunchKernelGGL(pr_hub_diff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const u32*)At->hub_chunks,
+                                   At->n_hub_chunks, (const u32*)At->rowptr, (const float*)tp, (const float*)rp,
+                                   part2.p);
+            } else {
+                FGPU_HIP(hipMemsetAsync(part2.p, 0, sizeof(float), ctx->stream));
+            }
+            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)part2.p, grid + 1,
+                               0.0f, 1.0f, scal.p + 1);
+            FGPU_HIP(hipGetLastError());
+            FGPU_HIP(hipMemcpyAsync(ctx->pinned, scal.p + 1, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            FGPU_HIP(hipStreamSynchronize(ctx->stream));
+            memcpy(&rdiff, ctx->pinned, sizeof(float));
+        }
+        if (iters) *iters = it;
+        FGPU_HIP(hipMemcpyAsync(centrality, rp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        return FGPU_OK;
+    };
+    if (info == FGPU_OK) info = run();
+    if (dA) fgpu_mat_free(dA);
+    if (dAt) fgpu_mat_free(dAt);
+    return info;
+}

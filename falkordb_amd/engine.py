@@ -318,6 +318,18 @@ def bfs(ctx: Context, A: Mat, At: Mat | None, src: int, max_level: int = -1, wan
     return level, parent, edges.value
 
 
+def pagerank(ctx: Context, A: Mat, At: Mat | None = None, active_bitmap=None, damping: float = 0.85,
+             tol: float = 1e-4, itermax: int = 100):
+    """fgpu_pagerank: LAGr_PageRank's numbers for algo.pageRank (FP32).  Returns (scores float32[n], iters)."""
+    n = A.nrows
+    out = np.zeros(n, dtype=np.float32)
+    act = _u64(active_bitmap) if active_bitmap is not None else None
+    it = C.c_int32()
+    check(ctx.lib.fgpu_pagerank(ctx._h, A._h, At._h if At else None, _p(act), C.c_float(damping), C.c_float(tol),
+                                C.c_int32(itermax), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(it)))
+    return out, it.value
+
+
 class BfsPlan:
     """fgpu_bfs_plan: resident BFS workspace (+ slab partition state for multi-rank runs)."""
 

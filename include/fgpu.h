@@ -236,6 +236,15 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
 fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t* mask,
                    const fgpu_mat* A, const fgpu_mat* At, int direction);
 
+/* PageRank: replaces LAGr_PageRank(&centrality, &iters, G, damping, tol, itermax, msg) as called by
+ * algo.pageRank (algo_procedures.rs:741-752 with 0.85 / 1e-4 / 100; binding lagraph_bindings.rs:549-558) on the
+ * adjacency matrix A (At nullable: transposed internally).  FP32 like the reference's GrB_FP32 vectors; sinks
+ * (vertices without out-edges) spread their score evenly.  `active_bitmap` (nullable, nrows bits) restricts the run
+ * to the induced subgraph of the flagged vertices — the label-filtered form (algo_procedures.rs:725-733) — and
+ * leaves 0 in the other slots.  centrality[nrows] is a HOST array; *iters (nullable) the iterations taken. */
+fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, const uint64_t* active_bitmap,
+                        float damping, float tol, int32_t itermax, float* centrality, int32_t* iters);
+
 /* Level-synchronous BFS: replaces LAGr_BreadthFirstSearch_Extended(level, parent, G,
  * src, max_level, -1, false) as called by algo.BFS (algo_procedures.rs:1079-1088;
  * binding lagraphx_bindings.rs:585-594).  level[n] (int32, -1 = unreached, source = 0),
