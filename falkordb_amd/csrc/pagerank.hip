@@ -125,17 +125,44 @@ __global__ __launch_bounds__(256) void pr_spmv_kernel(CsrView at, const u64* __r
             for (int j = 0; j < PR_A; ++j) acc += (c[j] != 0xFFFFFFFFu) ? w[c[j]] : 0.0f;
         }
         // rows longer than PR_A (and shorter than HUB_DEG): the wave sums the rest, 64 coalesced elements per trip
+        // FOUR rows per trip (each row's gathers are a dependent col -> w chain of ~1 us; one row at a time left the
+        // wave waiting on a single chain), slot state wave-uniform in SGPRs
         u64 pend = __ballot(!hub && deg > (u32)PR_A);
         while (pend) {
-            const int l = (int)__builtin_ctzll(pend);
-            pend &= pend - 1ull;
-            const u32 b0 = (u32)__builtin_amdgcn_readlane((int)rb, l) + PR_A;
-            const u32 e0 = (u32)__builtin_amdgcn_readlane((int)re, l);
-            float s = 0.0f;
-            for (u32 q = b0 + lane; q < e0; q += 64) s += w[col[q]];
+            int sl[4];
+            u32 sb[4], se[4];
+            float ss[4];
 #pragma unroll
-            for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k, 64);
-            if ((int)lane == l) acc += s;
+            for (int k = 0; k < 4; ++k) {
+                sl[k] = -1; sb[k] = 0; se[k] = 0; ss[k] = 0.0f;
+                if (pend) {
+                    sl[k] = (int)__builtin_ctzll(pend);
+                    pend &= pend - 1ull;
+                    sb[k] = (u32)__builtin_amdgcn_readlane((int)rb, sl[k]) + PR_A;
+                    se[k] = (u32)__builtin_amdgcn_readlane((int)re, sl[k]);
+                }
+            }
+            for (;;) {
+                bool more = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) more |= sb[k] < se[k];
+                if (!more) break;
+                u32 x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = (sb[k] + lane < se[k]) ? col[sb[k] + lane] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ss[k] += (x[k] != 0xFFFFFFFFu) ? w[x[k]] : 0.0f;
+                    sb[k] += 64;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = ss[k];
+#pragma unroll
+                for (int d2 = 32; d2 >= 1; d2 >>= 1) s += __shfl_xor(s, d2, 64);
+                if ((int)lane == sl[k]) acc += s;
+            }
         }
         if (v < n) {
             const float rv = on ? tp + acc : 0.0f;
@@ -190,6 +217,21 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
     const u32 n = (u32)A->nrows;
     if (iters) *iters = 0;
     if (n == 0) return FGPU_OK;
+    if (A->nnz == 0) {
+        // no edges: every vertex is a sink, the first iteration reproduces r = 1/n exactly (teleport = (1-d)/n + d/n)
+        // and rdiff = 0 ends the loop — written out here so that empty / hypersparse-empty snapshots need no kernels
+        u64 n_act = n;
+        if (active_bitmap) {
+            n_act = 0;
+            for (u32 v = 0; v < n; ++v) n_act += (active_bitmap[v >> 6] >> (v & 63)) & 1ull;
+        }
+        for (u32 v = 0; v < n; ++v) {
+            const bool on = !active_bitmap || ((active_bitmap[v >> 6] >> (v & 63)) & 1ull);
+            centrality[v] = (on && n_act) ? 1.0f / (float)n_act : 0.0f;
+        }
+        if (iters) *iters = (n_act && itermax > 0 && tol < 1.0f) ? 1 : 0;
+        return FGPU_OK;
+    }
     // dense row pointers are indexed directly below: hypersparse inputs are densified, a missing transpose is built
     fgpu_mat *dA = nullptr, *dAt = nullptr;
     fgpu_info info = FGPU_OK;
@@ -200,9 +242,13 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
     if (info == FGPU_OK && !At) {
         info = fgpu_mat_transpose(ctx, &dAt, A);
         At = dAt;
-    } else if (info == FGPU_OK && At->is_hyper()) {
-        info = mat_merge_entries(ctx, &dAt, At, nullptr, nullptr, false, At->nrows, At->ncols, true);
-        At = dAt;
+    }
+    if (info == FGPU_OK && At->is_hyper()) {
+        fgpu_mat* dense = nullptr;
+        info = mat_merge_entries(ctx, &dense, At, nullptr, nullptr, false, At->nrows, At->ncols, true);
+        if (dAt) fgpu_mat_free(dAt);
+        dAt = dense;
+        At = dense;
     }
     auto run = [&]() -> fgpu_info {
         FGPU_TRY(mat_ensure_finalized(At));

@@ -44,11 +44,13 @@ def load():
         L.fh_free.restype = None
         for name in declared_symbols():
             fn = getattr(L, name)  # raises if the library lacks a declared symbol
-            if name not in ("fh_last_error", "fh_free", "fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free"):
+            if name not in ("fh_last_error", "fh_free", "fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free",
+                            "fh_last_op_ns"):
                 fn.restype = C.c_int
         for name in ("fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free"):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [C.c_void_p]
+        L.fh_last_op_ns.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -417,6 +419,16 @@ class Graph:
                                   C.byref(n)))
         return list(zip(_take(orow, n.value).tolist(), _take(osrc, n.value).tolist(),
                         _take(odst, n.value).tolist(), _take(oedge, n.value).tolist()))
+
+    def algo_pagerank(self, label=None, rel_type=None):
+        """CALL algo.pageRank(label, relationshipType) YIELD node, score -> (nodes, scores float64)."""
+        nodes = u64p()
+        scores = C.POINTER(C.c_double)()
+        n = C.c_uint64()
+        _ck(self.L.fh_algo_pagerank(self.h, label.encode() if label is not None else None,
+                                    rel_type.encode() if rel_type is not None else None, C.byref(nodes),
+                                    C.byref(scores), C.byref(n)))
+        return _take(nodes, n.value), _take(scores, n.value, np.float64)
 
     def algo_bfs(self, source, max_depth=-1, rel_type=None, want_edges=False):
         has = C.c_int()

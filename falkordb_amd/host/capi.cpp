@@ -401,4 +401,18 @@ int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_
     });
 }
 
+int fh_algo_pagerank(fh_graph* g, const char* label, const char* rel_type, uint64_t** nodes, double** scores,
+                     uint64_t* n) {
+    return guard([&] {
+        PageRankResult r = algo_pagerank(g->g, label ? std::optional<std::string>(label) : std::nullopt,
+                                         rel_type ? std::optional<std::string>(rel_type) : std::nullopt);
+        *nodes = hand(r.nodes);
+        double* sc = (double*)malloc((r.scores.size() ? r.scores.size() : 1) * sizeof(double));
+        if (sc && !r.scores.empty()) memcpy(sc, r.scores.data(), r.scores.size() * sizeof(double));
+        *scores = sc;
+        *n = r.nodes.size();
+        return 0;
+    });
+}
+
 }  // extern "C"

@@ -468,4 +468,46 @@ BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
     return res;
 }
 
+// ---- algo.pageRank -------------------------------------------------------------------------------------
+PageRankResult algo_pagerank(const Graph& g, const std::optional<std::string>& label,
+                             const std::optional<std::string>& rel_type) {
+    PageRankResult res;
+    const u64 n = g.node_cap();
+    u64 live = 0;
+    for (u64 v = 0; v < n; ++v) live += g.is_node_deleted(v) ? 0 : 1;
+    if (live == 0) return res;                                           // node_count() == 0 (:699-701)
+    std::vector<std::string> types;
+    if (rel_type) types.push_back(*rel_type);
+    // a label that covers every live node is the unfiltered run (:711-713); otherwise the labelled nodes form a
+    // compact graph of their own (:725-733) — here the induced subgraph selected by a bitmap
+    std::vector<u64> active;
+    bool filtered = false;
+    if (label) {
+        auto lid = g.label_id(*label);
+        if (!lid) return res;                                            // no node carries an unknown label
+        active = g.label_bitmap({*lid});
+        u64 cnt = 0;
+        for (u64 v = 0; v < n; ++v) {
+            if (g.is_node_deleted(v)) active[v >> 6] &= ~(1ull << (v & 63));
+            cnt += (active[v >> 6] >> (v & 63)) & 1ull;
+        }
+        filtered = cnt != live;
+        if (cnt == 0) return res;
+    }
+    Matrix adj = g.build_adjacency_matrix(types);                        // graph.rs:3870-3894
+    std::vector<float> score(n);
+    int32_t iters = 0;
+    // deleted ids stay in the unfiltered matrix as isolated vertices (n = node_count + deleted_nodes_count, :718-720)
+    check(fgpu_pagerank(g.ctx().raw(), adj.snapshot(), nullptr, filtered ? active.data() : nullptr, 0.85f, 1e-4f, 100,
+                        score.data(), &iters),
+          "LAGr_PageRank");
+    for (u64 v = 0; v < n; ++v) {
+        if (g.is_node_deleted(v)) continue;                              // :768-770
+        if (filtered && !((active[v >> 6] >> (v & 63)) & 1ull)) continue;
+        res.nodes.push_back(v);
+        res.scores.push_back((double)score[v]);
+    }
+    return res;
+}
+
 }  // namespace falkor

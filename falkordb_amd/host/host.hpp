@@ -365,4 +365,12 @@ struct BfsResult {
 BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
                    const std::optional<std::string>& rel_type, bool want_edges);
 
+struct PageRankResult {
+    std::vector<u64> nodes;
+    std::vector<double> scores;   // Column::Floats: the FP32 centrality widened (extract_vector_f64)
+};
+// algo.pageRank (runtime/functions/algo_procedures.rs:687-783): label / rel_type NULL = all
+PageRankResult algo_pagerank(const Graph& g, const std::optional<std::string>& label,
+                             const std::optional<std::string>& rel_type);
+
 }  // namespace falkor

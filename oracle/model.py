@@ -8,6 +8,7 @@ citation per method (file:line relative to /root/reference).
     expand_batch      graph/src/runtime/ops/cond_traverse.rs:452-751
     expand_into_row   graph/src/runtime/ops/expand_into.rs:121-258
     algo_bfs          graph/src/runtime/functions/algo_procedures.rs:1021-1160
+    algo_pagerank     graph/src/runtime/functions/algo_procedures.rs:687-783
 """
 from __future__ import annotations
 
@@ -442,3 +443,29 @@ def algo_bfs(g: Graph, source, max_depth=-1, rel_type=None, want_edges=False):
     if not nodes:
         return None
     return nodes, edges
+
+
+def algo_pagerank(g: Graph, label=None, rel_type=None):
+    """algo.pageRank (algo_procedures.rs:687-783): (nodes ascending, scores) over the live nodes; a label that does
+    not cover every live node selects the compact graph of its nodes (:711-733); deleted ids stay in the unfiltered
+    matrix as isolated vertices (:718-720) and are dropped from the output (:768-770)."""
+    from . import pagerank as _pr
+    live = [v for v in range(g.n) if v not in g.deleted_nodes]
+    if not live:
+        return [], []
+    types = [rel_type] if rel_type is not None else []
+    active = None
+    if label is not None:
+        lids = g.resolve_label_ids([label])
+        if lids is None:
+            return [], []
+        members = [v for v in live if g.node_has_label_id(v, lids[0])]
+        if not members:
+            return [], []
+        if len(members) != len(live):
+            active = np.zeros(g.n, dtype=bool)
+            active[members] = True
+    adj = g.build_adjacency_matrix(types)
+    scores, _ = _pr.pagerank(adj, 0.85, 1e-4, 100, active=active)
+    nodes = [v for v in live if active is None or active[v]]
+    return nodes, [float(scores[v]) for v in nodes]

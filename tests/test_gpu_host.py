@@ -743,3 +743,87 @@ def test_algo_bfs_matches_the_oracle_on_rmat(rnd_graph):     # algo_procedures.r
         for v, e in zip(got[0], got[1]):
             s, d = by_edge[e]
             assert d == v and level[s] + 1 == level[v]
+
+
+# ---- algo.pageRank (algo_procedures.rs:687-783; tests/flow/test_pagerank.py) -----------------------------------
+def _model_edge(og, type_id, s, d, eid):
+    """the oracle graph is a read-side model: install a committed single edge directly"""
+    og.tensors[type_id].m[(s, d)] = eid
+    og.adjacency.m.add((s, d))
+
+
+def _pr_close(got_scores, want_scores):
+    # FP32 iteration, summation order differs (tests/test_gpu_pagerank.py states the tolerance): the stopping test may
+    # flip one iteration apart, which moves the scores by at most ~tol in L1
+    g, w = np.asarray(got_scores, dtype=np.float64), np.asarray(want_scores, dtype=np.float64)
+    assert g.shape == w.shape
+    assert np.abs(g - w).sum() <= 2e-4 or np.allclose(g, w, rtol=2e-5, atol=2e-6)
+
+
+def test_algo_pagerank_reference_flow_cases(hctx):
+    # test_pagerank_null_arguments (:40-105): six Node nodes A->B->C->F->E->D->A plus E->B
+    names = "ABCDEF"
+    idx = {c: i for i, c in enumerate(names)}
+    edges = [("A", "B"), ("B", "C"), ("C", "F"), ("F", "E"), ("E", "D"), ("D", "A"), ("E", "B")]
+    g, og = host.Graph(hctx, 6), model.Graph(6)
+    t, ot = g.add_type("CONNECTS"), og.add_type("CONNECTS")
+    l, ol = g.add_label("Node"), og.add_label("Node")
+    for v in range(6):
+        g.label_node(v, l)
+        og.node_labels.add((v, ol))
+    for eid, (x, y) in enumerate(edges):
+        g.create_edge(t, idx[x], idx[y], eid)
+        _model_edge(og, ot, idx[x], idx[y], eid)
+    nodes, scores = g.algo_pagerank(None, None)
+    wn, ws = model.algo_pagerank(og, None, None)
+    assert nodes.tolist() == wn == list(range(6))
+    _pr_close(scores, ws)
+    assert (scores > 0).all() and abs(float(scores.sum()) - 1.0) < 1e-4
+    assert all(scores[idx["B"]] >= s for s in scores)
+    # a label that covers every node is the unfiltered run (:711-713)
+    n2, s2 = g.algo_pagerank("Node", "CONNECTS")
+    assert n2.tolist() == nodes.tolist()
+    _pr_close(s2, scores)
+    # unknown label / unknown type
+    assert len(g.algo_pagerank("Nope", None)[0]) == 0
+    n3, s3 = g.algo_pagerank(None, "NoSuchType")
+    assert n3.tolist() == list(range(6)) and np.allclose(s3, 1 / 6, rtol=1e-5)     # edgeless: uniform
+    # a deleted node stays in the matrix as an isolated vertex and leaves the output (:718-720, :768-770)
+    g.delete_node(idx["C"]); og.deleted_nodes.add(idx["C"])
+    n4, s4 = g.algo_pagerank(None, None)
+    w4n, w4s = model.algo_pagerank(og, None, None)
+    assert n4.tolist() == w4n and idx["C"] not in n4.tolist()
+    _pr_close(s4, w4s)
+
+
+def test_algo_pagerank_specific_labels(hctx):
+    # test_pagerank_specific_labels (:107-151): A->B (Node, CONNECTS) and S1->S2 (Special, SPECIAL_CONNECTS)
+    g, og = host.Graph(hctx, 4), model.Graph(4)
+    ln, ls = g.add_label("Node"), g.add_label("Special")
+    oln, ols = og.add_label("Node"), og.add_label("Special")
+    for v, (lab, olab) in enumerate([(ln, oln), (ln, oln), (ls, ols), (ls, ols)]):
+        g.label_node(v, lab)
+        og.node_labels.add((v, olab))
+    g.create_edge(g.add_type("CONNECTS"), 0, 1, 0); _model_edge(og, og.add_type("CONNECTS"), 0, 1, 0)
+    g.create_edge(g.add_type("SPECIAL_CONNECTS"), 2, 3, 1); _model_edge(og, og.add_type("SPECIAL_CONNECTS"), 2, 3, 1)
+    nodes, scores = g.algo_pagerank("Special", "SPECIAL_CONNECTS")
+    wn, ws = model.algo_pagerank(og, "Special", "SPECIAL_CONNECTS")
+    assert nodes.tolist() == wn == [2, 3]
+    _pr_close(scores, ws)
+    assert scores[1] > scores[0] > 0                         # S2 has the in-edge
+    assert len(host.Graph(hctx, 0 + 1).algo_pagerank(None, None)[0]) == 1   # one isolated node: score 1
+    empty = host.Graph(hctx, 3)
+    for v in range(3):
+        empty.delete_node(v)
+    assert len(empty.algo_pagerank(None, None)[0]) == 0      # no live node: empty result (:153-160)
+
+
+def test_algo_pagerank_matches_the_oracle_on_rmat(rnd_graph):
+    g, og, n, _ = rnd_graph
+    for label, rel in [(None, None), (None, "A"), ("P", None), ("Q", "B")]:
+        nodes, scores = g.algo_pagerank(label, rel)
+        wn, ws = model.algo_pagerank(og, label, rel)
+        assert nodes.tolist() == wn
+        _pr_close(scores, ws)
+        if len(wn):
+            assert abs(float(scores.sum()) - 1.0) < 1e-3

@@ -10,7 +10,9 @@
   reach   [*1..4] DISTINCT reachability (fgpu_expand_levels) with dirty layers, device fold, folded rerun
           (SURVEY §8d config 5 stand-in)
 
-usage: python tools/bench_paths.py [merge|expand|reach|host|all] [scale]
+  pagerank  algo.pageRank's core (fgpu_pagerank, FP32 plus_second pull SpMV) on RMAT-<scale>: ms per iteration
+
+usage: python tools/bench_paths.py [merge|expand|reach|host|pagerank|all] [scale]
 """
 import json
 import sys
@@ -144,6 +146,31 @@ def bench_reach(ctx, scale=19, edge_factor=38, hops=4, batch=1024):
                           "GTEPS": round(r["flops"] / dt / 1e9, 2)}), flush=True)
 
 
+def bench_pagerank(ctx, scale):
+    """LAGr_PageRank's iteration on device: fixed 20 iterations (tol 0) so that the figure is per iteration;
+    B_alg per iteration = 4 nnz (column ids of A') + 8 (N+1) (row pointers) + 6 x 4 N (t, d, w read / w, r written,
+    sink bytes) with the gathers of w counted as cache traffic like the bitmap probes of the BFS formulas."""
+    A = ctx.mat_rmat(scale)
+    At = A.transpose()
+    n, nnz = A.nrows, A.nvals
+    engine.pagerank(ctx, A, At, None, 0.85, 0.0, 3)
+    ctx.sync()
+    its = 20
+    t0 = time.perf_counter()
+    scores, it = engine.pagerank(ctx, A, At, None, 0.85, 0.0, its)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    s2, it2 = engine.pagerank(ctx, A, At)
+    dt2 = time.perf_counter() - t1
+    b_alg = 4 * nnz + 8 * (n + 1) + 24 * n
+    print(json.dumps({"path": "pagerank", "scale": scale, "vertices": n, "edges": nnz, "iterations": it,
+                      "ms_per_iteration": round(dt / it * 1e3, 3), "alg_bytes_per_iteration": b_alg,
+                      "GBps": round(b_alg * it / dt / 1e9, 1), "frac_hbm": round(b_alg * it / dt / 8e12, 4),
+                      "default_run": {"tol": 1e-4, "iterations": it2, "ms": round(dt2 * 1e3, 3)},
+                      "sum": round(float(scores.astype(np.float64).sum()), 6),
+                      "note": "whole fgpu_pagerank call incl. one host sync per iteration and the D2H of the scores"}), flush=True)
+
+
 def bench_host(scale):
     """expand_batch through libfalkor_host.so (label probes, layer waits, result hand-off) vs bare fgpu_expand."""
     from falkordb_amd import host
@@ -214,6 +241,10 @@ if __name__ == "__main__":
     if what in ("reach", "all"):
         c = engine.Context(0)
         bench_reach(c, scale or 19)
+        c.close()
+    if what in ("pagerank", "all"):
+        c = engine.Context(0)
+        bench_pagerank(c, scale or 22)
         c.close()
     if what in ("host", "all"):
         bench_host(scale or 18)
