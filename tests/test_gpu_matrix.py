@@ -255,3 +255,53 @@ def test_slabs(ctx):
     ref = oracle.build_csr(a.nrows, a.ncols, rows[keep], cols[keep])
     np.testing.assert_array_equal(rp, ref.rowptr)
     np.testing.assert_array_equal(ci, ref.colidx)
+
+
+@pytest.mark.parametrize("hyper", [False, True], ids=["dense-rowptr", "hypersparse-m"])
+def test_merge_clean_word_path_with_sparse_deltas(ctx, hyper):
+    """The clean-word fast path of merge.hip (a 64-entry word none of whose rows a delta touches is a shifted copy):
+    a large base with long runs of EMPTY rows, dp inserting into empty rows that sit between the rows of one word
+    (the word must then take the per-entry path: its offset changes mid-word), dm removing single entries, a few
+    dirty rows per thousand so that clean and dirty words interleave; also the no-delta copy, a grow and a shrink
+    (clip) resize, and UINT64 values riding along."""
+    rng = np.random.default_rng(77)
+    n = 200_000 if not hyper else 3_000_000
+    live = np.sort(rng.choice(n, 30_000, replace=False))             # rows that store anything
+    deg = rng.integers(1, 9, len(live))
+    deg[rng.choice(len(live), 40, replace=False)] = 700              # some rows spanning many words
+    rows = np.repeat(live, deg).astype(np.uint64)
+    cols = rng.integers(0, n, len(rows), dtype=np.uint64)
+    m = oracle.build_csr(n, n, rows, cols)
+    mr, mc = m.pairs()
+    # dp: 300 entries into rows that are EMPTY in m (between live rows) + 200 into live rows
+    empty_rows = np.setdiff1d(rng.choice(n, 2000, replace=False), live)[:300]
+    pr = np.concatenate([empty_rows, rng.choice(live, 200)]).astype(np.uint64)
+    pc = rng.integers(0, n, len(pr), dtype=np.uint64)
+    kill = rng.choice(m.nnz, 400, replace=False)
+    dr, dc = mr[kill], mc[kill]
+    dp, dm = oracle.build_csr(n, n, pr, pc), oracle.build_csr(n, n, dr, dc)
+    M = ctx.mat_from_coo(n, n, mr, mc)                                # device COO build
+    if hyper:
+        assert M.export_csr()[0] is not None
+    DP, DM = ctx.mat_from_coo(n, n, pr, pc), ctx.mat_from_coo(n, n, dr, dc)
+    for masks_dp in (False, True):
+        assert_same(M.merge(DP, DM, dm_masks_dp=masks_dp), oracle.merge(m, dp, dm, masks_dp))
+    assert_same(M.merge(DP, None), oracle.merge(m, dp, None))
+    assert_same(M.merge(None, DM), oracle.merge(m, None, dm))
+    assert_same(M.merge(None, None), m)
+    # resize: growing keeps every entry (no clip: fast path), shrinking drops rows / columns past the new dims
+    big = M.resize(n + 1000, n + 5)
+    assert big.nrows == n + 1000 and big.nvals == m.nnz
+    keep = (mr < n // 2) & (mc < n // 3)
+    assert_same(M.resize(n // 2, n // 3), oracle.build_csr(n // 2, n // 3, mr[keep], mc[keep]))
+    # UINT64 layers: values follow their entries through the shifted copy
+    vals = (mr * np.uint64(1_000_003) + mc).astype(np.uint64)
+    V = ctx.mat_from_coo(n, n, mr, mc, vals)
+    r2, c2, v2 = V.merge(DP, DM).extract()
+    ref = oracle.merge(m, dp, dm)
+    rr, rc = ref.pairs()
+    np.testing.assert_array_equal(r2, rr)
+    np.testing.assert_array_equal(c2, rc)
+    from_m = ~np.isin(rr * np.uint64(n) + rc, pr * np.uint64(n) + pc)
+    np.testing.assert_array_equal(v2[from_m], (rr * np.uint64(1_000_003) + rc)[from_m])
+    assert (v2[~from_m] == 1).all()                                   # BOOL dp entries carry the iso value 1
