@@ -439,3 +439,69 @@ class Graph:
                                C.byref(has), C.byref(nodes), C.byref(nn), C.byref(edges), C.byref(ne)))
         nv, ev = _take(nodes, nn.value).tolist(), _take(edges, ne.value).tolist()
         return (nv, ev) if has.value else None
+
+
+# ---- planner slice (fuse_anonymous_traverse) -------------------------------------------------------------
+def _node_txt(n):
+    return n["alias"] + "".join(":" + l for l in n.get("labels", [])) + ("*" if n.get("attrs") else "")
+
+
+def _rel_txt(r):
+    flags = ("b" if r.get("bidirectional") else "") + ("v" if r.get("var_len") else "") + ("a" if r.get("attrs") else "")
+    return "|".join([r["alias"], _node_txt(r["from"]), _node_txt(r["to"]), ",".join(r.get("types", [])), flags])
+
+
+def plan_to_text(ops):
+    """ops: list of dicts {id, parent, kind: "CT" | "X", ...} (see tests/test_host_cpu.py); children keep list order."""
+    lines = []
+    for op in ops:
+        if op["kind"] == "X":
+            lines.append(f"X {op['id']} {op['parent']} {op.get('name', 'Op')} refs={','.join(op.get('refs', []))}")
+        else:
+            flags = ("e" if op.get("emit") else "") + ("t" if op.get("transposed") else "") + \
+                    ("o" if op.get("optional") else "") + ("" if op.get("bind", True) else "n")
+            lines.append(f"CT {op['id']} {op['parent']} rel={_rel_txt(op['rel'])} flags={flags} "
+                         f"sib={','.join(op.get('siblings', []))} chain={';'.join(_rel_txt(r) for r in op.get('chain', []))}")
+    return "\n".join(lines) + "\n"
+
+
+def _node_from(txt):
+    attrs = txt.endswith("*")
+    parts = txt.rstrip("*").split(":")
+    return {"alias": parts[0], "labels": [p for p in parts[1:] if p], "attrs": attrs}
+
+
+def _rel_from(txt):
+    f = (txt.split("|") + [""] * 5)[:5]
+    return {"alias": f[0], "from": _node_from(f[1]), "to": _node_from(f[2]), "types": [t for t in f[3].split(",") if t],
+            "bidirectional": "b" in f[4], "var_len": "v" in f[4], "attrs": "a" in f[4]}
+
+
+def plan_from_text(text):
+    ops = []
+    for line in text.splitlines():
+        tok = line.split()
+        if not tok:
+            continue
+        kv = dict(t.split("=", 1) for t in tok[3:] if "=" in t)
+        if tok[0] == "X":
+            ops.append({"id": int(tok[1]), "parent": int(tok[2]), "kind": "X", "name": tok[3],
+                        "refs": [a for a in kv.get("refs", "").split(",") if a]})
+        else:
+            fl = kv.get("flags", "")
+            ops.append({"id": int(tok[1]), "parent": int(tok[2]), "kind": "CT", "rel": _rel_from(kv["rel"]),
+                        "emit": "e" in fl, "transposed": "t" in fl, "optional": "o" in fl, "bind": "n" not in fl,
+                        "siblings": [a for a in kv.get("sib", "").split(",") if a],
+                        "chain": [_rel_from(r) for r in kv.get("chain", "").split(";") if r]})
+    return ops
+
+
+def plan_fuse(ops, lower_id=-1):
+    """fuse_anonymous_traverse on a plan (list of op dicts); returns (ops after the pass, runtime spec of CondTraverse
+    node `lower_id` as bytes for Graph.cond_traverse_batch, or None)."""
+    L = load()
+    out, spec = C.c_char_p(), C.c_char_p()
+    L.fh_plan_fuse.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+    _ck(L.fh_plan_fuse(plan_to_text(ops).encode(), lower_id, C.byref(out), C.byref(spec)))
+    text, sp = out.value.decode(), spec.value
+    return plan_from_text(text), (sp if lower_id >= 0 else None)

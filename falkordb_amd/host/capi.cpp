@@ -401,6 +401,36 @@ int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_
     });
 }
 
+// plan text in, plan text out after fuse_anonymous_traverse; *spec (nullable) receives the runtime spec string
+// (the fh_cond_traverse_batch format) of the CondTraverse node `lower_id` of the RESULT, or "" if lower_id < 0
+int fh_plan_fuse(const char* plan_text, int lower_id, char** out_text, char** spec) {
+    return guard([&] {
+        Plan plan = parse_plan(plan_text ? plan_text : "");
+        fuse_anonymous_traverse(plan);
+        const std::string txt = print_plan(plan);
+        *out_text = strdup(txt.c_str());
+        if (spec) {
+            std::string sp;
+            if (lower_id >= 0 && (size_t)lower_id < plan.ops.size() && plan.ops[lower_id].kind == PlanOp::CondTraverse) {
+                CondTraverseOp op = lower_cond_traverse(plan.ops[lower_id]);
+                sp = "src=";
+                for (size_t i = 0; i < op.src_labels.size(); ++i) sp += (i ? "," : "") + op.src_labels[i];
+                for (auto& h : op.hops) {
+                    sp += ";hop=";
+                    for (size_t i = 0; i < h.types.size(); ++i) sp += (i ? "," : "") + h.types[i];
+                    sp += "|";
+                    for (size_t i = 0; i < h.dst_labels.size(); ++i) sp += (i ? "," : "") + h.dst_labels[i];
+                }
+                sp += std::string(";optional=") + (op.optional ? "1" : "0") + ";bind=" + (op.bind_relationship ? "1" : "0") +
+                      ";emit=" + (op.emit_relationship ? "1" : "0") + ";bidir=" + (op.bidirectional ? "1" : "0") +
+                      ";siblings=" + (op.has_sibling_edges ? "1" : "0") + ";attrs=" + (op.has_inline_attrs ? "1" : "0");
+            }
+            *spec = strdup(sp.c_str());
+        }
+        return 0;
+    });
+}
+
 int fh_algo_pagerank(fh_graph* g, const char* label, const char* rel_type, uint64_t** nodes, double** scores,
                      uint64_t* n) {
     return guard([&] {

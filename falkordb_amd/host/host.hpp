@@ -365,6 +365,44 @@ struct BfsResult {
 BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
                    const std::optional<std::string>& rel_type, bool want_edges);
 
+// ---- planner slice: the rule that decides which queries reach the fused chain ---------------------------
+// (planner/optimizer/fuse_anonymous_traverse.rs).  The model keeps only what the rule inspects.
+struct PlanNodeRef {
+    std::string alias;                 // "_anon*" = anonymous (fuse_anonymous_traverse.rs:38-40)
+    std::vector<std::string> labels;
+    bool attrs_empty = true;           // inline attribute map is `{}` (:55-63)
+};
+struct PlanRel {                       // QueryRelationship
+    std::string alias;
+    PlanNodeRef from, to;
+    std::vector<std::string> types;
+    bool bidirectional = false;
+    bool var_len = false;              // min_hops.is_some()
+    bool attrs_empty = true;           // :43-53
+};
+struct PlanOp {
+    enum Kind { CondTraverse, Other, Pruned } kind = Other;
+    int parent = -1;
+    std::vector<int> children;
+    // IR::CondTraverse (planner/mod.rs:183-213)
+    PlanRel rel;
+    bool emit_relationship = false, transposed = false, optional = false, bind_relationship = true;
+    std::vector<std::string> sibling_edges;
+    std::vector<PlanRel> chain;
+    // any other IR node: its name and the aliases its expressions reference (reduce_expand_into.rs:22-75)
+    std::string name;
+    std::vector<std::string> references;
+};
+struct Plan {
+    std::vector<PlanOp> ops;           // index = node id
+    int root = -1;
+};
+bool can_fuse(const Plan& plan, int parent_idx, int child_idx);            // fuse_anonymous_traverse.rs:83-188
+void fuse_anonymous_traverse(Plan& plan);                                   // :190-284
+CondTraverseOp lower_cond_traverse(const PlanOp& op);                       // plan node -> runtime operator
+Plan parse_plan(const std::string& text);                                   // text form: see planner.cpp
+std::string print_plan(const Plan& plan);
+
 struct PageRankResult {
     std::vector<u64> nodes;
     std::vector<double> scores;   // Column::Floats: the FP32 centrality widened (extract_vector_f64)

@@ -124,6 +124,11 @@ int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_r
 int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges,
                 int* has_row, uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges); /* algo_procedures.rs:1021-1160 */
 
+/* fuse_anonymous_traverse (planner/optimizer/fuse_anonymous_traverse.rs:83-284) on a plan in the text form
+ * documented in falkordb_amd/host/planner.cpp; *out_text = the plan after the pass, *spec (nullable) = the runtime
+ * spec (fh_cond_traverse_batch format) of CondTraverse node `lower_id` of the result.  Free both with fh_free. */
+int fh_plan_fuse(const char* plan_text, int lower_id, char** out_text, char** spec);
+
 /* label / rel_type NULL = all; nodes ascending, scores[k] = centrality of nodes[k] (free both with fh_free) */
 int fh_algo_pagerank(fh_graph* g, const char* label, const char* rel_type, uint64_t** nodes, double** scores,
                      uint64_t* n);                                                          /* algo_procedures.rs:687-783 */

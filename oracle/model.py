@@ -9,6 +9,7 @@ citation per method (file:line relative to /root/reference).
     expand_into_row   graph/src/runtime/ops/expand_into.rs:121-258
     algo_bfs          graph/src/runtime/functions/algo_procedures.rs:1021-1160
     algo_pagerank     graph/src/runtime/functions/algo_procedures.rs:687-783
+    fuse_anonymous_traverse  graph/src/planner/optimizer/fuse_anonymous_traverse.rs:83-284
 """
 from __future__ import annotations
 
@@ -469,3 +470,83 @@ def algo_pagerank(g: Graph, label=None, rel_type=None):
     scores, _ = _pr.pagerank(adj, 0.85, 1e-4, 100, active=active)
     nodes = [v for v in live if active is None or active[v]]
     return nodes, [float(scores[v]) for v in nodes]
+
+
+# ---- planner: fuse_anonymous_traverse (planner/optimizer/fuse_anonymous_traverse.rs) ------------------------
+def _is_anon(alias):                                  # :38-40
+    return alias.startswith("_anon")
+
+
+def can_fuse(ops_by_id, parent, child):               # :83-188  (parent = outer hop (b)-->(c), child = (a)-->(b))
+    p, c = ops_by_id[parent], ops_by_id[child]
+    if p["kind"] != "CT" or c["kind"] != "CT":
+        return False
+    if not p.get("bind", True) or not c.get("bind", True):
+        return False
+    if p.get("optional") or c.get("optional"):        # :111-115
+        return False
+    if p.get("transposed") or c.get("transposed"):    # :118-122
+        return False
+    pr, cr = p["rel"], c["rel"]
+    if not _is_anon(pr["alias"]) or not _is_anon(cr["alias"]):     # :125-127
+        return False
+    if p.get("emit") or c.get("emit"):                # :131-133
+        return False
+    if p.get("siblings") or c.get("siblings"):        # :135-137
+        return False
+    if pr.get("bidirectional") or cr.get("bidirectional"):         # :139-141
+        return False
+    if pr.get("var_len") or cr.get("var_len"):        # :142-144
+        return False
+    if pr.get("attrs") or cr.get("attrs"):            # :146-148
+        return False
+    if pr["from"]["alias"] != cr["to"]["alias"]:      # :150-154
+        return False
+    mid = pr["from"]
+    if not _is_anon(mid["alias"]) or mid.get("labels") or mid.get("attrs"):   # :157-165
+        return False
+    cur = p["parent"]                                  # :66-79, :180-186: ancestors of the outer hop
+    while cur >= 0:
+        a = ops_by_id[cur]
+        if a["kind"] == "X" and mid["alias"] in a.get("refs", []):
+            return False
+        cur = a["parent"]
+    return True
+
+
+def fuse_anonymous_traverse(ops):
+    """ops: list of dicts (id, parent, kind "CT" | "X", ...), children ordered as listed.  Returns the list after the
+    pass (:190-284): repeatedly merge the first fusable (parent, only-child) pair found in BFS order."""
+    import copy
+    ops = copy.deepcopy(ops)
+    while True:
+        by_id = {o["id"]: o for o in ops}
+        kids = {o["id"]: [] for o in ops}
+        root = None
+        for o in ops:
+            if o["parent"] < 0:
+                root = o["id"]
+            else:
+                kids[o["parent"]].append(o["id"])
+        target, queue = None, ([root] if root is not None else [])
+        while queue and target is None:
+            idx = queue.pop(0)
+            queue.extend(kids[idx])
+            if by_id[idx]["kind"] == "CT" and len(kids[idx]) == 1 and can_fuse(by_id, idx, kids[idx][0]):
+                target = idx
+        if target is None:
+            return ops
+        parent, child = by_id[target], by_id[kids[target][0]]
+        parent["chain"] = list(child.get("chain", [])) + [parent["rel"]] + list(parent.get("chain", []))   # :236-241
+        parent["rel"] = child["rel"]
+        parent["transposed"], parent["optional"], parent["bind"] = False, False, True                   # :255-263
+        for g in kids[child["id"]]:
+            by_id[g]["parent"] = target
+        # the grandchildren take the pruned child's place in the listing order
+        pos = ops.index(child)
+        ops.remove(child)
+        grand = [o for o in ops if o["parent"] == target and o["id"] in kids[child["id"]]]
+        for g in grand:
+            ops.remove(g)
+        for k, g in enumerate(grand):
+            ops.insert(min(pos + k, len(ops)), g)

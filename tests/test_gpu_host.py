@@ -398,6 +398,18 @@ def test_social_queries(hctx, commit):                     # social_queries.py:5
     rows3, _, flops = g.cond_traverse_batch(fused, [roi])
     assert sorted(names[d] for _, d in rows3) == sorted(set(fof))
     assert flops > 0
+    # the same operator obtained from the plan: MATCH (a:person)-[:friend]->()-[:friend]->(c:person) — two
+    # CondTraverse nodes that fuse_anonymous_traverse merges, lowered to the runtime spec
+    plan = [{"id": 0, "parent": -1, "kind": "X", "name": "Project", "refs": ["c"]},
+            {"id": 1, "parent": 0, "kind": "CT", "rel": {"alias": "_anon_e2", "from": {"alias": "_anon_1", "labels": []},
+                                                         "to": {"alias": "c", "labels": ["person"]}, "types": ["friend"]}},
+            {"id": 2, "parent": 1, "kind": "CT", "rel": {"alias": "_anon_e1", "from": {"alias": "a", "labels": ["person"]},
+                                                         "to": {"alias": "_anon_1", "labels": []}, "types": ["friend"]}},
+            {"id": 3, "parent": 2, "kind": "X", "name": "NodeByLabelScan", "refs": []}]
+    after, spec = host.plan_fuse(plan, lower_id=1)
+    assert sum(o["kind"] == "CT" for o in after) == 1
+    rows5, _, _ = g.cond_traverse_batch(spec, [roi])
+    assert rows5 == rows3
     # visited Netherlands and single
     attrs = {p["name"]: p for p in s["persons"]}
     singles = [ids[n] for n in fof if attrs[n]["status"] == "single"]

@@ -108,3 +108,132 @@ def test_no_cpu_fallback_host_init_fails_without_a_device():
     with pytest.raises(host.HostError) as e:
         host.Context(0)
     assert e.value.code == -7002    # FGPU_DEVICE
+
+
+# ---- planner slice: fuse_anonymous_traverse (planner/optimizer/fuse_anonymous_traverse.rs:83-284) ----------------
+def _node(alias, labels=(), attrs=False):
+    return {"alias": alias, "labels": list(labels), "attrs": attrs}
+
+
+def _rel(alias, frm, to, types=("KNOWS",), **kw):
+    return {"alias": alias, "from": frm, "to": to, "types": list(types), "bidirectional": kw.get("bidirectional", False),
+            "var_len": kw.get("var_len", False), "attrs": kw.get("attrs", False)}
+
+
+def _ct(i, parent, rel, **kw):
+    return {"id": i, "parent": parent, "kind": "CT", "rel": rel, "emit": kw.get("emit", False),
+            "transposed": kw.get("transposed", False), "optional": kw.get("optional", False), "bind": kw.get("bind", True),
+            "siblings": list(kw.get("siblings", [])), "chain": list(kw.get("chain", []))}
+
+
+def _x(i, parent, name, refs=()):
+    return {"id": i, "parent": parent, "kind": "X", "name": name, "refs": list(refs)}
+
+
+def _three_hop(override=None):
+    """MATCH (a:P)-->()-->()-->(c:Q) RETURN count(c): Project / CT(_b2->c) / CT(_b1->_b2) / CT(a->_b1) / scan"""
+    a, b1, b2, c = _node("a", ["P"]), _node("_anon_1"), _node("_anon_2"), _node("c", ["Q"])
+    ops = [_x(0, -1, "Aggregate", ["c"]),
+           _ct(1, 0, _rel("_anon_e3", b2, c)),
+           _ct(2, 1, _rel("_anon_e2", b1, b2)),
+           _ct(3, 2, _rel("_anon_e1", a, b1)),
+           _x(4, 3, "NodeByLabelScan", [])]
+    for (op_id, path), value in (override or {}).items():
+        tgt = ops[op_id]
+        for k in path[:-1]:
+            tgt = tgt[k]
+        tgt[path[-1]] = value
+    return ops
+
+
+def _canon(ops):
+    return sorted((json.dumps(o, sort_keys=True) for o in ops))
+
+
+def test_fuse_anonymous_traverse_collapses_a_three_hop_chain():
+    from falkordb_amd import host
+    from oracle import model
+    ops = _three_hop()
+    got, spec = host.plan_fuse(ops, lower_id=1)
+    want = model.fuse_anonymous_traverse(ops)
+    assert _canon(got) == _canon(want)
+    cts = [o for o in got if o["kind"] == "CT"]
+    assert len(cts) == 1 and cts[0]["id"] == 1 and cts[0]["parent"] == 0
+    ct = cts[0]
+    # entry hop first, then the chain in traversal order (:236-241); the scan hangs under the merged op (:266-271)
+    assert ct["rel"]["alias"] == "_anon_e1" and [r["alias"] for r in ct["chain"]] == ["_anon_e2", "_anon_e3"]
+    assert [o for o in got if o["id"] == 4][0]["parent"] == 1
+    assert not ct["transposed"] and not ct["optional"] and ct["bind"]
+    # the runtime operator: source label P, three hops, destination label Q on the last hop only
+    assert spec == b"src=P;hop=KNOWS|;hop=KNOWS|;hop=KNOWS|Q;optional=0;bind=0;emit=0;bidir=0;siblings=0;attrs=0"
+    L = host.load()
+    assert L.fh_cond_traverse_eligible(spec) == 1
+
+
+@pytest.mark.parametrize("name,override,fused_pairs", [
+    ("optional hop", {(2, ("optional",)): True}, 0),
+    ("transposed hop", {(2, ("transposed",)): True}, 0),
+    ("named edge", {(2, ("rel", "alias")): "e"}, 0),
+    ("emitted edge", {(2, ("emit",)): True}, 0),
+    ("sibling edges", {(2, ("siblings",)): ["_anon_e9"]}, 0),
+    ("bidirectional hop", {(2, ("rel", "bidirectional")): True}, 0),
+    ("variable length hop", {(2, ("rel", "var_len")): True}, 0),
+    ("edge attributes", {(2, ("rel", "attrs")): True}, 0),
+    ("bind_relationship off", {(2, ("bind",)): False}, 0),
+    # the middle hop spoils both pairs; spoiling only an END hop leaves the other pair fusable:
+    ("named last edge", {(1, ("rel", "alias")): "e"}, 1),
+    ("optional first hop", {(3, ("optional",)): True}, 1),
+])
+def test_fuse_anonymous_traverse_conditions(name, override, fused_pairs):
+    from falkordb_amd import host
+    from oracle import model
+    ops = _three_hop(override)
+    got, _ = host.plan_fuse(ops)
+    want = model.fuse_anonymous_traverse(ops)
+    assert _canon(got) == _canon(want), name
+    assert sum(o["kind"] == "CT" for o in got) == 3 - fused_pairs, name
+
+
+@pytest.mark.parametrize("name,mutate,n_ct", [
+    ("labelled intermediate", lambda ops: ops[1]["rel"]["from"]["labels"].append("P") or ops[2]["rel"]["to"]["labels"].append("P"), 2),
+    ("named intermediate", lambda ops: [ops[1]["rel"]["from"].update(alias="b"), ops[2]["rel"]["to"].update(alias="b")], 2),
+    ("intermediate with attributes", lambda ops: [ops[1]["rel"]["from"].update(attrs=True), ops[2]["rel"]["to"].update(attrs=True)], 2),
+    ("intermediate referenced above", lambda ops: ops[0]["refs"].append("_anon_2"), 2),
+    ("hops do not share the intermediate",
+     lambda ops: ops[1]["rel"].update({"from": dict(ops[1]["rel"]["from"], alias="_anon_9")}), 2),
+])
+def test_fuse_anonymous_traverse_intermediate_rules(name, mutate, n_ct):
+    from falkordb_amd import host
+    from oracle import model
+    ops = _three_hop()
+    mutate(ops)
+    got, _ = host.plan_fuse(ops)
+    want = model.fuse_anonymous_traverse(ops)
+    assert _canon(got) == _canon(want), name
+    assert sum(o["kind"] == "CT" for o in got) == n_ct, name
+
+
+def test_fuse_anonymous_traverse_needs_an_only_child_and_keeps_branches():
+    from falkordb_amd import host
+    from oracle import model
+    # a CondTraverse with two children (e.g. under an Apply) is left alone (:198-200); a fusable pair elsewhere in the
+    # tree is still merged, and a filter between the hops blocks the pair it separates (the child is not a CT)
+    a, b1, b2, c = _node("a"), _node("_anon_1"), _node("_anon_2"), _node("c")
+    ops = [_x(0, -1, "Project", ["a", "c"]),
+           _ct(1, 0, _rel("_anon_e2", b1, c)),
+           _ct(2, 1, _rel("_anon_e1", a, b1)),
+           _x(3, 2, "AllNodeScan"),
+           _x(4, 1, "Argument")]                       # second child of op 1
+    got, _ = host.plan_fuse(ops)
+    assert _canon(got) == _canon(model.fuse_anonymous_traverse(ops)) == _canon(ops)
+    ops2 = [_x(0, -1, "Project", ["c"]),
+            _ct(1, 0, _rel("_anon_e3", b2, c)),
+            _x(2, 1, "Filter", ["a"]),
+            _ct(3, 2, _rel("_anon_e2", b1, b2)),
+            _ct(4, 3, _rel("_anon_e1", a, b1)),
+            _x(5, 4, "AllNodeScan")]
+    got2, spec = host.plan_fuse(ops2, lower_id=3)
+    want2 = model.fuse_anonymous_traverse(ops2)
+    assert _canon(got2) == _canon(want2)
+    assert sorted(o["id"] for o in got2 if o["kind"] == "CT") == [1, 3]
+    assert spec.startswith(b"src=;hop=KNOWS|;hop=KNOWS|;")
