@@ -45,9 +45,9 @@ def load():
         for name in declared_symbols():
             fn = getattr(L, name)  # raises if the library lacks a declared symbol
             if name not in ("fh_last_error", "fh_free", "fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free",
-                            "fh_last_op_ns"):
+                            "fh_last_op_ns", "fh_mat_cursor_free"):
                 fn.restype = C.c_int
-        for name in ("fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free"):
+        for name in ("fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free", "fh_mat_cursor_free"):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [C.c_void_p]
         L.fh_last_op_ns.restype = C.c_uint64
@@ -106,6 +106,35 @@ class Context:
         if self.h:
             self.L.fh_finalize(self.h)
             self.h = C.c_void_p()
+
+
+class MatrixCursor:
+    """fh_mat_cursor_*: Iter::new / seek / next (matrix.rs:1471-1605); keeps its matrix alive."""
+
+    def __init__(self, m, min_row, max_row, batch=4096):
+        self.m, self.L, self.batch = m, m.L, batch
+        self.h = C.c_void_p()
+        _ck(self.L.fh_mat_cursor_new(m.h, C.c_uint64(min_row), C.c_uint64(max_row), C.byref(self.h)))
+
+    def seek(self, min_row, max_row):
+        _ck(self.L.fh_mat_cursor_seek(self.h, C.c_uint64(min_row), C.c_uint64(max_row)))
+        return self
+
+    def __iter__(self):
+        r, c, v = (np.zeros(self.batch, dtype=np.uint64) for _ in range(3))
+        n = C.c_uint64()
+        while True:
+            _ck(self.L.fh_mat_cursor_next(self.h, C.c_uint64(self.batch), _p(r), _p(c), _p(v), C.byref(n)))
+            yield from zip(r[:n.value].tolist(), c[:n.value].tolist(), v[:n.value].tolist())
+            if n.value < self.batch:
+                return
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.fh_mat_cursor_free(self.h)
+        except Exception:
+            pass
 
 
 class Matrix:
@@ -167,6 +196,10 @@ class Matrix:
         _ck(self.L.fh_mat_iter(self.h, C.c_uint64(min_row), C.c_uint64(max_row), C.byref(r), C.byref(c), C.byref(v),
                                C.byref(n)))
         return list(zip(_take(r, n.value).tolist(), _take(c, n.value).tolist(), _take(v, n.value).tolist()))
+
+    def cursor(self, min_row=0, max_row=2**64 - 1):
+        """matrix::Iter as a reusable streaming cursor: .seek(min, max), iteration yields (row, col, val)."""
+        return MatrixCursor(self, min_row, max_row)
 
     def _unary(self, fn, *args):
         h = C.c_void_p()

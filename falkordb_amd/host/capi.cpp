@@ -130,6 +130,31 @@ int fh_mat_iter(fh_mat* m, uint64_t min_row, uint64_t max_row, uint64_t** rows, 
         return 0;
     });
 }
+// streaming cursor (matrix::Iter): new / seek / next-batch / free
+struct fh_mat_cursor { MatrixIter it; };
+int fh_mat_cursor_new(fh_mat* m, uint64_t min_row, uint64_t max_row, fh_mat_cursor** out) {
+    return guard([&] { *out = new fh_mat_cursor{MatrixIter(m->m, min_row, max_row)}; return 0; });
+}
+int fh_mat_cursor_seek(fh_mat_cursor* c, uint64_t min_row, uint64_t max_row) {
+    return guard([&] { c->it.seek(min_row, max_row); return 0; });
+}
+// up to `cap` entries into caller arrays; *n < cap means the cursor is exhausted
+int fh_mat_cursor_next(fh_mat_cursor* c, uint64_t cap, uint64_t* rows, uint64_t* cols, uint64_t* vals, uint64_t* n) {
+    return guard([&] {
+        uint64_t k = 0;
+        for (; k < cap; ++k) {
+            auto e = c->it.next();
+            if (!e) break;
+            rows[k] = e->row;
+            cols[k] = e->col;
+            if (vals) vals[k] = e->val;
+        }
+        *n = k;
+        return 0;
+    });
+}
+void fh_mat_cursor_free(fh_mat_cursor* c) { delete c; }
+
 int fh_mat_dup(fh_mat* m, fh_mat** out) { return guard([&] { *out = new fh_mat{m->m.dup()}; return 0; }); }
 int fh_mat_transpose(fh_mat* m, fh_mat** out) { return guard([&] { *out = new fh_mat{m->m.transpose()}; return 0; }); }
 int fh_mat_grown(fh_mat* m, uint64_t nrows, uint64_t ncols, fh_mat** out) {

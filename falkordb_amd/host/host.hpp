@@ -120,6 +120,24 @@ class Matrix {
     void replace(fgpu_mat* fresh) const;
 };
 
+// matrix::Iter<E> (matrix.rs:1471-1605): a reusable streaming cursor over the entries of rows [min, max] in
+// ascending (row, col) order.  `seek` re-aims the same cursor (what CondTraverseOp::expand_row does once per input
+// row, cond_traverse.rs:758-974) and keeps the matrix alive like the reference's Arc clone (:1472, 1485-1497).
+// Entries come from the device in windows of rows (fgpu_mat_extract), not one FFI call per entry.
+class MatrixIter {
+   public:
+    MatrixIter(const Matrix& m, u64 min_row, u64 max_row);   // Iter::new   matrix.rs:1500-1540
+    void seek(u64 min_row, u64 max_row);                      // Iter::seek  matrix.rs:1542-1570
+    std::optional<Entry> next();                              // Iterator::next  matrix.rs:1572-1605
+   private:
+    Matrix m_;
+    u64 cur_ = 0, max_ = 0, window_ = 1024;
+    bool depleted_ = true;
+    std::vector<Entry> buf_;
+    size_t pos_ = 0;
+    void refill();
+};
+
 // fold policy (versioned_matrix.rs:140-200) — pure integer arithmetic, pinned by versioned_matrix.rs:1278-1330
 constexpr u64 WRITE_FOLD_K = 20500000;
 constexpr u64 READ_FOLD_K = 82000;

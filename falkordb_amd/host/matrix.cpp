@@ -187,6 +187,44 @@ std::vector<Entry> Matrix::iter(u64 min_row, u64 max_row) const {
     return out;
 }
 
+// ---- MatrixIter ---------------------------------------------------------------------------------------
+MatrixIter::MatrixIter(const Matrix& m, u64 min_row, u64 max_row) : m_(m) { seek(min_row, max_row); }
+
+void MatrixIter::seek(u64 min_row, u64 max_row) {
+    m_.wait();
+    const u64 last = m_.nrows() ? m_.nrows() - 1 : 0;
+    cur_ = min_row;
+    max_ = max_row < last ? max_row : last;
+    depleted_ = m_.nrows() == 0 || min_row > max_;
+    window_ = 1024;
+    buf_.clear();
+    pos_ = 0;
+}
+
+void MatrixIter::refill() {
+    buf_.clear();
+    pos_ = 0;
+    while (!depleted_ && buf_.empty()) {
+        const u64 hi = (max_ - cur_ < window_) ? max_ : cur_ + window_ - 1;
+        buf_ = m_.iter(cur_, hi);
+        if (hi >= max_) depleted_ = true;
+        else cur_ = hi + 1;
+        // empty windows grow, dense ones shrink back: a sparse range is crossed in O(log) extracts, a dense one
+        // never pulls more than a few hundred thousand entries at a time
+        if (buf_.empty()) window_ = window_ < (1ull << 40) ? window_ * 8 : window_;
+        else if (buf_.size() > (1u << 18) && window_ > 64) window_ /= 8;
+    }
+}
+
+std::optional<Entry> MatrixIter::next() {
+    if (pos_ >= buf_.size()) {
+        if (depleted_) return std::nullopt;
+        refill();
+        if (buf_.empty()) return std::nullopt;
+    }
+    return buf_[pos_++];
+}
+
 Matrix Matrix::dup() const {
     auto s = std::make_shared<State>();
     s->ctx = s_->ctx;

@@ -45,6 +45,13 @@ int fh_mat_nvals(fh_mat* m, uint64_t* out);                                     
 int fh_mat_dims(fh_mat* m, uint64_t* nrows, uint64_t* ncols);
 int fh_mat_pending(fh_mat* m, int* out);                                               /* :764 */
 int fh_mat_wait(fh_mat* m);                                                            /* :781 */
+/* matrix::Iter as a reusable streaming cursor (matrix.rs:1471-1605): new / seek (re-aim, :1542-1570) / next.
+ * fh_mat_cursor_next fills up to `cap` entries of the caller's arrays (vals nullable); *n < cap = exhausted. */
+typedef struct fh_mat_cursor fh_mat_cursor;
+int fh_mat_cursor_new(fh_mat* m, uint64_t min_row, uint64_t max_row, fh_mat_cursor** out);
+int fh_mat_cursor_seek(fh_mat_cursor* c, uint64_t min_row, uint64_t max_row);
+int fh_mat_cursor_next(fh_mat_cursor* c, uint64_t cap, uint64_t* rows, uint64_t* cols, uint64_t* vals, uint64_t* n);
+void fh_mat_cursor_free(fh_mat_cursor* c);
 int fh_mat_iter(fh_mat* m, uint64_t min_row, uint64_t max_row, uint64_t** rows, uint64_t** cols,
                 uint64_t** vals, uint64_t* n);                                         /* Iter :1471-1605 */
 int fh_mat_dup(fh_mat* m, fh_mat** out);                                               /* :370 */
