@@ -453,6 +453,12 @@ class Graph:
         return list(zip(_take(orow, n.value).tolist(), _take(osrc, n.value).tolist(),
                         _take(odst, n.value).tolist(), _take(oedge, n.value).tolist()))
 
+    def build_adjacency(self, types=(), symmetric=False):
+        """Graph::build_adjacency_matrix / build_symmetric_adjacency_matrix (graph.rs:3870-3907) -> Matrix"""
+        h = C.c_void_p()
+        _ck(self.L.fh_graph_build_adjacency(self.h, ",".join(types).encode(), 1 if symmetric else 0, C.byref(h)))
+        return Matrix(self.ctx, _h=h)
+
     def algo_pagerank(self, label=None, rel_type=None):
         """CALL algo.pageRank(label, relationshipType) YIELD node, score -> (nodes, scores float64)."""
         nodes = u64p()

@@ -426,6 +426,17 @@ int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_
     });
 }
 
+// build_adjacency_matrix / build_symmetric_adjacency_matrix (graph.rs:3870-3907); types = comma list, "" = all
+int fh_graph_build_adjacency(fh_graph* g, const char* types, int symmetric, fh_mat** out) {
+    return guard([&] {
+        std::vector<std::string> ts;
+        for (auto& t : split(types ? types : "", ','))
+            if (!t.empty()) ts.push_back(t);
+        *out = new fh_mat{symmetric ? g->g.build_symmetric_adjacency_matrix(ts) : g->g.build_adjacency_matrix(ts)};
+        return 0;
+    });
+}
+
 // plan text in, plan text out after fuse_anonymous_traverse; *spec (nullable) receives the runtime spec string
 // (the fh_cond_traverse_batch format) of the CondTraverse node `lower_id` of the RESULT, or "" if lower_id < 0
 int fh_plan_fuse(const char* plan_text, int lower_id, char** out_text, char** spec) {

@@ -128,6 +128,15 @@ Matrix Graph::build_adjacency_matrix(const std::vector<std::string>& types) cons
     return result;
 }
 
+Matrix Graph::build_symmetric_adjacency_matrix(const std::vector<std::string>& types) const {
+    // graph.rs:3898-3907: result = A (+) A'  (the undirected view WCC / CDLP / MSF run on)
+    Matrix a = build_adjacency_matrix(types);
+    Matrix at = a.transpose();
+    Matrix result(*ctx_, Type::Bool, n_, n_);
+    result.element_wise_add(nullptr, &a, &at, Descriptor::None);
+    return result;
+}
+
 std::vector<u64> Graph::get_src_dest_relationships(u64 src, u64 dst, const std::vector<u64>& type_ids) const {
     std::vector<u64> out;
     for (u64 t : type_ids) {

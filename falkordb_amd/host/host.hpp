@@ -304,6 +304,7 @@ class Graph {
     std::vector<u64> label_bitmap(const std::vector<LabelId>& ids) const;
     Matrix build_relationship_matrix_unrestricted(const std::vector<u64>& type_ids) const;  // graph.rs:2520-2549
     Matrix build_adjacency_matrix(const std::vector<std::string>& types) const;             // graph.rs:3870-3894
+    Matrix build_symmetric_adjacency_matrix(const std::vector<std::string>& types) const;   // graph.rs:3898-3907 (A + A')
     std::vector<u64> get_src_dest_relationships(u64 src, u64 dst, const std::vector<u64>& type_ids) const;  // :1797-1837
 
    private:

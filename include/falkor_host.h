@@ -131,6 +131,10 @@ int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_r
 int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges,
                 int* has_row, uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges); /* algo_procedures.rs:1021-1160 */
 
+/* build_adjacency_matrix (graph.rs:3870-3894) or, symmetric != 0, build_symmetric_adjacency_matrix (:3898-3907):
+ * types = comma-separated relationship types, "" / NULL = the adjacency of all types */
+int fh_graph_build_adjacency(fh_graph* g, const char* types, int symmetric, fh_mat** out);
+
 /* fuse_anonymous_traverse (planner/optimizer/fuse_anonymous_traverse.rs:83-284) on a plan in the text form
  * documented in falkordb_amd/host/planner.cpp; *out_text = the plan after the pass, *spec (nullable) = the runtime
  * spec (fh_cond_traverse_batch format) of CondTraverse node `lower_id` of the result.  Free both with fh_free. */

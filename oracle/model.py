@@ -331,6 +331,11 @@ class Graph:
                 u |= self.tensors[self.type_ids[t]].structure()
         return _csr(self.n, self.n, u)
 
+    def build_symmetric_adjacency_matrix(self, types) -> CSR:   # graph.rs:3898-3907: A (+) A'
+        a = self.build_adjacency_matrix(types)
+        r, c = a.pairs()
+        return build_csr(self.n, self.n, np.concatenate([r, c]), np.concatenate([c, r]))
+
     def get_src_dest_relationships(self, s, d, types):   # graph.rs:1797-1837 (ids in type order)
         ids = []
         tids = [self.type_ids[t] for t in types if t in self.type_ids] if types else range(len(self.tensors))

@@ -876,3 +876,13 @@ def test_matrix_cursor_new_seek_next(hctx):
     b = host.Matrix(hctx, host.Matrix.BOOL, 100, 100)
     b.build(np.array([1, 1, 50], dtype=np.uint64), np.array([2, 3, 99], dtype=np.uint64))
     assert list(b.cursor(1, 50)) == [(1, 2, 1), (1, 3, 1), (50, 99, 1)]
+
+
+def test_adjacency_builders_match_the_oracle(rnd_graph):    # graph.rs:3870-3907
+    g, og, n, _ = rnd_graph
+    for types in ([], ["A"], ["A", "B"], ["Nope"]):
+        for sym in (False, True):
+            got = g.build_adjacency(types, symmetric=sym)
+            ref = og.build_symmetric_adjacency_matrix(types) if sym else og.build_adjacency_matrix(types)
+            rr, rc = ref.pairs()
+            assert [(r, c) for r, c, _ in got.iter()] == list(zip(rr.tolist(), rc.tolist())), (types, sym)
