@@ -15,15 +15,13 @@
 // algo_procedures.rs:725-733): n = |active|, edges with an inactive endpoint do not exist, inactive scores = 0.
 //
 // One iteration = three passes: (1) elementwise w = r/d + block partials of the sink mass, (2) the pull
-// SpMV over CSR(A') — a wavefront per 64 rows: every lane sums its row's first 8 in-neighbours, longer rows are
-// finished by the whole wave, rows >= HUB_DEG by the static hub chunk list with float atomics — fused with the
-// |t - r| partials, (3) fixed-order reductions of the partials (deterministic apart from the hub atomics).
+// SpMV over CSR(A') — entry-parallel over the contiguous entry range of every 64-row word, per-row sums in LDS,
+// rows >= HUB_DEG by the static hub chunk list with float atomics — fused with the |t - r| partials,
+// (3) fixed-order reductions of the partials (the LDS and hub float atomics make the low bits order-dependent).
 // Bytes per iteration: 4 nnz (column ids) + gathers of w (16 MB at RMAT-22, L2 / MALL resident) + 6 n-vectors.
 #include "common.hpp"
 
 namespace fgpu {
-
-constexpr int PR_A = 8;   // in-neighbours a lane sums alone before the wave takes the row over
 
 __device__ __forceinline__ bool pr_active(const u64* __restrict__ act, u32 v) {
     return !act || ((act[v >> 6] >> (v & 63)) & 1ull);
@@ -95,77 +93,72 @@ __global__ __launch_bounds__(256) void pr_reduce_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[0] = base + scale * tot;
 }
 
-// r[v] = teleport + sum_{u in in(v)} w[u]   (rows < HUB_DEG; hub rows get teleport only, the chunks add the rest)
+// r[v] = teleport + sum_{u in in(v)} w[u]   (rows < HUB_DEG; hub rows get teleport only, the chunks add the rest).
+// ENTRY-parallel like every kernel of this engine that meets R-MAT rows: the entries of a 64-row word are one
+// contiguous range of CSR(A'); the wave walks it 256 entries per trip (a lane per entry, four trips' loads in
+// flight), finds each entry's row among the word's 64 with a 6-step search over the row offsets in LDS, and adds
+// w[col] into the row's LDS accumulator (ds_add_f32).  A lane-per-row / wave-per-long-row version of this kernel
+// took 0.58 ms per pass at RMAT-22 whatever the locality of the gathers (column tiles of 2 MB changed nothing):
+// it was a chain of dependent round trips per row, not a bandwidth problem.
 __global__ __launch_bounds__(256) void pr_spmv_kernel(CsrView at, const u64* __restrict__ act, u32 n,
                                                      const float* __restrict__ w, const float* __restrict__ tele,
                                                      const float* __restrict__ t, float* __restrict__ r,
                                                      float* __restrict__ part) {
     __shared__ float s_red[4];
+    __shared__ u32 s_off[4][65];     // exclusive prefix of the word's effective row lengths
+    __shared__ u32 s_rb[4][64];      // first entry of each row
+    __shared__ float s_acc[4][64];
     const u32 lane = lane_id();
+    const u32 wv = threadIdx.x >> 6;
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
     const u32 nwords = (n + 63) >> 6;
     const float tp = tele[0];
     const u32* __restrict__ col = at.colidx;
+    u32* off = s_off[wv];
+    u32* rbs = s_rb[wv];
+    float* acc = s_acc[wv];
     float diff = 0.0f;
     for (u32 g = wave; g < nwords; g += nwaves) {
         const u32 v = (g << 6) + lane;
-        const u32 vc = v < n ? v : n;
+        const u32 vc = v < n ? v : n - 1;
         const u32 rb = at.rowptr[vc];
-        const u32 re = at.rowptr[vc + 1 <= n ? vc + 1 : n];
+        const u32 re = at.rowptr[vc + 1];
         const bool on = v < n && pr_active(act, v);
-        const u32 deg = on ? re - rb : 0u;
-        const bool hub = deg >= HUB_DEG;
-        float acc = 0.0f;
-        if (!hub) {
-            u32 c[PR_A];
+        const bool hub = re - rb >= HUB_DEG;
+        const u32 deg = (on && !hub) ? re - rb : 0u;
+        u32 inc = deg;
 #pragma unroll
-            for (int j = 0; j < PR_A; ++j) c[j] = ((u32)j < deg) ? col[rb + j] : 0xFFFFFFFFu;
-#pragma unroll
-            for (int j = 0; j < PR_A; ++j) acc += (c[j] != 0xFFFFFFFFu) ? w[c[j]] : 0.0f;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 y = __shfl_up(inc, d, 64);
+            if (lane >= (u32)d) inc += y;
         }
-        // rows longer than PR_A (and shorter than HUB_DEG): the wave sums the rest, 64 coalesced elements per trip
-        // FOUR rows per trip (each row's gathers are a dependent col -> w chain of ~1 us; one row at a time left the
-        // wave waiting on a single chain), slot state wave-uniform in SGPRs
-        u64 pend = __ballot(!hub && deg > (u32)PR_A);
-        while (pend) {
-            int sl[4];
-            u32 sb[4], se[4];
-            float ss[4];
+        off[lane + 1] = inc;
+        if (lane == 0) off[0] = 0;
+        rbs[lane] = rb;
+        acc[lane] = 0.0f;
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        for (u32 e0 = 0; e0 < total; e0 += 256) {
+            u32 row[4], x[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                sl[k] = -1; sb[k] = 0; se[k] = 0; ss[k] = 0.0f;
-                if (pend) {
-                    sl[k] = (int)__builtin_ctzll(pend);
-                    pend &= pend - 1ull;
-                    sb[k] = (u32)__builtin_amdgcn_readlane((int)rb, sl[k]) + PR_A;
-                    se[k] = (u32)__builtin_amdgcn_readlane((int)re, sl[k]);
+                const u32 e = e0 + 64 * k + lane;
+                u32 lo = 0, hi = 64;               // largest lo with off[lo] <= e
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (off[mid] <= e) lo = mid; else hi = mid;
                 }
-            }
-            for (;;) {
-                bool more = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) more |= sb[k] < se[k];
-                if (!more) break;
-                u32 x[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = (sb[k] + lane < se[k]) ? col[sb[k] + lane] : 0xFFFFFFFFu;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ss[k] += (x[k] != 0xFFFFFFFFu) ? w[x[k]] : 0.0f;
-                    sb[k] += 64;
-                }
+                row[k] = lo;
+                x[k] = (e < total) ? col[rbs[lo] + (e - off[lo])] : 0xFFFFFFFFu;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float s = ss[k];
-#pragma unroll
-                for (int d2 = 32; d2 >= 1; d2 >>= 1) s += __shfl_xor(s, d2, 64);
-                if ((int)lane == sl[k]) acc += s;
-            }
+            for (int k = 0; k < 4; ++k)
+                if (x[k] != 0xFFFFFFFFu) atomicAdd(&acc[row[k]], w[x[k]]);
         }
+        const float sum = acc[lane];
         if (v < n) {
-            const float rv = on ? tp + acc : 0.0f;
+            const float rv = on ? tp + sum : 0.0f;
             r[v] = rv;
             if (!hub) diff += fabsf(t[v] - rv);
         }
@@ -296,14 +289,21 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
         int it = 0;
         float* rp = r.p;   // current scores
         float* tp = t.p;   // previous scores
+        const bool timing = getenv("FGPU_PR_TIMING") != nullptr;
+        hipEvent_t ev[6];
+        float acc_ms[5] = {0, 0, 0, 0, 0};
+        if (timing) for (auto& e : ev) (void)hipEventCreate(&e);
         for (; it < itermax && rdiff > tol; ++it) {
             float* tmp = tp; tp = rp; rp = tmp;   // t = old r
+            if (timing) (void)hipEventRecord(ev[0], ctx->stream);
             hipLaunchKernelGGL(pr_prep_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const float*)tp,
                                (const float*)d.p, (const unsigned char*)sink.p, (const u64*)act.p, n, w.p, part.p);
             hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)part.p, nb,
                                teleport0, damp_over_n, scal.p);
+            if (timing) (void)hipEventRecord(ev[1], ctx->stream);
             hipLaunchKernelGGL(pr_spmv_kernel, dim3(grid), dim3(256), 0, ctx->stream, vat, (const u64*)act.p, n,
                                (const float*)w.p, (const float*)scal.p, (const float*)tp, rp, part2.p + 1);
+            if (timing) (void)hipEventRecord(ev[2], ctx->stream);
             if (At->n_hub_chunks) {
                 const u32 hg = At->n_hub_chunks < (u32)ctx->cus * 8 ? At->n_hub_chunks : (u32)ctx->cus * 8;
                 hipLaunchKernelGGL(pr_hub_kernel, dim3(hg), dim3(256), 0, ctx->stream, (const u32*)At->hub_chunks,
@@ -314,12 +314,27 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
             } else {
                 FGPU_HIP(hipMemsetAsync(part2.p, 0, sizeof(float), ctx->stream));
             }
+            if (timing) (void)hipEventRecord(ev[3], ctx->stream);
             hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)part2.p, grid + 1,
                                0.0f, 1.0f, scal.p + 1);
+            if (timing) (void)hipEventRecord(ev[4], ctx->stream);
             FGPU_HIP(hipGetLastError());
             FGPU_HIP(hipMemcpyAsync(ctx->pinned, scal.p + 1, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
             FGPU_HIP(hipStreamSynchronize(ctx->stream));
             memcpy(&rdiff, ctx->pinned, sizeof(float));
+            if (timing) {
+                for (int k = 0; k < 4; ++k) {
+                    float ms = 0;
+                    (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+                    acc_ms[k] += ms;
+                }
+            }
+        }
+        if (timing) {
+            fprintf(stderr, "fgpu_pagerank timing over %d iterations (ms): prep+reduce %.3f  spmv %.3f  hubs %.3f  "
+                            "final reduce %.3f  (n_hub_chunks %u)\n", it, acc_ms[0], acc_ms[1], acc_ms[2], acc_ms[3],
+                    At->n_hub_chunks);
+            for (auto& e : ev) (void)hipEventDestroy(e);
         }
         if (iters) *iters = it;
         FGPU_HIP(hipMemcpyAsync(centrality, rp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
