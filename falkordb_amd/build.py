@@ -71,7 +71,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(LIBDIR, "libfalkor_host.so")
-HOST_SOURCES = ["matrix.cpp", "versioned_matrix.cpp", "tensor.cpp", "graph.cpp", "planner.cpp", "capi.cpp"]
+HOST_SOURCES = ["matrix.cpp", "versioned_matrix.cpp", "tensor.cpp", "graph.cpp", "planner.cpp", "serialize.cpp", "capi.cpp"]
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:

@@ -480,6 +480,41 @@ class Graph:
         return (nv, ev) if has.value else None
 
 
+# ---- v19 matrix payload (Encode<19> / Decode<19> for Matrix<T>) ---------------------------------------------
+def container_parse(payload: bytes):
+    """CPU-only: {nrows, ncols, nvals, hyper, valued, consumed, p, h, i, x} of a container payload."""
+    L = load()
+    buf = (C.c_uint8 * len(payload)).from_buffer_copy(payload)
+    dims = (C.c_uint64 * 6)()
+    p, h, i, x = u64p(), u64p(), u64p(), u64p()
+    np_, nh = C.c_uint64(), C.c_uint64()
+    _ck(L.fh_container_parse(buf, C.c_uint64(len(payload)), dims, C.byref(p), C.byref(np_), C.byref(h), C.byref(nh),
+                             C.byref(i), C.byref(x)))
+    nvals, valued = dims[2], bool(dims[4])
+    return {"nrows": dims[0], "ncols": dims[1], "nvals": nvals, "hyper": bool(dims[3]), "valued": valued,
+            "consumed": dims[5], "p": _take(p, np_.value), "h": _take(h, nh.value), "i": _take(i, nvals),
+            "x": _take(x, nvals if valued else 0)}
+
+
+def matrix_decode(ctx, payload: bytes):
+    """Decode<19> for Matrix<T>: payload -> Matrix (arrays go to the device as they are)."""
+    buf = (C.c_uint8 * len(payload)).from_buffer_copy(payload)
+    h = C.c_void_p()
+    used = C.c_uint64()
+    _ck(ctx.L.fh_mat_decode(ctx.h, buf, C.c_uint64(len(payload)), C.byref(h), C.byref(used)))
+    return Matrix(ctx, _h=h), used.value
+
+
+def matrix_encode(m) -> bytes:
+    """Encode<19> for Matrix<T>."""
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_uint64()
+    _ck(m.L.fh_mat_encode(m.h, C.byref(out), C.byref(n)))
+    data = bytes(out[:n.value])
+    m.L.fh_free(C.cast(out, C.c_void_p))
+    return data
+
+
 # ---- planner slice (fuse_anonymous_traverse) -------------------------------------------------------------
 def _node_txt(n):
     return n["alias"] + "".join(":" + l for l in n.get("labels", [])) + ("*" if n.get("attrs") else "")

@@ -426,6 +426,42 @@ int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_
     });
 }
 
+// ---- v19 matrix payload (serialize.cpp) -------------------------------------------------------------------
+// CPU-only parse of a container payload: dims, flags and the index / value arrays it carries
+int fh_container_parse(const uint8_t* bytes, uint64_t len, uint64_t* dims /* nrows, ncols, nvals, hyper, valued, consumed */,
+                       uint64_t** p, uint64_t* np, uint64_t** h, uint64_t* nh, uint64_t** i, uint64_t** x) {
+    return guard([&] {
+        ByteReader r(bytes, len);
+        ContainerData c = parse_container(r);
+        dims[0] = c.nrows; dims[1] = c.ncols; dims[2] = c.nvals; dims[3] = c.hyper ? 1 : 0; dims[4] = c.valued ? 1 : 0;
+        dims[5] = r.pos;
+        *p = hand(c.p); *np = c.p.size();
+        *h = hand(c.h); *nh = c.h.size();
+        *i = hand(c.i);
+        *x = hand(c.x);
+        return 0;
+    });
+}
+int fh_mat_decode(fh_ctx* ctx, const uint8_t* bytes, uint64_t len, fh_mat** out, uint64_t* consumed) {
+    return guard([&] {
+        ByteReader r(bytes, len);
+        *out = new fh_mat{Matrix::decode(ctx->c, r)};
+        if (consumed) *consumed = r.pos;
+        return 0;
+    });
+}
+int fh_mat_encode(fh_mat* m, uint8_t** bytes, uint64_t* len) {
+    return guard([&] {
+        ByteWriter w;
+        m->m.encode(w);
+        uint8_t* out = (uint8_t*)malloc(w.buf.size() ? w.buf.size() : 1);
+        memcpy(out, w.buf.data(), w.buf.size());
+        *bytes = out;
+        *len = w.buf.size();
+        return 0;
+    });
+}
+
 // build_adjacency_matrix / build_symmetric_adjacency_matrix (graph.rs:3870-3907); types = comma list, "" = all
 int fh_graph_build_adjacency(fh_graph* g, const char* types, int symmetric, fh_mat** out) {
     return guard([&] {

@@ -63,6 +63,31 @@ struct Entry {
     bool operator==(const Entry& o) const { return row == o.row && col == o.col && val == o.val; }
 };
 
+// Byte stream primitives of the v19 encoders (the reference's Reader / Writer traits; serialize.cpp)
+struct ByteWriter {
+    std::vector<uint8_t> buf;
+    void write_unsigned(u64 v);
+    void write_signed(int64_t v);
+    void write_buffer(const void* p, size_t n);
+};
+struct ByteReader {
+    const uint8_t* p = nullptr;
+    size_t n = 0, pos = 0;
+    ByteReader(const uint8_t* data, size_t len) : p(data), n(len) {}
+    u64 read_unsigned();
+    int64_t read_signed();
+    std::vector<uint8_t> read_buffer();
+};
+// The content of a GxB_Container as the graph stores matrices: sparse or hypersparse, row-major, iso BOOL or UINT64
+struct ContainerData {
+    u64 nrows = 0, ncols = 0, nvals = 0;
+    int format = 2, orientation = 0;
+    bool iso = false, jumbled = false, hyper = false, valued = false;
+    std::vector<u64> p, h, i, x;   // row pointers (nvec + 1), stored rows (hypersparse), column ids, values
+};
+ContainerData parse_container(ByteReader& r);                 // Decode<19> for Matrix<T>, CPU part (matrix.rs:428-504)
+void write_container(ByteWriter& w, const ContainerData& c);  // Encode<19> for Matrix<T> (matrix.rs:506-546)
+
 // Matrix<T> (graphblas/matrix.rs:360-368): an Arc-shared handle; copies share the underlying matrix,
 // `dup()` deep-copies.  The device holds the materialized state as an immutable fgpu_mat snapshot; writes
 // queue in a host pending log (GraphBLAS pending tuples / zombies) until wait() folds them in with one
@@ -112,6 +137,8 @@ class Matrix {
     u64 intersection_nvals(const Matrix& b) const;       // matrix.rs:743-761
 
     const fgpu_mat* snapshot() const;  // wait()ed device state, valid until the next mutation
+    static Matrix decode(Context& ctx, ByteReader& r);   // Decode<19>  matrix.rs:428-504
+    void encode(ByteWriter& w) const;                    // Encode<19>  matrix.rs:506-546
 
    private:
     struct State;

@@ -131,6 +131,16 @@ int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_r
 int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges,
                 int* has_row, uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges); /* algo_procedures.rs:1021-1160 */
 
+/* The v19 on-disk form of a Matrix<T> (Encode<19> / Decode<19>, matrix.rs:428-546): the 608 bytes of
+ * GxB_Container_struct + its vectors x, h, p, i, b in Vector<bool>'s unload-to-array form (vector.rs:241-309).
+ * Stream framing: unsigned / signed = 8 bytes little-endian, buffer = unsigned length + bytes.
+ * fh_container_parse is CPU-only: dims = {nrows, ncols, nvals, hypersparse, valued, bytes consumed}; p (np entries),
+ * h (nh), i (nvals), x (nvals when valued) are returned as u64 arrays (fh_free). */
+int fh_container_parse(const uint8_t* bytes, uint64_t len, uint64_t* dims, uint64_t** p, uint64_t* np, uint64_t** h,
+                       uint64_t* nh, uint64_t** i, uint64_t** x);
+int fh_mat_decode(fh_ctx* ctx, const uint8_t* bytes, uint64_t len, fh_mat** out, uint64_t* consumed);
+int fh_mat_encode(fh_mat* m, uint8_t** bytes, uint64_t* len);   /* the wait()ed state; free with fh_free */
+
 /* build_adjacency_matrix (graph.rs:3870-3894) or, symmetric != 0, build_symmetric_adjacency_matrix (:3898-3907):
  * types = comma-separated relationship types, "" / NULL = the adjacency of all types */
 int fh_graph_build_adjacency(fh_graph* g, const char* types, int symmetric, fh_mat** out);

@@ -886,3 +886,35 @@ def test_adjacency_builders_match_the_oracle(rnd_graph):    # graph.rs:3870-3907
             ref = og.build_symmetric_adjacency_matrix(types) if sym else og.build_adjacency_matrix(types)
             rr, rc = ref.pairs()
             assert [(r, c) for r, c, _ in got.iter()] == list(zip(rr.tolist(), rc.tolist())), (types, sym)
+
+
+def test_matrix_v19_payload_decode_and_encode(hctx):
+    """Decode<19> / Encode<19> for Matrix<T> (matrix.rs:428-546): container payloads built by hand from the documented
+    layout decode to the right matrices (sparse / hypersparse, 32- and 64-bit indices, iso BOOL and UINT64 values),
+    and what encode() writes parses back to the same arrays and decodes to an equal matrix."""
+    from test_host_cpu import _container
+    for bits in (32, 64):
+        m, used = host.matrix_decode(hctx, _container(5, 7, [0, 2, 2, 3, 3, 6], [1, 4, 0, 2, 3, 6], idx_bits=bits))
+        assert (*m.dims(), m.nvals()) == (5, 7, 6)
+        assert m.iter() == [(0, 1, 1), (0, 4, 1), (2, 0, 1), (4, 2, 1), (4, 3, 1), (4, 6, 1)]
+        big = 3_000_000
+        hm, _ = host.matrix_decode(hctx, _container(big, big, [0, 1, 3], [5, 0, big - 1], x=[11, 22, 2 ** 63 + 5],
+                                                    h=[3, big - 1], idx_bits=bits))
+        assert hm.iter() == [(3, 5, 11), (big - 1, 0, 22), (big - 1, big - 1, 2 ** 63 + 5)]
+        assert hm.get(big - 1, 0) == 22 and hm.get(4, 5) is None
+    rng = np.random.default_rng(12)
+    for typ, n, k in [(host.Matrix.BOOL, 300, 2000), (host.Matrix.UINT64, 300, 2000), (host.Matrix.UINT64, 2_000_000, 500)]:
+        r = rng.integers(0, n, k).astype(np.uint64)
+        c = rng.integers(0, n, k).astype(np.uint64)
+        m = host.Matrix(hctx, typ, n, n)
+        m.build(r, c, rng.integers(1, 1 << 62, k).astype(np.uint64) if typ == host.Matrix.UINT64 else None)
+        payload = host.matrix_encode(m)
+        d = host.container_parse(payload)
+        assert d["consumed"] == len(payload) and d["nvals"] == m.nvals() and d["valued"] == (typ == host.Matrix.UINT64)
+        assert d["hyper"] == (n == 2_000_000)                       # mostly empty rows are written hypersparse
+        back, used = host.matrix_decode(hctx, payload)
+        assert used == len(payload) and back.iter() == m.iter()
+        assert host.matrix_encode(back) == payload                  # canonical: encode(decode(x)) == x
+    e = host.Matrix(hctx, host.Matrix.BOOL, 9, 4)
+    back, _ = host.matrix_decode(hctx, host.matrix_encode(e))
+    assert (*back.dims(), back.nvals()) == (9, 4, 0)

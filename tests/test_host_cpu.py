@@ -237,3 +237,79 @@ def test_fuse_anonymous_traverse_needs_an_only_child_and_keeps_branches():
     assert _canon(got2) == _canon(want2)
     assert sorted(o["id"] for o in got2 if o["kind"] == "CT") == [1, 3]
     assert spec.startswith(b"src=;hop=KNOWS|;hop=KNOWS|;")
+
+
+# ---- v19 matrix payload: GxB_Container_struct bytes + five unload-form vectors (matrix.rs:428-546, vector.rs:241-309)
+def _frame_u(v):
+    import struct
+    return struct.pack("<Q", v)
+
+
+def _frame_buf(b):
+    return _frame_u(len(b)) + bytes(b)
+
+
+def _vec(arr, type_name):
+    """Vector<bool>::encode: buffer(array), buffer(type name + NUL), unsigned(n_entries), unsigned(n_bytes), signed(handling)"""
+    import numpy as np
+    raw = np.ascontiguousarray(arr).tobytes()
+    return _frame_buf(raw) + _frame_buf(type_name.encode() + b"\0") + _frame_u(len(arr)) + _frame_u(len(raw)) + _frame_u(0)
+
+
+def _container(nrows, ncols, p, i, x=None, h=None, idx_bits=64, fmt=None, orientation=0, iso=None, jumbled=False):
+    """The payload an encoder following graphblas/mod.rs:14165-14188 + matrix.rs:506-546 writes, built independently
+    of the library: struct offsets nrows 0, ncols 8, nrows_nonempty 16, ncols_nonempty 24, nvals 32, format 128,
+    orientation 132, iso 448, jumbled 449, size 608."""
+    import struct
+    import numpy as np
+    st = bytearray(608)
+    nvals = int(p[-1]) if len(p) else 0
+    struct.pack_into("<QQqqQ", st, 0, nrows, ncols, -1, -1, nvals)
+    struct.pack_into("<ii", st, 128, fmt if fmt is not None else (1 if h is not None else 2), orientation)
+    st[448] = 1 if (iso if iso is not None else x is None) else 0
+    st[449] = 1 if jumbled else 0
+    it = np.uint32 if idx_bits == 32 else np.uint64
+    tn = "GrB_UINT32" if idx_bits == 32 else "GrB_UINT64"
+    xs = _vec(np.array([1] if nvals else [], dtype=np.uint8), "GrB_BOOL") if x is None else _vec(np.asarray(x, dtype=np.uint64), "GrB_UINT64")
+    hs = _vec(np.asarray(h if h is not None else [], dtype=it), tn)
+    return _frame_buf(st) + xs + hs + _vec(np.asarray(p, dtype=it), tn) + _vec(np.asarray(i, dtype=it), tn) + \
+        _vec(np.array([], dtype=np.int8), "GrB_INT8")
+
+
+@pytest.mark.parametrize("idx_bits", [32, 64])
+def test_container_payload_parse(idx_bits):
+    import numpy as np
+    from falkordb_amd import host
+    # sparse 5 x 7 iso-bool: rows 0: {1,4}, 2: {0}, 4: {2,3,6}
+    d = host.container_parse(_container(5, 7, [0, 2, 2, 3, 3, 6], [1, 4, 0, 2, 3, 6], idx_bits=idx_bits) + b"trailing")
+    assert (d["nrows"], d["ncols"], d["nvals"], d["hyper"], d["valued"]) == (5, 7, 6, False, False)
+    assert d["p"].tolist() == [0, 2, 2, 3, 3, 6] and d["i"].tolist() == [1, 4, 0, 2, 3, 6]
+    assert d["consumed"] == len(_container(5, 7, [0, 2, 2, 3, 3, 6], [1, 4, 0, 2, 3, 6], idx_bits=idx_bits))
+    # hypersparse 10^9 x 10^9 UINT64: stored rows 3 and 999999999
+    big = 10 ** 9
+    d = host.container_parse(_container(big, big, [0, 1, 3], [5, 0, big - 1], x=[11, 22, 2 ** 63 + 5], h=[3, big - 1],
+                                        idx_bits=idx_bits))
+    assert d["hyper"] and d["valued"] and d["h"].tolist() == [3, big - 1]
+    assert d["p"].tolist() == [0, 1, 3] and d["i"].tolist() == [5, 0, big - 1] and d["x"].tolist() == [11, 22, 2 ** 63 + 5]
+    # iso UINT64 (one stored value for every entry) and the empty matrix
+    d = host.container_parse(_container(3, 3, [0, 1, 2, 2], [2, 0], x=[9], iso=True, idx_bits=idx_bits))
+    assert d["x"].tolist() == [9, 9]
+    d = host.container_parse(_container(4, 4, [0, 0, 0, 0, 0], [], idx_bits=idx_bits))
+    assert d["nvals"] == 0 and d["p"].tolist() == [0] * 5
+
+
+@pytest.mark.parametrize("bad,why", [
+    (lambda: _container(5, 7, [0, 2, 2, 3, 3, 6], [1, 4, 0, 2, 3, 6])[:300], "truncated"),
+    (lambda: _container(5, 7, [0, 2, 2, 3, 3, 6], [1, 4, 0, 2, 3, 9]), "column out of range"),
+    (lambda: _container(5, 7, [0, 2, 1, 3, 3, 6], [1, 4, 0, 2, 3, 6]), "pointers decrease"),
+    (lambda: _container(5, 7, [0, 2, 2, 3, 3, 5], [1, 4, 0, 2, 3, 6], fmt=4), "bitmap format"),
+    (lambda: _container(5, 7, [0, 2, 2, 3, 3, 6], [1, 4, 0, 2, 3, 6], orientation=1), "column major"),
+    (lambda: _container(5, 7, [0, 2, 2, 3, 3, 6], [1, 4, 0, 2, 3, 6], jumbled=True), "jumbled"),
+    (lambda: _container(5, 7, [0, 2, 3], [1, 4, 0], h=[4, 2]), "hyper list not ascending"),
+    (lambda: _container(5, 7, [0, 2, 2, 3], [1, 4, 0]), "sparse with nvec != nrows"),
+    (lambda: _frame_buf(b"x" * 100), "struct too small"),
+])
+def test_container_payload_rejects_malformed_input(bad, why):
+    from falkordb_amd import host
+    with pytest.raises(host.HostError):
+        host.container_parse(bad())
