@@ -21,6 +21,11 @@
  *    the same demand, tensor.rs:154-163) and nnz per matrix must be < 2^32;
  *  - outputs returned through `T**` are host buffers owned by the caller until
  *    fgpu_free().
+ *  - threading: a context owns ONE HIP stream, one pinned staging buffer and its scratch pool; calls on the same
+ *    fgpu_ctx must be serialised by the caller (the pool itself is mutex-guarded, the stream and the staging
+ *    buffer are not).  The reference's reader threads map to one context each; snapshots are immutable, so a
+ *    context may read a snapshot another context of the same device created, after that context synchronised
+ *    (fgpu_sync).  SURVEY.md §8b's per-thread stream pool inside one context is not implemented.
  *  - There is NO CPU fallback: without a HIP device fgpu_init fails with
  *    FGPU_DEVICE and nothing else can be called.
  */
