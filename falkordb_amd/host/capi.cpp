@@ -45,6 +45,8 @@ static std::vector<std::string> split(const std::string& s, char sep) {
     return out;
 }
 
+static thread_local uint64_t g_last_op_ns = 0;   // duration of the last timed operator inside this thread (fh_last_op_ns)
+
 static CondTraverseOp parse_spec(const char* spec) {
     CondTraverseOp op;
     for (auto& kv : split(spec ? spec : "", ';')) {
@@ -331,7 +333,6 @@ static Value to_value(int64_t x) {
     return Value{};
 }
 
-static thread_local uint64_t g_last_op_ns = 0;
 uint64_t fh_last_op_ns(void) { return g_last_op_ns; }
 
 int fh_cond_traverse_eligible(const char* spec) { return parse_spec(spec).batched_eligible() ? 1 : 0; }
@@ -415,8 +416,10 @@ int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_r
 int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges, int* has_row,
                 uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges) {
     return guard([&] {
+        const auto t0 = std::chrono::steady_clock::now();
         BfsResult r = algo_bfs(g->g, source >= 0 ? std::optional<u64>((u64)source) : std::nullopt, max_depth,
                                rel_type ? std::optional<std::string>(rel_type) : std::nullopt, want_edges != 0);
+        g_last_op_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         *has_row = r.has_row ? 1 : 0;
         *nodes = hand(r.nodes);
         *n_nodes = r.nodes.size();
@@ -506,8 +509,10 @@ int fh_plan_fuse(const char* plan_text, int lower_id, char** out_text, char** sp
 int fh_algo_pagerank(fh_graph* g, const char* label, const char* rel_type, uint64_t** nodes, double** scores,
                      uint64_t* n) {
     return guard([&] {
+        const auto t0 = std::chrono::steady_clock::now();
         PageRankResult r = algo_pagerank(g->g, label ? std::optional<std::string>(label) : std::nullopt,
                                          rel_type ? std::optional<std::string>(rel_type) : std::nullopt);
+        g_last_op_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         *nodes = hand(r.nodes);
         double* sc = (double*)malloc((r.scores.size() ? r.scores.size() : 1) * sizeof(double));
         if (sc && !r.scores.empty()) memcpy(sc, r.scores.data(), r.scores.size() * sizeof(double));

@@ -441,12 +441,32 @@ BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
     std::vector<std::string> types;
     if (rel_type) types.push_back(*rel_type);
     Matrix adj = g.build_adjacency_matrix(types);                        // graph.rs:3870-3894
-    Matrix adj_t = adj.transpose();
+    const std::string key = rel_type ? *rel_type : std::string();
+    std::shared_ptr<Graph::BfsPlanCache> pc = g.bfs_cache_;
+    if (!pc || pc->key != key || pc->adj.snapshot() != adj.snapshot()) {
+        // a new adjacency (the layers changed, or another type): new plan; a clean committed graph keeps handing
+        // out the same snapshot (VersionedMatrix::extract shares the base) and its cached transpose
+        pc = std::make_shared<Graph::BfsPlanCache>(adj, adj.transpose());
+        pc->key = key;
+        // plans index dense row pointers: a hypersparse adjacency (an unknown type's empty matrix, a tiny delta-only
+        // graph) goes through the one-shot entry point below, which densifies it
+        if (fgpu_bfs_plan_create(g.ctx().raw(), &pc->plan, pc->adj.snapshot(), pc->adj_t.snapshot(), 0, 1) != FGPU_OK) {
+            pc->plan = nullptr;
+            pc.reset();
+        }
+        g.bfs_cache_ = pc;
+    }
     std::vector<int32_t> level(n);
     std::vector<int64_t> parent(want_edges ? n : 0);
-    check(fgpu_bfs(g.ctx().raw(), adj.snapshot(), adj_t.snapshot(), *source, max_depth < 0 ? -1 : max_depth,
-                   level.data(), want_edges ? parent.data() : nullptr, nullptr),
-          "LAGr_BreadthFirstSearch");
+    if (pc) {
+        check(fgpu_bfs_run(pc->plan, *source, max_depth < 0 ? -1 : max_depth, want_edges ? 1 : 0), "LAGr_BreadthFirstSearch");
+        check(fgpu_bfs_fetch(pc->plan, level.data(), want_edges ? parent.data() : nullptr), "LAGr_BreadthFirstSearch");
+    } else {
+        Matrix adj_t = adj.transpose();
+        check(fgpu_bfs(g.ctx().raw(), adj.snapshot(), adj_t.snapshot(), *source, max_depth < 0 ? -1 : max_depth,
+                       level.data(), want_edges ? parent.data() : nullptr, nullptr),
+              "LAGr_BreadthFirstSearch");
+    }
     std::vector<u64> ps, pd;
     for (u64 v = 0; v < n; ++v) {
         if (level[v] < 0 || v == *source || g.is_node_deleted(v)) continue;

@@ -315,7 +315,8 @@ class Graph {
     std::optional<u64> type_id(const std::string& name) const;
     void label_node(u64 node, LabelId l) { labels_.set(node, l, true); }
     void delete_node(u64 node) { deleted_[node] = true; }
-    bool is_node_deleted(u64 node) const { return deleted_.count(node) != 0; }
+    bool is_node_deleted(u64 node) const { return !deleted_.empty() && deleted_.count(node) != 0; }
+    u64 deleted_nodes_count() const { return deleted_.size(); }   // graph.rs deleted_nodes_count
     // create one edge of `type` (adjacency + tensor), the write-side minimum the tests need
     void create_edge(u64 type, u64 src, u64 dst, u64 edge_id);             // graph.rs:1493-1560 (effect only)
     void delete_edge(u64 type, u64 src, u64 dst, u64 edge_id);             // graph.rs:1623-1700 (effect only)
@@ -342,6 +343,18 @@ class Graph {
     std::unordered_map<std::string, LabelId> label_ids_;
     std::unordered_map<std::string, u64> type_ids_;
     std::unordered_map<u64, bool> deleted_;
+
+   public:
+    // algo.BFS keeps its device plan (workspace, pinned control block, acceleration indexes) between calls for as
+    // long as the adjacency it was built on is the same immutable snapshot — creating one costs more than the search
+    struct BfsPlanCache {
+        Matrix adj, adj_t;                 // keep the snapshots (and their cached indexes) alive
+        fgpu_bfs_plan* plan = nullptr;
+        std::string key;                   // relationship types the adjacency was built for
+        BfsPlanCache(Matrix a, Matrix at) : adj(std::move(a)), adj_t(std::move(at)) {}
+        ~BfsPlanCache() { if (plan) fgpu_bfs_plan_free(plan); }
+    };
+    mutable std::shared_ptr<BfsPlanCache> bfs_cache_;
 };
 
 // A bound value of one batch row, reduced to what the traversal operators inspect.

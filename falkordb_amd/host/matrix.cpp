@@ -24,6 +24,11 @@ Context::~Context() {
 namespace {
 struct Snap {  // one immutable device snapshot; shared between a matrix and its dup()s until either mutates
     fgpu_mat* h = nullptr;
+    // the transpose of an immutable snapshot is itself immutable: computed once, shared by every Matrix::transpose()
+    // of every handle on this snapshot (the reference keeps `mt` per tensor for the same reason, tensor.rs:814-816;
+    // algo.BFS / algo.pageRank on a clean committed graph would otherwise pay a 13 ms transpose per call at RMAT-22)
+    std::shared_ptr<Snap> transposed;
+    std::mutex tmu;
     explicit Snap(fgpu_mat* m) : h(m) {}
     ~Snap() { if (h) fgpu_mat_free(h); }
     Snap(const Snap&) = delete;
@@ -237,9 +242,25 @@ Matrix Matrix::dup() const {
 }
 
 Matrix Matrix::transpose() const {
-    fgpu_mat* t = nullptr;
-    check(fgpu_mat_transpose(s_->ctx->raw(), &t, snapshot()), "GrB_transpose");
-    return adopt(*s_->ctx, s_->type, t);
+    snapshot();   // wait()
+    std::shared_ptr<Snap> base = s_->snap;
+    std::shared_ptr<Snap> tr;
+    {
+        std::lock_guard<std::mutex> g(base->tmu);
+        if (!base->transposed) {
+            fgpu_mat* t = nullptr;
+            check(fgpu_mat_transpose(s_->ctx->raw(), &t, base->h), "GrB_transpose");
+            base->transposed = std::make_shared<Snap>(t);
+        }
+        tr = base->transposed;
+    }
+    auto st = std::make_shared<State>();
+    st->ctx = s_->ctx;
+    st->type = s_->type;
+    st->nrows = s_->ncols;
+    st->ncols = s_->nrows;
+    st->snap = tr;        // copy-on-write like dup(): a mutation of the result installs its own snapshot
+    return Matrix(std::move(st));
 }
 
 Matrix Matrix::grown(u64 nrows, u64 ncols) const {

@@ -117,6 +117,10 @@ u64 VersionedMatrix::nvals() const {
 
 Matrix VersionedMatrix::extract() const {
     wait();
+    // clean layers: the effective state IS the base; share its immutable snapshot (copy-on-write) instead of a device
+    // copy — the result is a fresh handle exactly as versioned_matrix.rs:609-620 returns, and a caller that mutates
+    // it (set_pattern in build_relationship_matrix_unrestricted) gets its own snapshot on the first write
+    if (m_.type() == Type::Bool && dp_.layer().nvals() == 0 && dm_.layer().nvals() == 0) return m_.dup();
     fgpu_mat* o = nullptr;
     check(fgpu_mat_merge_pattern(m_.ctx().raw(), &o, m_.snapshot(), dp_.layer().snapshot(), dm_.layer().snapshot(), 0),
           "VersionedMatrix::extract");

@@ -117,7 +117,7 @@ int fh_cond_traverse_batch(fh_graph* g, const char* spec, const int64_t* src, co
                            uint64_t k, int* batched, uint64_t** out_row, uint64_t** out_dest,
                            int64_t** out_edge, uint64_t* n, uint64_t** null_rows, uint64_t* n_null,
                            uint64_t* flops);                                            /* cond_traverse.rs:452-751 */
-/* duration of the C++ CondTraverseOp::expand_batch inside this thread's last fh_cond_traverse_batch call (ns):
+/* duration (ns) of the C++ operator inside this thread's last fh_cond_traverse_batch / fh_algo_bfs / fh_algo_pagerank call:
  * what the operator costs without the ctypes harness' result copies (tools/bench_paths.py host) */
 uint64_t fh_last_op_ns(void);
 int fh_cond_traverse_eligible(const char* spec);                                       /* cond_traverse.rs:308-316 */
