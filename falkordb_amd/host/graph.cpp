@@ -527,7 +527,8 @@ PageRankResult algo_pagerank(const Graph& g, const std::optional<std::string>& l
     std::vector<float> score(n);
     int32_t iters = 0;
     // deleted ids stay in the unfiltered matrix as isolated vertices (n = node_count + deleted_nodes_count, :718-720)
-    check(fgpu_pagerank(g.ctx().raw(), adj.snapshot(), nullptr, filtered ? active.data() : nullptr, 0.85f, 1e-4f, 100,
+    Matrix adj_t = adj.transpose();                                      // LAGraph_Cached_AT (:736-737); cached per snapshot
+    check(fgpu_pagerank(g.ctx().raw(), adj.snapshot(), adj_t.snapshot(), filtered ? active.data() : nullptr, 0.85f, 1e-4f, 100,
                         score.data(), &iters),
           "LAGr_PageRank");
     for (u64 v = 0; v < n; ++v) {
