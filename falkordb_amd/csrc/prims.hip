@@ -141,9 +141,9 @@ __global__ __launch_bounds__(256) void segsort_wave_kernel(u32* __restrict__ dat
                                                           u32 nseg, u32* __restrict__ cnt,
                                                           u32* __restrict__ mid_list, u32* __restrict__ big_list,
                                                           u32* __restrict__ list_counts,
-                                                          const uint8_t* __restrict__ dirty) {
+                                                          const uint8_t* __restrict__ dirty, u32 seg_base) {
     const u32 lane = lane_id();
-    const u32 seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u32 seg = seg_base + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seg >= nseg) return;
     if (dirty && !dirty[seg]) return;  // caller pre-filled cnt[seg]; keys already sorted unique
     const u64 b = off[seg];
@@ -304,9 +304,13 @@ fgpu_info segsort_unique(fgpu_ctx* ctx, u32* data, const u64* off, u32 nseg, u32
     FGPU_TRY(big.alloc(ctx, nseg));
     FGPU_TRY(counts.alloc(ctx, 2));
     FGPU_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(u32), ctx->stream));
-    hipLaunchKernelGGL(segsort_wave_kernel, dim3(cdiv(nseg, 4)), dim3(256), 0, ctx->stream, data, off, nseg, cnt,
-                       mid.p, big.p, counts.p, dirty);
-    FGPU_HIP(hipGetLastError());
+    // a wavefront per segment: 2^26 rows (RMAT-26) would be 2^32 threads in one grid, past what a launch accepts
+    for (u64 base = 0; base < nseg; base += (1ull << 24)) {
+        const u32 part = (u32)((nseg - base < (1ull << 24)) ? nseg - base : (1ull << 24));
+        hipLaunchKernelGGL(segsort_wave_kernel, dim3(cdiv(part, 4)), dim3(256), 0, ctx->stream, data, off, nseg, cnt,
+                           mid.p, big.p, counts.p, dirty, (u32)base);
+        FGPU_HIP(hipGetLastError());
+    }
     // mid segments: grid-stride over the device-side list, no host round trip
     {
         u32 grid = ctx->cus * 8;
