@@ -97,15 +97,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("max_level", [-1, 2])
-def test_two_rank_slab_bfs_matches_single_process_oracle(max_level):
-    scale = 10
+@pytest.mark.parametrize("world,max_level", [(2, -1), (2, 2), (3, -1)])
+def test_multi_rank_slab_bfs_matches_single_process_oracle(world, max_level):
+    # world 3: slabs of unequal use (the last one is mostly padding: slab = ceil(n / 3) rounded up to 4096)
+    scale = 10 if world == 2 else 13
     a = oracle.rmat_csr(scale)
     srcs = [int(np.argmax(np.diff(a.rowptr))), 3]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, scale, srcs, max_level, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scale, srcs, max_level, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=120)
