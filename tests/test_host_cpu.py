@@ -313,3 +313,41 @@ def test_container_payload_rejects_malformed_input(bad, why):
     from falkordb_amd import host
     with pytest.raises(host.HostError):
         host.container_parse(bad())
+
+
+def test_container_payload_parse_random_matrices():
+    """Property test (hypothesis): any sorted-unique CSR, sparse or hypersparse, 32- or 64-bit indices, iso BOOL or
+    UINT64 values, survives build-by-hand -> parse unchanged, and the parser consumes exactly the payload."""
+    import numpy as np
+    from hypothesis import given, settings, strategies as st
+    from falkordb_amd import host
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 40), st.integers(1, 40), st.integers(0, 2 ** 32 - 1), st.booleans(), st.booleans(),
+           st.sampled_from([32, 64]))
+    def check(nrows, ncols, seed, hyper, valued, bits):
+        rng = np.random.default_rng(seed)
+        dense = rng.random((nrows, ncols)) < 0.15
+        if hyper:
+            dense[rng.random(nrows) < 0.6] = False              # most rows empty
+        rows, cols = np.nonzero(dense)
+        counts = np.bincount(rows, minlength=nrows)
+        if hyper:
+            stored = np.nonzero(counts)[0]
+            p = np.concatenate([[0], np.cumsum(counts[stored])])
+            h = stored
+        else:
+            p = np.concatenate([[0], np.cumsum(counts)])
+            h = None
+        x = rng.integers(0, 2 ** 63, len(cols)) if valued else None
+        payload = _container(nrows, ncols, p, cols, x=x, h=h, idx_bits=bits)
+        d = host.container_parse(payload + b"\\x00\\x01")
+        assert d["consumed"] == len(payload)
+        assert (d["nrows"], d["ncols"], d["nvals"], d["hyper"], d["valued"]) == (nrows, ncols, len(cols), hyper, valued)
+        assert d["p"].tolist() == p.tolist() and d["i"].tolist() == cols.tolist()
+        if hyper:
+            assert d["h"].tolist() == h.tolist()
+        if valued:
+            assert d["x"].tolist() == x.tolist()
+
+    check()
