@@ -351,3 +351,67 @@ def test_container_payload_parse_random_matrices():
             assert d["x"].tolist() == x.tolist()
 
     check()
+
+
+def test_fuse_anonymous_traverse_random_plans_match_the_oracle():
+    """Property test (hypothesis): random linear plans — chains of CondTraverse hops with random flags, labels,
+    aliases, interleaved Filter nodes — give the same plan from the C++ mirror and the Python restatement, the pass
+    is idempotent, and every hop of the input survives in order in exactly one operator."""
+    from hypothesis import given, settings, strategies as st
+    from falkordb_amd import host
+    from oracle import model
+
+    hop = st.fixed_dictionaries({
+        "named_edge": st.booleans(), "emit": st.booleans(), "transposed": st.sampled_from([False, False, False, True]),
+        "optional": st.sampled_from([False, False, False, True]), "bidir": st.sampled_from([False, False, True]),
+        "var_len": st.sampled_from([False, False, False, True]), "attrs": st.sampled_from([False, False, True]),
+        "mid_named": st.sampled_from([False, False, True]), "mid_label": st.sampled_from([False, False, True]),
+        "filter_above": st.sampled_from([None, None, None, "mid", "other"]), "bind": st.sampled_from([True, True, False]),
+    })
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(hop, min_size=1, max_size=6))
+    def check(hops):
+        k = len(hops)
+        # node aliases: n0 = a ... nk = end; intermediates anonymous unless mid_named
+        nodes = []
+        for i in range(k + 1):
+            inner = 0 < i < k
+            named = (not inner) or hops[i]["mid_named"]
+            nodes.append({"alias": (f"n{i}" if named else f"_anon_n{i}"),
+                          "labels": (["L"] if (inner and hops[i]["mid_label"]) else []), "attrs": False})
+        ops, nid = [{"id": 0, "parent": -1, "kind": "X", "name": "Project", "refs": [nodes[k]["alias"]]}], 1
+        parent = 0
+        for i in range(k - 1, -1, -1):                  # the last hop sits highest in the plan
+            h = hops[i]
+            if h["filter_above"]:
+                ref = nodes[i + 1]["alias"] if h["filter_above"] == "mid" else "zzz"
+                ops.append({"id": nid, "parent": parent, "kind": "X", "name": "Filter", "refs": [ref]})
+                parent, nid = nid, nid + 1
+            rel = {"alias": (f"e{i}" if h["named_edge"] else f"_anon_e{i}"), "from": dict(nodes[i]), "to": dict(nodes[i + 1]),
+                   "types": ["T"], "bidirectional": h["bidir"], "var_len": h["var_len"], "attrs": h["attrs"]}
+            ops.append({"id": nid, "parent": parent, "kind": "CT", "rel": rel, "emit": h["emit"], "transposed": h["transposed"],
+                        "optional": h["optional"], "bind": h["bind"], "siblings": [], "chain": []})
+            parent, nid = nid, nid + 1
+        ops.append({"id": nid, "parent": parent, "kind": "X", "name": "AllNodeScan", "refs": []})
+        got, _ = host.plan_fuse(ops)
+        want = model.fuse_anonymous_traverse(ops)
+        assert _canon(got) == _canon(want)
+        again, _ = host.plan_fuse(got)
+        assert _canon(again) == _canon(got)                                   # idempotent
+        # every input hop appears exactly once, in traversal order, across the surviving operators (leaf to root)
+        by_id = {o["id"]: o for o in got}
+        order, cur = [], [o for o in got if o["parent"] == -1][0]["id"]
+        kids = {o["id"]: [c["id"] for c in got if c["parent"] == o["id"]] for o in got}
+        chain_top_down = []
+        while True:
+            o = by_id[cur]
+            if o["kind"] == "CT":
+                chain_top_down.append([o["rel"]["alias"]] + [r["alias"] for r in o["chain"]])
+            if not kids[cur]:
+                break
+            cur = kids[cur][0]
+        flat = [a for grp in reversed(chain_top_down) for a in grp]
+        assert flat == [(f"e{i}" if hops[i]["named_edge"] else f"_anon_e{i}") for i in range(k)]
+
+    check()
