@@ -193,6 +193,13 @@ Plan parse_plan(const std::string& text) {
         tmp[id] = op;
         ids.push_back(id);
     }
+    // ids need not be dense (a plan printed after a fusion has lost the pruned children): the gaps are not nodes
+    {
+        std::vector<bool> listed(tmp.size(), false);
+        for (int id : ids) listed[id] = true;
+        for (size_t k = 0; k < tmp.size(); ++k)
+            if (!listed[k]) tmp[k].kind = PlanOp::Pruned;
+    }
     plan.ops = tmp;
     plan.root = -1;
     for (int id : ids) {
