@@ -305,3 +305,40 @@ def test_merge_clean_word_path_with_sparse_deltas(ctx, hyper):
     from_m = ~np.isin(rr * np.uint64(n) + rc, pr * np.uint64(n) + pc)
     np.testing.assert_array_equal(v2[from_m], (rr * np.uint64(1_000_003) + rc)[from_m])
     assert (v2[~from_m] == 1).all()                                   # BOOL dp entries carry the iso value 1
+
+
+def test_merge_random_configurations(ctx):
+    """Seeded fuzz of the entry-parallel merge (clean-word and per-entry paths interleaved): 40 random shapes — row
+    distributions from dense to mostly empty, deltas from none to heavy, dp landing in empty rows, dm hitting rows
+    that span several 64-entry words — each against the oracle, both masking modes."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n = int(rng.choice([70, 500, 3000, 20000]))
+        fill = float(rng.choice([0.02, 0.2, 0.9]))
+        live = np.nonzero(rng.random(n) < fill)[0]
+        if len(live) == 0:
+            live = np.array([0])
+        deg = rng.integers(1, int(rng.choice([3, 12, 200])) + 1, len(live))
+        rows = np.repeat(live, deg).astype(np.uint64)
+        cols = rng.integers(0, n, len(rows)).astype(np.uint64)
+        m = oracle.build_csr(n, n, rows, cols)
+        mr, mc = m.pairs()
+        n_dp = int(rng.choice([0, 1, 30, 2000]))
+        n_dm = int(rng.choice([0, 1, 30, 2000]))
+        pr = rng.integers(0, n, n_dp).astype(np.uint64)
+        pc = rng.integers(0, n, n_dp).astype(np.uint64)
+        kill = rng.choice(m.nnz, min(n_dm, m.nnz), replace=False) if m.nnz else np.array([], dtype=np.int64)
+        dr = np.concatenate([mr[kill], pr[: n_dp // 3]])      # some tombstones also shadow pending adds
+        dc = np.concatenate([mc[kill], pc[: n_dp // 3]])
+        dp = oracle.build_csr(n, n, pr, pc) if n_dp else None
+        dm = oracle.build_csr(n, n, dr, dc) if len(dr) else None
+        M = ctx.mat_from_csr(n, n, m.rowptr, m.colidx)
+        DP = ctx.mat_from_coo(n, n, pr, pc) if n_dp else None
+        DM = ctx.mat_from_coo(n, n, dr, dc) if len(dr) else None
+        for masks_dp in (False, True):
+            got = M.merge(DP, DM, dm_masks_dp=masks_dp)
+            ref = oracle.merge(m, dp, dm, masks_dp)
+            rp, ci, _ = got.export_csr()
+            assert got.nvals == ref.nnz, (case, masks_dp)
+            np.testing.assert_array_equal(rp, ref.rowptr, err_msg=f"case {case} masks_dp {masks_dp}")
+            np.testing.assert_array_equal(ci, ref.colidx, err_msg=f"case {case} masks_dp {masks_dp}")
