@@ -12,8 +12,12 @@ scale = 22 + log2(N), i.e. the per-GPU edge count stays that of RMAT-22 (overrid
 Rank 0 prints ONE JSON line; `value` = total traversed edges (sum over BFS runs of the
 out-degrees of reached vertices) / max-over-ranks wall time of the K steps.
 Extra objects: `roofline` (dominant kernel, HIP-event timed in a second pass over the same
-roots), `spmv_full_pass` (the north-star "RMAT-22 boolean SpMV" full-matrix pass) and
-`cpu_baseline` (the CPU oracle's BFS timed on this box's host cores, bounded sample).
+roots), `spmv_full_pass` (the north-star "RMAT-22 boolean SpMV" full-matrix pass), `khop_match`
+(BASELINE config 3: RMAT-24 3-hop MATCH as a masked GrB_mxm chain — CondTraverseOp::expand_batch's
+device core, cond_traverse.rs:452-751 / matrix.rs:1317-1402 — clean and dirty layers, with its own
+roofline object and CPU baseline) and `cpu_baseline` (the CPU oracle's BFS timed on this box's host
+cores, bounded sample).  `traffic` figures are HBM bytes per launch from rocprofv3 --pmc passes that
+bench.py runs over a reduced replay of the same workload (`--pmc-child`) at the end of the run.
 """
 from __future__ import annotations
 
@@ -33,19 +37,103 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def pmc_traffic(kernel, scale):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/traffic.json, written by tools/prof_bench.sh + tools/pmc_summary.py: FETCH_SIZE x2 on
-    gfx950 + WRITE_SIZE, MI355X_MICROARCH.md §HBM).  PMC needs rocprofv3 around the process, so it is not
-    collected live; null when no profile of this workload is committed."""
+def committed_traffic(kernel, scale):
+    """Fallback when the live PMC passes cannot run: HBM bytes per launch from the committed rocprofv3 --pmc passes
+    of this same command (profiles/traffic.json, tools/prof_bench.sh) — only if that file was taken from the
+    kernel sources as they are now (it records their hash)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
+        if t.get("_csrc_sha256") != csrc_hash():
+            return None
         e = t.get(f"rmat{scale}", {}).get(kernel)
         return int(e["hbm_bytes_per_dispatch"]) if e else None
     except (OSError, ValueError, KeyError):
         return None
+
+
+def csrc_hash():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "falkordb_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()
+
+
+PMC_GROUPS = (  # (reported name, regex over rocprofv3's Kernel_Name)
+    ("bfs_fused_kernel (push level)", r"bfs_fused_kernel<(true|false), 1>"),
+    ("bfs_fused_kernel (pull level)", r"bfs_fused_kernel<(true|false), 2>"),
+    ("bfs_fused_kernel (blind loop)", r"bfs_fused_kernel<(true|false), 0>"),
+    ("tiled_mxv_kernel", r"tiled_mxv_kernel"),
+    ("bp_pull_kernel<dense>", r"bp_pull_kernel<\d+, false>"),
+    ("bp_pull_kernel<sparse>", r"bp_pull_kernel<\d+, true>"),
+    ("bp_count_kernel<checksum>", r"bp_count_kernel<true>"),
+    ("bp_count_kernel<count>", r"bp_count_kernel<false>"),
+    ("bp_delta_kernel<dm>", r"bp_delta_kernel<true>"),
+    ("bp_delta_kernel<dp>", r"bp_delta_kernel<false>"),
+)
+
+
+def live_pmc(args, timeout_s=420):
+    """HBM bytes per launch of the hot kernels, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass: TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots") over
+    `bench.py --pmc-child`, a reduced replay of this run's workloads (same graphs, same kernels, a few steps).
+    FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 64 B per 128 B request of a wide stream, so the read
+    side is doubled (MI355X_MICROARCH.md §HBM).  Returns {name: {...}} or {"error": ...}."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    out = tempfile.mkdtemp(prefix="fgpu_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--scale", str(args.scale or 22),
+             "--khop-scale", str(args.khop_scale)]
+    raw = {}
+    t0 = time.time()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr)
+            r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True,
+                               timeout=max(30, timeout_s - (time.time() - t0)))
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {ctr} exited {r.returncode}: {r.stderr[-300:]}"}
+            acc = collections.defaultdict(lambda: [0.0, 0])
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    for name, rx in PMC_GROUPS:
+                        if re.search(rx, row["Kernel_Name"]):
+                            acc[name][0] += float(row["Counter_Value"])
+                            acc[name][1] += 1
+                            break
+            for name, (tot, n) in acc.items():
+                raw.setdefault(name, {})[ctr] = (tot / n * 1024.0, n)
+    except subprocess.TimeoutExpired:
+        return {"error": f"rocprofv3 passes exceeded {timeout_s} s"}
+    except OSError as e:
+        return {"error": str(e)}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    res = {}
+    for name, d in raw.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            f, nf = d["FETCH_SIZE"]
+            w, _ = d["WRITE_SIZE"]
+            res[name] = {"fetch_bytes_raw": int(f), "fetch_bytes_x2": int(2 * f), "write_bytes": int(w),
+                         "hbm_bytes_per_dispatch": int(2 * f + w), "dispatches": nf}
+    res["_seconds"] = round(time.time() - t0, 1)
+    return res
 
 
 def _cgroup_cpus():
@@ -76,6 +164,181 @@ def pick_roots(A, want=64):
     return [int(r) for r in roots]
 
 
+def mix64_np(z):
+    z = np.asarray(z, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def p_label_sources(n):
+    """The synthetic label :P of SURVEY.md §8d: ids with hash(id) % 16 == 0 (hash = splitmix64 finaliser), ascending."""
+    ids = np.arange(n, dtype=np.uint64)
+    return ids[mix64_np(ids) % np.uint64(16) == 0]
+
+
+def khop_inputs(ctx, scale, edge_factor):
+    """RMAT-<scale> adjacency + one dirty layer pair: dm = a uniformly random 0.1 % of the stored entries
+    (fgpu_mat_sample), dp = as many uniformly random coordinates outside the matrix (the Delta invariants
+    dm ⊆ m, dp ∩ m = ∅, versioned_matrix.rs:214-235)."""
+    A = ctx.mat_rmat(scale, edge_factor, 0x5EED1234 + scale)
+    n = A.nrows
+    dm = A.sample(0xD3170 + scale, 1000)
+    rng = np.random.default_rng(0xADD5 + scale)
+    k = max(1, A.nvals // 1000)
+    raw = ctx.mat_from_coo(n, n, rng.integers(0, n, k, dtype=np.uint64), rng.integers(0, n, k, dtype=np.uint64))
+    dp = raw.merge(None, A)
+    raw.free()
+    return A, dp, dm
+
+
+def khop_alg_bytes(rows, hop_nnz, flops, mask_nnz=0):
+    """SURVEY.md §8d, one ANY_PAIR SpGEMM hop C<¬M> = F·A: 4(r+1) + 4 nnz(F) (read F) + 8 nnz(F) (A row-pointer
+    pairs) + 4 flops (A column ids gathered) + 4 nnz(M) + 4(r+1) + 4 nnz(C) (write C); the chain is the sum."""
+    f_nnz = [rows] + list(hop_nnz[:-1])
+    return sum(8 * (rows + 1) + 12 * f + 4 * c for f, c in zip(f_nnz, hop_nnz)) + 4 * flops + 4 * mask_nnz
+
+
+def khop_leg(ctx, engine, args):
+    """BASELINE config 3: RMAT-24 3-hop MATCH (a:P)-->()-->()-->(c) as a masked GrB_mxm chain = the device core of
+    CondTraverseOp::expand_batch (cond_traverse.rs:452-751: F = build(sources); F = delta_lmxm(F; hop) per hop,
+    matrix.rs:1317-1402), batches of 1024 :P sources, result = count + order-independent checksum on the device
+    (the full (row, dest) stream of 1.5 G entries per batch does not fit a host buffer).  t = wall time of the
+    fgpu_expand_count calls, H2D of the sources and D2H of the results included; matrices resident."""
+    scale, hops, B = args.khop_scale, 3, 1024
+    t0 = time.time()
+    A, dp, dm = khop_inputs(ctx, scale, args.edge_factor)
+    ctx.sync()
+    t_build = time.time() - t0
+    n, nnz = A.nrows, A.nvals
+    srcs = p_label_sources(n)
+    nb_all = len(srcs) // B
+    nb = nb_all if args.khop_batches <= 0 else min(args.khop_batches, nb_all)
+    batches = [srcs[i * B:(i + 1) * B] for i in range(nb)]
+    out = {"workload": f"RMAT scale-{scale} {hops}-hop MATCH (a:P)-->()-->()-->(c): CondTraverse expand_batch core "
+                       f"(masked GrB_mxm ANY_PAIR chain), sources = label :P (hash(id) % 16 == 0), batches of {B}",
+           "scale": scale, "vertices": int(n), "edges": int(nnz), "hops": hops, "batch_rows": B,
+           "label_P_sources": int(len(srcs)), "batches_timed": nb,
+           "sample": (f"the first {nb} of {nb_all} batches of the :P set in ascending id order" if nb < nb_all
+                      else "the whole :P set"),
+           "result": "count + checksum on device (fgpu_expand_count)", "build_seconds": round(t_build, 2),
+           "nnz_dp": int(dp.nvals), "nnz_dm": int(dm.nvals)}
+    prof_tables = {}
+    for name, layers in (("clean", ([A] * hops, None, None)), ("dirty", ([A] * hops, [dp] * hops, [dm] * hops))):
+        for b in batches[:2]:                                   # warm-up: transpose cache, item lists, pools
+            engine.expand_count(ctx, b, *layers)
+        ctx.sync()
+        t1 = time.perf_counter()
+        tot_f = tot_n = 0
+        cs = 0
+        for b in batches:
+            nn, c, f = engine.expand_count(ctx, b, *layers)
+            tot_n += nn
+            tot_f += f
+            cs = (cs + c) & 0xFFFFFFFFFFFFFFFF
+        dt = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        for b in batches:
+            engine.expand_count(ctx, b, *layers, want_checksum=False)
+        dt_count = time.perf_counter() - t1
+        # kernel table: the same calls again with HIP events around every modelled launch
+        ctx.prof_enable(True)
+        t1 = time.perf_counter()
+        for b in batches:
+            engine.expand_count(ctx, b, *layers)
+        dt_prof = time.perf_counter() - t1
+        prof = ctx.prof_read()
+        ctx.prof_enable(False)
+        prof_tables[name] = prof
+        # per-hop result sizes (untimed) for the §8d byte count
+        alg = 0
+        hop_tot = [0] * hops
+        for b in batches:
+            lv = engine.expand_levels(ctx, b, *layers)
+            hn = [int(x) for x in lv["hop_nnz"]]
+            alg += khop_alg_bytes(B, hn, int(lv["flops"]))
+            hop_tot = [a_ + b_ for a_, b_ in zip(hop_tot, hn)]
+        out[name] = {"ms_per_batch": round(dt / nb * 1e3, 3), "TEPS": round(tot_f / dt, 1),
+                     "flops": int(tot_f), "out_nnz": int(tot_n), "checksum": f"{cs:016x}",
+                     "hop_nnz_per_batch": [h // nb for h in hop_tot],
+                     "alg_bytes": int(alg), "GBps": round(alg / dt / 1e9, 1), "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+                     "count_only": {"ms_per_batch": round(dt_count / nb * 1e3, 3), "TEPS": round(tot_f / dt_count, 1)},
+                     "ms_per_batch_with_kernel_events": round(dt_prof / nb * 1e3, 3)}
+    out["note"] = ("alg_bytes follows SURVEY.md §8d's SpGEMM row (4 B per traversed edge + F / C / row-pointer terms); "
+                   "dense hops run in bit form (one pass over A' per hop whatever the traversed-edge count), so the "
+                   "chain moves fewer bytes than that formula charges — the kernel-level roofline is `roofline` below")
+    # dominant kernel of the clean run, with the dirty run's table beside it
+    kern = sorted(prof_tables["clean"], key=lambda k: -k["ms"])
+    out["kernels"] = {name: [{"kernel": k["kernel"], "ms_total": round(k["ms"], 3), "launches": k["launches"],
+                              "avg_launch_us": round(k["ms"] / max(k["launches"], 1) * 1e3, 2),
+                              "alg_bytes_per_launch": int(k["alg_bytes"] / max(k["launches"], 1)),
+                              "GBps": round(k["alg_bytes"] / max(k["ms"], 1e-9) / 1e6, 1)}
+                             for k in sorted(tab, key=lambda k: -k["ms"])[:10]] for name, tab in prof_tables.items()}
+    if kern:
+        d = kern[0]
+        ach = d["alg_bytes"] / max(d["ms"], 1e-9) / 1e6
+        out["roofline"] = {"bound": "hbm", "kernel": d["kernel"], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "alg_bytes_per_launch": int(d["alg_bytes"] / d["launches"]),
+                           "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches": d["launches"],
+                           "share_of_kernel_time": round(d["ms"] / max(sum(k["ms"] for k in kern), 1e-9), 3),
+                           "timing": "HIP events around each launch (fgpu_prof_*), clean layers, the timed batches replayed"}
+    return out, (A, dp, dm, batches)
+
+
+def khop_cpu_baseline(engine, ctx, A, batch, threads, seconds):
+    """The oracle's row-parallel Gustavson chain (oracle/oracle_omp.c orc_mxm_omp — the algorithm family of
+    SuiteSparse's saxpy3) on the first sources of the first batch, same graph, clean layers."""
+    import oracle
+    rp, ci, _ = A.export_csr()
+    a = oracle.CSR(A.nrows, A.ncols, rp, ci)
+    k, done, t_cpu, fl_cpu, nnz_cpu = 4, 0, 0.0, 0, 0
+    while done < len(batch) and t_cpu < seconds:
+        src = batch[done:done + k]
+        t1 = time.perf_counter()
+        c, fl, _ = oracle.expand_omp(src, [(a, None, None)] * 3, threads=threads)
+        t_cpu += time.perf_counter() - t1
+        fl_cpu += fl
+        nnz_cpu += c.nnz
+        done += len(src)
+        k = min(2 * k, 64)
+    return {"value": round(fl_cpu / t_cpu, 1), "unit": "TEPS", "cores": threads, "kind": "port",
+            "sample": f"{done} of the first batch's 1024 :P sources, 3 hops, clean layers, {t_cpu:.1f} s, row-parallel "
+                      f"Gustavson ANY_PAIR products (oracle/oracle_omp.c orc_mxm_omp) on {threads} threads; CPU stand-in "
+                      f"for SuiteSparse:GraphBLAS GrB_mxm, which is absent from this image",
+            "flops": int(fl_cpu), "out_nnz": int(nnz_cpu)}
+
+
+def pmc_child(args):
+    """Reduced replay of the bench workloads for the rocprofv3 --pmc passes (live_pmc): no timing, no JSON line."""
+    from falkordb_amd import engine
+    ctx = engine.Context(0)
+    scale = args.scale or 22
+    A = ctx.mat_rmat(scale, args.edge_factor, 0x5EED1234 + scale)
+    At = A.transpose()
+    roots = pick_roots(A, 8)
+    plan = engine.BfsPlan(ctx, A, At)
+    plan.run(roots[0], -1, False)
+    ctx.set_option("bfs_prof_split", 1)          # name push / pull launches for the profiler
+    plan.profile(True)
+    for r in roots:
+        plan.run(r, -1, False)
+    plan.profile(False)
+    At.build_tiles()
+    engine.bench_spmv(ctx, At, which=2, iters=4)
+    plan.free(); At.free(); A.free()
+    if not args.no_khop:
+        K, dp, dm = khop_inputs(ctx, args.khop_scale, args.edge_factor)
+        srcs = p_label_sources(K.nrows)
+        for i in range(3):
+            b = srcs[i * 1024:(i + 1) * 1024]
+            engine.expand_count(ctx, b, [K] * 3)
+            if i:
+                engine.expand_count(ctx, b, [K] * 3, [dp] * 3, [dm] * 3)
+    ctx.sync()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +353,14 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (fgpu_set_option)")
+    ap.add_argument("--no-khop", action="store_true", help="skip the k-hop MATCH leg (BASELINE config 3)")
+    ap.add_argument("--khop-scale", type=int, default=24)
+    ap.add_argument("--khop-batches", type=int, default=32, help="1024-source batches of the :P set to time (0 = all)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (traffic = committed / null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -221,31 +491,32 @@ def main():
         plan.profile(False)
         steps = [p for p in prof if p["launches"]]
         if steps:
-            # The dominant kernel of the workload is bfs_fused_kernel: ONE kernel runs every level (the
-            # <.., 1> / <.., 2> instantiations of the profiled pass only name a launch push / pull for the
-            # profilers).  `roofline` is that kernel over all its level launches; the split by direction
-            # (push levels are latency / atomic bound, pull levels stream column ids) is in `by_direction`.
+            # The dominant kernel of the workload is bfs_fused_kernel: ONE kernel runs every level, and this pass
+            # launches the same instantiation (<.., 0>) as the timed blind level loop, one level at a time with
+            # the direction read back from the control block.  `roofline` is that kernel over all its level
+            # launches; the split by direction (push levels are latency / atomic bound, pull levels stream
+            # column ids) is in `by_direction`.  `traffic` is filled in by the live PMC passes at the end.
             launches = sum(p["launches"] for p in steps)
             tot_ms = sum(p["ms"] for p in steps)
             tot_bytes = sum(p["alg_bytes"] for p in steps)
             per_launch_bytes = tot_bytes / launches
             per_launch_ms = tot_ms / launches
             ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-            tr = [(pmc_traffic(p["kernel"].split(" (")[0], scale), p["launches"]) for p in steps]
-            traffic = (int(sum(t * n for t, n in tr) / launches) if all(t is not None for t, _ in tr) else None)
+            for p in steps:
+                p["kernel"] = "bfs_fused_kernel " + p["kernel"].split(" ", 2)[-1]    # "(push level)" / "(pull level)"
             roofline = {"bound": "hbm", "kernel": "bfs_fused_kernel (every BFS level: push and pull launches)",
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": traffic,
+                        "traffic": None,
                         "alg_bytes_per_launch": int(per_launch_bytes), "avg_launch_us": round(per_launch_ms * 1e3, 2),
                         "launches": int(launches),
-                        "timing": "HIP events on the ctx stream around each launch of the profiled pass "
-                                  "(same roots as the timed region)",
+                        "timing": "HIP events on the ctx stream around each level launch of a second, level-synchronous "
+                                  "pass over the same roots (same kernel instantiation as the timed blind loop)",
                         "by_direction": [{"kernel": p["kernel"], "ms_total": round(p["ms"], 4),
                                           "launches": int(p["launches"]),
                                           "avg_launch_us": round(p["ms"] / p["launches"] * 1e3, 2),
                                           "alg_bytes_per_launch": int(p["alg_bytes"] / p["launches"]),
-                                          "traffic": pmc_traffic(p["kernel"].split(" (")[0], scale),
+                                          "traffic": None,
                                           "GBps": round(p["alg_bytes"] / max(p["ms"], 1e-9) / 1e6, 2),
                                           "frac": round(p["alg_bytes"] / max(p["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
                                          for p in steps],
@@ -259,7 +530,7 @@ def main():
         ms0, _ = engine.bench_spmv(ctx, At, which=0, iters=10)
         spmv = {"kernel": "tiled_mxv_kernel", "avg_launch_us": round(ms * 1e3, 2), "alg_bytes": int(ab),
                 "achieved": round(g, 2), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(g / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic("tiled_mxv_kernel", scale),
+                "traffic": None,
                 "layout": {k: tinfo[k] for k in ("tile_bits", "tiles", "items", "entries", "vec", "k", "bytes")},
                 "csr_pull_us": round(ms0 * 1e3, 2), "csr_pull_GBps": round(ab / (ms0 * 1e-3) / 1e9, 2)}
 
@@ -323,6 +594,44 @@ def main():
                "serial": {"value": round(e_ser / t_ser, 1), "cores": 1,
                           "sample": f"{ks} roots, {t_ser:.1f} s, serial queue BFS (oracle/oracle.c orc_bfs)"}}
 
+    # ---- BASELINE config 3: k-hop MATCH leg (own graph, own roofline, own CPU baseline) ------------------
+    khop = None
+    if not args.no_khop and not use_dist and rank == 0:
+        khop, (KA, Kdp, Kdm, kbatches) = khop_leg(ctx, engine, args)
+        if not args.no_cpu_baseline:
+            khop["cpu_baseline"] = khop_cpu_baseline(engine, ctx, KA, kbatches[0], cpu["cores"] if cpu else 1,
+                                                     args.cpu_seconds * 0.6)
+        Kdp.free(); Kdm.free(); KA.free()
+
+    # ---- HBM traffic per launch, measured now: rocprofv3 --pmc passes over a reduced replay -------------
+    pmc = None
+    if not args.no_pmc and not args.no_roofline and not use_dist and rank == 0:
+        pmc = live_pmc(args)
+
+        def hbm(name):
+            e = pmc.get(name) if isinstance(pmc, dict) else None
+            return e["hbm_bytes_per_dispatch"] if e else None
+        src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py over `--pmc-child` (reduced replay, "
+               "same graphs and kernels); FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes per launch")
+        if "error" in pmc:
+            src = f"live PMC passes failed ({pmc['error']}); committed profiles/traffic.json used where its source hash matches"
+        if roofline:
+            tot, cnt = 0, 0
+            for d in roofline["by_direction"]:                     # per direction, then weighted by this run's launches
+                d["traffic"] = hbm(d["kernel"])
+                if d["traffic"] is not None:
+                    tot += d["traffic"] * d["launches"]
+                    cnt += d["launches"]
+            roofline["traffic"] = int(tot / cnt) if cnt == roofline["launches"] and cnt else \
+                committed_traffic("bfs_fused_kernel", scale)
+            roofline["traffic_source"] = src
+        if spmv:
+            spmv["traffic"] = hbm("tiled_mxv_kernel") or committed_traffic("tiled_mxv_kernel", scale)
+        if khop and khop.get("roofline"):
+            khop["roofline"]["traffic"] = hbm(khop["roofline"]["kernel"])
+            khop["roofline"]["traffic_source"] = src
+            khop["pmc"] = {k: v for k, v in pmc.items() if k.startswith("bp_")} if "error" not in pmc else pmc
+
     if rank == 0:
         st0 = stats_by_root[roots[0]]
         out = {
@@ -350,7 +659,9 @@ def main():
             },
             "roofline": roofline,
             "spmv_full_pass": spmv,
+            "khop_match": khop,
             "cpu_baseline": cpu,
+            "pmc": ({k: v for k, v in pmc.items() if not k.startswith("bp_")} if pmc else None),
         }
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -93,6 +93,10 @@ SIGNATURES = {
     "fgpu_mat_col_slab": (C.c_int32, [vp, vpp, vp, C.c_uint64, C.c_uint64]),
     "fgpu_mat_row_slab": (C.c_int32, [vp, vpp, vp, C.c_uint64, C.c_uint64]),
     "fgpu_bench_spmv": (C.c_int32, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), u64p]),
+    "fgpu_prof_enable": (C.c_int32, [vp, C.c_int]),
+    "fgpu_prof_read": (C.c_int32, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p, u64p, C.c_int,
+                                   C.POINTER(C.c_int)]),
+    "fgpu_mat_sample": (C.c_int32, [vp, vpp, vp, C.c_uint64, C.c_uint32]),
     "fgpu_bfs_plan_profile": (C.c_int32, [vp, C.c_int]),
     "fgpu_bfs_plan_profile_read": (C.c_int32, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p, u64p,
                                                C.c_int, C.POINTER(C.c_int)]),

@@ -53,31 +53,35 @@ __global__ void bp_item_fill_kernel(const u32* __restrict__ rowptr, u32 nrows, c
 // pattern transpose of `m`, built once per snapshot and owned by it (the reference keeps the same
 // thing per relationship type: Tensor::matrix_t, tensor.rs:886-888)
 static fgpu_info transposed_with_items(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat** out) {
-    fgpu_mat* mm = const_cast<fgpu_mat*>(m);
-    if (!mm->tcache) {
+    std::lock_guard<std::mutex> idx_guard(m->idx_mu);   // one builder; the build is synchronised before it is published
+    if (!m->tcache) {
         fgpu_mat* t = nullptr;
         FGPU_TRY(mat_transpose_pattern(ctx, &t, m));
-        mm->tcache = t;
+        FGPU_HIP(hipStreamSynchronize(ctx->stream()));
+        m->tcache = t;
     }
-    fgpu_mat* t = mm->tcache;
+    const fgpu_mat* t = m->tcache;   // reachable only through m: m's mutex covers its item list too
     if (!t->bp_items && t->nnz) {
         FGPU_REQUIRE(!t->is_hyper(), FGPU_INVALID, "bit-parallel expansion needs a non-hypersparse transpose");
         const u32 nrows = (u32)t->nrows;
         DevBuf<u32> cnt, off;
         FGPU_TRY(cnt.alloc(ctx, (size_t)nrows + 1));
         FGPU_TRY(off.alloc(ctx, (size_t)nrows + 1));
-        hipLaunchKernelGGL(bp_item_count_kernel, dim3(cdiv((u64)nrows + 1, 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(bp_item_count_kernel, dim3(cdiv((u64)nrows + 1, 256)), dim3(256), 0, ctx->stream(),
                            (const u32*)t->rowptr, nrows, cnt.p);
         FGPU_HIP(hipGetLastError());
         FGPU_TRY(scan_u32(ctx, cnt.p, off.p, (u64)nrows + 1, nullptr));
         u32 n = 0;
         FGPU_TRY(read_u32(ctx, off.p + nrows, &n));
-        FGPU_TRY(ctx->dev_alloc((void**)&t->bp_items, (size_t)(n ? n : 1) * 3 * sizeof(u32)));
-        hipLaunchKernelGGL(bp_item_fill_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream,
-                           (const u32*)t->rowptr, nrows, (const u32*)off.p, t->bp_items);
-        FGPU_HIP(hipGetLastError());
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        u32* items = nullptr;
+        FGPU_TRY(ctx->dev_alloc((void**)&items, (size_t)(n ? n : 1) * 3 * sizeof(u32)));
+        hipLaunchKernelGGL(bp_item_fill_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream(),
+                           (const u32*)t->rowptr, nrows, (const u32*)off.p, items);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
+        if (e != hipSuccess) { ctx->dev_free(items); set_error("item list build failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
         t->n_bp_items = n;
+        t->bp_items = items;
     }
     *out = t;
     return FGPU_OK;
@@ -347,24 +351,26 @@ static void bp_layout(BitState& s, u32 n, u32 nsrc) {
 static fgpu_info bp_alloc_zero(fgpu_ctx* ctx, DevBuf<u64>& buf, const BitState& s) {
     const size_t words = (size_t)s.n * s.ws;
     FGPU_TRY(buf.alloc(ctx, words));
-    FGPU_HIP(hipMemsetAsync(buf.p, 0, words * sizeof(u64), ctx->stream));
+    ProfScope ps(ctx, "bit-state memset", words * sizeof(u64));
+    FGPU_HIP(hipMemsetAsync(buf.p, 0, words * sizeof(u64), ctx->stream()));
     return FGPU_OK;
 }
 
 static fgpu_info bp_alloc_flags(fgpu_ctx* ctx, BitState& s) {
     FGPU_TRY(s.flag.alloc(ctx, (size_t)s.n + 1));
-    FGPU_HIP(hipMemsetAsync(s.flag.p, 0, (size_t)s.n + 1, ctx->stream));
+    FGPU_HIP(hipMemsetAsync(s.flag.p, 0, (size_t)s.n + 1, ctx->stream()));
     return FGPU_OK;
 }
 
 static fgpu_info bp_count_flags(fgpu_ctx* ctx, BitState& s) {
     DevBuf<u64> acc;
     FGPU_TRY(acc.alloc(ctx, 1));
-    FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream()));
     if (s.n) {
+        ProfScope ps(ctx, "bp_flag_count_kernel", (u64)s.n);
         u32 grid = cdiv(s.n, 256);
         if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
-        hipLaunchKernelGGL(bp_flag_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*)s.flag.p, s.n,
+        hipLaunchKernelGGL(bp_flag_count_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const uint8_t*)s.flag.p, s.n,
                            (unsigned long long*)acc.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -377,9 +383,10 @@ fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f) {
     FGPU_TRY(bp_alloc_zero(ctx, s.x, s));
     FGPU_TRY(bp_alloc_flags(ctx, s));
     if (f->nnz) {
+        ProfScope ps(ctx, "bp_scatter_csr_kernel", 4 * (u64)f->nnz + 4 * ((u64)f->nrows + 1) + 16 * (u64)f->nnz);
         u32 grid = cdiv(f->nnz, 256);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-        hipLaunchKernelGGL(bp_scatter_csr_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(f), (u32)f->nrows,
+        hipLaunchKernelGGL(bp_scatter_csr_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(f), (u32)f->nrows,
                            (u32)f->nnz, s.ws, s.x.p, s.flag.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -403,9 +410,10 @@ fgpu_info bp_accumulate(fgpu_ctx* ctx, BitState& u, const BitState& x) {
     FGPU_REQUIRE(u.n == x.n && u.ws == x.ws, FGPU_DIM_MISMATCH, "bit-state union: layouts differ");
     const u64 words = (u64)x.n * x.ws;
     if (words) {
+        ProfScope ps(ctx, "bp_or_kernel", 3 * words * sizeof(u64));
         u32 grid = cdiv(words, 256);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-        hipLaunchKernelGGL(bp_or_kernel, dim3(grid), dim3(256), 0, ctx->stream, u.x.p, (const u64*)x.x.p, words);
+        hipLaunchKernelGGL(bp_or_kernel, dim3(grid), dim3(256), 0, ctx->stream(), u.x.p, (const u64*)x.x.p, words);
         FGPU_HIP(hipGetLastError());
     }
     return FGPU_OK;
@@ -414,16 +422,17 @@ fgpu_info bp_accumulate(fgpu_ctx* ctx, BitState& u, const BitState& x) {
 fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum) {
     DevBuf<u64> acc;
     FGPU_TRY(acc.alloc(ctx, 2));
-    FGPU_HIP(hipMemsetAsync(acc.p, 0, 2 * sizeof(u64), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(acc.p, 0, 2 * sizeof(u64), ctx->stream()));
     const u64 total = (u64)s.n * s.w;
     if (total) {
+        ProfScope ps(ctx, checksum ? "bp_count_kernel<checksum>" : "bp_count_kernel<count>", total * sizeof(u64));
         u32 grid = cdiv(total, 256);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
         if (checksum)
-            hipLaunchKernelGGL(bp_count_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n,
+            hipLaunchKernelGGL(bp_count_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n,
                                s.w, s.ws, label_dev, (unsigned long long*)acc.p);
         else
-            hipLaunchKernelGGL(bp_count_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n,
+            hipLaunchKernelGGL(bp_count_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n,
                                s.w, s.ws, label_dev, (unsigned long long*)acc.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -436,10 +445,11 @@ static fgpu_info bp_flops(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* a, u
     if (!a || a->nnz == 0) return FGPU_OK;
     DevBuf<u64> acc;
     FGPU_TRY(acc.alloc(ctx, 1));
-    FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream()));
+    ProfScope ps(ctx, "bp_flops_kernel", 4 * ((u64)a->nvec + 1) + (u64)s.n * s.w * 8);
     u32 grid = cdiv(a->nvec ? a->nvec : 1, 256);
     if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-    hipLaunchKernelGGL(bp_flops_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(a), s.w, s.ws,
+    hipLaunchKernelGGL(bp_flops_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(a), s.w, s.ws,
                        (const u64*)s.x.p, (unsigned long long*)acc.p);
     FGPU_HIP(hipGetLastError());
     u64 v = 0;
@@ -461,6 +471,7 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
     bp_layout(o, (u32)m->ncols, s.nsrc);
     FGPU_TRY(bp_alloc_zero(ctx, o.x, o));
     FGPU_TRY(bp_alloc_flags(ctx, o));
+    int pull_idx = -1;
     if (m->nnz) {
         const fgpu_mat* t = nullptr;
         FGPU_TRY(transposed_with_items(ctx, m, &t));
@@ -470,14 +481,21 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
         const u32 ln = s.ws < 64 ? s.ws : 64;
         // fewer than 1 row in 8 flagged: probing a byte per neighbour first beats gathering 8 W-byte rows
         const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n;
+        // algorithmic bytes of the launch: the column ids of A' and the item list once, every non-zero X row once
+        // (the per-entry row gathers beyond that are cache traffic), a flag byte per vertex in the sparse form;
+        // the non-zero Y rows written are added once they are counted (bp_count_flags below)
+        const u64 xrows = s.nz_rows < (u64)s.n ? s.nz_rows : (u64)s.n;
+        ProfScope ps(ctx, sparse ? "bp_pull_kernel<sparse>" : "bp_pull_kernel<dense>",
+                     4 * (u64)t->nnz + 12 * (u64)nitems + xrows * 8 * s.w + (sparse ? (u64)s.n : 0));
+        ps.idx_out = &pull_idx;
 #define BP_LAUNCH(LN)                                                                                                   \
     do {                                                                                                                \
         if (sparse)                                                                                                     \
-            hipLaunchKernelGGL((bp_pull_kernel<LN, true>), dim3(grid), dim3(256), 0, ctx->stream, view_of(t),         \
+            hipLaunchKernelGGL((bp_pull_kernel<LN, true>), dim3(grid), dim3(256), 0, ctx->stream(), view_of(t),         \
                                (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const uint8_t*)s.flag.p,     \
                                o.x.p, o.flag.p);                                                                        \
         else                                                                                                            \
-            hipLaunchKernelGGL((bp_pull_kernel<LN, false>), dim3(grid), dim3(256), 0, ctx->stream, view_of(t),        \
+            hipLaunchKernelGGL((bp_pull_kernel<LN, false>), dim3(grid), dim3(256), 0, ctx->stream(), view_of(t),        \
                                (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const uint8_t*)s.flag.p,     \
                                o.x.p, o.flag.p);                                                                        \
     } while (0)
@@ -497,21 +515,24 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
         u32 ln = 1;                               // lanes per delta entry: a power of two covering the row words
         while (ln < s.w && ln < 64) ln <<= 1;
         if (dm && dm->nnz) {
+            ProfScope ps(ctx, "bp_delta_kernel<dm>", (u64)dm->nnz * (4 + 16 * s.w));
             u32 grid = cdiv((u64)dm->nnz * ln, 256);
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-            hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, view_of(dm), (u32)dm->nnz,
+            hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dm), (u32)dm->nnz,
                                s.w, s.ws, ln, (const u64*)s.x.p, o.x.p, o.flag.p);
             FGPU_HIP(hipGetLastError());
         }
         if (dp && dp->nnz) {
+            ProfScope ps(ctx, "bp_delta_kernel<dp>", (u64)dp->nnz * (4 + 16 * s.w));
             u32 grid = cdiv((u64)dp->nnz * ln, 256);
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-            hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, view_of(dp), (u32)dp->nnz,
+            hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dp), (u32)dp->nnz,
                                s.w, s.ws, ln, (const u64*)s.x.p, o.x.p, o.flag.p);
             FGPU_HIP(hipGetLastError());
         }
     }
     FGPU_TRY(bp_count_flags(ctx, o));
+    prof_add_bytes(ctx, pull_idx, o.nz_rows * 8 * s.w);
     s.x = std::move(o.x);
     s.flag = std::move(o.flag);
     s.nz_rows = o.nz_rows;
@@ -529,11 +550,11 @@ fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu
     DevBuf<u64> off;
     FGPU_TRY(cnt.alloc(ctx, ncnt + 1));
     FGPU_TRY(off.alloc(ctx, ncnt + 1));
-    FGPU_HIP(hipMemsetAsync(cnt.p + ncnt, 0, sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(cnt.p + ncnt, 0, sizeof(u32), ctx->stream()));
     const u32 total = nchunks * s.w;
     u32 grid = cdiv(total, 4);
     if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-    hipLaunchKernelGGL(bp_rows_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n, s.w, s.ws,
+    hipLaunchKernelGGL(bp_rows_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n, s.w, s.ws,
                        nchunks, label_dev, cnt.p, (const u64*)nullptr, (u32*)nullptr);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY(scan_u32_to_u64(ctx, cnt.p, off.p, ncnt + 1, nullptr));
@@ -545,16 +566,16 @@ fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, s.nsrc, s.n, nnz, false, 0, false));
     // rows >= nsrc are empty, so off[nsrc * nchunks] == nnz already
-    hipLaunchKernelGGL(bp_rowptr_kernel, dim3(cdiv((u64)s.nsrc + 1, 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(bp_rowptr_kernel, dim3(cdiv((u64)s.nsrc + 1, 256)), dim3(256), 0, ctx->stream(),
                        (const u64*)off.p, s.nsrc, nchunks, o->rowptr);
     if (nnz) {
-        hipLaunchKernelGGL(bp_rows_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream, (const u64*)s.x.p, s.n, s.w,
+        hipLaunchKernelGGL(bp_rows_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n, s.w,
                            s.ws, nchunks, label_dev, (u32*)nullptr, (const u64*)off.p, o->colidx);
     }
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
     if (e != hipSuccess) {
-        fgpu_mat_free(o);
+        mat_release(o);
         set_error("bit-parallel emission failed: %s", hipGetErrorString(e));
         return FGPU_DEVICE;
     }

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -53,9 +54,12 @@ const char* get_error();
 }  // namespace fgpu
 
 // ---- context -----------------------------------------------------------------
-// One per process+device.  Owns a HIP stream, a size-class device pool (hipMalloc
-// is ~100 us; traversal calls must not pay it per hop) and the host allocator
-// hooks the caller handed to fgpu_init.
+// One per process+device, shared by every host thread of the process (the reference calls GraphBLAS from a
+// worker pool on shared handles: threadpool.rs:89-128, matrix.rs:781-796).  Each host thread that calls into
+// the library is bound to a LANE of the context: its own HIP stream, its own pinned staging block and its own
+// free-list of device blocks (hipMalloc is ~100 us; traversal calls must not pay it per hop), so calls of
+// different threads never share a stream-ordered resource.  The context owns the host allocator hooks the
+// caller handed to fgpu_init, the engine options and the kernel profiler.
 struct fgpu_options {  // fgpu_set_option
     int tiled_u = 8;           // items in flight per wavefront of the tiled kernel (8 KiB of entries per wave)
     int tiled_nt = 0;          // nontemporal entry loads
@@ -66,31 +70,77 @@ struct fgpu_options {  // fgpu_set_option
     int bfs_tiny = 2;          // consecutive tiny BFS levels in one single-workgroup launch (bfs_tiny_kernel): 0 off, 1 on,
                                // 2 = when the plan's previous search took more than 12 levels
     int bfs_hub_first = 1;     // pull levels read A' rows reordered hub-first (bfs.hip ensure_pull_order)
+    int bfs_prof_split = 0;    // profiled BFS pass launches the <.., 1|2> twins that name a level push / pull (PMC passes)
     int merge_mode = 0;        // Delta merge: 0 entry-parallel (merge.hip), 1 one wavefront per row (pattern only)
+    int transpose_mode = 0;    // pattern transpose: 0 counting transpose (no sort), 1 COO rebuild through the sorter (A/B)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
+};
+
+struct fgpu_lane {  // one per host thread using the context
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;        // own_stream, or the stream handed to fgpu_set_stream by this thread
+    void* pinned = nullptr;              // small pinned staging block for control read-backs
+    size_t pinned_bytes = 0;
+    std::multimap<size_t, void*> pool;   // free device blocks by capacity, recycled in this lane's stream order (ctx->mu)
+    hipEvent_t fence = nullptr;          // recorded on `stream` by a thread that frees a shared object (fence_mu)
+    std::mutex fence_mu;
+    bool bound = false;                  // a live thread holds it (ctx->mu)
+};
+
+struct fgpu_prof_entry {   // fgpu_prof_enable / fgpu_prof_read: HIP-event pairs around launches of named kernels
+    const char* name;
+    hipEvent_t e0, e1;
+    uint64_t alg_bytes;
 };
 
 struct fgpu_ctx {
     int device = 0;
+    uint64_t id = 0;           // unique over the process lifetime (thread-local lane caches key on it)
     fgpu_options opt;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
     void* (*mal)(size_t) = nullptr;
     void (*fre)(void*) = nullptr;
     int cus = 0;
-    std::mutex mu;
-    std::multimap<size_t, void*> pool;  // free blocks by capacity
+    std::mutex mu;                      // lanes, pools, live map, byte counters
+    std::vector<fgpu_lane*> lanes;
     std::map<void*, size_t> live;       // capacity of live blocks
     uint64_t bytes_in_use = 0, bytes_pooled = 0;
-    void* pinned = nullptr;  // small pinned staging block for control read-backs
-    size_t pinned_bytes = 0;
+    // kernel profiler (measurement hook): off unless fgpu_prof_enable(ctx, 1)
+    bool prof_on = false;
+    std::mutex prof_mu;
+    std::vector<fgpu_prof_entry> prof;
+    std::vector<hipEvent_t> prof_free;  // recycled events
 
+    fgpu_lane* lane();                  // the calling thread's lane (bound on first use; makes ctx->device current)
+    hipStream_t stream() { return lane()->stream; }
+    void* pinned() { return lane()->pinned; }
+    bool multi_lane();                  // more than one lane has ever been bound
+    // Order every LATER operation of the calling thread's stream after all work queued so far on every other
+    // lane: called before a shared object's (snapshot, plan) blocks return to the calling lane's free-list.
+    void fence_lanes();
+    // A handle about to be returned to the caller may be handed to another thread: when several lanes exist,
+    // wait for the work that produced it (single-lane contexts stay asynchronous).
+    fgpu_info publish();
     fgpu_info dev_alloc(void** p, size_t bytes);
     void dev_free(void* p);
     void* host_alloc(size_t bytes);
     void host_free(void* p);
     void trim();
 };
+
+namespace fgpu {
+// RAII: HIP events around one kernel launch (or a short sequence) when the ctx profiler is on.
+struct ProfScope {
+    fgpu_ctx* ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char* name;      // static string
+    uint64_t bytes;        // algorithmic bytes of the launch (SURVEY.md §8d accounting), 0 when not modelled
+    int* idx_out = nullptr;  // receives the record's index (or -1) for prof_add_bytes
+    ProfScope(fgpu_ctx* c, const char* n, uint64_t alg_bytes);
+    ~ProfScope();
+};
+// add bytes to a record whose size is only known after a later read-back (e.g. the non-zero output rows of a hop)
+void prof_add_bytes(fgpu_ctx* ctx, int idx, uint64_t extra);
+}  // namespace fgpu
 
 namespace fgpu {
 
@@ -138,8 +188,13 @@ struct DevBuf {
 // rowptr has nvec+1 entries; row lookups binary-search hrows.
 struct fgpu_tiles;  // tiled.hip: LDS-staged frontier-tile edge layout (acceleration index)
 
+// The stored matrix (dims, rowptr, colidx, vals, hrows) never changes after creation.  The acceleration indexes
+// below are built lazily on first use; every such build happens under `idx_mu`, is complete on the device
+// (stream synchronised) before its pointer is published, and is never replaced afterwards — concurrent readers
+// on other lanes either see no index (and take the lock) or a finished one.
 struct fgpu_mat {
     fgpu_ctx* ctx = nullptr;
+    mutable std::mutex idx_mu;
     uint64_t nrows = 0, ncols = 0, nnz = 0;
     uint32_t nvec = 0;          // number of stored rows (== nrows when not hyper)
     uint32_t* rowptr = nullptr; // device
@@ -147,22 +202,22 @@ struct fgpu_mat {
     uint64_t* vals = nullptr;   // device, nullable (BOOL: pattern only)
     uint32_t* hrows = nullptr;  // device, nullable
     // static hub list for the push kernels (rows with degree >= HUB_DEG), device
-    uint32_t* hub_chunks = nullptr;  // triples (row, begin, end)
-    uint32_t n_hub_chunks = 0;
+    mutable uint32_t* hub_chunks = nullptr;  // triples (row, begin, end)
+    mutable uint32_t n_hub_chunks = 0;
     // finer list for the fused push levels (rows >= PUSH_HUB_DEG in PUSH_HUB_CHUNK-edge items): a frontier of a
     // few hundred near-hub rows must spread over the whole chip, not over frontier/4 workgroups
-    uint32_t* push_chunks = nullptr;
-    uint32_t n_push_chunks = 0;
-    uint32_t max_deg = 0;
-    bool finalized = false;       // hub list / max_deg computed (mat_finalize); merges leave it to the first BFS plan
-    uint32_t* pull_col = nullptr; // bfs.hip: column ids with every row reordered hub-first, for the pull levels (lazy, owned)
-    uint32_t* wordrow = nullptr;  // merge.hip: stored-row index of entry 64 w, for w in [0, ceil(nnz/64)] (lazy, owned)
-    fgpu_tiles* tiles = nullptr;  // built on demand by fgpu_mat_build_tiles; owned by the matrix
+    mutable uint32_t* push_chunks = nullptr;
+    mutable uint32_t n_push_chunks = 0;
+    mutable uint32_t max_deg = 0;
+    mutable std::atomic<bool> finalized{false};       // hub list / max_deg computed (mat_finalize); merges leave it to the first BFS plan
+    mutable uint32_t* pull_col = nullptr; // bfs.hip: column ids with every row reordered hub-first, for the pull levels (lazy, owned)
+    mutable uint32_t* wordrow = nullptr;  // merge.hip: stored-row index of entry 64 w, for w in [0, ceil(nnz/64)] (lazy, owned)
+    mutable fgpu_tiles* tiles = nullptr;  // built on demand by fgpu_mat_build_tiles; owned by the matrix
     // bit-parallel expansion (bitexpand.hip): cached pattern transpose of this matrix, and (on that
     // transpose) its rows cut into items of <= 256 entries
-    fgpu_mat* tcache = nullptr;
-    uint32_t* bp_items = nullptr;  // triples (row, begin, end | split << 31)
-    uint32_t n_bp_items = 0;
+    mutable fgpu_mat* tcache = nullptr;
+    mutable uint32_t* bp_items = nullptr;  // triples (row, begin, end | split << 31)
+    mutable uint32_t n_bp_items = 0;
     bool is_hyper() const { return hrows != nullptr; }
 };
 
@@ -247,6 +302,8 @@ fgpu_info compact_segments(fgpu_ctx* ctx, const u32* data, const u64* off, const
                            u32 nseg, u32* col_out);
 
 // ---- matrix helpers (mat.hip) ---------------------------------------------------
+// free a snapshot no other thread has seen (temporaries, failed builds); fgpu_mat_free adds the cross-lane fence
+void mat_release(fgpu_mat* m);
 fgpu_info mat_alloc(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, u64 nnz, bool with_vals,
                     u32 nvec_hyper, bool hyper);
 // (m \ dm) U dp, pattern only, on device (K3/K6).
@@ -263,7 +320,7 @@ fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 // dense (nrows+1) rowptr of a possibly hypersparse matrix.
 fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp);
 fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
-fgpu_info mat_finalize(fgpu_mat* m);  // hub list, max degree (after rowptr/colidx are filled)
+fgpu_info mat_finalize(const fgpu_mat* m);  // hub list, max degree (after rowptr/colidx are filled; private or under idx_mu)
 fgpu_info mat_ensure_finalized(const fgpu_mat* m);  // lazily, for snapshots produced by the merge kernels
 // device COO (u32 rows / cols, n entries) -> CSR snapshot, duplicates collapsed.
 fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
@@ -274,7 +331,7 @@ fgpu_info read_u64(fgpu_ctx* ctx, const u64* dev, u64* host);
 
 void tiles_release(fgpu_tiles* t);
 // tiled.hip: build the LDS-tile layout of `m` (0 = automatic parameter) / run out = m (x) x & ~mask
-fgpu_info tiles_build(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k);
+fgpu_info tiles_build(fgpu_ctx* ctx, const fgpu_mat* m, int tile_bits, int vec, int k, bool rebuild);
 fgpu_info tiles_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 x_words64, const u64* mask_dev,
                     u64* out_dev, bool zero_out);
 

@@ -18,21 +18,143 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 fgpu_info read_u32(fgpu_ctx* ctx, const u32* dev, u32* host) {
-    FGPU_HIP(hipMemcpyAsync(ctx->pinned, dev, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    *host = *(u32*)ctx->pinned;
+    fgpu_lane* l = ctx->lane();
+    FGPU_HIP(hipMemcpyAsync(l->pinned, dev, sizeof(u32), hipMemcpyDeviceToHost, l->stream));
+    FGPU_HIP(hipStreamSynchronize(l->stream));
+    *host = *(u32*)l->pinned;
     return FGPU_OK;
 }
 fgpu_info read_u64(fgpu_ctx* ctx, const u64* dev, u64* host) {
-    FGPU_HIP(hipMemcpyAsync(ctx->pinned, dev, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    *host = *(u64*)ctx->pinned;
+    fgpu_lane* l = ctx->lane();
+    FGPU_HIP(hipMemcpyAsync(l->pinned, dev, sizeof(u64), hipMemcpyDeviceToHost, l->stream));
+    FGPU_HIP(hipStreamSynchronize(l->stream));
+    *host = *(u64*)l->pinned;
     return FGPU_OK;
 }
 
 }  // namespace fgpu
 
 using namespace fgpu;
+
+// ---- lanes: one stream + staging block + free-list per host thread -------------------------------------
+namespace {
+
+std::mutex g_reg_mu;                        // lock order: g_reg_mu -> ctx->mu -> lane->fence_mu
+std::map<uint64_t, fgpu_ctx*> g_live_ctx;   // contexts between fgpu_init and fgpu_finalize
+std::atomic<uint64_t> g_next_id{1};
+
+struct LaneRef { uint64_t id; fgpu_ctx* ctx; fgpu_lane* lane; };
+struct ThreadLanes {
+    std::vector<LaneRef> refs;
+    uint64_t last_id = 0;        // the context this thread called last (its device is current)
+    fgpu_lane* last_lane = nullptr;
+    ~ThreadLanes() {             // the thread exits: its lanes go back to their contexts for the next new thread
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        for (auto& r : refs) {
+            auto it = g_live_ctx.find(r.id);
+            if (it == g_live_ctx.end() || it->second != r.ctx) continue;
+            std::lock_guard<std::mutex> g2(r.ctx->mu);
+            r.lane->bound = false;
+        }
+    }
+};
+thread_local ThreadLanes tl_lanes;
+
+fgpu_lane* lane_create() {
+    fgpu_lane* l = new (std::nothrow) fgpu_lane();
+    if (!l) return nullptr;
+    if (hipStreamCreateWithFlags(&l->own_stream, hipStreamNonBlocking) != hipSuccess) { delete l; return nullptr; }
+    l->stream = l->own_stream;
+    l->pinned_bytes = 1 << 16;
+    if (hipHostMalloc(&l->pinned, l->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(l->own_stream);
+        delete l;
+        return nullptr;
+    }
+    if (hipEventCreateWithFlags(&l->fence, hipEventDisableTiming) != hipSuccess) {
+        (void)hipHostFree(l->pinned);
+        (void)hipStreamDestroy(l->own_stream);
+        delete l;
+        return nullptr;
+    }
+    return l;
+}
+
+void lane_destroy(fgpu_lane* l) {
+    if (!l) return;
+    if (l->fence) (void)hipEventDestroy(l->fence);
+    if (l->pinned) (void)hipHostFree(l->pinned);
+    if (l->own_stream) (void)hipStreamDestroy(l->own_stream);
+    delete l;
+}
+
+}  // namespace
+
+fgpu_lane* fgpu_ctx::lane() {
+    ThreadLanes& t = tl_lanes;
+    if (t.last_id == id) return t.last_lane;
+    (void)hipSetDevice(device);   // HIP's current device is per thread; this thread last called another context (or none)
+    for (auto& r : t.refs)
+        if (r.id == id) { t.last_id = id; t.last_lane = r.lane; return r.lane; }
+    // first call of this thread on this context: adopt a lane an exited thread left behind, or make one
+    fgpu_lane* l = nullptr;
+    bool others = false;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (fgpu_lane* c : lanes)
+            if (!c->bound) { l = c; break; }
+        if (l) l->bound = true;
+        others = !lanes.empty();
+    }
+    if (!l) {
+        l = lane_create();
+        if (!l) {
+            // out of streams / pinned memory (never seen): degrade to sharing the first lane rather than crash;
+            // the sharing threads then need the caller-side serialisation the single-stream design asked for
+            std::lock_guard<std::mutex> g(mu);
+            l = lanes.empty() ? nullptr : lanes[0];
+        } else {
+            l->bound = true;
+            std::lock_guard<std::mutex> g(mu);
+            lanes.push_back(l);
+        }
+    }
+    if (l && others) {
+        // joining a context that is already in use: whatever earlier threads queued (snapshots they created and
+        // have since handed to this thread) must be complete before this lane's stream reads it
+        std::vector<fgpu_lane*> ls;
+        { std::lock_guard<std::mutex> g(mu); ls = lanes; }
+        for (fgpu_lane* o : ls)
+            if (o != l) (void)hipStreamSynchronize(o->stream);
+    }
+    t.refs.push_back({id, this, l});
+    t.last_id = id;
+    t.last_lane = l;
+    return l;
+}
+
+bool fgpu_ctx::multi_lane() {
+    std::lock_guard<std::mutex> g(mu);
+    return lanes.size() > 1;
+}
+
+fgpu_info fgpu_ctx::publish() {
+    if (!multi_lane()) return FGPU_OK;
+    FGPU_HIP(hipStreamSynchronize(stream()));
+    return FGPU_OK;
+}
+
+void fgpu_ctx::fence_lanes() {
+    fgpu_lane* me = lane();
+    std::vector<fgpu_lane*> ls;
+    { std::lock_guard<std::mutex> g(mu); if (lanes.size() <= 1) return; ls = lanes; }
+    for (fgpu_lane* o : ls) {
+        if (o == me) continue;
+        std::lock_guard<std::mutex> g(o->fence_mu);
+        if (hipEventRecord(o->fence, o->stream) == hipSuccess) (void)hipStreamWaitEvent(me->stream, o->fence, 0);
+        else { (void)hipGetLastError(); (void)hipStreamSynchronize(o->stream); }
+    }
+}
 
 static size_t size_class(size_t bytes) {
     // 256 B granularity below 1 MiB, then 1/8-octave steps: bounded waste, high reuse.
@@ -46,13 +168,14 @@ static size_t size_class(size_t bytes) {
 
 fgpu_info fgpu_ctx::dev_alloc(void** p, size_t bytes) {
     size_t cap = size_class(bytes);
-    {
+    fgpu_lane* ln = lane();
+    if (ln) {
         std::lock_guard<std::mutex> g(mu);
-        auto it = pool.lower_bound(cap);
-        if (it != pool.end() && it->first <= cap + (cap >> 2)) {
+        auto it = ln->pool.lower_bound(cap);
+        if (it != ln->pool.end() && it->first <= cap + (cap >> 2)) {
             *p = it->second;
             size_t c = it->first;
-            pool.erase(it);
+            ln->pool.erase(it);
             live[*p] = c;
             bytes_pooled -= c;
             bytes_in_use += c;
@@ -80,28 +203,68 @@ fgpu_info fgpu_ctx::dev_alloc(void** p, size_t bytes) {
 
 void fgpu_ctx::dev_free(void* p) {
     if (!p) return;
+    fgpu_lane* ln = lane();
     std::lock_guard<std::mutex> g(mu);
     auto it = live.find(p);
     if (it == live.end()) return;
     size_t c = it->second;
     live.erase(it);
     bytes_in_use -= c;
-    // Blocks are recycled stream-ordered: every kernel of this ctx runs on ctx->stream,
-    // so a block handed out again is only touched after its previous users finished.
-    pool.emplace(c, p);
+    if (!ln) { (void)hipFree(p); return; }
+    // Blocks are recycled stream-ordered inside ONE lane: a block handed out again is only touched by this lane's
+    // stream, after its previous users on that stream finished.  Objects other lanes may have touched (snapshots,
+    // plans) call fence_lanes() before their blocks come here.
+    ln->pool.emplace(c, p);
     bytes_pooled += c;
 }
 
 void fgpu_ctx::trim() {
-    std::multimap<size_t, void*> old;
+    std::vector<void*> old;
+    std::vector<fgpu_lane*> ls;
     {
         std::lock_guard<std::mutex> g(mu);
-        old.swap(pool);
+        for (fgpu_lane* l : lanes) {
+            for (auto& kv : l->pool) old.push_back(kv.second);
+            l->pool.clear();
+        }
         bytes_pooled = 0;
+        ls = lanes;
     }
-    if (!old.empty()) (void)hipStreamSynchronize(stream);
-    for (auto& kv : old) (void)hipFree(kv.second);
+    if (old.empty()) return;
+    for (fgpu_lane* l : ls) (void)hipStreamSynchronize(l->stream);
+    for (void* p : old) (void)hipFree(p);
 }
+
+// ---- kernel profiler ----------------------------------------------------------------------------------------
+namespace fgpu {
+ProfScope::ProfScope(fgpu_ctx* c, const char* n, uint64_t alg_bytes) : ctx(c), name(n), bytes(alg_bytes) {
+    if (!c || !c->prof_on) return;
+    {
+        std::lock_guard<std::mutex> g(c->prof_mu);
+        if (c->prof_free.size() >= 2) {
+            e0 = c->prof_free.back(); c->prof_free.pop_back();
+            e1 = c->prof_free.back(); c->prof_free.pop_back();
+        }
+    }
+    if (!e0) {
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+    }
+    (void)hipEventRecord(e0, c->stream());
+}
+ProfScope::~ProfScope() {
+    if (idx_out) *idx_out = -1;
+    if (!e0) return;
+    (void)hipEventRecord(e1, ctx->stream());
+    std::lock_guard<std::mutex> g(ctx->prof_mu);
+    if (idx_out) *idx_out = (int)ctx->prof.size();
+    ctx->prof.push_back({name, e0, e1, bytes});
+}
+void prof_add_bytes(fgpu_ctx* ctx, int idx, uint64_t extra) {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> g(ctx->prof_mu);
+    if ((size_t)idx < ctx->prof.size()) ctx->prof[idx].alg_bytes += extra;
+}
+}  // namespace fgpu
 
 void* fgpu_ctx::host_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
@@ -137,24 +300,19 @@ fgpu_info fgpu_init(fgpu_ctx** out, int device, void* (*mal)(size_t), void (*fre
     fgpu_ctx* c = new (std::nothrow) fgpu_ctx();
     FGPU_REQUIRE(c != nullptr, FGPU_OOM, "fgpu_init: out of host memory");
     c->device = device;
+    c->id = g_next_id.fetch_add(1);
     c->mal = mal;
     c->fre = fre;
     c->cus = prop.multiProcessorCount;
     c->opt.lds_limit = (int)prop.sharedMemPerBlock;
-    hipError_t se = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (se != hipSuccess) {
-        set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+    if (c->lane() == nullptr) {   // the calling thread's lane: stream + pinned staging block + fence event
+        set_error("fgpu_init: could not create a stream / pinned staging block on device %d", device);
         delete c;
         return FGPU_DEVICE;
     }
-    c->stream = c->own_stream;
-    c->pinned_bytes = 1 << 16;
-    se = hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault);
-    if (se != hipSuccess) {
-        set_error("hipHostMalloc failed: %s", hipGetErrorString(se));
-        (void)hipStreamDestroy(c->own_stream);
-        delete c;
-        return FGPU_DEVICE;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        g_live_ctx[c->id] = c;
     }
     *out = c;
     return FGPU_OK;
@@ -162,14 +320,23 @@ fgpu_info fgpu_init(fgpu_ctx** out, int device, void* (*mal)(size_t), void (*fre
 
 fgpu_info fgpu_finalize(fgpu_ctx* ctx) {
     if (!ctx) return FGPU_OK;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);   // exiting threads stop looking at this context
+        g_live_ctx.erase(ctx->id);
+    }
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    for (fgpu_lane* l : ctx->lanes) (void)hipStreamSynchronize(l->stream);
     ctx->trim();
     // live blocks still owned by un-freed matrices are released here too
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     ctx->live.clear();
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    for (auto& e : ctx->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
+    for (fgpu_lane* l : ctx->lanes) lane_destroy(l);
+    // threads that still cache a lane of this context key their cache on ctx->id, which is never reused
+    if (tl_lanes.last_id == ctx->id) { tl_lanes.last_id = 0; tl_lanes.last_lane = nullptr; }
+    for (size_t i = 0; i < tl_lanes.refs.size();)
+        if (tl_lanes.refs[i].id == ctx->id) tl_lanes.refs.erase(tl_lanes.refs.begin() + i); else ++i;
     delete ctx;
     return FGPU_OK;
 }
@@ -181,9 +348,50 @@ void fgpu_free(fgpu_ctx* ctx, void* p) {
 
 fgpu_info fgpu_set_stream(fgpu_ctx* ctx, void* hip_stream) {
     FGPU_REQUIRE(ctx != nullptr, FGPU_NULL_POINTER, "fgpu_set_stream: NULL ctx");
+    fgpu_lane* l = ctx->lane();
     // drain work queued on the previous stream so pooled blocks stay stream-ordered
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    FGPU_HIP(hipStreamSynchronize(l->stream));
+    std::lock_guard<std::mutex> g(l->fence_mu);
+    l->stream = hip_stream ? (hipStream_t)hip_stream : l->own_stream;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_prof_enable(fgpu_ctx* ctx, int enable) {
+    FGPU_REQUIRE(ctx != nullptr, FGPU_NULL_POINTER, "fgpu_prof_enable: NULL ctx");
+    std::lock_guard<std::mutex> g(ctx->prof_mu);
+    if (enable) {
+        for (auto& e : ctx->prof) { ctx->prof_free.push_back(e.e0); ctx->prof_free.push_back(e.e1); }
+        ctx->prof.clear();
+    }
+    ctx->prof_on = enable != 0;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_prof_read(fgpu_ctx* ctx, const char** names, double* ms, uint64_t* launches, uint64_t* alg_bytes,
+                         int cap, int* n) {
+    FGPU_REQUIRE(ctx && names && ms && launches && alg_bytes && n, FGPU_NULL_POINTER, "fgpu_prof_read: NULL argument");
+    std::vector<fgpu_lane*> ls;
+    { std::lock_guard<std::mutex> g(ctx->mu); ls = ctx->lanes; }
+    for (fgpu_lane* l : ls) FGPU_HIP(hipStreamSynchronize(l->stream));
+    std::lock_guard<std::mutex> g(ctx->prof_mu);
+    int k = 0;
+    for (auto& e : ctx->prof) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.e0, e.e1) != hipSuccess) { (void)hipGetLastError(); t = 0.f; }
+        int j = 0;
+        for (; j < k; ++j)
+            if (names[j] == e.name || !strcmp(names[j], e.name)) break;
+        if (j == k) {
+            if (k == cap) continue;
+            names[k] = e.name; ms[k] = 0; launches[k] = 0; alg_bytes[k] = 0;
+            ++k;
+        }
+        ms[j] += t; launches[j] += 1; alg_bytes[j] += e.alg_bytes;
+        ctx->prof_free.push_back(e.e0);
+        ctx->prof_free.push_back(e.e1);
+    }
+    ctx->prof.clear();
+    *n = k;
     return FGPU_OK;
 }
 
@@ -202,8 +410,13 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "bfs_tiny")) {
         FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "bfs_tiny must be 0, 1 or 2");
         ctx->opt.bfs_tiny = (int)value;
+    } else if (!strcmp(name, "bfs_prof_split")) {
+        ctx->opt.bfs_prof_split = value != 0;
     } else if (!strcmp(name, "bfs_hub_first")) {
         ctx->opt.bfs_hub_first = value != 0;
+    } else if (!strcmp(name, "transpose_mode")) {
+        FGPU_REQUIRE(value == 0 || value == 1, FGPU_INVALID, "transpose_mode must be 0 (counting) or 1 (COO rebuild)");
+        ctx->opt.transpose_mode = (int)value;
     } else if (!strcmp(name, "merge_mode")) {
         FGPU_REQUIRE(value == 0 || value == 1, FGPU_INVALID, "merge_mode must be 0 (entry-parallel) or 1 (row-wave)");
         ctx->opt.merge_mode = (int)value;
@@ -225,7 +438,7 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
 
 fgpu_info fgpu_sync(fgpu_ctx* ctx) {
     FGPU_REQUIRE(ctx != nullptr, FGPU_NULL_POINTER, "fgpu_sync: NULL ctx");
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream()));   // the calling thread's lane
     return FGPU_OK;
 }
 

@@ -17,7 +17,7 @@ namespace fgpu {
 // ---------------------------------------------------------------------------------
 // allocation / finalisation
 // ---------------------------------------------------------------------------------
-static void mat_release(fgpu_mat* m) {
+void mat_release(fgpu_mat* m) {
     if (!m) return;
     fgpu_ctx* c = m->ctx;
     if (c) {
@@ -92,46 +92,51 @@ __global__ void hub_scan_kernel(const u32* __restrict__ rowptr, u32 nvec, u32* _
     }
 }
 
-static fgpu_info build_hub_list(fgpu_mat* m, u32 deg_min, u32 chunk, u32** out, u32* n_out) {
+static fgpu_info build_hub_list(const fgpu_mat* m, u32 deg_min, u32 chunk, u32** out, u32* n_out) {
     fgpu_ctx* ctx = m->ctx;
     // every hub chunk holds >= 1 edge and at most nnz / chunk + (#hub rows) chunks exist
     u32 cap = (u32)(m->nnz / chunk + m->nnz / deg_min + 1);
     DevBuf<u32> meta, chunks;
     FGPU_TRY(meta.alloc(ctx, 2));
     FGPU_TRY(chunks.alloc(ctx, (size_t)cap * 3));
-    FGPU_HIP(hipMemsetAsync(meta.p, 0, 2 * sizeof(u32), ctx->stream));
-    hipLaunchKernelGGL(hub_scan_kernel, dim3(cdiv(m->nvec, 256)), dim3(256), 0, ctx->stream, m->rowptr, m->nvec,
+    FGPU_HIP(hipMemsetAsync(meta.p, 0, 2 * sizeof(u32), ctx->stream()));
+    hipLaunchKernelGGL(hub_scan_kernel, dim3(cdiv(m->nvec, 256)), dim3(256), 0, ctx->stream(), m->rowptr, m->nvec,
                        meta.p, meta.p + 1, chunks.p, cap, m->hrows, deg_min, chunk);
     FGPU_HIP(hipGetLastError());
     u32 h[2];
-    FGPU_HIP(hipMemcpyAsync(ctx->pinned, meta.p, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(h, ctx->pinned, sizeof(h));
+    FGPU_HIP(hipMemcpyAsync(ctx->pinned(), meta.p, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream()));
+    memcpy(h, ctx->pinned(), sizeof(h));
     m->max_deg = h[0];
     *n_out = h[1] < cap ? h[1] : cap;
     if (*n_out) {
         FGPU_TRY(ctx->dev_alloc((void**)out, (size_t)*n_out * 3 * sizeof(u32)));
         FGPU_HIP(hipMemcpyAsync(*out, chunks.p, (size_t)*n_out * 3 * sizeof(u32), hipMemcpyDeviceToDevice,
-                                ctx->stream));
+                                ctx->stream()));
     }
     return FGPU_OK;
 }
 
-fgpu_info mat_finalize(fgpu_mat* m) {
+// Called on a matrix no other thread can see yet (its builder) or under m->idx_mu (mat_ensure_finalized).
+fgpu_info mat_finalize(const fgpu_mat* m) {
     m->max_deg = 0;
     m->n_hub_chunks = 0;
     m->n_push_chunks = 0;
-    m->finalized = true;
-    if (m->nnz == 0 || m->nvec == 0) return FGPU_OK;
-    FGPU_TRY(build_hub_list(m, HUB_DEG, HUB_CHUNK, &m->hub_chunks, &m->n_hub_chunks));
-    if (m->max_deg >= PUSH_HUB_DEG)
-        FGPU_TRY(build_hub_list(m, PUSH_HUB_DEG, PUSH_HUB_CHUNK, &m->push_chunks, &m->n_push_chunks));
+    if (m->nnz && m->nvec) {
+        FGPU_TRY(build_hub_list(m, HUB_DEG, HUB_CHUNK, &m->hub_chunks, &m->n_hub_chunks));
+        if (m->max_deg >= PUSH_HUB_DEG)
+            FGPU_TRY(build_hub_list(m, PUSH_HUB_DEG, PUSH_HUB_CHUNK, &m->push_chunks, &m->n_push_chunks));
+        FGPU_HIP(hipStreamSynchronize(m->ctx->stream()));   // the chunk copies are complete before the flag is raised
+    }
+    m->finalized.store(true, std::memory_order_release);
     return FGPU_OK;
 }
 
 fgpu_info mat_ensure_finalized(const fgpu_mat* m) {
-    if (m->finalized) return FGPU_OK;
-    return mat_finalize(const_cast<fgpu_mat*>(m));
+    if (m->finalized.load(std::memory_order_acquire)) return FGPU_OK;
+    std::lock_guard<std::mutex> idx_guard(m->idx_mu);
+    if (m->finalized.load(std::memory_order_acquire)) return FGPU_OK;
+    return mat_finalize(m);
 }
 
 // ---------------------------------------------------------------------------------
@@ -163,10 +168,10 @@ fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncol
     FGPU_TRY(hist.alloc(ctx, nrows + 1));
     FGPU_TRY(off.alloc(ctx, nrows + 1));
     FGPU_TRY(tot.alloc(ctx, 1));
-    FGPU_HIP(hipMemsetAsync(hist.p, 0, (nrows + 1) * sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(hist.p, 0, (nrows + 1) * sizeof(u32), ctx->stream()));
     u32 grid = ctx->cus * 16;
     if (n) {
-        hipLaunchKernelGGL(coo_hist_kernel, dim3(grid), dim3(256), 0, ctx->stream, rows, n, hist.p);
+        hipLaunchKernelGGL(coo_hist_kernel, dim3(grid), dim3(256), 0, ctx->stream(), rows, n, hist.p);
         FGPU_HIP(hipGetLastError());
     }
     FGPU_TRY(scan_u32_to_u64(ctx, hist.p, off.p, nrows + 1, tot.p));
@@ -174,10 +179,10 @@ fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncol
     FGPU_TRY(read_u64(ctx, tot.p, &nvalid));
     FGPU_TRY(tmp.alloc(ctx, nvalid));
     FGPU_TRY(cnt.alloc(ctx, nrows + 1));
-    FGPU_HIP(hipMemsetAsync(hist.p, 0, (nrows + 1) * sizeof(u32), ctx->stream));
-    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(hist.p, 0, (nrows + 1) * sizeof(u32), ctx->stream()));
+    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream()));
     if (n) {
-        hipLaunchKernelGGL(coo_scatter_kernel, dim3(grid), dim3(256), 0, ctx->stream, rows, cols, n, off.p, hist.p,
+        hipLaunchKernelGGL(coo_scatter_kernel, dim3(grid), dim3(256), 0, ctx->stream(), rows, cols, n, off.p, hist.p,
                            tmp.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -189,7 +194,7 @@ fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncol
     FGPU_TRY(read_u32(ctx, rowptr.p + nrows, &nnz));
     fgpu_mat* m = nullptr;
     FGPU_TRY(mat_alloc(ctx, &m, nrows, ncols, nnz, false, 0, false));
-    FGPU_HIP(hipMemcpyAsync(m->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(m->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()));
     fgpu_info i = compact_segments(ctx, tmp.p, off.p, m->rowptr, (u32)nrows, m->colidx);
     if (i == FGPU_OK) i = mat_finalize(m);
     if (i != FGPU_OK) { mat_release(m); return i; }
@@ -207,15 +212,15 @@ static fgpu_info upload_host_csr(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 n
     fgpu_mat* m = nullptr;
     FGPU_TRY(mat_alloc(ctx, &m, nrows, ncols, nnz, vals != nullptr, (u32)hrows_or_empty.size(), hyper));
     hipError_t e = hipMemcpyAsync(m->rowptr, rowptr.data(), rowptr.size() * sizeof(u32), hipMemcpyHostToDevice,
-                                  ctx->stream);
+                                  ctx->stream());
     if (e == hipSuccess && nnz)
-        e = hipMemcpyAsync(m->colidx, colidx.data(), nnz * sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(m->colidx, colidx.data(), nnz * sizeof(u32), hipMemcpyHostToDevice, ctx->stream());
     if (e == hipSuccess && vals && nnz)
-        e = hipMemcpyAsync(m->vals, vals->data(), nnz * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(m->vals, vals->data(), nnz * sizeof(u64), hipMemcpyHostToDevice, ctx->stream());
     if (e == hipSuccess && hyper && !hrows_or_empty.empty())
         e = hipMemcpyAsync(m->hrows, hrows_or_empty.data(), hrows_or_empty.size() * sizeof(u32),
-                           hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host vectors die with the caller
+                           hipMemcpyHostToDevice, ctx->stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());  // host vectors die with the caller
     if (e != hipSuccess) {
         set_error("matrix upload failed: %s", hipGetErrorString(e));
         mat_release(m);
@@ -463,6 +468,26 @@ __global__ __launch_bounds__(256) void csr_to_coo_t_kernel(CsrView a, u32* __res
     }
 }
 
+// uniform sample of the stored entries (bench / test data: "0.1 % random tombstones"):
+// entry (r, c) is kept iff mix64(seed ^ mix64(r << 32 | c)) % denom == 0 — a function of the coordinate, so the
+// CPU oracle draws the same sample from its own copy of the matrix
+__global__ __launch_bounds__(256) void sample_coo_kernel(CsrView a, u64 seed, u32 denom, u32* __restrict__ rows_out,
+                                                        u32* __restrict__ cols_out) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    for (u32 i = wave; i < a.nvec; i += nwaves) {
+        const u32 r = a.hrows ? a.hrows[i] : i;
+        const u32 b = a.rowptr[i], e = a.rowptr[i + 1];
+        for (u32 k = b + lane; k < e; k += 64) {
+            const u32 c = a.colidx[k];
+            const bool keep = mix64(seed ^ mix64(((u64)r << 32) | c)) % denom == 0;
+            rows_out[k] = keep ? r : ROW_INVALID;
+            cols_out[k] = c;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // R-MAT generator
 // ---------------------------------------------------------------------------------
@@ -514,7 +539,7 @@ fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a
     FGPU_TRY(cols.alloc(ctx, a->nnz));
     u32 grid = cdiv(a->nvec, 4);
     if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-    hipLaunchKernelGGL(csr_to_coo_t_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(a), rows.p, cols.p);
+    hipLaunchKernelGGL(csr_to_coo_t_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(a), rows.p, cols.p);
     FGPU_HIP(hipGetLastError());
     return mat_from_device_coo(ctx, out, a->ncols, a->nrows, rows.p, cols.p, a->nnz);
 }
@@ -523,6 +548,9 @@ fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a
 extern "C" {
 
 fgpu_info fgpu_mat_free(fgpu_mat* m) {
+    // other lanes may still have reads of this snapshot in flight (asynchronous calls of other threads): order the
+    // reuse of its blocks, which go to the calling lane's free-list, after everything queued so far
+    if (m && m->ctx) m->ctx->fence_lanes();
     mat_release(m);
     return FGPU_OK;
 }
@@ -547,13 +575,13 @@ fgpu_info fgpu_mat_has_values(const fgpu_mat* m, int32_t* out) {
     return FGPU_OK;
 }
 
-fgpu_info fgpu_mat_new(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols) {
+static fgpu_info mat_new_impl(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols) {
     FGPU_REQUIRE(ctx && out, FGPU_NULL_POINTER, "fgpu_mat_new: NULL argument");
     std::vector<u32> none, rowptr(1, 0), col;
     return upload_host_csr(ctx, out, nrows, ncols, none, true, rowptr, col, nullptr);
 }
 
-fgpu_info fgpu_mat_from_coo(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols, const uint64_t* rows,
+static fgpu_info mat_from_coo_impl(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols, const uint64_t* rows,
                             const uint64_t* cols, const uint64_t* vals, uint64_t n) {
     FGPU_REQUIRE(ctx && out, FGPU_NULL_POINTER, "fgpu_mat_from_coo: NULL argument");
     FGPU_REQUIRE(n == 0 || (rows && cols), FGPU_NULL_POINTER, "fgpu_mat_from_coo: NULL tuple arrays");
@@ -575,13 +603,13 @@ fgpu_info fgpu_mat_from_coo(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint6
         DevBuf<u64> dv;
         FGPU_TRY(dr.alloc(ctx, n));
         FGPU_TRY(dc.alloc(ctx, n));
-        FGPU_HIP(hipMemcpyAsync(dr.p, r32.data(), n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-        FGPU_HIP(hipMemcpyAsync(dc.p, c32.data(), n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(dr.p, r32.data(), n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream()));
+        FGPU_HIP(hipMemcpyAsync(dc.p, c32.data(), n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream()));
         if (vals) {
             FGPU_TRY(dv.alloc(ctx, n));
-            FGPU_HIP(hipMemcpyAsync(dv.p, vals, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            FGPU_HIP(hipMemcpyAsync(dv.p, vals, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
         }
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream()));
         if (vals) return mat_from_device_coo_vals(ctx, out, nrows, ncols, dr.p, dc.p, dv.p, n);
         return mat_from_device_coo(ctx, out, nrows, ncols, dr.p, dc.p, n);
     }
@@ -622,7 +650,7 @@ fgpu_info fgpu_mat_from_coo(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint6
     return upload_host_csr(ctx, out, nrows, ncols, none, false, rowptr, col, vals ? &val : nullptr);
 }
 
-fgpu_info fgpu_mat_from_csr(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols, uint64_t nnz,
+static fgpu_info mat_from_csr_impl(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols, uint64_t nnz,
                             const void* rowptr, int rowptr_bits, const void* colidx, int colidx_bits,
                             const uint64_t* vals, const uint64_t* hyper_rows, uint64_t nvec) {
     FGPU_REQUIRE(ctx && out && rowptr, FGPU_NULL_POINTER, "fgpu_mat_from_csr: NULL argument");
@@ -666,7 +694,7 @@ fgpu_info fgpu_mat_from_csr(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint6
     return upload_host_csr(ctx, out, nrows, ncols, hr, hyper, rp, ci, vals ? &vv : nullptr);
 }
 
-fgpu_info fgpu_mat_rmat(fgpu_ctx* ctx, fgpu_mat** out, int scale, int edge_factor, uint64_t seed, uint32_t a16,
+static fgpu_info mat_rmat_impl(fgpu_ctx* ctx, fgpu_mat** out, int scale, int edge_factor, uint64_t seed, uint32_t a16,
                         uint32_t b16, uint32_t c16) {
     FGPU_REQUIRE(ctx && out, FGPU_NULL_POINTER, "fgpu_mat_rmat: NULL argument");
     FGPU_REQUIRE(scale >= 1 && scale <= 30 && edge_factor >= 1, FGPU_INVALID, "fgpu_mat_rmat: scale in [1,30]");
@@ -682,10 +710,26 @@ fgpu_info fgpu_mat_rmat(fgpu_ctx* ctx, fgpu_mat** out, int scale, int edge_facto
     DevBuf<u32> rows, cols;
     FGPU_TRY(rows.alloc(ctx, nedges));
     FGPU_TRY(cols.alloc(ctx, nedges));
-    hipLaunchKernelGGL(rmat_kernel, dim3(ctx->cus * 16), dim3(256), 0, ctx->stream, scale, nedges, seed, a32, ab32,
+    hipLaunchKernelGGL(rmat_kernel, dim3(ctx->cus * 16), dim3(256), 0, ctx->stream(), scale, nedges, seed, a32, ab32,
                        abc32, rows.p, cols.p);
     FGPU_HIP(hipGetLastError());
     return mat_from_device_coo(ctx, out, n, n, rows.p, cols.p, nedges);
+}
+
+fgpu_info fgpu_mat_sample(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t seed, uint32_t denom) {
+    FGPU_REQUIRE(ctx && out && a, FGPU_NULL_POINTER, "fgpu_mat_sample: NULL argument");
+    FGPU_REQUIRE(denom >= 1, FGPU_INVALID, "fgpu_mat_sample: denom must be >= 1");
+    if (a->nnz == 0) return fgpu_mat_new(ctx, out, a->nrows, a->ncols);
+    DevBuf<u32> rows, cols;
+    FGPU_TRY(rows.alloc(ctx, a->nnz));
+    FGPU_TRY(cols.alloc(ctx, a->nnz));
+    u32 grid = cdiv(a->nvec, 4);
+    if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+    hipLaunchKernelGGL(sample_coo_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(a), seed, denom, rows.p,
+                       cols.p);
+    FGPU_HIP(hipGetLastError());
+    FGPU_TRY(mat_from_device_coo(ctx, out, a->nrows, a->ncols, rows.p, cols.p, a->nnz));
+    return ctx->publish();
 }
 
 // ---- export -------------------------------------------------------------------------
@@ -693,19 +737,19 @@ static fgpu_info download_mat(fgpu_ctx* ctx, const fgpu_mat* m, std::vector<u32>
                               std::vector<u64>& vv, std::vector<u32>& hr) {
     rp.resize((size_t)m->nvec + 1);
     ci.resize(m->nnz);
-    FGPU_HIP(hipMemcpyAsync(rp.data(), m->rowptr, rp.size() * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(rp.data(), m->rowptr, rp.size() * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
     if (m->nnz)
-        FGPU_HIP(hipMemcpyAsync(ci.data(), m->colidx, m->nnz * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(ci.data(), m->colidx, m->nnz * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
     if (m->vals && m->nnz) {
         vv.resize(m->nnz);
-        FGPU_HIP(hipMemcpyAsync(vv.data(), m->vals, m->nnz * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(vv.data(), m->vals, m->nnz * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
     }
     if (m->hrows && m->nvec) {
         hr.resize(m->nvec);
         FGPU_HIP(hipMemcpyAsync(hr.data(), m->hrows, (size_t)m->nvec * sizeof(u32), hipMemcpyDeviceToHost,
-                                ctx->stream));
+                                ctx->stream()));
     }
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     return FGPU_OK;
 }
 
@@ -753,8 +797,8 @@ fgpu_info fgpu_mat_extract(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t min_row, u
     if (m->is_hyper()) {
         hr.resize(m->nvec);
         FGPU_HIP(hipMemcpyAsync(hr.data(), m->hrows, (size_t)m->nvec * sizeof(u32), hipMemcpyDeviceToHost,
-                                ctx->stream));
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+                                ctx->stream()));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream()));
         i0 = (u32)(std::lower_bound(hr.begin(), hr.end(), (u32)min_row) - hr.begin());
         i1 = (u32)(std::upper_bound(hr.begin(), hr.end(), (u32)max_row) - hr.begin());
     } else {
@@ -764,18 +808,18 @@ fgpu_info fgpu_mat_extract(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t min_row, u
     if (i0 >= i1) return FGPU_OK;
     std::vector<u32> rp(i1 - i0 + 1);
     FGPU_HIP(hipMemcpyAsync(rp.data(), m->rowptr + i0, rp.size() * sizeof(u32), hipMemcpyDeviceToHost,
-                            ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+                            ctx->stream()));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     u64 b = rp.front(), e = rp.back(), cnt = e - b;
     if (cnt == 0) return FGPU_OK;
     std::vector<u32> ci(cnt);
     std::vector<u64> vv;
-    FGPU_HIP(hipMemcpyAsync(ci.data(), m->colidx + b, cnt * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(ci.data(), m->colidx + b, cnt * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
     if (vals && m->vals) {
         vv.resize(cnt);
-        FGPU_HIP(hipMemcpyAsync(vv.data(), m->vals + b, cnt * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(vv.data(), m->vals + b, cnt * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
     }
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     u64* orow = (u64*)ctx->host_alloc(cnt * sizeof(u64));
     u64* ocol = (u64*)ctx->host_alloc(cnt * sizeof(u64));
     u64* oval = (vals && m->vals) ? (u64*)ctx->host_alloc(cnt * sizeof(u64)) : nullptr;
@@ -801,7 +845,7 @@ fgpu_info fgpu_mat_extract(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t min_row, u
 }
 
 // ---- transpose ---------------------------------------------------------------------
-fgpu_info fgpu_mat_transpose(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
+static fgpu_info mat_transpose_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
     FGPU_REQUIRE(ctx && out && a, FGPU_NULL_POINTER, "fgpu_mat_transpose: NULL argument");
     if (a->vals) return mat_transpose_vals(ctx, out, a);
     return mat_transpose_pattern(ctx, out, a);
@@ -819,15 +863,15 @@ fgpu_info fgpu_mat_probe(fgpu_ctx* ctx, const fgpu_mat* m, const uint64_t* rows,
     FGPU_TRY(dc.alloc(ctx, n));
     FGPU_TRY(dp.alloc(ctx, n));
     if (vals) FGPU_TRY(dv.alloc(ctx, n));
-    FGPU_HIP(hipMemcpyAsync(dr.p, rows, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    FGPU_HIP(hipMemcpyAsync(dc.p, cols, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(probe_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, view_of(m),
+    FGPU_HIP(hipMemcpyAsync(dr.p, rows, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+    FGPU_HIP(hipMemcpyAsync(dc.p, cols, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+    hipLaunchKernelGGL(probe_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream(), view_of(m),
                        (const u64*)m->vals, (const u64*)dr.p, (const u64*)dc.p, n, m->nrows, m->ncols, dp.p,
                        vals ? dv.p : (u64*)nullptr);
     FGPU_HIP(hipGetLastError());
-    FGPU_HIP(hipMemcpyAsync(present, dp.p, n, hipMemcpyDeviceToHost, ctx->stream));
-    if (vals) FGPU_HIP(hipMemcpyAsync(vals, dv.p, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(present, dp.p, n, hipMemcpyDeviceToHost, ctx->stream()));
+    if (vals) FGPU_HIP(hipMemcpyAsync(vals, dv.p, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
+    FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     return FGPU_OK;
 }
 
@@ -847,12 +891,12 @@ fgpu_info mat_merge_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, con
     FGPU_TRY(off.alloc(ctx, nrows + 1));
     FGPU_TRY(tot.alloc(ctx, 1));
     FGPU_TRY(dirty.alloc(ctx, nrows + 1));
-    FGPU_HIP(hipMemsetAsync(dirty.p, 0, nrows + 1, ctx->stream));
-    hipLaunchKernelGGL(row_len_kernel, dim3(cdiv(nrows + 1, 256)), dim3(256), 0, ctx->stream, view_of(m),
+    FGPU_HIP(hipMemsetAsync(dirty.p, 0, nrows + 1, ctx->stream()));
+    hipLaunchKernelGGL(row_len_kernel, dim3(cdiv(nrows + 1, 256)), dim3(256), 0, ctx->stream(), view_of(m),
                        (u32)nrows, ub.p);
     FGPU_HIP(hipGetLastError());
     if (has_dp) {
-        hipLaunchKernelGGL(add_stored_row_len_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(add_stored_row_len_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream(),
                            view_of(dp), ub.p, dirty.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -861,12 +905,12 @@ fgpu_info mat_merge_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, con
     FGPU_TRY(read_u64(ctx, tot.p, &total));
     FGPU_TRY(tmp.alloc(ctx, total));
     FGPU_TRY(cnt.alloc(ctx, nrows + 1));
-    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream()));
     CsrView vm = view_of(m), vdp = has_dp ? view_of(dp) : vm, vdm = has_dm ? view_of(dm) : vm;
     if (nrows) {
         u32 grid = cdiv(nrows, 4);
         if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-        hipLaunchKernelGGL(merge_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, vm, vdp, vdm, has_dp, has_dm,
+        hipLaunchKernelGGL(merge_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream(), vm, vdp, vdm, has_dp, has_dm,
                            dm_masks_dp, (u32)nrows, (const u64*)off.p, tmp.p, cnt.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -880,13 +924,13 @@ fgpu_info mat_merge_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, con
         FGPU_TRY(off2.alloc(ctx, 2 * nrows + 1));
         FGPU_TRY(cnt2.alloc(ctx, 2 * nrows));
         FGPU_TRY(dirty2.alloc(ctx, 2 * nrows));
-        hipLaunchKernelGGL(tight_off_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream, (const u64*)off.p,
+        hipLaunchKernelGGL(tight_off_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream(), (const u64*)off.p,
                            (const u32*)cnt.p, (const uint8_t*)dirty.p, (u32)nrows, off2.p, cnt2.p, dirty2.p);
         FGPU_HIP(hipGetLastError());
         FGPU_HIP(hipMemcpyAsync(off2.p + 2 * nrows, off.p + nrows, sizeof(u64), hipMemcpyDeviceToDevice,
-                                ctx->stream));
+                                ctx->stream()));
         FGPU_TRY(segsort_unique(ctx, tmp.p, off2.p, (u32)(2 * nrows), (u32)m->ncols, cnt2.p, dirty2.p));
-        hipLaunchKernelGGL(take_even_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream, (const u32*)cnt2.p,
+        hipLaunchKernelGGL(take_even_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream(), (const u32*)cnt2.p,
                            (u32)nrows, cnt.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -896,10 +940,10 @@ fgpu_info mat_merge_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, con
     FGPU_TRY(read_u32(ctx, rowptr.p + nrows, &nnz));
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, nrows, m->ncols, nnz, false, 0, false));
-    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()));
     fgpu_info i = compact_segments(ctx, tmp.p, off.p, o->rowptr, (u32)nrows, o->colidx);
     if (i == FGPU_OK) i = mat_finalize(o);
-    if (i != FGPU_OK) { fgpu_mat_free(o); return i; }
+    if (i != FGPU_OK) { mat_release(o); return i; }
     *out = o;
     return FGPU_OK;
 }
@@ -909,12 +953,12 @@ fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp) {
     FGPU_TRY(rp.alloc(ctx, a->nrows + 1));
     if (!a->is_hyper()) {
         FGPU_HIP(hipMemcpyAsync(rp.p, a->rowptr, (a->nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice,
-                                ctx->stream));
+                                ctx->stream()));
         return FGPU_OK;
     }
-    FGPU_HIP(hipMemsetAsync(rp.p, 0, (a->nrows + 1) * sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(rp.p, 0, (a->nrows + 1) * sizeof(u32), ctx->stream()));
     if (a->nvec) {
-        hipLaunchKernelGGL(dense_rowptr_len_kernel, dim3(cdiv(a->nvec, 256)), dim3(256), 0, ctx->stream, view_of(a),
+        hipLaunchKernelGGL(dense_rowptr_len_kernel, dim3(cdiv(a->nvec, 256)), dim3(256), 0, ctx->stream(), view_of(a),
                            rp.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -925,7 +969,7 @@ fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp) {
 
 extern "C" {
 
-fgpu_info fgpu_mat_merge(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
+static fgpu_info mat_merge_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
                          int dm_masks_dp) {
     FGPU_REQUIRE(ctx && out && m, FGPU_NULL_POINTER, "fgpu_mat_merge: NULL argument");
     FGPU_REQUIRE(!dp || (dp->nrows == m->nrows && dp->ncols == m->ncols), FGPU_DIM_MISMATCH,
@@ -947,11 +991,11 @@ static fgpu_info intersect_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a
     FGPU_TRY(tmp.alloc(ctx, a->nnz));
     const bool with_vals = (out != nullptr) && b->vals;
     if (with_vals) FGPU_TRY(tmpv.alloc(ctx, a->nnz));
-    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream()));
     if (nrows && a->nnz && b->nnz) {
         u32 grid = cdiv(nrows, 4);
         if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-        hipLaunchKernelGGL(intersect_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(a), view_of(b),
+        hipLaunchKernelGGL(intersect_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(a), view_of(b),
                            (const u64*)b->vals, (u32)nrows, tmp.p, with_vals ? tmpv.p : (u64*)nullptr, cnt.p,
                            (const u32*)arp.p);
         FGPU_HIP(hipGetLastError());
@@ -964,22 +1008,22 @@ static fgpu_info intersect_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a
     if (!out) return FGPU_OK;
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, nrows, a->ncols, nnz, with_vals, 0, false));
-    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()));
     if (nrows && nnz) {
         u32 grid = cdiv(nrows, 4);
         if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-        hipLaunchKernelGGL(compact32_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const u32*)tmp.p,
+        hipLaunchKernelGGL(compact32_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const u32*)tmp.p,
                            (const u64*)(with_vals ? tmpv.p : nullptr), (const u32*)arp.p, (const u32*)o->rowptr,
                            (u32)nrows, o->colidx, o->vals);
         FGPU_HIP(hipGetLastError());
     }
     fgpu_info i = mat_finalize(o);
-    if (i != FGPU_OK) { fgpu_mat_free(o); return i; }
+    if (i != FGPU_OK) { mat_release(o); return i; }
     *out = o;
     return FGPU_OK;
 }
 
-fgpu_info fgpu_mat_intersect(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, const fgpu_mat* b) {
+static fgpu_info mat_intersect_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, const fgpu_mat* b) {
     FGPU_REQUIRE(ctx && out && a && b, FGPU_NULL_POINTER, "fgpu_mat_intersect: NULL argument");
     return intersect_impl(ctx, out, a, b, nullptr);
 }
@@ -994,15 +1038,15 @@ fgpu_info fgpu_mat_row_degrees(fgpu_ctx* ctx, const fgpu_mat* a, uint32_t* out_d
     DevBuf<u32> rp;
     FGPU_TRY(dense_rowptr(ctx, a, rp));
     if (a->nrows) {
-        hipLaunchKernelGGL(row_degree_kernel, dim3(cdiv(a->nrows, 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(row_degree_kernel, dim3(cdiv(a->nrows, 256)), dim3(256), 0, ctx->stream(),
                            (const u32*)rp.p, (u32)a->nrows, out_dev);
         FGPU_HIP(hipGetLastError());
     }
-    FGPU_HIP(hipStreamSynchronize(ctx->stream));   // `rp` may return to the pool
+    FGPU_HIP(hipStreamSynchronize(ctx->stream()));   // `rp` may return to the pool
     return FGPU_OK;
 }
 
-fgpu_info fgpu_mat_col_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo, uint64_t hi) {
+static fgpu_info mat_col_slab_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo, uint64_t hi) {
     FGPU_REQUIRE(ctx && out && a, FGPU_NULL_POINTER, "fgpu_mat_col_slab: NULL argument");
     FGPU_REQUIRE(!a->is_hyper() && !a->vals, FGPU_INVALID, "fgpu_mat_col_slab: needs a non-hypersparse pattern matrix");
     if (hi > a->ncols) hi = a->ncols;
@@ -1010,9 +1054,9 @@ fgpu_info fgpu_mat_col_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, ui
     const u64 nrows = a->nrows;
     DevBuf<u32> cnt, rowptr;
     FGPU_TRY(cnt.alloc(ctx, nrows + 1));
-    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream()));
     if (nrows) {
-        hipLaunchKernelGGL(col_slab_count_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream, view_of(a),
+        hipLaunchKernelGGL(col_slab_count_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream(), view_of(a),
                            (u32)lo, (u32)hi, cnt.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -1022,21 +1066,21 @@ fgpu_info fgpu_mat_col_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, ui
     FGPU_TRY(read_u32(ctx, rowptr.p + nrows, &nnz));
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, nrows, a->ncols, nnz, false, 0, false));
-    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()));
     if (nrows && nnz) {
         u32 grid = cdiv(nrows, 4);
         if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-        hipLaunchKernelGGL(col_slab_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(a), (u32)lo,
+        hipLaunchKernelGGL(col_slab_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(a), (u32)lo,
                            (u32)hi, (const u32*)o->rowptr, o->colidx);
         FGPU_HIP(hipGetLastError());
     }
     fgpu_info i = mat_finalize(o);
-    if (i != FGPU_OK) { fgpu_mat_free(o); return i; }
+    if (i != FGPU_OK) { mat_release(o); return i; }
     *out = o;
     return FGPU_OK;
 }
 
-fgpu_info fgpu_mat_row_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo, uint64_t hi) {
+static fgpu_info mat_row_slab_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo, uint64_t hi) {
     FGPU_REQUIRE(ctx && out && a, FGPU_NULL_POINTER, "fgpu_mat_row_slab: NULL argument");
     FGPU_REQUIRE(!a->is_hyper() && !a->vals, FGPU_INVALID, "fgpu_mat_row_slab: needs a non-hypersparse pattern matrix");
     if (hi > a->nrows) hi = a->nrows;
@@ -1044,7 +1088,7 @@ fgpu_info fgpu_mat_row_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, ui
     const u64 nrows = a->nrows;
     DevBuf<u32> cnt, rowptr;
     FGPU_TRY(cnt.alloc(ctx, nrows + 1));
-    hipLaunchKernelGGL(row_slab_count_kernel, dim3(cdiv(nrows + 1, 256)), dim3(256), 0, ctx->stream, view_of(a),
+    hipLaunchKernelGGL(row_slab_count_kernel, dim3(cdiv(nrows + 1, 256)), dim3(256), 0, ctx->stream(), view_of(a),
                        (u32)lo, (u32)hi, cnt.p);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY(rowptr.alloc(ctx, nrows + 1));
@@ -1053,18 +1097,82 @@ fgpu_info fgpu_mat_row_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, ui
     FGPU_TRY(read_u32(ctx, rowptr.p + nrows, &nnz));
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, nrows, a->ncols, nnz, false, 0, false));
-    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()));
     if (nnz) {
         // rows [lo,hi) are contiguous in a's colidx
         u32 b = 0;
         FGPU_TRY(read_u32(ctx, a->rowptr + lo, &b));
         FGPU_HIP(hipMemcpyAsync(o->colidx, a->colidx + b, (size_t)nnz * sizeof(u32), hipMemcpyDeviceToDevice,
-                                ctx->stream));
+                                ctx->stream()));
     }
     fgpu_info i = mat_finalize(o);
-    if (i != FGPU_OK) { fgpu_mat_free(o); return i; }
+    if (i != FGPU_OK) { mat_release(o); return i; }
     *out = o;
     return FGPU_OK;
+}
+
+}  // extern "C"
+
+// Public producers of snapshots: the implementation above, then fgpu_ctx::publish().
+extern "C" {
+
+fgpu_info fgpu_mat_new(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols) {
+    fgpu_info i_ = mat_new_impl(ctx, out, nrows, ncols);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_from_coo(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols, const uint64_t* rows,
+                            const uint64_t* cols, const uint64_t* vals, uint64_t n) {
+    fgpu_info i_ = mat_from_coo_impl(ctx, out, nrows, ncols, rows, cols, vals, n);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_from_csr(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows, uint64_t ncols, uint64_t nnz,
+                            const void* rowptr, int rowptr_bits, const void* colidx, int colidx_bits,
+                            const uint64_t* vals, const uint64_t* hyper_rows, uint64_t nvec) {
+    fgpu_info i_ = mat_from_csr_impl(ctx, out, nrows, ncols, nnz, rowptr, rowptr_bits, colidx, colidx_bits, vals, hyper_rows, nvec);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_rmat(fgpu_ctx* ctx, fgpu_mat** out, int scale, int edge_factor, uint64_t seed, uint32_t a16,
+                        uint32_t b16, uint32_t c16) {
+    fgpu_info i_ = mat_rmat_impl(ctx, out, scale, edge_factor, seed, a16, b16, c16);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_transpose(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
+    fgpu_info i_ = mat_transpose_impl(ctx, out, a);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_merge(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
+                         int dm_masks_dp) {
+    fgpu_info i_ = mat_merge_impl(ctx, out, m, dp, dm, dm_masks_dp);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_intersect(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, const fgpu_mat* b) {
+    fgpu_info i_ = mat_intersect_impl(ctx, out, a, b);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_col_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo, uint64_t hi) {
+    fgpu_info i_ = mat_col_slab_impl(ctx, out, a, lo, hi);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_row_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo, uint64_t hi) {
+    fgpu_info i_ = mat_row_slab_impl(ctx, out, a, lo, hi);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
 }
 
 }  // extern "C"

@@ -228,22 +228,24 @@ static fgpu_info layer_of(fgpu_ctx* ctx, const fgpu_mat* a, Layer& l) {
     l.nnz = (u32)a->nnz;
     l.wordrow = nullptr;
     if (a->nnz == 0) return FGPU_OK;
-    fgpu_mat* aa = const_cast<fgpu_mat*>(a);
-    if (!aa->wordrow) {
+    std::lock_guard<std::mutex> idx_guard(a->idx_mu);
+    if (!a->wordrow) {
         const u32 nwords = (u32)((a->nnz + 63) >> 6);
         u32* wr = nullptr;
         FGPU_TRY(ctx->dev_alloc((void**)&wr, ((size_t)nwords + 1) * sizeof(u32)));
-        hipLaunchKernelGGL(wordrow_kernel, dim3(cdiv((u64)nwords + 1, 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(wordrow_kernel, dim3(cdiv((u64)nwords + 1, 256)), dim3(256), 0, ctx->stream(),
                            (const u32*)a->rowptr, a->nvec, nwords, wr);
         hipError_t e = hipGetLastError();
+        // complete on the device before it is published: other lanes read it from their own streams
+        if (e == hipSuccess && ctx->multi_lane()) e = hipStreamSynchronize(ctx->stream());
         if (e != hipSuccess) {
             ctx->dev_free(wr);
-            set_error("wordrow launch failed: %s", hipGetErrorString(e));
+            set_error("wordrow build failed: %s", hipGetErrorString(e));
             return FGPU_DEVICE;
         }
-        aa->wordrow = wr;
+        a->wordrow = wr;
     }
-    l.wordrow = aa->wordrow;
+    l.wordrow = a->wordrow;
     return FGPU_OK;
 }
 
@@ -255,8 +257,8 @@ struct Keep {  // keep bits + exclusive prefix of their per-word popcounts
         FGPU_TRY(kb.alloc(ctx, (size_t)nwords + 1));
         FGPU_TRY(ks.alloc(ctx, (size_t)nwords + 1));
         // the word past the end is read by kept_before(nnz) when nnz is a multiple of 64
-        FGPU_HIP(hipMemsetAsync(kb.p + nwords, 0, sizeof(u64), ctx->stream));
-        FGPU_HIP(hipMemsetAsync(ks.p + nwords, 0, sizeof(u32), ctx->stream));
+        FGPU_HIP(hipMemsetAsync(kb.p + nwords, 0, sizeof(u64), ctx->stream()));
+        FGPU_HIP(hipMemsetAsync(ks.p + nwords, 0, sizeof(u32), ctx->stream()));
         return FGPU_OK;
     }
 };
@@ -283,25 +285,25 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     if (has_dp || has_dm) {
         const size_t nb = (size_t)(max_rows >> 5) + 2;
         FGPU_TRY(rowbits.alloc(ctx, nb));
-        FGPU_HIP(hipMemsetAsync(rowbits.p, 0, nb * sizeof(u32), ctx->stream));
+        FGPU_HIP(hipMemsetAsync(rowbits.p, 0, nb * sizeof(u32), ctx->stream()));
         if (has_dp)
-            hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream, lp.v, rowbits.p);
+            hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream(), lp.v, rowbits.p);
         if (has_dm)
-            hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dm->nvec, 256)), dim3(256), 0, ctx->stream, ld.v, rowbits.p);
+            hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dm->nvec, 256)), dim3(256), 0, ctx->stream(), ld.v, rowbits.p);
         FGPU_HIP(hipGetLastError());
     }
     Keep km, kp;
     FGPU_TRY(km.alloc(ctx, lm.nnz));
     FGPU_TRY(kp.alloc(ctx, has_dp ? lp.nnz : 0));
     if (lm.nnz) {
-        hipLaunchKernelGGL(merge_mark_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream, lm, lp,
+        hipLaunchKernelGGL(merge_mark_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream(), lm, lp,
                            ld, has_dp, has_dm, dm_masks_dp, (const u32*)rowbits.p, (u32)out_nrows, (u32)out_ncols,
                            km.kb.p, km.ks.p, clip);
         FGPU_HIP(hipGetLastError());
     }
     FGPU_TRY(scan_u32(ctx, km.ks.p, km.ks.p, ((u64)(lm.nnz + 63) >> 6) + 1, nullptr));
     if (has_dp) {
-        hipLaunchKernelGGL(merge_mark_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream, lp, lm,
+        hipLaunchKernelGGL(merge_mark_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream(), lp, lm,
                            ld, lm.nnz != 0, has_dm, dm_masks_dp, (const u32*)rowbits.p, (u32)out_nrows,
                            (u32)out_ncols, kp.kb.p, kp.ks.p, clip);
         FGPU_HIP(hipGetLastError());
@@ -309,7 +311,7 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     }
     DevBuf<u32> orp;
     FGPU_TRY(orp.alloc(ctx, out_nrows + 1));
-    hipLaunchKernelGGL(merge_rowlen_kernel, dim3(cdiv(out_nrows + 1, 256)), dim3(256), 0, ctx->stream, lm, lp, has_dp,
+    hipLaunchKernelGGL(merge_rowlen_kernel, dim3(cdiv(out_nrows + 1, 256)), dim3(256), 0, ctx->stream(), lm, lp, has_dp,
                        (const u32*)rowbits.p, (const u64*)km.kb.p, (const u32*)km.ks.p, (const u64*)kp.kb.p,
                        (const u32*)kp.ks.p, (u32)out_nrows, orp.p);
     FGPU_HIP(hipGetLastError());
@@ -319,24 +321,24 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, out_nrows, out_ncols, nnz, with_vals, 0, false));
     hipError_t e = hipMemcpyAsync(o->rowptr, orp.p, (out_nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice,
-                                  ctx->stream);
+                                  ctx->stream());
     if (e == hipSuccess && lm.nnz && nnz) {
-        hipLaunchKernelGGL(merge_scatter_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream, lm,
+        hipLaunchKernelGGL(merge_scatter_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream(), lm,
                            lp, has_dp, (const u32*)rowbits.p, (const u64*)km.kb.p, (const u32*)km.ks.p,
                            (const u64*)kp.kb.p, (const u32*)kp.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip);
         e = hipGetLastError();
     }
     if (e == hipSuccess && has_dp && nnz) {
-        hipLaunchKernelGGL(merge_scatter_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream, lp,
+        hipLaunchKernelGGL(merge_scatter_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream(), lp,
                            lm, lm.nnz != 0, (const u32*)rowbits.p, (const u64*)kp.kb.p, (const u32*)kp.ks.p,
                            (const u64*)km.kb.p, (const u32*)km.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip);
         e = hipGetLastError();
     }
     // the scratch buffers above go back to the pool when this returns: the kernels reading them must be done
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
     if (e != hipSuccess) {
         set_error("merge failed: %s", hipGetErrorString(e));
-        fgpu_mat_free(o);
+        mat_release(o);
         return FGPU_DEVICE;
     }
     // hub list / max degree are computed when a BFS plan first needs them (mat_ensure_finalized)
@@ -375,21 +377,21 @@ fgpu_info mat_from_device_coo_vals(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64
         if (a->nnz == 0) break;
         DevBuf<u32> win;
         if ((i = win.alloc(ctx, a->nnz)) != FGPU_OK) break;
-        hipError_t e = hipMemsetAsync(win.p, 0, a->nnz * sizeof(u32), ctx->stream);
+        hipError_t e = hipMemsetAsync(win.p, 0, a->nnz * sizeof(u32), ctx->stream());
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(coo_winner_kernel, dim3(ctx->cus * 16), dim3(256), 0, ctx->stream, rows, cols, n,
+            hipLaunchKernelGGL(coo_winner_kernel, dim3(ctx->cus * 16), dim3(256), 0, ctx->stream(), rows, cols, n,
                                (const u32*)a->rowptr, (const u32*)a->colidx, win.p);
-            hipLaunchKernelGGL(coo_take_winner_kernel, dim3(cdiv(a->nnz, 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(coo_take_winner_kernel, dim3(cdiv(a->nnz, 256)), dim3(256), 0, ctx->stream(),
                                (const u32*)win.p, vals, (u32)a->nnz, a->vals);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `win` returns to the pool
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());  // `win` returns to the pool
         if (e != hipSuccess) {
             set_error("valued COO build failed: %s", hipGetErrorString(e));
             i = FGPU_DEVICE;
         }
     } while (0);
-    if (i != FGPU_OK) { fgpu_mat_free(a); return i; }
+    if (i != FGPU_OK) { mat_release(a); return i; }
     *out = a;
     return FGPU_OK;
 }
@@ -426,16 +428,16 @@ fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
         if (a->nnz == 0) break;
         Layer la{};
         if ((i = layer_of(ctx, a, la)) != FGPU_OK) break;
-        hipLaunchKernelGGL(transpose_vals_kernel, dim3(entry_grid(ctx, la.nnz)), dim3(256), 0, ctx->stream, la,
+        hipLaunchKernelGGL(transpose_vals_kernel, dim3(entry_grid(ctx, la.nnz)), dim3(256), 0, ctx->stream(), la,
                            (const u32*)t->rowptr, (const u32*)t->colidx, t->vals);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
         if (e != hipSuccess) {
             set_error("valued transpose failed: %s", hipGetErrorString(e));
             i = FGPU_DEVICE;
         }
     } while (0);
-    if (i != FGPU_OK) { fgpu_mat_free(t); return i; }
+    if (i != FGPU_OK) { mat_release(t); return i; }
     *out = t;
     return FGPU_OK;
 }
@@ -444,14 +446,14 @@ fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
 
 extern "C" {
 
-fgpu_info fgpu_mat_resize(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t nrows, uint64_t ncols) {
+static fgpu_info mat_resize_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t nrows, uint64_t ncols) {
     FGPU_REQUIRE(ctx && out && a, FGPU_NULL_POINTER, "fgpu_mat_resize: NULL argument");
     FGPU_REQUIRE(nrows < 0xFFFFFFFFull && ncols < 0xFFFFFFFFull, FGPU_INVALID,
                  "fgpu_mat_resize: dims exceed the 32-bit id space");
     return fgpu::mat_merge_entries(ctx, out, a, nullptr, nullptr, false, nrows, ncols, false);
 }
 
-fgpu_info fgpu_mat_merge_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
+static fgpu_info mat_merge_pattern_impl(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
                                  const fgpu_mat* dm, int dm_masks_dp) {
     FGPU_REQUIRE(ctx && out && m, FGPU_NULL_POINTER, "fgpu_mat_merge_pattern: NULL argument");
     FGPU_REQUIRE(!dp || (dp->nrows == m->nrows && dp->ncols == m->ncols), FGPU_DIM_MISMATCH,
@@ -459,6 +461,24 @@ fgpu_info fgpu_mat_merge_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* 
     FGPU_REQUIRE(!dm || (dm->nrows == m->nrows && dm->ncols == m->ncols), FGPU_DIM_MISMATCH,
                  "fgpu_mat_merge_pattern: dm dims differ from m");
     return fgpu::mat_merge_entries(ctx, out, m, dp, dm, dm_masks_dp != 0, m->nrows, m->ncols, true);
+}
+
+}  // extern "C"
+
+// Public producers of snapshots: the implementation above, then fgpu_ctx::publish().
+extern "C" {
+
+fgpu_info fgpu_mat_merge_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, const fgpu_mat* dp,
+                                 const fgpu_mat* dm, int dm_masks_dp) {
+    fgpu_info i_ = mat_merge_pattern_impl(ctx, out, m, dp, dm, dm_masks_dp);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_mat_resize(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t nrows, uint64_t ncols) {
+    fgpu_info i_ = mat_resize_impl(ctx, out, a, nrows, ncols);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
 }
 
 }  // extern "C"

@@ -239,7 +239,7 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
     if (info == FGPU_OK && At->is_hyper()) {
         fgpu_mat* dense = nullptr;
         info = mat_merge_entries(ctx, &dense, At, nullptr, nullptr, false, At->nrows, At->ncols, true);
-        if (dAt) fgpu_mat_free(dAt);
+        if (dAt) mat_release(dAt);
         dAt = dense;
         At = dense;
     }
@@ -261,9 +261,9 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
                 n_act += (u64)__builtin_popcountll(x);
             }
             FGPU_TRY(act.alloc(ctx, words));
-            FGPU_HIP(hipMemcpyAsync(act.p, active_bitmap, words * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            FGPU_HIP(hipMemcpyAsync(act.p, active_bitmap, words * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
             FGPU_TRY(deg.alloc(ctx, n));
-            hipLaunchKernelGGL(pr_degree_kernel, dim3(nb), dim3(256), 0, ctx->stream, view_of(A), (const u64*)act.p, n,
+            hipLaunchKernelGGL(pr_degree_kernel, dim3(nb), dim3(256), 0, ctx->stream(), view_of(A), (const u64*)act.p, n,
                                deg.p);
             FGPU_HIP(hipGetLastError());
         }
@@ -280,7 +280,7 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
             return FGPU_OK;
         }
         const float fn = (float)n_act;
-        hipLaunchKernelGGL(pr_init_kernel, dim3(nb), dim3(256), 0, ctx->stream, view_of(A), (const u64*)act.p,
+        hipLaunchKernelGGL(pr_init_kernel, dim3(nb), dim3(256), 0, ctx->stream(), view_of(A), (const u64*)act.p,
                            (const u32*)deg.p, n, 1.0f / fn, damping, r.p, d.p, sink.p);
         FGPU_HIP(hipGetLastError());
         const float teleport0 = (1.0f - damping) / fn, damp_over_n = damping / fn;
@@ -295,33 +295,33 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
         if (timing) for (auto& e : ev) (void)hipEventCreate(&e);
         for (; it < itermax && rdiff > tol; ++it) {
             float* tmp = tp; tp = rp; rp = tmp;   // t = old r
-            if (timing) (void)hipEventRecord(ev[0], ctx->stream);
-            hipLaunchKernelGGL(pr_prep_kernel, dim3(nb), dim3(256), 0, ctx->stream, (const float*)tp,
+            if (timing) (void)hipEventRecord(ev[0], ctx->stream());
+            hipLaunchKernelGGL(pr_prep_kernel, dim3(nb), dim3(256), 0, ctx->stream(), (const float*)tp,
                                (const float*)d.p, (const unsigned char*)sink.p, (const u64*)act.p, n, w.p, part.p);
-            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)part.p, nb,
+            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const float*)part.p, nb,
                                teleport0, damp_over_n, scal.p);
-            if (timing) (void)hipEventRecord(ev[1], ctx->stream);
-            hipLaunchKernelGGL(pr_spmv_kernel, dim3(grid), dim3(256), 0, ctx->stream, vat, (const u64*)act.p, n,
+            if (timing) (void)hipEventRecord(ev[1], ctx->stream());
+            hipLaunchKernelGGL(pr_spmv_kernel, dim3(grid), dim3(256), 0, ctx->stream(), vat, (const u64*)act.p, n,
                                (const float*)w.p, (const float*)scal.p, (const float*)tp, rp, part2.p + 1);
-            if (timing) (void)hipEventRecord(ev[2], ctx->stream);
+            if (timing) (void)hipEventRecord(ev[2], ctx->stream());
             if (At->n_hub_chunks) {
                 const u32 hg = At->n_hub_chunks < (u32)ctx->cus * 8 ? At->n_hub_chunks : (u32)ctx->cus * 8;
-                hipLaunchKernelGGL(pr_hub_kernel, dim3(hg), dim3(256), 0, ctx->stream, (const u32*)At->hub_chunks,
+                hipLaunchKernelGGL(pr_hub_kernel, dim3(hg), dim3(256), 0, ctx->stream(), (const u32*)At->hub_chunks,
                                    At->n_hub_chunks, (const u32*)At->colidx, (const u64*)act.p, (const float*)w.p, rp);
-                hipLaunchKernelGGL(pr_hub_diff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const u32*)At->hub_chunks,
+                hipLaunchKernelGGL(pr_hub_diff_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const u32*)At->hub_chunks,
                                    At->n_hub_chunks, (const u32*)At->rowptr, (const float*)tp, (const float*)rp,
                                    part2.p);
             } else {
-                FGPU_HIP(hipMemsetAsync(part2.p, 0, sizeof(float), ctx->stream));
+                FGPU_HIP(hipMemsetAsync(part2.p, 0, sizeof(float), ctx->stream()));
             }
-            if (timing) (void)hipEventRecord(ev[3], ctx->stream);
-            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)part2.p, grid + 1,
+            if (timing) (void)hipEventRecord(ev[3], ctx->stream());
+            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const float*)part2.p, grid + 1,
                                0.0f, 1.0f, scal.p + 1);
-            if (timing) (void)hipEventRecord(ev[4], ctx->stream);
+            if (timing) (void)hipEventRecord(ev[4], ctx->stream());
             FGPU_HIP(hipGetLastError());
-            FGPU_HIP(hipMemcpyAsync(ctx->pinned, scal.p + 1, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-            FGPU_HIP(hipStreamSynchronize(ctx->stream));
-            memcpy(&rdiff, ctx->pinned, sizeof(float));
+            FGPU_HIP(hipMemcpyAsync(ctx->pinned(), scal.p + 1, sizeof(float), hipMemcpyDeviceToHost, ctx->stream()));
+            FGPU_HIP(hipStreamSynchronize(ctx->stream()));
+            memcpy(&rdiff, ctx->pinned(), sizeof(float));
             if (timing) {
                 for (int k = 0; k < 4; ++k) {
                     float ms = 0;
@@ -337,12 +337,12 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
             for (auto& e : ev) (void)hipEventDestroy(e);
         }
         if (iters) *iters = it;
-        FGPU_HIP(hipMemcpyAsync(centrality, rp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        FGPU_HIP(hipStreamSynchronize(ctx->stream));
+        FGPU_HIP(hipMemcpyAsync(centrality, rp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream()));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream()));
         return FGPU_OK;
     };
     if (info == FGPU_OK) info = run();
-    if (dA) fgpu_mat_free(dA);
-    if (dAt) fgpu_mat_free(dAt);
+    if (dA) mat_release(dA);
+    if (dAt) mat_release(dAt);
     return info;
 }

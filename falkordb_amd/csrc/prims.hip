@@ -99,23 +99,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const Tin* __r
 template <typename Tin, typename Tout>
 static fgpu_info scan_impl(fgpu_ctx* ctx, const Tin* in, Tout* out, u64 n, Tout* total_dev) {
     if (n == 0) {
-        if (total_dev) FGPU_HIP(hipMemsetAsync(total_dev, 0, sizeof(Tout), ctx->stream));
+        if (total_dev) FGPU_HIP(hipMemsetAsync(total_dev, 0, sizeof(Tout), ctx->stream()));
         return FGPU_OK;
     }
     u32 nblocks = cdiv(n, SCAN_TILE);
     if (nblocks == 1) {
-        hipLaunchKernelGGL((scan_apply_kernel<Tin, Tout>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, out,
+        hipLaunchKernelGGL((scan_apply_kernel<Tin, Tout>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream(), in, out,
                            n, (const Tout*)nullptr, total_dev);
         FGPU_HIP(hipGetLastError());
         return FGPU_OK;
     }
     DevBuf<Tout> sums;
     FGPU_TRY(sums.alloc(ctx, nblocks));
-    hipLaunchKernelGGL((scan_reduce_kernel<Tin, Tout>), dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, in,
+    hipLaunchKernelGGL((scan_reduce_kernel<Tin, Tout>), dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream(), in,
                        n, sums.p);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY((scan_impl<Tout, Tout>(ctx, sums.p, sums.p, nblocks, (Tout*)nullptr)));
-    hipLaunchKernelGGL((scan_apply_kernel<Tin, Tout>), dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream, in,
+    hipLaunchKernelGGL((scan_apply_kernel<Tin, Tout>), dim3(nblocks), dim3(SCAN_THREADS), 0, ctx->stream(), in,
                        out, n, (const Tout*)sums.p, total_dev);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
@@ -303,11 +303,11 @@ fgpu_info segsort_unique(fgpu_ctx* ctx, u32* data, const u64* off, u32 nseg, u32
     FGPU_TRY(mid.alloc(ctx, nseg));
     FGPU_TRY(big.alloc(ctx, nseg));
     FGPU_TRY(counts.alloc(ctx, 2));
-    FGPU_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(counts.p, 0, 2 * sizeof(u32), ctx->stream()));
     // a wavefront per segment: 2^26 rows (RMAT-26) would be 2^32 threads in one grid, past what a launch accepts
     for (u64 base = 0; base < nseg; base += (1ull << 24)) {
         const u32 part = (u32)((nseg - base < (1ull << 24)) ? nseg - base : (1ull << 24));
-        hipLaunchKernelGGL(segsort_wave_kernel, dim3(cdiv(part, 4)), dim3(256), 0, ctx->stream, data, off, nseg, cnt,
+        hipLaunchKernelGGL(segsort_wave_kernel, dim3(cdiv(part, 4)), dim3(256), 0, ctx->stream(), data, off, nseg, cnt,
                            mid.p, big.p, counts.p, dirty, (u32)base);
         FGPU_HIP(hipGetLastError());
     }
@@ -315,7 +315,7 @@ fgpu_info segsort_unique(fgpu_ctx* ctx, u32* data, const u64* off, u32 nseg, u32
     {
         u32 grid = ctx->cus * 8;
         if (grid > nseg) grid = nseg;
-        hipLaunchKernelGGL(segsort_block_kernel, dim3(grid), dim3(256), 0, ctx->stream, data, off, mid.p, counts.p,
+        hipLaunchKernelGGL(segsort_block_kernel, dim3(grid), dim3(256), 0, ctx->stream(), data, off, mid.p, counts.p,
                            cnt);
         FGPU_HIP(hipGetLastError());
     }
@@ -331,13 +331,13 @@ fgpu_info segsort_unique(fgpu_ctx* ctx, u32* data, const u64* off, u32 nseg, u32
         if (slots > 65535) slots = 65535;
         DevBuf<u32> bitmaps;
         FGPU_TRY(bitmaps.alloc(ctx, (size_t)slots * words));
-        FGPU_HIP(hipMemsetAsync(bitmaps.p, 0, (size_t)slots * words * sizeof(u32), ctx->stream));
+        FGPU_HIP(hipMemsetAsync(bitmaps.p, 0, (size_t)slots * words * sizeof(u32), ctx->stream()));
         for (u32 first = 0; first < nbig; first += slots) {
             u32 ns = (nbig - first < slots) ? (nbig - first) : slots;
-            hipLaunchKernelGGL(segsort_big_scatter_kernel, dim3(64, ns), dim3(256), 0, ctx->stream, data, off,
+            hipLaunchKernelGGL(segsort_big_scatter_kernel, dim3(64, ns), dim3(256), 0, ctx->stream(), data, off,
                                big.p, first, ns, bitmaps.p, words);
             FGPU_HIP(hipGetLastError());
-            hipLaunchKernelGGL(segsort_big_emit_kernel, dim3(ns), dim3(1024), 0, ctx->stream, data, off, big.p,
+            hipLaunchKernelGGL(segsort_big_emit_kernel, dim3(ns), dim3(1024), 0, ctx->stream(), data, off, big.p,
                                first, bitmaps.p, words, cnt);
             FGPU_HIP(hipGetLastError());
         }
@@ -371,7 +371,7 @@ fgpu_info compact_segments(fgpu_ctx* ctx, const u32* data, const u64* off, const
     u32 grid = cdiv(nseg, 4);
     u32 cap = ctx->cus * 16;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(compact_segments_kernel, dim3(grid), dim3(256), 0, ctx->stream, data, off, rowptr, nseg,
+    hipLaunchKernelGGL(compact_segments_kernel, dim3(grid), dim3(256), 0, ctx->stream(), data, off, rowptr, nseg,
                        col_out);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;

@@ -127,7 +127,7 @@ static fgpu_info mxm_flops(fgpu_ctx* ctx, const fgpu_mat* F, const fgpu_mat* B, 
     FGPU_TRY(deg.alloc(ctx, (size_t)nnzf + 1));
     FGPU_TRY(eoff.alloc(ctx, (size_t)nnzf + 1));
     FGPU_TRY(tot.alloc(ctx, 1));
-    hipLaunchKernelGGL(entry_deg_kernel, dim3(cdiv((u64)nnzf + 1, 256)), dim3(256), 0, ctx->stream, view_of(F),
+    hipLaunchKernelGGL(entry_deg_kernel, dim3(cdiv((u64)nnzf + 1, 256)), dim3(256), 0, ctx->stream(), view_of(F),
                        view_of(B), nnzf, deg.p);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY(scan_u32_to_u64(ctx, deg.p, eoff.p, (u64)nnzf + 1, tot.p));
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void checksum_entries_kernel(CsrView c, u32 nr
 static fgpu_info empty_dense(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols) {
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, nrows, ncols, 0, false, 0, false));
-    hipError_t e = hipMemsetAsync(o->rowptr, 0, (nrows + 1) * sizeof(u32), ctx->stream);
-    if (e != hipSuccess) { fgpu_mat_free(o); set_error("memset failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+    hipError_t e = hipMemsetAsync(o->rowptr, 0, (nrows + 1) * sizeof(u32), ctx->stream());
+    if (e != hipSuccess) { mat_release(o); set_error("memset failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
     *out = o;
     return FGPU_OK;
 }
@@ -175,14 +175,14 @@ fgpu_info mxm_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* F, const fgp
     FGPU_TRY(deg.alloc(ctx, (size_t)nnzf + 1));
     FGPU_TRY(eoff.alloc(ctx, (size_t)nnzf + 1));
     FGPU_TRY(tot.alloc(ctx, 1));
-    hipLaunchKernelGGL(entry_deg_kernel, dim3(cdiv((u64)nnzf + 1, 256)), dim3(256), 0, ctx->stream, view_of(F),
+    hipLaunchKernelGGL(entry_deg_kernel, dim3(cdiv((u64)nnzf + 1, 256)), dim3(256), 0, ctx->stream(), view_of(F),
                        view_of(B), nnzf, deg.p);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY(scan_u32_to_u64(ctx, deg.p, eoff.p, (u64)nnzf + 1, tot.p));
     FGPU_TRY(roff.alloc(ctx, k + 1));
     FGPU_TRY(maxlen.alloc(ctx, 1));
-    FGPU_HIP(hipMemsetAsync(maxlen.p, 0, sizeof(u32), ctx->stream));
-    hipLaunchKernelGGL(gather_u64_kernel, dim3(cdiv(k + 1, 256)), dim3(256), 0, ctx->stream, (const u64*)eoff.p,
+    FGPU_HIP(hipMemsetAsync(maxlen.p, 0, sizeof(u32), ctx->stream()));
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(cdiv(k + 1, 256)), dim3(256), 0, ctx->stream(), (const u64*)eoff.p,
                        (const u32*)frp.p, (u32)k, roff.p, maxlen.p);
     FGPU_HIP(hipGetLastError());
     u64 T = 0;
@@ -197,19 +197,21 @@ fgpu_info mxm_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* F, const fgp
     DevBuf<u32> tmp;
     FGPU_TRY(tmp.alloc(ctx, T));
     {
+        ProfScope ps(ctx, "gather_rows_kernel", 12 * (u64)nnzf + 8 * T);   // F entry + B row-pointer pair, B row read + written
         u32 grid = cdiv(nnzf, 4);
         if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(F), view_of(B), nnzf,
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(F), view_of(B), nnzf,
                            (const u64*)eoff.p, tmp.p);
         FGPU_HIP(hipGetLastError());
     }
     FGPU_TRY(cnt.alloc(ctx, k + 1));
     if (ml <= 1) {
-        hipLaunchKernelGGL(seg_len_kernel, dim3(cdiv(k + 1, 256)), dim3(256), 0, ctx->stream, (const u64*)roff.p,
+        hipLaunchKernelGGL(seg_len_kernel, dim3(cdiv(k + 1, 256)), dim3(256), 0, ctx->stream(), (const u64*)roff.p,
                            (u32)k, cnt.p);
         FGPU_HIP(hipGetLastError());
     } else {
-        FGPU_HIP(hipMemsetAsync(cnt.p, 0, (k + 1) * sizeof(u32), ctx->stream));
+        FGPU_HIP(hipMemsetAsync(cnt.p, 0, (k + 1) * sizeof(u32), ctx->stream()));
+        ProfScope ps(ctx, "segsort_unique (product rows)", 8 * T);
         FGPU_TRY(segsort_unique(ctx, tmp.p, roff.p, (u32)k, (u32)B->ncols, cnt.p, nullptr));
     }
     FGPU_TRY(rowptr.alloc(ctx, k + 1));
@@ -218,9 +220,13 @@ fgpu_info mxm_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* F, const fgp
     FGPU_TRY(read_u32(ctx, rowptr.p + k, &nnz));
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, k, B->ncols, nnz, false, 0, false));
-    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (k + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
-    fgpu_info i = compact_segments(ctx, tmp.p, roff.p, o->rowptr, (u32)k, o->colidx);
-    if (i != FGPU_OK) { fgpu_mat_free(o); return i; }
+    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (k + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()));
+    fgpu_info i;
+    {
+        ProfScope ps(ctx, "compact_segments_kernel", 8 * (u64)nnz);
+        i = compact_segments(ctx, tmp.p, roff.p, o->rowptr, (u32)k, o->colidx);
+    }
+    if (i != FGPU_OK) { mat_release(o); return i; }
     // hub lists are only needed by BFS; products skip mat_finalize (no extra sync per hop)
     *out = o;
     return FGPU_OK;
@@ -234,22 +240,22 @@ fgpu_info delta_lmxm_device(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* F, co
     fgpu_info i = FGPU_OK;
     if (has_dm) {
         i = mxm_device(ctx, &mask, F, dm, nullptr);
-        if (i == FGPU_OK && mask->nnz == 0) { fgpu_mat_free(mask); mask = nullptr; }
+        if (i == FGPU_OK && mask->nnz == 0) { mat_release(mask); mask = nullptr; }
     }
     if (i == FGPU_OK && has_dp) {
         i = mxm_device(ctx, &acc, F, dp, flops);
-        if (i == FGPU_OK && acc->nnz == 0) { fgpu_mat_free(acc); acc = nullptr; }
+        if (i == FGPU_OK && acc->nnz == 0) { mat_release(acc); acc = nullptr; }
     }
     if (i == FGPU_OK) i = mxm_device(ctx, &c, F, m, flops);
     if (i == FGPU_OK && (mask || acc)) {
         fgpu_mat* merged = nullptr;
         // (F.m with MASK removed) U ACCUM — the accumulated dp product is not masked (matrix.rs:1382-1400)
         i = mat_merge_entries(ctx, &merged, c, acc, mask, false, c->nrows, c->ncols, true);
-        if (i == FGPU_OK) { fgpu_mat_free(c); c = merged; }
+        if (i == FGPU_OK) { mat_release(c); c = merged; }
     }
-    fgpu_mat_free(mask);
-    fgpu_mat_free(acc);
-    if (i != FGPU_OK) { fgpu_mat_free(c); return i; }
+    mat_release(mask);
+    mat_release(acc);
+    if (i != FGPU_OK) { mat_release(c); return i; }
     *out = c;
     return FGPU_OK;
 }
@@ -259,11 +265,11 @@ static fgpu_info filter_by_bitmap(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat*
     DevBuf<u32> tmp, cnt, rowptr;
     FGPU_TRY(tmp.alloc(ctx, c->nnz));
     FGPU_TRY(cnt.alloc(ctx, nrows + 1));
-    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (nrows + 1) * sizeof(u32), ctx->stream()));
     u32 grid = cdiv(nrows ? nrows : 1, 4);
     if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
     if (nrows && c->nnz) {
-        hipLaunchKernelGGL(bitmap_filter_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(c), bitmap_dev,
+        hipLaunchKernelGGL(bitmap_filter_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(c), bitmap_dev,
                            (u32)nrows, tmp.p, cnt.p);
         FGPU_HIP(hipGetLastError());
     }
@@ -273,9 +279,9 @@ static fgpu_info filter_by_bitmap(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat*
     FGPU_TRY(read_u32(ctx, rowptr.p + nrows, &nnz));
     fgpu_mat* o = nullptr;
     FGPU_TRY(mat_alloc(ctx, &o, nrows, c->ncols, nnz, false, 0, false));
-    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    FGPU_HIP(hipMemcpyAsync(o->rowptr, rowptr.p, (nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()));
     if (nnz) {
-        hipLaunchKernelGGL(compact_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const u32*)tmp.p,
+        hipLaunchKernelGGL(compact_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const u32*)tmp.p,
                            (const u32*)c->rowptr, (const u32*)o->rowptr, (u32)nrows, o->colidx);
         FGPU_HIP(hipGetLastError());
     }
@@ -298,11 +304,11 @@ static fgpu_info upload_sources(fgpu_ctx* ctx, fgpu_mat** out, const uint64_t* s
     }
     fgpu_mat* f = nullptr;
     FGPU_TRY(mat_alloc(ctx, &f, nsrc, ncols0, ci.size(), false, 0, false));
-    hipError_t e = hipMemcpyAsync(f->rowptr, rp.data(), rp.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMemcpyAsync(f->rowptr, rp.data(), rp.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream());
     if (e == hipSuccess && !ci.empty())
-        e = hipMemcpyAsync(f->colidx, ci.data(), ci.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { fgpu_mat_free(f); set_error("expand: source upload failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+        e = hipMemcpyAsync(f->colidx, ci.data(), ci.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
+    if (e != hipSuccess) { mat_release(f); set_error("expand: source upload failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
     *out = f;
     return FGPU_OK;
 }
@@ -351,14 +357,14 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
             if (mode == 0 && mem < (64ull << 30)) {
                 u64 T = 0;
                 fgpu_info i = mxm_flops(ctx, f, mh, &T);
-                if (i != FGPU_OK) { fgpu_mat_free(f); return i; }
+                if (i != FGPU_OK) { mat_release(f); return i; }
                 // measured on RMAT-22 / 1024 rows: a sorted-CSR hop costs ~0.16 ns per gathered entry
                 // (6 ms at T = 36 M), a bit hop ~2.7 ms per 65 M matrix entries at 128 B rows
                 go = T * 1024 > mh->nnz * row_bytes;
             }
             if (go) {
                 fgpu_info i = bp_from_csr(ctx, bs, f);
-                fgpu_mat_free(f);
+                mat_release(f);
                 f = nullptr;
                 if (i != FGPU_OK) return i;
                 bits = true;
@@ -370,7 +376,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         }
         fgpu_mat* c = nullptr;
         fgpu_info i = delta_lmxm_device(ctx, &c, f, mh, dph, dmh, flops);
-        fgpu_mat_free(f);
+        mat_release(f);
         if (i != FGPU_OK) return i;
         f = c;
     }
@@ -379,7 +385,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         if (dst_label_bitmap) {
             const u64 nw = ((u64)bs.n + 63) / 64;
             FGPU_TRY(bm.alloc(ctx, nw + 1));
-            FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
         }
         if (count_only) {
             *result = nullptr;
@@ -393,13 +399,13 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         DevBuf<u64> bm;
         fgpu_info i = bm.alloc(ctx, nw + 1);
         if (i == FGPU_OK) {
-            hipError_t e2 = hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+            hipError_t e2 = hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream());
             if (e2 != hipSuccess) { set_error("expand: label bitmap upload failed: %s", hipGetErrorString(e2)); i = FGPU_DEVICE; }
         }
         fgpu_mat* c = nullptr;
         if (i == FGPU_OK) i = filter_by_bitmap(ctx, &c, f, bm.p);
-        if (i == FGPU_OK) i = (hipStreamSynchronize(ctx->stream) == hipSuccess) ? FGPU_OK : FGPU_DEVICE;
-        fgpu_mat_free(f);
+        if (i == FGPU_OK) i = (hipStreamSynchronize(ctx->stream()) == hipSuccess) ? FGPU_OK : FGPU_DEVICE;
+        mat_release(f);
         if (i != FGPU_OK) return i;
         f = c;
     }
@@ -413,12 +419,12 @@ using namespace fgpu;
 
 extern "C" {
 
-fgpu_info fgpu_mxm(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* b) {
+static fgpu_info mxm_impl(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* b) {
     FGPU_REQUIRE(ctx && c && f && b, FGPU_NULL_POINTER, "fgpu_mxm: NULL argument");
     return mxm_device(ctx, c, f, b, nullptr);
 }
 
-fgpu_info fgpu_delta_lmxm(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* dp,
+static fgpu_info delta_lmxm_impl(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* dp,
                           const fgpu_mat* dm) {
     FGPU_REQUIRE(ctx && c && f && m, FGPU_NULL_POINTER, "fgpu_delta_lmxm: NULL argument");
     FGPU_REQUIRE(!dp || (dp->nrows == m->nrows && dp->ncols == m->ncols), FGPU_DIM_MISMATCH,
@@ -439,7 +445,7 @@ fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, con
     FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
     uint64_t *vals = nullptr;
     fgpu_info i = fgpu_mat_export_csr(ctx, r, out_rowptr, out_dest, &vals, out_nnz);
-    fgpu_mat_free(r);
+    mat_release(r);
     return i;
 }
 
@@ -466,23 +472,23 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
             DevBuf<u64> acc;
             i = acc.alloc(ctx, 1);
             if (i == FGPU_OK) {
-                (void)hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream);
+                (void)hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream());
                 if (r->nnz / r->nrows >= 1024 && r->nnz < 0xFFFFFFFFull) {
                     u32 grid = cdiv(r->nnz, 256);
                     if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-                    hipLaunchKernelGGL(checksum_entries_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(r),
+                    hipLaunchKernelGGL(checksum_entries_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(r),
                                        (u32)r->nrows, (u32)r->nnz, (unsigned long long*)acc.p);
                 } else {
                     u32 grid = cdiv(r->nrows, 4);
                     if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-                    hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, ctx->stream, view_of(r),
+                    hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(r),
                                        (u32)r->nrows, (unsigned long long*)acc.p);
                 }
                 i = read_u64(ctx, acc.p, checksum);
             }
         }
     }
-    fgpu_mat_free(r);
+    mat_release(r);
     return i;
 }
 
@@ -505,7 +511,7 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
     // transpose whatever the frontier size, and the union over the hops is a word-wise OR
     BitState bs, un;
     fgpu_info i = bp_from_csr(ctx, bs, f);
-    fgpu_mat_free(f);
+    mat_release(f);
     if (i != FGPU_OK) return i;
     DevBuf<u64> bm;
     const u64* label_dev = nullptr;
@@ -514,7 +520,7 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
         if (dst_label_bitmap && h == 0) {   // the destination label applies to every reported set
             const u64 nw = ((u64)bs.n + 63) / 64;
             FGPU_TRY(bm.alloc(ctx, nw + 1));
-            FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
             label_dev = bm.p;
         }
         u64 n = 0, cs = 0;
@@ -530,6 +536,24 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
         if (union_checksum) *union_checksum = cs;
     }
     return FGPU_OK;
+}
+
+}  // extern "C"
+
+// Public producers of snapshots: the implementation above, then fgpu_ctx::publish().
+extern "C" {
+
+fgpu_info fgpu_mxm(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* b) {
+    fgpu_info i_ = mxm_impl(ctx, c, f, b);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
+}
+
+fgpu_info fgpu_delta_lmxm(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* dp,
+                          const fgpu_mat* dm) {
+    fgpu_info i_ = delta_lmxm_impl(ctx, c, f, m, dp, dm);
+    if (i_ == FGPU_OK && ctx) i_ = ctx->publish();   // the new handle may go to another thread
+    return i_;
 }
 
 }  // extern "C"

@@ -397,7 +397,7 @@ static tiled_fn pick_kernel(u32 vec, u32 k, int U, bool nt) {
 // out (ngroups words, device) = M (x) x, AND-NOT mask.  `out` is zeroed here.
 fgpu_info tiles_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 x_words64, const u64* mask_dev,
                     u64* out_dev, bool zero_out) {
-    if (zero_out) FGPU_HIP(hipMemsetAsync(out_dev, 0, (size_t)t->ngroups * sizeof(u64), ctx->stream));
+    if (zero_out) FGPU_HIP(hipMemsetAsync(out_dev, 0, (size_t)t->ngroups * sizeof(u64), ctx->stream()));
     if (t->nitems == 0) return FGPU_OK;
     tiled_fn fn = pick_kernel(t->vec, t->k, ctx->opt.tiled_u, ctx->opt.tiled_nt != 0);
     const size_t lds = ((size_t)1 << t->tile_bits) / 8 + 16;
@@ -419,13 +419,17 @@ fgpu_info tiles_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 x_
     if (wpt > max_wpt) wpt = max_wpt ? max_wpt : 1;
     const u32 nvirt = wpt * t->ntiles;
     if (grid > nvirt) grid = nvirt;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, ctx->stream, view_of(t), x_dev, x_words64 * 2, mask_dev,
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, ctx->stream(), view_of(t), x_dev, x_words64 * 2, mask_dev,
                        out_dev, wpt);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
 
-fgpu_info tiles_build(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k) {
+// Built once per snapshot under its index mutex (first dense-frontier vxm on it); `rebuild` = the measurement hook
+// fgpu_mat_build_tiles replacing the layout with other parameters, which needs the snapshot to itself.
+fgpu_info tiles_build(fgpu_ctx* ctx, const fgpu_mat* m, int tile_bits, int vec, int k, bool rebuild) {
+    std::lock_guard<std::mutex> idx_guard(m->idx_mu);
+    if (m->tiles && !rebuild) return FGPU_OK;
     FGPU_REQUIRE(m->nrows >= 1 && m->ncols >= 1, FGPU_INVALID, "tiles: empty matrix");
     if (tile_bits <= 0) {
         tile_bits = 7;
@@ -459,8 +463,8 @@ fgpu_info tiles_build(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k)
     FGPU_TRY(cnt_i.alloc(ctx, nslots + 1));
     FGPU_TRY(ioff.alloc(ctx, nslots + 1));
     FGPU_TRY(eoff.alloc(ctx, nslots + 1));
-    FGPU_HIP(hipMemsetAsync(cnt_e.p + nslots, 0, sizeof(u32), ctx->stream));
-    FGPU_HIP(hipMemsetAsync(cnt_i.p + nslots, 0, sizeof(u32), ctx->stream));
+    FGPU_HIP(hipMemsetAsync(cnt_e.p + nslots, 0, sizeof(u32), ctx->stream()));
+    FGPU_HIP(hipMemsetAsync(cnt_i.p + nslots, 0, sizeof(u32), ctx->stream()));
     fgpu_tiles* t = new (std::nothrow) fgpu_tiles();
     FGPU_REQUIRE(t, FGPU_OOM, "out of host memory");
     t->ctx = ctx; t->tile_bits = (u32)tile_bits; t->ntiles = ntiles; t->ngroups = ngroups;
@@ -471,7 +475,7 @@ fgpu_info tiles_build(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k)
         if ((info = ctx->dev_alloc((void**)&t->tile_item, ((size_t)ntiles + 1) * sizeof(u32))) != FGPU_OK) break;
         u32 grid = cdiv(ngroups, 4);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-        hipLaunchKernelGGL(tiles_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, mv, (u32)m->nrows,
+        hipLaunchKernelGGL(tiles_count_kernel, dim3(grid), dim3(256), 0, ctx->stream(), mv, (u32)m->nrows,
                            ngroups, (u32)tile_bits, ntiles, (u32)vec, cap, cnt_e.p, cnt_i.p, t->row_has);
         if (hipGetLastError() != hipSuccess) { set_error("tiles_count launch failed"); info = FGPU_DEVICE; break; }
         if ((info = scan_u32_to_u64(ctx, cnt_e.p, eoff.p, nslots + 1, nullptr)) != FGPU_OK) break;
@@ -491,15 +495,15 @@ fgpu_info tiles_build(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k)
         if ((info = ctx->dev_alloc((void**)&t->entries, (size_t)total_e * sizeof(u32))) != FGPU_OK) break;
         if ((info = ctx->dev_alloc((void**)&t->item_off, ((size_t)total_i + 1) * sizeof(u32))) != FGPU_OK) break;
         if ((info = ctx->dev_alloc((void**)&t->item_group, ((size_t)total_i + 1) * sizeof(u32))) != FGPU_OK) break;
-        hipLaunchKernelGGL(tiles_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, mv, (u32)m->nrows, ngroups,
+        hipLaunchKernelGGL(tiles_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream(), mv, (u32)m->nrows, ngroups,
                            (u32)tile_bits, ntiles, (u32)vec, cap, (const u64*)eoff.p, (const u32*)ioff.p, t->entries, t->item_off,
                            t->item_group);
         if (hipGetLastError() != hipSuccess) { set_error("tiles_fill launch failed"); info = FGPU_DEVICE; break; }
-        hipLaunchKernelGGL(tiles_finish_kernel, dim3(cdiv((u64)ntiles + 1, 64)), dim3(64), 0, ctx->stream,
+        hipLaunchKernelGGL(tiles_finish_kernel, dim3(cdiv((u64)ntiles + 1, 64)), dim3(64), 0, ctx->stream(),
                            (const u32*)ioff.p, (const u64*)eoff.p, ngroups, ntiles, (u32)tile_bits, t->tile_item,
                            t->item_off, t->entries);
         if (hipGetLastError() != hipSuccess) { set_error("tiles_finish launch failed"); info = FGPU_DEVICE; break; }
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("tiles build failed"); info = FGPU_DEVICE; break; }
+        if (hipStreamSynchronize(ctx->stream()) != hipSuccess) { set_error("tiles build failed"); info = FGPU_DEVICE; break; }
     } while (0);
     if (info != FGPU_OK) { tiles_release(t); return info; }
     tiles_release(m->tiles);
@@ -515,7 +519,7 @@ extern "C" {
 
 fgpu_info fgpu_mat_build_tiles(fgpu_ctx* ctx, fgpu_mat* m, int tile_bits, int vec, int k) {
     FGPU_REQUIRE(ctx && m, FGPU_NULL_POINTER, "fgpu_mat_build_tiles: NULL argument");
-    return tiles_build(ctx, m, tile_bits, vec, k);
+    return tiles_build(ctx, m, tile_bits, vec, k, true);
 }
 
 fgpu_info fgpu_mat_tiles_info(const fgpu_mat* m, uint64_t info[8]) {

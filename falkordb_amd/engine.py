@@ -55,6 +55,21 @@ class Context:
     def set_option(self, name: str, value: int):
         check(self.lib.fgpu_set_option(self._h, name.encode(), int(value)))
 
+    def prof_enable(self, enable=True):
+        """Context-wide kernel profiler (HIP events around the modelled kernels of the non-BFS paths)."""
+        check(self.lib.fgpu_prof_enable(self._h, 1 if enable else 0))
+
+    def prof_read(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        launches = (C.c_uint64 * cap)()
+        ab = (C.c_uint64 * cap)()
+        n = C.c_int()
+        check(self.lib.fgpu_prof_read(self._h, names, ms, launches, ab, cap, C.byref(n)))
+        return [{"kernel": names[i].decode(), "ms": ms[i], "launches": int(launches[i]), "alg_bytes": int(ab[i])}
+                for i in range(n.value)]
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus, wave = C.c_int32(), C.c_int32()
@@ -173,6 +188,12 @@ class Mat:
     def transpose(self) -> "Mat":
         h = C.c_void_p()
         check(self.ctx.lib.fgpu_mat_transpose(self.ctx._h, C.byref(h), self._h))
+        return Mat(self.ctx, h)
+
+    def sample(self, seed: int, denom: int) -> "Mat":
+        """Entries (r, c) with mix64(seed ^ mix64(r << 32 | c)) % denom == 0 (bench / test data)."""
+        h = C.c_void_p()
+        check(self.ctx.lib.fgpu_mat_sample(self.ctx._h, C.byref(h), self._h, C.c_uint64(seed), C.c_uint32(denom)))
         return Mat(self.ctx, h)
 
     def probe(self, rows, cols, want_vals=False):

@@ -159,24 +159,32 @@ struct HopLayers {
     std::vector<const fgpu_mat*> m, dp, dm;
 };
 
+// Type names of one hop -> tensor ids, the way the reference resolves them: a single unknown type is no_match
+// (cond_traverse.rs:481-490), an alternation drops its unknown names (`filter_map` in
+// build_relationship_matrix_unrestricted, graph.rs:2524-2527, and in edge_type_indices, cond_traverse.rs:418-426)
+// and is no_match only when none is known.  Returns false for no_match.
+bool resolve_hop_types(const Graph& g, const std::vector<std::string>& types, std::vector<u64>& ids) {
+    ids.clear();
+    for (auto& t : types)
+        if (auto id = g.type_id(t)) ids.push_back(*id);
+    return types.empty() || !ids.empty();
+}
+
 // Matrix choice per hop (cond_traverse.rs:478-505): no type -> adjacency; one type -> that tensor's forward
-// layers; several -> materialized union with clean deltas.  Returns false for an unknown type.
+// layers; an alternation -> materialized union of its known types with clean deltas (also when only one of them
+// is known: the reference branches on the number of NAMES).  Returns false for no_match.
 bool hop_layers(const Graph& g, const std::vector<Hop>& hops, HopLayers& hl, std::vector<std::vector<u64>>& type_ids) {
     for (auto& h : hops) {
         std::vector<u64> ids;
-        for (auto& t : h.types) {
-            auto id = g.type_id(t);
-            if (!id) return false;
-            ids.push_back(*id);
-        }
+        if (!resolve_hop_types(g, h.types, ids)) return false;
         type_ids.push_back(ids);
-        if (ids.empty()) {
+        if (h.types.empty()) {
             const VersionedMatrix& a = g.adjacency_matrix();
             a.wait();
             hl.m.push_back(a.m().snapshot());
             hl.dp.push_back(a.dp().nvals() ? a.dp().snapshot() : nullptr);
             hl.dm.push_back(a.dm().nvals() ? a.dm().snapshot() : nullptr);
-        } else if (ids.size() == 1) {
+        } else if (h.types.size() == 1) {
             const Tensor& t = g.relationship_tensors()[ids[0]];
             t.wait_fwd();
             hl.m.push_back(t.fwd_m().snapshot());

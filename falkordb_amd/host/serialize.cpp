@@ -79,11 +79,11 @@ void write_vector(ByteWriter& w, const void* data, size_t bytes, const char* typ
 int index_bits(const RawVector& v, const char* what) {
     if (v.n_entries == 0) return 64;
     if (v.type == "GrB_UINT32" || v.type == "GrB_INT32") {
-        if (v.bytes.size() < v.n_entries * 4) throw GrbError(FGPU_INVALID, std::string("container: short ") + what);
+        if (v.bytes.size() / 4 < v.n_entries) throw GrbError(FGPU_INVALID, std::string("container: short ") + what);
         return 32;
     }
     if (v.type == "GrB_UINT64" || v.type == "GrB_INT64") {
-        if (v.bytes.size() < v.n_entries * 8) throw GrbError(FGPU_INVALID, std::string("container: short ") + what);
+        if (v.bytes.size() / 8 < v.n_entries) throw GrbError(FGPU_INVALID, std::string("container: short ") + what);
         return 64;
     }
     throw GrbError(FGPU_INVALID, std::string("container: ") + what + " has type " + v.type);
@@ -116,6 +116,10 @@ ContainerData parse_container(ByteReader& r) {
                                      "(pin_sparse, matrix.rs:405-426); got format " + std::to_string(c.format));
     if (c.orientation != GRB_ROWMAJOR) throw GrbError(FGPU_INVALID, "container: column-major matrix");
     if (c.jumbled) throw GrbError(FGPU_INVALID, "container: jumbled rows (the encoder writes wait()ed matrices)");
+    // sizes come from an untrusted GRAPH.RESTORE-style payload: bound them by the device format (32-bit ids / row
+    // pointers, fgpu.h) BEFORE anything is allocated from them, and compare lengths by division, never by a product
+    if (c.nrows >= 0xFFFFFFFFull || c.ncols >= 0xFFFFFFFFull || c.nvals >= 0xFFFFFFFFull)
+        throw GrbError(FGPU_INVALID, "container: dims / nvals exceed the 32-bit device format");
     const int pb = index_bits(p, "p"), ib = index_bits(i, "i"), hb = index_bits(h, "h");
     if (p.n_entries == 0) {                      // an empty matrix may come with an empty pointer vector
         if (c.nvals) throw GrbError(FGPU_INVALID, "container: nvals without row pointers");
@@ -125,6 +129,7 @@ ContainerData parse_container(ByteReader& r) {
         return c;
     }
     const u64 nvec = p.n_entries - 1;
+    if (nvec > c.nrows) throw GrbError(FGPU_INVALID, "container: more stored vectors than rows");
     c.hyper = c.format == GXB_HYPERSPARSE;
     if (c.hyper && h.n_entries < nvec) throw GrbError(FGPU_INVALID, "container: hyper list shorter than the pointer vector");
     if (!c.hyper && nvec != c.nrows) throw GrbError(FGPU_INVALID, "container: sparse matrix with nvec != nrows");
@@ -150,7 +155,7 @@ ContainerData parse_container(ByteReader& r) {
     if (x.type == "GrB_UINT64") {
         c.valued = true;
         const u64 need = c.iso ? (c.nvals ? 1 : 0) : c.nvals;
-        if (x.bytes.size() < need * 8) throw GrbError(FGPU_INVALID, "container: value vector too short");
+        if (x.bytes.size() / 8 < need) throw GrbError(FGPU_INVALID, "container: value vector too short");
         c.x.resize(c.nvals);
         for (u64 k = 0; k < c.nvals; ++k) memcpy(&c.x[k], x.bytes.data() + 8 * (c.iso ? 0 : k), 8);
     } else if (x.type == "GrB_BOOL" || x.n_entries == 0) {
@@ -198,8 +203,12 @@ Matrix Matrix::decode(Context& ctx, ByteReader& r) {
     ContainerData c = parse_container(r);
     fgpu_mat* snap = nullptr;
     const u64 nvec = c.p.size() - 1;
+    // fgpu_mat_from_csr reads "hypersparse" off a non-NULL hyper list: a hypersparse container without stored rows
+    // (p = [0], h = [] — every clean dp / dm layer of a real graph) has an empty vector whose data() is NULL
+    static const u64 no_rows = 0;
+    const u64* hlist = c.hyper ? (c.h.empty() ? &no_rows : c.h.data()) : nullptr;
     check(fgpu_mat_from_csr(ctx.raw(), &snap, c.nrows, c.ncols, c.nvals, c.p.data(), 64, c.i.data(), 64,
-                            c.valued ? c.x.data() : nullptr, c.hyper ? c.h.data() : nullptr, c.hyper ? nvec : 0),
+                            c.valued ? c.x.data() : nullptr, hlist, c.hyper ? nvec : 0),
           "GxB_load_Matrix_from_Container");
     return Matrix::adopt(ctx, c.valued ? Type::UInt64 : Type::Bool, snap);
 }

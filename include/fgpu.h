@@ -21,11 +21,20 @@
  *    the same demand, tensor.rs:154-163) and nnz per matrix must be < 2^32;
  *  - outputs returned through `T**` are host buffers owned by the caller until
  *    fgpu_free().
- *  - threading: a context owns ONE HIP stream, one pinned staging buffer and its scratch pool; calls on the same
- *    fgpu_ctx must be serialised by the caller (the pool itself is mutex-guarded, the stream and the staging
- *    buffer are not).  The reference's reader threads map to one context each; snapshots are immutable, so a
- *    context may read a snapshot another context of the same device created, after that context synchronised
- *    (fgpu_sync).  SURVEY.md §8b's per-thread stream pool inside one context is not implemented.
+ *  - threading: ONE fgpu_ctx per process and device, shared by all host threads — the reference calls GraphBLAS
+ *    from a worker pool on shared materialised handles (threadpool.rs:89-128, matrix.rs:781-796).  Every calling
+ *    thread is bound, on its first call, to a LANE of the context: its own HIP stream, pinned staging block and
+ *    free-list of device blocks, so concurrent calls never share a stream-ordered resource.  Any number of threads
+ *    may concurrently call read-side entry points (fgpu_expand*, fgpu_mxm, fgpu_delta_lmxm, fgpu_mat_probe /
+ *    extract / export, fgpu_vxm, fgpu_bfs, fgpu_pagerank, merges, transposes ...) on the SAME snapshots: a snapshot's
+ *    stored content never changes, its acceleration indexes are built once under a per-snapshot mutex and
+ *    published only when complete, and a call that returns a new fgpu_mat* synchronises its lane first whenever
+ *    more than one lane exists, so a handle can be handed to another thread as soon as the call returns.
+ *    What the caller keeps exclusive — exactly what the reference keeps exclusive (the caller's own F, a matrix
+ *    under its `wait` mutex): an fgpu_bfs_plan is used by one thread at a time (run_async / wait on the same
+ *    thread); fgpu_mat_free may be called from any thread once no call that takes the snapshot is executing
+ *    (work other threads queued asynchronously is fenced inside the library); fgpu_set_option, fgpu_mat_build_tiles
+ *    with explicit parameters and fgpu_prof_* are configuration / measurement calls made while no other call runs.
  *  - There is NO CPU fallback: without a HIP device fgpu_init fails with
  *    FGPU_DEVICE and nothing else can be called.
  */
@@ -39,7 +48,7 @@
 extern "C" {
 #endif
 
-typedef struct fgpu_ctx fgpu_ctx; /* one per process+device (matrix::init, matrix.rs:116-185) */
+typedef struct fgpu_ctx fgpu_ctx; /* one per process+device, shared by all threads (matrix::init, matrix.rs:116-185) */
 typedef struct fgpu_mat fgpu_mat; /* immutable device CSR snapshot of one matrix layer        */
 typedef struct fgpu_bfs_plan fgpu_bfs_plan; /* per-(A,At) BFS workspace + partition state       */
 
@@ -63,18 +72,21 @@ fgpu_info fgpu_init(fgpu_ctx** ctx, int device, void* (*mal)(size_t), void (*fre
 fgpu_info fgpu_finalize(fgpu_ctx* ctx);
 const char* fgpu_last_error(void);
 void fgpu_free(fgpu_ctx* ctx, void* p);
-/* Run all subsequent work of this ctx on an externally owned hipStream_t
+/* Run all subsequent work of the CALLING THREAD's lane on an externally owned hipStream_t
  * (plumbing for torch.distributed: pass torch.cuda.current_stream().cuda_stream).
- * NULL restores the ctx's own stream. */
+ * NULL restores the lane's own stream. */
 fgpu_info fgpu_set_stream(fgpu_ctx* ctx, void* hip_stream);
+/* Wait for the work the calling thread has queued on its lane. */
 fgpu_info fgpu_sync(fgpu_ctx* ctx);
 /* Engine tunables (the analogue of GrB_Global_set_INT32, matrix.rs:151-159): "tiled_u" (items in
  * flight per wavefront of the LDS-tiled vxm: 1/2/4/8), "tiled_threads" (256/512/1024),
  * "tiled_wgs" (grid of that kernel, 0 = fill the CUs), "tiled_nt" (nontemporal entry loads),
+ * "transpose_mode" (pattern transpose: 0 = counting transpose, 1 = COO rebuild through the sorter),
  * "expand_mode" (fgpu_expand: 0 = pick per hop, 1 = sorted-CSR products only, 2 = bit-parallel from the
  * first hop), "bfs_wgs_per_cu" (grid of the fused BFS level kernel), "merge_mode" (fgpu_mat_merge:
  * 0 = entry-parallel, 1 = one wavefront per row, pattern layers only), "bfs_tiny" (consecutive tiny BFS levels in one single-workgroup launch: 0 off, 1 on,
- * 2 = when the plan's previous search took more than 12 levels), "bfs_hub_first" (1 = BFS plans
+ * 2 = when the plan's previous search took more than 12 levels), "bfs_prof_split" (1 = a profiled plan launches
+ * the push / pull twins of the level kernel so rocprofv3 can tell them apart by name), "bfs_hub_first" (1 = BFS plans
  * read the pull direction from a copy of At whose rows are reordered by descending out-degree class). */
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
 /* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */
@@ -349,6 +361,17 @@ fgpu_info fgpu_mat_row_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, ui
  * (SURVEY.md §8d formulas). */
 fgpu_info fgpu_bench_spmv(fgpu_ctx* ctx, const fgpu_mat* A, int which, int iters,
                           double* avg_ms, uint64_t* alg_bytes);
+/* Context-wide kernel profiler for the non-BFS paths (k-hop products, merges, transposes): while enabled, every
+ * launch of a modelled kernel is bracketed by HIP events on its lane's stream.  fgpu_prof_read synchronises,
+ * folds the records by kernel name (static strings), returns total ms / launch count / algorithmic bytes
+ * (SURVEY.md §8d accounting; 0 = not modelled) per name and clears them.  Enabling clears earlier records. */
+fgpu_info fgpu_prof_enable(fgpu_ctx* ctx, int enable);
+fgpu_info fgpu_prof_read(fgpu_ctx* ctx, const char** names, double* ms, uint64_t* launches,
+                         uint64_t* alg_bytes, int cap, int* n);
+/* Uniform sample of the stored entries of `a` (bench / test data for "0.1 % random tombstones"):
+ * (r, c) is kept iff mix64(seed ^ mix64(r << 32 | c)) % denom == 0, mix64 = the splitmix64 finaliser — a function
+ * of the coordinate, so a CPU model draws the same sample.  Pattern only.  Not a reference API. */
+fgpu_info fgpu_mat_sample(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t seed, uint32_t denom);
 /* Per-kernel accumulated HIP-event timings of a plan (enabled by
  * fgpu_bfs_plan_profile(plan,1)): names[i] (static strings), ms[i], launches[i],
  * alg_bytes[i]; returns count in *n (<= cap). */

@@ -51,6 +51,11 @@ def omp_lib():
         L = ctypes.CDLL(_OMP_PATH)
         L.orc_bfs_omp.restype = ctypes.c_uint64
         L.orc_omp_threads.restype = ctypes.c_int
+        L.orc_mxm_omp.restype = ctypes.c_uint64
+        L.orc_merge_omp.restype = ctypes.c_uint64
+        L.orc_checksum_omp.restype = ctypes.c_uint64
+        L.orc_free.restype = None
+        L.orc_free.argtypes = [ctypes.c_void_p]
         _omp = L
     return _omp
 
@@ -196,6 +201,90 @@ def delta_lmxm(f: CSR, m: CSR, dp: CSR | None, dm: CSR | None):
     if mask is not None or acc is not None:
         c = merge(c, acc, mask, False)        # replace+complemented mask, then eWiseAdd (:1398-1400)
     return c, flops
+
+
+def _take_malloced(ptr, n):
+    """numpy copy of a malloc'ed u64 array returned by oracle_omp.c, then free it."""
+    out = np.ctypeslib.as_array(ptr, shape=(max(int(n), 1),))[:int(n)].copy() if n else np.zeros(0, dtype=U64)
+    omp_lib().orc_free(ctypes.cast(ptr, ctypes.c_void_p))
+    return out
+
+
+def mxm_omp(f: CSR, b: CSR, threads: int = 0):
+    """Matrix::lmxm (matrix.rs:930-947), row-parallel (oracle_omp.c orc_mxm_omp): the same result as mxm()
+    (tests/test_oracle_golden.py holds them equal), usable at BASELINE sizes.  Returns (C, flops)."""
+    assert f.ncols == b.nrows
+    crp = np.zeros(f.nrows + 1, dtype=U64)
+    fl = ctypes.c_uint64(0)
+    cci = _p64()
+    nnz = omp_lib().orc_mxm_omp(ctypes.c_uint64(f.nrows), _ptr(f.rowptr), _ptr(f.colidx), _ptr(b.rowptr),
+                                _ptr(b.colidx), ctypes.c_uint64(b.ncols), _ptr(crp), ctypes.byref(cci),
+                                ctypes.byref(fl), ctypes.c_int(threads))
+    return CSR(f.nrows, b.ncols, crp, _take_malloced(cci, nnz)), int(fl.value)
+
+
+def merge_omp(a: CSR, add: CSR | None, mask: CSR | None, threads: int = 0) -> CSR:
+    """(a \\ mask) U add, add entries not masked (matrix.rs:1382-1400), row-parallel."""
+    orp = np.zeros(a.nrows + 1, dtype=U64)
+    oci = _p64()
+    nnz = omp_lib().orc_merge_omp(ctypes.c_uint64(a.nrows), _ptr(a.rowptr), _ptr(a.colidx),
+                                  _ptr(add.rowptr) if add is not None else None,
+                                  _ptr(add.colidx) if add is not None else None,
+                                  _ptr(mask.rowptr) if mask is not None else None,
+                                  _ptr(mask.colidx) if mask is not None else None, _ptr(orp), ctypes.byref(oci),
+                                  ctypes.c_int(threads))
+    return CSR(a.nrows, a.ncols, orp, _take_malloced(oci, nnz))
+
+
+def delta_lmxm_omp(f: CSR, m: CSR, dp: CSR | None, dm: CSR | None, threads: int = 0):
+    """Matrix::delta_lmxm (matrix.rs:1317-1402) exactly as delta_lmxm() above, on the row-parallel kernels."""
+    dp_n = dp.nnz if dp is not None else 0
+    dm_n = dm.nnz if dm is not None else 0
+    if dp_n == 0 and dm_n == 0:
+        return mxm_omp(f, m, threads)
+    mask = acc = None
+    flops = 0
+    if dm_n > 0:
+        mk, _ = mxm_omp(f, dm, threads)
+        if mk.nnz > 0:
+            mask = mk
+    if dp_n > 0:
+        ac, fl = mxm_omp(f, dp, threads)
+        flops += fl
+        if ac.nnz > 0:
+            acc = ac
+    c, fl = mxm_omp(f, m, threads)
+    flops += fl
+    if mask is not None or acc is not None:
+        c = merge_omp(c, acc, mask, threads)
+    return c, flops
+
+
+def expand_omp(src_ids, layers, threads: int = 0, n: int | None = None):
+    """The device core of expand_batch (cond_traverse.rs:600-605): F[i, src_i] = 1, then one delta_lmxm per hop.
+    layers = [(m, dp, dm), ...].  Returns (C, flops, per-hop nnz)."""
+    src_ids = np.asarray(src_ids, dtype=U64)
+    n = n if n is not None else layers[0][0].nrows
+    f = build_csr(len(src_ids), n, np.arange(len(src_ids), dtype=U64), src_ids)
+    flops, hop_nnz = 0, []
+    for (m, dp, dm) in layers:
+        f, fl = delta_lmxm_omp(f, m, dp, dm, threads)
+        flops += fl
+        hop_nnz.append(f.nnz)
+    return f, flops, hop_nnz
+
+
+def checksum_omp(c: CSR, threads: int = 0) -> int:
+    return int(omp_lib().orc_checksum_omp(ctypes.c_uint64(c.nrows), _ptr(c.rowptr), _ptr(c.colidx),
+                                          ctypes.c_int(threads)))
+
+
+def sample(a: CSR, seed: int, denom: int) -> CSR:
+    """The entries fgpu_mat_sample keeps: mix64(seed ^ mix64(r << 32 | c)) % denom == 0."""
+    r, c = a.pairs()
+    h = mix64(np.uint64(seed) ^ mix64((r << np.uint64(32)) | c))
+    keep = (h % np.uint64(denom)) == 0
+    return build_csr(a.nrows, a.ncols, r[keep], c[keep])
 
 
 def bfs(a: CSR, src: int, max_level: int = -1, want_parent: bool = True):

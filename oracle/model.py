@@ -307,16 +307,19 @@ class Graph:
     def traversal_layers(self, types):
         """Matrix choice of expand_batch (cond_traverse.rs:478-505): [] -> adjacency; one type -> that
         Tensor's forward layers; several -> materialized union with clean deltas
-        (build_relationship_matrix_unrestricted, graph.rs:2520-2549).  Unknown type -> None."""
+        (build_relationship_matrix_unrestricted, graph.rs:2520-2549).  A single unknown type -> None
+        (:481-490); in an alternation the unknown names are filtered out (`filter_map`, graph.rs:2524-2527) and
+        only an alternation with NO known type gives None — `[:KNOWS|NOPE]` still returns the KNOWS edges, through
+        the materialized union (clean deltas), even when one type is left."""
         if not types:
             return self.adjacency.layers()
-        ids = []
-        for t in types:
-            if t not in self.type_ids:
+        if len(types) == 1:
+            if types[0] not in self.type_ids:
                 return None
-            ids.append(self.type_ids[t])
-        if len(ids) == 1:
-            return self.tensors[ids[0]].fwd_layers()
+            return self.tensors[self.type_ids[types[0]]].fwd_layers()
+        ids = [self.type_ids[t] for t in types if t in self.type_ids]
+        if not ids:
+            return None
         u = set()
         for i in ids:
             u |= self.tensors[i].structure()

@@ -918,3 +918,17 @@ def test_matrix_v19_payload_decode_and_encode(hctx):
     e = host.Matrix(hctx, host.Matrix.BOOL, 9, 4)
     back, _ = host.matrix_decode(hctx, host.matrix_encode(e))
     assert (*back.dims(), back.nvals()) == (9, 4, 0)
+    # an EMPTY matrix with > 1024 rows is written hypersparse with p = [0], h = [] — what every clean dp / dm layer of
+    # a real graph encodes to; the decoder must not mistake the empty hyper list for "not hypersparse"
+    for typ in (host.Matrix.BOOL, host.Matrix.UINT64):
+        e = host.Matrix(hctx, typ, 2_000_000, 2_000_000)
+        payload = host.matrix_encode(e)
+        d = host.container_parse(payload)
+        assert d["hyper"] and d["nvals"] == 0 and list(d["p"]) == [0] and len(d["h"]) == 0
+        back, used = host.matrix_decode(hctx, payload)
+        assert used == len(payload) and (*back.dims(), back.nvals()) == (2_000_000, 2_000_000, 0)
+        assert back.iter() == [] and back.get(5, 5) is None
+        assert host.matrix_encode(back) == payload
+    for bits in (32, 64):                                           # the same state built by hand
+        hm, _ = host.matrix_decode(hctx, _container(3_000_000, 3_000_000, [0], [], h=[], idx_bits=bits))
+        assert (*hm.dims(), hm.nvals()) == (3_000_000, 3_000_000, 0) and hm.iter() == []
