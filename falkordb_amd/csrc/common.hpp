@@ -320,6 +320,10 @@ fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 // dense (nrows+1) rowptr of a possibly hypersparse matrix.
 fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp);
 fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
+// transpose.hip: the sort-free builders (stable two-level counting sort); FGPU_NO_VALUE = not applicable, fall back
+fgpu_info mat_transpose_counting(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
+fgpu_info mat_from_device_coo_counting(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
+                                       const u32* cols, u64 n);
 fgpu_info mat_finalize(const fgpu_mat* m);  // hub list, max degree (after rowptr/colidx are filled; private or under idx_mu)
 fgpu_info mat_ensure_finalized(const fgpu_mat* m);  // lazily, for snapshots produced by the merge kernels
 // device COO (u32 rows / cols, n entries) -> CSR snapshot, duplicates collapsed.

@@ -163,6 +163,10 @@ __global__ void coo_scatter_kernel(const u32* __restrict__ rows, const u32* __re
 
 fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows, const u32* cols,
                               u64 n) {
+    if (ctx->opt.transpose_mode == 0) {   // two stable counting sorts, no atomics, no per-row sort (transpose.hip)
+        fgpu_info ci = mat_from_device_coo_counting(ctx, out, nrows, ncols, rows, cols, n);
+        if (ci != FGPU_NO_VALUE) return ci;
+    }
     DevBuf<u32> hist, cnt, tmp, rowptr;
     DevBuf<u64> off, tot;
     FGPU_TRY(hist.alloc(ctx, nrows + 1));
@@ -534,6 +538,10 @@ namespace fgpu {
 // pattern-only transpose on device (values, if any, are ignored)
 fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
     if (a->nnz == 0) return fgpu_mat_new(ctx, out, a->ncols, a->nrows);
+    if (ctx->opt.transpose_mode == 0) {   // stable partition by column: rows of the result come out ascending, no sort
+        fgpu_info ci = mat_transpose_counting(ctx, out, a);
+        if (ci != FGPU_NO_VALUE) return ci;
+    }
     DevBuf<u32> rows, cols;
     FGPU_TRY(rows.alloc(ctx, a->nnz));
     FGPU_TRY(cols.alloc(ctx, a->nnz));

@@ -83,6 +83,29 @@ def test_transpose(ctx, seed):
     assert_same(ctx.mat_from_coo(3000, 2000, r, c).transpose(), oracle.transpose(a))
 
 
+@pytest.mark.parametrize("nrows,ncols,n", [(3000, 2000, 40000), (257, 70000, 100000), (70000, 255, 90000),
+                                           (1 << 17, 1 << 17, 1 << 21), (5000, 1 << 20, 300000), (40, 40, 9000)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_counting_builders_match_the_oracle(ctx, nrows, ncols, n, mode):
+    """transpose.hip: the sort-free builders (two stable counting-sort passes) against the oracle and against the
+    round-1 sorter path (transpose_mode 1) — rectangular shapes, key spaces that are not a multiple of the bucket
+    width, one bucket only, heavy duplication (40 x 40 with 9000 tuples), a hub column and a hub row."""
+    rng = np.random.default_rng(nrows + 3 * ncols + n)
+    r, c = rand_coo(rng, nrows, ncols, n)
+    r[: n // 8] = nrows // 3                      # hub row
+    c[n // 8: n // 4] = ncols - 1                 # hub column, last key of the last bucket
+    ref = oracle.build_csr(nrows, ncols, r, c)
+    try:
+        ctx.set_option("transpose_mode", mode)
+        A = ctx.mat_from_coo(nrows, ncols, r, c)
+        assert_same(A, ref)
+        At = A.transpose()
+        assert_same(At, oracle.transpose(ref))
+        assert_same(At.transpose(), ref)
+    finally:
+        ctx.set_option("transpose_mode", 0)
+
+
 def test_from_csr_roundtrip_and_validation(ctx):
     rng = np.random.default_rng(3)
     r, c = rand_coo(rng, 500, 500, 5000)
