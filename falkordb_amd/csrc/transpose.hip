@@ -40,8 +40,11 @@ struct KsGeom {
 static bool ks_geometry(u64 n, u64 nkeys, KsGeom& g) {
     u32 kb = 1;
     while (kb < 32 && (1ull << kb) < nkeys) ++kb;
-    u32 wb = kb > 11 ? kb - 11 : 0;            // aim for ~2048 buckets ...
-    if (wb < 8) wb = 8;                        // ... of at least 256 keys (a pass-2 thread owns 2^wb / 256 of them)
+    // split the key bits between the two digits so that neither LDS footprint starves its kernel of wavefronts:
+    // pass 1 keeps B x 4 B per single-wavefront workgroup, pass 2 keeps 4 x 2^wb x 4 B per 4-wavefront workgroup
+    u32 wb = kb > 22 ? kb - 12 : (kb > 11 ? 11 : 8);   // <= 2^22 keys: 2048 x 2048; 2^24: 4096 x 4096; 2^26: 8192 x 8192
+    if (wb < 8) wb = 8;                                // a pass-2 thread owns 2^wb / 256 keys
+    if (kb > wb + 13) wb = kb - 13;
     if (wb > KS_MAX_WB) wb = KS_MAX_WB;
     const u64 B = (nkeys + (1ull << wb) - 1) >> wb;
     if (B > KS_MAX_BUCKETS) return false;      // > 2^26 keys: three digits would be needed
@@ -95,6 +98,39 @@ __global__ __launch_bounds__(256) void ks_count_kernel(const u32* __restrict__ k
     for (u32 b = threadIdx.x; b < g.B; b += 256) cnt[(size_t)b * g.nblk + blockIdx.x] = s_hist[b];
 }
 
+// rows of 64 consecutive CSR entries (lane j holds entry i0 + j, `on` = valid): the row boundaries from `rcur` on are
+// fetched 64 at a time with ONE coalesced load and searched with shuffles — a per-lane binary search over the global
+// row pointers is a chain of ~12 dependent loads, which is what a trip then costs (measured: 6-7 us per trip).
+__device__ __forceinline__ u32 rows_of_trip(const u32* __restrict__ rowptr, u32 nrows, u32 rcur, u32 i, bool on, u32 lane) {
+    u32 row = rcur, base = rcur;
+    bool open = on;
+    for (u32 guard = 0; __ballot(open) != 0ull; ++guard) {
+        if (guard == 64) {   // thousands of empty rows inside one trip: finish with a plain search
+            if (open) {
+                u32 lo = base, hi = nrows - 1;
+                while (lo < hi) {
+                    const u32 mid = (lo + hi + 1) >> 1;
+                    if (rowptr[mid] <= i) lo = mid; else hi = mid - 1;
+                }
+                row = lo;
+            }
+            break;
+        }
+        const u32 at = base + 1 + lane;
+        const u32 bnd = rowptr[at < nrows ? at : nrows];   // rowptr[nrows] = nnz > every entry index
+        u32 lo = 0, hi = 64;                                // #boundaries <= i among the 64 loaded (they ascend with the lane)
+#pragma unroll
+        for (int st = 0; st < 7; ++st) {                    // 65 possible answers: 7 halvings
+            const u32 mid = (lo + hi) >> 1;
+            const u32 v = (u32)__shfl((int)bnd, (int)(mid & 63u), 64);
+            if (lo < hi) { if (v <= i) lo = mid + 1; else hi = mid; }
+        }
+        if (open && lo < 64) { row = base + lo; open = false; }
+        base += 64;
+    }
+    return row;
+}
+
 template <bool IMPLICIT>
 __global__ __launch_bounds__(64) void ks_scatter_kernel(const u32* __restrict__ key, const u32* __restrict__ val,
                                                        const u32* __restrict__ rowptr, u32 nrows, u64 n, KsGeom g,
@@ -105,34 +141,41 @@ __global__ __launch_bounds__(64) void ks_scatter_kernel(const u32* __restrict__ 
     __syncthreads();
     const u64 e0 = (u64)blockIdx.x * g.EB;
     const u64 e1 = e0 + g.EB < n ? e0 + g.EB : n;
-    u32 rlo = 0, rhi = 0;
-    if (IMPLICIT) {   // rows spanned by the block
-        rlo = row_of_entry(rowptr, 0, nrows - 1, (u32)e0);
-        rhi = row_of_entry(rowptr, rlo, nrows - 1, (u32)(e1 - 1));
-    }
-    for (u64 i0 = e0; i0 < e1; i0 += 64) {
-        const u64 i = i0 + lane;
-        bool on = i < e1;
-        u32 k = 0, v = 0;
-        if (on) {
-            k = key[i];
-            if (IMPLICIT) {
-                v = row_of_entry(rowptr, rlo, rhi, (u32)i);
-            } else {
-                v = val[i];
-                on = v != KS_INVALID;
-            }
+    u32 rcur = 0;
+    if (IMPLICIT) rcur = row_of_entry(rowptr, 0, nrows - 1, (u32)e0);
+    constexpr int U = 4;   // trips whose loads are issued together
+    for (u64 i0 = e0; i0 < e1; i0 += 64 * U) {
+        u32 k[U], v[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u64 i = i0 + (u64)u * 64 + lane;
+            on[u] = i < e1;
+            k[u] = on[u] ? key[i] : 0u;
+            v[u] = (!IMPLICIT && on[u]) ? val[i] : 0u;
         }
-        if (IMPLICIT) rlo = (u32)__builtin_amdgcn_readfirstlane((int)v);   // rows only grow along the block
-        const u32 b = k >> g.wb;
-        const u64 peers = match_digit(b, g.bbits, on);
-        if (on) {
-            const u32 rank = (u32)__popcll(peers & ((1ull << lane) - 1ull));
-            const u32 leader = (u32)__builtin_ctzll(peers);
-            u32 base = 0;
-            if (lane == leader) base = atomicAdd(&s_cur[b], (u32)__popcll(peers));
-            base = (u32)__shfl((int)base, (int)leader, 64);
-            out[base + rank] = make_uint2(k, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + (u64)u * 64 >= e1) break;   // wave-uniform
+            const u64 i = i0 + (u64)u * 64 + lane;
+            if (IMPLICIT) {
+                v[u] = rows_of_trip(rowptr, nrows, rcur, (u32)i, on[u], lane);
+                // rows only grow along the block: the next trip starts at the row of this trip's last entry
+                const u64 m = __ballot(on[u]);
+                rcur = (u32)__shfl((int)v[u], 63 - (int)__builtin_clzll(m), 64);
+            } else {
+                on[u] = on[u] && v[u] != KS_INVALID;
+            }
+            const u32 b = k[u] >> g.wb;
+            const u64 peers = match_digit(b, g.bbits, on[u]);
+            if (on[u]) {
+                const u32 rank = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+                const u32 leader = (u32)__builtin_ctzll(peers);
+                u32 base = 0;
+                if (lane == leader) base = atomicAdd(&s_cur[b], (u32)__popcll(peers));
+                base = (u32)__shfl((int)base, (int)leader, 64);
+                out[base + rank] = make_uint2(k[u], v[u]);
+            }
         }
     }
 }
@@ -184,20 +227,29 @@ __global__ __launch_bounds__(256) void ks_bucket_kernel(const uint2* __restrict_
         run += t0 + t1 + t2 + t3;
     }
     __syncthreads();
-    for (u32 i0 = qs; i0 < qe; i0 += 64) {
-        const u32 i = i0 + lane;
-        const bool on = i < qe;
-        uint2 p = make_uint2(0, 0);
-        if (on) p = pairs[i];
-        const u32 c = p.x & (W - 1);
-        const u64 peers = match_digit(c, g.wb, on);
-        if (on) {
-            const u32 rank = (u32)__popcll(peers & ((1ull << lane) - 1ull));
-            const u32 leader = (u32)__builtin_ctzll(peers);
-            u32 base = 0;
-            if (lane == leader) base = atomicAdd(&s_cnt[q * W + c], (u32)__popcll(peers));
-            base = (u32)__shfl((int)base, (int)leader, 64);
-            out_val[base + rank] = p.y;
+    constexpr int U = 4;   // trips whose loads are issued together
+    for (u32 i0 = qs; i0 < qe; i0 += 64 * U) {
+        uint2 p[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u32 i = i0 + u * 64 + lane;
+            on[u] = i < qe;
+            p[u] = on[u] ? pairs[i] : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * 64 >= qe) break;   // wave-uniform
+            const u32 c = p[u].x & (W - 1);
+            const u64 peers = match_digit(c, g.wb, on[u]);
+            if (on[u]) {
+                const u32 rank = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+                const u32 leader = (u32)__builtin_ctzll(peers);
+                u32 base = 0;
+                if (lane == leader) base = atomicAdd(&s_cnt[q * W + c], (u32)__popcll(peers));
+                base = (u32)__shfl((int)base, (int)leader, 64);
+                out_val[base + rank] = p[u].y;
+            }
         }
     }
 }
@@ -242,8 +294,8 @@ fgpu_info sort_pairs_by_key(fgpu_ctx* ctx, const u32* key, const u32* val, const
                                nrows, n, g, (const u32*)pos.p, pairs.p);
         FGPU_HIP(hipGetLastError());
     }
-    u32 n_valid = 0;
-    FGPU_TRY(read_u32(ctx, tot.p, &n_valid));
+    u32 n_valid = (u32)n;   // implicit values are never dropped: no read-back, no host sync
+    if (!implicit) FGPU_TRY(read_u32(ctx, tot.p, &n_valid));
     const size_t lds2 = (size_t)4 * (1u << g.wb) * sizeof(u32);
     if (lds2 > 48 * 1024)
         FGPU_HIP(hipFuncSetAttribute((const void*)ks_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -299,7 +351,7 @@ fgpu_info mat_transpose_counting(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* 
     FGPU_TRY(mat_alloc(ctx, &t, a->ncols, a->nrows, a->nnz, false, 0, false));
     fgpu_info i = sort_pairs_by_key(ctx, a->colidx, nullptr, a->rowptr, (u32)a->nrows, a->nnz, a->ncols, t->colidx,
                                     t->rowptr, nullptr);
-    if (i == FGPU_OK) i = mat_finalize(t);
+    // hub lists / max degree are built when a BFS plan, vxm or PageRank first asks (mat_ensure_finalized)
     if (i != FGPU_OK) { mat_release(t); return i; }
     *out = t;
     return FGPU_OK;
@@ -346,8 +398,7 @@ fgpu_info mat_from_device_coo_counting(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows,
     hipLaunchKernelGGL(dedup_scatter_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const u32*)byr_col.p,
                        (const u32*)keep.p, (const u32*)newpos.p, nv, m->colidx);
     hipError_t e = hipGetLastError();
-    i = e == hipSuccess ? mat_finalize(m) : FGPU_DEVICE;
-    if (i != FGPU_OK) { if (e != hipSuccess) set_error("COO build failed: %s", hipGetErrorString(e)); mat_release(m); return i; }
+    if (e != hipSuccess) { set_error("COO build failed: %s", hipGetErrorString(e)); mat_release(m); return FGPU_DEVICE; }
     *out = m;
     return FGPU_OK;
 }
