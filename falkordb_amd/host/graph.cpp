@@ -444,7 +444,11 @@ BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
                    const std::optional<std::string>& rel_type, bool want_edges) {
     BfsResult res;
     const u64 n = g.node_cap();
-    if (!source || n == 0) return res;                                   // NULL source / empty graph: no row
+    if (!source) return res;                                             // NULL source: no row (:1029)
+    // node_count() == 0 is tested BEFORE the deleted-source check (:1043-1048): with every node deleted the reference
+    // returns the empty batch, not "Source node not found"
+    const u64 live = n > g.deleted_nodes_count() ? n - g.deleted_nodes_count() : 0;
+    if (live == 0) return res;
     if (g.is_node_deleted(*source)) throw GrbError(FGPU_INVALID, "Source node not found in graph");
     std::vector<std::string> types;
     if (rel_type) types.push_back(*rel_type);

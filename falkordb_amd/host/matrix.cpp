@@ -1,6 +1,8 @@
 // matrix.cpp — Matrix<T> over libfgpu (mirrors graph/src/graph/graphblas/matrix.rs).
 #include <string.h>
 
+#include <atomic>
+
 #include "host.hpp"
 
 namespace falkor {
@@ -43,7 +45,11 @@ struct Matrix::State {
     std::shared_ptr<Snap> snap;
     // pending tuples / zombies: coordinate -> value to store, or nullopt to delete (last write wins)
     std::map<std::pair<u64, u64>, std::optional<u64>> pend;
-    std::mutex lock;  // Matrix::wait's per-matrix mutex (matrix.rs:781-796)
+    // Matrix::wait's protocol (matrix.rs:781-796): `has_pending` is what concurrent READERS look at (acquire); only
+    // the one that wins `lock` touches `pend` / `snap`, and it publishes the new snapshot with a release store of
+    // the flag.  Writers (set / remove / build ...) hold the matrix exclusively, as `&mut self` makes them in Rust.
+    std::atomic<bool> has_pending{false};
+    std::mutex lock;
 };
 
 static fgpu_mat* new_empty(Context& ctx, u64 nrows, u64 ncols) {
@@ -74,18 +80,19 @@ Type Matrix::type() const { return s_->type; }
 Context& Matrix::ctx() const { return *s_->ctx; }
 u64 Matrix::nrows() const { return s_->nrows; }
 u64 Matrix::ncols() const { return s_->ncols; }
-bool Matrix::pending() const { return !s_->pend.empty(); }
-bool Matrix::is_synced() const { return s_->pend.empty(); }
+bool Matrix::pending() const { return s_->has_pending.load(std::memory_order_acquire); }
+bool Matrix::is_synced() const { return !s_->has_pending.load(std::memory_order_acquire); }
 
 void Matrix::replace(fgpu_mat* fresh) const {
     s_->snap = std::make_shared<Snap>(fresh);
     s_->pend.clear();
+    s_->has_pending.store(false, std::memory_order_release);
 }
 
 void Matrix::wait() const {
-    if (s_->pend.empty()) return;
+    if (!s_->has_pending.load(std::memory_order_acquire)) return;
     std::lock_guard<std::mutex> g(s_->lock);
-    if (s_->pend.empty()) return;
+    if (!s_->has_pending.load(std::memory_order_relaxed)) return;
     std::vector<u64> ar, ac, av, dr, dc;
     for (auto& kv : s_->pend) {
         if (kv.second) {
@@ -112,6 +119,7 @@ void Matrix::wait() const {
     check(i, "GrB_Matrix_wait");
     s_->snap = std::make_shared<Snap>(out);
     s_->pend.clear();
+    s_->has_pending.store(false, std::memory_order_release);
 }
 
 const fgpu_mat* Matrix::snapshot() const {
@@ -145,12 +153,14 @@ void Matrix::set_element(u64 i, u64 j, u64 v) {
     if (i >= s_->nrows || j >= s_->ncols)
         throw GrbError(FGPU_OUT_OF_BOUNDS, "GrB_Matrix_setElement: index out of bounds");
     s_->pend[{i, j}] = s_->type == Type::Bool ? 1 : v;
+    s_->has_pending.store(true, std::memory_order_release);
 }
 
 void Matrix::remove_element(u64 i, u64 j) {
     if (i >= s_->nrows || j >= s_->ncols)
         throw GrbError(FGPU_OUT_OF_BOUNDS, "GrB_Matrix_removeElement: index out of bounds");
     s_->pend[{i, j}] = std::nullopt;
+    s_->has_pending.store(true, std::memory_order_release);
 }
 
 void Matrix::probe(const std::vector<u64>& rows, const std::vector<u64>& cols, std::vector<uint8_t>& present,
@@ -238,6 +248,7 @@ Matrix Matrix::dup() const {
     s->ncols = s_->ncols;
     s->snap = s_->snap;   // immutable on the device: copy-on-write for free
     s->pend = s_->pend;
+    s->has_pending.store(!s->pend.empty(), std::memory_order_release);
     return Matrix(std::move(s));
 }
 

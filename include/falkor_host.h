@@ -127,7 +127,10 @@ int fh_cond_traverse_row(fh_graph* g, const char* spec, int64_t from_id, int64_t
 int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_relationship, int batched,
                    const uint64_t* srcs, const uint64_t* dsts, uint64_t k, uint64_t** out_row,
                    uint64_t** out_src, uint64_t** out_dst, uint64_t** out_edge, uint64_t* n);  /* expand_into.rs:121-258 */
-/* source < 0 = NULL; rel_type NULL = all types */
+/* source < 0 = NULL; rel_type NULL = all types.  `edges` holds one id per (parent, child) pair that HAS a
+ * representative edge among the types, in node order; a pair without one is skipped in `edges` but its child stays in
+ * `nodes` — exactly what the reference yields (algo_procedures.rs:1121-1150) — so the two lists are parallel only
+ * while n_edges == n_nodes, which holds whenever the adjacency was built from the same types. */
 int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges,
                 int* has_row, uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges); /* algo_procedures.rs:1021-1160 */
 
