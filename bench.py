@@ -5,9 +5,12 @@
 
 A "step" is one whole BFS (the GrB_vxm frontier loop behind algo.BFS) from one of the 64
 Graph500-style roots of a synthetic R-MAT graph resident in HBM.  N=1 runs BASELINE.json
-configs[1] (RMAT scale-22, edge factor 16).  N>1 runs the same path on the column-slab
-partition (one process per GPU, frontier all-gather over RCCL each level) with weak scaling:
-scale = 22 + log2(N), i.e. the per-GPU edge count stays that of RMAT-22 (override: --scale).
+configs[1] (RMAT scale-22, edge factor 16).  N>1 runs the same path on a column-slab partition
+balanced by nnz (one process per GPU, one frontier all-gather-v over RCCL/xGMI per level).
+
+N > 1 runs RMAT-26 (BASELINE config 4: the same graph at every N, strong scaling, `--gpus 1 --scale 26` is the base
+point); the level loop and the per-level frontier exchange run inside libfgpu.so (fgpu_bfs_dist_run over an RCCL
+communicator the library owns), torch.distributed only launches the ranks, carries the communicator id and fences.
 
 Rank 0 prints ONE JSON line; `value` = total traversed edges (sum over BFS runs of the
 out-degrees of reached vertices) / max-over-ranks wall time of the K steps.
@@ -344,7 +347,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--scale", type=int, default=0, help="R-MAT scale (default 22 + log2(gpus))")
+    ap.add_argument("--scale", type=int, default=0, help="R-MAT scale (default: 22 on one GPU, 26 on several)")
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--alpha", type=float, default=0.0, help="push->pull switch factor (0 = library default)")
     ap.add_argument("--force-dir", type=int, default=0, help="0 auto, 1 push only, 2 pull only")
@@ -389,12 +392,11 @@ def main():
         import torch.distributed as td
         td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    scale = args.scale or (22 + int(round(math.log2(world))))
+    # N = 1: BASELINE config 2 (RMAT-22).  N > 1: BASELINE config 4 / north_star's scaling curve — RMAT-26, the SAME
+    # graph at every N (strong scaling); `--gpus 1 --scale 26` gives the curve's base point on one device.
+    scale = args.scale or (26 if world > 1 else 22)
     seed = 0x5EED1234 + scale
     ctx = engine.Context(local_rank)
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
     info = ctx.device_info()
     for kv in args.opt:
         k, v = kv.split("=")
@@ -405,23 +407,37 @@ def main():
     A_full = ctx.mat_rmat(scale, args.edge_factor, seed)
     n, nnz = A_full.nrows, A_full.nvals
     roots = pick_roots(A_full, 64)
+    splits, slab_nnz = None, None
     if use_dist:
-        lo, hi, slab = fdist.slab_range(n, rank, world)
-        A = A_full.col_slab(lo, min(hi, n))
+        # column-slab partition, boundaries balanced by nnz (prefix sum of in-degrees, multiples of 4096): rank r owns
+        # destinations [splits[r], splits[r+1]) and holds A[:, slab] (push) and A'[slab, :] (pull)
+        splits = A_full.balanced_splits(world)
+        A = A_full.col_slab(int(splits[rank]), int(min(splits[rank + 1], n)))
+        A_host = None
+        if rank == 0 and not args.no_cpu_baseline:
+            A_host = A_full.export_csr()[:2]       # the CPU baseline needs the whole graph; taken before it is freed
         A_full.free()
         At = A.transpose()
+        # the communicator lives inside libfgpu.so (fgpu_comm_*): the launcher's channel only carries the unique id
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        td.broadcast_object_list(uid, src=0, device=dev)
+        ctx.comm_init_rank(world, rank, uid[0])
+        plan = engine.BfsPlan(ctx, A, At, rank, world, splits=splits)
+        t = torch.zeros(world, dtype=torch.int64, device=dev)
+        t[rank] = A.nvals
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        slab_nnz = [int(x) for x in t.tolist()]
     else:
         A = A_full
         At = A.transpose()
-    backend = fdist.HipSlabBackend(ctx, A, At, rank if use_dist else 0, world if use_dist else 1, dev)
-    plan = backend.plan
+        plan = engine.BfsPlan(ctx, A, At)
     plan.tune(alpha=args.alpha, force_direction=args.force_dir)
     ctx.sync()
     t_build = time.time() - t_build
 
     def run_one(src):
         if use_dist:
-            backend.run(src)
+            engine.bfs_dist_run([plan], src, -1, False)   # level loop + frontier exchange inside the library
         else:
             plan.run(src, -1, False)
 
@@ -480,9 +496,42 @@ def main():
     total_edges = sum(edges_by_root[roots[i % len(roots)]] for i in range(args.steps))
     teps = total_edges / dt
 
-    # ---- roofline: per-kernel HIP-event timings over the same roots (second pass) ------------
+    # ---- multi-rank: time split of the timed searches (HIP events inside fgpu_bfs_dist_run), rank 0's view ---
     roofline = None
     spmv = None
+    dist_split = None
+    if use_dist:
+        lm = cm = 0.0
+        nl = sc = rl = 0
+        for i in range(min(args.steps, len(roots))):         # untimed replay: per-search event sums + scan counters
+            run_one(roots[i])
+            a_, b_, c_ = plan.dist_times()
+            st = plan.stats()
+            lm += a_; cm += b_; nl += c_
+            sc += st["scanned_push"] + st["scanned_pull"]
+            rl += st["reached"]
+        k = min(args.steps, len(roots))
+        nw_bytes = ((n + 4095) // 4096 * 4096) // 8
+        alg = 4 * sc + 2 * nw_bytes * nl + 20 * rl           # column ids examined + both bitmaps per level + level/deg of owned discoveries
+        tt = torch.tensor([lm, cm, float(alg), float(nl)], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        td.all_gather(gathered, tt)
+        per_rank = [[float(x) for x in g.tolist()] for g in gathered]
+        if rank == 0:
+            ach = alg / max(lm, 1e-9) / 1e6
+            roofline = {"bound": "hbm", "kernel": "bfs_fused_kernel (slab mode: every BFS level of rank 0's column slab)",
+                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": None, "alg_bytes_per_launch": int(alg / max(nl, 1)),
+                        "avg_launch_us": round(lm / max(nl, 1) * 1e3, 2), "launches": int(nl),
+                        "timing": "HIP events around every level kernel and every frontier exchange inside "
+                                  "fgpu_bfs_dist_run, replay of the first roots after the timed region"}
+            dist_split = {"searches": k, "per_search_ms": {"level_kernels": round(lm / k, 4), "frontier_exchange": round(cm / k, 4)},
+                          "exchange": "all-gather-v of the ranks' owned frontier words into every rank's bitmap: grouped "
+                                      "ncclSend / ncclRecv over RCCL (xGMI), inside libfgpu.so; includes the wait for the slowest rank",
+                          "per_rank_ms_per_search": [{"rank": r, "level_kernels": round(x[0] / k, 4),
+                                                      "frontier_exchange": round(x[1] / k, 4)} for r, x in enumerate(per_rank)],
+                          "frontier_bitmap_bytes": int(nw_bytes), "levels_per_search": round(nl / k, 2)}
+
     if not args.no_roofline and not use_dist:
         plan.profile(True)
         for i in range(args.steps):
@@ -540,12 +589,15 @@ def main():
     # direction-optimizing BFS (oracle/oracle_omp.c, same algorithm family) on every host core, with the
     # serial queue BFS (oracle/oracle.c) beside it.  Baseline only: the roofline fraction is the quality bar.
     cpu = None
-    if not args.no_cpu_baseline and not use_dist and rank == 0:
+    if not args.no_cpu_baseline and rank == 0:
         import oracle
-        rp, ci, _ = A.export_csr()
+        rp, ci = A_host if use_dist else A.export_csr()[:2]
         a = oracle.CSR(n, n, rp, ci)
-        trp, tci, _ = At.export_csr()
-        at = oracle.CSR(n, n, trp, tci)
+        A_host = None
+        at = None
+        if not use_dist and scale < 25:          # RMAT-25+ (17 GB of host arrays with the transpose): push-only baseline
+            trp, tci, _ = At.export_csr()
+            at = oracle.CSR(n, n, trp, tci)
         # thread count: the box reports every hardware thread of the host, but a job usually owns fewer
         # (cgroup quota) and an oversubscribed OpenMP team is slower than one thread — calibrate on one root
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -587,7 +639,8 @@ def main():
             if t_ser > args.cpu_seconds * 0.3:
                 break
         cpu = {"value": round(e_cpu / t_cpu, 1), "unit": "TEPS", "cores": threads, "kind": "port",
-               "sample": f"{k} BFS runs cycling the 64 roots of the same RMAT-{scale} graph, {t_cpu:.1f} s, OpenMP push/pull BFS "
+               "sample": f"{k} BFS runs cycling the 64 roots of the same RMAT-{scale} graph, {t_cpu:.1f} s, OpenMP "
+                         f"{'push/pull' if at is not None else 'push-only (no transposed copy on the host at this size)'} BFS "
                          f"(oracle/oracle_omp.c orc_bfs_omp) on {threads} threads; CPU stand-in for "
                          f"LAGraph + SuiteSparse:GraphBLAS, which are absent from this image",
                "threads_calibration_MTEPS": calib, "host_cpus_visible": ncpu, "cgroup_cpu_quota": quota,
@@ -643,7 +696,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 5),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
@@ -651,13 +704,18 @@ def main():
                 "workload": f"RMAT scale-{scale} BFS (boolean GrB_vxm frontier loop), edge factor {args.edge_factor}, "
                             f"64 Graph500-style roots, directed, deduplicated",
                 "scale": scale, "vertices": int(n), "edges": int(nnz),
-                "parallelism": ("1 GPU" if world == 1 else f"column-slab x{world} + frontier all-gather (RCCL)"),
+                "parallelism": ("1 GPU" if not use_dist else
+                                f"{world} column slabs balanced by nnz, one rank per GPU; per level one kernel per rank + one "
+                                f"all-gather-v of the frontier bitmap over RCCL/xGMI, loop and collective inside libfgpu.so"),
+                "slab_splits": [int(x) for x in splits] if splits is not None else None,
+                "slab_nnz": slab_nnz,
                 "direction": {0: "auto push/pull", 1: "push only", 2: "pull only"}[args.force_dir],
                 "device": info["name"], "build_seconds": round(t_build, 2),
                 "root0_levels": st0["levels"], "root0_push_levels": st0["push_levels"],
                 "root0_pull_levels": st0["pull_levels"],
             },
             "roofline": roofline,
+            "time_split": dist_split,
             "spmv_full_pass": spmv,
             "khop_match": khop,
             "cpu_baseline": cpu,

@@ -93,6 +93,15 @@ SIGNATURES = {
     "fgpu_mat_col_slab": (C.c_int32, [vp, vpp, vp, C.c_uint64, C.c_uint64]),
     "fgpu_mat_row_slab": (C.c_int32, [vp, vpp, vp, C.c_uint64, C.c_uint64]),
     "fgpu_bench_spmv": (C.c_int32, [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), u64p]),
+    "fgpu_comm_unique_id": (C.c_int32, [u8p]),
+    "fgpu_comm_init_rank": (C.c_int32, [vp, C.c_int, C.c_int, u8p]),
+    "fgpu_comm_init_all": (C.c_int32, [vpp, C.c_int]),
+    "fgpu_comm_finalize": (C.c_int32, [vp]),
+    "fgpu_comm_info": (C.c_int32, [vp, i32p, i32p]),
+    "fgpu_mat_balanced_splits": (C.c_int32, [vp, vp, C.c_int, u64p]),
+    "fgpu_bfs_plan_create_slab": (C.c_int32, [vp, vpp, vp, vp, C.c_int, C.c_int, u64p]),
+    "fgpu_bfs_dist_run": (C.c_int32, [vpp, C.c_int, C.c_uint64, C.c_int64, C.c_int]),
+    "fgpu_bfs_dist_times": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p]),
     "fgpu_prof_enable": (C.c_int32, [vp, C.c_int]),
     "fgpu_prof_read": (C.c_int32, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p, u64p, C.c_int,
                                    C.POINTER(C.c_int)]),

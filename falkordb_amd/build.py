@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libfgpu.so")
-SOURCES = ["ctx.hip", "prims.hip", "mat.hip", "bfs.hip", "spgemm.hip", "tiled.hip", "bitexpand.hip", "merge.hip", "pagerank.hip", "transpose.hip"]
+SOURCES = ["ctx.hip", "prims.hip", "mat.hip", "bfs.hip", "spgemm.hip", "tiled.hip", "bitexpand.hip", "merge.hip", "pagerank.hip", "transpose.hip", "dist.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -62,7 +62,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES
             if os.path.exists(os.path.join(CSRC, s))]
     if force or jobs or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        # RCCL: the frontier exchange of the multi-GPU BFS runs inside the library (dist.hip)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl",
+               "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -1559,6 +1559,16 @@ struct fgpu_bfs_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     u32 grid = 0;   // multi-rank step kernel
     u32 fgrid = 0;  // fused single-rank level kernel: every workgroup resident at once
+    // in-library multi-GPU loop (fgpu_bfs_dist_run): slab boundaries of every rank, library-owned exchange buffers,
+    // the global out-degree vector, and the time split compute / collective of the last search
+    std::vector<u64> splits;            // nranks + 1 vertex ids, multiples of 4096; empty = equal slabs
+    u64* dist_send[2] = {nullptr, nullptr};
+    u64* dist_glob = nullptr;
+    u32* dist_deg = nullptr;
+    bool dist_ready = false;
+    std::vector<hipEvent_t> dist_ev;    // 3 per level: before the level kernel, after it, after the collective
+    double dist_level_ms = 0, dist_coll_ms = 0;
+    u64 dist_levels = 0;
 };
 
 static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
@@ -1601,6 +1611,7 @@ extern "C" {
 fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     if (!p) return FGPU_OK;
     fgpu_ctx* c = p->ctx;
+    c->fence_lanes();   // the plan may have been driven from another thread's lane before
     c->dev_free(p->cur);
     c->dev_free(p->bm_block);
     c->dev_free(p->queue_block);
@@ -1612,6 +1623,11 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->level);
     c->dev_free(p->parent);
     c->dev_free(p->ctrl);
+    c->dev_free(p->dist_send[0]);
+    c->dev_free(p->dist_send[1]);
+    c->dev_free(p->dist_glob);
+    c->dev_free(p->dist_deg);
+    for (hipEvent_t e : p->dist_ev) (void)hipEventDestroy(e);
     if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
     if (p->h_done) (void)hipHostFree(p->h_done);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -1620,8 +1636,22 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     return FGPU_OK;
 }
 
+static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat* A, const fgpu_mat* At, int rank,
+                             int nranks, const uint64_t* splits);
+
 fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat* A, const fgpu_mat* At, int rank,
                                int nranks) {
+    return plan_create(ctx, out, A, At, rank, nranks, nullptr);
+}
+
+fgpu_info fgpu_bfs_plan_create_slab(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat* A_slab, const fgpu_mat* At_slab,
+                                    int rank, int nranks, const uint64_t* splits) {
+    FGPU_REQUIRE(splits, FGPU_NULL_POINTER, "fgpu_bfs_plan_create_slab: NULL splits");
+    return plan_create(ctx, out, A_slab, At_slab, rank, nranks, splits);
+}
+
+static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat* A, const fgpu_mat* At, int rank,
+                             int nranks, const uint64_t* splits) {
     FGPU_REQUIRE(ctx && out && A, FGPU_NULL_POINTER, "fgpu_bfs_plan_create: NULL argument");
     FGPU_REQUIRE(A->nrows == A->ncols, FGPU_DIM_MISMATCH, "BFS needs a square adjacency (%llu x %llu)",
                  (unsigned long long)A->nrows, (unsigned long long)A->ncols);
@@ -1638,20 +1668,40 @@ fgpu_info fgpu_bfs_plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_ma
     FGPU_REQUIRE(p, FGPU_OOM, "out of host memory");
     p->ctx = ctx; p->A = A; p->At = At; p->rank = rank; p->nranks = nranks;
     p->n = (u32)A->nrows;
-    u64 per = (A->nrows + nranks - 1) / nranks;
-    per = (per + 4095) & ~4095ull;
-    p->slab = (u32)per;
-    p->slabw = p->slab / 64;
-    p->nw = p->slabw * nranks;
-    p->lo = p->slab * rank;
-    p->hi = p->lo + p->slab;
+    if (splits) {
+        // caller-chosen slab boundaries (nnz-balanced, fgpu_mat_balanced_splits): ascending multiples of 4096 from 0 to
+        // the vertex count rounded up to 4096; the global frontier bitmap keeps its plain layout, rank r's words
+        // sit at word splits[r] / 64
+        bool ok = splits[0] == 0 && splits[nranks] >= A->nrows && splits[nranks] < A->nrows + 4096 &&
+                  splits[nranks] < 0xFFFFF000ull;
+        for (int r = 0; r < nranks && ok; ++r) ok = splits[r] <= splits[r + 1] && (splits[r + 1] & 4095ull) == 0;
+        if (!ok) {
+            delete p;
+            set_error("fgpu_bfs_plan_create_slab: splits must ascend from 0 to ceil4096(n) in multiples of 4096");
+            return FGPU_INVALID;
+        }
+        p->splits.assign(splits, splits + nranks + 1);
+        p->lo = (u32)splits[rank];
+        p->hi = (u32)splits[rank + 1];
+        p->slab = p->hi - p->lo;
+        p->slabw = p->slab / 64;
+        p->nw = (u32)(splits[nranks] / 64);
+    } else {
+        u64 per = (A->nrows + nranks - 1) / nranks;
+        per = (per + 4095) & ~4095ull;
+        p->slab = (u32)per;
+        p->slabw = p->slab / 64;
+        p->nw = p->slabw * nranks;
+        p->lo = p->slab * rank;
+        p->hi = p->lo + p->slab;
+    }
     fgpu_info i = FGPU_OK;
     const size_t wb = (size_t)p->nw * sizeof(u64);
     do {
         if ((i = ctx->dev_alloc((void**)&p->cur, wb)) != FGPU_OK) break;
         if ((i = ctx->dev_alloc((void**)&p->nxt_global, wb)) != FGPU_OK) break;
         if (nranks == 1) p->nxt_local = p->nxt_global;
-        else if ((i = ctx->dev_alloc((void**)&p->nxt_local, (size_t)p->slabw * sizeof(u64))) != FGPU_OK) break;
+        else if ((i = ctx->dev_alloc((void**)&p->nxt_local, ((size_t)p->slabw + 1) * sizeof(u64))) != FGPU_OK) break;
         if ((i = ctx->dev_alloc((void**)&p->visited, wb)) != FGPU_OK) break;
         if ((i = ctx->dev_alloc((void**)&p->level, (size_t)p->nw * 64 * sizeof(i32))) != FGPU_OK) break;
         if ((i = ctx->dev_alloc((void**)&p->parent, (size_t)p->nw * 64 * sizeof(u32))) != FGPU_OK) break;
@@ -1817,6 +1867,204 @@ fgpu_info fgpu_bfs_slab_level(fgpu_bfs_plan* p, int* send_index) {
     FGPU_HIP(hipGetLastError());
     if (send_index) *send_index = (int)(p->launch & 1);
     p->launch += 1;
+    return FGPU_OK;
+}
+
+// in-library multi-GPU loop ------------------------------------------------------------------
+static fgpu_info fetch_ctrl(fgpu_bfs_plan* p);
+// One search over a column-slab partition, driven entirely from here: per level ONE kernel per rank
+// (fgpu_bfs_slab_level) and ONE frontier exchange (all-gather-v of the ranks' owned words into every rank's global
+// bitmap).  `plans` holds this process' ranks: one plan when every GPU has its own process (the exchange then goes
+// through the context's RCCL communicator), all of them when one process drives the whole node (RCCL if the contexts
+// were joined by fgpu_comm_init_all, plain peer copies ordered by events otherwise — also how the loop is tested with
+// several slabs on one device).  Termination is read from the first plan's control block once per batch of blind
+// levels; it is decided from the population of the gathered bitmap, identical on every rank, so every rank issues the
+// same number of exchanges.
+__global__ void add_u32_kernel(u32* __restrict__ acc, const u32* __restrict__ x, u64 n) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) acc[i] += x[i];
+}
+
+static fgpu_info dist_setup(fgpu_bfs_plan* const* P, int np) {
+    bool all_ready = true;
+    for (int k = 0; k < np; ++k) all_ready = all_ready && P[k]->dist_ready;
+    if (all_ready) return FGPU_OK;
+    for (int k = 0; k < np; ++k) {
+        fgpu_bfs_plan* p = P[k];
+        fgpu_ctx* c = p->ctx;
+        if (!p->dist_send[0]) {
+            FGPU_TRY(c->dev_alloc((void**)&p->dist_send[0], ((size_t)p->slabw + 1) * sizeof(u64)));
+            FGPU_TRY(c->dev_alloc((void**)&p->dist_send[1], ((size_t)p->slabw + 1) * sizeof(u64)));
+            FGPU_TRY(c->dev_alloc((void**)&p->dist_glob, ((size_t)p->nw + 1) * sizeof(u64)));
+            FGPU_TRY(c->dev_alloc((void**)&p->dist_deg, ((size_t)p->n + 1) * sizeof(u32)));
+            FGPU_TRY(fgpu_bfs_slab_set_buffers(p, p->dist_send[0], p->dist_send[1], p->dist_glob));
+            p->external_bufs = true;   // dist_* are released by fgpu_bfs_plan_free through their own fields
+        }
+        // global out-degrees: a column slab holds only its share of every row; the owner of a vertex accounts the
+        // whole degree at discovery (edges_traversed) and feeds its push / pull rule with it
+        FGPU_TRY(fgpu_mat_row_degrees(c, p->A, p->dist_deg));
+    }
+    const bool rccl = P[0]->ctx->comm != nullptr && P[0]->nranks > 1;
+    if (rccl) {
+        if (np > 1) FGPU_TRY(comm_group_begin());
+        for (int k = 0; k < np; ++k) FGPU_TRY(comm_allreduce_sum_u32(P[k]->ctx, P[k]->dist_deg, P[k]->n));
+        if (np > 1) FGPU_TRY(comm_group_end());
+    } else if (np > 1) {
+        // gang without a communicator (several slabs driven by one process, e.g. on one device): sum on plan 0, copy back
+        fgpu_ctx* c0 = P[0]->ctx;
+        DevBuf<u32> tmp;
+        FGPU_TRY(tmp.alloc(c0, (size_t)P[0]->n + 1));
+        for (int k = 1; k < np; ++k) {
+            FGPU_HIP(hipStreamSynchronize(P[k]->ctx->stream()));
+            FGPU_HIP(hipMemcpyAsync(tmp.p, P[k]->dist_deg, (size_t)P[0]->n * sizeof(u32), hipMemcpyDefault, c0->stream()));
+            hipLaunchKernelGGL(add_u32_kernel, dim3(c0->cus * 8), dim3(256), 0, c0->stream(), P[0]->dist_deg,
+                               (const u32*)tmp.p, (u64)P[0]->n);
+            FGPU_HIP(hipGetLastError());
+        }
+        FGPU_HIP(hipStreamSynchronize(c0->stream()));
+        for (int k = 1; k < np; ++k) {
+            FGPU_HIP(hipMemcpyAsync(P[k]->dist_deg, P[0]->dist_deg, (size_t)P[0]->n * sizeof(u32), hipMemcpyDefault,
+                                    P[k]->ctx->stream()));
+            FGPU_HIP(hipStreamSynchronize(P[k]->ctx->stream()));
+        }
+    }
+    for (int k = 0; k < np; ++k) {
+        FGPU_TRY(fgpu_bfs_slab_set_degrees(P[k], P[k]->dist_deg));
+        FGPU_HIP(hipStreamSynchronize(P[k]->ctx->stream()));
+        P[k]->dist_ready = true;
+    }
+    return FGPU_OK;
+}
+
+// word offsets / counts of every rank's slab in the global bitmap
+static void slab_layout(const fgpu_bfs_plan* p, std::vector<u64>& offs, std::vector<u64>& cnts) {
+    offs.resize(p->nranks);
+    cnts.resize(p->nranks);
+    for (int r = 0; r < p->nranks; ++r) {
+        if (!p->splits.empty()) {
+            offs[r] = p->splits[r] / 64;
+            cnts[r] = (p->splits[r + 1] - p->splits[r]) / 64;
+        } else {
+            offs[r] = (u64)p->slabw * r;
+            cnts[r] = p->slabw;
+        }
+    }
+}
+
+static fgpu_info dist_event(fgpu_bfs_plan* p, size_t idx) {
+    while (p->dist_ev.size() <= idx) {
+        hipEvent_t e = nullptr;
+        FGPU_HIP(hipEventCreate(&e));
+        p->dist_ev.push_back(e);
+    }
+    FGPU_HIP(hipEventRecord(p->dist_ev[idx], p->ctx->stream()));
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t src, int64_t max_level, int want_parent) {
+    FGPU_REQUIRE(plans && nplans >= 1 && plans[0], FGPU_NULL_POINTER, "fgpu_bfs_dist_run: NULL plans");
+    fgpu_bfs_plan* p0 = plans[0];
+    FGPU_REQUIRE(nplans == 1 || nplans == p0->nranks, FGPU_INVALID,
+                 "fgpu_bfs_dist_run: pass this process' one plan, or the plans of all %d ranks", p0->nranks);
+    for (int k = 0; k < nplans; ++k) {
+        FGPU_REQUIRE(plans[k] && plans[k]->nranks == p0->nranks && plans[k]->nw == p0->nw && plans[k]->n == p0->n,
+                     FGPU_INVALID, "fgpu_bfs_dist_run: plan %d does not belong to the same partition", k);
+        FGPU_REQUIRE(nplans == 1 || plans[k]->rank == k, FGPU_INVALID, "fgpu_bfs_dist_run: plans must come in rank order");
+    }
+    const bool rccl = p0->ctx->comm != nullptr && p0->nranks > 1;
+    FGPU_REQUIRE(nplans == p0->nranks || rccl, FGPU_INVALID,
+                 "fgpu_bfs_dist_run: rank %d of %d has no communicator (fgpu_comm_init_rank / fgpu_comm_init_all)",
+                 p0->rank, p0->nranks);
+    FGPU_REQUIRE(!rccl || (p0->ctx->comm_nranks == p0->nranks && (nplans > 1 || p0->ctx->comm_rank == p0->rank)),
+                 FGPU_INVALID, "fgpu_bfs_dist_run: the plan's rank / size differ from its context's communicator");
+    FGPU_TRY(dist_setup(plans, nplans));
+    std::vector<u64> offs, cnts;
+    slab_layout(p0, offs, cnts);
+    for (int k = 0; k < nplans; ++k) FGPU_TRY(fgpu_bfs_slab_begin(plans[k], src, max_level, want_parent));
+    std::vector<hipEvent_t> lvl_done(nplans, nullptr), copied(nplans, nullptr);   // peer mode only
+    const bool peer = !rccl && nplans > 1;
+    fgpu_info rc = FGPU_OK;
+    if (peer)
+        for (int k = 0; k < nplans && rc == FGPU_OK; ++k) {
+            if (hipEventCreateWithFlags(&lvl_done[k], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&copied[k], hipEventDisableTiming) != hipSuccess) {
+                set_error("fgpu_bfs_dist_run: event creation failed");
+                rc = FGPU_DEVICE;
+            }
+        }
+    int budget = p0->last_levels ? (p0->last_levels + 1 > 4 ? p0->last_levels + 1 : 4) : 6;
+    u64 nlev = 0;
+    std::vector<int> idx(nplans, 0);
+    auto one_level = [&]() -> fgpu_info {
+        for (int k = 0; k < nplans; ++k) {
+            FGPU_TRY(dist_event(plans[k], 3 * nlev));
+            FGPU_TRY(fgpu_bfs_slab_level(plans[k], &idx[k]));
+            FGPU_TRY(dist_event(plans[k], 3 * nlev + 1));
+        }
+        if (!peer) {
+            if (rccl && nplans > 1) FGPU_TRY(comm_group_begin());
+            for (int k = 0; k < nplans; ++k)
+                FGPU_TRY(comm_allgatherv_u64(plans[k]->ctx, plans[k]->dist_send[idx[k]], plans[k]->dist_glob, offs.data(),
+                                             cnts.data()));
+            if (rccl && nplans > 1) FGPU_TRY(comm_group_end());
+        } else {
+            // every rank's slab goes to every rank's bitmap; a copy waits for the level that produced its source, and
+            // the next level of a rank (which clears the send buffer it is about to reuse) waits for every copy
+            for (int s = 0; s < nplans; ++s) FGPU_HIP(hipEventRecord(lvl_done[s], plans[s]->ctx->stream()));
+            for (int d = 0; d < nplans; ++d) {
+                hipStream_t st = plans[d]->ctx->stream();
+                for (int s = 0; s < nplans; ++s) {
+                    if (s != d) FGPU_HIP(hipStreamWaitEvent(st, lvl_done[s], 0));
+                    if (cnts[s])
+                        FGPU_HIP(hipMemcpyAsync(plans[d]->dist_glob + offs[s], plans[s]->dist_send[idx[s]],
+                                                cnts[s] * sizeof(u64), hipMemcpyDefault, st));
+                }
+                FGPU_HIP(hipEventRecord(copied[d], st));
+            }
+            for (int s = 0; s < nplans; ++s)
+                for (int d = 0; d < nplans; ++d)
+                    if (s != d) FGPU_HIP(hipStreamWaitEvent(plans[s]->ctx->stream(), copied[d], 0));
+        }
+        for (int k = 0; k < nplans; ++k) FGPU_TRY(dist_event(plans[k], 3 * nlev + 2));
+        ++nlev;
+        return FGPU_OK;
+    };
+    while (rc == FGPU_OK) {
+        for (int k = 0; k < budget && rc == FGPU_OK; ++k) rc = one_level();
+        if (rc != FGPU_OK) break;
+        for (int k = 1; k < nplans; ++k)
+            if (hipStreamSynchronize(plans[k]->ctx->stream()) != hipSuccess) { set_error("fgpu_bfs_dist_run: stream failed"); rc = FGPU_DEVICE; }
+        if (rc == FGPU_OK) rc = fetch_ctrl(p0);
+        if (rc != FGPU_OK || p0->h_ctrl->done) break;
+        budget = 2;
+    }
+    for (int k = 0; k < nplans; ++k) {
+        if (lvl_done[k]) (void)hipEventDestroy(lvl_done[k]);
+        if (copied[k]) (void)hipEventDestroy(copied[k]);
+    }
+    if (rc != FGPU_OK) return rc;
+    for (int k = 0; k < nplans; ++k) {
+        fgpu_bfs_plan* p = plans[k];
+        FGPU_HIP(hipStreamSynchronize(p->ctx->stream()));
+        p->last_levels = (int)p0->h_ctrl->level;
+        double lm = 0, cm = 0;
+        for (u64 l = 0; l < nlev; ++l) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, p->dist_ev[3 * l], p->dist_ev[3 * l + 1]) == hipSuccess) lm += a;
+            if (hipEventElapsedTime(&b, p->dist_ev[3 * l + 1], p->dist_ev[3 * l + 2]) == hipSuccess) cm += b;
+        }
+        (void)hipGetLastError();
+        p->dist_level_ms = lm;
+        p->dist_coll_ms = cm;
+        p->dist_levels = nlev;
+    }
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_bfs_dist_times(fgpu_bfs_plan* p, double* level_ms, double* collective_ms, uint64_t* launches) {
+    FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_dist_times: NULL plan");
+    if (level_ms) *level_ms = p->dist_level_ms;
+    if (collective_ms) *collective_ms = p->dist_coll_ms;
+    if (launches) *launches = p->dist_levels;
     return FGPU_OK;
 }
 

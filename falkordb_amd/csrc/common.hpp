@@ -72,6 +72,8 @@ struct fgpu_options {  // fgpu_set_option
     int bfs_hub_first = 1;     // pull levels read A' rows reordered hub-first (bfs.hip ensure_pull_order)
     int bfs_prof_split = 0;    // profiled BFS pass launches the <.., 1|2> twins that name a level push / pull (PMC passes)
     int merge_mode = 0;        // Delta merge: 0 entry-parallel (merge.hip), 1 one wavefront per row (pattern only)
+    int dist_collective = 0;   // frontier exchange of the in-library multi-GPU BFS: 0 grouped ncclSend/ncclRecv
+                               // (all-gather-v, direct peer-to-peer over xGMI), 1 one ncclBroadcast per rank in a group
     int transpose_mode = 0;    // pattern transpose: 0 counting transpose (no sort), 1 COO rebuild through the sorter (A/B)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
 };
@@ -104,6 +106,9 @@ struct fgpu_ctx {
     std::vector<fgpu_lane*> lanes;
     std::map<void*, size_t> live;       // capacity of live blocks
     uint64_t bytes_in_use = 0, bytes_pooled = 0;
+    // multi-GPU: this context's rank in an RCCL communicator (dist.hip); nullptr = not part of one
+    void* comm = nullptr;               // ncclComm_t
+    int comm_rank = 0, comm_nranks = 1;
     // kernel profiler (measurement hook): off unless fgpu_prof_enable(ctx, 1)
     bool prof_on = false;
     std::mutex prof_mu;
@@ -332,6 +337,13 @@ fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncol
 // read one u32 / u64 from device on the ctx stream (synchronises).
 fgpu_info read_u32(fgpu_ctx* ctx, const u32* dev, u32* host);
 fgpu_info read_u64(fgpu_ctx* ctx, const u64* dev, u64* host);
+
+// dist.hip: frontier exchange over the context's communicator.  Rank r's `counts[r]` words live at `buf + offs[r]` on
+// every rank after the call; this rank's own piece is `send` (copied into place on the stream).  u64 words.
+fgpu_info comm_allgatherv_u64(fgpu_ctx* ctx, const u64* send, u64* buf, const u64* offs, const u64* counts);
+fgpu_info comm_allreduce_sum_u32(fgpu_ctx* ctx, u32* buf, u64 n);
+fgpu_info comm_group_begin();   // ncclGroupStart / End around the calls of several ranks driven by one thread
+fgpu_info comm_group_end();
 
 void tiles_release(fgpu_tiles* t);
 // tiled.hip: build the LDS-tile layout of `m` (0 = automatic parameter) / run out = m (x) x & ~mask

@@ -1,0 +1,182 @@
+// dist.hip — the multi-GPU side of the C ABI: RCCL communicators owned by fgpu contexts, the frontier exchange
+// (all-gather-v) of the partitioned BFS, and nnz-balanced slab boundaries.
+//
+// SURVEY.md §8e / BASELINE.json north_star: "the adjacency matrix row-partitions across the 8 GPUs of one node with an
+// RCCL allgatherv of the frontier vector over xGMI each hop".  The reference reaches its BFS through one call
+// (LAGr_BreadthFirstSearch_Extended, algo_procedures.rs:1079-1088); a Redis-module process that links libfgpu.so
+// must reach the multi-GPU form the same way — so the communicator, the level loop and the collective live in this
+// library (fgpu_bfs_dist_run, bfs.hip), not in a Python driver.  Two ways in:
+//   * one process per GPU (torchrun, MPI, ...): rank 0 calls fgpu_comm_unique_id, the launcher's own channel carries
+//     the 128 bytes to the other ranks, every rank calls fgpu_comm_init_rank;
+//   * one process, several GPUs (the Redis module): one context per device, fgpu_comm_init_all.
+// xGMI is point-to-point (7 links per GPU): the exchange is a grouped ncclSend / ncclRecv to every peer — each piece
+// crosses exactly one link once — not a ring.
+#include <math.h>
+#include <rccl/rccl.h>
+
+#include "common.hpp"
+
+namespace fgpu {
+
+#define FGPU_NCCL(expr)                                                                                   \
+    do {                                                                                                  \
+        ncclResult_t _r = (expr);                                                                         \
+        if (_r != ncclSuccess) {                                                                          \
+            ::fgpu::set_error("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_r), __FILE__, __LINE__); \
+            return FGPU_DEVICE;                                                                           \
+        }                                                                                                 \
+    } while (0)
+
+fgpu_info comm_allgatherv_u64(fgpu_ctx* ctx, const u64* send, u64* buf, const u64* offs, const u64* counts) {
+    const int me = ctx->comm_rank, nr = ctx->comm_nranks;
+    hipStream_t st = ctx->stream();
+    if (counts[me])
+        FGPU_HIP(hipMemcpyAsync(buf + offs[me], send, counts[me] * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    if (nr == 1 || !ctx->comm) return FGPU_OK;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    FGPU_NCCL(ncclGroupStart());
+    if (ctx->opt.dist_collective == 1) {
+        for (int r = 0; r < nr; ++r)
+            if (counts[r])
+                FGPU_NCCL(ncclBroadcast(r == me ? (const void*)send : (const void*)(buf + offs[r]), buf + offs[r],
+                                        counts[r], ncclUint64, r, comm, st));
+    } else {
+        for (int r = 0; r < nr; ++r) {
+            if (r == me) continue;
+            if (counts[me]) FGPU_NCCL(ncclSend(send, counts[me], ncclUint64, r, comm, st));
+            if (counts[r]) FGPU_NCCL(ncclRecv(buf + offs[r], counts[r], ncclUint64, r, comm, st));
+        }
+    }
+    FGPU_NCCL(ncclGroupEnd());
+    return FGPU_OK;
+}
+
+fgpu_info comm_allreduce_sum_u32(fgpu_ctx* ctx, u32* buf, u64 n) {
+    if (ctx->comm_nranks == 1 || !ctx->comm) return FGPU_OK;
+    FGPU_NCCL(ncclAllReduce(buf, buf, n, ncclUint32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream()));
+    return FGPU_OK;
+}
+
+// nested grouping for a single-process gang: all ranks' calls of one exchange are issued by one thread
+fgpu_info comm_group_begin() { FGPU_NCCL(ncclGroupStart()); return FGPU_OK; }
+fgpu_info comm_group_end() { FGPU_NCCL(ncclGroupEnd()); return FGPU_OK; }
+
+// entries per block of 2^shift columns (LDS-privatised: no per-entry global atomic)
+__global__ __launch_bounds__(256) void colblock_hist_kernel(const u32* __restrict__ col, u64 nnz, u32 shift, u32 nblocks,
+                                                           unsigned long long* __restrict__ hist) {
+    extern __shared__ u32 s_h[];
+    for (u32 b = threadIdx.x; b < nblocks; b += 256) s_h[b] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (u64)gridDim.x * 256) atomicAdd(&s_h[col[i] >> shift], 1u);
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < nblocks; b += 256)
+        if (s_h[b]) atomicAdd(&hist[b], (unsigned long long)s_h[b]);
+}
+
+}  // namespace fgpu
+
+using namespace fgpu;
+
+extern "C" {
+
+fgpu_info fgpu_comm_unique_id(uint8_t* id) {
+    FGPU_REQUIRE(id, FGPU_NULL_POINTER, "fgpu_comm_unique_id: NULL id");
+    static_assert(sizeof(ncclUniqueId) == FGPU_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    FGPU_NCCL(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_comm_init_rank(fgpu_ctx* ctx, int nranks, int rank, const uint8_t* id) {
+    FGPU_REQUIRE(ctx && id, FGPU_NULL_POINTER, "fgpu_comm_init_rank: NULL argument");
+    FGPU_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, FGPU_INVALID, "fgpu_comm_init_rank: bad rank %d / %d", rank, nranks);
+    FGPU_REQUIRE(!ctx->comm, FGPU_INVALID, "fgpu_comm_init_rank: the context already has a communicator");
+    (void)ctx->lane();   // makes ctx->device current on this thread
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t c = nullptr;
+    FGPU_NCCL(ncclCommInitRank(&c, nranks, u, rank));
+    ctx->comm = c;
+    ctx->comm_rank = rank;
+    ctx->comm_nranks = nranks;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_comm_init_all(fgpu_ctx* const* ctxs, int n) {
+    FGPU_REQUIRE(ctxs && n >= 1, FGPU_INVALID, "fgpu_comm_init_all: need at least one context");
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) {
+        FGPU_REQUIRE(ctxs[i] && !ctxs[i]->comm, FGPU_INVALID, "fgpu_comm_init_all: context %d is NULL or already in a communicator", i);
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; ++j)
+            FGPU_REQUIRE(devs[j] != devs[i], FGPU_INVALID,
+                         "fgpu_comm_init_all: contexts %d and %d share device %d (RCCL wants one rank per GPU)", j, i, devs[i]);
+    }
+    std::vector<ncclComm_t> comms(n, nullptr);
+    FGPU_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) {
+        ctxs[i]->comm = comms[i];
+        ctxs[i]->comm_rank = i;
+        ctxs[i]->comm_nranks = n;
+    }
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_comm_finalize(fgpu_ctx* ctx) {
+    FGPU_REQUIRE(ctx, FGPU_NULL_POINTER, "fgpu_comm_finalize: NULL ctx");
+    if (ctx->comm) {
+        (void)hipStreamSynchronize(ctx->stream());
+        (void)ncclCommDestroy((ncclComm_t)ctx->comm);
+    }
+    ctx->comm = nullptr;
+    ctx->comm_rank = 0;
+    ctx->comm_nranks = 1;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_comm_info(fgpu_ctx* ctx, int32_t* rank, int32_t* nranks) {
+    FGPU_REQUIRE(ctx, FGPU_NULL_POINTER, "fgpu_comm_info: NULL ctx");
+    if (rank) *rank = ctx->comm_rank;
+    if (nranks) *nranks = ctx->comm ? ctx->comm_nranks : 1;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_mat_balanced_splits(fgpu_ctx* ctx, const fgpu_mat* a, int nparts, uint64_t* splits) {
+    FGPU_REQUIRE(ctx && a && splits, FGPU_NULL_POINTER, "fgpu_mat_balanced_splits: NULL argument");
+    FGPU_REQUIRE(nparts >= 1, FGPU_INVALID, "fgpu_mat_balanced_splits: nparts must be >= 1");
+    // in-degree per block of 2^shift columns; boundaries are block boundaries (>= 4096 so that they stay word-aligned
+    // for every bitmap and level kernel), chosen where the running entry count crosses k * nnz / nparts
+    u32 shift = 12;
+    while (((a->ncols + (1ull << shift) - 1) >> shift) > 8192) ++shift;
+    const u32 nblocks = (u32)((a->ncols + (1ull << shift) - 1) >> shift);
+    const u64 top = (((a->ncols + 4095) >> 12) << 12);   // the padded vertex count every plan uses
+    std::vector<unsigned long long> h(nblocks, 0);
+    if (a->nnz) {
+        DevBuf<unsigned long long> dh;
+        FGPU_TRY(dh.alloc(ctx, nblocks));
+        FGPU_HIP(hipMemsetAsync(dh.p, 0, (size_t)nblocks * sizeof(unsigned long long), ctx->stream()));
+        u32 grid = cdiv(a->nnz, 256 * 64);
+        if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
+        hipLaunchKernelGGL(colblock_hist_kernel, dim3(grid ? grid : 1), dim3(256), (size_t)nblocks * sizeof(u32), ctx->stream(),
+                           (const u32*)a->colidx, (u64)a->nnz, shift, nblocks, dh.p);
+        FGPU_HIP(hipGetLastError());
+        FGPU_HIP(hipMemcpyAsync(h.data(), dh.p, (size_t)nblocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream()));
+        FGPU_HIP(hipStreamSynchronize(ctx->stream()));
+    }
+    // boundary k sits at the block edge whose entry prefix is nearest to k * nnz / nparts (edges never move backwards)
+    std::vector<u64> pre(nblocks + 1, 0);
+    for (u32 b = 0; b < nblocks; ++b) pre[b + 1] = pre[b] + h[b];
+    splits[0] = 0;
+    u32 j = 0;
+    for (int k = 1; k < nparts; ++k) {
+        const double t = (double)a->nnz * (double)k / (double)nparts;
+        while (j < nblocks && fabs((double)pre[j + 1] - t) <= fabs((double)pre[j] - t)) ++j;
+        const u64 edge = (u64)j << shift;
+        splits[k] = edge < top ? edge : top;
+    }
+    splits[nparts] = top;
+    return FGPU_OK;
+}
+
+}  // extern "C"

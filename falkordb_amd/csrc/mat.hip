@@ -537,7 +537,17 @@ using namespace fgpu;
 namespace fgpu {
 // pattern-only transpose on device (values, if any, are ignored)
 fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
-    if (a->nnz == 0) return fgpu_mat_new(ctx, out, a->ncols, a->nrows);
+    if (a->nnz == 0) {
+        if (a->is_hyper()) return fgpu_mat_new(ctx, out, a->ncols, a->nrows);
+        // an empty matrix in the dense-row-pointer form stays in that form (an empty column slab of a partitioned
+        // BFS — more ranks than populated vertex blocks — still needs a plan over dense row pointers)
+        fgpu_mat* o = nullptr;
+        FGPU_TRY(mat_alloc(ctx, &o, a->ncols, a->nrows, 0, false, 0, false));
+        hipError_t e = hipMemsetAsync(o->rowptr, 0, (a->ncols + 1) * sizeof(u32), ctx->stream());
+        if (e != hipSuccess) { mat_release(o); set_error("memset failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+        *out = o;
+        return FGPU_OK;
+    }
     if (ctx->opt.transpose_mode == 0) {   // stable partition by column: rows of the result come out ascending, no sort
         fgpu_info ci = mat_transpose_counting(ctx, out, a);
         if (ci != FGPU_NO_VALUE) return ci;

@@ -28,6 +28,33 @@ def slab_range(n: int, rank: int, nranks: int) -> tuple[int, int, int]:
     return rank * slab, (rank + 1) * slab, slab
 
 
+def balanced_splits(block_counts, n: int, nparts: int, shift: int = 12):
+    """Python twin of fgpu_mat_balanced_splits (dist.hip): `block_counts[b]` = entries whose column lies in block b of
+    2**shift columns; boundary k is the block edge whose entry prefix is nearest to k * nnz / nparts; boundaries are
+    multiples of 4096, start at 0 and end at n rounded up to 4096."""
+    top = ((n + 4095) >> 12) << 12
+    pre = [0]
+    for c in block_counts:
+        pre.append(pre[-1] + int(c))
+    nnz, nblocks = pre[-1], len(block_counts)
+    splits, j = [0], 0
+    for k in range(1, nparts):
+        t = nnz * k / nparts
+        while j < nblocks and abs(pre[j + 1] - t) <= abs(pre[j] - t):
+            j += 1
+        splits.append(min(j << shift, top))
+    splits.append(top)
+    return splits
+
+
+def splits_shift(ncols: int) -> int:
+    """Block size fgpu_mat_balanced_splits uses for `ncols` columns (at most 8192 blocks of >= 4096 columns)."""
+    shift = 12
+    while ((ncols + (1 << shift) - 1) >> shift) > 8192:
+        shift += 1
+    return shift
+
+
 def run_levels(backend, gather: Callable[[], None], src: int, max_level: int = -1, first_batch: int = 6,
                batch: int = 3) -> int:
     """Drive one BFS: returns the number of levels.  `backend.done()` is the only host sync."""

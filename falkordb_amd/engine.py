@@ -55,6 +55,25 @@ class Context:
     def set_option(self, name: str, value: int):
         check(self.lib.fgpu_set_option(self._h, name.encode(), int(value)))
 
+    # ---- multi-GPU communicator (RCCL inside libfgpu.so; dist.hip) ----
+    def comm_unique_id(self) -> bytes:
+        """ncclGetUniqueId: rank 0 calls it, the launcher's own channel carries the 128 bytes to the other ranks."""
+        buf = (C.c_uint8 * 128)()
+        check(self.lib.fgpu_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init_rank(self, nranks: int, rank: int, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        check(self.lib.fgpu_comm_init_rank(self._h, nranks, rank, buf))
+
+    def comm_finalize(self):
+        check(self.lib.fgpu_comm_finalize(self._h))
+
+    def comm_info(self):
+        r, n = C.c_int32(), C.c_int32()
+        check(self.lib.fgpu_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
     def prof_enable(self, enable=True):
         """Context-wide kernel profiler (HIP events around the modelled kernels of the non-BFS paths)."""
         check(self.lib.fgpu_prof_enable(self._h, 1 if enable else 0))
@@ -189,6 +208,12 @@ class Mat:
         h = C.c_void_p()
         check(self.ctx.lib.fgpu_mat_transpose(self.ctx._h, C.byref(h), self._h))
         return Mat(self.ctx, h)
+
+    def balanced_splits(self, nparts: int):
+        """nnz-balanced boundaries of the destination vertices (columns) for `nparts` column slabs (multiples of 4096)."""
+        out = np.zeros(nparts + 1, dtype=U64)
+        check(self.ctx.lib.fgpu_mat_balanced_splits(self.ctx._h, self._h, nparts, _p(out)))
+        return out
 
     def sample(self, seed: int, denom: int) -> "Mat":
         """Entries (r, c) with mix64(seed ^ mix64(r << 32 | c)) % denom == 0 (bench / test data)."""
@@ -354,11 +379,24 @@ def pagerank(ctx: Context, A: Mat, At: Mat | None = None, active_bitmap=None, da
 class BfsPlan:
     """fgpu_bfs_plan: resident BFS workspace (+ slab partition state for multi-rank runs)."""
 
-    def __init__(self, ctx: Context, A: Mat, At: Mat | None, rank=0, nranks=1):
+    def __init__(self, ctx: Context, A: Mat, At: Mat | None, rank=0, nranks=1, splits=None):
         self.ctx, self.A, self.At = ctx, A, At
         self._h = C.c_void_p()
-        check(ctx.lib.fgpu_bfs_plan_create(ctx._h, C.byref(self._h), A._h, At._h if At else None, rank, nranks))
+        self.rank, self.nranks = rank, nranks
+        if splits is None:
+            check(ctx.lib.fgpu_bfs_plan_create(ctx._h, C.byref(self._h), A._h, At._h if At else None, rank, nranks))
+        else:   # caller-chosen (nnz-balanced) slab boundaries
+            sp = _u64(splits)
+            assert len(sp) == nranks + 1
+            check(ctx.lib.fgpu_bfs_plan_create_slab(ctx._h, C.byref(self._h), A._h, At._h if At else None, rank,
+                                                    nranks, _p(sp)))
         self.n = A.nrows
+
+    def dist_times(self):
+        """(level-kernel ms, collective ms, level launches) of this rank's last bfs_dist_run (HIP-event sums)."""
+        lm, cm, nl = C.c_double(), C.c_double(), C.c_uint64()
+        check(self.ctx.lib.fgpu_bfs_dist_times(self._h, C.byref(lm), C.byref(cm), C.byref(nl)))
+        return lm.value, cm.value, nl.value
 
     def free(self):
         if self._h:
@@ -450,6 +488,16 @@ class BfsPlan:
         d, l = C.c_int32(), C.c_int32()
         check(self.ctx.lib.fgpu_bfs_part_done(self._h, C.byref(d), C.byref(l)))
         return bool(d.value), l.value
+
+
+def bfs_dist_run(plans, src: int, max_level: int = -1, want_parent: bool = False):
+    """fgpu_bfs_dist_run: one whole search over a column-slab partition, level loop and frontier exchange inside the
+    library.  `plans` = this process' ranks: one BfsPlan (one process per GPU, RCCL communicator on its context) or
+    the plans of every rank in rank order (one process drives them all)."""
+    plans = list(plans)
+    arr = (C.c_void_p * len(plans))(*[p._h for p in plans])
+    check(plans[0].ctx.lib.fgpu_bfs_dist_run(arr, len(plans), C.c_uint64(src), C.c_int64(max_level),
+                                             1 if want_parent else 0))
 
 
 def bench_spmv(ctx: Context, A: Mat, which=0, iters=20):

@@ -85,7 +85,8 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * "expand_mode" (fgpu_expand: 0 = pick per hop, 1 = sorted-CSR products only, 2 = bit-parallel from the
  * first hop), "bfs_wgs_per_cu" (grid of the fused BFS level kernel), "merge_mode" (fgpu_mat_merge:
  * 0 = entry-parallel, 1 = one wavefront per row, pattern layers only), "bfs_tiny" (consecutive tiny BFS levels in one single-workgroup launch: 0 off, 1 on,
- * 2 = when the plan's previous search took more than 12 levels), "bfs_prof_split" (1 = a profiled plan launches
+ * 2 = when the plan's previous search took more than 12 levels), "dist_collective" (frontier exchange of
+ * fgpu_bfs_dist_run: 0 = grouped ncclSend / ncclRecv, 1 = one ncclBroadcast per rank), "bfs_prof_split" (1 = a profiled plan launches
  * the push / pull twins of the level kernel so rocprofv3 can tell them apart by name), "bfs_hub_first" (1 = BFS plans
  * read the pull direction from a copy of At whose rows are reordered by descending out-degree class). */
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
@@ -351,6 +352,39 @@ fgpu_info fgpu_mat_col_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, ui
                             uint64_t hi);
 fgpu_info fgpu_mat_row_slab(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a, uint64_t lo,
                             uint64_t hi);
+
+/* ---- multi-GPU: RCCL communicator + in-library partitioned BFS -------------------------
+ * The reference reaches its BFS through one call (LAGr_BreadthFirstSearch_Extended, algo_procedures.rs:1079-1088);
+ * a process that links this library reaches the multi-GPU form the same way: the communicator, the level loop and
+ * the frontier exchange (an all-gather-v: grouped ncclSend / ncclRecv to every peer, one xGMI link per piece) are
+ * inside libfgpu.so.
+ *   one process per GPU : rank 0 calls fgpu_comm_unique_id, the launcher's own channel carries the 128 bytes,
+ *                         every rank calls fgpu_comm_init_rank on its context;
+ *   one process, N GPUs : one context per device, fgpu_comm_init_all (ncclCommInitAll) — the Redis-module form. */
+#define FGPU_COMM_ID_BYTES 128
+fgpu_info fgpu_comm_unique_id(uint8_t* id /* FGPU_COMM_ID_BYTES */);
+fgpu_info fgpu_comm_init_rank(fgpu_ctx* ctx, int nranks, int rank, const uint8_t* id);
+fgpu_info fgpu_comm_init_all(fgpu_ctx* const* ctxs, int n);
+fgpu_info fgpu_comm_finalize(fgpu_ctx* ctx);
+fgpu_info fgpu_comm_info(fgpu_ctx* ctx, int32_t* rank, int32_t* nranks);
+/* nnz-balanced slab boundaries of the destination vertices (= columns of A): splits[0] = 0, splits[nparts] = the
+ * vertex count rounded up to 4096, every boundary a multiple of 4096, part k holding ~ nnz / nparts of A's entries
+ * (prefix sum of in-degrees; R-MAT skew otherwise overloads the parts that own the hubs). */
+fgpu_info fgpu_mat_balanced_splits(fgpu_ctx* ctx, const fgpu_mat* a, int nparts, uint64_t* splits /* nparts + 1 */);
+/* fgpu_bfs_plan_create with caller-chosen slab boundaries: rank owns destinations [splits[rank], splits[rank+1]);
+ * A_slab = A[:, slab], At_slab = A'[slab, :] (fgpu_mat_col_slab + fgpu_mat_transpose), global ids. */
+fgpu_info fgpu_bfs_plan_create_slab(fgpu_ctx* ctx, fgpu_bfs_plan** plan, const fgpu_mat* A_slab,
+                                    const fgpu_mat* At_slab, int rank, int nranks, const uint64_t* splits);
+/* One whole search over the partition: per level one kernel per rank and one frontier exchange.  `plans` = this
+ * process' ranks: ONE plan when every GPU has its own process (exchange over the context's communicator), ALL plans
+ * in rank order when one process drives the node (RCCL if the contexts were joined by fgpu_comm_init_all, event-ordered
+ * peer copies otherwise).  Results per rank through fgpu_bfs_fetch (the owned range) / fgpu_bfs_stats (the rank's
+ * share of reached / edges_traversed: sum over ranks). */
+fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t src, int64_t max_level,
+                            int want_parent);
+/* Time split of the plan's last fgpu_bfs_dist_run: HIP-event sums over its level kernels and over its exchanges
+ * (an exchange includes the wait for the slowest rank), and the number of level launches. */
+fgpu_info fgpu_bfs_dist_times(fgpu_bfs_plan* plan, double* level_ms, double* collective_ms, uint64_t* launches);
 
 /* ---- measurement hooks (bench.py; not reference APIs) --------------------- */
 

@@ -129,3 +129,100 @@ def test_row_sharded_expand_concatenates_to_the_whole_batch(ctx, nranks):
     np.testing.assert_array_equal(np.concatenate([[0], np.cumsum(counts)]), c.rowptr)
     np.testing.assert_array_equal(dest, c.colidx)
     assert flops == flops_ref
+
+
+# ---- the in-library loop (fgpu_bfs_dist_run): level kernels + frontier exchange inside libfgpu.so ------------------
+
+def _col_block_counts(a: oracle.CSR, shift):
+    return np.bincount((a.colidx >> np.uint64(shift)).astype(np.int64), minlength=((a.ncols + (1 << shift) - 1) >> shift))
+
+
+@pytest.mark.parametrize("scale,nparts", [(14, 1), (14, 2), (14, 3), (16, 8)])
+def test_balanced_splits_follow_the_in_degree_prefix(ctx, scale, nparts):
+    a = oracle.rmat_csr(scale)
+    A = ctx.mat_rmat(scale)
+    got = A.balanced_splits(nparts).tolist()
+    shift = fdist.splits_shift(a.ncols)
+    assert got == fdist.balanced_splits(_col_block_counts(a, shift), a.ncols, nparts, shift)
+    assert got[0] == 0 and got[-1] == ((a.ncols + 4095) >> 12) << 12 and all(x % 4096 == 0 for x in got)
+    assert all(x <= y for x, y in zip(got, got[1:]))
+    # every part holds its share of the entries, to within one 4096-column block of in-edges
+    cols = a.colidx.astype(np.int64)
+    per = [int(((cols >= lo) & (cols < hi)).sum()) for lo, hi in zip(got, got[1:])]
+    assert sum(per) == a.nnz
+    biggest_block = int(_col_block_counts(a, shift).max())
+    assert max(per) <= a.nnz / nparts + biggest_block
+
+
+def _gang_plans(ctx, A, nranks, splits):
+    plans, keep = [], []
+    for r in range(nranks):
+        a_slab = A.col_slab(int(splits[r]), int(min(splits[r + 1], A.ncols)))
+        at_slab = a_slab.transpose()
+        keep += [a_slab, at_slab]
+        plans.append(engine.BfsPlan(ctx, a_slab, at_slab, r, nranks, splits=splits))
+    return plans, keep
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 4])
+@pytest.mark.parametrize("force", [0, 1, 2])
+def test_in_library_dist_loop_matches_the_oracle(ctx, nranks, force):
+    """fgpu_bfs_dist_run with the plans of ALL ranks on one device (exchange = event-ordered copies): nnz-balanced,
+    hence uneven, slabs; levels, parents and the per-rank shares of reached / edges_traversed against the oracle."""
+    scale = 14
+    a = oracle.rmat_csr(scale)
+    A = ctx.mat_rmat(scale)
+    n = a.nrows
+    splits = A.balanced_splits(nranks)
+    if nranks == 3:
+        assert len({int(splits[r + 1] - splits[r]) for r in range(nranks)}) > 1   # 4 blocks over 3 ranks: uneven slabs
+    plans, keep = _gang_plans(ctx, A, nranks, splits)
+    for p in plans:
+        p.tune(force_direction=force)
+    deg = np.diff(a.rowptr)
+    for src in [int(np.argmax(deg)), 5, int(np.nonzero(deg > 0)[0][-1])]:
+        for max_level in (-1, 2):
+            engine.bfs_dist_run(plans, src, max_level, want_parent=True)
+            ref, _, ref_edges = oracle.bfs(a, src, max_level)
+            level = np.full(n, -1, dtype=np.int32)
+            parent = np.full(n, -1, dtype=np.int64)
+            for r, p in enumerate(plans):
+                lv, par = p.fetch(want_parent=True)
+                lo, hi = int(splits[r]), int(min(splits[r + 1], n))
+                level[lo:hi] = lv[lo:hi]
+                parent[lo:hi] = par[lo:hi]
+            np.testing.assert_array_equal(level, ref)
+            reached = np.nonzero((ref > 0))[0]
+            assert (ref[parent[reached]] + 1 == ref[reached]).all() and parent[src] == src
+            s_ = a.to_set()
+            assert all((int(parent[v]), int(v)) in s_ for v in reached[:500])
+            if max_level < 0:
+                st = [p.stats() for p in plans]
+                assert sum(x["reached"] for x in st) == int((ref >= 0).sum())
+                assert sum(x["edges_traversed"] for x in st) == ref_edges
+            lm, cm, nl = plans[0].dist_times()
+            assert nl >= int(ref.max()) and lm > 0
+
+
+def test_in_library_loop_over_an_rccl_communicator_of_one(ctx):
+    """The RCCL side of the boundary on a 1-GPU box: ncclGetUniqueId / ncclCommInitRank inside libfgpu.so, a
+    partitioned plan of one rank, fgpu_bfs_dist_run through the communicator."""
+    ctx2 = engine.Context(0)
+    try:
+        uid = ctx2.comm_unique_id()
+        assert len(uid) == 128
+        ctx2.comm_init_rank(1, 0, uid)
+        assert ctx2.comm_info() == (0, 1)
+        a = oracle.rmat_csr(13)
+        A = ctx2.mat_rmat(13)
+        splits = A.balanced_splits(1)
+        plan = engine.BfsPlan(ctx2, A, A.transpose(), 0, 1, splits=splits)
+        for src in (3, int(np.argmax(np.diff(a.rowptr)))):
+            engine.bfs_dist_run([plan], src)
+            lv, _ = plan.fetch()
+            np.testing.assert_array_equal(lv[:a.nrows], oracle.bfs(a, src, -1)[0])
+        plan.free()
+        ctx2.comm_finalize()
+        assert ctx2.comm_info() == (0, 1)
+    finally:
+        ctx2.close()
