@@ -312,6 +312,48 @@ def khop_cpu_baseline(engine, ctx, A, batch, threads, seconds):
             "flops": int(fl_cpu), "out_nnz": int(nnz_cpu)}
 
 
+def strong_scaling_base(ctx, engine, args, scale=26, steps=32, warmup=8):
+    """The N = 1 point of the curve `--gpus N` (N > 1) measures: the same RMAT-26 BFS on this one device, same 64-root
+    rule, same two-plan pipelined loop as the headline.  Reported inside the N = 1 line so that the driver's N = 1, 2, 4,
+    8 series has its base point on the same graph."""
+    t0 = time.time()
+    A = ctx.mat_rmat(scale, args.edge_factor, 0x5EED1234 + scale)
+    At = A.transpose()
+    roots = pick_roots(A, 64)
+    plans = [engine.BfsPlan(ctx, A, At), engine.BfsPlan(ctx, A, At)]
+    for p in plans:
+        p.tune(alpha=args.alpha, force_direction=args.force_dir)
+    ctx.sync()
+    t_build = time.time() - t0
+    edges = {}
+    for r in roots[:max(steps, warmup)]:
+        plans[0].run(r, -1, False)
+        edges[r] = plans[0].stats()["edges_traversed"]
+
+    def pipelined(srcs):
+        for i, src in enumerate(srcs):
+            plans[i % 2].run_async(src, -1, False, 0)
+            if i > 0:
+                plans[(i - 1) % 2].wait()
+        plans[(len(srcs) - 1) % 2].wait()
+
+    pipelined([roots[i % len(roots)] for i in range(warmup)])
+    ctx.sync()
+    t1 = time.perf_counter()
+    pipelined([roots[i % len(roots)] for i in range(steps)])
+    ctx.sync()
+    dt = time.perf_counter() - t1
+    tot = sum(edges[roots[i % len(roots)]] for i in range(steps))
+    out = {"workload": f"RMAT scale-{scale} BFS on 1 GPU (base point of the `--gpus N` strong-scaling curve, BASELINE config 4)",
+           "scale": scale, "vertices": int(A.nrows), "edges": int(A.nvals), "value": round(tot / dt, 1), "unit": "TEPS",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "build_seconds": round(t_build, 2)}
+    for p in plans:
+        p.free()
+    At.free()
+    A.free()
+    return out
+
+
 def pmc_child(args):
     """Reduced replay of the bench workloads for the rocprofv3 --pmc passes (live_pmc): no timing, no JSON line."""
     from falkordb_amd import engine
@@ -359,6 +401,7 @@ def main():
     ap.add_argument("--no-khop", action="store_true", help="skip the k-hop MATCH leg (BASELINE config 3)")
     ap.add_argument("--khop-scale", type=int, default=24)
     ap.add_argument("--khop-batches", type=int, default=32, help="1024-source batches of the :P set to time (0 = all)")
+    ap.add_argument("--no-scale-base", action="store_true", help="skip the RMAT-26 single-GPU base point of the scaling curve")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (traffic = committed / null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -647,6 +690,11 @@ def main():
                "serial": {"value": round(e_ser / t_ser, 1), "cores": 1,
                           "sample": f"{ks} roots, {t_ser:.1f} s, serial queue BFS (oracle/oracle.c orc_bfs)"}}
 
+    # ---- base point of the strong-scaling curve the N > 1 runs measure (RMAT-26 on this one GPU) ----------
+    base26 = None
+    if world == 1 and not use_dist and scale == 22 and not args.no_scale_base:
+        base26 = strong_scaling_base(ctx, engine, args)
+
     # ---- BASELINE config 3: k-hop MATCH leg (own graph, own roofline, own CPU baseline) ------------------
     khop = None
     if not args.no_khop and not use_dist and rank == 0:
@@ -717,6 +765,7 @@ def main():
             "roofline": roofline,
             "time_split": dist_split,
             "spmv_full_pass": spmv,
+            "rmat26_single_gpu": base26,
             "khop_match": khop,
             "cpu_baseline": cpu,
             "pmc": ({k: v for k, v in pmc.items() if not k.startswith("bp_")} if pmc else None),
