@@ -47,6 +47,22 @@ def balanced_splits(block_counts, n: int, nparts: int, shift: int = 12):
     return splits
 
 
+def allgatherv_words(glob, piece, splits, rank: int, nranks: int, all_gather):
+    """The frontier exchange of fgpu_bfs_dist_run (dist.hip comm_allgatherv_u64) for launchers whose collective only
+    takes equal pieces (gloo in the CPU tests): rank r's words live at word splits[r] / 64 of the global bitmap.
+    `all_gather(out, inp)` = all_gather_into_tensor of equal-size tensors; pieces are padded to the widest slab."""
+    import torch
+    words = [(int(splits[r + 1]) - int(splits[r])) // 64 for r in range(nranks)]
+    wmax = max(max(words), 1)
+    pad = torch.zeros(wmax, dtype=glob.dtype, device=glob.device)
+    pad[:words[rank]] = piece[:words[rank]]
+    out = torch.zeros(wmax * nranks, dtype=glob.dtype, device=glob.device)
+    all_gather(out, pad)
+    for r in range(nranks):
+        off = int(splits[r]) // 64
+        glob[off:off + words[r]] = out[r * wmax:r * wmax + words[r]]
+
+
 def splits_shift(ncols: int) -> int:
     """Block size fgpu_mat_balanced_splits uses for `ncols` columns (at most 8192 blocks of >= 4096 columns)."""
     shift = 12

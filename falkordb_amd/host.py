@@ -480,6 +480,20 @@ class Graph:
         return (nv, ev) if has.value else None
 
 
+def algo_bfs_multi(graph, gang, source, max_depth=-1, rel_type=None, want_edges=False):
+    """algo.BFS partitioned over the contexts of `gang` (host.Context objects, gang[0] = the graph's own)."""
+    has = C.c_int()
+    nodes, edges = u64p(), u64p()
+    nn, ne = C.c_uint64(), C.c_uint64()
+    arr = (C.c_void_p * len(gang))(*[c.h for c in gang])
+    _ck(graph.L.fh_algo_bfs_multi(graph.h, arr, len(gang), C.c_int64(-1 if source is None else source),
+                                  C.c_int64(max_depth), rel_type.encode() if rel_type is not None else None,
+                                  1 if want_edges else 0, C.byref(has), C.byref(nodes), C.byref(nn), C.byref(edges),
+                                  C.byref(ne)))
+    nv, ev = _take(nodes, nn.value).tolist(), _take(edges, ne.value).tolist()
+    return (nv, ev) if has.value else None
+
+
 # ---- v19 matrix payload (Encode<19> / Decode<19> for Matrix<T>) ---------------------------------------------
 def container_parse(payload: bytes):
     """CPU-only: {nrows, ncols, nvals, hyper, valued, consumed, p, h, i, x} of a container payload."""

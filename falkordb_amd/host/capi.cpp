@@ -429,6 +429,23 @@ int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_
     });
 }
 
+int fh_algo_bfs_multi(fh_graph* g, fh_ctx* const* gang, int n_gang, int64_t source, int64_t max_depth,
+                      const char* rel_type, int want_edges, int* has_row, uint64_t** nodes, uint64_t* n_nodes,
+                      uint64_t** edges, uint64_t* n_edges) {
+    return guard([&] {
+        std::vector<Context*> cs;
+        for (int i = 0; i < n_gang; ++i) cs.push_back(&gang[i]->c);
+        BfsResult r = algo_bfs(g->g, source >= 0 ? std::optional<u64>((u64)source) : std::nullopt, max_depth,
+                               rel_type ? std::optional<std::string>(rel_type) : std::nullopt, want_edges != 0, &cs);
+        *has_row = r.has_row ? 1 : 0;
+        *nodes = hand(r.nodes);
+        *n_nodes = r.nodes.size();
+        *edges = hand(r.edges);
+        *n_edges = r.edges.size();
+        return 0;
+    });
+}
+
 // ---- v19 matrix payload (serialize.cpp) -------------------------------------------------------------------
 // CPU-only parse of a container payload: dims, flags and the index / value arrays it carries
 int fh_container_parse(const uint8_t* bytes, uint64_t len, uint64_t* dims /* nrows, ncols, nvals, hyper, valued, consumed */,

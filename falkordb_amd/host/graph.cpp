@@ -440,8 +440,59 @@ void ExpandIntoOp::expand_batch(const Graph& g, const std::vector<u64>& srcs, co
 }
 
 // ---- algo.BFS --------------------------------------------------------------------------------------------
+// The partitioned form of the search below: the adjacency is cut into nnz-balanced column slabs, one
+// per context of `gang` (one context per GPU; several contexts on one device work too and are how this is tested),
+// and ONE call — fgpu_bfs_dist_run — drives every rank's level kernels and the per-level frontier exchange inside
+// libfgpu.so (RCCL when the contexts were joined by fgpu_comm_init_all, event-ordered peer copies otherwise).
+// Everything goes through include/fgpu.h.  Slabs that live on another context travel through the host once per
+// call (no cross-device snapshot copy in the ABI yet; a cache keyed on the adjacency snapshot is the obvious next step).
+static void bfs_partitioned(const Graph& g, const std::vector<Context*>& gang, const Matrix& adj, u64 source,
+                            int64_t max_depth, bool want_edges, std::vector<int32_t>& level, std::vector<int64_t>& parent) {
+    const int nr = (int)gang.size();
+    fgpu_ctx* c0 = g.ctx().raw();
+    std::vector<u64> splits((size_t)nr + 1);
+    check(fgpu_mat_balanced_splits(c0, adj.snapshot(), nr, splits.data()), "fgpu_mat_balanced_splits");
+    std::vector<fgpu_mat*> slabs(nr, nullptr), slabs_t(nr, nullptr);
+    std::vector<fgpu_bfs_plan*> plans(nr, nullptr);
+    auto cleanup = [&]() {
+        for (auto* p : plans) if (p) fgpu_bfs_plan_free(p);
+        for (auto* m : slabs_t) if (m) fgpu_mat_free(m);
+        for (auto* m : slabs) if (m) fgpu_mat_free(m);
+    };
+    try {
+        const u64 n = g.node_cap();
+        for (int r = 0; r < nr; ++r) {
+            fgpu_ctx* cr = gang[r]->raw();
+            fgpu_mat* local = nullptr;
+            check(fgpu_mat_col_slab(c0, &local, adj.snapshot(), splits[r], splits[r + 1] < n ? splits[r + 1] : n), "fgpu_mat_col_slab");
+            if (cr == c0) {
+                slabs[r] = local;
+            } else {
+                u64 *rp = nullptr, *ci = nullptr, nnz = 0;
+                fgpu_info i = fgpu_mat_export_csr(c0, local, &rp, &ci, nullptr, &nnz);
+                fgpu_mat_free(local);
+                check(i, "GxB_unload_Matrix_into_Container");
+                i = fgpu_mat_from_csr(cr, &slabs[r], n, n, nnz, rp, 64, ci, 64, nullptr, nullptr, 0);
+                fgpu_free(c0, rp);
+                fgpu_free(c0, ci);
+                check(i, "GxB_load_Matrix_from_Container");
+            }
+            check(fgpu_mat_transpose(cr, &slabs_t[r], slabs[r]), "GrB_transpose");
+            check(fgpu_bfs_plan_create_slab(cr, &plans[r], slabs[r], slabs_t[r], r, nr, splits.data()), "fgpu_bfs_plan_create_slab");
+        }
+        check(fgpu_bfs_dist_run(plans.data(), nr, source, max_depth < 0 ? -1 : max_depth, want_edges ? 1 : 0),
+              "LAGr_BreadthFirstSearch (partitioned)");
+        for (int r = 0; r < nr; ++r)   // every rank fills its own range [splits[r], splits[r+1])
+            check(fgpu_bfs_fetch(plans[r], level.data(), want_edges ? parent.data() : nullptr), "fgpu_bfs_fetch");
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+}
+
 BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
-                   const std::optional<std::string>& rel_type, bool want_edges) {
+                   const std::optional<std::string>& rel_type, bool want_edges, const std::vector<Context*>* gang) {
     BfsResult res;
     const u64 n = g.node_cap();
     if (!source) return res;                                             // NULL source: no row (:1029)
@@ -454,8 +505,12 @@ BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
     if (rel_type) types.push_back(*rel_type);
     Matrix adj = g.build_adjacency_matrix(types);                        // graph.rs:3870-3894
     const std::string key = rel_type ? *rel_type : std::string();
-    std::shared_ptr<Graph::BfsPlanCache> pc = g.bfs_cache_;
-    if (!pc || pc->key != key || pc->adj.snapshot() != adj.snapshot()) {
+    std::vector<int32_t> level(n);
+    std::vector<int64_t> parent(want_edges ? n : 0);
+    const bool partitioned = gang && gang->size() > 1 && adj.nvals() > 0;
+    if (partitioned) bfs_partitioned(g, *gang, adj, *source, max_depth, want_edges, level, parent);
+    std::shared_ptr<Graph::BfsPlanCache> pc = partitioned ? nullptr : g.bfs_cache_;
+    if (!partitioned && (!pc || pc->key != key || pc->adj.snapshot() != adj.snapshot())) {
         // a new adjacency (the layers changed, or another type): new plan; a clean committed graph keeps handing
         // out the same snapshot (VersionedMatrix::extract shares the base) and its cached transpose
         pc = std::make_shared<Graph::BfsPlanCache>(adj, adj.transpose());
@@ -468,9 +523,9 @@ BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
         }
         g.bfs_cache_ = pc;
     }
-    std::vector<int32_t> level(n);
-    std::vector<int64_t> parent(want_edges ? n : 0);
-    if (pc) {
+    if (partitioned) {
+        // levels / parents were assembled from the ranks above
+    } else if (pc) {
         check(fgpu_bfs_run(pc->plan, *source, max_depth < 0 ? -1 : max_depth, want_edges ? 1 : 0), "LAGr_BreadthFirstSearch");
         check(fgpu_bfs_fetch(pc->plan, level.data(), want_edges ? parent.data() : nullptr), "LAGr_BreadthFirstSearch");
     } else {

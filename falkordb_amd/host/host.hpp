@@ -421,8 +421,12 @@ struct BfsResult {
     std::vector<u64> nodes, edges;
 };
 // algo.BFS (runtime/functions/algo_procedures.rs:1021-1160)
+// `gang` (nullable): contexts of the GPUs to partition the search over (one nnz-balanced column slab each; gang[0] is
+// normally the graph's own context); the level loop and the frontier exchange then run inside libfgpu.so
+// (fgpu_bfs_dist_run).  Same results as the single-device call.
 BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
-                   const std::optional<std::string>& rel_type, bool want_edges);
+                   const std::optional<std::string>& rel_type, bool want_edges,
+                   const std::vector<Context*>* gang = nullptr);
 
 // ---- planner slice: the rule that decides which queries reach the fused chain ---------------------------
 // (planner/optimizer/fuse_anonymous_traverse.rs).  The model keeps only what the rule inspects.

@@ -134,6 +134,12 @@ int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_r
 int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges,
                 int* has_row, uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges); /* algo_procedures.rs:1021-1160 */
 
+/* The same procedure partitioned over the contexts of `gang` (one per GPU; gang[0] = the graph's context): nnz-balanced
+ * column slabs, level loop + frontier exchange inside libfgpu.so (fgpu_bfs_dist_run).  Same output. */
+int fh_algo_bfs_multi(fh_graph* g, fh_ctx* const* gang, int n_gang, int64_t source, int64_t max_depth,
+                      const char* rel_type, int want_edges, int* has_row, uint64_t** nodes, uint64_t* n_nodes,
+                      uint64_t** edges, uint64_t* n_edges);
+
 /* The v19 on-disk form of a Matrix<T> (Encode<19> / Decode<19>, matrix.rs:428-546): the 608 bytes of
  * GxB_Container_struct + its vectors x, h, p, i, b in Vector<bool>'s unload-to-array form (vector.rs:241-309).
  * Stream framing: unsigned / signed = 8 bytes little-endian, buffer = unsigned length + bytes.

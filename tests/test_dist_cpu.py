@@ -20,20 +20,33 @@ U64 = np.uint64
 class OracleSlabBackend:
     """Same contract as dist.HipSlabBackend, numpy inside: rank owns destinations [lo, hi)."""
 
-    def __init__(self, a: oracle.CSR, rank, nranks):
+    def __init__(self, a: oracle.CSR, rank, nranks, splits=None):
         self.n = a.nrows
         self.rank, self.nranks = rank, nranks
-        self.lo, self.hi, self.slab = fdist.slab_range(self.n, rank, nranks)
+        if splits is None:                       # equal slabs (fgpu_bfs_plan_create)
+            self.lo, self.hi, self.slab = fdist.slab_range(self.n, rank, nranks)
+            self.npad = self.slab * nranks
+        else:                                    # caller-chosen, nnz-balanced, uneven (fgpu_bfs_plan_create_slab)
+            self.lo, self.hi = int(splits[rank]), int(splits[rank + 1])
+            self.slab = self.hi - self.lo
+            self.npad = int(splits[nranks])
+        self.splits = splits
         rows, cols = a.pairs()
         keep = (cols >= self.lo) & (cols < self.hi)
         self.a_slab = oracle.build_csr(self.n, self.n, rows[keep], cols[keep])   # A[:, lo:hi)
         self.words_per_rank = self.slab // 64
-        self.local = torch.zeros(self.words_per_rank, dtype=torch.int64)
-        self.glob = torch.zeros(self.words_per_rank * nranks, dtype=torch.int64)
+        self.local = torch.zeros(max(self.words_per_rank, 1), dtype=torch.int64)
+        self.glob = torch.zeros(self.npad // 64, dtype=torch.int64)
         self.level = np.full(self.n, -1, dtype=np.int32)
 
+    def gather(self):
+        if self.splits is None:
+            td.all_gather_into_tensor(self.glob, self.local)
+        else:
+            fdist.allgatherv_words(self.glob, self.local, self.splits, self.rank, self.nranks, td.all_gather_into_tensor)
+
     def begin(self, src, max_level=-1):
-        npad = self.words_per_rank * self.nranks * 64
+        npad = self.npad
         self.cur = np.zeros(npad // 64, dtype=U64)
         self.cur[src >> 6] = U64(1) << U64(src & 63)
         self.visited = self.cur.copy()
@@ -50,7 +63,7 @@ class OracleSlabBackend:
         full = np.zeros(len(self.cur), dtype=U64)
         full[:nw] = w
         lo_w = self.lo // 64
-        self.local.copy_(torch.from_numpy(full[lo_w:lo_w + self.words_per_rank].view(np.int64).copy()))
+        self.local[:self.words_per_rank] = torch.from_numpy(full[lo_w:lo_w + self.words_per_rank].view(np.int64).copy())
 
     def commit(self):
         if self.is_done:
@@ -69,17 +82,22 @@ class OracleSlabBackend:
         return self.is_done, self.lvl
 
 
-def _worker(rank, world, port, scale, srcs, max_level, q):
+def _balanced(a: oracle.CSR, world):
+    shift = fdist.splits_shift(a.ncols)
+    counts = np.bincount((a.colidx >> np.uint64(shift)).astype(np.int64), minlength=(a.ncols + (1 << shift) - 1) >> shift)
+    return fdist.balanced_splits(counts, a.ncols, world, shift)
+
+
+def _worker(rank, world, port, scale, srcs, max_level, q, balanced=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
         a = oracle.rmat_csr(scale)
-        be = OracleSlabBackend(a, rank, world)
+        be = OracleSlabBackend(a, rank, world, _balanced(a, world) if balanced else None)
         out = []
         for src in srcs:
-            nlev = fdist.run_levels(be, lambda: td.all_gather_into_tensor(be.glob, be.local), src, max_level,
-                                    first_batch=2, batch=1)
+            nlev = fdist.run_levels(be, be.gather, src, max_level, first_batch=2, batch=1)
             lv = torch.from_numpy(be.level.copy())
             td.all_reduce(lv, op=td.ReduceOp.MAX)      # owners hold the levels, everyone else -1
             out.append((nlev, lv.numpy()))
@@ -97,16 +115,23 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,max_level", [(2, -1), (2, 2), (3, -1)])
-def test_multi_rank_slab_bfs_matches_single_process_oracle(world, max_level):
-    # world 3: slabs of unequal use (the last one is mostly padding: slab = ceil(n / 3) rounded up to 4096)
-    scale = 10 if world == 2 else 13
+@pytest.mark.parametrize("world,max_level,balanced", [(2, -1, False), (2, 2, False), (3, -1, False),
+                                                      (2, -1, True), (3, -1, True), (3, 2, True)])
+def test_multi_rank_slab_bfs_matches_single_process_oracle(world, max_level, balanced):
+    # world 3, equal slabs: the last one is mostly padding (slab = ceil(n / 3) rounded up to 4096).
+    # balanced: nnz-balanced boundaries (the product's fgpu_mat_balanced_splits rule) — 4 blocks of 4096 vertices over
+    # 3 ranks are uneven, 2 blocks over 3 ranks leave one rank an EMPTY slab; the exchange is an all-gather-v
+    scale = (14 if max_level < 0 else 13) if balanced else (10 if world == 2 else 13)
     a = oracle.rmat_csr(scale)
+    if balanced and world == 3:
+        sp = _balanced(a, world)
+        widths = {sp[r + 1] - sp[r] for r in range(world)}
+        assert len(widths) > 1 and (scale != 13 or 0 in widths)
     srcs = [int(np.argmax(np.diff(a.rowptr))), 3]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, scale, srcs, max_level, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scale, srcs, max_level, q, balanced)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=120)
@@ -116,6 +141,17 @@ def test_multi_rank_slab_bfs_matches_single_process_oracle(world, max_level):
     for src, (nlev, level) in zip(srcs, out):
         ref, _, _ = oracle.bfs(a, src, max_level)
         np.testing.assert_array_equal(level, ref)
+
+
+def test_balanced_splits_rule():
+    # boundary k = the 4096-aligned block edge whose entry prefix is nearest to k * nnz / nparts (dist.hip)
+    assert fdist.balanced_splits([20, 35, 25, 20], 16384, 4) == [0, 4096, 8192, 12288, 16384]
+    assert fdist.balanced_splits([70, 10, 10, 10], 16384, 2) == [0, 4096, 16384]
+    assert fdist.balanced_splits([10, 10, 10, 70], 16000, 2) == [0, 12288, 16384]
+    assert fdist.balanced_splits([], 100, 3) == [0, 0, 0, 4096]
+    sp = fdist.balanced_splits([5] * 8192, 8192 * 8192, 8, 13)
+    assert sp == [i * (1 << 23) for i in range(9)]
+    assert fdist.splits_shift(1 << 22) == 12 and fdist.splits_shift(1 << 26) == 13 and fdist.splits_shift(1 << 30) == 17
 
 
 def test_slab_range_matches_plan_rounding():

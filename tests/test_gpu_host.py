@@ -757,6 +757,42 @@ def test_algo_bfs_matches_the_oracle_on_rmat(rnd_graph):     # algo_procedures.r
             assert d == v and level[s] + 1 == level[v]
 
 
+def test_algo_bfs_partitioned_over_a_gang_of_contexts(rnd_graph, hctx):
+    """libfalkor_host's algo.BFS over several contexts (here three contexts on the one device): nnz-balanced
+    column slabs, level loop + frontier exchange inside libfgpu.so (fgpu_bfs_dist_run) — everything through
+    include/fgpu.h — must return what the single-device procedure returns: the same node list, and edges that are valid
+    BFS-tree edges."""
+    g, og, n, per_type = rnd_graph
+    others = [host.Context(0), host.Context(0)]
+    gang = [hctx] + others
+    try:
+        deg = {}
+        for (s, d) in og.adjacency.extract():
+            deg[s] = deg.get(s, 0) + 1
+        for src in (max(deg, key=deg.get), min(deg)):
+            for rel, depth in [(None, -1), ("A", -1), ("B", 2)]:
+                one = g.algo_bfs(src, depth, rel, want_edges=True)
+                got = host.algo_bfs_multi(g, gang, src, depth, rel, want_edges=True)
+                assert (got is None) == (one is None)
+                if got is None:
+                    continue
+                assert got[0] == one[0] and len(got[1]) == len(one[1])
+                adj = og.build_adjacency_matrix([rel] if rel else [])
+                level, _, _ = oracle.bfs(adj, src, depth, want_parent=False)
+                by_edge = {}
+                for k in ((0, 1) if rel is None else (og.type_ids[rel],)):
+                    for (s, d), es in per_type[k].items():
+                        for e in es:
+                            by_edge[e] = (s, d)
+                for v, e in zip(got[0], got[1]):
+                    s, d = by_edge[e]
+                    assert d == v and level[s] + 1 == level[v]
+        assert host.algo_bfs_multi(g, gang, None) is None        # NULL source: no row
+    finally:
+        for c in others:
+            c.close()
+
+
 # ---- algo.pageRank (algo_procedures.rs:687-783; tests/flow/test_pagerank.py) -----------------------------------
 def _model_edge(og, type_id, s, d, eid):
     """the oracle graph is a read-side model: install a committed single edge directly"""
