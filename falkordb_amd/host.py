@@ -45,9 +45,9 @@ def load():
         for name in declared_symbols():
             fn = getattr(L, name)  # raises if the library lacks a declared symbol
             if name not in ("fh_last_error", "fh_free", "fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free",
-                            "fh_last_op_ns", "fh_mat_cursor_free"):
+                            "fh_last_op_ns", "fh_mat_cursor_free", "fh_tn_free"):
                 fn.restype = C.c_int
-        for name in ("fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free", "fh_mat_cursor_free"):
+        for name in ("fh_finalize", "fh_mat_free", "fh_vm_free", "fh_graph_free", "fh_mat_cursor_free", "fh_tn_free"):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [C.c_void_p]
         L.fh_last_op_ns.restype = C.c_uint64
@@ -478,6 +478,67 @@ class Graph:
                                C.byref(has), C.byref(nodes), C.byref(nn), C.byref(edges), C.byref(ne)))
         nv, ev = _take(nodes, nn.value).tolist(), _take(edges, ne.value).tolist()
         return (nv, ev) if has.value else None
+
+
+class Tensor:
+    """A Tensor on its own (tensor.rs:184-989), as the reference's unit tests drive it (fh_tn_*)."""
+    MULTI_EDGE = 2 ** 64 - 1
+
+    def __init__(self, ctx, nrows=None, ncols=None, _h=None):
+        self.ctx, self.L = ctx, ctx.L
+        self.h = _h if _h is not None else C.c_void_p()
+        if _h is None:
+            _ck(self.L.fh_tn_new(ctx.h, C.byref(self.h), C.c_uint64(nrows), C.c_uint64(ncols)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.fh_tn_free(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+    def dup(self):
+        h = C.c_void_p()
+        _ck(self.L.fh_tn_dup(self.h, C.byref(h)))
+        return Tensor(self.ctx, _h=h)
+
+    def set_all_from_slices(self, srcs, dsts, ids):
+        s, d, i = _u64(srcs), _u64(dsts), _u64(ids)
+        _ck(self.L.fh_tn_set_all(self.h, _p(s), _p(d), _p(i), C.c_uint64(len(s))))
+
+    def remove_all(self, rels):
+        """rels = [(edge id, src, dst)]; returns the emptied (src, dst) pairs."""
+        flat = _u64(np.asarray(list(rels), dtype=np.uint64).reshape(-1))
+        es, ed, n = u64p(), u64p(), C.c_uint64()
+        _ck(self.L.fh_tn_remove_all(self.h, _p(flat), C.c_uint64(len(flat) // 3), C.byref(es), C.byref(ed), C.byref(n)))
+        return list(zip(_take(es, n.value).tolist(), _take(ed, n.value).tolist()))
+
+    def flush(self): _ck(self.L.fh_tn_op(self.h, 0, C.c_uint64(0), C.c_uint64(0)))
+    def fold_oversized(self): _ck(self.L.fh_tn_op(self.h, 1, C.c_uint64(0), C.c_uint64(0)))
+    def wait(self): _ck(self.L.fh_tn_op(self.h, 2, C.c_uint64(0), C.c_uint64(0)))
+    def wait_fwd(self): _ck(self.L.fh_tn_op(self.h, 3, C.c_uint64(0), C.c_uint64(0)))
+    def resize(self, nrows, ncols): _ck(self.L.fh_tn_op(self.h, 4, C.c_uint64(nrows), C.c_uint64(ncols)))
+
+    def get(self, src, dst):
+        ids, n = u64p(), C.c_uint64()
+        _ck(self.L.fh_tn_get(self.h, C.c_uint64(src), C.c_uint64(dst), C.byref(ids), C.byref(n)))
+        return _take(ids, n.value).tolist()
+
+    def _probe(self, which, src, dst):
+        v = C.c_uint64()
+        code = self.L.fh_tn_probe(self.h, which, C.c_uint64(src), C.c_uint64(dst), C.byref(v))
+        _ck(code, allow=(0, 1))
+        return v.value if code == 0 else None
+
+    def eff_get(self, src, dst): return self._probe(0, src, dst)
+    def m_get(self, src, dst): return self._probe(1, src, dst)
+    def extract_contains(self, src, dst): return self._probe(2, src, dst) is not None
+
+    def state(self):
+        out = (C.c_uint64 * 8)()
+        _ck(self.L.fh_tn_state(self.h, out))
+        return dict(zip(("m", "dp", "dm", "multi_pairs", "mt", "me_nvals", "edge_count", "m_pending"), [int(x) for x in out]))
 
 
 def algo_bfs_multi(graph, gang, source, max_depth=-1, rel_type=None, want_edges=False):

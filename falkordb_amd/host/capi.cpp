@@ -14,6 +14,7 @@ struct fh_ctx { Context c; explicit fh_ctx(int d) : c(d) {} };
 struct fh_mat { Matrix m; };
 struct fh_vm { VersionedMatrix v; };
 struct fh_graph { Graph g; fh_graph(Context& c, u64 n) : g(c, n) {} };
+struct fh_tn { Tensor t; };
 
 static thread_local std::string g_err;
 
@@ -298,6 +299,83 @@ int fh_tensor_state(fh_graph* g, uint64_t type_id, uint64_t out[5]) {
         out[2] = t.fwd_dm().nvals();
         out[3] = t.multi_pairs();
         out[4] = t.matrix_t().nvals();
+        return 0;
+    });
+}
+
+// ---- a Tensor on its own (the unit tests of tensor.rs:1340-1669 drive one directly) ----------------------------
+int fh_tn_new(fh_ctx* ctx, fh_tn** out, uint64_t nrows, uint64_t ncols) {
+    return guard([&] { *out = new fh_tn{Tensor(ctx->c, nrows, ncols)}; return 0; });
+}
+void fh_tn_free(fh_tn* t) { delete t; }
+int fh_tn_dup(fh_tn* t, fh_tn** out) {
+    return guard([&] { *out = new fh_tn{t->t.dup()}; return 0; });
+}
+int fh_tn_set_all(fh_tn* t, const uint64_t* srcs, const uint64_t* dsts, const uint64_t* ids, uint64_t n) {
+    return guard([&] {
+        t->t.set_all_from_slices(std::vector<u64>(srcs, srcs + n), std::vector<u64>(dsts, dsts + n),
+                                 std::vector<u64>(ids, ids + n));
+        return 0;
+    });
+}
+int fh_tn_remove_all(fh_tn* t, const uint64_t* rels, uint64_t n, uint64_t** emptied_src, uint64_t** emptied_dst,
+                     uint64_t* n_emptied) {
+    return guard([&] {
+        std::vector<std::array<u64, 3>> r(n);
+        for (u64 i = 0; i < n; ++i) r[i] = {rels[3 * i], rels[3 * i + 1], rels[3 * i + 2]};   // (edge id, src, dst)
+        auto e = t->t.remove_all(r);
+        std::vector<u64> es, ed;
+        for (auto& p : e) { es.push_back(p.first); ed.push_back(p.second); }
+        *emptied_src = hand(es);
+        *emptied_dst = hand(ed);
+        *n_emptied = e.size();
+        return 0;
+    });
+}
+int fh_tn_op(fh_tn* t, int op, uint64_t a, uint64_t b) {
+    return guard([&] {
+        switch (op) {
+            case 0: t->t.flush(); break;
+            case 1: t->t.fold_oversized(); break;
+            case 2: t->t.wait(); break;
+            case 3: t->t.wait_fwd(); break;
+            case 4: t->t.resize(a, b); break;
+            default: throw GrbError(FGPU_INVALID, "fh_tn_op: unknown op");
+        }
+        return 0;
+    });
+}
+int fh_tn_get(fh_tn* t, uint64_t src, uint64_t dst, uint64_t** ids, uint64_t* n) {
+    return guard([&] {
+        auto v = t->t.get(src, dst);
+        *ids = hand(v);
+        *n = v.size();
+        return 0;
+    });
+}
+int fh_tn_probe(fh_tn* t, int which, uint64_t src, uint64_t dst, uint64_t* val) {
+    return guard([&] {
+        std::optional<u64> v;
+        if (which == 0) v = t->t.eff_get(src, dst);                     // eff_get_for_test
+        else if (which == 1) { t->t.fwd_m().wait(); v = t->t.fwd_m().get(src, dst); }
+        else if (which == 2) { Matrix e = t->t.extract(); e.wait(); v = e.get(src, dst); }
+        else throw GrbError(FGPU_INVALID, "fh_tn_probe: which must be 0 (effective), 1 (m) or 2 (extract)");
+        if (!v) return (int)FGPU_NO_VALUE;
+        *val = *v;
+        return 0;
+    });
+}
+int fh_tn_state(fh_tn* t, uint64_t out[8]) {
+    return guard([&] {
+        out[7] = t->t.fwd_m().pending() ? 1 : 0;     // read BEFORE anything waits (resize_leaves_base_materialized)
+        t->t.wait_fwd();
+        out[0] = t->t.fwd_m().nvals();
+        out[1] = t->t.fwd_dp().nvals();
+        out[2] = t->t.fwd_dm().nvals();
+        out[3] = t->t.multi_pairs();
+        out[4] = t->t.matrix_t().extract().nvals();
+        out[5] = t->t.me_nvals();
+        out[6] = t->t.edge_count();
         return 0;
     });
 }

@@ -286,6 +286,8 @@ class Tensor {
     std::vector<Entry> iter_edges() const;                                 // :973-989 (src, dst, edge id)
     u64 edge_count() const;                                                // :955-967
     u64 multi_pairs() const { return me_.size(); }
+    u64 me_nvals() const { u64 n = 0; for (auto& kv : me_) n += kv.second.size(); return n; }   // `me.nvals()` of the tests
+    void wait() const { wait_fwd(); mt_.wait(); }                           // Tensor::wait: every layer materialised
 
    private:
     Matrix m_;

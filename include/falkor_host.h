@@ -105,6 +105,24 @@ int fh_tensor_iter_edges(fh_graph* g, uint64_t type_id, uint64_t** srcs, uint64_
 /* out[0..2] = nvals of fwd m, dp, dm; out[3] = multi pairs; out[4] = nvals of mt (effective) */
 int fh_tensor_state(fh_graph* g, uint64_t type_id, uint64_t out[5]);
 
+/* A Tensor on its own (tensor.rs:184-989) — what the unit tests of tensor.rs:1340-1669 drive.
+ * rels = n triples (edge id, src, dst) as Tensor::remove_all takes them; emptied = the pairs left without an edge.
+ * fh_tn_op: 0 flush, 1 fold_oversized, 2 wait (every layer), 3 wait_fwd, 4 resize(a, b).
+ * fh_tn_probe: which 0 = effective forward value (eff_get; the MULTI_EDGE sentinel is UINT64_MAX), 1 = committed base
+ * m, 2 = extract() pattern; returns 1 (GrB_NO_VALUE) when absent.
+ * fh_tn_state: nvals of m, dp, dm; multi pairs; nvals of mt.extract(); ids held in me; edge_count; m.pending(). */
+typedef struct fh_tn fh_tn;
+int fh_tn_new(fh_ctx* ctx, fh_tn** out, uint64_t nrows, uint64_t ncols);
+void fh_tn_free(fh_tn* t);
+int fh_tn_dup(fh_tn* t, fh_tn** out);
+int fh_tn_set_all(fh_tn* t, const uint64_t* srcs, const uint64_t* dsts, const uint64_t* ids, uint64_t n);
+int fh_tn_remove_all(fh_tn* t, const uint64_t* rels, uint64_t n, uint64_t** emptied_src, uint64_t** emptied_dst,
+                     uint64_t* n_emptied);
+int fh_tn_op(fh_tn* t, int op, uint64_t a, uint64_t b);
+int fh_tn_get(fh_tn* t, uint64_t src, uint64_t dst, uint64_t** ids, uint64_t* n);
+int fh_tn_probe(fh_tn* t, int which, uint64_t src, uint64_t dst, uint64_t* val);
+int fh_tn_state(fh_tn* t, uint64_t out[8]);
+
 /* Raw layer dump for tests: type_id < 0 = the adjacency matrix; which 0 = m, 1 = dp, 2 = dm. */
 int fh_graph_layer_iter(fh_graph* g, int64_t type_id, int which, uint64_t** rows, uint64_t** cols,
                         uint64_t** vals, uint64_t* n);

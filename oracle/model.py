@@ -272,6 +272,57 @@ class Tensor:
                 _csr(self.nrows, self.ncols, self.dm))
 
 
+class TensorPairs:
+    """Pair-level model of a Tensor (tensor.rs:184-989): what every layer state (m / dp / dm / me, the diagram at
+    :72-108) must look like from outside — (src, dst) -> ascending edge ids.  The reference's own unit tests
+    (tensor.rs:1340-1669) are stated on exactly these observables plus layer sizes; the observables are replayed here
+    (tests/test_oracle_golden.py) and, with the layer sizes, on the product (tests/test_gpu_host.py)."""
+    MULTI_EDGE = U64_MAX
+
+    def __init__(self):
+        self.pairs = {}
+
+    def set_all_from_slices(self, srcs, dsts, ids):          # :333-455: duplicates of a pair in one batch promote it
+        for s, d, e in zip(srcs, dsts, ids):
+            row = self.pairs.setdefault((int(s), int(d)), [])
+            if int(e) not in row:
+                row.append(int(e))
+                row.sort()
+
+    def remove_all(self, rels):                              # :461-657 -> the pairs left without an edge, each once
+        emptied = []
+        for e, s, d in rels:
+            row = self.pairs.get((int(s), int(d)))
+            if row is None or int(e) not in row:
+                continue                                     # foreign / repeated ids change nothing (:1590-1630)
+            row.remove(int(e))
+            if not row:
+                del self.pairs[(int(s), int(d))]
+                emptied.append((int(s), int(d)))
+        return emptied
+
+    def get(self, s, d):                                     # :307-319
+        return list(self.pairs.get((s, d), []))
+
+    def eff_get(self, s, d):                                 # :286-299: inline id, or the sentinel for a multi pair
+        row = self.pairs.get((s, d))
+        if not row:
+            return None
+        return row[0] if len(row) == 1 else self.MULTI_EDGE
+
+    def edge_count(self):                                    # :955-967
+        return sum(len(r) for r in self.pairs.values())
+
+    def multi_pairs(self):
+        return sum(1 for r in self.pairs.values() if len(r) > 1)
+
+    def me_nvals(self):                                      # ids held in `me`: those of the multi pairs
+        return sum(len(r) for r in self.pairs.values() if len(r) > 1)
+
+    def extract(self):                                       # :838-850 pattern
+        return set(self.pairs)
+
+
 class Graph:
     """The traversal-facing slice of graph.rs: adjacency, node-label matrix, per-type tensors."""
 

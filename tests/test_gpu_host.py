@@ -338,6 +338,126 @@ def test_tensor_random_walk_matches_the_pair_model(hctx):  # tensor.rs:1340-1669
     assert sorted(rows) == sorted(mdl.pairs)
 
 
+def test_tensor_rust_unit_pins(hctx):
+    """The #[test]s of tensor.rs:1340-1669, transcribed one for one (tests/golden/rust_unit_pins.json lists them) and
+    run against the C++ Tensor on the device.  Each block carries its reference test's name and assertions."""
+    T = PINS["tensor_unit_tests"]
+    M = host.Tensor.MULTI_EDGE
+
+    # multi_pairs_after_within_batch_duplicates (:1340-1381): one batch, each pair repeated `dup` times consecutively
+    for pairs, dup in T["multi_pairs_after_within_batch_duplicates"]["cases"]:
+        t = host.Tensor(hctx, pairs + 1, pairs + 1)
+        srcs = np.repeat(np.arange(pairs), dup)
+        t.set_all_from_slices(srcs, srcs + 1, np.arange(pairs * dup))
+        t.wait_fwd()
+        sentinels = sum(t.eff_get(i, i + 1) == M for i in range(pairs))
+        edges = sum(len(t.get(i, i + 1)) for i in range(0, pairs, max(1, pairs // 64))) * 1
+        st = t.state()
+        assert st["multi_pairs"] == sentinels == pairs                       # "multi_pairs disagrees (within-batch dups)"
+        assert st["edge_count"] == pairs * dup                               # "edge_count disagrees with a full scan"
+        assert edges == dup * len(range(0, pairs, max(1, pairs // 64)))
+        assert t.get(0, 1) == list(range(dup))
+
+    # multi_pairs_matches_the_sentinel_count (:1386-1425): `dup` edges per pair, inserted as separate batches
+    for pairs, dup in T["multi_pairs_matches_the_sentinel_count"]["cases"]:
+        t = host.Tensor(hctx, pairs + 1, pairs + 1)
+        srcs = np.arange(pairs)
+        for rnd in range(dup):
+            t.set_all_from_slices(srcs, srcs + 1, rnd * pairs + srcs)
+        t.wait_fwd()
+        probe = range(0, pairs, max(1, pairs // 128))
+        assert all(t.eff_get(i, i + 1) == M for i in probe)
+        st = t.state()
+        assert st["multi_pairs"] == pairs and st["edge_count"] == pairs * dup and st["me_nvals"] == pairs * dup
+        assert t.get(3, 4) == [3 + r * pairs for r in range(dup)]
+
+    # bulk_remove_and_extract_edge_id_zero (:1427-1460)
+    c = T["bulk_remove_and_extract_edge_id_zero"]
+    n = c["n"]
+    t = host.Tensor(hctx, n + 1, n + 1)
+    srcs = np.arange(n)
+    t.set_all_from_slices(srcs, srcs + 1, srcs)
+    t = t.dup()
+    t.flush()
+    assert t.m_get(0, 1) == 0                                                # "edge id 0 not folded into base"
+    t.remove_all([tuple(r) for r in c["remove"]])
+    assert t.get(0, 1) == [] and t.get(5, 6) == []                           # "edge id 0 / 5 still readable"
+    assert t.extract_contains(1, 2)                                          # "unrelated live pair (1,2) disappeared"
+    assert not t.extract_contains(5, 6)                                      # "control pair (5,6) not deleted"
+    assert not t.extract_contains(0, 1)                                      # edge id 0 must not be typecast to false in dm
+
+    # resize_leaves_base_materialized (:1478-1501)
+    c = T["resize_leaves_base_materialized"]
+    n = c["n"]
+    t = host.Tensor(hctx, n + 1, n + 1)
+    t.set_all_from_slices(srcs, srcs + 1, srcs)
+    t.flush()
+    t.wait()
+    t.resize(c["resize_to"], c["resize_to"])
+    assert t.state()["m_pending"] == 0                                       # "resize left the committed base pending"
+    t.wait_fwd()
+    assert t.get(0, 1) == [0]                                                # "edge lost across resize"
+
+    # deleting_everything_folds_the_tombstones_away (:1509-1535)
+    n = T["deleting_everything_folds_the_tombstones_away"]["n"]
+    t = host.Tensor(hctx, n + 1, n + 1)
+    t.set_all_from_slices(srcs, srcs + 1, srcs)
+    t = t.dup()
+    t.flush()
+    t.wait_fwd()
+    assert t.state()["m"] == n                                               # "adds did not fold into the base"
+    t = t.dup()
+    t.remove_all([(i, i, i + 1) for i in range(n)])
+    t.fold_oversized()
+    st = t.state()
+    assert st["m"] == 0 and st["dm"] == 0 and t.get(0, 1) == []              # base / tombstones folded away
+
+    N = T["FOLDABLE"]
+
+    def committed_pairs(k):                                                  # (:1543-1556)
+        t = host.Tensor(hctx, k + 1, k + 1)
+        s2 = np.repeat(np.arange(k), 2)
+        t.set_all_from_slices(s2, s2 + 1, np.arange(2 * k))
+        t.fold_oversized()
+        t.wait()
+        assert t.state()["m"] == k                                           # "sentinels not folded into the base"
+        return t.dup()
+
+    # batch_demote_leaves_every_survivor_inline (:1563-1584)
+    t = committed_pairs(N)
+    emptied = t.remove_all([(2 * i + 1, i, i + 1) for i in range(N)])
+    st = t.state()
+    assert emptied == [] and st["edge_count"] == N and st["multi_pairs"] == 0 and st["me_nvals"] == 0
+    assert all(t.get(i, i + 1) == [2 * i] for i in range(N))                 # "pair lost its surviving edge"
+
+    # batch_can_demote_and_then_empty_the_same_pair (:1590-1630)
+    t = committed_pairs(N)
+    rels = []
+    for i in range(N):
+        rels += [(2 * i + 1, i, i + 1), (2 * i + 1, i, i + 1), (7 * N + i, i, i + 1), (2 * i, i, i + 1), (2 * i, i, i + 1)]
+    emptied = sorted(t.remove_all(rels))
+    assert emptied == [(i, i + 1) for i in range(N)]                         # every pair emptied exactly once
+    st = t.state()
+    assert st["edge_count"] == 0 and st["multi_pairs"] == 0 and st["me_nvals"] == 0 and st["mt"] == 0
+    assert all(t.get(i, i + 1) == [] for i in range(N))
+
+    # demoting_to_the_committed_value_cancels_to_clean (:1636-1668)
+    t = host.Tensor(hctx, N + 1, N + 1)
+    s1 = np.arange(N)
+    t.set_all_from_slices(s1, s1 + 1, s1 + 1)
+    t.fold_oversized()
+    t.wait()
+    assert t.m_get(0, 1) == 1                                                # "single edge not committed"
+    t = t.dup()
+    t.set_all_from_slices([0], [1], [9])
+    emptied = t.remove_all([(9, 0, 1)])
+    assert emptied == []
+    t.wait()
+    st = t.state()
+    assert st["dp"] == 0 and st["dm"] == 0 and st["me_nvals"] == 0 and st["edge_count"] == N
+    assert t.get(0, 1) == [1]                                                # "committed edge lost"
+
+
 def test_bulk_delete_folds_tombstones_at_commit(hctx):     # tensor.rs:1590-1669 (delete-all folds tombstones)
     n = 2000
     g = host.Graph(hctx, n)
