@@ -442,6 +442,23 @@ class Graph:
                                         C.byref(f), C.byref(t), C.byref(e), C.byref(n)))
         return list(zip(_take(f, n.value).tolist(), _take(t, n.value).tolist(), _take(e, n.value).tolist()))
 
+    def cond_traverse_rows(self, spec, from_ids, to_ids, transposed=False, used_edges=(), dedup_src=None):
+        """The per-row fallback over one input batch: from / to = node id, None (unbound) or "x" (bound to a non-node).
+        Returns [(row, from, to, edge)] in emission order."""
+        enc = lambda v: -1 if v is None else (-2 if isinstance(v, str) else int(v))
+        k = len(from_ids)
+        f = (C.c_int64 * k)(*[enc(v) for v in from_ids])
+        t = (C.c_int64 * k)(*[enc(v) for v in to_ids])
+        dd = (C.c_int64 * k)(*[enc(v) for v in dedup_src]) if dedup_src is not None else None
+        used = _u64(list(used_edges))
+        orow, of, ot, oe = u64p(), u64p(), u64p(), u64p()
+        n = C.c_uint64()
+        _ck(self.L.fh_cond_traverse_rows(self.h, spec, f, t, dd, C.c_uint64(k), 1 if transposed else 0, _p(used),
+                                         C.c_uint64(len(used)), C.byref(orow), C.byref(of), C.byref(ot), C.byref(oe),
+                                         C.byref(n)))
+        return list(zip(_take(orow, n.value).tolist(), _take(of, n.value).tolist(), _take(ot, n.value).tolist(),
+                        _take(oe, n.value).tolist()))
+
     def expand_into(self, types, srcs, dsts, bidirectional=False, emit_relationship=True, batched=True):
         s, d = _u64(srcs), _u64(dsts)
         orow, osrc, odst, oedge = u64p(), u64p(), u64p(), u64p()

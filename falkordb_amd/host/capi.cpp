@@ -448,21 +448,41 @@ int fh_cond_traverse_batch(fh_graph* g, const char* spec, const int64_t* src, co
     });
 }
 
-int fh_cond_traverse_row(fh_graph* g, const char* spec, int64_t from_id, int64_t to_id, int transposed,
-                         uint64_t** out_from, uint64_t** out_to, uint64_t** out_edge, uint64_t* n) {
+int fh_cond_traverse_rows(fh_graph* g, const char* spec, const int64_t* from_ids, const int64_t* to_ids,
+                          const int64_t* dedup_src, uint64_t k, int transposed, const uint64_t* used_edges,
+                          uint64_t n_used, uint64_t** out_row, uint64_t** out_from, uint64_t** out_to,
+                          uint64_t** out_edge, uint64_t* n) {
     return guard([&] {
         CondTraverseOp op = parse_spec(spec);
-        std::vector<std::array<u64, 3>> out;
-        op.expand_row(g->g, from_id >= 0 ? std::optional<u64>((u64)from_id) : std::nullopt,
-                      to_id >= 0 ? std::optional<u64>((u64)to_id) : std::nullopt, transposed != 0, {}, out);
-        std::vector<u64> f, t, e;
-        for (auto& x : out) { f.push_back(x[0]); t.push_back(x[1]); e.push_back(x[2]); }
+        CondTraverseOp::BidirDedup dd;                       // one input batch: fresh dedup state (:1268-1270)
+        std::vector<u64> used(used_edges, used_edges + (used_edges ? n_used : 0));
+        std::vector<u64> r, f, t, e;
+        for (u64 i = 0; i < k; ++i) {
+            if (from_ids[i] == -2 || to_ids[i] == -2) continue;   // bound to a non-node: no rows (:792-803)
+            std::vector<std::array<u64, 3>> out;
+            const bool dedup = dedup_src != nullptr;
+            op.expand_row(g->g, from_ids[i] >= 0 ? std::optional<u64>((u64)from_ids[i]) : std::nullopt,
+                          to_ids[i] >= 0 ? std::optional<u64>((u64)to_ids[i]) : std::nullopt, transposed != 0, used, out,
+                          dedup ? &dd : nullptr,
+                          dedup && dedup_src[i] >= 0 ? std::optional<u64>((u64)dedup_src[i]) : std::nullopt);
+            for (auto& x : out) { r.push_back(i); f.push_back(x[0]); t.push_back(x[1]); e.push_back(x[2]); }
+        }
+        *out_row = hand(r);
         *out_from = hand(f);
         *out_to = hand(t);
         *out_edge = hand(e);
-        *n = out.size();
+        *n = r.size();
         return 0;
     });
+}
+
+int fh_cond_traverse_row(fh_graph* g, const char* spec, int64_t from_id, int64_t to_id, int transposed,
+                         uint64_t** out_from, uint64_t** out_to, uint64_t** out_edge, uint64_t* n) {
+    uint64_t* rows = nullptr;
+    int rc = fh_cond_traverse_rows(g, spec, &from_id, &to_id, nullptr, 1, transposed, nullptr, 0, &rows, out_from, out_to,
+                                   out_edge, n);
+    if (rc == 0) fh_free(rows);
+    return rc;
 }
 
 int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_relationship, int batched,

@@ -326,62 +326,91 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
 }
 
 void CondTraverseOp::expand_row(const Graph& g, std::optional<u64> from_id, std::optional<u64> to_id, bool transposed,
-                                const std::vector<u64>& used_edges, std::vector<std::array<u64, 3>>& out) const {
+                                const std::vector<u64>& used_edges, std::vector<std::array<u64, 3>>& out,
+                                BidirDedup* dedup, std::optional<u64> dedup_src) const {
     const Hop& h = hops.at(0);
+    // build_state (cond_traverse.rs:362-440): labels of the matrix source / destination for the forward pass and,
+    // for a bidirectional pattern, for the reverse pass; any unknown label or an unresolvable type is no_match
     std::vector<u64> tids;
-    for (auto& t : h.types) {
-        auto id = g.type_id(t);
-        if (!id) return;                                                 // state.no_match
-        tids.push_back(*id);
-    }
-    auto src_l = g.resolve_label_ids(src_labels);
-    auto dst_l = g.resolve_label_ids(h.dst_labels);
-    if (!src_l || !dst_l) return;
-    // matrix coordinates: (src, dst) of the stored direction; `transposed` swaps the pattern's endpoints
-    std::optional<u64> msrc = transposed ? to_id : from_id;
-    std::optional<u64> mdst = transposed ? from_id : to_id;
-    const std::vector<LabelId>& msrc_l = transposed ? *dst_l : *src_l;
-    const std::vector<LabelId>& mdst_l = transposed ? *src_l : *dst_l;
-    std::vector<std::pair<u64, u64>> pairs;
-    auto fwd_rows = [&](u64 lo, u64 hi) {
-        std::vector<Entry> es;
-        if (tids.empty()) es = g.adjacency_matrix().iter(lo, hi);
-        else if (tids.size() == 1) es = g.relationship_tensors()[tids[0]].structural_iter(lo, hi);
-        else es = g.build_relationship_matrix_unrestricted(tids).iter(lo, hi);
-        return es;
-    };
-    if (!msrc && mdst) {
-        // only the matrix destination is bound: walk its incoming pairs over the transposed structure
-        std::vector<Entry> es;
-        if (tids.size() == 1) es = g.relationship_tensors()[tids[0]].matrix_t().iter(*mdst, *mdst);
-        else {
-            Matrix a = tids.empty() ? g.adjacency_matrix().extract() : g.build_relationship_matrix_unrestricted(tids);
-            es = a.transpose().iter(*mdst, *mdst);
-        }
-        for (auto& e : es) pairs.push_back({e.col, e.row});
-    } else {
-        for (auto& e : fwd_rows(msrc ? *msrc : 0, msrc ? *msrc : ~0ull))
-            if (!mdst || *mdst == e.col) pairs.push_back({e.row, e.col});
-    }
-    std::vector<u64> scan = tids;
-    if (scan.empty())
+    if (!resolve_hop_types(g, h.types, tids)) return;                    // build_unrestricted_iter -> None
+    auto from_l = g.resolve_label_ids(src_labels);
+    auto to_l = g.resolve_label_ids(h.dst_labels);
+    if (!from_l || !to_l) return;
+    const std::vector<LabelId>& fwd_src_l = transposed ? *to_l : *from_l;
+    const std::vector<LabelId>& fwd_dst_l = transposed ? *from_l : *to_l;
+    const std::vector<LabelId>& rev_src_l = transposed ? *from_l : *to_l;       // :376-389
+    const std::vector<LabelId>& rev_dst_l = transposed ? *to_l : *from_l;
+    std::vector<u64> scan = tids;                                        // edge_type_indices (:418-426)
+    if (h.types.empty())
         for (u64 t = 0; t < g.relationship_tensors().size(); ++t) scan.push_back(t);
-    for (auto& pr : pairs) {                                             // process_pairs (:978-1117)
-        const u64 s = pr.first, d = pr.second;
-        bool okl = true;
-        for (LabelId l : msrc_l) okl = okl && g.node_has_label_id(s, l);
-        for (LabelId l : mdst_l) okl = okl && g.node_has_label_id(d, l);
-        if (!okl) continue;
-        const u64 from_node = transposed ? d : s, to_node = transposed ? s : d;
-        bool first_only = !emit_relationship;
-        for (u64 t : scan) {
+
+    // rows [lo, hi] of the unrestricted pair matrix in ascending (row, col) order (build_unrestricted_iter :196-209)
+    auto fwd_rows = [&](u64 lo, u64 hi) {
+        if (h.types.empty()) return g.adjacency_matrix().iter(lo, hi);
+        if (h.types.size() == 1) return g.relationship_tensors()[tids[0]].structural_iter(lo, hi);
+        return g.build_relationship_matrix_unrestricted(tids).iter(lo, hi);
+    };
+    // row d of the TRANSPOSED pair matrix: (dest, src) ascending (build_transposed_iter :221-235)
+    auto bwd_row = [&](u64 d) {
+        if (h.types.size() == 1) return g.relationship_tensors()[tids[0]].matrix_t().iter(d, d);
+        Matrix a = h.types.empty() ? g.adjacency_matrix().extract() : g.build_relationship_matrix_unrestricted(tids);
+        return a.transpose().iter(d, d);
+    };
+    // (src, dst) matrix coordinates of one pass (:852-874 / :897-921)
+    auto pairs_of = [&](std::optional<u64> msrc, std::optional<u64> mdst, bool drop_loops) {
+        std::vector<std::pair<u64, u64>> pairs;
+        if (!msrc && mdst) {
+            for (auto& e : bwd_row(*mdst)) pairs.push_back({e.col, e.row});
+        } else {
+            for (auto& e : fwd_rows(msrc ? *msrc : 0, msrc ? *msrc : ~0ull))
+                if (!mdst || *mdst == e.col) pairs.push_back({e.row, e.col});
+        }
+        if (drop_loops)
+            pairs.erase(std::remove_if(pairs.begin(), pairs.end(), [](auto& p) { return p.first == p.second; }), pairs.end());
+        return pairs;
+    };
+    // process_pairs (:978-1117), without the attribute filters (the attribute store is out of scope)
+    auto process = [&](const std::vector<std::pair<u64, u64>>& pairs, bool is_reverse, const std::vector<LabelId>& sl,
+                       const std::vector<LabelId>& dl) {
+        for (auto& pr : pairs) {
+            const u64 s = pr.first, d = pr.second;
+            bool okl = true;
+            for (LabelId l : sl) okl = okl && g.node_has_label_id(s, l);
+            for (LabelId l : dl) okl = okl && g.node_has_label_id(d, l);
+            if (!okl) continue;
+            const u64 from_node = is_reverse ? d : s, to_node = is_reverse ? s : d;
+            if (from_id && *from_id != from_node) continue;
+            if (to_id && *to_id != to_node) continue;
+            const bool first_only = !emit_relationship;                  // one representative edge per pair (:1063-1081)
             bool done = false;
-            for (u64 id : g.relationship_tensors()[t].get(s, d)) {
-                if (std::find(used_edges.begin(), used_edges.end(), id) != used_edges.end()) continue;
-                out.push_back({from_node, to_node, id});
-                if (first_only) { done = true; break; }
+            for (u64 t : scan) {
+                for (u64 id : g.relationship_tensors()[t].get(s, d)) {
+                    if (std::find(used_edges.begin(), used_edges.end(), id) != used_edges.end()) continue;
+                    out.push_back({from_node, to_node, id});
+                    if (first_only) { done = true; break; }
+                }
+                if (done) break;
             }
-            if (done) break;
+        }
+    };
+    const size_t start = out.size();
+    const std::optional<u64> fwd_src = transposed ? to_id : from_id, fwd_dst = transposed ? from_id : to_id;
+    process(pairs_of(fwd_src, fwd_dst, false), transposed, fwd_src_l, fwd_dst_l);
+    if (bidirectional) {                                                 // the reverse relationships (:894-945)
+        const std::optional<u64> rev_src = transposed ? from_id : to_id, rev_dst = transposed ? to_id : from_id;
+        process(pairs_of(rev_src, rev_dst, true), !transposed, rev_src_l, rev_dst_l);
+    }
+    // anonymous bidirectional CT over an anonymous bidirectional child: one row per (scan source, final dest) across the
+    // expand_row calls of a batch — swap_remove, as the reference does, so the surviving order is the reference's (:948-970)
+    if (dedup && dedup_src) {
+        size_t i = start;
+        while (i < out.size()) {
+            if (!dedup->seen.insert({*dedup_src, out[i][1]}).second) {
+                out[i] = out.back();
+                out.pop_back();
+                continue;
+            }
+            ++i;
         }
     }
 }

@@ -17,6 +17,7 @@
 
 #include <array>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -399,10 +400,17 @@ struct CondTraverseOp {
     // and `null_rows` with the active rows an OPTIONAL traverse null-pads (:737-747).
     bool expand_batch(const Graph& g, const std::vector<Value>& src, const std::vector<Value>* to_bound,
                       ExpandedRows& rows, std::vector<u64>& null_rows, u64* flops = nullptr) const;
-    // expand_row + process_pairs (cond_traverse.rs:758-974, 978-1117) without attribute filters: the pairs
-    // of one source (or, transposed, one destination) with label checks and per-pair edge lookup.
+    // (scan source, final dest) pairs already emitted by an anonymous bidirectional CT whose child is one too
+    // (cond_traverse.rs:176-186, 262-299); cleared for every new input batch (:1268-1270)
+    struct BidirDedup { std::set<std::pair<u64, u64>> seen; };
+    // expand_row + process_pairs (cond_traverse.rs:758-974, 978-1117) without attribute filters: forward pass (over
+    // the transposed structure when only the matrix destination is bound), the reverse pass of a bidirectional
+    // pattern (self-loops dropped there), label / endpoint checks, per-pair edge lookup (one representative edge
+    // unless emit_relationship), cross-row (src, dst) dedup.  An endpoint bound to a non-node gives no rows: the
+    // caller does not call.  `dedup_src` = the value of the dedup source alias on this row.
     void expand_row(const Graph& g, std::optional<u64> from_id, std::optional<u64> to_id, bool transposed,
-                    const std::vector<u64>& used_edges, std::vector<std::array<u64, 3>>& out) const;
+                    const std::vector<u64>& used_edges, std::vector<std::array<u64, 3>>& out,
+                    BidirDedup* dedup = nullptr, std::optional<u64> dedup_src = std::nullopt) const;
 };
 
 // ExpandIntoOp (runtime/ops/expand_into.rs:121-258)

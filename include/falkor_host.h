@@ -141,6 +141,13 @@ uint64_t fh_last_op_ns(void);
 int fh_cond_traverse_eligible(const char* spec);                                       /* cond_traverse.rs:308-316 */
 int fh_cond_traverse_row(fh_graph* g, const char* spec, int64_t from_id, int64_t to_id, int transposed,
                          uint64_t** out_from, uint64_t** out_to, uint64_t** out_edge, uint64_t* n); /* :758-1117 */
+/* The per-row fallback over one input batch of k rows (from / to: node id, -1 unbound, -2 bound to a non-node), with
+ * the sibling-edge uniqueness list and, when dedup_src != NULL, the cross-row (scan source, final dest) dedup of an
+ * anonymous bidirectional CT over an anonymous bidirectional child (cond_traverse.rs:262-299, 948-970). */
+int fh_cond_traverse_rows(fh_graph* g, const char* spec, const int64_t* from_ids, const int64_t* to_ids,
+                          const int64_t* dedup_src, uint64_t k, int transposed, const uint64_t* used_edges,
+                          uint64_t n_used, uint64_t** out_row, uint64_t** out_from, uint64_t** out_to,
+                          uint64_t** out_edge, uint64_t* n);
 /* types: comma list ("" = all).  batched != 0 runs the whole input through one set of device probes. */
 int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_relationship, int batched,
                    const uint64_t* srcs, const uint64_t* dsts, uint64_t k, uint64_t** out_row,

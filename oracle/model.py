@@ -454,6 +454,90 @@ def expand_batch(g: Graph, src_values, types, src_labels=(), dst_labels=(), chai
     return out, nulls
 
 
+def expand_row(g: Graph, from_id, to_id, types, from_labels=(), to_labels=(), transposed=False, bidirectional=False,
+               emit_relationship=False, used_edges=(), dedup=None, dedup_src=None):
+    """CondTraverseOp::expand_row + process_pairs (cond_traverse.rs:758-974, 978-1117), the per-row fallback, without the
+    attribute filters: returns [(from, to, edge id)] in emission order.
+
+    build_state (:362-440): the pair matrix is the adjacency ([] types), one tensor's structure, or the union of the
+    KNOWN types of an alternation (None known / a single unknown type -> no rows); an unknown label -> no rows.
+    Forward pass: the rows of the matrix source, or — only the matrix destination bound — that node's row of the
+    TRANSPOSED matrix ((dest, src) ascending, :221-235, 852-864).  Bidirectional: a second pass with the endpoints
+    swapped, self-loops dropped (:894-945).  process_pairs: label checks on the raw matrix coordinates, from / to
+    filters on the oriented pair, one representative edge per pair unless emit_relationship, ids already bound to a
+    sibling edge alias skipped.  `dedup` (a set shared by the rows of one input batch): rows whose (dedup_src, to) was
+    seen are removed with swap_remove (:948-970)."""
+    types = list(types)
+    if not types:
+        struct = set(g.adjacency.extract())
+        scan = list(range(len(g.tensors)))
+    elif len(types) == 1:
+        if types[0] not in g.type_ids:
+            return []
+        struct = g.tensors[g.type_ids[types[0]]].structure()
+        scan = [g.type_ids[types[0]]]
+    else:
+        scan = [g.type_ids[t] for t in types if t in g.type_ids]
+        if not scan:
+            return []
+        struct = set()
+        for t in scan:
+            struct |= g.tensors[t].structure()
+    from_l, to_l = g.resolve_label_ids(list(from_labels)), g.resolve_label_ids(list(to_labels))
+    if from_l is None or to_l is None:
+        return []
+    fwd = sorted(struct)                                       # ascending (row, col)
+    bwd = sorted((d, s) for (s, d) in struct)                  # the transposed matrix, ascending (dest, src)
+
+    def pairs_of(msrc, mdst, drop_loops):
+        if msrc is None and mdst is not None:
+            ps = [(s, d) for (d, s) in bwd if d == mdst]
+        else:
+            ps = [(s, d) for (s, d) in fwd if (msrc is None or s == msrc) and (mdst is None or d == mdst)]
+        return [(s, d) for (s, d) in ps if not (drop_loops and s == d)]
+
+    out = []
+
+    def process(pairs, is_reverse, sl, dl):
+        for (s, d) in pairs:
+            if not all(g.node_has_label_id(s, l) for l in sl) or not all(g.node_has_label_id(d, l) for l in dl):
+                continue
+            fn, tn = (d, s) if is_reverse else (s, d)
+            if from_id is not None and from_id != fn:
+                continue
+            if to_id is not None and to_id != tn:
+                continue
+            done = False
+            for t in scan:
+                for e in g.tensors[t].get(s, d):
+                    if e in used_edges:
+                        continue
+                    out.append((fn, tn, e))
+                    if not emit_relationship:
+                        done = True
+                        break
+                if done:
+                    break
+
+    fwd_src, fwd_dst = (to_id, from_id) if transposed else (from_id, to_id)
+    process(pairs_of(fwd_src, fwd_dst, False), transposed, to_l if transposed else from_l, from_l if transposed else to_l)
+    if bidirectional:
+        rev_src, rev_dst = (from_id, to_id) if transposed else (to_id, from_id)
+        process(pairs_of(rev_src, rev_dst, True), not transposed, from_l if transposed else to_l,
+                to_l if transposed else from_l)
+    if dedup is not None and dedup_src is not None:
+        i = 0
+        while i < len(out):
+            key = (dedup_src, out[i][1])
+            if key in dedup:
+                out[i] = out[-1]
+                out.pop()
+                continue
+            dedup.add(key)
+            i += 1
+    return out
+
+
 def expand_into_row(g: Graph, src, dst, types, bidirectional=False, emit_relationship=True, used_edges=()):
     """ExpandIntoOp::expand_row (expand_into.rs:121-258), SURVEY Appendix A.5: edge ids connecting the
     two bound endpoints, scanning the type tensors in order, ids ascending per type; without

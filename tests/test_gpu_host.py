@@ -766,6 +766,10 @@ CASES = [
     dict(types=["A"], src_labels=[], dst_labels=[], chain=[], optional=True),
     dict(types=["Nope"], src_labels=[], dst_labels=[], chain=[], optional=True),
     dict(types=["A"], src_labels=["NoSuchLabel"], dst_labels=[], chain=[]),
+    dict(types=["A", "Nope"], src_labels=[], dst_labels=[], chain=[]),                 # [:A|Nope] keeps the A edges (filter_map)
+    dict(types=["Nope", "Nada"], src_labels=[], dst_labels=[], chain=[], optional=True),   # no known type: no_match
+    dict(types=["A"], src_labels=[], dst_labels=[], chain=[(["Nope", "B"], [])]),      # the same in a fused hop
+    dict(types=["B", "Nope"], src_labels=[], dst_labels=[], chain=[], bind=True),      # representative edge scan skips unknowns
 ]
 
 
@@ -824,6 +828,71 @@ def test_expand_row_fallback_matches_brute_force(rnd_graph):   # cond_traverse.r
         got = g.cond_traverse_row(anon, from_id=s)
         want = sorted((s, d, es[0]) for (x, d), es in a.items() if x == s)
         assert sorted(got) == want
+
+
+ROW_CASES = [
+    dict(types=["A"], emit=True),
+    dict(types=["A"], emit=False, bidir=True),
+    dict(types=[], emit=False, bidir=True, from_labels=["P"], to_labels=["Q"]),
+    dict(types=["A", "B"], emit=True, bidir=True, to_labels=["P"]),
+    dict(types=["A", "Nope"], emit=False),                       # an alternation drops its unknown names
+    dict(types=["Nope"], emit=True),                             # a single unknown type: no rows
+    dict(types=["Nope", "Nada"], emit=True, bidir=True),         # an alternation with no known type: no rows
+    dict(types=["B"], emit=True, transposed=True, from_labels=["Q"]),
+    dict(types=[], emit=False, transposed=True, bidir=True, to_labels=["P"]),
+    dict(types=["A"], emit=True, from_labels=["NoSuchLabel"]),
+]
+
+
+@pytest.mark.parametrize("case", ROW_CASES, ids=lambda c: json.dumps(c, separators=(",", ":"))[:70])
+def test_expand_row_matches_the_oracle_model(rnd_graph, case):   # cond_traverse.rs:758-1117 vs oracle/model.py expand_row
+    """The per-row fallback against the oracle's restatement, emission order included: from-bound, to-bound (walks the
+    transposed structure), both bound, neither bound; bidirectional reverse pass; sibling-edge uniqueness; an endpoint
+    bound to a non-node."""
+    g, og, n, per_type = rnd_graph
+    rng = np.random.default_rng(91)
+    spec = host.cond_spec(src_labels=case.get("from_labels", []), hops=[(case["types"], case.get("to_labels", []))],
+                          emit=case["emit"], bidir=case.get("bidir", False))
+    pairs = list(per_type[0])[:40] + list(per_type[1])[:40]
+    used = [per_type[0][p][0] for p in list(per_type[0])[:25]]    # ids "already bound to a sibling edge alias"
+    rows = [(s, None) for s, _ in pairs[:30]] + [(None, d) for _, d in pairs[30:60]] + pairs[60:75] + \
+           [(d, s) for s, d in pairs[:10]] + [(int(rng.integers(0, n)), None) for _ in range(10)] + [("x", None), (3, "x")]
+    kw = dict(from_labels=case.get("from_labels", ()), to_labels=case.get("to_labels", ()),
+              transposed=case.get("transposed", False), bidirectional=case.get("bidir", False),
+              emit_relationship=case["emit"])
+    for used_edges in ((), used):
+        got = g.cond_traverse_rows(spec, [r[0] for r in rows], [r[1] for r in rows], transposed=case.get("transposed", False),
+                                   used_edges=used_edges)
+        want = []
+        for i, (f, t) in enumerate(rows):
+            if isinstance(f, str) or isinstance(t, str):
+                continue
+            want += [(i,) + x for x in model.expand_row(og, f, t, case["types"], used_edges=used_edges, **kw)]
+        assert got == want
+    # the whole pair matrix (nothing bound) on the first case only: one long row
+    if case is ROW_CASES[1]:
+        got = g.cond_traverse_rows(spec, [None], [None])
+        assert got == [(0,) + x for x in model.expand_row(og, None, None, case["types"], **kw)]
+        assert len(got) > 500
+
+
+def test_expand_row_bidirectional_dedup_across_rows(rnd_graph):   # cond_traverse.rs:262-299, 948-970
+    """An anonymous bidirectional CT whose child is one too keeps ONE row per (scan source, final dest) across the rows of
+    an input batch (swap_remove order), with a fresh set for every batch."""
+    g, og, n, per_type = rnd_graph
+    spec = host.cond_spec(hops=[([], [])], emit=False, bidir=True)
+    mids = [s for s, _ in list(per_type[0])[:60]]                  # the intermediate nodes this CT expands from
+    scan = [m % 7 for m in mids]                                   # few distinct scan sources: many collisions
+    got = g.cond_traverse_rows(spec, mids, [None] * len(mids), dedup_src=scan)
+    seen, want = set(), []
+    for i, (m, sc) in enumerate(zip(mids, scan)):
+        want += [(i,) + x for x in model.expand_row(og, m, None, [], bidirectional=True, dedup=seen, dedup_src=sc)]
+    assert got == want
+    keys = [(scan[r], t) for r, _, t, _ in got]
+    assert len(keys) == len(set(keys))                             # one row per (scan source, dest)
+    plain = g.cond_traverse_rows(spec, mids, [None] * len(mids))
+    assert len(plain) > len(got) and {(scan[r], t) for r, _, t, _ in plain} == set(keys)
+    assert g.cond_traverse_rows(spec, mids, [None] * len(mids), dedup_src=scan) == got   # a new batch starts clean
 
 
 def test_expand_into_batch_matches_the_oracle(rnd_graph):    # expand_into.rs:121-258
