@@ -13,6 +13,14 @@ properly", binding doc lagraph_bindings.rs:549), all vectors GrB_FP32:
         t <-> r ;  w = t ./ d ;  r = teleport ;  r += A' (plus_second) w
         t -= r ; t = |t| ; rdiff = sum(t)
 
+Arithmetic model: the vectors are FP32 (GrB_FP32), every sum — a row of the plus_second product, the sink mass, rdiff —
+is accumulated in FP64 here and rounded to FP32 once.  The reference accumulates in FP32 in a GraphBLAS-internal order,
+so each of its sums carries a rounding error of up to ~sqrt(k) ulps that depends on an order nobody specifies; the
+FP64-accumulated value is the centre of that cloud and the one number every legal FP32 order approximates.  The engine
+(pagerank.hip) accumulates the same way, so engine and oracle agree to FP32 rounding of identical values: the -m gpu test
+holds 1e-6 relative per score (north_star's PLUS_TIMES tolerance); against an FP32-order reference the expected
+deviation is the reference's own rounding, ~1e-6 on hub rows.
+
 PARITY UNPINNED beyond the properties the reference's flow test holds (tests/flow/test_pagerank.py:40-151: one
 score per node, scores sum to 1 +- 1e-4, all positive, the node with two in-edges ranks highest, S2 > S1):
 LAGraph's source is absent, so this is a restatement from its published algorithm, and GraphBLAS' summation
@@ -28,15 +36,15 @@ F32 = np.float32
 
 
 def _row_sums(at: CSR, w: np.ndarray) -> np.ndarray:
-    """sum of w over every row's column ids, FP32 accumulation in row order."""
+    """sum of w over every row's column ids, FP64 accumulation (returned as float64; the caller rounds once)."""
     n = at.nrows
-    out = np.zeros(n, dtype=F32)
+    out = np.zeros(n, dtype=np.float64)
     if at.nnz == 0:
         return out
     rp = at.rowptr.astype(np.int64)
-    vals = w[at.colidx.astype(np.int64)]
+    vals = w[at.colidx.astype(np.int64)].astype(np.float64)
     nz = np.nonzero(np.diff(rp))[0]
-    out[nz] = np.add.reduceat(vals, rp[nz]).astype(F32)
+    out[nz] = np.add.reduceat(vals, rp[nz])
     return out
 
 
@@ -76,10 +84,10 @@ def pagerank(a: CSR, damping=0.85, tol=1e-4, itermax=100, active=None):
     while iters < itermax and rdiff > tol:
         teleport = teleport0
         if nsinks:
-            teleport = F32(teleport0 + damp_over_n * r[sink].sum(dtype=F32))
+            teleport = F32(np.float64(teleport0) + np.float64(damp_over_n) * r[sink].sum(dtype=np.float64))
         t, r = r, t
         w = (t / d).astype(F32)
-        r = (F32(teleport) + _row_sums(at, w)).astype(F32)
-        rdiff = np.abs(t - r).sum(dtype=F32)
+        r = (np.float64(teleport) + _row_sums(at, w)).astype(F32)
+        rdiff = F32(np.abs(t.astype(np.float64) - r.astype(np.float64)).sum(dtype=np.float64))
         iters += 1
     return r, iters

@@ -1,10 +1,14 @@
 """GPU: fgpu_pagerank (algo.pageRank's LAGr_PageRank core, FP32) against the numpy restatement in
 oracle/pagerank.py, plus the properties the reference's flow test holds (tests/flow/test_pagerank.py:40-151).
 
-Tolerance (floating point, stated here as the task requires): both sides run the same FP32 iteration but sum in
-different orders (GraphBLAS' order is internal anyway), so when the iteration counts agree every score must match
-to 2e-6 absolute + 2e-5 relative; the stopping test `rdiff > tol` may flip one iteration apart when rdiff lands
-within rounding of tol, in which case the L1 distance is bounded by 2 * tol."""
+Tolerance (floating point, stated here as the task requires): BASELINE.json's north_star asks for 1e-6 relative on
+PLUS_TIMES float semirings, and that is what is asserted, per score: RTOL = 1e-6, no absolute slack.  Both sides keep
+FP32 vectors and accumulate every sum in FP64 before the one rounding (oracle/pagerank.py explains why that is the right
+reading of an FP32 reference whose summation order is unspecified), so they differ only where an FP64 sum lands within
+~1e-16 of an FP32 rounding boundary — a 1-ulp (1.2e-7) flip that the 0.85 contraction keeps below 1e-6.  The stopping
+test `rdiff > tol` could still flip one iteration apart if rdiff landed within that distance of tol; the L1 distance is
+then bounded by 2 * tol.  The result is reproducible bit for bit (fixed-order hub reduction, no inter-workgroup float
+atomics): test_scores_are_reproducible_bit_for_bit."""
 import numpy as np
 import pytest
 
@@ -27,10 +31,13 @@ def up(ctx, a):
     return ctx.mat_from_csr(a.nrows, a.ncols, a.rowptr, a.colidx)
 
 
+RTOL = 1e-6   # north_star: "within 1e-6 rel for PLUS_TIMES float semirings"
+
+
 def compare(got, it, ref, it_ref, tol=1e-4):
     assert abs(it - it_ref) <= 1, (it, it_ref)
     if it == it_ref:
-        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(got, ref, rtol=RTOL, atol=0)
     else:
         assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).sum()) <= 2 * tol
 
@@ -95,6 +102,23 @@ def test_hub_rows_and_random_label_mask(ctx):
     ref, it_ref = opr.pagerank(a, active=active)
     compare(got, it, ref, it_ref)
     assert (got[~active] == 0).all()
+
+
+def test_scores_are_reproducible_bit_for_bit(ctx):
+    """Hub rows (in-degree >= 4096) included: three runs of the same call return identical bits, and the measured
+    worst relative deviation from the oracle is reported (and far inside RTOL)."""
+    a = oracle.rmat_csr(17)
+    A = up(ctx, a)
+    At = A.transpose()
+    assert int(np.diff(oracle.transpose(a).rowptr).max()) >= 4096          # the hub chunk path really runs
+    runs = [engine.pagerank(ctx, A, At) for _ in range(3)]
+    assert all(it == runs[0][1] for _, it in runs)
+    assert all(np.array_equal(s.view(np.uint32), runs[0][0].view(np.uint32)) for s, _ in runs)
+    ref, it_ref = opr.pagerank(a)
+    assert it_ref == runs[0][1]
+    rel = np.abs(runs[0][0].astype(np.float64) - ref.astype(np.float64)) / ref.astype(np.float64)
+    print(f"pagerank RMAT-17: max relative deviation from the FP64-accumulated oracle = {rel.max():.3e}")
+    assert rel.max() <= RTOL
 
 
 def test_empty_and_edgeless_graphs(ctx):
