@@ -67,6 +67,8 @@ SIGNATURES = {
     "fgpu_expand": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, C.POINTER(u64p),
                                 C.POINTER(u64p), u64p, u64p]),
     "fgpu_expand_levels": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p]),
+    "fgpu_expand_trail_counts": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, C.c_int, C.POINTER(u64p),
+                                             C.POINTER(u64p), C.POINTER(u64p), u64p]),
     "fgpu_expand_count": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u64p, u64p, u64p]),
     "fgpu_vxm": (C.c_int32, [vp, u64p, u64p, u64p, vp, vp, C.c_int]),
     "fgpu_bfs": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_int64, i32p, i64p, u64p]),

@@ -62,9 +62,9 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES
             if os.path.exists(os.path.join(CSRC, s))]
     if force or jobs or not os.path.exists(LIB):
-        # RCCL: the frontier exchange of the multi-GPU BFS runs inside the library (dist.hip)
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrccl",
-               "-Wl,-rpath,/opt/rocm/lib"]
+        # RCCL (the frontier exchange of the multi-GPU BFS, dist.hip) is bound with dlopen at first use, not linked:
+        # a process that also hosts PyTorch must share PyTorch's copy of librccl.so.1 (see dist.hip)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

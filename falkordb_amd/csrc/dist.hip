@@ -11,18 +11,76 @@
 //   * one process, several GPUs (the Redis module): one context per device, fgpu_comm_init_all.
 // xGMI is point-to-point (7 links per GPU): the exchange is a grouped ncclSend / ncclRecv to every peer — each piece
 // crosses exactly one link once — not a ring.
+#include <dlfcn.h>
 #include <math.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is bound at first use, see below
 
 #include "common.hpp"
 
 namespace fgpu {
 
+// RCCL is bound with dlopen at the first fgpu_comm_* call instead of a DT_NEEDED entry: a process that also hosts
+// PyTorch (bench.py, the tests) already has PyTorch's own librccl.so.1 mapped, and a second copy of RCCL in one
+// process aborts at exit (two sets of static state) — dlopen by SONAME hands back the copy that is already there.  A
+// process without PyTorch (the Redis module) gets the system's /opt/rocm/lib/librccl.so.1.
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&::ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&::ncclGroupStart) GroupStart = nullptr;
+    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&::ncclSend) Send = nullptr;
+    decltype(&::ncclRecv) Recv = nullptr;
+    decltype(&::ncclBroadcast) Broadcast = nullptr;
+    decltype(&::ncclAllReduce) AllReduce = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+const Rccl* rccl() {
+    std::call_once(g_rccl_once, [] {
+        Rccl& r = g_rccl;
+        for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
+        bool ok = true;
+        auto bind = [&](auto& fn, const char* sym) {
+            fn = (std::remove_reference_t<decltype(fn)>)dlsym(g_rccl.handle, sym);
+            if (!fn) { ok = false; g_rccl.error = std::string("librccl lacks ") + sym; }
+        };
+        bind(r.GetUniqueId, "ncclGetUniqueId");
+        bind(r.CommInitRank, "ncclCommInitRank");
+        bind(r.CommInitAll, "ncclCommInitAll");
+        bind(r.CommDestroy, "ncclCommDestroy");
+        bind(r.GroupStart, "ncclGroupStart");
+        bind(r.GroupEnd, "ncclGroupEnd");
+        bind(r.Send, "ncclSend");
+        bind(r.Recv, "ncclRecv");
+        bind(r.Broadcast, "ncclBroadcast");
+        bind(r.AllReduce, "ncclAllReduce");
+        bind(r.GetErrorString, "ncclGetErrorString");
+        if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+    });
+    return g_rccl.handle ? &g_rccl : nullptr;
+}
+}  // namespace
+
+#define FGPU_RCCL_OR_FAIL(R)                                                                  \
+    const Rccl* R = rccl();                                                                   \
+    if (!R) { ::fgpu::set_error("RCCL unavailable: %s", g_rccl.error.c_str()); return FGPU_DEVICE; }
+
 #define FGPU_NCCL(expr)                                                                                   \
     do {                                                                                                  \
         ncclResult_t _r = (expr);                                                                         \
         if (_r != ncclSuccess) {                                                                          \
-            ::fgpu::set_error("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_r), __FILE__, __LINE__); \
+            ::fgpu::set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?", __FILE__, __LINE__); \
             return FGPU_DEVICE;                                                                           \
         }                                                                                                 \
     } while (0)
@@ -33,33 +91,35 @@ fgpu_info comm_allgatherv_u64(fgpu_ctx* ctx, const u64* send, u64* buf, const u6
     if (counts[me])
         FGPU_HIP(hipMemcpyAsync(buf + offs[me], send, counts[me] * sizeof(u64), hipMemcpyDeviceToDevice, st));
     if (nr == 1 || !ctx->comm) return FGPU_OK;
+    FGPU_RCCL_OR_FAIL(R);
     ncclComm_t comm = (ncclComm_t)ctx->comm;
-    FGPU_NCCL(ncclGroupStart());
+    FGPU_NCCL(R->GroupStart());
     if (ctx->opt.dist_collective == 1) {
         for (int r = 0; r < nr; ++r)
             if (counts[r])
-                FGPU_NCCL(ncclBroadcast(r == me ? (const void*)send : (const void*)(buf + offs[r]), buf + offs[r],
+                FGPU_NCCL(R->Broadcast(r == me ? (const void*)send : (const void*)(buf + offs[r]), buf + offs[r],
                                         counts[r], ncclUint64, r, comm, st));
     } else {
         for (int r = 0; r < nr; ++r) {
             if (r == me) continue;
-            if (counts[me]) FGPU_NCCL(ncclSend(send, counts[me], ncclUint64, r, comm, st));
-            if (counts[r]) FGPU_NCCL(ncclRecv(buf + offs[r], counts[r], ncclUint64, r, comm, st));
+            if (counts[me]) FGPU_NCCL(R->Send(send, counts[me], ncclUint64, r, comm, st));
+            if (counts[r]) FGPU_NCCL(R->Recv(buf + offs[r], counts[r], ncclUint64, r, comm, st));
         }
     }
-    FGPU_NCCL(ncclGroupEnd());
+    FGPU_NCCL(R->GroupEnd());
     return FGPU_OK;
 }
 
 fgpu_info comm_allreduce_sum_u32(fgpu_ctx* ctx, u32* buf, u64 n) {
     if (ctx->comm_nranks == 1 || !ctx->comm) return FGPU_OK;
-    FGPU_NCCL(ncclAllReduce(buf, buf, n, ncclUint32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream()));
+    FGPU_RCCL_OR_FAIL(R);
+    FGPU_NCCL(R->AllReduce(buf, buf, n, ncclUint32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream()));
     return FGPU_OK;
 }
 
 // nested grouping for a single-process gang: all ranks' calls of one exchange are issued by one thread
-fgpu_info comm_group_begin() { FGPU_NCCL(ncclGroupStart()); return FGPU_OK; }
-fgpu_info comm_group_end() { FGPU_NCCL(ncclGroupEnd()); return FGPU_OK; }
+fgpu_info comm_group_begin() { FGPU_RCCL_OR_FAIL(R); FGPU_NCCL(R->GroupStart()); return FGPU_OK; }
+fgpu_info comm_group_end() { FGPU_RCCL_OR_FAIL(R); FGPU_NCCL(R->GroupEnd()); return FGPU_OK; }
 
 // entries per block of 2^shift columns (LDS-privatised: no per-entry global atomic)
 __global__ __launch_bounds__(256) void colblock_hist_kernel(const u32* __restrict__ col, u64 nnz, u32 shift, u32 nblocks,
@@ -82,8 +142,9 @@ extern "C" {
 fgpu_info fgpu_comm_unique_id(uint8_t* id) {
     FGPU_REQUIRE(id, FGPU_NULL_POINTER, "fgpu_comm_unique_id: NULL id");
     static_assert(sizeof(ncclUniqueId) == FGPU_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    FGPU_RCCL_OR_FAIL(R);
     ncclUniqueId u;
-    FGPU_NCCL(ncclGetUniqueId(&u));
+    FGPU_NCCL(R->GetUniqueId(&u));
     memcpy(id, &u, sizeof(u));
     return FGPU_OK;
 }
@@ -93,10 +154,11 @@ fgpu_info fgpu_comm_init_rank(fgpu_ctx* ctx, int nranks, int rank, const uint8_t
     FGPU_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, FGPU_INVALID, "fgpu_comm_init_rank: bad rank %d / %d", rank, nranks);
     FGPU_REQUIRE(!ctx->comm, FGPU_INVALID, "fgpu_comm_init_rank: the context already has a communicator");
     (void)ctx->lane();   // makes ctx->device current on this thread
+    FGPU_RCCL_OR_FAIL(R);
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     ncclComm_t c = nullptr;
-    FGPU_NCCL(ncclCommInitRank(&c, nranks, u, rank));
+    FGPU_NCCL(R->CommInitRank(&c, nranks, u, rank));
     ctx->comm = c;
     ctx->comm_rank = rank;
     ctx->comm_nranks = nranks;
@@ -113,8 +175,9 @@ fgpu_info fgpu_comm_init_all(fgpu_ctx* const* ctxs, int n) {
             FGPU_REQUIRE(devs[j] != devs[i], FGPU_INVALID,
                          "fgpu_comm_init_all: contexts %d and %d share device %d (RCCL wants one rank per GPU)", j, i, devs[i]);
     }
+    FGPU_RCCL_OR_FAIL(R);
     std::vector<ncclComm_t> comms(n, nullptr);
-    FGPU_NCCL(ncclCommInitAll(comms.data(), n, devs.data()));
+    FGPU_NCCL(R->CommInitAll(comms.data(), n, devs.data()));
     for (int i = 0; i < n; ++i) {
         ctxs[i]->comm = comms[i];
         ctxs[i]->comm_rank = i;
@@ -127,7 +190,7 @@ fgpu_info fgpu_comm_finalize(fgpu_ctx* ctx) {
     FGPU_REQUIRE(ctx, FGPU_NULL_POINTER, "fgpu_comm_finalize: NULL ctx");
     if (ctx->comm) {
         (void)hipStreamSynchronize(ctx->stream());
-        (void)ncclCommDestroy((ncclComm_t)ctx->comm);
+        if (const Rccl* R = rccl()) (void)R->CommDestroy((ncclComm_t)ctx->comm);
     }
     ctx->comm = nullptr;
     ctx->comm_rank = 0;

@@ -413,6 +413,64 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
     return FGPU_OK;
 }
 
+// ---- exact trail counts for k <= 2 -------------------------------------------------------------
+// The reference evaluates `[*1..k]` with a per-row DFS over TRAILS (edge-unique paths, one row per path:
+// CondVarLenTraverseOp, cond_var_len_traverse.rs:196-387).  For k <= 2 the number of trails between two nodes is a
+// counting product over the effective adjacency: length 1 = the pair's multiplicity; length 2 = sum over the
+// intermediates m of w(a, m) * w(m, b) — PLUS_PAIR on pattern matrices, PLUS_TIMES when the matrices carry per-pair
+// multiplicities — minus the walks that use ONE edge twice, which at length 2 can only be a self-loop a -> a -> a
+// (w(a, a) of them).  From k = 3 on walks that revisit an edge no longer have a product form, so the DFS stays.
+__global__ __launch_bounds__(256) void row_weight_kernel(CsrView c1, CsrView a, const u64* __restrict__ aw,
+                                                        const u32* __restrict__ src, u32 nrows, u64* __restrict__ w1) {
+    // C1 = F0 x A with one source per row: row i of C1 IS row src[i] of A, entry for entry
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    for (u32 i = wave; i < nrows; i += nwaves) {
+        const u32 cb = c1.rowptr[i], ce = c1.rowptr[i + 1];
+        if (cb == ce) continue;
+        u32 ab, ae;
+        row_range(a, src[i], ab, ae);
+        for (u32 k = lane; k < ce - cb; k += 64) w1[cb + k] = aw ? aw[ab + k] : 1ull;
+    }
+}
+
+// one wavefront per F1 entry (i, m): every b in A[m, :] adds w1 * w2 to the count of (i, b) in C2 (binary search in
+// the sorted row), less the self-loop walk
+__global__ __launch_bounds__(256) void trail2_count_kernel(CsrView f1, const u64* __restrict__ w1, CsrView a,
+                                                          const u64* __restrict__ aw, CsrView c2,
+                                                          const u32* __restrict__ src, u32 nnzf,
+                                                          unsigned long long* __restrict__ counts) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    for (u32 e = wave; e < nnzf; e += nwaves) {
+        u32 lo = 0, hi = f1.nrows - 1;                 // row of entry e
+        while (lo < hi) {
+            const u32 mid = (lo + hi + 1) >> 1;
+            if (f1.rowptr[mid] <= e) lo = mid; else hi = mid - 1;
+        }
+        const u32 i = lo, m = f1.colidx[e], s = src[i];
+        const u64 wa = w1[e];
+        u32 rb, re;
+        row_range(a, m, rb, re);
+        const u32 cb = c2.rowptr[i], ce = c2.rowptr[i + 1];
+        for (u32 q = rb + lane; q < re; q += 64) {
+            const u32 b = a.colidx[q];
+            const u64 wb = aw ? aw[q] : 1ull;
+            u64 add = wa * wb;
+            if (m == s && b == s) add -= wa;           // a -> a -> a over the same edge: not a trail
+            if (add == 0) continue;
+            u32 l = cb, h = ce;
+            while (l < h) {
+                const u32 mid = (l + h) >> 1;
+                if (c2.colidx[mid] < b) l = mid + 1; else h = mid;
+            }
+            atomicAdd(&counts[l], (unsigned long long)add);   // (i, b) is in C2 by construction
+        }
+    }
+}
+
 }  // namespace fgpu
 
 using namespace fgpu;
@@ -539,6 +597,109 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
 }
 
 }  // extern "C"
+
+extern "C" fgpu_info fgpu_expand_trail_counts(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                                              const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                                              const fgpu_mat* const* dm, int nhops, int weighted,
+                                              uint64_t** out_rowptr, uint64_t** out_dest, uint64_t** out_count,
+                                              uint64_t* out_nnz) {
+    FGPU_REQUIRE(ctx && out_rowptr && out_dest && out_count && out_nnz, FGPU_NULL_POINTER, "fgpu_expand_trail_counts: NULL argument");
+    FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_trail_counts: NULL src_ids");
+    FGPU_REQUIRE(nhops == 1 || nhops == 2, FGPU_INVALID,
+                 "fgpu_expand_trail_counts: trail counts have a product form for 1 or 2 hops only (cond_var_len_traverse.rs keeps the DFS beyond)");
+    FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
+    for (u64 i = 0; i < nsrc; ++i)
+        FGPU_REQUIRE(src_ids[i] != UINT64_MAX, FGPU_INVALID, "fgpu_expand_trail_counts: every row needs a source");
+    // effective layers (m \ dm) U dp — real edges, no row-level mask quirk: these are counts of paths, not a delta_lmxm
+    std::vector<const fgpu_mat*> eff(nhops, nullptr);
+    std::vector<fgpu_mat*> owned;
+    auto cleanup = [&]() { for (auto* x : owned) mat_release(x); };
+    fgpu_info i = FGPU_OK;
+    for (int h = 0; h < nhops && i == FGPU_OK; ++h) {
+        const fgpu_mat* dph = dp ? dp[h] : nullptr;
+        const fgpu_mat* dmh = dm ? dm[h] : nullptr;
+        const bool dirty = (dph && dph->nnz) || (dmh && dmh->nnz);
+        if (!dirty && !m[h]->is_hyper()) { eff[h] = m[h]; continue; }
+        fgpu_mat* e = nullptr;
+        i = mat_merge_entries(ctx, &e, m[h], dph, dmh, false, m[h]->nrows, m[h]->ncols, !weighted);
+        if (i == FGPU_OK) { owned.push_back(e); eff[h] = e; }
+    }
+    if (i != FGPU_OK) { cleanup(); return i; }
+    if (weighted)
+        for (int h = 0; h < nhops; ++h)
+            if (!eff[h]->vals) { cleanup(); set_error("fgpu_expand_trail_counts: weighted counts need UINT64 multiplicity layers"); return FGPU_INVALID; }
+    fgpu_mat *f0 = nullptr, *c1 = nullptr, *c2 = nullptr;
+    DevBuf<u32> dsrc;
+    DevBuf<u64> w1, cnt;
+    std::vector<u32> s32(nsrc);
+    for (u64 k = 0; k < nsrc; ++k) s32[k] = (u32)src_ids[k];
+    auto run = [&]() -> fgpu_info {
+        FGPU_TRY(upload_sources(ctx, &f0, src_ids, nsrc, eff[0]->nrows));
+        FGPU_TRY(dsrc.alloc(ctx, nsrc));
+        FGPU_HIP(hipMemcpyAsync(dsrc.p, s32.data(), nsrc * sizeof(u32), hipMemcpyHostToDevice, ctx->stream()));
+        FGPU_TRY(mxm_device(ctx, &c1, f0, eff[0], nullptr));
+        FGPU_TRY(w1.alloc(ctx, c1->nnz));
+        if (c1->nnz) {
+            u32 grid = cdiv(nsrc, 4);
+            if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+            hipLaunchKernelGGL(row_weight_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(c1), view_of(eff[0]),
+                               weighted ? (const u64*)eff[0]->vals : (const u64*)nullptr, (const u32*)dsrc.p, (u32)nsrc, w1.p);
+            FGPU_HIP(hipGetLastError());
+        }
+        const fgpu_mat* res = c1;
+        const u64* res_cnt = w1.p;
+        if (nhops == 2) {
+            FGPU_TRY(mxm_device(ctx, &c2, c1, eff[1], nullptr));
+            FGPU_TRY(cnt.alloc(ctx, c2->nnz));
+            FGPU_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(c2->nnz ? c2->nnz : 1) * sizeof(u64), ctx->stream()));
+            if (c1->nnz && c2->nnz) {
+                u32 grid = cdiv(c1->nnz, 4);
+                if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+                hipLaunchKernelGGL(trail2_count_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(c1), (const u64*)w1.p,
+                                   view_of(eff[1]), weighted ? (const u64*)eff[1]->vals : (const u64*)nullptr, view_of(c2),
+                                   (const u32*)dsrc.p, (u32)c1->nnz, (unsigned long long*)cnt.p);
+                FGPU_HIP(hipGetLastError());
+            }
+            res = c2;
+            res_cnt = cnt.p;
+        }
+        // host hand-over: rowptr / dest as fgpu_expand does, counts beside them.  Pairs reached only through the
+        // self-loop walk keep a zero count: they are walks, not trails, and are dropped here.
+        std::vector<u32> rp((size_t)nsrc + 1), ci(res->nnz);
+        std::vector<u64> cv(res->nnz);
+        FGPU_HIP(hipMemcpyAsync(rp.data(), res->rowptr, rp.size() * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
+        if (res->nnz) {
+            FGPU_HIP(hipMemcpyAsync(ci.data(), res->colidx, res->nnz * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
+            FGPU_HIP(hipMemcpyAsync(cv.data(), res_cnt, res->nnz * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
+        }
+        FGPU_HIP(hipStreamSynchronize(ctx->stream()));
+        u64 keep = 0;
+        for (u64 k = 0; k < res->nnz; ++k) keep += cv[k] != 0;
+        u64* orp = (u64*)ctx->host_alloc((nsrc + 1) * sizeof(u64));
+        u64* od = (u64*)ctx->host_alloc((keep ? keep : 1) * sizeof(u64));
+        u64* oc = (u64*)ctx->host_alloc((keep ? keep : 1) * sizeof(u64));
+        if (!orp || !od || !oc) {
+            ctx->host_free(orp); ctx->host_free(od); ctx->host_free(oc);
+            set_error("fgpu_expand_trail_counts: host allocation failed");
+            return FGPU_OOM;
+        }
+        u64 o = 0;
+        for (u64 r = 0; r < nsrc; ++r) {
+            orp[r] = o;
+            for (u32 k = rp[r]; k < rp[r + 1]; ++k)
+                if (cv[k]) { od[o] = ci[k]; oc[o] = cv[k]; ++o; }
+        }
+        orp[nsrc] = o;
+        *out_rowptr = orp; *out_dest = od; *out_count = oc; *out_nnz = o;
+        return FGPU_OK;
+    };
+    i = run();
+    if (f0) mat_release(f0);
+    if (c1) mat_release(c1);
+    if (c2) mat_release(c2);
+    cleanup();
+    return i;
+}
 
 // Public producers of snapshots: the implementation above, then fgpu_ctx::publish().
 extern "C" {

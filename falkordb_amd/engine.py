@@ -330,6 +330,23 @@ def expand_count(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=No
     return nnz.value, cs.value, flops.value
 
 
+def expand_trail_counts(ctx: Context, src_ids, m, dp=None, dm=None, weighted=False):
+    """fgpu_expand_trail_counts: trails of exactly len(m) (1 or 2) hops per (source row, destination).
+    Returns (rowptr, dest, count)."""
+    src = _u64(src_ids)
+    am = _hop_arrays(m)
+    adp = _hop_arrays(dp) if dp is not None else None
+    adm = _hop_arrays(dm) if dm is not None else None
+    rp, ci, cv = u64p(), u64p(), u64p()
+    nnz = C.c_uint64()
+    check(ctx.lib.fgpu_expand_trail_counts(ctx._h, _p(src), len(src), am, adp, adm, len(m), 1 if weighted else 0,
+                                           C.byref(rp), C.byref(ci), C.byref(cv), C.byref(nnz)))
+    rowptr = ctx._take(rp, len(src) + 1)
+    dest = ctx._take(ci, max(nnz.value, 1))[: nnz.value]
+    count = ctx._take(cv, max(nnz.value, 1))[: nnz.value]
+    return rowptr, dest, count
+
+
 def expand_levels(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
     """fgpu_expand_levels: per-hop (nnz, checksum) of the chain and the DISTINCT union over the hops."""
     src = _u64(src_ids)

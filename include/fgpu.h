@@ -243,6 +243,18 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
                              uint64_t* hop_nnz, uint64_t* hop_checksum, uint64_t* union_nnz,
                              uint64_t* union_checksum, uint64_t* flops);
 
+/* Exact trail counts for variable-length patterns of at most two hops.  The reference's `[*1..k]`
+ * DFS emits one row per TRAIL (edge-unique path, cond_var_len_traverse.rs:196-387); for exactly `nhops` (1 or 2) hops
+ * the number of trails from source i to a destination is a counting product over the effective layers (m \ dm) U dp:
+ * PLUS_PAIR on pattern layers, PLUS_TIMES on UINT64 layers holding per-pair edge multiplicities (`weighted`), less the
+ * length-2 walks that cross one self-loop twice.  Output CSR over the nsrc rows: dest ascending, count > 0.  Longer
+ * trails have no product form (a walk may revisit an edge): use fgpu_expand_levels' reachable sets to prune the DFS. */
+fgpu_info fgpu_expand_trail_counts(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                                   const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                                   const fgpu_mat* const* dm, int nhops, int weighted,
+                                   uint64_t** out_rowptr, uint64_t** out_dest, uint64_t** out_count,
+                                   uint64_t* out_nnz);
+
 /* ---- boolean vxm / BFS (K9) ---------------------------------------------- */
 
 /* w<!mask, replace> = f x A over the boolean (ANY_PAIR) semiring, vectors as

@@ -538,6 +538,30 @@ def expand_row(g: Graph, from_id, to_id, types, from_labels=(), to_labels=(), tr
     return out
 
 
+def trail_counts(edges, src, k):
+    """Trails (edge-unique paths) of exactly k hops from `src`, counted per destination by depth-first enumeration —
+    what CondVarLenTraverseOp's DFS (cond_var_len_traverse.rs:196-387) emits one row each for.  `edges` = list of
+    (edge id, from, to) of the effective graph (multi-edges = several ids on one pair).  Small graphs only."""
+    out_edges = {}
+    for e, a, b in edges:
+        out_edges.setdefault(a, []).append((e, b))
+    counts = {}
+
+    def dfs(v, depth, used):
+        if depth == k:
+            counts[v] = counts.get(v, 0) + 1
+            return
+        for e, w in out_edges.get(v, ()):
+            if e in used:
+                continue
+            used.add(e)
+            dfs(w, depth + 1, used)
+            used.discard(e)
+
+    dfs(src, 0, set())
+    return counts
+
+
 def expand_into_row(g: Graph, src, dst, types, bidirectional=False, emit_relationship=True, used_edges=()):
     """ExpandIntoOp::expand_row (expand_into.rs:121-258), SURVEY Appendix A.5: edge ids connecting the
     two bound endpoints, scanning the type tensors in order, ids ascending per type; without

@@ -199,6 +199,67 @@ def test_expand_levels_per_hop_sets_and_distinct_union(ctx, k, with_delta, with_
             assert mine - {int(src[i])} == reach - {int(src[i])}
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("dirty", [False, True])
+def test_trail_counts_for_one_and_two_hops_match_the_dfs(ctx, weighted, dirty):
+    """fgpu_expand_trail_counts (exact path counts for k <= 2) against the oracle's DFS over trails
+    (cond_var_len_traverse.rs:196-387): a small cyclic graph with self-loops, reciprocal edges, a hub, and — weighted —
+    multi-edges given as per-pair multiplicities; clean and with pending adds / tombstones."""
+    from oracle import model
+    rng = np.random.default_rng(5 + weighted + 2 * dirty)
+    n = 40
+    pairs = {(int(a), int(b)) for a, b in rng.integers(0, n, (260, 2))}
+    pairs |= {(3, 3), (7, 7), (3, 7), (7, 3), (0, 0)} | {(5, int(b)) for b in range(0, n, 2)}
+    mult = {p: (int(rng.integers(1, 4)) if weighted else 1) for p in pairs}
+    base = sorted(pairs)
+    dm_pairs = [base[i] for i in rng.choice(len(base), 25, replace=False)] if dirty else []
+    dp_pairs = [(int(a), int(b)) for a, b in rng.integers(0, n, (30, 2)) if (int(a), int(b)) not in pairs] if dirty else []
+    dp_mult = {p: (int(rng.integers(1, 4)) if weighted else 1) for p in set(dp_pairs)}
+
+    def mat(ps, w):
+        ps = sorted(set(ps))
+        r = np.array([p[0] for p in ps], dtype=U64)
+        c = np.array([p[1] for p in ps], dtype=U64)
+        v = np.array([w[p] for p in ps], dtype=U64) if weighted else None
+        return ctx.mat_from_coo(n, n, r, c, v)
+
+    M = mat(base, mult)
+    DP = mat(dp_pairs, dp_mult) if dp_pairs else None
+    DM = ctx.mat_from_coo(n, n, np.array([p[0] for p in dm_pairs], dtype=U64), np.array([p[1] for p in dm_pairs], dtype=U64)) if dm_pairs else None
+    eff = {p: mult[p] for p in pairs if p not in set(dm_pairs)}
+    eff.update(dp_mult)
+    edges, eid = [], 0
+    for (a, b), w in sorted(eff.items()):
+        for _ in range(w):
+            edges.append((eid, a, b))
+            eid += 1
+    src = np.array([3, 7, 0, 5, 11, 39, 3], dtype=U64)
+    for k in (1, 2):
+        rowptr, dest, count = engine.expand_trail_counts(ctx, src, [M] * k, [DP] * k if dirty else None,
+                                                         [DM] * k if dirty else None, weighted=weighted)
+        for i, s_ in enumerate(src.tolist()):
+            want = model.trail_counts(edges, s_, k)
+            got = dict(zip(dest[rowptr[i]:rowptr[i + 1]].tolist(), count[rowptr[i]:rowptr[i + 1]].tolist()))
+            assert got == want, (k, s_)
+            assert list(dest[rowptr[i]:rowptr[i + 1]]) == sorted(want)       # ascending destinations
+    with pytest.raises(Exception):
+        engine.expand_trail_counts(ctx, src, [M] * 3)                       # no product form beyond two hops
+
+
+def test_trail_counts_on_rmat_agree_with_the_products(ctx):
+    """On a graph without self-loops the 2-hop trail count of (row, dest) is the number of intermediates: the sum of the
+    counts is the traversed-edge count of the second hop and the support is the 2-hop reachable set."""
+    a = oracle.rmat_csr(12)
+    A = up(ctx, a)
+    src = np.random.default_rng(8).choice(a.nrows, 300, replace=False).astype(U64)
+    rowptr, dest, count = engine.expand_trail_counts(ctx, src, [A, A])
+    f = f_matrix(len(src), a.nrows, src)
+    c1, _ = oracle.mxm(f, a)
+    c2, fl2 = oracle.mxm(c1, a)
+    assert np.array_equal(rowptr, c2.rowptr) and np.array_equal(dest, c2.colidx)
+    assert int(count.sum()) == fl2 and int(count.min()) >= 1
+
+
 def test_expand_rmat22_three_hops_both_forms_agree(ctx):
     """Full-size graph (BASELINE.json configs[1]/[2] shape): 512 sources, 3 hops — the sorted-CSR chain
     and the bit-parallel chain must give the same result size, order-independent checksum and flops."""
