@@ -509,9 +509,9 @@ class Tensor:
 
     def __del__(self):
         try:
-            if self.h:
+            if self.h and self.ctx.h:      # a tensor that outlives its context has nothing left to free
                 self.L.fh_tn_free(self.h)
-                self.h = C.c_void_p()
+            self.h = C.c_void_p()
         except Exception:
             pass
 
@@ -551,6 +551,20 @@ class Tensor:
     def eff_get(self, src, dst): return self._probe(0, src, dst)
     def m_get(self, src, dst): return self._probe(1, src, dst)
     def extract_contains(self, src, dst): return self._probe(2, src, dst) is not None
+
+    def encode(self) -> bytes:
+        b, n = C.POINTER(C.c_uint8)(), C.c_uint64()
+        _ck(self.L.fh_tn_encode(self.h, C.byref(b), C.byref(n)))
+        out = bytes(C.cast(b, C.POINTER(C.c_uint8 * max(n.value, 1))).contents)[:n.value]
+        self.L.fh_free(b)
+        return out
+
+    @staticmethod
+    def decode(ctx, payload: bytes):
+        buf = (C.c_uint8 * len(payload)).from_buffer_copy(payload)
+        h, used = C.c_void_p(), C.c_uint64()
+        _ck(ctx.L.fh_tn_decode(ctx.h, buf, C.c_uint64(len(payload)), C.byref(h), C.byref(used)))
+        return Tensor(ctx, _h=h), used.value
 
     def state(self):
         out = (C.c_uint64 * 8)()

@@ -380,6 +380,29 @@ int fh_tn_state(fh_tn* t, uint64_t out[8]) {
     });
 }
 
+int fh_tn_encode(fh_tn* t, uint8_t** bytes, uint64_t* len) {
+    return guard([&] {
+        ByteWriter w;
+        t->t.encode(w);
+        uint8_t* out = (uint8_t*)malloc(w.buf.size() ? w.buf.size() : 1);
+        if (!out) throw GrbError(FGPU_OOM, "out of host memory");
+        memcpy(out, w.buf.data(), w.buf.size());
+        *bytes = out;
+        *len = w.buf.size();
+        return 0;
+    });
+}
+int fh_tn_decode(fh_ctx* ctx, const uint8_t* bytes, uint64_t len, fh_tn** out, uint64_t* consumed) {
+    return guard([&] {
+        ByteReader r(bytes, len);
+        Tensor t = Tensor::decode(ctx->c, r);
+        t.rebuild_backward();                              // what the reference's caller does after decode (:1193-1195)
+        *out = new fh_tn{std::move(t)};
+        *consumed = r.pos;
+        return 0;
+    });
+}
+
 int fh_graph_layer_iter(fh_graph* g, int64_t type_id, int which, uint64_t** rows, uint64_t** cols, uint64_t** vals,
                         uint64_t* n) {
     return guard([&] {

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include <array>
+#include <functional>
 #include <map>
 #include <set>
 #include <memory>
@@ -286,6 +287,20 @@ class Tensor {
     std::vector<Entry> structural_iter(u64 min_row, u64 max_row) const;    // :909-921
     std::vector<Entry> iter_edges() const;                                 // :973-989 (src, dst, edge id)
     u64 edge_count() const;                                                // :955-967
+    // Encode<19> / Decode<19> for Tensor (tensor.rs:1053-1209): three container payloads (effective forward matrix —
+    // single-edge pairs store the id, multi-edge pairs `count | 1 << 63` — then empty dp and dm), the edge count, and
+    // the tensor section: two groups (base, delta-plus) of (src, dst, id-list blob).  The blob is what C FalkorDB
+    // writes with GxB_Vector_serialize — GraphBLAS' own serialisation of a BOOL vector whose INDICES are the edge ids;
+    // it can only be produced / parsed by GraphBLAS itself, so it goes through `BlobCodec` (see serialize.cpp).  The
+    // backward matrix is rebuilt after decode (rebuild_backward, as the reference's caller does).
+    struct BlobCodec {
+        std::function<std::vector<uint8_t>(const std::vector<u64>& ids)> encode;
+        std::function<std::vector<u64>(const std::vector<uint8_t>& blob)> decode;
+    };
+    static const BlobCodec& plain_blob_codec();
+    void encode(ByteWriter& w, const BlobCodec& codec = plain_blob_codec()) const;
+    static Tensor decode(Context& ctx, ByteReader& r, const BlobCodec& codec = plain_blob_codec());
+    void rebuild_backward();
     u64 multi_pairs() const { return me_.size(); }
     u64 me_nvals() const { u64 n = 0; for (auto& kv : me_) n += kv.second.size(); return n; }   // `me.nvals()` of the tests
     void wait() const { wait_fwd(); mt_.wait(); }                           // Tensor::wait: every layer materialised

@@ -9,7 +9,9 @@
 // (Reader / Writer traits); here: unsigned and signed = 8 bytes little-endian, buffer = unsigned length + bytes.
 // Tensor's multi-edge section (tensor.rs:1100-1128) uses GxB_Vector_serialize blobs — GraphBLAS' own compressed
 // format — and is not decoded here.
+#include <algorithm>
 #include <cstring>
+#include <map>
 
 #include "host.hpp"
 
@@ -239,6 +241,140 @@ void Matrix::encode(ByteWriter& w) const {
     fgpu_free(raw, ci);
     if (vals) fgpu_free(raw, vals);
     write_container(w, c);
+}
+
+// ---- Tensor (tensor.rs:1053-1209) ------------------------------------------------------------------------------
+namespace {
+constexpr u64 MSB_MASK = 1ull << 63;            // tensor.rs:1049-1051: multi-edge marker of the on-disk forward matrix
+constexpr char PLAIN_MAGIC[8] = {'F', 'G', 'I', 'D', 'L', 'S', 'T', '1'};
+}  // namespace
+
+// The id list of a multi-edge pair.  C FalkorDB and the reference write it with GxB_Vector_serialize
+// (vector.rs:150-174): GraphBLAS' internal, optionally ZSTD/LZ4-compressed blob of a GrB_BOOL vector of length
+// GrB_INDEX_MAX with one `true` per edge id.  That format belongs to the un-vendored SuiteSparse:GraphBLAS v10.5.0 and
+// no fixture of it exists in the reference tree, so it is NOT restated here: a process that embeds this layer next to
+// GraphBLAS (the reference does) passes a codec built on GxB_Vector_serialize / _deserialize; the default codec
+// writes a plain little-endian list (magic, count, ids) for this repository's own round trips and refuses anything
+// else with an explicit error instead of guessing.  PARITY UNPINNED for the blob, pinned for the framing around it.
+const Tensor::BlobCodec& Tensor::plain_blob_codec() {
+    static const BlobCodec codec{
+        [](const std::vector<u64>& ids) {
+            std::vector<uint8_t> b(sizeof(PLAIN_MAGIC) + 8 + ids.size() * 8);
+            memcpy(b.data(), PLAIN_MAGIC, sizeof(PLAIN_MAGIC));
+            const u64 n = ids.size();
+            memcpy(b.data() + 8, &n, 8);
+            if (n) memcpy(b.data() + 16, ids.data(), n * 8);
+            return b;
+        },
+        [](const std::vector<uint8_t>& b) {
+            if (b.size() < 16 || memcmp(b.data(), PLAIN_MAGIC, sizeof(PLAIN_MAGIC)) != 0)
+                throw GrbError(FGPU_INVALID,
+                               "Tensor decode: the id-list blob is not in this library's plain form — a GxB_Vector_serialize blob "
+                               "must be decoded by GraphBLAS (pass a BlobCodec built on GxB_Vector_deserialize)");
+            u64 n = 0;
+            memcpy(&n, b.data() + 8, 8);
+            if ((b.size() - 16) / 8 < n) throw GrbError(FGPU_INVALID, "Tensor decode: truncated id list");
+            std::vector<u64> ids(n);
+            if (n) memcpy(ids.data(), b.data() + 16, n * 8);
+            for (u64 k = 1; k < n; ++k)
+                if (ids[k] <= ids[k - 1]) throw GrbError(FGPU_INVALID, "Tensor decode: id list not ascending");
+            return ids;
+        }};
+    return codec;
+}
+
+void Tensor::encode(ByteWriter& w, const BlobCodec& codec) const {
+    // the effective inline state, C-compatible (:1063-1081)
+    std::vector<u64> rows, cols, vals;
+    std::vector<std::pair<std::pair<u64, u64>, const std::vector<u64>*>> multi;
+    wait_fwd();
+    for (auto& e : merge_layers(m_.iter(0, ~0ull), dp_.layer().iter(0, ~0ull), dm_.layer().iter(0, ~0ull))) {
+        rows.push_back(e.row);
+        cols.push_back(e.col);
+        if (e.val == MULTI_EDGE) {
+            auto it = me_.find(compound_key(e.row, e.col));
+            static const std::vector<u64> none;
+            const std::vector<u64>& ids = it == me_.end() ? none : it->second;
+            vals.push_back((u64)ids.size() | MSB_MASK);
+            multi.push_back({{e.row, e.col}, &ids});
+        } else {
+            vals.push_back(e.val);
+        }
+    }
+    Context& ctx = m_.ctx();
+    Matrix empty(ctx, Type::UInt64, nrows(), ncols());
+    if (rows.empty()) {
+        empty.encode(w);
+    } else {
+        Matrix fm(ctx, Type::UInt64, nrows(), ncols());
+        fm.build(rows, cols, &vals);
+        fm.encode(w);
+    }
+    empty.encode(w);                                      // delta-plus (:1093)
+    Matrix(ctx, Type::Bool, nrows(), ncols()).encode(w);  // delta-minus (decoded as Matrix<bool>, :1134)
+    const u64 total = edge_count();
+    w.write_unsigned(total);
+    if (total == 0) return;
+    w.write_unsigned(multi.size());                       // base group (:1106-1124)
+    for (auto& mp : multi) {
+        w.write_unsigned(mp.first.first);
+        w.write_unsigned(mp.first.second);
+        std::vector<uint8_t> blob = codec.encode(*mp.second);
+        w.write_buffer(blob.data(), blob.size());
+    }
+    w.write_unsigned(0);                                  // empty delta-plus group (:1125)
+}
+
+Tensor Tensor::decode(Context& ctx, ByteReader& r, const BlobCodec& codec) {
+    Matrix fwd_m = Matrix::decode(ctx, r);
+    Matrix fwd_dp = Matrix::decode(ctx, r);
+    Matrix fwd_dm = Matrix::decode(ctx, r);
+    if (fwd_m.type() != Type::UInt64) throw GrbError(FGPU_INVALID, "Tensor decode: the forward matrix is not UINT64");
+    const u64 nr = fwd_m.nrows(), nc = fwd_m.ncols();
+    // (fwd_m \ fwd_dm) U fwd_dp, MSB-flagged values -> the MULTI_EDGE sentinel (:1141-1166)
+    std::vector<u64> rows, cols, vals;
+    const bool dm_empty = fwd_dm.nvals() == 0;
+    std::map<std::pair<u64, u64>, u64> inl;
+    for (auto& e : fwd_m.iter(0, ~0ull)) {
+        if (!dm_empty && fwd_dm.contains(e.row, e.col)) continue;
+        inl[{e.row, e.col}] = (e.val & MSB_MASK) ? MULTI_EDGE : e.val;
+    }
+    if (fwd_dp.nvals())
+        for (auto& e : fwd_dp.iter(0, ~0ull)) inl[{e.row, e.col}] = (e.val & MSB_MASK) ? MULTI_EDGE : e.val;
+    for (auto& kv : inl) { rows.push_back(kv.first.first); cols.push_back(kv.first.second); vals.push_back(kv.second); }
+    Tensor t(ctx, nr, nc);
+    if (!rows.empty()) t.m_.build(rows, cols, &vals);
+    const u64 total = r.read_unsigned();
+    if (total > 0) {
+        for (int group = 0; group < 2; ++group) {           // base, then delta-plus (:1170-1187)
+            const u64 count = r.read_unsigned();
+            for (u64 k = 0; k < count; ++k) {
+                const u64 src = r.read_unsigned(), dst = r.read_unsigned();
+                std::vector<uint8_t> blob = r.read_buffer();
+                std::vector<u64> ids = codec.decode(blob);
+                auto& row = t.me_[compound_key(src, dst)];
+                row.insert(row.end(), ids.begin(), ids.end());
+                std::sort(row.begin(), row.end());
+                row.erase(std::unique(row.begin(), row.end()), row.end());
+            }
+        }
+    }
+    t.m_.wait();                                             // the committed base is never pending (:1190-1192)
+    for (auto& kv : inl)
+        if (kv.second == MULTI_EDGE && !t.me_.count(compound_key(kv.first.first, kv.first.second)))
+            throw GrbError(FGPU_INVALID, "Tensor decode: a multi-edge pair has no id list in the tensor section");
+    return t;
+}
+
+void Tensor::rebuild_backward() {
+    std::vector<u64> r, c;
+    for (auto& e : structural_iter(0, ~0ull)) { r.push_back(e.col); c.push_back(e.row); }
+    mt_ = VersionedMatrix(m_.ctx(), ncols(), nrows());
+    if (!r.empty()) {
+        Matrix b(m_.ctx(), Type::Bool, ncols(), nrows());
+        b.build(r, c);
+        mt_ = VersionedMatrix::from_matrix(b);
+    }
 }
 
 }  // namespace falkor

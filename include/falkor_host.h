@@ -122,6 +122,11 @@ int fh_tn_op(fh_tn* t, int op, uint64_t a, uint64_t b);
 int fh_tn_get(fh_tn* t, uint64_t src, uint64_t dst, uint64_t** ids, uint64_t* n);
 int fh_tn_probe(fh_tn* t, int which, uint64_t src, uint64_t dst, uint64_t* val);
 int fh_tn_state(fh_tn* t, uint64_t out[8]);
+/* Encode<19> / Decode<19> for Tensor (tensor.rs:1053-1209): forward matrix (multi-edge pairs as count | 1 << 63), empty
+ * dp / dm, edge count, tensor section (base group, delta-plus group) of (src, dst, id-list blob).  The blob of the
+ * default codec is this library's plain list; a GxB_Vector_serialize blob needs GraphBLAS (see serialize.cpp). */
+int fh_tn_encode(fh_tn* t, uint8_t** bytes, uint64_t* len);
+int fh_tn_decode(fh_ctx* ctx, const uint8_t* bytes, uint64_t len, fh_tn** out, uint64_t* consumed);
 
 /* Raw layer dump for tests: type_id < 0 = the adjacency matrix; which 0 = m, 1 = dp, 2 = dm. */
 int fh_graph_layer_iter(fh_graph* g, int64_t type_id, int which, uint64_t** rows, uint64_t** cols,

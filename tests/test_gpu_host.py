@@ -458,6 +458,61 @@ def test_tensor_rust_unit_pins(hctx):
     assert t.get(0, 1) == [1]                                                # "committed edge lost"
 
 
+def test_tensor_v19_payload_with_multi_edges(hctx):
+    """Encode<19> / Decode<19> for Tensor (tensor.rs:1053-1209): a tensor with single edges, multi-edge pairs (committed
+    and pending), a deleted pair and edge id 0 survives encode -> decode; the payload's framing is checked field by field
+    against the layout the reference writes; a foreign (GraphBLAS-serialised) id-list blob is refused, not guessed at."""
+    from test_host_cpu import _frame_u
+    n = 300
+    t = host.Tensor(hctx, n, n)
+    s = np.arange(100)
+    t.set_all_from_slices(s, s + 1, s)                       # ids 0..99, one per pair (edge id 0 included)
+    t.set_all_from_slices([5, 5, 9], [6, 6, 10], [500, 501, 502])   # (5,6) -> 3 edges, (9,10) -> 2 edges
+    t.fold_oversized()
+    t = t.dup()
+    t.set_all_from_slices([200, 200], [201, 201], [900, 901])       # a pending multi pair
+    t.remove_all([(42, 42, 43)])                                     # a tombstone
+    payload = t.encode()
+    back, used = host.Tensor.decode(hctx, payload)
+    assert used == len(payload)
+    st, sb = t.state(), back.state()
+    assert sb["edge_count"] == st["edge_count"] == 100 - 1 + 3 + 2
+    assert sb["multi_pairs"] == st["multi_pairs"] == 3 and sb["me_nvals"] == st["me_nvals"] == 3 + 2 + 2
+    assert (sb["dp"], sb["dm"]) == (0, 0)                            # deltas are folded into the on-disk base (:1083-1094)
+    assert sb["mt"] == st["mt"]                                      # backward matrix rebuilt
+    for (a, b) in [(0, 1), (5, 6), (9, 10), (200, 201), (42, 43), (7, 8)]:
+        assert back.get(a, b) == t.get(a, b)
+    assert back.get(0, 1) == [0] and back.get(5, 6) == [5, 500, 501] and back.get(42, 43) == []
+    assert back.eff_get(5, 6) == host.Tensor.MULTI_EDGE
+    assert back.encode() == payload                                  # canonical
+    # framing: three containers, then total, base count, (src, dst, blob)*, 0
+    d = host.container_parse(payload)
+    assert d["valued"] and d["nvals"] == 100 - 1 + 1 and (d["nrows"], d["ncols"]) == (n, n)   # pairs: one deleted, one new
+    msb = 1 << 63
+    multi_vals = sorted(int(x) & ~msb for x in d["x"] if int(x) & msb)
+    assert multi_vals == [2, 2, 3]                                   # count | MSB for the three multi pairs
+    off = d["consumed"]
+    d2 = host.container_parse(payload[off:]); off += d2["consumed"]
+    d3 = host.container_parse(payload[off:]); off += d3["consumed"]
+    assert d2["nvals"] == 0 and d3["nvals"] == 0 and not d3["valued"]
+    rd = lambda o: int.from_bytes(payload[o:o + 8], "little")
+    assert rd(off) == sb["edge_count"] and rd(off + 8) == 3          # total edges, multi pairs in the base group
+    assert (rd(off + 16), rd(off + 24)) == (5, 6)                    # first pair in (row, col) order
+    assert payload[-8:] == _frame_u(0)                               # empty delta-plus group
+    # an empty tensor: three empty containers and a zero count, nothing else
+    e = host.Tensor(hctx, 10, 10)
+    pe = e.encode()
+    be, used = host.Tensor.decode(hctx, pe)
+    assert used == len(pe) and be.state()["edge_count"] == 0 and pe[-8:] == _frame_u(0)
+    # a blob that is not this library's plain list (what GxB_Vector_serialize writes starts with its own size)
+    blob_at = off + 32
+    blob_len = rd(blob_at)
+    foreign = payload[:blob_at + 8] + blob_len.to_bytes(8, "little") + payload[blob_at + 16:]
+    with pytest.raises(host.HostError) as ei:
+        host.Tensor.decode(hctx, foreign)
+    assert "GxB_Vector" in str(ei.value)
+
+
 def test_bulk_delete_folds_tombstones_at_commit(hctx):     # tensor.rs:1590-1669 (delete-all folds tombstones)
     n = 2000
     g = host.Graph(hctx, n)
