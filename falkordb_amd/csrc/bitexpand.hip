@@ -115,23 +115,43 @@ __global__ void bp_flag_count_kernel(const uint8_t* __restrict__ flag, u32 n, un
     if (lane_id() == 0 && c) atomicAdd(out, (unsigned long long)c);
 }
 
-// nnz and the order-independent checksum of the result (sum of mix64((row << 32) | dest)) straight from the
-// bit state — fgpu_expand_count needs no CSR.  One lane per (vertex, word).
-template <bool WITH_SUM>   // the checksum hashes every set bit (VALU-bound: ~35 instructions per result entry)
+// nnz and the order-independent checksum of the result (sum of row_hash(row) * dest_hash(dest), common.hpp) straight
+// from the bit state — fgpu_expand_count needs no CSR.  One lane per (vertex, word).
+// tab[k][j][x] = sum of row_hash(64 k + 4 j + b) over the set bits b of the nibble x: 16 look-ups per word replace a
+// loop over its set bits (divergent: a wavefront ran as long as its fullest word) with two 64-bit multiplies each.
+__global__ void bp_cs_table_kernel(u32 w, u64* __restrict__ tab) {
+    const u32 t = blockIdx.x * 256 + threadIdx.x;     // (k, j, x)
+    if (t >= w * 256) return;
+    const u32 k = t >> 8, j = (t >> 4) & 15, x = t & 15;
+    u64 s = 0;
+    for (u32 b = 0; b < 4; ++b)
+        if ((x >> b) & 1u) s += cs_row_hash((u64)k * 64 + 4 * j + b);
+    tab[t] = s;
+}
+
+template <bool WITH_SUM>
 __global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws,
-                                                      const u64* __restrict__ label,
+                                                      const u64* __restrict__ label, const u64* __restrict__ tab,
                                                       unsigned long long* __restrict__ acc) {
+    extern __shared__ u64 s_tab[];                    // w x 16 x 16 sums (2 KiB per word index)
+    if (WITH_SUM) {
+        for (u32 i = threadIdx.x; i < w * 256; i += 256) s_tab[i] = tab[i];
+        __syncthreads();
+    }
     u64 cnt = 0, sum = 0;
     const u64 total = (u64)n * w;
     for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < total; t += (u64)gridDim.x * 256) {
         const u32 v = (u32)(t / w), k = (u32)(t % w);
         if (label && !((label[v >> 6] >> (v & 63)) & 1ull)) continue;
-        u64 bits = y[(size_t)v * ws + k];
+        const u64 bits = y[(size_t)v * ws + k];
+        if (bits == 0ull) continue;
         cnt += (u64)__popcll(bits);
-        while (WITH_SUM && bits) {
-            const u32 b = (u32)__builtin_ctzll(bits);
-            bits &= bits - 1;
-            sum += mix64(((u64)(k * 64 + b) << 32) | v);
+        if (WITH_SUM) {
+            const u64* tk = s_tab + (size_t)k * 256;
+            u64 rs = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rs += tk[j * 16 + (u32)((bits >> (4 * j)) & 15ull)];
+            sum += rs * cs_dest_hash(v);
         }
     }
 #pragma unroll
@@ -154,9 +174,24 @@ __global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y
 // a few 10^4 non-zero rows among 10^7 vertices).  A byte flag per vertex ("X[u] has a bit set", written by
 // whoever wrote X) is probed first — 64 neighbours per wavefront step, one byte each — and only flagged
 // neighbours pay the 8 W-byte row gather.  Every variant writes the flags of Y for the next hop.
+// flag bytes -> flag bits: the sparse pull probes one flag per matrix entry, and a 1-bit-per-vertex map (2 MiB at
+// scale 24) stays in every XCD's L2 where the byte map (16 MiB) does not — measured: the byte probes alone made the
+// sparse hop fetch 25 GB through the fabric (profiles/r02d_kernel_counters.json: 198 M fabric reads per launch)
+__global__ __launch_bounds__(256) void bp_flag_bits_kernel(const uint8_t* __restrict__ flag, u32 n, u64* __restrict__ bits) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwords = (n + 63) >> 6;
+    for (u32 w = wave; w < nwords; w += nwaves) {
+        const u32 v = (w << 6) + lane;
+        const u64 m = __ballot(v < n && flag[v] != 0);
+        if (lane == 0) bits[w] = m;
+    }
+}
+
 template <int LN, bool SPARSE>
 __global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __restrict__ items, u32 nitems, u32 ws,
-                                                     const u64* __restrict__ x, const uint8_t* __restrict__ xflag,
+                                                     const u64* __restrict__ x, const u64* __restrict__ xbits,
                                                      u64* __restrict__ y, uint8_t* __restrict__ yflag) {
     constexpr int SLOTS = 64 / LN;
     const u32 lane = lane_id();
@@ -177,7 +212,7 @@ __global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __r
                 for (u32 q0 = b; q0 < e; q0 += 64) {
                     const u32 q = q0 + lane;
                     const u32 un = (q < e) ? at.colidx[q] : 0u;
-                    u64 live = __ballot((q < e) && xflag[un] != 0);
+                    u64 live = __ballot((q < e) && ((xbits[un >> 6] >> (un & 63)) & 1ull));
                     while (live) {   // wave-uniform: SLOTS flagged neighbours per trip
                         u32 src = 0;
                         bool on = false;
@@ -254,6 +289,7 @@ __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w
 
 // traversed-edge count of a hop: sum_v popcount(X[v]) * deg(v)
 __global__ __launch_bounds__(256) void bp_flops_kernel(CsrView a, u32 w, u32 ws, const u64* __restrict__ x,
+                                                      const uint8_t* __restrict__ xflag,
                                                       unsigned long long* __restrict__ out) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -265,6 +301,7 @@ __global__ __launch_bounds__(256) void bp_flops_kernel(CsrView a, u32 w, u32 ws,
         const u32 deg = a.rowptr[r + 1] - a.rowptr[r];
         if (deg == 0) continue;
         const u32 v = a.hrows ? a.hrows[r] : r;
+        if (xflag && !xflag[v]) continue;   // a byte instead of the 8 W-byte row: most rows of a sparse state are empty
         u32 pc = 0;
         for (u32 k = 0; k < w; ++k) pc += (u32)__popcll(x[(size_t)v * ws + k]);
         sum += (u64)pc * deg;
@@ -420,20 +457,31 @@ fgpu_info bp_accumulate(fgpu_ctx* ctx, BitState& u, const BitState& x) {
 }
 
 fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum) {
-    DevBuf<u64> acc;
+    DevBuf<u64> acc, tab;
     FGPU_TRY(acc.alloc(ctx, 2));
     FGPU_HIP(hipMemsetAsync(acc.p, 0, 2 * sizeof(u64), ctx->stream()));
     const u64 total = (u64)s.n * s.w;
     if (total) {
+        // the look-up tables live in LDS: 2 KiB per word of the row, i.e. batches of up to 4096 source rows per pass
+        const size_t lds = checksum ? (size_t)s.w * 256 * sizeof(u64) : 0;
+        FGPU_REQUIRE(lds <= (size_t)ctx->opt.lds_limit, FGPU_INVALID,
+                     "expand checksum: %u source rows need %zu B of LDS tables (limit %d); batch the sources", s.nsrc, lds,
+                     ctx->opt.lds_limit);
         ProfScope ps(ctx, checksum ? "bp_count_kernel<checksum>" : "bp_count_kernel<count>", total * sizeof(u64));
         u32 grid = cdiv(total, 256);
-        if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-        if (checksum)
-            hipLaunchKernelGGL(bp_count_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n,
-                               s.w, s.ws, label_dev, (unsigned long long*)acc.p);
-        else
+        const u32 cap = checksum ? (u32)ctx->cus * 8 : (u32)ctx->cus * 32;   // every workgroup copies the tables once
+        if (grid > cap) grid = cap;
+        if (checksum) {
+            FGPU_TRY(tab.alloc(ctx, (size_t)s.w * 256));
+            hipLaunchKernelGGL(bp_cs_table_kernel, dim3(s.w), dim3(256), 0, ctx->stream(), s.w, tab.p);
+            if (lds > 48 * 1024)
+                FGPU_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(bp_count_kernel<true>, dim3(grid), dim3(256), lds, ctx->stream(), (const u64*)s.x.p, s.n,
+                               s.w, s.ws, label_dev, (const u64*)tab.p, (unsigned long long*)acc.p);
+        } else {
             hipLaunchKernelGGL(bp_count_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n,
-                               s.w, s.ws, label_dev, (unsigned long long*)acc.p);
+                               s.w, s.ws, label_dev, (const u64*)nullptr, (unsigned long long*)acc.p);
+        }
         FGPU_HIP(hipGetLastError());
     }
     FGPU_TRY(read_u64(ctx, acc.p, nnz));
@@ -446,11 +494,11 @@ static fgpu_info bp_flops(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* a, u
     DevBuf<u64> acc;
     FGPU_TRY(acc.alloc(ctx, 1));
     FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream()));
-    ProfScope ps(ctx, "bp_flops_kernel", 4 * ((u64)a->nvec + 1) + (u64)s.n * s.w * 8);
+    ProfScope ps(ctx, "bp_flops_kernel", 4 * ((u64)a->nvec + 1) + (u64)s.n + (s.nz_rows < s.n ? s.nz_rows : (u64)s.n) * s.w * 8);
     u32 grid = cdiv(a->nvec ? a->nvec : 1, 256);
     if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
     hipLaunchKernelGGL(bp_flops_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(a), s.w, s.ws,
-                       (const u64*)s.x.p, (unsigned long long*)acc.p);
+                       (const u64*)s.x.p, (const uint8_t*)s.flag.p, (unsigned long long*)acc.p);
     FGPU_HIP(hipGetLastError());
     u64 v = 0;
     FGPU_TRY(read_u64(ctx, acc.p, &v));
@@ -481,6 +529,13 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
         const u32 ln = s.ws < 64 ? s.ws : 64;
         // fewer than 1 row in 8 flagged: probing a byte per neighbour first beats gathering 8 W-byte rows
         const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n;
+        DevBuf<u64> xbits;
+        if (sparse) {
+            FGPU_TRY(xbits.alloc(ctx, ((size_t)s.n + 63) / 64 + 1));
+            hipLaunchKernelGGL(bp_flag_bits_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), (const uint8_t*)s.flag.p,
+                               s.n, xbits.p);
+            FGPU_HIP(hipGetLastError());
+        }
         // algorithmic bytes of the launch: the column ids of A' and the item list once, every non-zero X row once
         // (the per-entry row gathers beyond that are cache traffic), a flag byte per vertex in the sparse form;
         // the non-zero Y rows written are added once they are counted (bp_count_flags below)
@@ -492,11 +547,11 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
     do {                                                                                                                \
         if (sparse)                                                                                                     \
             hipLaunchKernelGGL((bp_pull_kernel<LN, true>), dim3(grid), dim3(256), 0, ctx->stream(), view_of(t),         \
-                               (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const uint8_t*)s.flag.p,     \
+                               (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const u64*)xbits.p,          \
                                o.x.p, o.flag.p);                                                                        \
         else                                                                                                            \
             hipLaunchKernelGGL((bp_pull_kernel<LN, false>), dim3(grid), dim3(256), 0, ctx->stream(), view_of(t),        \
-                               (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const uint8_t*)s.flag.p,     \
+                               (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const u64*)nullptr,          \
                                o.x.p, o.flag.p);                                                                        \
     } while (0)
         switch (ln) {

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void checksum_kernel(CsrView c, u32 nrows, uns
     u64 sum = 0;
     for (u32 r = wave; r < nrows; r += nwaves) {
         const u32 rb = c.rowptr[r], re = c.rowptr[r + 1];
-        for (u32 i = rb + lane; i < re; i += 64) sum += mix64(((u64)r << 32) | c.colidx[i]);
+        const u64 hr = cs_row_hash(r);
+        for (u32 i = rb + lane; i < re; i += 64) sum += hr * cs_dest_hash(c.colidx[i]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void checksum_entries_kernel(CsrView c, u32 nr
             u32 mid = (lo + hi + 1) >> 1;
             if (c.rowptr[mid] <= q) lo = mid; else hi = mid - 1;
         }
-        sum += mix64(((u64)lo << 32) | c.colidx[q]);
+        sum += cs_row_hash(lo) * cs_dest_hash(c.colidx[q]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);

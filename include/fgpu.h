@@ -220,8 +220,9 @@ fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
 
 /* Same as fgpu_expand but the result stays on device and only its size and an
  * order-independent checksum come back (full-size configs whose output would not
- * fit a host buffer): checksum = sum over entries of
- * mix64((row << 32) | dest) mod 2^64. */
+ * fit a host buffer): checksum = sum over the (row, dest) entries of
+ * mix64(row) * (mix64(dest ^ 0x9e3779b97f4a7c15) | 1) mod 2^64, mix64 = the splitmix64 finaliser (a product of a row
+ * hash and a destination hash: the bit-parallel state sums it per vertex through look-up tables instead of per entry). */
 fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
                             const fgpu_mat* const* m, const fgpu_mat* const* dp,
                             const fgpu_mat* const* dm, int nhops,

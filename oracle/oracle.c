@@ -180,9 +180,13 @@ static u64 mix64(u64 z) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return z ^ (z >> 31);
 }
+/* order-independent checksum of a (row, dest) result: sum of row_hash(row) * dest_hash(dest) mod 2^64 with
+ * row_hash = mix64, dest_hash = mix64(dest ^ golden) | 1 — the definition include/fgpu.h gives for fgpu_expand_count */
 u64 orc_checksum(u64 nrows, const u64* rp, const u64* ci) {
     u64 s = 0;
-    for (u64 r = 0; r < nrows; ++r)
-        for (u64 k = rp[r]; k < rp[r + 1]; ++k) s += mix64((r << 32) | ci[k]);
+    for (u64 r = 0; r < nrows; ++r) {
+        const u64 hr = mix64(r);
+        for (u64 k = rp[r]; k < rp[r + 1]; ++k) s += hr * (mix64(ci[k] ^ 0x9e3779b97f4a7c15ull) | 1ull);
+    }
     return s;
 }

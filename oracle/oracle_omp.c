@@ -236,7 +236,7 @@ u64 orc_merge_omp(u64 nrows, const u64* arp, const u64* aci, const u64* prp, con
     return orp[nrows];
 }
 
-/* order-independent checksum of a CSR result: sum of mix64((row << 32) | col) mod 2^64 (fgpu_expand_count's) */
+/* order-independent checksum of a CSR result: sum of mix64(row) * (mix64(col ^ golden) | 1) mod 2^64 (fgpu_expand_count's) */
 static inline u64 mix64_omp(u64 z) {
     z += 0x9e3779b97f4a7c15ull;
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
@@ -247,7 +247,9 @@ u64 orc_checksum_omp(u64 nrows, const u64* rp, const u64* ci, int threads) {
     if (threads > 0) omp_set_num_threads(threads);
     u64 sum = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : sum)
-    for (u64 r = 0; r < nrows; ++r)
-        for (u64 k = rp[r]; k < rp[r + 1]; ++k) sum += mix64_omp((r << 32) | ci[k]);
+    for (u64 r = 0; r < nrows; ++r) {
+        const u64 hr = mix64_omp(r);
+        for (u64 k = rp[r]; k < rp[r + 1]; ++k) sum += hr * (mix64_omp(ci[k] ^ 0x9e3779b97f4a7c15ull) | 1ull);
+    }
     return sum;
 }
