@@ -2396,6 +2396,15 @@ fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t
     FGPU_REQUIRE(A->nrows == A->ncols, FGPU_DIM_MISMATCH, "fgpu_vxm: square matrices only");
     FGPU_REQUIRE(!A->is_hyper() && (!At || !At->is_hyper()), FGPU_INVALID, "fgpu_vxm: non-hypersparse snapshots only");
     FGPU_REQUIRE(direction >= 0 && direction <= 3 && (direction < 2 || At), FGPU_INVALID, "fgpu_vxm: bad direction");
+    if (direction == 0) {
+        // auto: a sparse frontier is pushed over A (work ~ its out-edges, one atomic per discovery); once 1 / 32 of the
+        // vertices are in it a whole pass over A' costs less than those atomics, and the pass that streams A' at
+        // bandwidth is the LDS-tiled one (tiled.hip; the layout is built on the snapshot's first dense call)
+        u64 nf = 0;
+        const u64 words = (A->nrows + 63) / 64;
+        for (u64 k = 0; k < words; ++k) nf += (u64)__builtin_popcountll(f[k]);
+        direction = (At && At->nnz >= 4096 && nf * 32 >= A->nrows) ? 3 : 1;
+    }
     if (direction == 3) FGPU_TRY(tiles_build(ctx, At, 0, 0, 0, false));
     FGPU_TRY(mat_ensure_finalized(A));
     if (At) FGPU_TRY(mat_ensure_finalized(At));

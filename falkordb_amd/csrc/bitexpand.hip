@@ -21,7 +21,8 @@
 
 namespace fgpu {
 
-constexpr u32 BP_ITEM = 256;    // entries of A' per work item
+constexpr u32 BP_ITEM = 256;    // entries of A' per work item (the sparse pull walks an item as 4 trips of 64)
+static_assert(BP_ITEM == 256, "bp_pull_kernel<.., SPARSE> unrolls an item into four 64-entry trips");
 constexpr u32 BP_VCHUNK = 4096; // vertices per emission chunk (64 blocks of 64)
 
 // ---------------------------------------------------------------------------------
@@ -31,6 +32,19 @@ __global__ void bp_item_count_kernel(const u32* __restrict__ rowptr, u32 nrows, 
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > nrows) return;
     cnt[r] = (r < nrows) ? (rowptr[r + 1] - rowptr[r] + BP_ITEM - 1) / BP_ITEM : 0u;
+}
+
+// bit v <=> row v has more than BP_ITEM entries (its items OR into one row: they need a zeroed, shared target)
+__global__ __launch_bounds__(256) void bp_split_bits_kernel(const u32* __restrict__ rowptr, u32 nrows, u64* __restrict__ bits) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwords = (nrows + 63) >> 6;
+    for (u32 w = wave; w < nwords; w += nwaves) {
+        const u32 r = (w << 6) + lane;
+        const u64 m = __ballot(r < nrows && rowptr[r + 1] - rowptr[r] > BP_ITEM);
+        if (lane == 0) bits[w] = m;
+    }
 }
 
 __global__ void bp_item_fill_kernel(const u32* __restrict__ rowptr, u32 nrows, const u32* __restrict__ off,
@@ -77,6 +91,12 @@ static fgpu_info transposed_with_items(fgpu_ctx* ctx, const fgpu_mat* m, const f
         FGPU_TRY(ctx->dev_alloc((void**)&items, (size_t)(n ? n : 1) * 3 * sizeof(u32)));
         hipLaunchKernelGGL(bp_item_fill_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream(),
                            (const u32*)t->rowptr, nrows, (const u32*)off.p, items);
+        u64* sbits = nullptr;
+        fgpu_info si = ctx->dev_alloc((void**)&sbits, ((size_t)nrows / 64 + 2) * sizeof(u64));
+        if (si != FGPU_OK) { ctx->dev_free(items); return si; }
+        hipLaunchKernelGGL(bp_split_bits_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), (const u32*)t->rowptr,
+                           nrows, sbits);
+        t->bp_split_bits = sbits;
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
         if (e != hipSuccess) { ctx->dev_free(items); set_error("item list build failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
@@ -132,7 +152,8 @@ __global__ void bp_cs_table_kernel(u32 w, u64* __restrict__ tab) {
 template <bool WITH_SUM>
 __global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws,
                                                       const u64* __restrict__ label, const u64* __restrict__ tab,
-                                                      unsigned long long* __restrict__ acc) {
+                                                      unsigned long long* __restrict__ acc,
+                                                      const u32* __restrict__ vmap /* nullable: row r holds vertex vmap[r] */) {
     extern __shared__ u64 s_tab[];                    // w x 16 x 16 sums (2 KiB per word index)
     if (WITH_SUM) {
         for (u32 i = threadIdx.x; i < w * 256; i += 256) s_tab[i] = tab[i];
@@ -141,9 +162,10 @@ __global__ __launch_bounds__(256) void bp_count_kernel(const u64* __restrict__ y
     u64 cnt = 0, sum = 0;
     const u64 total = (u64)n * w;
     for (u64 t = (u64)blockIdx.x * 256 + threadIdx.x; t < total; t += (u64)gridDim.x * 256) {
-        const u32 v = (u32)(t / w), k = (u32)(t % w);
+        const u32 r = (u32)(t / w), k = (u32)(t % w);
+        const u32 v = vmap ? vmap[r] : r;
         if (label && !((label[v >> 6] >> (v & 63)) & 1ull)) continue;
-        const u64 bits = y[(size_t)v * ws + k];
+        const u64 bits = y[(size_t)r * ws + k];
         if (bits == 0ull) continue;
         cnt += (u64)__popcll(bits);
         if (WITH_SUM) {
@@ -189,19 +211,44 @@ __global__ __launch_bounds__(256) void bp_flag_bits_kernel(const uint8_t* __rest
     }
 }
 
-template <int LN, bool SPARSE>
-__global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __restrict__ items, u32 nitems, u32 ws,
+// What happens to a finished row (MODE): 0 = it is stored into Y (split rows OR into it) and flagged — a hop in the
+// middle of a chain; 1 / 2 = the LAST hop of a count-only chain: the row is counted here (2: and its checksum terms
+// summed through the LDS nibble tables) and never written, except for "touched" rows — rows cut into several items or
+// named by a delta layer — which go to their slot of the side buffer `y` (slot = rank of v in the touched bitmap).
+struct BpFinal {
+    const u64* tbits;        // touched bitmap (n bits)
+    const u32* tpref;        // exclusive prefix of its word popcounts
+    const u64* label;        // destination-label bitmap (nullable)
+    const u64* tab;          // checksum tables, w x 256 (MODE 2)
+    unsigned long long* acc; // [0] nnz, [1] checksum
+    u32 w;
+};
+
+template <int LN, bool SPARSE, int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView at, const u32* __restrict__ items, u32 nitems, u32 ws,
                                                      const u64* __restrict__ x, const u64* __restrict__ xbits,
-                                                     u64* __restrict__ y, uint8_t* __restrict__ yflag) {
+                                                     u64* __restrict__ y, uint8_t* __restrict__ yflag, BpFinal fin) {
+    // MODE 2 runs 1024-thread workgroups: the 2 KiB-per-word tables are shared by 16 wavefronts, so the LDS they take
+    // does not cost resident wavefronts (the gathers are latency-bound: 20 instead of 32 waves per CU made the dense
+    // hop 1.6 x slower when every 256-thread workgroup carried its own copy)
+    extern __shared__ u64 s_tab[];
+    if (MODE == 2) {
+        for (u32 i = threadIdx.x; i < fin.w * 256; i += blockDim.x) s_tab[i] = fin.tab[i];
+        __syncthreads();
+    }
+    u64 f_cnt = 0, f_sum = 0;
     constexpr int SLOTS = 64 / LN;
     const u32 lane = lane_id();
     const u32 wl = lane % LN, slot = lane / LN;
-    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
     const u32 nwb = ws / LN;  // word blocks per row (1 unless ws > 64)
     for (u32 it = wave; it < nitems; it += nwaves) {
-        const u32 v = items[3 * it], b = items[3 * it + 1];
-        const u32 e3 = items[3 * it + 2];
+        // an item belongs to one wavefront: its fields are wave-uniform — kept in scalar registers, so the row
+        // addresses and (counting hop) the vertex hash are scalar work
+        const u32 v = (u32)__builtin_amdgcn_readfirstlane((int)items[3 * it]);
+        const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)items[3 * it + 1]);
+        const u32 e3 = (u32)__builtin_amdgcn_readfirstlane((int)items[3 * it + 2]);
         const u32 e = e3 & 0x7FFFFFFFu;
         const bool split = (e3 >> 31) != 0;
         bool any = false;
@@ -209,22 +256,35 @@ __global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __r
             const u32 wo = wb * LN + wl;
             u64 acc = 0ull;
             if (SPARSE) {
-                for (u32 q0 = b; q0 < e; q0 += 64) {
-                    const u32 q = q0 + lane;
-                    const u32 un = (q < e) ? at.colidx[q] : 0u;
-                    u64 live = __ballot((q < e) && ((xbits[un >> 6] >> (un & 63)) & 1ull));
-                    while (live) {   // wave-uniform: SLOTS flagged neighbours per trip
+                // all four 64-entry trips of an item issue their column-id loads and their flag probes before any of
+                // them is consumed: a trip is a chain of two dependent round trips (column id -> flag word)
+                u32 un[4];
+                u64 live[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 q = b + 64 * k + lane;
+                    un[k] = (q < e) ? at.colidx[q] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool hit = un[k] != 0xFFFFFFFFu && ((xbits[un[k] >> 6] >> (un[k] & 63)) & 1ull);
+                    live[k] = __ballot(hit);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    u64 lv = live[k];
+                    while (lv) {   // wave-uniform: SLOTS flagged neighbours per trip
                         u32 src = 0;
                         bool on = false;
 #pragma unroll
                         for (int sl = 0; sl < SLOTS; ++sl) {
-                            if (live) {
-                                const u32 idx = (u32)__builtin_ctzll(live);
-                                live &= live - 1ull;
+                            if (lv) {
+                                const u32 idx = (u32)__builtin_ctzll(lv);
+                                lv &= lv - 1ull;
                                 if ((int)slot == sl) { src = idx; on = true; }
                             }
                         }
-                        const u32 uu = (u32)__shfl((int)un, (int)src, 64);
+                        const u32 uu = (u32)__shfl((int)un[k], (int)src, 64);
                         if (on) acc |= x[(size_t)uu * ws + wo];
                     }
                 }
@@ -245,14 +305,67 @@ __global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __r
             }
 #pragma unroll
             for (int d = LN; d < 64; d <<= 1) acc |= __shfl_xor(acc, d, 64);
-            if (slot == 0 && acc) {
-                u64* dst = &y[(size_t)v * ws + wo];
-                if (split) atomicOr((unsigned long long*)dst, (unsigned long long)acc);
-                else *dst = acc;
+            if (MODE == 0) {
+                if (slot == 0 && acc) {
+                    u64* dst = &y[(size_t)v * ws + wo];
+                    if (split) atomicOr((unsigned long long*)dst, (unsigned long long)acc);
+                    else *dst = acc;
+                }
+                any |= __ballot(acc != 0ull) != 0ull;   // any word of the row, whichever lane holds it
+            } else if (acc) {                          // after the butterfly every slot holds the row's word `wo`
+                const u64 tw = fin.tbits[v >> 6];
+                if ((tw >> (v & 63)) & 1ull) {         // touched: several items and / or delta fix-ups meet in the side buffer
+                    if (slot == 0) {
+                        const u32 sl = fin.tpref[v >> 6] + (u32)__popcll(tw & ((1ull << (v & 63)) - 1ull));
+                        atomicOr((unsigned long long*)&y[(size_t)sl * ws + wo], (unsigned long long)acc);
+                    }
+                } else if (!fin.label || ((fin.label[v >> 6] >> (v & 63)) & 1ull)) {
+                    if (slot == 0) f_cnt += (u64)__popcll(acc);
+                    if (MODE == 2) {
+                        // the 16 nibble look-ups of the word are shared out over the SLOTS lanes that hold it
+                        const u64* tk = s_tab + (size_t)wo * 256;
+                        u64 rs = 0;
+#pragma unroll
+                        for (int j = (int)slot; j < 16; j += SLOTS) rs += tk[j * 16 + (u32)((acc >> (4 * j)) & 15ull)];
+                        f_sum += rs * cs_dest_hash(v);
+                    }
+                }
             }
-            any |= __ballot(acc != 0ull) != 0ull;   // any word of the row, whichever lane holds it
         }
-        if (any && lane == 0) yflag[v] = 1;   // "maybe non-zero": benign races, never cleared within a hop
+        if (MODE == 0 && any && lane == 0) yflag[v] = 1;   // "maybe non-zero": benign races, never cleared within a hop
+    }
+    if (MODE != 0) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            f_cnt += __shfl_xor(f_cnt, d, 64);
+            f_sum += __shfl_xor(f_sum, d, 64);
+        }
+        if (lane == 0 && f_cnt) {
+            atomicAdd(&fin.acc[0], (unsigned long long)f_cnt);
+            if (MODE == 2) atomicAdd(&fin.acc[1], (unsigned long long)f_sum);
+        }
+    }
+}
+
+// side-buffer bookkeeping of the counting hop: mark the destinations a delta layer names, popcount the touched words
+__global__ void bp_mark_cols_kernel(const u32* __restrict__ col, u32 nnz, u64* __restrict__ bits) {
+    for (u32 q = blockIdx.x * 256 + threadIdx.x; q < nnz; q += gridDim.x * 256)
+        atomicOr((unsigned long long*)&bits[col[q] >> 6], 1ull << (col[q] & 63));
+}
+__global__ void bp_word_popc_kernel(const u64* __restrict__ bits, u32 nwords, u32* __restrict__ pc) {
+    const u32 w = blockIdx.x * 256 + threadIdx.x;
+    if (w <= nwords) pc[w] = w < nwords ? (u32)__popcll(bits[w]) : 0u;
+}
+// vertex of every slot of the side buffer (slot = rank of v in the touched bitmap)
+__global__ __launch_bounds__(256) void bp_slot_vertex_kernel(const u64* __restrict__ tbits, const u32* __restrict__ tpref,
+                                                            u32 n, u32* __restrict__ vmap) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwords = (n + 63) >> 6;
+    for (u32 wd = wave; wd < nwords; wd += nwaves) {
+        const u64 tw = tbits[wd];
+        if ((tw >> lane) & 1ull) vmap[tpref[wd] + (u32)__popcll(tw & ((1ull << lane) - 1ull))] = (wd << 6) + lane;
     }
 }
 
@@ -263,7 +376,8 @@ __global__ __launch_bounds__(256) void bp_pull_kernel(CsrView at, const u32* __r
 template <bool IS_DM>
 __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w, u32 ws, u32 ln,
                                                       const u64* __restrict__ x, u64* __restrict__ y,
-                                                      uint8_t* __restrict__ yflag) {
+                                                      uint8_t* __restrict__ yflag, const u64* __restrict__ tbits,
+                                                      const u32* __restrict__ tpref) {
     const u32 t = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     const u32 per = nth / ln;             // entries in flight per sweep
     const u32 sub = t % ln;
@@ -275,13 +389,19 @@ __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w
         }
         const u32 u = d.hrows ? d.hrows[lo] : lo;
         const u32 v = d.colidx[q];
+        // the row of v: in Y, or (counting hop) in its slot of the side buffer — every delta destination is "touched"
+        size_t yrow = (size_t)v * ws;
+        if (tbits) {
+            const u64 tw = tbits[v >> 6];
+            yrow = (size_t)(tpref[v >> 6] + (u32)__popcll(tw & ((1ull << (v & 63)) - 1ull))) * ws;
+        }
         for (u32 k = sub; k < w; k += ln) {
             const u64 xv = x[(size_t)u * ws + k];
             if (xv == 0ull) continue;
-            if (IS_DM) atomicAnd((unsigned long long*)&y[(size_t)v * ws + k], (unsigned long long)~xv);
+            if (IS_DM) atomicAnd((unsigned long long*)&y[yrow + k], (unsigned long long)~xv);
             else {
-                atomicOr((unsigned long long*)&y[(size_t)v * ws + k], (unsigned long long)xv);
-                yflag[v] = 1;
+                atomicOr((unsigned long long*)&y[yrow + k], (unsigned long long)xv);
+                if (yflag) yflag[v] = 1;
             }
         }
     }
@@ -477,10 +597,10 @@ fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* 
             if (lds > 48 * 1024)
                 FGPU_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(bp_count_kernel<true>, dim3(grid), dim3(256), lds, ctx->stream(), (const u64*)s.x.p, s.n,
-                               s.w, s.ws, label_dev, (const u64*)tab.p, (unsigned long long*)acc.p);
+                               s.w, s.ws, label_dev, (const u64*)tab.p, (unsigned long long*)acc.p, (const u32*)nullptr);
         } else {
             hipLaunchKernelGGL(bp_count_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n,
-                               s.w, s.ws, label_dev, (const u64*)nullptr, (unsigned long long*)acc.p);
+                               s.w, s.ws, label_dev, (const u64*)nullptr, (unsigned long long*)acc.p, (const u32*)nullptr);
         }
         FGPU_HIP(hipGetLastError());
     }
@@ -507,7 +627,15 @@ static fgpu_info bp_flops(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* a, u
 }
 
 // one delta_lmxm in bit form: s.x <- ((X·m) & ~(X·dm)) | (X·dp)
-fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops) {
+// what the counting form of a hop needs beside the hop itself
+struct CountArgs {
+    const u64* label;   // destination-label bitmap on the device (nullable)
+    u64* nnz;
+    u64* checksum;      // nullable
+};
+
+static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
+                             u64* flops, const CountArgs* ca) {
     FGPU_REQUIRE(m->nrows == s.n, FGPU_DIM_MISMATCH, "bit-parallel hop: matrix has %llu rows, frontier %u",
                  (unsigned long long)m->nrows, s.n);
     FGPU_REQUIRE(m->nnz < 0x7FFFFFFFull, FGPU_INVALID, "bit-parallel hop: nnz must be < 2^31");
@@ -515,19 +643,71 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
         FGPU_TRY(bp_flops(ctx, s, m, flops));
         if (dp && dp->nnz) FGPU_TRY(bp_flops(ctx, s, dp, flops));
     }
+    const bool has_dm = dm && dm->nnz, has_dp = dp && dp->nnz;
+    const u32 n_out = (u32)m->ncols;
+    const fgpu_mat* t = nullptr;
+    if (m->nnz) FGPU_TRY(transposed_with_items(ctx, m, &t));
     BitState o;
-    bp_layout(o, (u32)m->ncols, s.nsrc);
-    FGPU_TRY(bp_alloc_zero(ctx, o.x, o));
-    FGPU_TRY(bp_alloc_flags(ctx, o));
+    bp_layout(o, n_out, s.nsrc);
+    // ---- counting hop: touched bitmap (split rows + delta destinations), its prefix, the side buffer, the tables
+    DevBuf<u64> tbits, side, tab, acc;
+    DevBuf<u32> tpc, tpref, ttot;
+    BpFinal fin = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    u32 ntouched = 0;
+    const int mode = !ca ? 0 : (ca->checksum ? 2 : 1);
+    size_t lds = 0;
+    if (ca) {
+        const u32 nwords = (n_out + 63) / 64;
+        FGPU_TRY(tbits.alloc(ctx, (size_t)nwords + 2));
+        if (t && t->bp_split_bits)
+            FGPU_HIP(hipMemcpyAsync(tbits.p, t->bp_split_bits, (size_t)nwords * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream()));
+        else
+            FGPU_HIP(hipMemsetAsync(tbits.p, 0, (size_t)nwords * sizeof(u64), ctx->stream()));
+        for (const fgpu_mat* d : {has_dm ? dm : nullptr, has_dp ? dp : nullptr}) {
+            if (!d) continue;
+            u32 grid = cdiv(d->nnz, 256);
+            if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
+            hipLaunchKernelGGL(bp_mark_cols_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const u32*)d->colidx, (u32)d->nnz, tbits.p);
+        }
+        FGPU_TRY(tpc.alloc(ctx, (size_t)nwords + 2));
+        FGPU_TRY(tpref.alloc(ctx, (size_t)nwords + 2));
+        FGPU_TRY(ttot.alloc(ctx, 1));
+        hipLaunchKernelGGL(bp_word_popc_kernel, dim3(cdiv((u64)nwords + 1, 256)), dim3(256), 0, ctx->stream(), (const u64*)tbits.p,
+                           nwords, tpc.p);
+        FGPU_HIP(hipGetLastError());
+        FGPU_TRY(scan_u32(ctx, tpc.p, tpref.p, (u64)nwords + 1, ttot.p));
+        FGPU_TRY(read_u32(ctx, ttot.p, &ntouched));
+        FGPU_TRY(side.alloc(ctx, (size_t)(ntouched ? ntouched : 1) * s.ws));
+        FGPU_HIP(hipMemsetAsync(side.p, 0, (size_t)(ntouched ? ntouched : 1) * s.ws * sizeof(u64), ctx->stream()));
+        FGPU_TRY(acc.alloc(ctx, 2));
+        FGPU_HIP(hipMemsetAsync(acc.p, 0, 2 * sizeof(u64), ctx->stream()));
+        if (mode == 2) {
+            lds = (size_t)s.w * 256 * sizeof(u64);
+            FGPU_REQUIRE(lds <= (size_t)ctx->opt.lds_limit, FGPU_INVALID,
+                         "expand checksum: %u source rows need %zu B of LDS tables (limit %d); batch the sources", s.nsrc, lds,
+                         ctx->opt.lds_limit);
+            FGPU_TRY(tab.alloc(ctx, (size_t)s.w * 256));
+            hipLaunchKernelGGL(bp_cs_table_kernel, dim3(s.w), dim3(256), 0, ctx->stream(), s.w, tab.p);
+        }
+        fin = BpFinal{tbits.p, tpref.p, ca->label, tab.p, (unsigned long long*)acc.p, s.w};
+    } else {
+        FGPU_TRY(bp_alloc_zero(ctx, o.x, o));
+        FGPU_TRY(bp_alloc_flags(ctx, o));
+    }
+    u64* ydst = ca ? side.p : o.x.p;          // rows of Y, or the slots of the side buffer
+    uint8_t* yflag = ca ? nullptr : o.flag.p;
     int pull_idx = -1;
     if (m->nnz) {
-        const fgpu_mat* t = nullptr;
-        FGPU_TRY(transposed_with_items(ctx, m, &t));
         const u32 nitems = t->n_bp_items;
         u32 grid = cdiv(nitems ? nitems : 1, 4);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+        const u32 threads = mode == 2 ? 1024 : 256;
+        if (mode == 2) {                              // 16-wavefront workgroups: same wavefront count, a quarter of the grid
+            grid = cdiv(nitems ? nitems : 1, 16);
+            if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
+        }
         const u32 ln = s.ws < 64 ? s.ws : 64;
-        // fewer than 1 row in 8 flagged: probing a byte per neighbour first beats gathering 8 W-byte rows
+        // fewer than 1 row in 8 flagged: probing a flag bit per neighbour first beats gathering 8 W-byte rows
         const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n;
         DevBuf<u64> xbits;
         if (sparse) {
@@ -537,22 +717,27 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
             FGPU_HIP(hipGetLastError());
         }
         // algorithmic bytes of the launch: the column ids of A' and the item list once, every non-zero X row once
-        // (the per-entry row gathers beyond that are cache traffic), a flag byte per vertex in the sparse form;
-        // the non-zero Y rows written are added once they are counted (bp_count_flags below)
+        // (the per-entry row gathers beyond that are cache traffic), the flag bitmap in the sparse form; the
+        // non-zero Y rows a mid-chain hop writes are added once they are counted (bp_count_flags below)
         const u64 xrows = s.nz_rows < (u64)s.n ? s.nz_rows : (u64)s.n;
-        ProfScope ps(ctx, sparse ? "bp_pull_kernel<sparse>" : "bp_pull_kernel<dense>",
-                     4 * (u64)t->nnz + 12 * (u64)nitems + xrows * 8 * s.w + (sparse ? (u64)s.n : 0));
+        const char* nm = ca ? (sparse ? "bp_pull_kernel<sparse, count>" : "bp_pull_kernel<dense, count>")
+                            : (sparse ? "bp_pull_kernel<sparse>" : "bp_pull_kernel<dense>");
+        ProfScope ps(ctx, nm, 4 * (u64)t->nnz + 12 * (u64)nitems + xrows * 8 * s.w + (sparse ? (u64)s.n / 8 : 0));
         ps.idx_out = &pull_idx;
+#define BP_LAUNCH3(LN, SP, MD)                                                                                          \
+    do {                                                                                                                \
+        if (lds > 48 * 1024)                                                                                            \
+            FGPU_HIP(hipFuncSetAttribute((const void*)bp_pull_kernel<LN, SP, MD>,                                       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hipLaunchKernelGGL((bp_pull_kernel<LN, SP, MD>), dim3(grid), dim3(threads), (MD == 2 ? lds : 0), ctx->stream(), \
+                           view_of(t), (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p,                        \
+                           (const u64*)(SP ? xbits.p : nullptr), ydst, yflag, fin);                                     \
+    } while (0)
 #define BP_LAUNCH(LN)                                                                                                   \
     do {                                                                                                                \
-        if (sparse)                                                                                                     \
-            hipLaunchKernelGGL((bp_pull_kernel<LN, true>), dim3(grid), dim3(256), 0, ctx->stream(), view_of(t),         \
-                               (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const u64*)xbits.p,          \
-                               o.x.p, o.flag.p);                                                                        \
-        else                                                                                                            \
-            hipLaunchKernelGGL((bp_pull_kernel<LN, false>), dim3(grid), dim3(256), 0, ctx->stream(), view_of(t),        \
-                               (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p, (const u64*)nullptr,          \
-                               o.x.p, o.flag.p);                                                                        \
+        if (mode == 0) { if (sparse) BP_LAUNCH3(LN, true, 0); else BP_LAUNCH3(LN, false, 0); }                          \
+        else if (mode == 1) { if (sparse) BP_LAUNCH3(LN, true, 1); else BP_LAUNCH3(LN, false, 1); }                     \
+        else { if (sparse) BP_LAUNCH3(LN, true, 2); else BP_LAUNCH3(LN, false, 2); }                                    \
     } while (0)
         switch (ln) {
             case 1: BP_LAUNCH(1); break;
@@ -564,27 +749,57 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
             default: BP_LAUNCH(64); break;
         }
 #undef BP_LAUNCH
+#undef BP_LAUNCH3
         FGPU_HIP(hipGetLastError());
     }
     {
         u32 ln = 1;                               // lanes per delta entry: a power of two covering the row words
         while (ln < s.w && ln < 64) ln <<= 1;
-        if (dm && dm->nnz) {
+        if (has_dm) {
             ProfScope ps(ctx, "bp_delta_kernel<dm>", (u64)dm->nnz * (4 + 16 * s.w));
             u32 grid = cdiv((u64)dm->nnz * ln, 256);
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
             hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dm), (u32)dm->nnz,
-                               s.w, s.ws, ln, (const u64*)s.x.p, o.x.p, o.flag.p);
+                               s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref);
             FGPU_HIP(hipGetLastError());
         }
-        if (dp && dp->nnz) {
+        if (has_dp) {
             ProfScope ps(ctx, "bp_delta_kernel<dp>", (u64)dp->nnz * (4 + 16 * s.w));
             u32 grid = cdiv((u64)dp->nnz * ln, 256);
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
             hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dp), (u32)dp->nnz,
-                               s.w, s.ws, ln, (const u64*)s.x.p, o.x.p, o.flag.p);
+                               s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref);
             FGPU_HIP(hipGetLastError());
         }
+    }
+    if (ca) {
+        if (ntouched) {
+            ProfScope ps(ctx, "bp_count_kernel<side rows>", (u64)ntouched * s.w * 8);
+            DevBuf<u32> vmap;
+            FGPU_TRY(vmap.alloc(ctx, (size_t)ntouched + 1));
+            hipLaunchKernelGGL(bp_slot_vertex_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), (const u64*)tbits.p,
+                               (const u32*)tpref.p, n_out, vmap.p);
+            const u64 total = (u64)ntouched * s.w;
+            u32 grid = cdiv(total, 256);
+            const u32 cap = mode == 2 ? (u32)ctx->cus * 4 : (u32)ctx->cus * 16;
+            if (grid > cap) grid = cap;
+            if (mode == 2) {
+                if (lds > 48 * 1024)
+                    FGPU_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(bp_count_kernel<true>, dim3(grid), dim3(256), lds, ctx->stream(), (const u64*)side.p, ntouched,
+                                   s.w, s.ws, ca->label, (const u64*)tab.p, (unsigned long long*)acc.p, (const u32*)vmap.p);
+            } else {
+                hipLaunchKernelGGL(bp_count_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)side.p, ntouched,
+                                   s.w, s.ws, ca->label, (const u64*)nullptr, (unsigned long long*)acc.p, (const u32*)vmap.p);
+            }
+            FGPU_HIP(hipGetLastError());
+        }
+        FGPU_TRY(read_u64(ctx, acc.p, ca->nnz));
+        if (ca->checksum) FGPU_TRY(read_u64(ctx, acc.p + 1, ca->checksum));
+        s.x.release();            // the chain ends here: no state is left behind
+        s.flag.release();
+        s.n = n_out;
+        return FGPU_OK;
     }
     FGPU_TRY(bp_count_flags(ctx, o));
     prof_add_bytes(ctx, pull_idx, o.nz_rows * 8 * s.w);
@@ -593,6 +808,16 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
     s.nz_rows = o.nz_rows;
     s.n = o.n;
     return FGPU_OK;
+}
+
+fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops) {
+    return bp_hop_impl(ctx, s, m, dp, dm, flops, nullptr);
+}
+
+fgpu_info bp_hop_count(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,
+                       const u64* label_dev, u64* nnz, u64* checksum) {
+    CountArgs ca{label_dev, nnz, checksum};
+    return bp_hop_impl(ctx, s, m, dp, dm, flops, &ca);
 }
 
 // X -> CSR snapshot with nsrc rows (dest ascending per row); `label_dev` (nullable) = destination

@@ -66,6 +66,7 @@ struct fgpu_options {  // fgpu_set_option
     int tiled_threads = 1024;  // its workgroup size
     int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)
     int expand_mode = 0;       // 0 auto, 1 sorted-CSR products only, 2 bit-parallel from the first hop
+    int expand_fuse_count = 1; // fgpu_expand_count: the last bit-parallel hop counts its rows in place (0 = separate count pass)
     int bfs_wgs_per_cu = 6;    // grid of the fused BFS level kernel, workgroups per CU
     int bfs_tiny = 2;          // consecutive tiny BFS levels in one single-workgroup launch (bfs_tiny_kernel): 0 off, 1 on,
                                // 2 = when the plan's previous search took more than 12 levels
@@ -223,6 +224,7 @@ struct fgpu_mat {
     mutable fgpu_mat* tcache = nullptr;
     mutable uint32_t* bp_items = nullptr;  // triples (row, begin, end | split << 31)
     mutable uint32_t n_bp_items = 0;
+    mutable uint64_t* bp_split_bits = nullptr;  // on the cached transpose: bit v set <=> row v is cut into several items
     bool is_hyper() const { return hrows != nullptr; }
 };
 
@@ -374,6 +376,10 @@ fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* 
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out);
 // nnz + order-independent checksum of the result read straight from the bit state (fgpu_expand_count)
 fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum);
+// the LAST hop of a count-only chain: the hop and the count in one pass — the result rows are counted where they are
+// produced and never written (only rows that several work items or a delta layer touch go through a side buffer)
+fgpu_info bp_hop_count(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,
+                       const u64* label_dev, u64* nnz, u64* checksum);
 // u |= x (u is allocated, zeroed, on first use): DISTINCT union over the hops of a [*1..k] pattern
 fgpu_info bp_accumulate(fgpu_ctx* ctx, BitState& u, const BitState& x);
 

@@ -372,6 +372,19 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
             }
         }
         if (bits) {
+            if (count_only && h == nhops - 1 && ctx->opt.expand_fuse_count) {
+                // the last hop of a count-only chain counts its rows where they are produced: no result state is
+                // written, zeroed or read back (bitexpand.hip bp_hop_count)
+                DevBuf<u64> bm;
+                if (dst_label_bitmap) {
+                    const u64 nw = ((u64)mh->ncols + 63) / 64;
+                    FGPU_TRY(bm.alloc(ctx, nw + 1));
+                    FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+                }
+                *result = nullptr;
+                return bp_hop_count(ctx, bs, mh, dph, dmh, flops, dst_label_bitmap ? bm.p : nullptr, &count_only[0],
+                                    want_checksum ? &count_only[1] : nullptr);
+            }
             FGPU_TRY(bp_hop(ctx, bs, mh, dph, dmh, flops));
             continue;
         }

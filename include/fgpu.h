@@ -83,7 +83,8 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * "tiled_wgs" (grid of that kernel, 0 = fill the CUs), "tiled_nt" (nontemporal entry loads),
  * "transpose_mode" (pattern transpose: 0 = counting transpose, 1 = COO rebuild through the sorter),
  * "expand_mode" (fgpu_expand: 0 = pick per hop, 1 = sorted-CSR products only, 2 = bit-parallel from the
- * first hop), "bfs_wgs_per_cu" (grid of the fused BFS level kernel), "merge_mode" (fgpu_mat_merge:
+ * first hop), "expand_fuse_count" (fgpu_expand_count: 1 = the last bit-parallel hop counts its rows where it produces
+ * them, 0 = it writes them and a separate pass counts), "bfs_wgs_per_cu" (grid of the fused BFS level kernel), "merge_mode" (fgpu_mat_merge:
  * 0 = entry-parallel, 1 = one wavefront per row, pattern layers only), "bfs_tiny" (consecutive tiny BFS levels in one single-workgroup launch: 0 off, 1 on,
  * 2 = when the plan's previous search took more than 12 levels), "dist_collective" (frontier exchange of
  * fgpu_bfs_dist_run: 0 = grouped ncclSend / ncclRecv, 1 = one ncclBroadcast per rank), "bfs_prof_split" (1 = a profiled plan launches
@@ -262,7 +263,8 @@ fgpu_info fgpu_expand_trail_counts(fgpu_ctx* ctx, const uint64_t* src_ids, uint6
  * ncols-/nrows-bit bitmaps (LSB-first 64-bit words, HOST pointers; copied in/out).
  * This is GrB_vxm (graphblas/mod.rs:11173) in the form LAGraph's BFS issues it.
  * mask may be NULL.  `At` (nullable) enables the pull direction; `direction`:
- * 0 = auto, 1 = push over A, 2 = pull over At's CSR (full pass, no early exit),
+ * 0 = auto (push over A while fewer than 1 / 32 of the vertices are in the frontier, else — given At — the LDS-tiled
+ * pull), 1 = push over A, 2 = pull over At's CSR (full pass, no early exit),
  * 3 = pull over At's LDS-tile layout (built on first use, fgpu_mat_build_tiles). */
 fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t* mask,
                    const fgpu_mat* A, const fgpu_mat* At, int direction);

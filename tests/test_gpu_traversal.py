@@ -148,10 +148,18 @@ def test_expand_modes_match_oracle(ctx, mode, k):
             np.testing.assert_array_equal(rp, c.rowptr)
             np.testing.assert_array_equal(dest, c.colidx)
             assert flops == flops_ref
-            nnz, cs, _ = engine.expand_count(ctx, src, mats, dps, dms, label if with_label else None)
-            assert nnz == c.nnz and cs == oracle.checksum(c)
+            nnz, cs, fl = engine.expand_count(ctx, src, mats, dps, dms, label if with_label else None)
+            assert nnz == c.nnz and cs == oracle.checksum(c) and fl == flops_ref
+            # the counting last hop (rows counted where they are produced) against the separate count pass, and the
+            # count-only form
+            ctx.set_option("expand_fuse_count", 0)
+            assert engine.expand_count(ctx, src, mats, dps, dms, label if with_label else None) == (nnz, cs, fl)
+            ctx.set_option("expand_fuse_count", 1)
+            assert engine.expand_count(ctx, src, mats, dps, dms, label if with_label else None,
+                                       want_checksum=False) == (nnz, 0, fl)
     finally:
         ctx.set_option("expand_mode", 0)
+        ctx.set_option("expand_fuse_count", 1)
 
 
 @pytest.mark.parametrize("k,with_delta,with_label", [(1, False, False), (70, True, False), (300, True, True),
@@ -378,6 +386,29 @@ def test_bfs_hub_source_and_isolated_source(ctx):
         level, parent, edges = engine.bfs(ctx, A, At, src, -1, want_parent=True)
         check_bfs(a, level, parent, src, ref)
         assert edges == ref_edges
+
+
+def test_vxm_auto_direction_picks_push_or_the_tiled_pull(ctx):
+    """direction 0: a sparse frontier is pushed, a dense one goes through the LDS-tiled pull (the kernel of the RMAT-22
+    boolean-SpMV roofline case) — same bits as the oracle either way, with and without a mask."""
+    a = oracle.rmat_csr(15)
+    n = a.nrows
+    A = up(ctx, a)
+    At = A.transpose()
+    rng = np.random.default_rng(40)
+    mask = oracle.bits_from_ids(n, rng.choice(n, n // 4, replace=False))
+    with pytest.raises(Exception):
+        At.tiles_info()                                       # no tiles yet
+    for k in (7, n // 64):                                    # both below 1 / 32 of the vertices: pushed, no tiles built
+        f = oracle.bits_from_ids(n, rng.choice(n, k, replace=False))
+        np.testing.assert_array_equal(engine.vxm(ctx, f, None, A, At, 0), oracle.vxm(a, f, None))
+    with pytest.raises(Exception):
+        At.tiles_info()
+    for k in (n // 16, n // 2, n):                            # dense: the tiled pull
+        f = oracle.bits_from_ids(n, rng.choice(n, k, replace=False))
+        np.testing.assert_array_equal(engine.vxm(ctx, f, mask, A, At, 0), oracle.vxm(a, f, mask))
+        np.testing.assert_array_equal(engine.vxm(ctx, f, None, A, None, 0), oracle.vxm(a, f, None))   # no At: pushed
+    assert At.tiles_info()["items"] > 0                       # the dense calls built the layout on At
 
 
 @pytest.mark.parametrize("direction", [1, 2])
