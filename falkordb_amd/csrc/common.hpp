@@ -372,6 +372,9 @@ struct BitState {
     u64 nz_rows = 0;       // number of flagged rows (what decides the sparse / dense form of the next hop)
 };
 fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f);
+// one hop from a CSR frontier into bit form by pushing (the hop at which a chain leaves the sorted-CSR products)
+fgpu_info bp_push_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* dp,
+                           const fgpu_mat* dm);
 fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops);
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out);
 // nnz + order-independent checksum of the result read straight from the bit state (fgpu_expand_count)

@@ -355,15 +355,37 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
             const u64 row_bytes = w * 8 > 64 ? w * 8 : 64;
             const u64 mem = 2ull * (mh->nrows > mh->ncols ? mh->nrows : mh->ncols) * (w <= 64 ? 2 * w : w + 64) * 8;
             bool go = (mode == 2);
-            if (mode == 0 && mem < (64ull << 30)) {
-                u64 T = 0;
+            u64 T = 0;
+            if ((mode == 0 && mem < (64ull << 30)) || go) {
                 fgpu_info i = mxm_flops(ctx, f, mh, &T);
                 if (i != FGPU_OK) { mat_release(f); return i; }
                 // measured on RMAT-22 / 1024 rows: a sorted-CSR hop costs ~0.16 ns per gathered entry
                 // (6 ms at T = 36 M), a bit hop ~2.7 ms per 65 M matrix entries at 128 B rows
-                go = T * 1024 > mh->nnz * row_bytes;
+                if (mode == 0) go = T * 1024 > mh->nnz * row_bytes;
             }
             if (go) {
+                // leaving the CSR form: a frontier whose out-edges are FEW beside the matrix is pushed into the bit state
+                // (one 8-byte atomic per traversed edge: measured ~8 G/s on random words of a 2 GiB state — 33 M edges
+                // took 4.06 ms where the sparse pull takes 2.64 ms, so the bar is a 32nd of the matrix, not a quarter),
+                // a heavier one is scattered to a dense X and pulled
+                const fgpu_mat* dph_ = dp ? dp[h] : nullptr;
+                if (T * 32 <= mh->nnz) {
+                    if (flops) {
+                        *flops += T;
+                        if (dph_ && dph_->nnz) {
+                            u64 Tp = 0;
+                            fgpu_info i = mxm_flops(ctx, f, dph_, &Tp);
+                            if (i != FGPU_OK) { mat_release(f); return i; }
+                            *flops += Tp;
+                        }
+                    }
+                    fgpu_info i = bp_push_from_csr(ctx, bs, f, mh, dph_, dmh);
+                    mat_release(f);
+                    f = nullptr;
+                    if (i != FGPU_OK) return i;
+                    bits = true;
+                    continue;                       // this hop is done
+                }
                 fgpu_info i = bp_from_csr(ctx, bs, f);
                 mat_release(f);
                 f = nullptr;
