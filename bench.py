@@ -71,8 +71,10 @@ PMC_GROUPS = (  # (reported name, regex over rocprofv3's Kernel_Name)
     ("bfs_fused_kernel (pull level)", r"bfs_fused_kernel<(true|false), 2>"),
     ("bfs_fused_kernel (blind loop)", r"bfs_fused_kernel<(true|false), 0>"),
     ("tiled_mxv_kernel", r"tiled_mxv_kernel"),
-    ("bp_pull_kernel<dense>", r"bp_pull_kernel<\d+, false>"),
-    ("bp_pull_kernel<sparse>", r"bp_pull_kernel<\d+, true>"),
+    ("bp_pull_kernel<dense>", r"bp_pull_kernel<\d+, false, 0>"),
+    ("bp_pull_kernel<sparse>", r"bp_pull_kernel<\d+, true, 0>"),
+    ("bp_pull_kernel<dense, count>", r"bp_pull_kernel<\d+, false, [12]>"),
+    ("bp_pull_kernel<sparse, count>", r"bp_pull_kernel<\d+, true, [12]>"),
     ("bp_count_kernel<checksum>", r"bp_count_kernel<true>"),
     ("bp_count_kernel<count>", r"bp_count_kernel<false>"),
     ("bp_delta_kernel<dm>", r"bp_delta_kernel<true>"),
