@@ -47,12 +47,22 @@ __global__ __launch_bounds__(256) void bp_split_bits_kernel(const u32* __restric
     }
 }
 
+__global__ void bp_sitem_count_kernel(const u32* __restrict__ rowptr, u32 nrows, u32* __restrict__ cnt) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrows) return;
+    const u32 d = (r < nrows) ? rowptr[r + 1] - rowptr[r] : 0u;
+    cnt[r] = d > BP_ITEM ? (d + BP_ITEM - 1) / BP_ITEM : 0u;
+}
+
+// SPLIT_ONLY: only the rows cut into several items (off = scan of bp_sitem_count_kernel's counts)
+template <bool SPLIT_ONLY>
 __global__ void bp_item_fill_kernel(const u32* __restrict__ rowptr, u32 nrows, const u32* __restrict__ off,
                                     u32* __restrict__ items) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
     const u32 b = rowptr[r], e = rowptr[r + 1];
     const u32 n = (e - b + BP_ITEM - 1) / BP_ITEM;
+    if (SPLIT_ONLY && n <= 1) return;
     const u32 split = n > 1 ? 0x80000000u : 0u;
     u32 o = off[r];
     for (u32 k = 0; k < n; ++k, ++o) {
@@ -89,17 +99,33 @@ static fgpu_info transposed_with_items(fgpu_ctx* ctx, const fgpu_mat* m, const f
         FGPU_TRY(read_u32(ctx, off.p + nrows, &n));
         u32* items = nullptr;
         FGPU_TRY(ctx->dev_alloc((void**)&items, (size_t)(n ? n : 1) * 3 * sizeof(u32)));
-        hipLaunchKernelGGL(bp_item_fill_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream(),
+        hipLaunchKernelGGL(bp_item_fill_kernel<false>, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream(),
                            (const u32*)t->rowptr, nrows, (const u32*)off.p, items);
+        // the split rows' items once more, on their own: the row-group form of the sparse pull leaves exactly these
+        // to the item kernel
+        hipLaunchKernelGGL(bp_sitem_count_kernel, dim3(cdiv((u64)nrows + 1, 256)), dim3(256), 0, ctx->stream(),
+                           (const u32*)t->rowptr, nrows, cnt.p);
+        FGPU_HIP(hipGetLastError());
+        FGPU_TRY(scan_u32(ctx, cnt.p, off.p, (u64)nrows + 1, nullptr));
+        u32 ns = 0;
+        FGPU_TRY(read_u32(ctx, off.p + nrows, &ns));
+        u32* sitems = nullptr;
+        fgpu_info ssi = ctx->dev_alloc((void**)&sitems, (size_t)(ns ? ns : 1) * 3 * sizeof(u32));
+        if (ssi != FGPU_OK) { ctx->dev_free(items); return ssi; }
+        if (ns)
+            hipLaunchKernelGGL(bp_item_fill_kernel<true>, dim3(cdiv(nrows, 256)), dim3(256), 0, ctx->stream(),
+                               (const u32*)t->rowptr, nrows, (const u32*)off.p, sitems);
         u64* sbits = nullptr;
         fgpu_info si = ctx->dev_alloc((void**)&sbits, ((size_t)nrows / 64 + 2) * sizeof(u64));
-        if (si != FGPU_OK) { ctx->dev_free(items); return si; }
+        if (si != FGPU_OK) { ctx->dev_free(items); ctx->dev_free(sitems); return si; }
         hipLaunchKernelGGL(bp_split_bits_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), (const u32*)t->rowptr,
                            nrows, sbits);
         t->bp_split_bits = sbits;
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
-        if (e != hipSuccess) { ctx->dev_free(items); set_error("item list build failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+        if (e != hipSuccess) { ctx->dev_free(items); ctx->dev_free(sitems); set_error("item list build failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+        t->n_bp_sitems = ns;
+        t->bp_sitems = sitems;
         t->n_bp_items = n;
         t->bp_items = items;
     }
@@ -211,6 +237,32 @@ __global__ __launch_bounds__(256) void bp_flag_bits_kernel(const uint8_t* __rest
     }
 }
 
+// coarse filter over the flag bits for the sparse pull: bit j <=> any flag among the 64 << g vertices of block j.  It is
+// small enough for LDS (<= 16 KiB), and after a hop from ~10^4 frontier vertices it is ~90 % zeros: most of the 263 M
+// probes of an RMAT-24 pull are answered from LDS instead of from L2 (where random 4-byte loads run at ~110 G/s: the
+// probes, not bytes, were what the sparse hop cost — 2.4 ms for 3 GB of traffic)
+__global__ __launch_bounds__(256) void bp_coarse_bits_kernel(const u64* __restrict__ bits, u32 nwords, u32 g,
+                                                             u64* __restrict__ coarse, u32 ncoarse_words) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    for (u32 cw = wave; cw < ncoarse_words; cw += nwaves) {
+        const u64 first = ((u64)cw * 64 + lane) << g;   // first fine word of this lane's block
+        u64 any = 0ull;
+        for (u32 k = 0; k < (1u << g); ++k)
+            if (first + k < nwords) any |= bits[first + k];
+        const u64 m = __ballot(any != 0ull);
+        if (lane == 0) coarse[cw] = m;
+    }
+}
+
+struct BpProbe {
+    const u64* bits;    // flag bit per vertex
+    const u64* coarse;  // flag bit per block of 64 << g vertices (staged in LDS)
+    u32 cshift;         // vertex >> cshift = coarse bit (6 + g)
+    u32 cwords;         // 64-bit words of the coarse map
+};
+
 // What happens to a finished row (MODE): 0 = it is stored into Y (split rows OR into it) and flagged — a hop in the
 // middle of a chain; 1 / 2 = the LAST hop of a count-only chain: the row is counted here (2: and its checksum terms
 // summed through the LDS nibble tables) and never written, except for "touched" rows — rows cut into several items or
@@ -226,16 +278,24 @@ struct BpFinal {
 
 template <int LN, bool SPARSE, int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView at, const u32* __restrict__ items, u32 nitems, u32 ws,
-                                                     const u64* __restrict__ x, const u64* __restrict__ xbits,
+                                                     const u64* __restrict__ x, BpProbe pr,
                                                      u64* __restrict__ y, uint8_t* __restrict__ yflag, BpFinal fin) {
     // MODE 2 runs 1024-thread workgroups: the 2 KiB-per-word tables are shared by 16 wavefronts, so the LDS they take
     // does not cost resident wavefronts (the gathers are latency-bound: 20 instead of 32 waves per CU made the dense
     // hop 1.6 x slower when every 256-thread workgroup carried its own copy)
     extern __shared__ u64 s_tab[];
-    if (MODE == 2) {
+    const u64* __restrict__ xbits = pr.bits;
+    const u32* s_co = reinterpret_cast<const u32*>(s_tab + (MODE == 2 ? fin.w * 256 : 0));   // coarse flag map (SPARSE)
+    if (MODE == 2)
         for (u32 i = threadIdx.x; i < fin.w * 256; i += blockDim.x) s_tab[i] = fin.tab[i];
-        __syncthreads();
+    if (SPARSE) {
+        u64* co = s_tab + (MODE == 2 ? fin.w * 256 : 0);
+        for (u32 i = threadIdx.x; i < pr.cwords; i += blockDim.x) co[i] = pr.coarse[i];
     }
+    if (MODE == 2 || SPARSE) __syncthreads();
+    // per-wavefront list of an item's live neighbours (SPARSE): BP_ITEM ids behind the tables and the coarse map
+    u32* s_live = reinterpret_cast<u32*>(s_tab + (MODE == 2 ? fin.w * 256 : 0) + (SPARSE ? pr.cwords : 0)) +
+                  (threadIdx.x >> 6) * BP_ITEM;
     u64 f_cnt = 0, f_sum = 0;
     constexpr int SLOTS = 64 / LN;
     const u32 lane = lane_id();
@@ -252,41 +312,55 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
         const u32 e = e3 & 0x7FFFFFFFu;
         const bool split = (e3 >> 31) != 0;
         bool any = false;
+        u32 n_live = 0;
+        if (SPARSE) {
+            // all four 64-entry trips of an item issue their column-id loads and their flag probes before any of them
+            // is consumed (a trip is a chain of two dependent round trips: column id -> flag word); the flagged
+            // neighbours are then compacted, in entry order, into the wavefront's list in LDS
+            u32 un[4];
+            u64 live[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 q = b + 64 * k + lane;
+                un[k] = (q < e) ? at.colidx[q] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool hit = un[k] != 0xFFFFFFFFu;
+                if (hit) {
+                    const u32 cb = un[k] >> pr.cshift;
+                    hit = (s_co[cb >> 5] >> (cb & 31)) & 1u;
+                }
+                if (hit) hit = (xbits[un[k] >> 6] >> (un[k] & 63)) & 1ull;
+                live[k] = __ballot(hit);
+            }
+            const u64 below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((live[k] >> lane) & 1ull) s_live[n_live + (u32)__popcll(live[k] & below)] = un[k];
+                n_live += (u32)__popcll(live[k]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is read by other lanes of this wavefront
+            __builtin_amdgcn_wave_barrier();
+        }
         for (u32 wb = 0; wb < nwb; ++wb) {
             const u32 wo = wb * LN + wl;
             u64 acc = 0ull;
             if (SPARSE) {
-                // all four 64-entry trips of an item issue their column-id loads and their flag probes before any of
-                // them is consumed: a trip is a chain of two dependent round trips (column id -> flag word)
-                u32 un[4];
-                u64 live[4];
+                // the item's live neighbours were compacted into the wavefront's LDS list: 4 gathers in flight per lane,
+                // as in the dense form (a loop that took SLOTS flagged neighbours per trip and waited for their rows
+                // before taking the next ones ran at one memory round trip per SLOTS rows: 2.6 ms a hop at RMAT-24)
+                for (u32 i0 = 0; i0 < n_live; i0 += 4 * SLOTS) {
+                    u32 u[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const u32 q = b + 64 * k + lane;
-                    un[k] = (q < e) ? at.colidx[q] : 0xFFFFFFFFu;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool hit = un[k] != 0xFFFFFFFFu && ((xbits[un[k] >> 6] >> (un[k] & 63)) & 1ull);
-                    live[k] = __ballot(hit);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    u64 lv = live[k];
-                    while (lv) {   // wave-uniform: SLOTS flagged neighbours per trip
-                        u32 src = 0;
-                        bool on = false;
-#pragma unroll
-                        for (int sl = 0; sl < SLOTS; ++sl) {
-                            if (lv) {
-                                const u32 idx = (u32)__builtin_ctzll(lv);
-                                lv &= lv - 1ull;
-                                if ((int)slot == sl) { src = idx; on = true; }
-                            }
-                        }
-                        const u32 uu = (u32)__shfl((int)un[k], (int)src, 64);
-                        if (on) acc |= x[(size_t)uu * ws + wo];
+                    for (int k = 0; k < 4; ++k) {
+                        const u32 i = i0 + k * SLOTS + slot;
+                        u[k] = (i < n_live) ? s_live[i] : 0xFFFFFFFFu;
                     }
+                    u64 xv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xv[k] = (u[k] != 0xFFFFFFFFu) ? x[(size_t)u[k] * ws + wo] : 0ull;
+                    acc |= (xv[0] | xv[1]) | (xv[2] | xv[3]);
                 }
             } else {
                 // 4 gathers in flight per lane
@@ -344,6 +418,126 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
             atomicAdd(&fin.acc[0], (unsigned long long)f_cnt);
             if (MODE == 2) atomicAdd(&fin.acc[1], (unsigned long long)f_sum);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// sparse pull, row-group form (a mid-chain hop whose X has few non-zero rows)
+// ---------------------------------------------------------------------------------
+// The item form gives a wavefront one row at a time: at RMAT-24 that is 8.5 M items of ~30 entries, each a chain of five
+// dependent round trips (item -> column ids -> flag words -> rows of X -> Y) run at 12 % lane occupancy — 2.3 ms a hop
+// whatever is done to the probes.  Here a wavefront takes BP_GROUP consecutive rows: their entries are one contiguous
+// range of A', walked a lane per entry (the row of an entry by a 5-step search of the group's offsets in LDS), flagged
+// neighbours are compacted into a list of (row, id) pairs, their rows of X are OR-ed into the group's accumulator in
+// LDS (ds_or_b64), and the non-zero rows are written to Y once, coalesced.  Rows of more than BP_ITEM entries are left
+// to the item kernel (bp_sitems): they OR into Y with atomics and would stall a group.
+constexpr u32 BP_GROUP = 32;
+constexpr u32 BP_GROUP_WAVES = 8;   // wavefronts per workgroup
+template <int LN>
+__global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(CsrView at, u32 nrows, const u64* __restrict__ x,
+                                                                             BpProbe pr, u64* __restrict__ y,
+                                                                             uint8_t* __restrict__ yflag) {
+    constexpr int SLOTS = 64 / LN;
+    constexpr u32 R = BP_GROUP;
+    extern __shared__ u64 s_mem[];
+    const u32* s_co = reinterpret_cast<const u32*>(s_mem);
+    for (u32 i = threadIdx.x; i < pr.cwords; i += blockDim.x) s_mem[i] = pr.coarse[i];
+    const u32 lane = lane_id();
+    const u32 wv = threadIdx.x >> 6;
+    u64* acc = s_mem + pr.cwords + (size_t)wv * ((size_t)R * LN + 256 + 32);   // R rows of LN words
+    u64* list = acc + (size_t)R * LN;                                           // (row << 32 | id) of up to 256 live entries
+    u32* pref = reinterpret_cast<u32*>(list + 256);                             // [0, R): entry offset of a row in the group
+    u32* base = pref + R;                                                       // [0, R): rowptr - pref
+    for (u32 i = lane; i < R * LN; i += 64) acc[i] = 0ull;
+    __syncthreads();
+    const u32 wl = lane % LN, slot = lane / LN;
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
+    const u32 ngroups = (nrows + R - 1) / R;
+    const u64 below = (1ull << lane) - 1ull;
+    for (u32 g = wave; g < ngroups; g += nwaves) {
+        const u32 v0 = g * R;
+        const u32 ri = v0 + lane < nrows ? v0 + lane : nrows;
+        const u32 rp = at.rowptr[ri];
+        const u32 rp1 = (u32)__shfl_down((int)rp, 1, 64);
+        u32 deg = lane < R ? rp1 - rp : 0u;
+        if (deg > BP_ITEM) deg = 0u;                     // split rows: the item kernel's
+        u32 incl = deg;
+#pragma unroll
+        for (int d = 1; d < (int)R; d <<= 1) {
+            const u32 t = (u32)__shfl_up((int)incl, d, 64);
+            if ((int)lane >= d) incl += t;
+        }
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, R - 1);
+        if (total == 0) continue;
+        if (lane < R) {
+            pref[lane] = incl - deg;
+            base[lane] = rp - (incl - deg);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 t0 = 0; t0 < total; t0 += 256) {
+            u32 un[4], rw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 t = t0 + 64 * k + lane;
+                u32 lo = 0;                                  // largest row with pref[row] <= t
+#pragma unroll
+                for (u32 step = R / 2; step >= 1; step >>= 1)
+                    if (pref[lo + step] <= t) lo += step;
+                rw[k] = lo;
+                un[k] = (t < total) ? at.colidx[t + base[lo]] : 0xFFFFFFFFu;
+            }
+            u64 live[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool hit = un[k] != 0xFFFFFFFFu;
+                if (hit) {
+                    const u32 cb = un[k] >> pr.cshift;
+                    hit = (s_co[cb >> 5] >> (cb & 31)) & 1u;
+                }
+                if (hit) hit = (pr.bits[un[k] >> 6] >> (un[k] & 63)) & 1ull;
+                live[k] = __ballot(hit);
+            }
+            u32 n_live = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((live[k] >> lane) & 1ull) list[n_live + (u32)__popcll(live[k] & below)] = ((u64)rw[k] << 32) | un[k];
+                n_live += (u32)__popcll(live[k]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (u32 i0 = 0; i0 < n_live; i0 += 4 * SLOTS) {
+                u64 pu[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 i = i0 + k * SLOTS + slot;
+                    pu[k] = (i < n_live) ? list[i] : ~0ull;
+                }
+                u64 xv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[k] = (pu[k] != ~0ull) ? x[(size_t)(u32)pu[k] * LN + wl] : 0ull;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (xv[k]) atomicOr((unsigned long long*)&acc[(u32)(pu[k] >> 32) * LN + wl], (unsigned long long)xv[k]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // flush: SLOTS rows per step, a row's LN words on LN consecutive lanes
+        for (u32 r0 = 0; r0 < R; r0 += SLOTS) {
+            const u32 row = r0 + slot;
+            const u64 a = row < R ? acc[row * LN + wl] : 0ull;   // (LN == 1: 64 slots, 32 rows)
+            if (a) {
+                y[(size_t)(v0 + row) * LN + wl] = a;
+                acc[row * LN + wl] = 0ull;
+            }
+            const u64 nzm = __ballot(a != 0ull);
+            const u64 mine = LN == 64 ? nzm : (nzm >> (slot * LN)) & ((1ull << (LN % 64)) - 1ull);
+            if (wl == 0 && mine) yflag[v0 + row] = 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -760,7 +954,13 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     uint8_t* yflag = ca ? nullptr : o.flag.p;
     int pull_idx = -1;
     if (m->nnz) {
-        const u32 nitems = t->n_bp_items;
+        // (the sparse form stages a <= 16 KiB coarse flag map in LDS next to the checksum tables of MODE 2)
+        const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n &&
+                            lds + 16384 + 16 * BP_ITEM * sizeof(u32) <= (size_t)ctx->opt.lds_limit;
+        // row-group form: rows of <= BP_ITEM entries by bp_pull_groups_kernel, the split rows' items by the item kernel
+        const bool groups = sparse && mode == 0 && s.ws <= 16 && ctx->opt.expand_row_groups;
+        const u32 nitems = groups ? t->n_bp_sitems : t->n_bp_items;
+        const u32* item_list = groups ? t->bp_sitems : t->bp_items;
         u32 grid = cdiv(nitems ? nitems : 1, 4);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
         const u32 threads = mode == 2 ? 1024 : 256;
@@ -770,13 +970,25 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         }
         const u32 ln = s.ws < 64 ? s.ws : 64;
         // fewer than 1 row in 8 flagged: probing a flag bit per neighbour first beats gathering 8 W-byte rows
-        const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n;
-        DevBuf<u64> xbits;
+        DevBuf<u64> xbits, xcoarse;
+        BpProbe pr = {nullptr, nullptr, 0, 0};
+        size_t lds_co = 0;
         if (sparse) {
-            FGPU_TRY(xbits.alloc(ctx, ((size_t)s.n + 63) / 64 + 1));
+            const u32 nw = (u32)(((size_t)s.n + 63) / 64);
+            FGPU_TRY(xbits.alloc(ctx, (size_t)nw + 1));
             hipLaunchKernelGGL(bp_flag_bits_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), (const uint8_t*)s.flag.p,
                                s.n, xbits.p);
             FGPU_HIP(hipGetLastError());
+            u32 g = 0;                                    // coarse map <= 16 KiB = 2048 words of 64 blocks
+            while ((((u64)nw + (1ull << g) - 1) >> g) > 2048ull * 64ull) ++g;
+            const u32 nblocks = (u32)(((u64)nw + (1ull << g) - 1) >> g);
+            const u32 cwords = (nblocks + 63) / 64;
+            FGPU_TRY(xcoarse.alloc(ctx, (size_t)cwords + 1));
+            hipLaunchKernelGGL(bp_coarse_bits_kernel, dim3(cdiv(cwords, 4)), dim3(256), 0, ctx->stream(), (const u64*)xbits.p, nw, g,
+                               xcoarse.p, cwords);
+            FGPU_HIP(hipGetLastError());
+            pr = BpProbe{xbits.p, xcoarse.p, 6 + g, cwords};
+            lds_co = (size_t)cwords * sizeof(u64);
         }
         // algorithmic bytes of the launch: the column ids of A' and the item list once, every non-zero X row once
         // (the per-entry row gathers beyond that are cache traffic), the flag bitmap in the sparse form; the
@@ -788,12 +1000,12 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         ps.idx_out = &pull_idx;
 #define BP_LAUNCH3(LN, SP, MD)                                                                                          \
     do {                                                                                                                \
-        if (lds > 48 * 1024)                                                                                            \
+        const size_t lds_all = (MD == 2 ? lds : 0) + (SP ? lds_co + (threads / 64) * BP_ITEM * sizeof(u32) : 0);        \
+        if (lds_all > 48 * 1024)                                                                                        \
             FGPU_HIP(hipFuncSetAttribute((const void*)bp_pull_kernel<LN, SP, MD>,                                       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hipLaunchKernelGGL((bp_pull_kernel<LN, SP, MD>), dim3(grid), dim3(threads), (MD == 2 ? lds : 0), ctx->stream(), \
-                           view_of(t), (const u32*)t->bp_items, nitems, s.ws, (const u64*)s.x.p,                        \
-                           (const u64*)(SP ? xbits.p : nullptr), ydst, yflag, fin);                                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all));                    \
+        hipLaunchKernelGGL((bp_pull_kernel<LN, SP, MD>), dim3(grid), dim3(threads), lds_all, ctx->stream(),             \
+                           view_of(t), item_list, nitems, s.ws, (const u64*)s.x.p, pr, ydst, yflag, fin);               \
     } while (0)
 #define BP_LAUNCH(LN)                                                                                                   \
     do {                                                                                                                \
@@ -801,7 +1013,32 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         else if (mode == 1) { if (sparse) BP_LAUNCH3(LN, true, 1); else BP_LAUNCH3(LN, false, 1); }                     \
         else { if (sparse) BP_LAUNCH3(LN, true, 2); else BP_LAUNCH3(LN, false, 2); }                                    \
     } while (0)
-        switch (ln) {
+        if (groups) {
+            const size_t per_wave = ((size_t)BP_GROUP * s.ws + 256 + 32) * sizeof(u64);
+            const size_t lds_g = lds_co + BP_GROUP_WAVES * per_wave;
+            u32 wgs = (u32)((size_t)ctx->opt.lds_limit / lds_g);
+            if (wgs < 1) wgs = 1;
+            if (wgs > 4) wgs = 4;
+            const u32 ggrid = (u32)ctx->cus * wgs;
+#define BP_GROUPS(LN)                                                                                                   \
+    do {                                                                                                                \
+        if (lds_g > 48 * 1024)                                                                                          \
+            FGPU_HIP(hipFuncSetAttribute((const void*)bp_pull_groups_kernel<LN>,                                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));                      \
+        hipLaunchKernelGGL(bp_pull_groups_kernel<LN>, dim3(ggrid), dim3(BP_GROUP_WAVES * 64), lds_g, ctx->stream(),     \
+                           view_of(t), (u32)t->nrows, (const u64*)s.x.p, pr, ydst, yflag);                              \
+    } while (0)
+            switch (s.ws) {
+                case 1: BP_GROUPS(1); break;
+                case 2: BP_GROUPS(2); break;
+                case 4: BP_GROUPS(4); break;
+                case 8: BP_GROUPS(8); break;
+                default: BP_GROUPS(16); break;
+            }
+#undef BP_GROUPS
+            FGPU_HIP(hipGetLastError());
+        }
+        if (nitems) switch (ln) {
             case 1: BP_LAUNCH(1); break;
             case 2: BP_LAUNCH(2); break;
             case 4: BP_LAUNCH(4); break;

@@ -66,6 +66,7 @@ struct fgpu_options {  // fgpu_set_option
     int tiled_threads = 1024;  // its workgroup size
     int tiled_wgs = 0;         // its grid (0 = one workgroup per CU)
     int expand_mode = 0;       // 0 auto, 1 sorted-CSR products only, 2 bit-parallel from the first hop
+    int expand_row_groups = 1; // sparse mid-chain pull: a wavefront per 32-row group (0 = a wavefront per row item)
     int expand_fuse_count = 1; // fgpu_expand_count: the last bit-parallel hop counts its rows in place (0 = separate count pass)
     int bfs_wgs_per_cu = 6;    // grid of the fused BFS level kernel, workgroups per CU
     int bfs_tiny = 2;          // consecutive tiny BFS levels in one single-workgroup launch (bfs_tiny_kernel): 0 off, 1 on,
@@ -224,6 +225,8 @@ struct fgpu_mat {
     mutable fgpu_mat* tcache = nullptr;
     mutable uint32_t* bp_items = nullptr;  // triples (row, begin, end | split << 31)
     mutable uint32_t n_bp_items = 0;
+    mutable uint32_t* bp_sitems = nullptr; // the items of split rows only (rows of more than BP_ITEM entries)
+    mutable uint32_t n_bp_sitems = 0;
     mutable uint64_t* bp_split_bits = nullptr;  // on the cached transpose: bit v set <=> row v is cut into several items
     bool is_hyper() const { return hrows != nullptr; }
 };

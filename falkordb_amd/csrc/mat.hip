@@ -32,6 +32,7 @@ void mat_release(fgpu_mat* m) {
     }
     tiles_release(m->tiles);
     if (c) c->dev_free(m->bp_items);
+    if (c) c->dev_free(m->bp_sitems);
     if (c) c->dev_free(m->bp_split_bits);
     if (m->tcache) mat_release(m->tcache);
     delete m;
