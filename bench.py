@@ -141,6 +141,31 @@ def live_pmc(args, timeout_s=420):
     return res
 
 
+def probe_reference_libs():
+    """look for the reference's own CPU libraries on this box before falling back to the port.  They
+    are not part of this image (no SuiteSparse:GraphBLAS, no LAGraph, no python-graphblas), so the expected answer is
+    "absent" — recorded in the bench line so the label "port" is checked, not assumed."""
+    import ctypes.util
+    import glob
+    found = {}
+    dirs = ("/usr/lib", "/usr/lib64", "/usr/local/lib", "/usr/lib/x86_64-linux-gnu", "/opt/lib", "/opt/local/lib")
+    for lib in ("graphblas", "lagraph", "lagraphx"):
+        path = ctypes.util.find_library(lib)          # ldconfig cache + the linker's search path
+        if not path:
+            hits = [h for d in dirs for h in glob.glob(os.path.join(d, f"lib{lib}.so*"))][:1]
+            path = hits[0] if hits else None
+        found["lib" + lib] = path
+    try:
+        import importlib.util
+        found["python_graphblas"] = importlib.util.find_spec("graphblas") is not None
+    except Exception:
+        found["python_graphblas"] = False
+    hdr = [h for h in ("/usr/include/GraphBLAS.h", "/usr/include/suitesparse/GraphBLAS.h", "/usr/local/include/GraphBLAS.h",
+                       "/usr/local/include/suitesparse/GraphBLAS.h") if os.path.exists(h)]
+    found["GraphBLAS.h"] = hdr[0] if hdr else None
+    return found
+
+
 def _cgroup_cpus():
     """CPUs the job may use per CFS period (cgroup v2 cpu.max or v1 cfs_quota/period); None when unlimited."""
     try:
@@ -688,6 +713,7 @@ def main():
                          f"{'push/pull' if at is not None else 'push-only (no transposed copy on the host at this size)'} BFS "
                          f"(oracle/oracle_omp.c orc_bfs_omp) on {threads} threads; CPU stand-in for "
                          f"LAGraph + SuiteSparse:GraphBLAS, which are absent from this image",
+               "reference_libs_probe": probe_reference_libs(),
                "threads_calibration_MTEPS": calib, "host_cpus_visible": ncpu, "cgroup_cpu_quota": quota,
                "serial": {"value": round(e_ser / t_ser, 1), "cores": 1,
                           "sample": f"{ks} roots, {t_ser:.1f} s, serial queue BFS (oracle/oracle.c orc_bfs)"}}

@@ -162,6 +162,56 @@ def test_expand_modes_match_oracle(ctx, mode, k):
         ctx.set_option("expand_fuse_count", 1)
 
 
+@pytest.mark.parametrize("k", [1, 3, 100, 200, 500, 1000])
+@pytest.mark.parametrize("dirty", [False, True])
+def test_sparse_pull_row_groups_match_the_item_form_and_the_oracle(ctx, k, dirty):
+    """The sparse mid-chain pull of the bit-parallel form (bp_pull_groups_kernel: a wavefront per 32 rows of A', split
+    rows left to the item kernel) on a graph built to hit its corners: a vertex count that is not a multiple of 32 or
+    64, in-degrees of 0, 1, exactly 256 (one item), 257 (the smallest split row), ~600 and > 4096 (hub chunks), rows
+    inside one group that mix all of these; k spans every row stride 1 / 2 / 4 / 8 / 16 words.  expand_mode 2 puts the
+    first hop in bit form, where X holds only the sources: the sparse pull runs.  Both forms, the oracle, flops."""
+    n = 5000 + 17
+    rng = np.random.default_rng(77 + k)
+    rows, cols = [], []
+    def fan_in(dst, deg):
+        srcs = rng.choice(n, deg, replace=False)
+        rows.extend(srcs.tolist()); cols.extend([dst] * deg)
+    for dst, deg in [(0, 256), (1, 257), (2, 600), (31, 1), (32, 4500), (33, 255), (63, 300), (n - 1, 258), (n - 2, 256),
+                     (4990, 5000), (100, 64), (101, 65), (102, 63)]:
+        fan_in(dst, deg)
+    extra = 20000
+    rows.extend(rng.integers(0, n, extra).tolist()); cols.extend(rng.integers(0, n, extra).tolist())
+    a = oracle.build_csr(n, n, np.array(rows, dtype=U64), np.array(cols, dtype=U64))
+    dp, dm = _delta_layers(a, rng, 80, 80) if dirty else (None, None)
+    src = rng.integers(0, n, k).astype(U64)
+    f = oracle.build_csr(k, n, np.arange(k, dtype=U64), src)
+    A = up(ctx, a)
+    DP, DM = (up(ctx, dp), up(ctx, dm)) if dirty else (None, None)
+    ctx.set_option("expand_mode", 2)
+    try:
+        for hops in (1, 2, 3):
+            c, flops_ref = f, 0
+            for _ in range(hops):
+                c, fl = oracle.delta_lmxm(c, a, dp, dm)
+                flops_ref += fl
+            mats = [A] * hops
+            dps = [DP] * hops if dirty else None
+            dms = [DM] * hops if dirty else None
+            got = {}
+            for groups in (1, 0):
+                ctx.set_option("expand_row_groups", groups)
+                rp, dest, flops = engine.expand(ctx, src, mats, dps, dms)
+                np.testing.assert_array_equal(rp, c.rowptr)
+                np.testing.assert_array_equal(dest, c.colidx)
+                assert flops == flops_ref
+                got[groups] = engine.expand_count(ctx, src, mats, dps, dms)
+                assert got[groups] == (c.nnz, oracle.checksum(c), flops_ref)
+            assert got[0] == got[1]
+    finally:
+        ctx.set_option("expand_mode", 0)
+        ctx.set_option("expand_row_groups", 1)
+
+
 @pytest.mark.parametrize("k,with_delta,with_label", [(1, False, False), (70, True, False), (300, True, True),
                                                      (1100, False, True)])
 def test_expand_levels_per_hop_sets_and_distinct_union(ctx, k, with_delta, with_label):

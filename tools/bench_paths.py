@@ -40,10 +40,10 @@ def timed(ctx, fn, reps=5, warm=1):
 def deltas(ctx, A, frac, rng, valued=False):
     n, nnz = A.nrows, A.nvals
     k = max(1, int(nnz * frac))
-    # tombstones: k existing entries; pending adds: k random coordinates
-    rows, cols, _ = A.extract(0, min(n - 1, 1 << 16))
-    pick = rng.choice(len(rows), min(k, len(rows)), replace=False)
-    dm = ctx.mat_from_coo(n, n, rows[pick], cols[pick])
+    # tombstones: a uniformly random `frac` of the stored entries, drawn on the device (fgpu_mat_sample) — the first
+    # version took them from rows [0, 65536] only, which clustered the touched rows and flattered the clean-word
+    # merge path; pending adds: k uniformly random coordinates
+    dm = A.sample(int(rng.integers(1, 1 << 30)), max(1, int(round(1.0 / frac))))
     pr = rng.integers(0, n, k, dtype=np.uint64)
     pc = rng.integers(0, n, k, dtype=np.uint64)
     dp = ctx.mat_from_coo(n, n, pr, pc, rng.integers(0, 1 << 40, k, dtype=np.uint64) if valued else None)
