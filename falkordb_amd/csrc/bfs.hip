@@ -2288,20 +2288,17 @@ fgpu_info fgpu_bfs_fetch(fgpu_bfs_plan* p, int32_t* level, int64_t* parent) {
     std::vector<i32> lv;
     const i32* lvp = level ? level + lo : nullptr;
     if (level) {
-        FGPU_HIP(hipMemcpyAsync(level + lo, p->level + lo, (size_t)(hi - lo) * sizeof(i32), hipMemcpyDeviceToHost,
-                                ctx->stream()));
+        FGPU_TRY(ctx->d2h(level + lo, p->level + lo, (size_t)(hi - lo) * sizeof(i32)));
     } else if (parent) {
         lv.resize(hi - lo);
-        FGPU_HIP(hipMemcpyAsync(lv.data(), p->level + lo, (size_t)(hi - lo) * sizeof(i32), hipMemcpyDeviceToHost,
-                                ctx->stream()));
+        FGPU_TRY(ctx->d2h(lv.data(), p->level + lo, (size_t)(hi - lo) * sizeof(i32)));
         lvp = lv.data();
     }
     std::vector<u32> par;
     if (parent) {
         FGPU_REQUIRE(p->want_parent, FGPU_INVALID, "the last run did not track parents");
         par.resize(hi - lo);
-        FGPU_HIP(hipMemcpyAsync(par.data(), p->parent + lo, (size_t)(hi - lo) * sizeof(u32), hipMemcpyDeviceToHost,
-                                ctx->stream()));
+        FGPU_TRY(ctx->d2h(par.data(), p->parent + lo, (size_t)(hi - lo) * sizeof(u32)));
     }
     FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     if (parent)
@@ -2416,11 +2413,11 @@ fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t
     FGPU_TRY(dw.alloc(ctx, nw));
     FGPU_HIP(hipMemsetAsync(df.p, 0, nw * sizeof(u64), ctx->stream()));
     FGPU_HIP(hipMemsetAsync(dw.p, 0, nw * sizeof(u64), ctx->stream()));
-    FGPU_HIP(hipMemcpyAsync(df.p, f, nw_user * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+    FGPU_TRY(ctx->h2d(df.p, f, nw_user * sizeof(u64)));
     if (mask) {
         FGPU_TRY(dm.alloc(ctx, nw));
         FGPU_HIP(hipMemsetAsync(dm.p, 0, nw * sizeof(u64), ctx->stream()));
-        FGPU_HIP(hipMemcpyAsync(dm.p, mask, nw_user * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+        FGPU_TRY(ctx->h2d(dm.p, mask, nw_user * sizeof(u64)));
     }
     BfsArgs a;
     vxm_args(a, A, At, n, dw.p, nw);
@@ -2435,7 +2432,7 @@ fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t
         hipLaunchKernelGGL(vxm_push_kernel, dim3(grid), dim3(256), 0, ctx->stream(), a, (const u64*)df.p,
                            (const u64*)(mask ? dm.p : nullptr));
     FGPU_HIP(hipGetLastError());
-    FGPU_HIP(hipMemcpyAsync(w, dw.p, nw_user * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
+    FGPU_TRY(ctx->d2h(w, dw.p, nw_user * sizeof(u64)));
     FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     return FGPU_OK;
 }
@@ -2458,7 +2455,7 @@ fgpu_info fgpu_bench_spmv(fgpu_ctx* ctx, const fgpu_mat* A, int which, int iters
     FGPU_HIP(hipMemsetAsync(df.p, 0xFF, (n / 64) * sizeof(u64), ctx->stream()));
     if (n % 64) {
         u64 tail = (1ull << (n % 64)) - 1ull;
-        FGPU_HIP(hipMemcpyAsync(df.p + n / 64, &tail, sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+        FGPU_TRY(ctx->h2d(df.p + n / 64, &tail, sizeof(u64)));
         FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     }
     BfsArgs a;

@@ -89,6 +89,12 @@ struct fgpu_lane {  // one per host thread using the context
     hipEvent_t fence = nullptr;          // recorded on `stream` by a thread that frees a shared object (fence_mu)
     std::mutex fence_mu;
     bool bound = false;                  // a live thread holds it (ctx->mu)
+    // transfer staging (h2d / d2h): two pinned halves, allocated on the lane's first bulk transfer
+    void* xfer = nullptr;
+    size_t xfer_half = 0;
+    hipEvent_t xfer_ev[2] = {nullptr, nullptr};
+    bool xfer_busy[2] = {false, false};
+    int xfer_next = 0;
 };
 
 struct fgpu_prof_entry {   // fgpu_prof_enable / fgpu_prof_read: HIP-event pairs around launches of named kernels
@@ -129,6 +135,14 @@ struct fgpu_ctx {
     fgpu_info publish();
     fgpu_info dev_alloc(void** p, size_t bytes);
     void dev_free(void* p);
+    // Bulk transfers between CALLER memory and the device always go through the lane's pinned halves: a
+    // hipMemcpyAsync on pageable memory makes the runtime pin / unpin the caller's pages, and once a process had
+    // freed and re-used large result buffers a 4 KiB upload was seen to take 27-35 ms that way.
+    // h2d returns once `host` has been consumed (the device copy is ordered on the lane's stream);
+    // d2h / d2h_widen return with the data in `host` (they wait for the stream).
+    fgpu_info h2d(void* dev, const void* host, size_t bytes);
+    fgpu_info d2h(void* host, const void* dev, size_t bytes);
+    fgpu_info d2h_widen(uint64_t* host, const uint32_t* dev, size_t count);   // u32 on the device, u64 for the caller
     void* host_alloc(size_t bytes);
     void host_free(void* p);
     void trim();

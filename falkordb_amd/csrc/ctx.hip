@@ -83,6 +83,9 @@ fgpu_lane* lane_create() {
 void lane_destroy(fgpu_lane* l) {
     if (!l) return;
     if (l->fence) (void)hipEventDestroy(l->fence);
+    for (int k = 0; k < 2; ++k)
+        if (l->xfer_ev[k]) (void)hipEventDestroy(l->xfer_ev[k]);
+    if (l->xfer) (void)hipHostFree(l->xfer);
     if (l->pinned) (void)hipHostFree(l->pinned);
     if (l->own_stream) (void)hipStreamDestroy(l->own_stream);
     delete l;
@@ -265,6 +268,100 @@ void prof_add_bytes(fgpu_ctx* ctx, int idx, uint64_t extra) {
     if ((size_t)idx < ctx->prof.size()) ctx->prof[idx].alg_bytes += extra;
 }
 }  // namespace fgpu
+
+// ---- staged transfers ---------------------------------------------------------------------------
+namespace {
+constexpr size_t XFER_HALF = 4u << 20;   // 4 MiB per half: ~80 us on the link, long enough to hide the host-side copy setup
+
+fgpu_info xfer_ready(fgpu_lane* l) {
+    if (l->xfer) return FGPU_OK;
+    void* p = nullptr;
+    FGPU_HIP(hipHostMalloc(&p, 2 * XFER_HALF, hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) {
+        if (hipEventCreateWithFlags(&l->xfer_ev[k], hipEventDisableTiming) != hipSuccess) {
+            (void)hipHostFree(p);
+            set_error("transfer staging: hipEventCreate failed");
+            return FGPU_DEVICE;
+        }
+    }
+    l->xfer = p;
+    l->xfer_half = XFER_HALF;
+    return FGPU_OK;
+}
+
+// wait until the device copy that last used half k has finished
+fgpu_info xfer_wait(fgpu_lane* l, int k) {
+    if (l->xfer_busy[k]) {
+        FGPU_HIP(hipEventSynchronize(l->xfer_ev[k]));
+        l->xfer_busy[k] = false;
+    }
+    return FGPU_OK;
+}
+}  // namespace
+
+fgpu_info fgpu_ctx::h2d(void* dev, const void* host, size_t bytes) {
+    if (bytes == 0) return FGPU_OK;
+    fgpu_lane* l = lane();
+    FGPU_TRY(xfer_ready(l));
+    const char* src = (const char*)host;
+    char* dst = (char*)dev;
+    for (size_t off = 0; off < bytes; off += l->xfer_half) {
+        const size_t n = bytes - off < l->xfer_half ? bytes - off : l->xfer_half;
+        const int k = l->xfer_next;
+        l->xfer_next ^= 1;
+        FGPU_TRY(xfer_wait(l, k));
+        char* half = (char*)l->xfer + (size_t)k * l->xfer_half;
+        memcpy(half, src + off, n);
+        FGPU_HIP(hipMemcpyAsync(dst + off, half, n, hipMemcpyHostToDevice, l->stream));
+        FGPU_HIP(hipEventRecord(l->xfer_ev[k], l->stream));
+        l->xfer_busy[k] = true;
+    }
+    return FGPU_OK;
+}
+
+namespace {
+// the common loop of d2h / d2h_widen: `unit` device bytes per element, `emit(half, first_element, count)` moves a
+// finished chunk into the caller's buffer while the next chunk is on the link
+template <class Emit>
+fgpu_info d2h_loop(fgpu_lane* l, const char* dev, size_t count, size_t unit, Emit emit) {
+    if (count == 0) return FGPU_OK;
+    FGPU_TRY(xfer_ready(l));
+    const size_t per = l->xfer_half / unit;
+    size_t pend_first = 0, pend_n = 0;
+    int pend_k = -1;
+    for (size_t first = 0; first < count; first += per) {
+        const size_t n = count - first < per ? count - first : per;
+        const int k = l->xfer_next;
+        l->xfer_next ^= 1;
+        FGPU_TRY(xfer_wait(l, k));   // (an earlier h2d may still be reading this half)
+        char* half = (char*)l->xfer + (size_t)k * l->xfer_half;
+        FGPU_HIP(hipMemcpyAsync(half, dev + first * unit, n * unit, hipMemcpyDeviceToHost, l->stream));
+        FGPU_HIP(hipEventRecord(l->xfer_ev[k], l->stream));
+        l->xfer_busy[k] = true;
+        if (pend_k >= 0) {
+            FGPU_TRY(xfer_wait(l, pend_k));
+            emit((const char*)l->xfer + (size_t)pend_k * l->xfer_half, pend_first, pend_n);
+        }
+        pend_k = k; pend_first = first; pend_n = n;
+    }
+    FGPU_TRY(xfer_wait(l, pend_k));
+    emit((const char*)l->xfer + (size_t)pend_k * l->xfer_half, pend_first, pend_n);
+    return FGPU_OK;
+}
+}  // namespace
+
+fgpu_info fgpu_ctx::d2h(void* host, const void* dev, size_t bytes) {
+    char* out = (char*)host;
+    return d2h_loop(lane(), (const char*)dev, bytes, 1, [&](const char* half, size_t first, size_t n) { memcpy(out + first, half, n); });
+}
+
+fgpu_info fgpu_ctx::d2h_widen(uint64_t* host, const uint32_t* dev, size_t count) {
+    return d2h_loop(lane(), (const char*)dev, count, sizeof(u32), [&](const char* half, size_t first, size_t n) {
+        const u32* s = (const u32*)half;
+        u64* d = host + first;
+        for (size_t i = 0; i < n; ++i) d[i] = s[i];
+    });
+}
 
 void* fgpu_ctx::host_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;

@@ -224,7 +224,7 @@ fgpu_info fgpu_mat_balanced_splits(fgpu_ctx* ctx, const fgpu_mat* a, int nparts,
         hipLaunchKernelGGL(colblock_hist_kernel, dim3(grid ? grid : 1), dim3(256), (size_t)nblocks * sizeof(u32), ctx->stream(),
                            (const u32*)a->colidx, (u64)a->nnz, shift, nblocks, dh.p);
         FGPU_HIP(hipGetLastError());
-        FGPU_HIP(hipMemcpyAsync(h.data(), dh.p, (size_t)nblocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream()));
+        FGPU_TRY(ctx->d2h(h.data(), dh.p, (size_t)nblocks * sizeof(unsigned long long)));
         FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     }
     // boundary k sits at the block edge whose entry prefix is nearest to k * nnz / nparts (edges never move backwards)

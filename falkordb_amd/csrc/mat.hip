@@ -217,20 +217,15 @@ static fgpu_info upload_host_csr(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 n
     u64 nnz = colidx.size();
     fgpu_mat* m = nullptr;
     FGPU_TRY(mat_alloc(ctx, &m, nrows, ncols, nnz, vals != nullptr, (u32)hrows_or_empty.size(), hyper));
-    hipError_t e = hipMemcpyAsync(m->rowptr, rowptr.data(), rowptr.size() * sizeof(u32), hipMemcpyHostToDevice,
-                                  ctx->stream());
-    if (e == hipSuccess && nnz)
-        e = hipMemcpyAsync(m->colidx, colidx.data(), nnz * sizeof(u32), hipMemcpyHostToDevice, ctx->stream());
-    if (e == hipSuccess && vals && nnz)
-        e = hipMemcpyAsync(m->vals, vals->data(), nnz * sizeof(u64), hipMemcpyHostToDevice, ctx->stream());
-    if (e == hipSuccess && hyper && !hrows_or_empty.empty())
-        e = hipMemcpyAsync(m->hrows, hrows_or_empty.data(), hrows_or_empty.size() * sizeof(u32),
-                           hipMemcpyHostToDevice, ctx->stream());
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());  // host vectors die with the caller
-    if (e != hipSuccess) {
-        set_error("matrix upload failed: %s", hipGetErrorString(e));
+    // (h2d returns once the host vectors have been consumed: they die with the caller)
+    fgpu_info u = ctx->h2d(m->rowptr, rowptr.data(), rowptr.size() * sizeof(u32));
+    if (u == FGPU_OK && nnz) u = ctx->h2d(m->colidx, colidx.data(), nnz * sizeof(u32));
+    if (u == FGPU_OK && vals && nnz) u = ctx->h2d(m->vals, vals->data(), nnz * sizeof(u64));
+    if (u == FGPU_OK && hyper && !hrows_or_empty.empty())
+        u = ctx->h2d(m->hrows, hrows_or_empty.data(), hrows_or_empty.size() * sizeof(u32));
+    if (u != FGPU_OK) {
         mat_release(m);
-        return FGPU_DEVICE;
+        return u;
     }
     fgpu_info i = mat_finalize(m);
     if (i != FGPU_OK) { mat_release(m); return i; }
@@ -623,11 +618,11 @@ static fgpu_info mat_from_coo_impl(fgpu_ctx* ctx, fgpu_mat** out, uint64_t nrows
         DevBuf<u64> dv;
         FGPU_TRY(dr.alloc(ctx, n));
         FGPU_TRY(dc.alloc(ctx, n));
-        FGPU_HIP(hipMemcpyAsync(dr.p, r32.data(), n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream()));
-        FGPU_HIP(hipMemcpyAsync(dc.p, c32.data(), n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream()));
+        FGPU_TRY(ctx->h2d(dr.p, r32.data(), n * sizeof(u32)));
+        FGPU_TRY(ctx->h2d(dc.p, c32.data(), n * sizeof(u32)));
         if (vals) {
             FGPU_TRY(dv.alloc(ctx, n));
-            FGPU_HIP(hipMemcpyAsync(dv.p, vals, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+            FGPU_TRY(ctx->h2d(dv.p, vals, n * sizeof(u64)));
         }
         FGPU_HIP(hipStreamSynchronize(ctx->stream()));
         if (vals) return mat_from_device_coo_vals(ctx, out, nrows, ncols, dr.p, dc.p, dv.p, n);
@@ -757,17 +752,16 @@ static fgpu_info download_mat(fgpu_ctx* ctx, const fgpu_mat* m, std::vector<u32>
                               std::vector<u64>& vv, std::vector<u32>& hr) {
     rp.resize((size_t)m->nvec + 1);
     ci.resize(m->nnz);
-    FGPU_HIP(hipMemcpyAsync(rp.data(), m->rowptr, rp.size() * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
+    FGPU_TRY(ctx->d2h(rp.data(), m->rowptr, rp.size() * sizeof(u32)));
     if (m->nnz)
-        FGPU_HIP(hipMemcpyAsync(ci.data(), m->colidx, m->nnz * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
+        FGPU_TRY(ctx->d2h(ci.data(), m->colidx, m->nnz * sizeof(u32)));
     if (m->vals && m->nnz) {
         vv.resize(m->nnz);
-        FGPU_HIP(hipMemcpyAsync(vv.data(), m->vals, m->nnz * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
+        FGPU_TRY(ctx->d2h(vv.data(), m->vals, m->nnz * sizeof(u64)));
     }
     if (m->hrows && m->nvec) {
         hr.resize(m->nvec);
-        FGPU_HIP(hipMemcpyAsync(hr.data(), m->hrows, (size_t)m->nvec * sizeof(u32), hipMemcpyDeviceToHost,
-                                ctx->stream()));
+        FGPU_TRY(ctx->d2h(hr.data(), m->hrows, (size_t)m->nvec * sizeof(u32)));
     }
     FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     return FGPU_OK;
@@ -776,9 +770,6 @@ static fgpu_info download_mat(fgpu_ctx* ctx, const fgpu_mat* m, std::vector<u32>
 fgpu_info fgpu_mat_export_csr(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t** rowptr, uint64_t** colidx,
                               uint64_t** vals, uint64_t* nnz) {
     FGPU_REQUIRE(ctx && m && rowptr && colidx && nnz, FGPU_NULL_POINTER, "fgpu_mat_export_csr: NULL argument");
-    std::vector<u32> rp, ci, hr;
-    std::vector<u64> vv;
-    FGPU_TRY(download_mat(ctx, m, rp, ci, vv, hr));
     u64* orp = (u64*)ctx->host_alloc((m->nrows + 1) * sizeof(u64));
     u64* oci = (u64*)ctx->host_alloc((m->nnz ? m->nnz : 1) * sizeof(u64));
     u64* ov = (vals && m->vals) ? (u64*)ctx->host_alloc((m->nnz ? m->nnz : 1) * sizeof(u64)) : nullptr;
@@ -787,15 +778,27 @@ fgpu_info fgpu_mat_export_csr(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t** rowpt
         set_error("fgpu_mat_export_csr: host allocation failed");
         return FGPU_OOM;
     }
+    // ids are 32-bit on the device and 64-bit for the caller (GrB_Index): widened chunk by chunk on the way out of the
+    // pinned staging halves, straight into the caller's arrays (no intermediate host copy)
+    fgpu_info i = FGPU_OK;
     if (m->is_hyper()) {
-        memset(orp, 0, (m->nrows + 1) * sizeof(u64));
-        for (u32 i = 0; i < m->nvec; ++i) orp[hr[i] + 1] = rp[i + 1] - rp[i];
-        for (u64 r = 0; r < m->nrows; ++r) orp[r + 1] += orp[r];
+        std::vector<u32> rp((size_t)m->nvec + 1), hr(m->nvec);
+        i = ctx->d2h(rp.data(), m->rowptr, rp.size() * sizeof(u32));
+        if (i == FGPU_OK && m->nvec) i = ctx->d2h(hr.data(), m->hrows, (size_t)m->nvec * sizeof(u32));
+        if (i == FGPU_OK) {
+            memset(orp, 0, (m->nrows + 1) * sizeof(u64));
+            for (u32 k = 0; k < m->nvec; ++k) orp[hr[k] + 1] = rp[k + 1] - rp[k];
+            for (u64 r = 0; r < m->nrows; ++r) orp[r + 1] += orp[r];
+        }
     } else {
-        for (u64 r = 0; r <= m->nrows; ++r) orp[r] = rp[r];
+        i = ctx->d2h_widen(orp, m->rowptr, m->nrows + 1);
     }
-    for (u64 i = 0; i < m->nnz; ++i) oci[i] = ci[i];
-    if (ov) memcpy(ov, vv.data(), m->nnz * sizeof(u64));
+    if (i == FGPU_OK && m->nnz) i = ctx->d2h_widen(oci, m->colidx, m->nnz);
+    if (i == FGPU_OK && ov && m->nnz) i = ctx->d2h(ov, m->vals, m->nnz * sizeof(u64));
+    if (i != FGPU_OK) {
+        ctx->host_free(orp); ctx->host_free(oci); ctx->host_free(ov);
+        return i;
+    }
     *rowptr = orp;
     *colidx = oci;
     if (vals) *vals = ov;
@@ -816,8 +819,7 @@ fgpu_info fgpu_mat_extract(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t min_row, u
     u32 i0, i1;
     if (m->is_hyper()) {
         hr.resize(m->nvec);
-        FGPU_HIP(hipMemcpyAsync(hr.data(), m->hrows, (size_t)m->nvec * sizeof(u32), hipMemcpyDeviceToHost,
-                                ctx->stream()));
+        FGPU_TRY(ctx->d2h(hr.data(), m->hrows, (size_t)m->nvec * sizeof(u32)));
         FGPU_HIP(hipStreamSynchronize(ctx->stream()));
         i0 = (u32)(std::lower_bound(hr.begin(), hr.end(), (u32)min_row) - hr.begin());
         i1 = (u32)(std::upper_bound(hr.begin(), hr.end(), (u32)max_row) - hr.begin());
@@ -827,17 +829,16 @@ fgpu_info fgpu_mat_extract(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t min_row, u
     }
     if (i0 >= i1) return FGPU_OK;
     std::vector<u32> rp(i1 - i0 + 1);
-    FGPU_HIP(hipMemcpyAsync(rp.data(), m->rowptr + i0, rp.size() * sizeof(u32), hipMemcpyDeviceToHost,
-                            ctx->stream()));
+    FGPU_TRY(ctx->d2h(rp.data(), m->rowptr + i0, rp.size() * sizeof(u32)));
     FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     u64 b = rp.front(), e = rp.back(), cnt = e - b;
     if (cnt == 0) return FGPU_OK;
     std::vector<u32> ci(cnt);
     std::vector<u64> vv;
-    FGPU_HIP(hipMemcpyAsync(ci.data(), m->colidx + b, cnt * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
+    FGPU_TRY(ctx->d2h(ci.data(), m->colidx + b, cnt * sizeof(u32)));
     if (vals && m->vals) {
         vv.resize(cnt);
-        FGPU_HIP(hipMemcpyAsync(vv.data(), m->vals + b, cnt * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
+        FGPU_TRY(ctx->d2h(vv.data(), m->vals + b, cnt * sizeof(u64)));
     }
     FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     u64* orow = (u64*)ctx->host_alloc(cnt * sizeof(u64));
@@ -883,14 +884,14 @@ fgpu_info fgpu_mat_probe(fgpu_ctx* ctx, const fgpu_mat* m, const uint64_t* rows,
     FGPU_TRY(dc.alloc(ctx, n));
     FGPU_TRY(dp.alloc(ctx, n));
     if (vals) FGPU_TRY(dv.alloc(ctx, n));
-    FGPU_HIP(hipMemcpyAsync(dr.p, rows, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
-    FGPU_HIP(hipMemcpyAsync(dc.p, cols, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+    FGPU_TRY(ctx->h2d(dr.p, rows, n * sizeof(u64)));
+    FGPU_TRY(ctx->h2d(dc.p, cols, n * sizeof(u64)));
     hipLaunchKernelGGL(probe_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream(), view_of(m),
                        (const u64*)m->vals, (const u64*)dr.p, (const u64*)dc.p, n, m->nrows, m->ncols, dp.p,
                        vals ? dv.p : (u64*)nullptr);
     FGPU_HIP(hipGetLastError());
-    FGPU_HIP(hipMemcpyAsync(present, dp.p, n, hipMemcpyDeviceToHost, ctx->stream()));
-    if (vals) FGPU_HIP(hipMemcpyAsync(vals, dv.p, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
+    FGPU_TRY(ctx->d2h(present, dp.p, n));
+    if (vals) FGPU_TRY(ctx->d2h(vals, dv.p, n * sizeof(u64)));
     FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     return FGPU_OK;
 }

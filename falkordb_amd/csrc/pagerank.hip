@@ -282,7 +282,7 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
                 n_act += (u64)__builtin_popcountll(x);
             }
             FGPU_TRY(act.alloc(ctx, words));
-            FGPU_HIP(hipMemcpyAsync(act.p, active_bitmap, words * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+            FGPU_TRY(ctx->h2d(act.p, active_bitmap, words * sizeof(u64)));
             FGPU_TRY(deg.alloc(ctx, n));
             hipLaunchKernelGGL(pr_degree_kernel, dim3(nb), dim3(256), 0, ctx->stream(), view_of(A), (const u64*)act.p, n,
                                deg.p);
@@ -359,7 +359,7 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
             for (auto& e : ev) (void)hipEventDestroy(e);
         }
         if (iters) *iters = it;
-        FGPU_HIP(hipMemcpyAsync(centrality, rp, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream()));
+        FGPU_TRY(ctx->d2h(centrality, rp, (size_t)n * sizeof(float)));
         FGPU_HIP(hipStreamSynchronize(ctx->stream()));
         return FGPU_OK;
     };

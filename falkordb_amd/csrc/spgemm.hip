@@ -305,11 +305,9 @@ static fgpu_info upload_sources(fgpu_ctx* ctx, fgpu_mat** out, const uint64_t* s
     }
     fgpu_mat* f = nullptr;
     FGPU_TRY(mat_alloc(ctx, &f, nsrc, ncols0, ci.size(), false, 0, false));
-    hipError_t e = hipMemcpyAsync(f->rowptr, rp.data(), rp.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream());
-    if (e == hipSuccess && !ci.empty())
-        e = hipMemcpyAsync(f->colidx, ci.data(), ci.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream());
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream());
-    if (e != hipSuccess) { mat_release(f); set_error("expand: source upload failed: %s", hipGetErrorString(e)); return FGPU_DEVICE; }
+    fgpu_info u = ctx->h2d(f->rowptr, rp.data(), rp.size() * sizeof(u32));
+    if (u == FGPU_OK && !ci.empty()) u = ctx->h2d(f->colidx, ci.data(), ci.size() * sizeof(u32));
+    if (u != FGPU_OK) { mat_release(f); return u; }
     *out = f;
     return FGPU_OK;
 }
@@ -401,7 +399,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 if (dst_label_bitmap) {
                     const u64 nw = ((u64)mh->ncols + 63) / 64;
                     FGPU_TRY(bm.alloc(ctx, nw + 1));
-                    FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+                    FGPU_TRY(ctx->h2d(bm.p, dst_label_bitmap, nw * sizeof(u64)));
                 }
                 *result = nullptr;
                 return bp_hop_count(ctx, bs, mh, dph, dmh, flops, dst_label_bitmap ? bm.p : nullptr, &count_only[0],
@@ -421,7 +419,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         if (dst_label_bitmap) {
             const u64 nw = ((u64)bs.n + 63) / 64;
             FGPU_TRY(bm.alloc(ctx, nw + 1));
-            FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+            FGPU_TRY(ctx->h2d(bm.p, dst_label_bitmap, nw * sizeof(u64)));
         }
         if (count_only) {
             *result = nullptr;
@@ -435,8 +433,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         DevBuf<u64> bm;
         fgpu_info i = bm.alloc(ctx, nw + 1);
         if (i == FGPU_OK) {
-            hipError_t e2 = hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream());
-            if (e2 != hipSuccess) { set_error("expand: label bitmap upload failed: %s", hipGetErrorString(e2)); i = FGPU_DEVICE; }
+            i = ctx->h2d(bm.p, dst_label_bitmap, nw * sizeof(u64));
         }
         fgpu_mat* c = nullptr;
         if (i == FGPU_OK) i = filter_by_bitmap(ctx, &c, f, bm.p);
@@ -614,7 +611,7 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
         if (dst_label_bitmap && h == 0) {   // the destination label applies to every reported set
             const u64 nw = ((u64)bs.n + 63) / 64;
             FGPU_TRY(bm.alloc(ctx, nw + 1));
-            FGPU_HIP(hipMemcpyAsync(bm.p, dst_label_bitmap, nw * sizeof(u64), hipMemcpyHostToDevice, ctx->stream()));
+            FGPU_TRY(ctx->h2d(bm.p, dst_label_bitmap, nw * sizeof(u64)));
             label_dev = bm.p;
         }
         u64 n = 0, cs = 0;
@@ -672,7 +669,7 @@ extern "C" fgpu_info fgpu_expand_trail_counts(fgpu_ctx* ctx, const uint64_t* src
     auto run = [&]() -> fgpu_info {
         FGPU_TRY(upload_sources(ctx, &f0, src_ids, nsrc, eff[0]->nrows));
         FGPU_TRY(dsrc.alloc(ctx, nsrc));
-        FGPU_HIP(hipMemcpyAsync(dsrc.p, s32.data(), nsrc * sizeof(u32), hipMemcpyHostToDevice, ctx->stream()));
+        FGPU_TRY(ctx->h2d(dsrc.p, s32.data(), nsrc * sizeof(u32)));
         FGPU_TRY(mxm_device(ctx, &c1, f0, eff[0], nullptr));
         FGPU_TRY(w1.alloc(ctx, c1->nnz));
         if (c1->nnz) {
@@ -703,10 +700,10 @@ extern "C" fgpu_info fgpu_expand_trail_counts(fgpu_ctx* ctx, const uint64_t* src
         // self-loop walk keep a zero count: they are walks, not trails, and are dropped here.
         std::vector<u32> rp((size_t)nsrc + 1), ci(res->nnz);
         std::vector<u64> cv(res->nnz);
-        FGPU_HIP(hipMemcpyAsync(rp.data(), res->rowptr, rp.size() * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
+        FGPU_TRY(ctx->d2h(rp.data(), res->rowptr, rp.size() * sizeof(u32)));
         if (res->nnz) {
-            FGPU_HIP(hipMemcpyAsync(ci.data(), res->colidx, res->nnz * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream()));
-            FGPU_HIP(hipMemcpyAsync(cv.data(), res_cnt, res->nnz * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream()));
+            FGPU_TRY(ctx->d2h(ci.data(), res->colidx, res->nnz * sizeof(u32)));
+            FGPU_TRY(ctx->d2h(cv.data(), res_cnt, res->nnz * sizeof(u64)));
         }
         FGPU_HIP(hipStreamSynchronize(ctx->stream()));
         u64 keep = 0;

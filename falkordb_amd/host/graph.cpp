@@ -212,9 +212,19 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
             for (u64 i = 0; i < k; ++i) null_rows.push_back(i);
         return true;
     };
+    // FH_TIMING=1: phase times of every call on stderr (tools/bench_paths.py host)
+    static const bool timing = getenv("FH_TIMING") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[expand_batch] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+        tp = now;
+    };
     HopLayers hl;
     std::vector<std::vector<u64>> type_ids;
     if (!hop_layers(g, hops, hl, type_ids)) return no_match();          // unknown type (:485-490)
+    lap("hop_layers");
     auto last_dst = g.resolve_label_ids(hops.back().dst_labels);
     auto src_lids = g.resolve_label_ids(src_labels);
     if (!last_dst || !src_lids) return no_match();                      // unknown label
@@ -252,6 +262,7 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
 
     std::vector<u64> bitmap;
     if (!last_dst->empty()) bitmap = g.label_bitmap(*last_dst);         // dst label filter of the LAST hop (:647-651)
+    lap("source labels, bitmap");
 
     fgpu_ctx* ctx = g.ctx().raw();
     u64 *rowptr = nullptr, *dest = nullptr, nnz = 0, fl = 0;
@@ -259,6 +270,7 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
                       bitmap.empty() ? nullptr : bitmap.data(), &rowptr, &dest, &nnz, &fl),
           "CondTraverse::expand_batch");
     if (flops) *flops = fl;
+    lap("fgpu_expand");
 
     std::vector<uint8_t> matched(k, 0);
     const bool want_edge = bind_relationship && hops.size() == 1;
@@ -287,8 +299,10 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
             }
         }
     }
+    lap("result columns");
     fgpu_free(ctx, rowptr);
     fgpu_free(ctx, dest);
+    lap("free");
     if (want_edge) {
         // representative edge: first id found scanning the types in order (:663-695), batched per type
         std::vector<u64> tids = type_ids[0];
