@@ -436,7 +436,13 @@ constexpr u32 BP_GROUP_WAVES = 8;   // wavefronts per workgroup
 template <int LN>
 __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(CsrView at, u32 nrows, const u64* __restrict__ x,
                                                                              BpProbe pr, u64* __restrict__ y,
-                                                                             uint8_t* __restrict__ yflag) {
+                                                                             uint8_t* __restrict__ yflag,
+                                                                             const u32* __restrict__ next_rowptr,
+                                                                             unsigned long long* __restrict__ stats) {
+    // stats (nullable, with next_rowptr): [0] += popcount(Y[v]) * out-degree of v in the next hop's matrix, [1] += rows
+    // written — what bp_flops / bp_count_flags would find in a pass of their own
+    u64 st_flops = 0;
+    u32 st_rows = 0;
     constexpr int SLOTS = 64 / LN;
     constexpr u32 R = BP_GROUP;
     extern __shared__ u64 s_mem[];
@@ -459,7 +465,9 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
         const u32 v0 = g * R;
         const u32 ri = v0 + lane < nrows ? v0 + lane : nrows;
         const u32 rp = at.rowptr[ri];
+        const u32 nrp = stats ? next_rowptr[ri] : 0u;   // next hop's out-degrees of the group's rows, loaded with the rest
         const u32 rp1 = (u32)__shfl_down((int)rp, 1, 64);
+        const u32 ndeg = (u32)__shfl_down((int)nrp, 1, 64) - nrp;
         u32 deg = lane < R ? rp1 - rp : 0u;
         if (deg > BP_ITEM) deg = 0u;                     // split rows: the item kernel's
         u32 incl = deg;
@@ -535,9 +543,56 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
             const u64 nzm = __ballot(a != 0ull);
             const u64 mine = LN == 64 ? nzm : (nzm >> (slot * LN)) & ((1ull << (LN % 64)) - 1ull);
             if (wl == 0 && mine) yflag[v0 + row] = 1;
+            if (stats) {   // (wave-uniform)
+                const u32 dg = (u32)__shfl((int)ndeg, (int)(row < R ? row : 0u), 64);
+                if (mine && wl == 0) st_rows += 1;
+                st_flops += (u64)__popcll(a) * dg;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if (stats) {
+        u64 r64 = st_rows;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            st_flops += __shfl_xor(st_flops, d, 64);
+            r64 += __shfl_xor(r64, d, 64);
+        }
+        if (lane == 0 && r64) {
+            atomicAdd(&stats[0], (unsigned long long)st_flops);
+            atomicAdd(&stats[1], (unsigned long long)r64);
+        }
+    }
+}
+
+// the same two sums over the rows the item kernel finished with atomics (rows of more than BP_ITEM entries: `bits`)
+__global__ __launch_bounds__(256) void bp_split_stats_kernel(const u64* __restrict__ bits, u32 n, u32 ws,
+                                                            const u64* __restrict__ y, const u32* __restrict__ next_rowptr,
+                                                            unsigned long long* __restrict__ stats) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwords = (n + 63) >> 6;
+    u64 fl = 0, rows = 0;
+    for (u32 w = wave; w < nwords; w += nwaves) {
+        u64 m = bits[w];                         // wave-uniform
+        while (m) {
+            const u32 v = (w << 6) + (u32)__builtin_ctzll(m);
+            m &= m - 1ull;
+            u32 pc = 0;
+            for (u32 k = lane; k < ws; k += 64) pc += (u32)__popcll(y[(size_t)v * ws + k]);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d, 64);
+            if (lane == 0 && pc) {
+                fl += (u64)pc * (next_rowptr[v + 1] - next_rowptr[v]);
+                rows += 1;
+            }
+        }
+    }
+    if (lane == 0 && rows) {
+        atomicAdd(&stats[0], (unsigned long long)fl);
+        atomicAdd(&stats[1], (unsigned long long)rows);
     }
 }
 
@@ -891,14 +946,16 @@ struct CountArgs {
 };
 
 static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
-                             u64* flops, const CountArgs* ca) {
+                             u64* flops, const CountArgs* ca, const fgpu_mat* next_m = nullptr) {
     FGPU_REQUIRE(m->nrows == s.n, FGPU_DIM_MISMATCH, "bit-parallel hop: matrix has %llu rows, frontier %u",
                  (unsigned long long)m->nrows, s.n);
     FGPU_REQUIRE(m->nnz < 0x7FFFFFFFull, FGPU_INVALID, "bit-parallel hop: nnz must be < 2^31");
     if (flops) {
-        FGPU_TRY(bp_flops(ctx, s, m, flops));
+        if (s.pre_for == m) *flops += s.pre_flops;     // summed by the hop that produced X
+        else FGPU_TRY(bp_flops(ctx, s, m, flops));
         if (dp && dp->nnz) FGPU_TRY(bp_flops(ctx, s, dp, flops));
     }
+    s.pre_for = nullptr;
     const bool has_dm = dm && dm->nnz, has_dp = dp && dp->nnz;
     const u32 n_out = (u32)m->ncols;
     const fgpu_mat* t = nullptr;
@@ -950,6 +1007,8 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         FGPU_TRY(bp_alloc_zero(ctx, o.x, o));
         FGPU_TRY(bp_alloc_flags(ctx, o));
     }
+    bool fuse_stats = false;
+    DevBuf<u64> gstats;
     u64* ydst = ca ? side.p : o.x.p;          // rows of Y, or the slots of the side buffer
     uint8_t* yflag = ca ? nullptr : o.flag.p;
     int pull_idx = -1;
@@ -959,6 +1018,9 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
                             lds + 16384 + 16 * BP_ITEM * sizeof(u32) <= (size_t)ctx->opt.lds_limit;
         // row-group form: rows of <= BP_ITEM entries by bp_pull_groups_kernel, the split rows' items by the item kernel
         const bool groups = sparse && mode == 0 && s.ws <= 16 && ctx->opt.expand_row_groups;
+        // ... and it can sum the next hop's traversed-edge count and the flagged rows on its way (clean layers only: a
+        // delta fix-up changes rows after the pull; the next matrix must be plain CSR over the same vertices)
+        fuse_stats = groups && next_m && !has_dm && !has_dp && !next_m->is_hyper() && next_m->nrows == m->ncols;
         const u32 nitems = groups ? t->n_bp_sitems : t->n_bp_items;
         const u32* item_list = groups ? t->bp_sitems : t->bp_items;
         u32 grid = cdiv(nitems ? nitems : 1, 4);
@@ -1013,6 +1075,10 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         else if (mode == 1) { if (sparse) BP_LAUNCH3(LN, true, 1); else BP_LAUNCH3(LN, false, 1); }                     \
         else { if (sparse) BP_LAUNCH3(LN, true, 2); else BP_LAUNCH3(LN, false, 2); }                                    \
     } while (0)
+        if (fuse_stats) {
+            FGPU_TRY(gstats.alloc(ctx, 2));
+            FGPU_HIP(hipMemsetAsync(gstats.p, 0, 2 * sizeof(u64), ctx->stream()));
+        }
         if (groups) {
             const size_t per_wave = ((size_t)BP_GROUP * s.ws + 256 + 32) * sizeof(u64);
             const size_t lds_g = lds_co + BP_GROUP_WAVES * per_wave;
@@ -1026,7 +1092,9 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             FGPU_HIP(hipFuncSetAttribute((const void*)bp_pull_groups_kernel<LN>,                                        \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));                      \
         hipLaunchKernelGGL(bp_pull_groups_kernel<LN>, dim3(ggrid), dim3(BP_GROUP_WAVES * 64), lds_g, ctx->stream(),     \
-                           view_of(t), (u32)t->nrows, (const u64*)s.x.p, pr, ydst, yflag);                              \
+                           view_of(t), (u32)t->nrows, (const u64*)s.x.p, pr, ydst, yflag,                               \
+                           fuse_stats ? (const u32*)next_m->rowptr : (const u32*)nullptr,                               \
+                           fuse_stats ? (unsigned long long*)gstats.p : (unsigned long long*)nullptr);                  \
     } while (0)
             switch (s.ws) {
                 case 1: BP_GROUPS(1); break;
@@ -1100,17 +1168,33 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         s.n = n_out;
         return FGPU_OK;
     }
-    FGPU_TRY(bp_count_flags(ctx, o));
+    if (fuse_stats) {
+        if (t->n_bp_sitems) {
+            hipLaunchKernelGGL(bp_split_stats_kernel, dim3(ctx->cus * 2), dim3(256), 0, ctx->stream(), (const u64*)t->bp_split_bits,
+                               n_out, s.ws, (const u64*)o.x.p, (const u32*)next_m->rowptr, (unsigned long long*)gstats.p);
+            FGPU_HIP(hipGetLastError());
+        }
+        u64 st[2] = {0, 0};
+        FGPU_TRY(ctx->d2h(st, gstats.p, sizeof(st)));
+        o.nz_rows = st[1];
+        o.pre_for = next_m;
+        o.pre_flops = st[0];
+    } else {
+        FGPU_TRY(bp_count_flags(ctx, o));
+    }
     prof_add_bytes(ctx, pull_idx, o.nz_rows * 8 * s.w);
     s.x = std::move(o.x);
     s.flag = std::move(o.flag);
     s.nz_rows = o.nz_rows;
+    s.pre_for = o.pre_for;
+    s.pre_flops = o.pre_flops;
     s.n = o.n;
     return FGPU_OK;
 }
 
-fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops) {
-    return bp_hop_impl(ctx, s, m, dp, dm, flops, nullptr);
+fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,
+                 const fgpu_mat* next_m) {
+    return bp_hop_impl(ctx, s, m, dp, dm, flops, nullptr, next_m);
 }
 
 fgpu_info bp_hop_count(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,

@@ -387,12 +387,18 @@ struct BitState {
     u32 ws = 0;     // row stride in words (power of two <= 64, or a multiple of 64)
     DevBuf<uint8_t> flag;  // one byte per vertex: != 0 => row v may hold a set bit (lets a hop skip empty rows)
     u64 nz_rows = 0;       // number of flagged rows (what decides the sparse / dense form of the next hop)
+    // traversed-edge count of the NEXT hop over `pre_for` (sum popcount(X[v]) * deg(v)), when the hop that produced X
+    // summed it on the way (bp_pull_groups_kernel): saves the pass over the non-zero rows bp_flops would make
+    const fgpu_mat* pre_for = nullptr;
+    u64 pre_flops = 0;
 };
 fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f);
 // one hop from a CSR frontier into bit form by pushing (the hop at which a chain leaves the sorted-CSR products)
 fgpu_info bp_push_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* dp,
                            const fgpu_mat* dm);
-fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops);
+// `next_m` (nullable): the base matrix of the hop after this one, if it will run in bit form too
+fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,
+                 const fgpu_mat* next_m = nullptr);
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out);
 // nnz + order-independent checksum of the result read straight from the bit state (fgpu_expand_count)
 fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum);

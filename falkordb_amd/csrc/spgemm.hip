@@ -388,6 +388,8 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 mat_release(f);
                 f = nullptr;
                 if (i != FGPU_OK) return i;
+                bs.pre_for = mh;                    // T is this hop's traversed-edge count over mh: no need to sum it again
+                bs.pre_flops = T;
                 bits = true;
             }
         }
@@ -405,7 +407,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 return bp_hop_count(ctx, bs, mh, dph, dmh, flops, dst_label_bitmap ? bm.p : nullptr, &count_only[0],
                                     want_checksum ? &count_only[1] : nullptr);
             }
-            FGPU_TRY(bp_hop(ctx, bs, mh, dph, dmh, flops));
+            FGPU_TRY(bp_hop(ctx, bs, mh, dph, dmh, flops, (flops && h + 1 < nhops) ? m[h + 1] : nullptr));
             continue;
         }
         fgpu_mat* c = nullptr;
