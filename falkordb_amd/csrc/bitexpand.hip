@@ -153,6 +153,18 @@ __global__ __launch_bounds__(256) void bp_scatter_csr_kernel(CsrView f, u32 nrow
     }
 }
 
+// lazy state: zero exactly the rows the scatter is about to touch (duplicates write the same zeros)
+__global__ __launch_bounds__(256) void bp_zero_rows_kernel(const u32* __restrict__ col, u32 nnz, u32 ws, u32 lnsh,
+                                                          u64* __restrict__ x) {
+    const u32 ln = 1u << lnsh;
+    const u32 t = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    const u32 sub = t & (ln - 1u);
+    for (u32 q = t >> lnsh; q < nnz; q += nth >> lnsh) {
+        const u32 c = col[q];
+        for (u32 k = sub; k < ws; k += ln) x[(size_t)c * ws + k] = 0ull;
+    }
+}
+
 __global__ void bp_flag_count_kernel(const uint8_t* __restrict__ flag, u32 n, unsigned long long* __restrict__ out) {
     u32 c = 0;
     for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += flag[i] != 0;
@@ -626,7 +638,8 @@ template <bool IS_DM>
 __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w, u32 ws, u32 ln,
                                                       const u64* __restrict__ x, u64* __restrict__ y,
                                                       uint8_t* __restrict__ yflag, const u64* __restrict__ tbits,
-                                                      const u32* __restrict__ tpref) {
+                                                      const u32* __restrict__ tpref,
+                                                      const uint8_t* __restrict__ xflag /* lazy X: rows without a flag are undefined (= empty) */) {
     const u32 t = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     const u32 per = nth / ln;             // entries in flight per sweep
     const u32 sub = t % ln;
@@ -637,6 +650,7 @@ __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w
             if (d.rowptr[mid] <= q) lo = mid; else hi = mid - 1;
         }
         const u32 u = d.hrows ? d.hrows[lo] : lo;
+        if (xflag && !xflag[u]) continue;
         const u32 v = d.colidx[q];
         // the row of v: in Y, or (counting hop) in its slot of the side buffer — every delta destination is "touched"
         size_t yrow = (size_t)v * ws;
@@ -768,6 +782,10 @@ static fgpu_info bp_alloc_flags(fgpu_ctx* ctx, BitState& s) {
     return FGPU_OK;
 }
 
+// LDS the sparse pull needs beside the checksum tables of a counting hop: the coarse flag map and the live lists
+constexpr size_t BP_SPARSE_LDS = 16384 + 16 * BP_ITEM * sizeof(u32);
+static bool bp_sparse_fits(const fgpu_ctx* ctx, size_t table_bytes) { return table_bytes + BP_SPARSE_LDS <= (size_t)ctx->opt.lds_limit; }
+
 static fgpu_info bp_count_flags(fgpu_ctx* ctx, BitState& s) {
     DevBuf<u64> acc;
     FGPU_TRY(acc.alloc(ctx, 1));
@@ -786,8 +804,21 @@ static fgpu_info bp_count_flags(fgpu_ctx* ctx, BitState& s) {
 fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f) {
     FGPU_REQUIRE(!f->is_hyper(), FGPU_INVALID, "bit-parallel expansion: F must not be hypersparse");
     bp_layout(s, (u32)f->ncols, (u32)f->nrows);
-    FGPU_TRY(bp_alloc_zero(ctx, s.x, s));
+    // a light frontier (the next pull is certainly the sparse one, whatever its counting mode): zero only the rows the
+    // scatter touches — the whole-state memset is 2 GiB = 0.32 ms at RMAT-24 for ~10^4 rows in use
+    s.lazy = f->nnz && f->nnz * 8 < (u64)s.n && bp_sparse_fits(ctx, (size_t)s.w * 256 * sizeof(u64));
+    if (s.lazy) FGPU_TRY(s.x.alloc(ctx, (size_t)s.n * s.ws));
+    else FGPU_TRY(bp_alloc_zero(ctx, s.x, s));
     FGPU_TRY(bp_alloc_flags(ctx, s));
+    if (s.lazy) {
+        u32 lnsh = 0;
+        while ((2u << lnsh) <= s.ws && lnsh < 6) ++lnsh;
+        u32 grid = cdiv((u64)f->nnz << lnsh, 256);
+        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        hipLaunchKernelGGL(bp_zero_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const u32*)f->colidx, (u32)f->nnz, s.ws,
+                           lnsh, s.x.p);
+        FGPU_HIP(hipGetLastError());
+    }
     if (f->nnz) {
         ProfScope ps(ctx, "bp_scatter_csr_kernel", 4 * (u64)f->nnz + 4 * ((u64)f->nrows + 1) + 16 * (u64)f->nnz);
         u32 grid = cdiv(f->nnz, 256);
@@ -1014,8 +1045,8 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     int pull_idx = -1;
     if (m->nnz) {
         // (the sparse form stages a <= 16 KiB coarse flag map in LDS next to the checksum tables of MODE 2)
-        const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n &&
-                            lds + 16384 + 16 * BP_ITEM * sizeof(u32) <= (size_t)ctx->opt.lds_limit;
+        const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n && bp_sparse_fits(ctx, lds);
+        FGPU_REQUIRE(sparse || !s.lazy, FGPU_INVALID, "bit-parallel hop: a lazily zeroed state needs the sparse pull");
         // row-group form: rows of <= BP_ITEM entries by bp_pull_groups_kernel, the split rows' items by the item kernel
         const bool groups = sparse && mode == 0 && s.ws <= 16 && ctx->opt.expand_row_groups;
         // ... and it can sum the next hop's traversed-edge count and the flagged rows on its way (clean layers only: a
@@ -1127,7 +1158,8 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             u32 grid = cdiv((u64)dm->nnz * ln, 256);
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
             hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dm), (u32)dm->nnz,
-                               s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref);
+                               s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref,
+                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr);
             FGPU_HIP(hipGetLastError());
         }
         if (has_dp) {
@@ -1135,7 +1167,8 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             u32 grid = cdiv((u64)dp->nnz * ln, 256);
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
             hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dp), (u32)dp->nnz,
-                               s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref);
+                               s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref,
+                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr);
             FGPU_HIP(hipGetLastError());
         }
     }
@@ -1186,6 +1219,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     s.x = std::move(o.x);
     s.flag = std::move(o.flag);
     s.nz_rows = o.nz_rows;
+    s.lazy = false;            // o.x was zeroed as a whole
     s.pre_for = o.pre_for;
     s.pre_flops = o.pre_flops;
     s.n = o.n;

@@ -391,6 +391,9 @@ struct BitState {
     // summed it on the way (bp_pull_groups_kernel): saves the pass over the non-zero rows bp_flops would make
     const fgpu_mat* pre_for = nullptr;
     u64 pre_flops = 0;
+    // rows of x are defined only where flag != 0 (bp_from_csr of a light frontier zeroes just the rows it scatters into
+    // instead of the whole 2 GiB state; every reader of such a state goes through the flags)
+    bool lazy = false;
 };
 fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f);
 // one hop from a CSR frontier into bit form by pushing (the hop at which a chain leaves the sorted-CSR products)
