@@ -154,6 +154,42 @@ __global__ __launch_bounds__(256) void merge_mark_kernel(Layer x, Layer other, L
     }
 }
 
+// The base layer the other way round (no clipping): every entry is kept until a delta entry says otherwise, so the
+// keep bits start as all-ones and each dm / dp entry clears its own coordinate in m (one binary search in m's row per
+// DELTA entry).  The per-entry form above asks the question from m's side — every entry of a touched row searches dm
+// and dp — and R-MAT tombstones land on hub rows in proportion to their length: with 0.1 % uniformly random tombstones
+// 47 % of the 64-entry words of RMAT-20 lie in a touched row, each of their entries paying a 16-step search of the
+// hypersparse row list.
+__global__ void merge_markall_kernel(u32 nnz, u64* __restrict__ kb) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nwords = (nnz + 63) >> 6;
+    if (w >= nwords) return;
+    const u32 left = nnz - (w << 6);
+    kb[w] = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+}
+__global__ __launch_bounds__(256) void merge_unmark_kernel(Layer d, Layer m, u64* __restrict__ kb) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwords = (d.nnz + 63) >> 6;
+    for (u32 w = wave; w < nwords; w += nwaves) {
+        const u32 q = (w << 6) + lane;
+        if (q >= d.nnz) continue;
+        u32 i, r;
+        lane_row(d, w, q, true, i, r);
+        const u32 c = d.v.colidx[q];
+        u32 b, e;
+        row_range(m.v, r, b, e);
+        if (b == e) continue;
+        const u32 p = lower_bound_col(m.v.colidx, b, e, c);
+        if (p < e && m.v.colidx[p] == c) atomicAnd((unsigned long long*)&kb[p >> 6], ~(1ull << (p & 63)));
+    }
+}
+__global__ void merge_popc_kernel(const u64* __restrict__ kb, u32 nwords, u32* __restrict__ kc) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) kc[w] = (u32)__popcll(kb[w]);
+}
+
 __global__ void merge_rowlen_kernel(Layer m, Layer dp, bool has_dp, const u32* __restrict__ rowbits,
                                     const u64* __restrict__ kbm, const u32* __restrict__ ksm,
                                     const u64* __restrict__ kbp, const u32* __restrict__ ksp, u32 out_nrows,
@@ -181,7 +217,8 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other
                                                            const u64* __restrict__ kbx, const u32* __restrict__ ksx,
                                                            const u64* __restrict__ kbo, const u32* __restrict__ kso,
                                                            const u32* __restrict__ out_rp, u32* __restrict__ out_col,
-                                                           u64* __restrict__ out_val, bool clip) {
+                                                           u64* __restrict__ out_val, bool clip,
+                                                           const u32* __restrict__ crossbits /* rows the OTHER layer stores (nullable = rowbits) */) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
@@ -207,7 +244,8 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other
         const u32 own = ksx[w] + (u32)__popcll(lane ? (mask & ((1ull << lane) - 1ull)) : 0ull) -
                         kept_before(kbx, ksx, x.v.rowptr[i]);
         u32 cross = 0;
-        if (has_other && (!IS_M || !rowbits || ((rowbits[r >> 5] >> (r & 31)) & 1u))) {
+        const u32* __restrict__ xb = crossbits ? crossbits : rowbits;
+        if (has_other && (!IS_M || !xb || ((xb[r >> 5] >> (r & 31)) & 1u))) {
             u32 b, e;
             row_range(other.v, r, b, e);
             if (b != e) {
@@ -280,14 +318,20 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     if (has_dp) FGPU_TRY(layer_of(ctx, dp, lp));
     if (has_dm) FGPU_TRY(layer_of(ctx, dm, ld));
     // rows touched by a delta layer
-    DevBuf<u32> rowbits;
+    DevBuf<u32> rowbits, rowbits_dp;
     const u64 max_rows = m->nrows > out_nrows ? m->nrows : out_nrows;
     if (has_dp || has_dm) {
         const size_t nb = (size_t)(max_rows >> 5) + 2;
         FGPU_TRY(rowbits.alloc(ctx, nb));
         FGPU_HIP(hipMemsetAsync(rowbits.p, 0, nb * sizeof(u32), ctx->stream()));
-        if (has_dp)
+        if (has_dp) {
             hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream(), lp.v, rowbits.p);
+            if (has_dm) {   // the rows dp stores, on their own: only they need a cross-rank lookup when m is scattered
+                FGPU_TRY(rowbits_dp.alloc(ctx, nb));
+                FGPU_HIP(hipMemsetAsync(rowbits_dp.p, 0, nb * sizeof(u32), ctx->stream()));
+                hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream(), lp.v, rowbits_dp.p);
+            }
+        }
         if (has_dm)
             hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dm->nvec, 256)), dim3(256), 0, ctx->stream(), ld.v, rowbits.p);
         FGPU_HIP(hipGetLastError());
@@ -295,7 +339,17 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     Keep km, kp;
     FGPU_TRY(km.alloc(ctx, lm.nnz));
     FGPU_TRY(kp.alloc(ctx, has_dp ? lp.nnz : 0));
-    if (lm.nnz) {
+    if (lm.nnz && !clip && ctx->opt.merge_mode != 2) {
+        const u32 nwords = (lm.nnz + 63) >> 6;
+        hipLaunchKernelGGL(merge_markall_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, ctx->stream(), lm.nnz, km.kb.p);
+        for (const Layer* d : {has_dm ? &ld : nullptr, has_dp ? &lp : nullptr}) {
+            if (!d) continue;
+            hipLaunchKernelGGL(merge_unmark_kernel, dim3(entry_grid(ctx, d->nnz)), dim3(256), 0, ctx->stream(), *d, lm, km.kb.p);
+        }
+        hipLaunchKernelGGL(merge_popc_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, ctx->stream(), (const u64*)km.kb.p, nwords,
+                           km.ks.p);
+        FGPU_HIP(hipGetLastError());
+    } else if (lm.nnz) {
         hipLaunchKernelGGL(merge_mark_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream(), lm, lp,
                            ld, has_dp, has_dm, dm_masks_dp, (const u32*)rowbits.p, (u32)out_nrows, (u32)out_ncols,
                            km.kb.p, km.ks.p, clip);
@@ -325,13 +379,15 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     if (e == hipSuccess && lm.nnz && nnz) {
         hipLaunchKernelGGL(merge_scatter_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream(), lm,
                            lp, has_dp, (const u32*)rowbits.p, (const u64*)km.kb.p, (const u32*)km.ks.p,
-                           (const u64*)kp.kb.p, (const u32*)kp.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip);
+                           (const u64*)kp.kb.p, (const u32*)kp.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip,
+                           (const u32*)rowbits_dp.p);
         e = hipGetLastError();
     }
     if (e == hipSuccess && has_dp && nnz) {
         hipLaunchKernelGGL(merge_scatter_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream(), lp,
                            lm, lm.nnz != 0, (const u32*)rowbits.p, (const u64*)kp.kb.p, (const u32*)kp.ks.p,
-                           (const u64*)km.kb.p, (const u32*)km.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip);
+                           (const u64*)km.kb.p, (const u32*)km.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip,
+                           (const u32*)nullptr);
         e = hipGetLastError();
     }
     // the scratch buffers above go back to the pool when this returns: the kernels reading them must be done

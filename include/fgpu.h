@@ -86,7 +86,8 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * first hop), "expand_fuse_count" (fgpu_expand_count: 1 = the last bit-parallel hop counts its rows where it produces
  * them, 0 = it writes them and a separate pass counts), "expand_row_groups" (sparse mid-chain pull of the bit-parallel
  * form: 1 = a wavefront per 32-row group, 0 = a wavefront per row item), "bfs_wgs_per_cu" (grid of the fused BFS level kernel), "merge_mode" (fgpu_mat_merge:
- * 0 = entry-parallel, 1 = one wavefront per row, pattern layers only), "bfs_tiny" (consecutive tiny BFS levels in one single-workgroup launch: 0 off, 1 on,
+ * 0 = entry-parallel with the base layer's keep bits cleared from the delta side, 1 = one wavefront per row, pattern
+ * layers only, 2 = entry-parallel with every base entry of a touched row searching the deltas), "bfs_tiny" (consecutive tiny BFS levels in one single-workgroup launch: 0 off, 1 on,
  * 2 = when the plan's previous search took more than 12 levels), "dist_collective" (frontier exchange of
  * fgpu_bfs_dist_run: 0 = grouped ncclSend / ncclRecv, 1 = one ncclBroadcast per rank), "bfs_prof_split" (1 = a profiled plan launches
  * the push / pull twins of the level kernel so rocprofv3 can tell them apart by name), "bfs_hub_first" (1 = BFS plans

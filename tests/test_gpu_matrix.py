@@ -149,9 +149,10 @@ def test_merge_delta_layers(ctx, masks_dp):
     assert_same(got, oracle.merge(m, dp, dm, masks_dp))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_merge_rmat_hub_rows_both_kernels(ctx, mode):
-    # the entry-parallel merge (merge.hip) and the wavefront-per-row one agree with the oracle on a skewed graph
+    # the entry-parallel merge (merge.hip; 0 = keep bits of the base layer cleared from the delta side, 2 = every base
+    # entry of a touched row searching the deltas) and the wavefront-per-row one agree with the oracle on a skewed graph
     a = oracle.rmat_csr(14)
     n = a.nrows
     rng = np.random.default_rng(9)

@@ -55,11 +55,12 @@ def bench_merge(ctx, scale):
     A = ctx.mat_rmat(scale)
     n, nnz = A.nrows, A.nvals
     dp, dm = deltas(ctx, A, 0.001, rng)
-    for mode in (0, 1):
+    for mode in (0, 2, 1):
         ctx.set_option("merge_mode", mode)
         dt, out = timed(ctx, lambda: A.merge(dp, dm))
         b_alg = 4 * (nnz + dp.nvals + dm.nvals) + 4 * out.nvals + 8 * (n + 1)
-        print(json.dumps({"path": "delta_merge", "layers": "bool", "kernel": ["entry-parallel", "row-wave"][mode],
+        print(json.dumps({"path": "delta_merge", "layers": "bool",
+                          "kernel": ["entry-parallel", "row-wave", "entry-parallel, base marked per entry"][mode],
                           "scale": scale, "nnz_m": nnz, "nnz_dp": dp.nvals, "nnz_dm": dm.nvals,
                           "nnz_out": out.nvals, "ms": round(dt * 1e3, 3), "alg_bytes": b_alg,
                           "GBps": round(b_alg / dt / 1e9, 1), "frac_hbm": round(b_alg / dt / 8e12, 4)}), flush=True)
