@@ -353,6 +353,7 @@ fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp);
 fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 // transpose.hip: the sort-free builders (stable two-level counting sort); FGPU_NO_VALUE = not applicable, fall back
+void ks_set_wb_override(int wb);   // experiment knob: low-digit bits of the counting sort (0 = pick)
 fgpu_info mat_transpose_counting(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 fgpu_info mat_from_device_coo_counting(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
                                        const u32* cols, u64 n);

@@ -504,6 +504,9 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "expand_mode")) {
         FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "expand_mode must be 0 (auto), 1 (sorted CSR) or 2 (bit-parallel)");
         ctx->opt.expand_mode = (int)value;
+    } else if (!strcmp(name, "transpose_wb")) {
+        ks_set_wb_override((int)value);
+
     } else if (!strcmp(name, "expand_row_groups")) {
         ctx->opt.expand_row_groups = value != 0;
     } else if (!strcmp(name, "expand_fuse_count")) {

@@ -37,14 +37,22 @@ struct KsGeom {
     u32 nblk;   // pass-1 blocks
 };
 
+static int g_ks_wb_override = 0;   // experiment knob (option "transpose_wb"): low-digit bits, 0 = pick
+void ks_set_wb_override(int wb) { g_ks_wb_override = wb; }
+
 static bool ks_geometry(u64 n, u64 nkeys, KsGeom& g) {
     u32 kb = 1;
     while (kb < 32 && (1ull << kb) < nkeys) ++kb;
     // split the key bits between the two digits so that neither LDS footprint starves its kernel of wavefronts:
     // pass 1 keeps B x 4 B per single-wavefront workgroup, pass 2 keeps 4 x 2^wb x 4 B per 4-wavefront workgroup
-    u32 wb = kb > 22 ? kb - 12 : (kb > 11 ? 11 : 8);   // <= 2^22 keys: 2048 x 2048; 2^24: 4096 x 4096; 2^26: 8192 x 8192
+    // Sweep at 2^22 keys (RMAT-22, tools/transpose_wb_sweep.py; count / scatter / bucket ms): wb 10: .29 / 1.38 / .86;
+    // 11: .18 / 1.46 / .99; 12: .13 / 1.01 / 1.23; 13: .11 / .66 / 2.26 — fewer pass-1 buckets mean longer runs per
+    // bucket (the scattered 8 B pairs combine into lines before they leave L2 / MALL), more pass-2 keys mean LDS
+    // counters that leave one workgroup per CU.  Smaller pass-1 blocks (4096, 2048 entries) changed nothing.
+    u32 wb = kb > 22 ? kb - 12 : (kb > 12 ? 12 : (kb > 11 ? 11 : 8));   // 2^22 keys: 1024 x 4096; 2^24: 4096 x 4096; 2^26: 8192 x 8192
     if (wb < 8) wb = 8;                                // a pass-2 thread owns 2^wb / 256 keys
     if (kb > wb + 13) wb = kb - 13;
+    if (g_ks_wb_override >= 8 && g_ks_wb_override <= (int)KS_MAX_WB && (u32)g_ks_wb_override + 13 >= kb) wb = (u32)g_ks_wb_override;
     if (wb > KS_MAX_WB) wb = KS_MAX_WB;
     const u64 B = (nkeys + (1ull << wb) - 1) >> wb;
     if (B > KS_MAX_BUCKETS) return false;      // > 2^26 keys: three digits would be needed
@@ -54,6 +62,7 @@ static bool ks_geometry(u64 n, u64 nkeys, KsGeom& g) {
     while ((1u << g.bbits) < g.B) ++g.bbits;
     u64 eb = 16384;
     while ((n + eb - 1) / eb > 4096) eb <<= 1;  // the count matrix stays <= B x 4096
+
     g.EB = (u32)eb;
     g.nblk = (u32)((n + eb - 1) / eb);
     if (g.nblk == 0) g.nblk = 1;

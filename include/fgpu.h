@@ -81,7 +81,8 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
 /* Engine tunables (the analogue of GrB_Global_set_INT32, matrix.rs:151-159): "tiled_u" (items in
  * flight per wavefront of the LDS-tiled vxm: 1/2/4/8), "tiled_threads" (256/512/1024),
  * "tiled_wgs" (grid of that kernel, 0 = fill the CUs), "tiled_nt" (nontemporal entry loads),
- * "transpose_mode" (pattern transpose: 0 = counting transpose, 1 = COO rebuild through the sorter),
+ * "transpose_mode" (pattern transpose: 0 = counting transpose, 1 = COO rebuild through the sorter), "transpose_wb"
+ * (low-digit bits of the counting transpose, 0 = pick; a process-wide experiment knob),
  * "expand_mode" (fgpu_expand: 0 = pick per hop, 1 = sorted-CSR products only, 2 = bit-parallel from the
  * first hop), "expand_fuse_count" (fgpu_expand_count: 1 = the last bit-parallel hop counts its rows where it produces
  * them, 0 = it writes them and a separate pass counts), "expand_row_groups" (sparse mid-chain pull of the bit-parallel
