@@ -271,7 +271,8 @@ void prof_add_bytes(fgpu_ctx* ctx, int idx, uint64_t extra) {
 
 // ---- staged transfers ---------------------------------------------------------------------------
 namespace {
-constexpr size_t XFER_HALF = 4u << 20;   // 4 MiB per half: ~80 us on the link, long enough to hide the host-side copy setup
+constexpr size_t XFER_HALF = 2u << 20;   // 2 MiB per half (4 MiB pinned per lane): ~40 us on the link per chunk, and a host thread
+                                         // copies 2 MiB out in ~200 us, so the link is never what is waited for
 
 fgpu_info xfer_ready(fgpu_lane* l) {
     if (l->xfer) return FGPU_OK;
