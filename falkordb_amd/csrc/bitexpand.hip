@@ -375,18 +375,21 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
                     acc |= (xv[0] | xv[1]) | (xv[2] | xv[3]);
                 }
             } else {
-                // 4 gathers in flight per lane
-                for (u32 q0 = b; q0 < e; q0 += 4 * SLOTS) {
-                    u32 u[4];
+                // G gathers in flight per lane: 8 when a row has 16+ words (SLOTS <= 4) — an item of A' holds ~30 entries at
+                // RMAT-24, so most items then finish in ONE round of gathers instead of two dependent ones
+                constexpr int G = SLOTS <= 4 ? 8 : 4;
+                for (u32 q0 = b; q0 < e; q0 += G * SLOTS) {
+                    u32 u[G];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < G; ++k) {
                         const u32 q = q0 + k * SLOTS + slot;
                         u[k] = (q < e) ? at.colidx[q] : 0xFFFFFFFFu;
                     }
-                    u64 xv[4];
+                    u64 xv[G];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) xv[k] = (u[k] != 0xFFFFFFFFu) ? x[(size_t)u[k] * ws + wo] : 0ull;
-                    acc |= (xv[0] | xv[1]) | (xv[2] | xv[3]);
+                    for (int k = 0; k < G; ++k) xv[k] = (u[k] != 0xFFFFFFFFu) ? x[(size_t)u[k] * ws + wo] : 0ull;
+#pragma unroll
+                    for (int k = 0; k < G; ++k) acc |= xv[k];
                 }
             }
 #pragma unroll
