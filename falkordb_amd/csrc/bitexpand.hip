@@ -642,12 +642,15 @@ __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w
                                                       const u64* __restrict__ x, u64* __restrict__ y,
                                                       uint8_t* __restrict__ yflag, const u64* __restrict__ tbits,
                                                       const u32* __restrict__ tpref,
-                                                      const uint8_t* __restrict__ xflag /* lazy X: rows without a flag are undefined (= empty) */) {
+                                                      const uint8_t* __restrict__ xflag /* lazy X: rows without a flag are undefined (= empty) */,
+                                                      const u32* __restrict__ wordrow /* stored row of every 64th entry */) {
     const u32 t = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     const u32 per = nth / ln;             // entries in flight per sweep
     const u32 sub = t % ln;
     for (u32 q = t / ln; q < nnz; q += per) {
-        u32 lo = 0, hi = d.nvec - 1;      // largest stored row i with rowptr[i] <= q
+        // largest stored row i with rowptr[i] <= q, searched between the rows of the 64-entry word's ends (a delta
+        // layer holds ~10^5 rows: the full search was 18 dependent loads per entry)
+        u32 lo = wordrow[q >> 6], hi = wordrow[(q >> 6) + 1];
         while (lo < hi) {
             const u32 mid = (lo + hi + 1) >> 1;
             if (d.rowptr[mid] <= q) lo = mid; else hi = mid - 1;
@@ -1156,13 +1159,16 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     {
         u32 ln = 1;                               // lanes per delta entry: a power of two covering the row words
         while (ln < s.w && ln < 64) ln <<= 1;
+        const u32 *wr_dm = nullptr, *wr_dp = nullptr;
+        if (has_dm) FGPU_TRY(mat_wordrow(ctx, dm, &wr_dm));
+        if (has_dp) FGPU_TRY(mat_wordrow(ctx, dp, &wr_dp));
         if (has_dm) {
             ProfScope ps(ctx, "bp_delta_kernel<dm>", (u64)dm->nnz * (4 + 16 * s.w));
             u32 grid = cdiv((u64)dm->nnz * ln, 256);
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
             hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dm), (u32)dm->nnz,
                                s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref,
-                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr);
+                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr, wr_dm);
             FGPU_HIP(hipGetLastError());
         }
         if (has_dp) {
@@ -1171,7 +1177,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
             hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dp), (u32)dp->nnz,
                                s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref,
-                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr);
+                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr, wr_dp);
             FGPU_HIP(hipGetLastError());
         }
     }

@@ -353,6 +353,8 @@ fgpu_info mat_transpose_vals(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 fgpu_info dense_rowptr(fgpu_ctx* ctx, const fgpu_mat* a, DevBuf<u32>& rp);
 fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 // transpose.hip: the sort-free builders (stable two-level counting sort); FGPU_NO_VALUE = not applicable, fall back
+// stored-row index of entry 64 w of a snapshot, w in [0, ceil(nnz / 64)] (merge.hip; lazy, owned by the snapshot)
+fgpu_info mat_wordrow(fgpu_ctx* ctx, const fgpu_mat* a, const uint32_t** out);
 void ks_set_wb_override(int wb);   // experiment knob: low-digit bits of the counting sort (0 = pick)
 fgpu_info mat_transpose_counting(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
 fgpu_info mat_from_device_coo_counting(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,

@@ -260,11 +260,8 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other
 }
 
 // the wordrow index of a snapshot: built on first use, owned (and freed) by the matrix
-static fgpu_info layer_of(fgpu_ctx* ctx, const fgpu_mat* a, Layer& l) {
-    l.v = view_of(a);
-    l.val = a->vals;
-    l.nnz = (u32)a->nnz;
-    l.wordrow = nullptr;
+fgpu_info mat_wordrow(fgpu_ctx* ctx, const fgpu_mat* a, const u32** out) {
+    *out = nullptr;
     if (a->nnz == 0) return FGPU_OK;
     std::lock_guard<std::mutex> idx_guard(a->idx_mu);
     if (!a->wordrow) {
@@ -283,8 +280,15 @@ static fgpu_info layer_of(fgpu_ctx* ctx, const fgpu_mat* a, Layer& l) {
         }
         a->wordrow = wr;
     }
-    l.wordrow = a->wordrow;
+    *out = a->wordrow;
     return FGPU_OK;
+}
+
+static fgpu_info layer_of(fgpu_ctx* ctx, const fgpu_mat* a, Layer& l) {
+    l.v = view_of(a);
+    l.val = a->vals;
+    l.nnz = (u32)a->nnz;
+    return mat_wordrow(ctx, a, &l.wordrow);
 }
 
 struct Keep {  // keep bits + exclusive prefix of their per-word popcounts
