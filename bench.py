@@ -798,6 +798,13 @@ def main():
             "cpu_baseline": cpu,
             "pmc": ({k: v for k, v in pmc.items() if not k.startswith("bp_")} if pmc else None),
         }
+        try:
+            # RCCL writes its version banner through C stdio, which would otherwise be flushed at exit — AFTER the JSON
+            # line; flush it first so that the bench line is the last line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if use_dist:
         td.barrier()

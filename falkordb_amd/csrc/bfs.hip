@@ -1740,6 +1740,12 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         if (fg > g) fg = g;
         p->fgrid = (u32)fg;
     }
+    // Default push -> pull switch factor.  A pull level probes the N-bit frontier bitmap once per scanned in-edge: while
+    // the bitmap sits in every XCD's 4 MiB L2 (<= 2 MiB: up to 2^24 vertices) pulling early pays, alpha = 32 (RMAT-22:
+    // 286.6 GTEPS at 32, 283.3 at 24, 278.5 at 20; RMAT-24 flat from 16 to 32); once it does not (RMAT-26: 8 MiB) the same
+    // probes miss L2 and a push of the same frontier is the cheaper level for longer: 460 GTEPS at 32, 489 at 24, 498 at 20,
+    // 495 at 12, 455 at 8.  fgpu_bfs_plan_tune overrides.
+    p->alpha = ((size_t)p->nw * sizeof(u64) > (2u << 20)) ? 20.0 : 32.0;
     p->prof = {{"bfs_fused_kernel<false, 1> (push level)"}, {"bfs_fused_kernel<false, 2> (pull level)"}};
     *out = p;
     return FGPU_OK;
