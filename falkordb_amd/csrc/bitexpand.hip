@@ -581,29 +581,43 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
     }
 }
 
-// the same two sums over the rows the item kernel finished with atomics (rows of more than BP_ITEM entries: `bits`)
-__global__ __launch_bounds__(256) void bp_split_stats_kernel(const u64* __restrict__ bits, u32 n, u32 ws,
+// the same two sums over the rows the item kernel finished with atomics (rows of more than BP_ITEM entries: `bits`).
+// LN = min(ws, 64) lanes read a row, 64 / LN rows per step (a wavefront per row with a 64-lane reduction took 180 us for
+// the ~10^5 split rows of RMAT-24: 48 of 64 lanes idle on 16-word rows, one dependent load per row).
+__global__ __launch_bounds__(256) void bp_split_stats_kernel(const u64* __restrict__ bits, u32 n, u32 ws, u32 lnsh,
                                                             const u64* __restrict__ y, const u32* __restrict__ next_rowptr,
                                                             unsigned long long* __restrict__ stats) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
     const u32 nwords = (n + 63) >> 6;
+    const u32 ln = 1u << lnsh, rpw = 64u >> lnsh;
+    const u32 wl = lane & (ln - 1u), slot = lane >> lnsh;
+    const u64 field = ln == 64 ? ~0ull : (((1ull << ln) - 1ull) << (slot * ln));
     u64 fl = 0, rows = 0;
     for (u32 w = wave; w < nwords; w += nwaves) {
         u64 m = bits[w];                         // wave-uniform
         while (m) {
-            const u32 v = (w << 6) + (u32)__builtin_ctzll(m);
-            m &= m - 1ull;
-            u32 pc = 0;
-            for (u32 k = lane; k < ws; k += 64) pc += (u32)__popcll(y[(size_t)v * ws + k]);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d, 64);
-            if (lane == 0 && pc) {
-                fl += (u64)pc * (next_rowptr[v + 1] - next_rowptr[v]);
-                rows += 1;
+            u32 v = 0xFFFFFFFFu;
+            for (u32 sl = 0; sl < rpw; ++sl) {
+                if (m) {
+                    const u32 idx = (u32)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    if (slot == sl) v = (w << 6) + idx;
+                }
             }
+            u32 pc = 0;
+            if (v != 0xFFFFFFFFu)
+                for (u32 k = wl; k < ws; k += ln) pc += (u32)__popcll(y[(size_t)v * ws + k]);
+            const u64 nz = __ballot(pc != 0);
+            if (pc) fl += (u64)pc * (next_rowptr[v + 1] - next_rowptr[v]);
+            if (wl == 0 && (nz & field)) rows += 1;
         }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        fl += __shfl_xor(fl, d, 64);
+        rows += __shfl_xor(rows, d, 64);
     }
     if (lane == 0 && rows) {
         atomicAdd(&stats[0], (unsigned long long)fl);
@@ -1212,8 +1226,10 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     }
     if (fuse_stats) {
         if (t->n_bp_sitems) {
+            u32 lnsh = 0;
+            while ((2u << lnsh) <= s.ws && lnsh < 6) ++lnsh;
             hipLaunchKernelGGL(bp_split_stats_kernel, dim3(ctx->cus * 2), dim3(256), 0, ctx->stream(), (const u64*)t->bp_split_bits,
-                               n_out, s.ws, (const u64*)o.x.p, (const u32*)next_m->rowptr, (unsigned long long*)gstats.p);
+                               n_out, s.ws, lnsh, (const u64*)o.x.p, (const u32*)next_m->rowptr, (unsigned long long*)gstats.p);
             FGPU_HIP(hipGetLastError());
         }
         u64 st[2] = {0, 0};
