@@ -470,6 +470,25 @@ class Graph:
         return list(zip(_take(orow, n.value).tolist(), _take(osrc, n.value).tolist(),
                         _take(odst, n.value).tolist(), _take(oedge, n.value).tolist()))
 
+    def var_len_traverse(self, start, types=(), dest=None, min_hops=1, max_hops=None, reversed=False,
+                         bidirectional=False, dst_labels=(), emit_path=False, prune=True):
+        """CondVarLenTraverse over one input row (cond_var_len_traverse.rs:81-387): [(from, to, path | None)] in the
+        reference's emission order, plus {frames, pruned, reach_products}."""
+        of, ot, op_, off = u64p(), u64p(), u64p(), u64p()
+        n = C.c_uint64()
+        st = (C.c_uint64 * 3)()
+        _ck(self.L.fh_var_len_traverse(self.h, ",".join(types).encode(), ",".join(dst_labels).encode(),
+                                       1 if reversed else 0, 1 if bidirectional else 0, C.c_uint32(min_hops),
+                                       C.c_uint32(0xFFFFFFFF if max_hops is None else max_hops), C.c_uint64(start),
+                                       C.c_int64(-1 if dest is None else dest), 1 if emit_path else 0, 1 if prune else 0,
+                                       C.byref(of), C.byref(ot), C.byref(op_), C.byref(off), C.byref(n), st))
+        k = n.value
+        offs = _take(off, k + 1).tolist()
+        f, t = _take(of, k).tolist(), _take(ot, k).tolist()
+        p = _take(op_, offs[-1]).tolist()
+        rows = [(f[i], t[i], p[offs[i]:offs[i + 1]] if emit_path else None) for i in range(k)]
+        return rows, {"frames": int(st[0]), "pruned": int(st[1]), "reach_products": int(st[2])}
+
     def build_adjacency(self, types=(), symmetric=False):
         """Graph::build_adjacency_matrix / build_symmetric_adjacency_matrix (graph.rs:3870-3907) -> Matrix"""
         h = C.c_void_p()

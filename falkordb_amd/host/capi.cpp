@@ -534,6 +534,40 @@ int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_r
     });
 }
 
+int fh_var_len_traverse(fh_graph* g, const char* types, const char* dst_labels, int reversed, int bidirectional,
+                        uint32_t min_hops, uint32_t max_hops, uint64_t start, int64_t dest, int emit_path, int prune,
+                        uint64_t** out_from, uint64_t** out_to, uint64_t** path, uint64_t** path_off, uint64_t* n,
+                        uint64_t stats[3]) {
+    return guard([&] {
+        CondVarLenTraverseOp op;
+        op.types = split(types ? types : "", ',');
+        op.dst_labels = split(dst_labels ? dst_labels : "", ',');
+        op.reversed = reversed != 0;
+        op.bidirectional = bidirectional != 0;
+        op.min_hops = min_hops;
+        op.max_hops = max_hops;
+        op.emit_path = emit_path != 0;
+        op.prune = prune != 0;
+        std::vector<VarLenRow> rows;
+        VarLenStats st;
+        op.expand_row(g->g, start, dest >= 0 ? std::optional<u64>((u64)dest) : std::nullopt, rows, &st);
+        std::vector<u64> f, t, p, off{0};
+        for (auto& r : rows) {
+            f.push_back(r.from);
+            t.push_back(r.to);
+            p.insert(p.end(), r.path.begin(), r.path.end());
+            off.push_back(p.size());
+        }
+        *out_from = hand(f);
+        *out_to = hand(t);
+        *path = hand(p);
+        *path_off = hand(off);
+        *n = rows.size();
+        if (stats) { stats[0] = st.frames; stats[1] = st.pruned; stats[2] = st.reach_products; }
+        return 0;
+    });
+}
+
 int fh_algo_bfs(fh_graph* g, int64_t source, int64_t max_depth, const char* rel_type, int want_edges, int* has_row,
                 uint64_t** nodes, uint64_t* n_nodes, uint64_t** edges, uint64_t* n_edges) {
     return guard([&] {

@@ -429,6 +429,134 @@ void CondTraverseOp::expand_row(const Graph& g, std::optional<u64> from_id, std:
     }
 }
 
+// ---- CondVarLenTraverse ---------------------------------------------------------------------------------
+namespace {
+struct VlEdge { u64 src, dst, id; };
+
+// Graph::get_node_relationships_by_type (graph.rs:1797-1835): per tensor (all of them, or the known ones among `types`,
+// in order) the outgoing half — Tensor::iter(id, id, false): (dst, edge id) ascending — then the incoming half —
+// Tensor::iter(id, id, true) over `mt`: (src, edge id) ascending — without the self-loops the outgoing half already gave
+std::vector<VlEdge> node_relationships(const Graph& g, u64 id, const std::vector<u64>& tids, bool outgoing, bool incoming) {
+    std::vector<VlEdge> out;
+    for (u64 t : tids) {
+        const Tensor& T = g.relationship_tensors()[t];
+        if (outgoing)
+            for (auto& e : T.structural_iter(id, id))
+                for (u64 eid : T.get(e.row, e.col)) out.push_back({e.row, e.col, eid});
+        if (incoming)
+            for (auto& e : T.matrix_t().iter(id, id)) {          // row = dst (= id), col = src
+                if (outgoing && e.col == id) continue;
+                for (u64 eid : T.get(e.col, id)) out.push_back({e.col, id, eid});
+            }
+    }
+    return out;
+}
+}  // namespace
+
+void CondVarLenTraverseOp::expand_row(const Graph& g, u64 start, std::optional<u64> dest, std::vector<VarLenRow>& out,
+                                      VarLenStats* stats) const {
+    VarLenStats local;
+    VarLenStats& st = stats ? *stats : local;
+    // types: none named = every tensor; named = the known ones (filter_map, graph.rs:1803-1810)
+    std::vector<u64> tids;
+    if (types.empty())
+        for (u64 t = 0; t < g.relationship_tensors().size(); ++t) tids.push_back(t);
+    else
+        for (auto& t : types)
+            if (auto id = g.type_id(t)) tids.push_back(*id);
+    // destination labels resolved once per row; an unknown label suppresses every emission (:100-107)
+    std::vector<LabelId> dl;
+    bool label_missing = false;
+    for (auto& l : dst_labels) {
+        if (auto id = g.label_id(l)) dl.push_back(*id);
+        else label_missing = true;
+    }
+    auto labels_ok = [&](u64 v) {
+        for (LabelId l : dl)
+            if (!g.node_has_label_id(v, l)) return false;
+        return true;
+    };
+    const bool with_out = bidirectional || !reversed, with_in = bidirectional || reversed;
+    auto emit = [&](u64 other, const std::vector<u64>& walk) {
+        VarLenRow r;
+        r.from = reversed ? other : start;
+        r.to = reversed ? start : other;
+        if (emit_path) {
+            r.path = walk;
+            if (reversed) std::reverse(r.path.begin(), r.path.end());   // path_value (:134-142)
+        }
+        out.push_back(std::move(r));
+    };
+    // 0-hop emission (:153-171)
+    if (min_hops == 0 && (!dest || *dest == start) && !label_missing && labels_ok(start)) emit(start, {start});
+
+    // reach[r] (r >= 1): nodes from which `dest` is reachable by a walk of 1..r steps in the direction the DFS moves.
+    // Walking back from dest: the DFS follows A (outgoing), A' (reversed) or A + A' (bidirectional), so the sets grow by
+    // products with A', A or A + A'.  Only worth it for a bound destination and a finite budget.
+    std::vector<std::vector<uint64_t>> reach;
+    const u64 n = g.node_cap();
+    if (prune && dest && max_hops != UINT32_MAX && max_hops >= 2 && max_hops <= 64 && !tids.empty()) {
+        // (build_adjacency_matrix takes the names: none = the adjacency of every type, unknown names are skipped)
+        Matrix back = bidirectional ? g.build_symmetric_adjacency_matrix(types)
+                                    : (reversed ? g.build_adjacency_matrix(types) : g.build_adjacency_matrix(types).transpose());
+        Matrix f(g.ctx(), Type::Bool, 1, n);
+        f.build({0}, {*dest});
+        std::vector<uint64_t> acc((n + 63) / 64, 0);
+        reach.resize(max_hops);                       // reach[r] for r in [1, max_hops - 1]
+        for (uint32_t r = 1; r + 1 <= max_hops; ++r) {
+            f.lmxm(back);
+            ++st.reach_products;
+            for (auto& e : f.iter(0, 0)) acc[e.col >> 6] |= 1ull << (e.col & 63);
+            reach[r] = acc;
+            if (f.nvals() == 0) {                     // the frontier died out: larger budgets add nothing
+                for (uint32_t q = r + 1; q + 1 <= max_hops; ++q) reach[q] = acc;
+                break;
+            }
+        }
+    }
+    auto can_reach = [&](u64 v, uint32_t budget) {
+        if (reach.empty() || budget == 0) return true;
+        if (budget >= reach.size()) budget = (uint32_t)reach.size() - 1;
+        return ((reach[budget][v >> 6] >> (v & 63)) & 1ull) != 0;
+    };
+
+    struct Frame { u64 node; std::vector<u64> walk; std::vector<u64> used; uint32_t depth; };
+    std::vector<Frame> stack;
+    std::unordered_map<u64, std::vector<VlEdge>> adj_cache;          // per row, like the reference's (:115-116)
+    stack.push_back({start, emit_path ? std::vector<u64>{start} : std::vector<u64>{}, {}, 0});
+    std::vector<std::pair<u64, u64>> scratch;                        // (edge id, neighbour)
+    while (!stack.empty()) {
+        Frame fr = std::move(stack.back());
+        stack.pop_back();
+        const uint32_t hop = fr.depth + 1;
+        if (hop > max_hops) continue;
+        ++st.frames;
+        auto it = adj_cache.find(fr.node);
+        if (it == adj_cache.end()) it = adj_cache.emplace(fr.node, node_relationships(g, fr.node, tids, with_out, with_in)).first;
+        scratch.clear();
+        for (const VlEdge& e : it->second) {
+            if (std::find(fr.used.begin(), fr.used.end(), e.id) != fr.used.end()) continue;   // relationship uniqueness
+            if (reversed) { if (e.dst == fr.node) scratch.push_back({e.id, e.src}); }
+            else if (e.src == fr.node) scratch.push_back({e.id, e.dst});
+            else if (bidirectional && e.dst == fr.node) scratch.push_back({e.id, e.src});
+        }
+        for (auto& [eid, nb] : scratch) {
+            const bool will_emit = hop >= min_hops && (!dest || *dest == nb) && !label_missing && labels_ok(nb);
+            bool will_continue = hop < max_hops;
+            if (will_continue && !can_reach(nb, max_hops - hop)) { will_continue = false; ++st.pruned; }
+            if (!will_emit && !will_continue) continue;
+            std::vector<u64> walk = fr.walk;
+            if (emit_path) { walk.push_back(eid); walk.push_back(nb); }
+            if (will_emit) emit(nb, walk);
+            if (will_continue) {
+                std::vector<u64> used = fr.used;
+                used.push_back(eid);
+                stack.push_back({nb, std::move(walk), std::move(used), hop});
+            }
+        }
+    }
+}
+
 // ---- ExpandInto ---------------------------------------------------------------------------------------
 static std::vector<u64> resolve_types(const Graph& g, const std::vector<std::string>& types) {
     std::vector<u64> tids;

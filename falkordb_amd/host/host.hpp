@@ -441,6 +441,36 @@ struct ExpandIntoOp {
                       std::vector<std::vector<std::array<u64, 3>>>& out) const;
 };
 
+// CondVarLenTraverse (runtime/ops/cond_var_len_traverse.rs:81-387): the per-row DFS of `(a)-[:T*min..max]->(b)` with
+// Cypher trail semantics (a relationship is used at most once per path, nodes may repeat), in the reference's emission
+// order: frames leave a LIFO stack, a frame's emissions follow its adjacency order (types in order; per type the
+// outgoing edges by (dst, id) ascending, then the incoming ones by (src, id) ascending, a self-loop only once).
+// The device is the DFS's pruning oracle when the destination is bound: the nodes that can still reach it within r more
+// hops (r = 1 .. max_hops - 1; walks, a superset of trails) come from r boolean products on the device, and a branch that
+// is not in the set for its remaining budget is never expanded — the emitted sequence is unchanged, only frames that
+// could not emit disappear.  Edge-attribute / WHERE filters need the attribute store (out of scope).
+struct VarLenRow {
+    u64 from, to;
+    std::vector<u64> path;   // emit_path: node, edge, node, ... in pattern order (from -> to); else empty
+};
+struct VarLenStats {
+    u64 frames = 0;          // DFS frames expanded (adjacency lists walked)
+    u64 pruned = 0;          // continuations the reach sets cut
+    u64 reach_products = 0;  // device products spent on the reach sets
+};
+struct CondVarLenTraverseOp {
+    std::vector<std::string> types;
+    std::vector<std::string> dst_labels;   // of the pattern's far endpoint (the one the DFS walks towards)
+    bool reversed = false;                 // the bound endpoint is the pattern's `to`: walk incoming edges
+    bool bidirectional = false;
+    uint32_t min_hops = 1, max_hops = 1;   // UINT32_MAX = unbounded
+    bool emit_path = false;
+    bool prune = true;                     // use the device reach sets when dest is bound
+    // one input row: DFS from `start`; `dest` = the other endpoint when it is bound too
+    void expand_row(const Graph& g, u64 start, std::optional<u64> dest, std::vector<VarLenRow>& out,
+                    VarLenStats* stats = nullptr) const;
+};
+
 struct BfsResult {
     bool has_row = false;
     std::vector<u64> nodes, edges;

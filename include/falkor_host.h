@@ -157,6 +157,17 @@ int fh_cond_traverse_rows(fh_graph* g, const char* spec, const int64_t* from_ids
 int fh_expand_into(fh_graph* g, const char* types, int bidirectional, int emit_relationship, int batched,
                    const uint64_t* srcs, const uint64_t* dsts, uint64_t k, uint64_t** out_row,
                    uint64_t** out_src, uint64_t** out_dst, uint64_t** out_edge, uint64_t* n);  /* expand_into.rs:121-258 */
+/* CondVarLenTraverse, one input row (cond_var_len_traverse.rs:81-387): the trail DFS of (start)-[:types*min..max]-(far end)
+ * in the reference's emission order.  types / dst_labels: comma lists ("" = all / none).  reversed: the bound endpoint is the
+ * pattern's `to` (walk incoming edges); max_hops = UINT32_MAX: unbounded; dest < 0: the far end is not bound.  emit_path:
+ * `path` holds node, edge, node, ... of every row back to back in pattern order, `path_off` (n + 1 offsets) cuts it.
+ * prune != 0: with a bound far end the device computes which nodes can still reach it within the remaining budget and
+ * branches outside that set are not expanded (same rows, same order).  stats (nullable): frames expanded, continuations
+ * pruned, device products spent on the reach sets. */
+int fh_var_len_traverse(fh_graph* g, const char* types, const char* dst_labels, int reversed, int bidirectional,
+                        uint32_t min_hops, uint32_t max_hops, uint64_t start, int64_t dest, int emit_path, int prune,
+                        uint64_t** out_from, uint64_t** out_to, uint64_t** path, uint64_t** path_off, uint64_t* n,
+                        uint64_t stats[3]);
 /* source < 0 = NULL; rel_type NULL = all types.  `edges` holds one id per (parent, child) pair that HAS a
  * representative edge among the types, in node order; a pair without one is skipped in `edges` but its child stays in
  * `nodes` — exactly what the reference yields (algo_procedures.rs:1121-1150) — so the two lists are parallel only

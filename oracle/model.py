@@ -538,6 +538,92 @@ def expand_row(g: Graph, from_id, to_id, types, from_labels=(), to_labels=(), tr
     return out
 
 
+def node_relationships(g: Graph, node, types, outgoing=True, incoming=False):
+    """Graph::get_node_relationships_by_type (graph.rs:1797-1835): [(src, dst, edge id)] — per tensor (all of them, or
+    the KNOWN ones among `types`, in the order given) the outgoing half (dst, id ascending: Tensor::iter(id, id, false)),
+    then the incoming half (src, id ascending: the transposed iterator), without the self-loops the outgoing half
+    already produced."""
+    tids = [g.type_ids[t] for t in types if t in g.type_ids] if types else list(range(len(g.tensors)))
+    out = []
+    for t in tids:
+        T = g.tensors[t]
+        struct = sorted(T.structure())
+        if outgoing:
+            for (s_, d_) in struct:
+                if s_ == node:
+                    out.extend((s_, d_, e) for e in T.get(s_, d_))
+        if incoming:
+            for (d_, s_) in sorted((d_, s_) for (s_, d_) in struct):
+                if d_ == node and not (outgoing and s_ == node):
+                    out.extend((s_, d_, e) for e in T.get(s_, d_))
+    return out
+
+
+def var_len_expand(g: Graph, start, types=(), dest=None, min_hops=1, max_hops=None, reversed=False, bidirectional=False,
+                   dst_labels=(), emit_path=False):
+    """CondVarLenTraverse over one input row (cond_var_len_traverse.rs:81-387, VarLenIter): [(from, to, path | None)] in
+    the reference's emission order.  Trail semantics: a relationship id is used at most once on a path, nodes may repeat
+    (:123-126).  Frames leave a LIFO stack (:221); a frame walks its node's cached adjacency (:240-243), keeps the
+    neighbours the direction allows (:253-266), and for each, in adjacency order, emits when hop >= min_hops and the
+    destination / label filters pass (:316-319), and pushes a continuation when hop < max_hops (:321); the frame's
+    emissions are yielded before the next frame runs (:379-383).  A reversed traversal walks incoming edges and reports
+    (neighbour, start) (:343-347); its path is reversed into pattern order (:134-142).  Attribute / WHERE edge filters are
+    out of scope (no attribute store)."""
+    types = list(types)
+    out = []
+    lids = []
+    label_missing = False
+    for l in dst_labels:
+        if l in g.label_ids:
+            lids.append(g.label_ids[l])
+        else:
+            label_missing = True
+
+    def labels_ok(v):
+        return all(g.node_has_label_id(v, l) for l in lids)
+
+    def emit(other, walk):
+        path = None
+        if emit_path:
+            path = list(walk[::-1]) if reversed else list(walk)
+        out.append((other, start, path) if reversed else (start, other, path))
+
+    if min_hops == 0 and (dest is None or dest == start) and not label_missing and labels_ok(start):   # :153-171
+        emit(start, [start])
+    w_out, w_in = bidirectional or not reversed, bidirectional or reversed
+    cache = {}
+    stack = [(start, [start] if emit_path else [], (), 0)]
+    while stack:
+        node, walk, used, depth = stack.pop()
+        hop = depth + 1
+        if max_hops is not None and hop > max_hops:
+            continue
+        if node not in cache:
+            cache[node] = node_relationships(g, node, types, w_out, w_in)
+        nbrs = []
+        for (s_, d_, e) in cache[node]:
+            if e in used:
+                continue
+            if reversed:
+                if d_ == node:
+                    nbrs.append((e, s_))
+            elif s_ == node:
+                nbrs.append((e, d_))
+            elif bidirectional and d_ == node:
+                nbrs.append((e, s_))
+        for (e, nb) in nbrs:
+            will_emit = hop >= min_hops and (dest is None or dest == nb) and not label_missing and labels_ok(nb)
+            will_continue = max_hops is None or hop < max_hops
+            if not will_emit and not will_continue:
+                continue
+            nwalk = walk + [e, nb] if emit_path else walk
+            if will_emit:
+                emit(nb, nwalk)
+            if will_continue:
+                stack.append((nb, nwalk, used + (e,), hop))
+    return out
+
+
 def trail_counts(edges, src, k):
     """Trails (edge-unique paths) of exactly k hops from `src`, counted per destination by depth-first enumeration —
     what CondVarLenTraverseOp's DFS (cond_var_len_traverse.rs:196-387) emits one row each for.  `edges` = list of

@@ -1212,3 +1212,94 @@ def test_matrix_v19_payload_decode_and_encode(hctx):
     for bits in (32, 64):                                           # the same state built by hand
         hm, _ = host.matrix_decode(hctx, _container(3_000_000, 3_000_000, [0], [], h=[], idx_bits=bits))
         assert (*hm.dims(), hm.nvals()) == (3_000_000, 3_000_000, 0) and hm.iter() == []
+
+
+# ---- CondVarLenTraverse (cond_var_len_traverse.rs:81-387): trail DFS, device reach sets as pruning oracle ------------
+def _twin_graphs(hctx, n, typed_edges, labels=(), commit=True):
+    """The same multigraph in the C++ host layer (on the GPU) and in the oracle model: typed_edges = [(type, src, dst)],
+    edge ids in list order; labels = [(label, node)]."""
+    g, og = host.Graph(hctx, n), model.Graph(n)
+    for name, v in labels:
+        lid = g.add_label(name); og.add_label(name)
+        g.label_node(v, lid); og.node_labels.add((v, og.label_ids[name]))
+    pairs = {}
+    for eid, (t, s_, d_) in enumerate(typed_edges):
+        tid = g.add_type(t); og.add_type(t)
+        g.create_edge(tid, s_, d_, eid)
+        pairs.setdefault((og.type_ids[t], s_, d_), []).append(eid)
+        og.adjacency.m.add((s_, d_))
+    for (t, s_, d_), es in pairs.items():
+        og.tensors[t].m[(s_, d_)] = es[0] if len(es) == 1 else model.MULTI_EDGE
+        if len(es) > 1:
+            og.tensors[t].me[(s_, d_)] = es
+    if commit:
+        g.commit()
+    return g, og
+
+
+def test_var_len_reference_flow_fixtures(hctx):
+    """Known answers of tests/flow/test_variable_length_traversals.py, through the host layer on the GPU and the model."""
+    # :14-39 the chain A->B->C->D; test02 (:50-62): (a)-[*]->(b) and (a)<-[*]-(b) give 6 rows; test06 (:98-104): 12
+    chain = [("knows", i, i + 1) for i in range(3)]
+    g, og = _twin_graphs(hctx, 4, chain)
+    for rev in (False, True):
+        rows = [r for v in range(4) for r in g.var_len_traverse(v, reversed=rev)[0]]
+        assert len(rows) == 6 and rows == [r for v in range(4) for r in model.var_len_expand(og, v, reversed=rev)]
+    both = [r for v in range(4) for r in g.var_len_traverse(v, bidirectional=True)[0]]
+    assert len(both) == 12
+    # test05 (:92-96): an unknown relationship type matches nothing; test07 (:106-112): ...except at zero length
+    assert [r for v in range(4) for r in g.var_len_traverse(v, types=["no_edge"])[0]] == []
+    assert len([r for v in range(4) for r in g.var_len_traverse(v, types=["not_knows"], min_hops=0, max_hops=1)[0]]) == 4
+    # test11 (:225-259): a->b->c->a, d->d; undirected paths between a and c
+    g, og = _twin_graphs(hctx, 4, [("R", 0, 1), ("R", 1, 2), ("R", 2, 0), ("R", 3, 3)])
+    lens = lambda rows: sorted((len(p) - 1) // 2 for (_, _, p) in rows)
+    assert lens(g.var_len_traverse(0, dest=2, min_hops=2, max_hops=2, bidirectional=True, emit_path=True)[0]) == [2]
+    assert lens(g.var_len_traverse(0, dest=2, min_hops=2, bidirectional=True, emit_path=True)[0]) == [2]
+    assert lens(g.var_len_traverse(0, dest=2, bidirectional=True, emit_path=True)[0]) == [1, 2]
+    assert lens(g.var_len_traverse(3, min_hops=0, max_hops=0, bidirectional=True, emit_path=True)[0]) == [0]
+    # test12 (:261-288): a->b->c->a plus a->d; (a)-[*2..]->(z) does not get stuck in the cycle: z = a, c and one more (d)
+    g, og = _twin_graphs(hctx, 4, [("R", 0, 1), ("R", 1, 2), ("R", 2, 0), ("R", 0, 3)])
+    z = sorted(t for (_, t, _) in g.var_len_traverse(0, min_hops=2)[0])
+    assert len(z) == 3 and z[0] == 0 and 2 in z
+    # test13 (:290-339): a tree of fanout 3, depth 2: (root)-[*0..]->(n) reaches all 13 nodes once
+    tree = [("R", 0, 1 + i) for i in range(3)] + [("R", 1 + i, 4 + 3 * i + j) for i in range(3) for j in range(3)]
+    g, og = _twin_graphs(hctx, 13, tree)
+    rows, _ = g.var_len_traverse(0, min_hops=0)
+    assert sorted(t for (_, t, _) in rows) == list(range(13))
+    assert rows == model.var_len_expand(og, 0, min_hops=0)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("commit", [True, False], ids=["committed", "pending-deltas"])
+def test_var_len_matches_model_on_random_multigraphs(hctx, seed, commit):
+    """Emission order, endpoints and paths against oracle/model.py var_len_expand on small multigraphs with two types,
+    multi-edges, self-loops and cycles: every direction, hop ranges, bound destination (pruned and unpruned: identical
+    rows, and the reach sets do cut frames), destination labels, an alternation with an unknown type."""
+    rng = np.random.default_rng(seed)
+    n = 9
+    edges = [(("KNOWS", "LIKES")[int(rng.integers(0, 2))], int(rng.integers(0, n)), int(rng.integers(0, n))) for _ in range(16)]
+    edges += [edges[0], edges[3]]                                  # multi-edge pairs
+    labels = [("L", v) for v in range(0, n, 2)]
+    g, og = _twin_graphs(hctx, n, edges, labels, commit)
+    cut = 0
+    for start in (0, 3, 7):
+        for kw in ({}, {"reversed": True}, {"bidirectional": True}):
+            for (lo, hi) in ((1, 1), (1, 3), (2, 4), (0, 2), (1, None)):
+                if hi is None and kw.get("bidirectional"):
+                    hi = 5                                          # unbounded undirected trails explode on 18 edges
+                want = model.var_len_expand(og, start, min_hops=lo, max_hops=hi, emit_path=True, **kw)
+                got, _ = g.var_len_traverse(start, min_hops=lo, max_hops=hi, emit_path=True, **kw)
+                assert got == want, (start, kw, lo, hi)
+                for dest in (2, start):
+                    want = model.var_len_expand(og, start, dest=dest, min_hops=lo, max_hops=hi, emit_path=True, **kw)
+                    got, st = g.var_len_traverse(start, dest=dest, min_hops=lo, max_hops=hi, emit_path=True, **kw)
+                    raw, st0 = g.var_len_traverse(start, dest=dest, min_hops=lo, max_hops=hi, emit_path=True, prune=False, **kw)
+                    assert got == want == raw, (start, dest, kw, lo, hi)
+                    assert st["frames"] <= st0["frames"] and st0["pruned"] == 0
+                    cut += st0["frames"] - st["frames"]
+            want = model.var_len_expand(og, start, types=["KNOWS"], max_hops=3, dst_labels=["L"], **kw)
+            assert g.var_len_traverse(start, types=["KNOWS"], max_hops=3, dst_labels=["L"], **kw)[0] == want
+            want = model.var_len_expand(og, start, types=["LIKES", "NOPE"], max_hops=2, **kw)
+            assert g.var_len_traverse(start, types=["LIKES", "NOPE"], max_hops=2, **kw)[0] == want
+            assert g.var_len_traverse(start, max_hops=2, dst_labels=["MISSING"], **kw)[0] == []
+    assert cut > 0                                                  # the device reach sets did prune something
