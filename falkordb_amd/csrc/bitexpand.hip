@@ -453,9 +453,11 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
                                                                              BpProbe pr, u64* __restrict__ y,
                                                                              uint8_t* __restrict__ yflag,
                                                                              const u32* __restrict__ next_rowptr,
-                                                                             unsigned long long* __restrict__ stats) {
+                                                                             unsigned long long* __restrict__ stats,
+                                                                             const u64* __restrict__ later_bits) {
     // stats (nullable, with next_rowptr): [0] += popcount(Y[v]) * out-degree of v in the next hop's matrix, [1] += rows
-    // written — what bp_flops / bp_count_flags would find in a pass of their own
+    // written — what bp_flops / bp_count_flags would find in a pass of their own.  Rows flagged in `later_bits`
+    // (nullable: destinations of a delta layer, whose rows change after this kernel) are left to bp_split_stats_kernel.
     u64 st_flops = 0;
     u32 st_rows = 0;
     constexpr int SLOTS = 64 / LN;
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
         const u32 ri = v0 + lane < nrows ? v0 + lane : nrows;
         const u32 rp = at.rowptr[ri];
         const u32 nrp = stats ? next_rowptr[ri] : 0u;   // next hop's out-degrees of the group's rows, loaded with the rest
+        const u32 later = later_bits ? (u32)(later_bits[v0 >> 6] >> (v0 & 63)) : 0u;   // (R = 32 rows: half a word)
         const u32 rp1 = (u32)__shfl_down((int)rp, 1, 64);
         const u32 ndeg = (u32)__shfl_down((int)nrp, 1, 64) - nrp;
         u32 deg = lane < R ? rp1 - rp : 0u;
@@ -560,8 +563,9 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
             if (wl == 0 && mine) yflag[v0 + row] = 1;
             if (stats) {   // (wave-uniform)
                 const u32 dg = (u32)__shfl((int)ndeg, (int)(row < R ? row : 0u), 64);
-                if (mine && wl == 0) st_rows += 1;
-                st_flops += (u64)__popcll(a) * dg;
+                const bool now = row < R && !((later >> row) & 1u);
+                if (now && mine && wl == 0) st_rows += 1;
+                if (now) st_flops += (u64)__popcll(a) * dg;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1059,7 +1063,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         FGPU_TRY(bp_alloc_flags(ctx, o));
     }
     bool fuse_stats = false;
-    DevBuf<u64> gstats;
+    DevBuf<u64> gstats, later;
     u64* ydst = ca ? side.p : o.x.p;          // rows of Y, or the slots of the side buffer
     uint8_t* yflag = ca ? nullptr : o.flag.p;
     int pull_idx = -1;
@@ -1069,9 +1073,9 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         FGPU_REQUIRE(sparse || !s.lazy, FGPU_INVALID, "bit-parallel hop: a lazily zeroed state needs the sparse pull");
         // row-group form: rows of <= BP_ITEM entries by bp_pull_groups_kernel, the split rows' items by the item kernel
         const bool groups = sparse && mode == 0 && s.ws <= 16 && ctx->opt.expand_row_groups;
-        // ... and it can sum the next hop's traversed-edge count and the flagged rows on its way (clean layers only: a
-        // delta fix-up changes rows after the pull; the next matrix must be plain CSR over the same vertices)
-        fuse_stats = groups && next_m && !has_dm && !has_dp && !next_m->is_hyper() && next_m->nrows == m->ncols;
+        // ... and it can sum the next hop's traversed-edge count and the flagged rows on its way (the next matrix must be
+        // plain CSR over the same vertices); rows a delta fix-up changes after the pull are summed after it
+        fuse_stats = groups && next_m && !next_m->is_hyper() && next_m->nrows == m->ncols;
         const u32 nitems = groups ? t->n_bp_sitems : t->n_bp_items;
         const u32* item_list = groups ? t->bp_sitems : t->bp_items;
         u32 grid = cdiv(nitems ? nitems : 1, 4);
@@ -1129,6 +1133,21 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         if (fuse_stats) {
             FGPU_TRY(gstats.alloc(ctx, 2));
             FGPU_HIP(hipMemsetAsync(gstats.p, 0, 2 * sizeof(u64), ctx->stream()));
+            if (has_dm || has_dp) {   // split rows + delta destinations: the rows summed after the fix-ups
+                const u32 nwords = (n_out + 63) / 64;
+                FGPU_TRY(later.alloc(ctx, (size_t)nwords + 2));
+                if (t->bp_split_bits)
+                    FGPU_HIP(hipMemcpyAsync(later.p, t->bp_split_bits, (size_t)nwords * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream()));
+                else
+                    FGPU_HIP(hipMemsetAsync(later.p, 0, (size_t)nwords * sizeof(u64), ctx->stream()));
+                for (const fgpu_mat* d : {has_dm ? dm : nullptr, has_dp ? dp : nullptr}) {
+                    if (!d) continue;
+                    u32 grid = cdiv(d->nnz, 256);
+                    if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
+                    hipLaunchKernelGGL(bp_mark_cols_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const u32*)d->colidx, (u32)d->nnz, later.p);
+                }
+                FGPU_HIP(hipGetLastError());
+            }
         }
         if (groups) {
             const size_t per_wave = ((size_t)BP_GROUP * s.ws + 256 + 32) * sizeof(u64);
@@ -1145,7 +1164,8 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         hipLaunchKernelGGL(bp_pull_groups_kernel<LN>, dim3(ggrid), dim3(BP_GROUP_WAVES * 64), lds_g, ctx->stream(),     \
                            view_of(t), (u32)t->nrows, (const u64*)s.x.p, pr, ydst, yflag,                               \
                            fuse_stats ? (const u32*)next_m->rowptr : (const u32*)nullptr,                               \
-                           fuse_stats ? (unsigned long long*)gstats.p : (unsigned long long*)nullptr);                  \
+                           fuse_stats ? (unsigned long long*)gstats.p : (unsigned long long*)nullptr,                   \
+                           (const u64*)later.p);                                                                        \
     } while (0)
             switch (s.ws) {
                 case 1: BP_GROUPS(1); break;
@@ -1225,10 +1245,11 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         return FGPU_OK;
     }
     if (fuse_stats) {
-        if (t->n_bp_sitems) {
+        if (t->n_bp_sitems || later.p) {
             u32 lnsh = 0;
             while ((2u << lnsh) <= s.ws && lnsh < 6) ++lnsh;
-            hipLaunchKernelGGL(bp_split_stats_kernel, dim3(ctx->cus * 2), dim3(256), 0, ctx->stream(), (const u64*)t->bp_split_bits,
+            hipLaunchKernelGGL(bp_split_stats_kernel, dim3(ctx->cus * 2), dim3(256), 0, ctx->stream(),
+                               later.p ? (const u64*)later.p : (const u64*)t->bp_split_bits,
                                n_out, s.ws, lnsh, (const u64*)o.x.p, (const u32*)next_m->rowptr, (unsigned long long*)gstats.p);
             FGPU_HIP(hipGetLastError());
         }
