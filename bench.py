@@ -219,6 +219,19 @@ def khop_inputs(ctx, scale, edge_factor):
     raw = ctx.mat_from_coo(n, n, rng.integers(0, n, k, dtype=np.uint64), rng.integers(0, n, k, dtype=np.uint64))
     dp = raw.merge(None, A)
     raw.free()
+
+    def hypersparse(m):
+        # Delta layers are hypersparse in the reference (Delta<T>::new pins them so, versioned_matrix.rs:214-235): a row list
+        # and a short row-pointer array instead of N + 1 row pointers for ~10^5 stored rows
+        rp, ci, _ = m.export_csr()
+        deg = np.diff(rp.astype(np.int64))
+        rows = np.nonzero(deg)[0].astype(np.uint64)
+        short = np.concatenate([[0], np.cumsum(deg[deg > 0])]).astype(np.uint64)
+        h = ctx.mat_from_csr(n, n, short, ci, hyper_rows=rows)
+        m.free()
+        return h
+    if os.environ.get("FGPU_BENCH_HYPER_DELTAS", "1") != "0":
+        dp, dm = hypersparse(dp), hypersparse(dm)
     return A, dp, dm
 
 
