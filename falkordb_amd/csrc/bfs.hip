@@ -1957,6 +1957,7 @@ static void slab_layout(const fgpu_bfs_plan* p, std::vector<u64>& offs, std::vec
 }
 
 static fgpu_info dist_event(fgpu_bfs_plan* p, size_t idx) {
+    (void)p->ctx->lane();   // the plan's device must be current when its events are created (a gang spans devices)
     while (p->dist_ev.size() <= idx) {
         hipEvent_t e = nullptr;
         FGPU_HIP(hipEventCreate(&e));
@@ -1991,6 +1992,7 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
     fgpu_info rc = FGPU_OK;
     if (peer)
         for (int k = 0; k < nplans && rc == FGPU_OK; ++k) {
+            (void)plans[k]->ctx->lane();   // events of plan k live on plan k's device
             if (hipEventCreateWithFlags(&lvl_done[k], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&copied[k], hipEventDisableTiming) != hipSuccess) {
                 set_error("fgpu_bfs_dist_run: event creation failed");

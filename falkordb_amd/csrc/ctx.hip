@@ -95,7 +95,13 @@ void lane_destroy(fgpu_lane* l) {
 
 fgpu_lane* fgpu_ctx::lane() {
     ThreadLanes& t = tl_lanes;
-    if (t.last_id == id) return t.last_lane;
+    if (t.last_id == id) {
+        // the process may host other HIP users (PyTorch in bench.py and the tests, a second context of a gang): whoever
+        // changed this thread's current device since our last call must not decide where hipMalloc / hipEventCreate land
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device) (void)hipSetDevice(device);
+        return t.last_lane;
+    }
     (void)hipSetDevice(device);   // HIP's current device is per thread; this thread last called another context (or none)
     for (auto& r : t.refs)
         if (r.id == id) { t.last_id = id; t.last_lane = r.lane; return r.lane; }

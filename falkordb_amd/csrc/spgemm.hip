@@ -645,6 +645,12 @@ extern "C" fgpu_info fgpu_expand_trail_counts(fgpu_ctx* ctx, const uint64_t* src
     FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
     for (u64 i = 0; i < nsrc; ++i)
         FGPU_REQUIRE(src_ids[i] != UINT64_MAX, FGPU_INVALID, "fgpu_expand_trail_counts: every row needs a source");
+    // `-[:T*1..2]->` walks ONE relationship: the "same edge twice" correction of the two-hop count (the a -> a -> a walk
+    // over one self-loop) is only meaningful when both hops read the same layers.  With different layers per hop no
+    // edge can repeat and the subtraction would undercount, so that form is refused rather than answered wrongly.
+    FGPU_REQUIRE(nhops == 1 || (m[0] == m[1] && (dp ? dp[0] : nullptr) == (dp ? dp[1] : nullptr) &&
+                                (dm ? dm[0] : nullptr) == (dm ? dm[1] : nullptr)),
+                 FGPU_INVALID, "fgpu_expand_trail_counts: both hops must read the same relationship layers (one var-length relationship)");
     // effective layers (m \ dm) U dp — real edges, no row-level mask quirk: these are counts of paths, not a delta_lmxm
     std::vector<const fgpu_mat*> eff(nhops, nullptr);
     std::vector<fgpu_mat*> owned;

@@ -125,6 +125,7 @@ ContainerData parse_container(ByteReader& r) {
     const int pb = index_bits(p, "p"), ib = index_bits(i, "i"), hb = index_bits(h, "h");
     if (p.n_entries == 0) {                      // an empty matrix may come with an empty pointer vector
         if (c.nvals) throw GrbError(FGPU_INVALID, "container: nvals without row pointers");
+        c.valued = x.type == "GrB_UINT64";       // an empty Matrix<u64> stays a Matrix<u64> (Tensor::decode checks the type)
         c.hyper = c.format == GXB_HYPERSPARSE;
         if (!c.hyper) c.p.assign(c.nrows + 1, 0);
         else c.p.assign(1, 0);
@@ -311,7 +312,7 @@ void Tensor::encode(ByteWriter& w, const BlobCodec& codec) const {
         fm.encode(w);
     }
     empty.encode(w);                                      // delta-plus (:1093)
-    Matrix(ctx, Type::Bool, nrows(), ncols()).encode(w);  // delta-minus (decoded as Matrix<bool>, :1134)
+    empty.encode(w);                                      // delta-minus: the same empty Matrix<u64> the reference writes (:1094)
     const u64 total = edge_count();
     w.write_unsigned(total);
     if (total == 0) return;
@@ -329,18 +330,30 @@ Tensor Tensor::decode(Context& ctx, ByteReader& r, const BlobCodec& codec) {
     Matrix fwd_m = Matrix::decode(ctx, r);
     Matrix fwd_dp = Matrix::decode(ctx, r);
     Matrix fwd_dm = Matrix::decode(ctx, r);
-    if (fwd_m.type() != Type::UInt64) throw GrbError(FGPU_INVALID, "Tensor decode: the forward matrix is not UINT64");
+    // an empty layer carries no values, so its element type is not recoverable from every encoder's payload: only a
+    // layer that HAS entries must be UINT64 (base and delta-plus hold edge ids; delta-minus is read for its pattern only)
+    if (fwd_m.nvals() && fwd_m.type() != Type::UInt64) throw GrbError(FGPU_INVALID, "Tensor decode: the forward matrix is not UINT64");
+    if (fwd_dp.nvals() && fwd_dp.type() != Type::UInt64) throw GrbError(FGPU_INVALID, "Tensor decode: the forward delta-plus is not UINT64");
+    if (fwd_dp.nrows() != fwd_m.nrows() || fwd_dp.ncols() != fwd_m.ncols() || fwd_dm.nrows() != fwd_m.nrows() ||
+        fwd_dm.ncols() != fwd_m.ncols())
+        throw GrbError(FGPU_DIM_MISMATCH, "Tensor decode: the forward layers differ in shape");
     const u64 nr = fwd_m.nrows(), nc = fwd_m.ncols();
     // (fwd_m \ fwd_dm) U fwd_dp, MSB-flagged values -> the MULTI_EDGE sentinel (:1141-1166)
     std::vector<u64> rows, cols, vals;
     const bool dm_empty = fwd_dm.nvals() == 0;
     std::map<std::pair<u64, u64>, u64> inl;
-    for (auto& e : fwd_m.iter(0, ~0ull)) {
-        if (!dm_empty && fwd_dm.contains(e.row, e.col)) continue;
+    std::map<std::pair<u64, u64>, u64> multi_count;         // pairs flagged multi-edge -> the id count their value carries
+    auto take = [&](const Entry& e) {
         inl[{e.row, e.col}] = (e.val & MSB_MASK) ? MULTI_EDGE : e.val;
-    }
+        if (e.val & MSB_MASK) multi_count[{e.row, e.col}] = e.val & ~MSB_MASK; else multi_count.erase({e.row, e.col});
+    };
+    if (fwd_m.nvals())
+        for (auto& e : fwd_m.iter(0, ~0ull)) {
+            if (!dm_empty && fwd_dm.contains(e.row, e.col)) continue;
+            take(e);
+        }
     if (fwd_dp.nvals())
-        for (auto& e : fwd_dp.iter(0, ~0ull)) inl[{e.row, e.col}] = (e.val & MSB_MASK) ? MULTI_EDGE : e.val;
+        for (auto& e : fwd_dp.iter(0, ~0ull)) take(e);
     for (auto& kv : inl) { rows.push_back(kv.first.first); cols.push_back(kv.first.second); vals.push_back(kv.second); }
     Tensor t(ctx, nr, nc);
     if (!rows.empty()) t.m_.build(rows, cols, &vals);
@@ -352,6 +365,11 @@ Tensor Tensor::decode(Context& ctx, ByteReader& r, const BlobCodec& codec) {
                 const u64 src = r.read_unsigned(), dst = r.read_unsigned();
                 std::vector<uint8_t> blob = r.read_buffer();
                 std::vector<u64> ids = codec.decode(blob);
+                // an id list belongs to a pair whose inline value is the multi-edge flag: anything else in an
+                // untrusted payload would leave `me` and the forward matrix telling different stories
+                auto in = inl.find({src, dst});
+                if (in == inl.end() || in->second != MULTI_EDGE)
+                    throw GrbError(FGPU_INVALID, "Tensor decode: id list for a pair that is not a multi-edge pair");
                 auto& row = t.me_[compound_key(src, dst)];
                 row.insert(row.end(), ids.begin(), ids.end());
                 std::sort(row.begin(), row.end());
@@ -360,9 +378,18 @@ Tensor Tensor::decode(Context& ctx, ByteReader& r, const BlobCodec& codec) {
         }
     }
     t.m_.wait();                                             // the committed base is never pending (:1190-1192)
-    for (auto& kv : inl)
-        if (kv.second == MULTI_EDGE && !t.me_.count(compound_key(kv.first.first, kv.first.second)))
+    u64 have = 0;
+    for (auto& kv : inl) {
+        if (kv.second != MULTI_EDGE) { ++have; continue; }
+        auto it = t.me_.find(compound_key(kv.first.first, kv.first.second));
+        if (it == t.me_.end())
             throw GrbError(FGPU_INVALID, "Tensor decode: a multi-edge pair has no id list in the tensor section");
+        auto mc = multi_count.find(kv.first);
+        if (mc != multi_count.end() && mc->second != it->second.size())
+            throw GrbError(FGPU_INVALID, "Tensor decode: a multi-edge pair's id list differs in length from its inline count");
+        have += it->second.size();
+    }
+    if (have != total) throw GrbError(FGPU_INVALID, "Tensor decode: the edge total does not match the decoded ids");
     return t;
 }
 

@@ -101,7 +101,8 @@ def multiple_edges():
 def rust_unit_pins():
     return {
         "source": "graph/src/graph/graphblas/{matrix,versioned_matrix}.rs #[test]s",
-        "dup_collapse": {"line": "matrix.rs:1686-1695", "rows": [0, 0, 0, 3, 3], "cols": [1, 1, 2, 0, 0], "nvals": 3},
+        "dup_collapse": {"line": "matrix.rs:1686-1695 (build_bool_tolerates_duplicate_pairs, literal vectors)", "dim": 8,
+                         "rows": [1, 3, 1, 3, 1], "cols": [2, 4, 2, 4, 2], "nvals": 2, "present": [[1, 2], [3, 4]]},
         "fold_thresholds": {"line": "versioned_matrix.rs:1278-1330", "READ_FOLD_K": 82000, "WRITE_FOLD_K": 20500000,
                             "MIN_FOLD_DELTA": 256, "threshold_read_tx1": 287, "threshold_write_tx1": 4528,
                             "threshold_read_tx100": 2864, "ratio": 15},

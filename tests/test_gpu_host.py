@@ -37,10 +37,12 @@ def hctx():
 # ---- Matrix<T> (graphblas/matrix.rs unit tests) -----------------------------------------------------
 def test_matrix_build_collapses_duplicates(hctx):          # matrix.rs:1686-1695
     p = PINS["dup_collapse"]
-    m = host.Matrix(hctx, host.Matrix.BOOL, 4, 4)
-    m.build(p["rows"], p["cols"])
+    m = host.Matrix(hctx, host.Matrix.BOOL, p["dim"], p["dim"])
+    m.build(p["rows"], p["cols"])                            # the reference's literal vectors: [1,3,1,3,1] / [2,4,2,4,2]
+    m.wait()
     want = sorted(set(zip(p["rows"], p["cols"])))
-    assert m.nvals() == len(want)
+    assert m.nvals() == len(want) == p["nvals"] == 2
+    assert m.get(1, 2) == 1 and m.get(3, 4) == 1             # matrix.rs:1693-1694
     assert [(r, c) for r, c, _ in m.iter()] == want
     assert all(v == 1 for _, _, v in m.iter())               # bool build is iso / pattern-only (:1709-1775)
 

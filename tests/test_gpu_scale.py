@@ -107,6 +107,73 @@ def test_khop_rmat24_clean_matches_the_oracle(ctx):
     assert ref[0] > 50_000_000
 
 
+def hypersparse(ctx, m):
+    """The layer as Delta<T> keeps it (versioned_matrix.rs:214-235): a row list + a short row-pointer array."""
+    rp, ci, _ = m.export_csr()
+    deg = np.diff(rp.astype(np.int64))
+    rows = np.nonzero(deg)[0].astype(U64)
+    short = np.concatenate([[0], np.cumsum(deg[deg > 0])]).astype(U64)
+    return ctx.mat_from_csr(m.nrows, m.ncols, short, ci, hyper_rows=rows)
+
+
+@pytest.fixture(scope="module")
+def rmat24_bench(ctx):
+    """Exactly what bench.py's khop_match leg times (bench.py khop_inputs): RMAT-24, dm = fgpu_mat_sample(0xD3170 + 24,
+    1000), dp = seeded random coordinates outside A, both hypersparse; batch 0 = the first 1024 :P sources.  The oracle
+    chains (clean, dirty) are computed once, 64 source rows at a time (oracle.expand_summary_omp)."""
+    scale = 24
+    A = ctx.mat_rmat(scale, 16, 0x5EED1234 + scale)
+    n = A.nrows
+    dm0 = A.sample(0xD3170 + scale, 1000)
+    rng = np.random.default_rng(0xADD5 + scale)
+    k = max(1, A.nvals // 1000)
+    raw = ctx.mat_from_coo(n, n, rng.integers(0, n, k, dtype=np.uint64), rng.integers(0, n, k, dtype=np.uint64))
+    dp0 = raw.merge(None, A)
+    raw.free()
+    a, hdp, hdm = host_csr(A), host_csr(dp0), host_csr(dm0)
+    dp, dm = hypersparse(ctx, dp0), hypersparse(ctx, dm0)
+    dp0.free(); dm0.free()
+    src = p_sources(n, 1024)
+    ref_clean = oracle.expand_summary_omp(src, [(a, None, None)] * 3)
+    ref_dirty = oracle.expand_summary_omp(src, [(a, hdp, hdm)] * 3)
+    return A, dp, dm, src, ref_clean, ref_dirty, (a, hdp, hdm)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("dirty", [False, True])
+def test_khop_rmat24_bench_batch_matches_the_oracle(ctx, rmat24_bench, mode, dirty):
+    """The configuration bench.py times, at its size: one 1024-row batch (16 words per vertex row) of the RMAT-24
+    3-hop chain, clean and with hypersparse dirty layers on every hop, in each expand_mode — nnz, checksum and
+    traversed-edge count of fgpu_expand_count, and the per-hop sizes of fgpu_expand_levels, against the oracle's
+    delta_lmxm chain (matrix.rs:1317-1402 driven as cond_traverse.rs:600-605 drives it)."""
+    A, dp, dm, src, ref_clean, ref_dirty, (a, hdp, hdm) = rmat24_bench
+    ref = ref_dirty if dirty else ref_clean
+    layers = ([A] * 3, [dp] * 3, [dm] * 3) if dirty else ([A] * 3,)
+    if mode == 1:
+        # sorted-CSR products only: the 3-hop product of 1024 rows is 21 G gathered entries — that mode runs the first
+        # 64 rows of the batch (the other two modes take the whole batch)
+        sub = src[:64]
+        want = oracle.expand_summary_omp(sub, [(a, hdp, hdm) if dirty else (a, None, None)] * 3)
+        try:
+            ctx.set_option("expand_mode", 1)
+            got = engine.expand_count(ctx, sub, *layers)
+        finally:
+            ctx.set_option("expand_mode", 0)
+        assert got == want[:3], (got, want)
+        return
+    try:
+        ctx.set_option("expand_mode", mode)
+        got = engine.expand_count(ctx, src, *layers)
+        nn, _, fl = engine.expand_count(ctx, src, *layers, want_checksum=False)
+        lv = engine.expand_levels(ctx, src, *layers)
+    finally:
+        ctx.set_option("expand_mode", 0)
+    assert got == ref[:3], (mode, dirty, got, ref)
+    assert (nn, fl) == (ref[0], ref[2])
+    assert list(lv["hop_nnz"]) == ref[3] and lv["flops"] == ref[2]
+    assert ref[0] > 1_000_000_000          # 1.5 G result entries per batch
+
+
 def test_varlen_reach_config5_standin_matches_the_oracle(ctx):
     """BASELINE config 5's stand-in (≈0.5 M vertices, ≈20 M edges: R-MAT scale 19, edge factor 38), `[*1..4]` with
     0.1 % tombstones + pending adds: per-hop set sizes / checksums and the DISTINCT union of fgpu_expand_levels
@@ -173,3 +240,65 @@ def test_bfs_rmat26_levels_are_the_bfs_levels(ctx):
         assert (level[parent[others]] + 1 == level[others]).all()
         assert (parent[level < 0] == -1).all()
         assert int((level >= 0).sum()) > n // 3
+
+
+def bench_roots(A, want=64):
+    """bench.py pick_roots: the first `want` vertex ids with out-degree > 0."""
+    rows, _, _ = A.extract(0, 4095)
+    return [int(r) for r in np.unique(rows)[:want]]
+
+
+def test_bfs_rmat22_all_bench_roots_match_the_oracle_levels(ctx):
+    """BASELINE config 2 exactly as bench.py times it: RMAT-22, the 64 roots of the bench, every level vector and
+    traversed-edge count against the oracle's BFS (oracle_omp.c orc_bfs_omp, held equal to the serial restatement by
+    tests/test_oracle_golden.py) — through the plan API the bench uses (synchronous and the pipelined two-plan loop)
+    and through the host-array ABI entry fgpu_bfs."""
+    A = ctx.mat_rmat(22)
+    At = A.transpose()
+    rp, ci, _ = A.export_csr()
+    a = oracle.CSR(A.nrows, A.ncols, rp, ci)
+    trp, tci, _ = At.export_csr()
+    at = oracle.CSR(A.nrows, A.ncols, trp, tci)
+    roots = bench_roots(A)
+    assert len(roots) == 64
+    want = {r: oracle.bfs_omp(a, at, r, -1) for r in roots}
+    plans = [engine.BfsPlan(ctx, A, At), engine.BfsPlan(ctx, A, At)]
+    for r in roots:
+        plans[0].run(r, -1, False)
+        level, _ = plans[0].fetch()
+        ref_level, ref_edges = want[r]
+        np.testing.assert_array_equal(level, ref_level)
+        assert plans[0].stats()["edges_traversed"] == ref_edges
+    # the pipelined loop of the timed region: search i + 1 is enqueued while search i runs
+    for i, r in enumerate(roots):
+        plans[i % 2].run_async(r, -1, False, 0)
+        if i > 0:
+            plans[(i - 1) % 2].wait()
+            level, _ = plans[(i - 1) % 2].fetch()
+            np.testing.assert_array_equal(level, want[roots[i - 1]][0])
+    plans[(len(roots) - 1) % 2].wait()
+    level, _ = plans[(len(roots) - 1) % 2].fetch()
+    np.testing.assert_array_equal(level, want[roots[-1]][0])
+    for r in roots[:4]:
+        level, parent, edges = engine.bfs(ctx, A, At, r, -1, want_parent=True)
+        np.testing.assert_array_equal(level, want[r][0])
+        assert edges == want[r][1]
+        others = level > 0
+        assert (level[parent[others]] + 1 == level[others]).all()
+
+
+def test_bfs_rmat26_two_roots_match_the_oracle_levels(ctx):
+    """BASELINE config 4's graph on one device, level for level against the oracle (push-only OpenMP BFS: the host
+    never holds the transposed copy of the 1.06 G-edge graph)."""
+    A = ctx.mat_rmat(26)
+    At = A.transpose()
+    rp, ci, _ = A.export_csr()
+    a = oracle.CSR(A.nrows, A.ncols, rp, ci)
+    del rp, ci
+    plan = engine.BfsPlan(ctx, A, At)
+    for r in bench_roots(A, 2):
+        ref_level, ref_edges = oracle.bfs_omp(a, None, r, -1)
+        plan.run(r, -1, False)
+        level, _ = plan.fetch()
+        np.testing.assert_array_equal(level, ref_level)
+        assert plan.stats()["edges_traversed"] == ref_edges

@@ -302,6 +302,9 @@ def test_trail_counts_for_one_and_two_hops_match_the_dfs(ctx, weighted, dirty):
             assert list(dest[rowptr[i]:rowptr[i + 1]]) == sorted(want)       # ascending destinations
     with pytest.raises(Exception):
         engine.expand_trail_counts(ctx, src, [M] * 3)                       # no product form beyond two hops
+    if DP is not None:
+        with pytest.raises(Exception):
+            engine.expand_trail_counts(ctx, src, [M, DP])    # two different layers: not ONE var-length relationship
 
 
 def test_trail_counts_on_rmat_agree_with_the_products(ctx):
