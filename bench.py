@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — TEPS of the boolean-vxm BFS on synthetic R-MAT graphs (BASELINE.json metric).
+"""bench.py — TEPS of the boolean-vxm BFS and of the k-hop MATCH chain on synthetic R-MAT graphs (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -79,6 +79,9 @@ PMC_GROUPS = (  # (reported name, regex over rocprofv3's Kernel_Name)
     ("bp_count_kernel<count>", r"bp_count_kernel<false>"),
     ("bp_delta_kernel<dm>", r"bp_delta_kernel<true>"),
     ("bp_delta_kernel<dp>", r"bp_delta_kernel<false>"),
+    ("bp_pull_groups_kernel", r"bp_pull_groups_kernel"),
+    ("bp_rows_kernel<emit>", r"bp_rows_kernel<true>"),
+    ("bp_rows_kernel<count>", r"bp_rows_kernel<false>"),
 )
 
 
@@ -207,10 +210,11 @@ def p_label_sources(n):
     return ids[mix64_np(ids) % np.uint64(16) == 0]
 
 
-def khop_inputs(ctx, scale, edge_factor):
+def khop_inputs(ctx, scale, edge_factor, want_host=False):
     """RMAT-<scale> adjacency + one dirty layer pair: dm = a uniformly random 0.1 % of the stored entries
     (fgpu_mat_sample), dp = as many uniformly random coordinates outside the matrix (the Delta invariants
-    dm ⊆ m, dp ∩ m = ∅, versioned_matrix.rs:214-235)."""
+    dm ⊆ m, dp ∩ m = ∅, versioned_matrix.rs:214-235).  want_host: also the three layers as oracle.CSR (the parity
+    check's inputs, exported before the delta layers are made hypersparse)."""
     A = ctx.mat_rmat(scale, edge_factor, 0x5EED1234 + scale)
     n = A.nrows
     dm = A.sample(0xD3170 + scale, 1000)
@@ -219,6 +223,10 @@ def khop_inputs(ctx, scale, edge_factor):
     raw = ctx.mat_from_coo(n, n, rng.integers(0, n, k, dtype=np.uint64), rng.integers(0, n, k, dtype=np.uint64))
     dp = raw.merge(None, A)
     raw.free()
+    host = None
+    if want_host:
+        import oracle
+        host = tuple(oracle.CSR(m.nrows, m.ncols, *m.export_csr()[:2]) for m in (A, dp, dm))
 
     def hypersparse(m):
         # Delta layers are hypersparse in the reference (Delta<T>::new pins them so, versioned_matrix.rs:214-235): a row list
@@ -232,7 +240,7 @@ def khop_inputs(ctx, scale, edge_factor):
         return h
     if os.environ.get("FGPU_BENCH_HYPER_DELTAS", "1") != "0":
         dp, dm = hypersparse(dp), hypersparse(dm)
-    return A, dp, dm
+    return A, dp, dm, host
 
 
 def khop_alg_bytes(rows, hop_nnz, flops, mask_nnz=0):
@@ -242,21 +250,32 @@ def khop_alg_bytes(rows, hop_nnz, flops, mask_nnz=0):
     return sum(8 * (rows + 1) + 12 * f + 4 * c for f, c in zip(f_nnz, hop_nnz)) + 4 * flops + 4 * mask_nnz
 
 
-def khop_leg(ctx, engine, args):
-    """BASELINE config 3: RMAT-24 3-hop MATCH (a:P)-->()-->()-->(c) as a masked GrB_mxm chain = the device core of
-    CondTraverseOp::expand_batch (cond_traverse.rs:452-751: F = build(sources); F = delta_lmxm(F; hop) per hop,
-    matrix.rs:1317-1402), batches of 1024 :P sources, result = count + order-independent checksum on the device
-    (the full (row, dest) stream of 1.5 G entries per batch does not fit a host buffer).  t = wall time of the
-    fgpu_expand_count calls, H2D of the sources and D2H of the results included; matrices resident."""
-    scale, hops, B = args.khop_scale, 3, 1024
+def cpu_threads():
+    """Threads for the CPU legs: the job's CPU quota (cgroup), not the host's hardware-thread count — an OpenMP team
+    beyond the quota is throttled by CFS and its rate becomes noise (4 thr 1433, 8 thr 992, 16 thr 2073,
+    32 thr 1306 MTEPS on a 16-CPU quota)."""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = _cgroup_cpus()
+    return max(1, min(ncpu, int(quota))) if quota else ncpu, ncpu, quota
+
+
+def khop_leg(ctx, engine, args, scale, nb_want, graph=None, parity_rows=1024):
+    """BASELINE config 3's shape at one scale: RMAT-<scale> 3-hop MATCH (a:P)-->()-->()-->(c) as a masked GrB_mxm chain =
+    the device core of CondTraverseOp::expand_batch (cond_traverse.rs:452-751: F = build(sources); F = delta_lmxm(F; hop)
+    per hop, matrix.rs:1317-1402), batches of 1024 :P sources, result = count + order-independent checksum on the device
+    (the (row, dest) stream of 1.5 G entries per batch at scale 24 does not fit a host buffer; the materialised form is
+    khop_emit_leg).  t = wall time of the fgpu_expand_count calls, H2D of the sources and D2H of the results included;
+    matrices resident.  Parity: batch 0's (nnz, checksum, flops), clean AND dirty, against the oracle's delta_lmxm
+    chain (oracle.expand_summary_omp, `parity_rows` of the batch's rows) — a mismatch aborts the bench line."""
+    hops, B = 3, 1024
     t0 = time.time()
-    A, dp, dm = khop_inputs(ctx, scale, args.edge_factor)
+    A, dp, dm, host = graph if graph is not None else khop_inputs(ctx, scale, args.edge_factor, want_host=not args.no_parity)
     ctx.sync()
     t_build = time.time() - t0
     n, nnz = A.nrows, A.nvals
     srcs = p_label_sources(n)
     nb_all = len(srcs) // B
-    nb = nb_all if args.khop_batches <= 0 else min(args.khop_batches, nb_all)
+    nb = nb_all if nb_want <= 0 else min(nb_want, nb_all)
     batches = [srcs[i * B:(i + 1) * B] for i in range(nb)]
     out = {"workload": f"RMAT scale-{scale} {hops}-hop MATCH (a:P)-->()-->()-->(c): CondTraverse expand_batch core "
                        f"(masked GrB_mxm ANY_PAIR chain), sources = label :P (hash(id) % 16 == 0), batches of {B}",
@@ -267,6 +286,7 @@ def khop_leg(ctx, engine, args):
            "result": "count + checksum on device (fgpu_expand_count)", "build_seconds": round(t_build, 2),
            "nnz_dp": int(dp.nvals), "nnz_dm": int(dm.nvals)}
     prof_tables = {}
+    batch0 = {}
     for name, layers in (("clean", ([A] * hops, None, None)), ("dirty", ([A] * hops, [dp] * hops, [dm] * hops))):
         for b in batches[:2]:                                   # warm-up: transpose cache, item lists, pools
             engine.expand_count(ctx, b, *layers)
@@ -274,8 +294,10 @@ def khop_leg(ctx, engine, args):
         t1 = time.perf_counter()
         tot_f = tot_n = 0
         cs = 0
-        for b in batches:
+        for i, b in enumerate(batches):
             nn, c, f = engine.expand_count(ctx, b, *layers)
+            if i == 0:
+                batch0[name] = (nn, c, f)
             tot_n += nn
             tot_f += f
             cs = (cs + c) & 0xFFFFFFFFFFFFFFFF
@@ -293,24 +315,25 @@ def khop_leg(ctx, engine, args):
         prof = ctx.prof_read()
         ctx.prof_enable(False)
         prof_tables[name] = prof
-        # per-hop result sizes (untimed) for the §8d byte count
+        # per-hop result sizes (untimed) for the §8d byte count of the SpGEMM form
         alg = 0
         hop_tot = [0] * hops
-        for b in batches:
+        nlv = min(nb, 4)
+        for b in batches[:nlv]:
             lv = engine.expand_levels(ctx, b, *layers)
             hn = [int(x) for x in lv["hop_nnz"]]
             alg += khop_alg_bytes(B, hn, int(lv["flops"]))
             hop_tot = [a_ + b_ for a_, b_ in zip(hop_tot, hn)]
         out[name] = {"ms_per_batch": round(dt / nb * 1e3, 3), "TEPS": round(tot_f / dt, 1),
                      "flops": int(tot_f), "out_nnz": int(tot_n), "checksum": f"{cs:016x}",
-                     "hop_nnz_per_batch": [h // nb for h in hop_tot],
-                     "alg_bytes": int(alg), "GBps": round(alg / dt / 1e9, 1), "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+                     "hop_nnz_per_batch": [h // nlv for h in hop_tot],
+                     "spgemm_form_alg_bytes_per_batch": int(alg // nlv),
                      "count_only": {"ms_per_batch": round(dt_count / nb * 1e3, 3), "TEPS": round(tot_f / dt_count, 1)},
                      "ms_per_batch_with_kernel_events": round(dt_prof / nb * 1e3, 3)}
-    out["note"] = ("alg_bytes follows SURVEY.md §8d's SpGEMM row (4 B per traversed edge + F / C / row-pointer terms); "
-                   "dense hops run in bit form (one pass over A' per hop whatever the traversed-edge count), so the "
-                   "chain moves fewer bytes than that formula charges — the kernel-level roofline is `roofline` below")
-    # dominant kernel of the clean run, with the dirty run's table beside it
+    out["note"] = ("spgemm_form_alg_bytes follows SURVEY.md §8d's SpGEMM row (4 B per traversed edge + F / C / row-pointer "
+                   "terms): what a gather-and-sort product of the same chain would move.  Dense hops run in bit form (one "
+                   "pass over A' per hop whatever the traversed-edge count), so no fraction of peak is quoted against that "
+                   "figure — the kernel-level roofline (compulsory bytes of the bit form, live traffic) is `roofline` below")
     kern = sorted(prof_tables["clean"], key=lambda k: -k["ms"])
     out["kernels"] = {name: [{"kernel": k["kernel"], "ms_total": round(k["ms"], 3), "launches": k["launches"],
                               "avg_launch_us": round(k["ms"] / max(k["launches"], 1) * 1e3, 2),
@@ -326,30 +349,145 @@ def khop_leg(ctx, engine, args):
                            "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches": d["launches"],
                            "share_of_kernel_time": round(d["ms"] / max(sum(k["ms"] for k in kern), 1e-9), 3),
                            "timing": "HIP events around each launch (fgpu_prof_*), clean layers, the timed batches replayed"}
-    return out, (A, dp, dm, batches)
-
-
-def khop_cpu_baseline(engine, ctx, A, batch, threads, seconds):
-    """The oracle's row-parallel Gustavson chain (oracle/oracle_omp.c orc_mxm_omp — the algorithm family of
-    SuiteSparse's saxpy3) on the first sources of the first batch, same graph, clean layers."""
-    import oracle
-    rp, ci, _ = A.export_csr()
-    a = oracle.CSR(A.nrows, A.ncols, rp, ci)
-    k, done, t_cpu, fl_cpu, nnz_cpu = 4, 0, 0.0, 0, 0
-    while done < len(batch) and t_cpu < seconds:
-        src = batch[done:done + k]
+    # ---- parity of what was just timed, and the CPU baseline from the same oracle run -------------------------
+    if not args.no_parity and host is not None:
+        import oracle
+        a, hdp, hdm = host
+        threads, ncpu, quota = cpu_threads()
+        rows = batches[0][:parity_rows]
+        gpu = dict(batch0)
+        if parity_rows < B:                                   # (scale 26: the oracle takes a slice of batch 0)
+            gpu = {"clean": engine.expand_count(ctx, rows, [A] * hops),
+                   "dirty": engine.expand_count(ctx, rows, [A] * hops, [dp] * hops, [dm] * hops)}
         t1 = time.perf_counter()
-        c, fl, _ = oracle.expand_omp(src, [(a, None, None)] * 3, threads=threads)
-        t_cpu += time.perf_counter() - t1
-        fl_cpu += fl
-        nnz_cpu += c.nnz
-        done += len(src)
-        k = min(2 * k, 64)
-    return {"value": round(fl_cpu / t_cpu, 1), "unit": "TEPS", "cores": threads, "kind": "port",
-            "sample": f"{done} of the first batch's 1024 :P sources, 3 hops, clean layers, {t_cpu:.1f} s, row-parallel "
-                      f"Gustavson ANY_PAIR products (oracle/oracle_omp.c orc_mxm_omp) on {threads} threads; CPU stand-in "
-                      f"for SuiteSparse:GraphBLAS GrB_mxm, which is absent from this image",
-            "flops": int(fl_cpu), "out_nnz": int(nnz_cpu)}
+        ref_clean = oracle.expand_summary_omp(rows, [(a, None, None)] * hops, chunk=64, threads=threads)
+        t_clean = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        ref_dirty = oracle.expand_summary_omp(rows, [(a, hdp, hdm)] * hops, chunk=64, threads=threads)
+        t_dirty = time.perf_counter() - t1
+        ok = tuple(gpu["clean"]) == tuple(ref_clean[:3]) and tuple(gpu["dirty"]) == tuple(ref_dirty[:3])
+        out["parity"] = {"checked": True, "ok": bool(ok), "rows": int(len(rows)),
+                         "what": f"(nnz, checksum, flops) of batch 0{'' if parity_rows >= B else ' rows [0, %d)' % parity_rows}, "
+                                 "clean and dirty layers, fgpu_expand_count vs the oracle's delta_lmxm chain "
+                                 "(oracle.expand_summary_omp, matrix.rs:1317-1402)",
+                         "clean": {"nnz": int(ref_clean[0]), "checksum": f"{ref_clean[1]:016x}", "flops": int(ref_clean[2])},
+                         "dirty": {"nnz": int(ref_dirty[0]), "checksum": f"{ref_dirty[1]:016x}", "flops": int(ref_dirty[2])}}
+        if not ok:
+            raise SystemExit(f"bench.py: k-hop parity FAILED at scale {scale}: gpu {gpu} vs oracle clean {ref_clean[:3]} "
+                             f"dirty {ref_dirty[:3]}")
+        out["cpu_baseline"] = {"value": round(ref_clean[2] / t_clean, 1), "unit": "TEPS", "cores": threads, "kind": "port",
+                               "sample": f"{len(rows)} of batch 0's 1024 :P sources, 3 hops, clean layers, {t_clean:.1f} s "
+                                         f"(dirty layers: {t_dirty:.1f} s = {ref_dirty[2] / t_dirty / 1e9:.2f} GTEPS), row-parallel "
+                                         f"Gustavson ANY_PAIR products (oracle/oracle_omp.c orc_mxm_omp) on {threads} threads "
+                                         f"(cgroup quota {quota}, {ncpu} hardware threads visible); CPU stand-in for "
+                                         f"SuiteSparse:GraphBLAS GrB_mxm, which is absent from this image",
+                               "flops": int(ref_clean[2]), "out_nnz": int(ref_clean[0])}
+    else:
+        out["parity"] = {"checked": False}
+    return out, (A, dp, dm, host, batches)
+
+
+def khop_emit_leg(ctx, engine, args, A, host, batches):
+    """The MATERIALISED form of the same chain: fgpu_expand_mat returns F on the device as the
+    (rowptr, dest) CSR the operator then walks (cond_traverse.rs:608, 644-751) — (i) the 2-hop chain of a 1024-row batch
+    (32 M entries per batch at RMAT-24), (ii) the 3-hop chain of 64 rows (90 M entries).  Timed: the call, result on the
+    device; beside it the host-array entry fgpu_expand (PCIe + widening to 64-bit ids included).  Batch 0 of each is
+    compared entry for entry with the oracle's chain."""
+    import oracle
+    out = {}
+    threads = cpu_threads()[0]
+    for name, hops, rows, nb in (("two_hop_1024_rows", 2, 1024, min(8, len(batches))),
+                                 ("three_hop_64_rows", 3, 64, min(8, len(batches)))):
+        bl = [b[:rows] for b in batches[:nb]]
+        for b in bl[:2]:
+            m_, _ = engine.expand_mat(ctx, b, [A] * hops)
+            m_.free()
+        ctx.sync()
+        t1 = time.perf_counter()
+        tot_n = tot_f = 0
+        for b in bl:
+            m_, f = engine.expand_mat(ctx, b, [A] * hops)
+            tot_n += m_.nvals
+            tot_f += f
+            m_.free()
+        ctx.sync()
+        dt = time.perf_counter() - t1
+        ctx.prof_enable(True)
+        for b in bl:
+            m_, f = engine.expand_mat(ctx, b, [A] * hops)
+            m_.free()
+        prof = ctx.prof_read()
+        ctx.prof_enable(False)
+        t1 = time.perf_counter()
+        rp, dest, _ = engine.expand(ctx, bl[0], [A] * hops)
+        dt_host = time.perf_counter() - t1
+        rec = {"hops": hops, "rows": rows, "batches": nb, "ms_per_batch": round(dt / nb * 1e3, 3),
+               "TEPS": round(tot_f / dt, 1), "out_nnz_per_batch": int(tot_n // nb),
+               "host_arrays_ms_first_batch": round(dt_host * 1e3, 3),
+               "kernels": [{"kernel": k["kernel"], "ms_total": round(k["ms"], 3), "launches": k["launches"],
+                            "avg_launch_us": round(k["ms"] / max(k["launches"], 1) * 1e3, 2),
+                            "alg_bytes_per_launch": int(k["alg_bytes"] / max(k["launches"], 1)),
+                            "GBps": round(k["alg_bytes"] / max(k["ms"], 1e-9) / 1e6, 1),
+                            "frac": round(k["alg_bytes"] / max(k["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+                           for k in sorted(prof, key=lambda k: -k["ms"])[:8]]}
+        if not args.no_parity and host is not None:
+            c, fl, _ = oracle.expand_omp(bl[0], [(host[0], None, None)] * hops, threads=threads)
+            ok = bool(np.array_equal(rp, c.rowptr) and np.array_equal(dest, c.colidx))
+            rec["parity"] = {"checked": True, "ok": ok, "what": "batch 0's (rowptr, dest) arrays vs the oracle's chain, entry for entry",
+                             "nnz": int(c.nnz)}
+            if not ok:
+                raise SystemExit(f"bench.py: materialised k-hop parity FAILED ({name})")
+            del c
+        out[name] = rec
+    return out
+
+
+def varlen_leg(ctx, engine, args, rank=0, world=1):
+    """BASELINE config 5's stand-in (~0.5 M vertices / ~20 M edges = R-MAT scale 19, edge factor 38),
+    `[*1..4]` reachability from 1024-source batches with 0.1 % tombstones + pending adds: fgpu_expand_levels (per-hop
+    frontier sets + the DISTINCT union).  Sources are sharded over the ranks (rank r takes batches r, r + world, ...), A
+    replicated: no collective on this path.  Returns this rank's (flops, seconds, batches)."""
+    A, dp, dm, _ = khop_inputs(ctx, 19, 38, want_host=False)
+    srcs = p_label_sources(A.nrows)
+    B = 1024
+    nb_all = len(srcs) // B
+    mine = [srcs[i * B:(i + 1) * B] for i in range(rank, nb_all, world)][:8]
+    layers = ([A] * 4, [dp] * 4, [dm] * 4)
+    for b in mine[:1]:
+        engine.expand_levels(ctx, b, *layers)
+    ctx.sync()
+    t1 = time.perf_counter()
+    fl = un = 0
+    for b in mine:
+        lv = engine.expand_levels(ctx, b, *layers)
+        fl += int(lv["flops"])
+        un += int(lv["union_nnz"])
+    dt = time.perf_counter() - t1
+    dp.free(); dm.free(); A.free()
+    return fl, dt, len(mine), un
+
+
+def spmv_pass(ctx, engine, At, scale, iters=50):
+    """The north-star roofline case: one full-matrix boolean pull pass (dense frontier, no mask, no early exit) over the
+    LDS-tile layout of A', HIP-event timed per launch.  `warm`: back-to-back passes (at RMAT-22 the 268 MB layout sits in
+    the 256 MiB Infinity Cache between passes — MI355X_MICROARCH.md: "scale past L3 before reading FETCH_SIZE");
+    `cold`: 512 MiB of scratch is READ before every timed pass (no dirty lines left behind), so the layout streams from HBM.  `frac` (the
+    headline of this object) is the COLD figure; the CSR pull of the same pass is beside it."""
+    tinfo = At.build_tiles()
+    ms, ab = engine.bench_spmv(ctx, At, which=2, iters=iters)
+    ms_c, _ = engine.bench_spmv(ctx, At, which=3, iters=max(8, iters // 4))
+    ms0, _ = engine.bench_spmv(ctx, At, which=0, iters=10)
+
+    def gb(ms_):
+        return ab / (ms_ * 1e-3) / 1e9
+    return {"kernel": "tiled_mxv_kernel", "scale": scale, "alg_bytes": int(ab),
+            "avg_launch_us": round(ms_c * 1e3, 2), "achieved": round(gb(ms_c), 2), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": round(gb(ms_c) / HBM_PEAK_GBS, 4), "cache_state": "cold (512 MiB of scratch read before every timed pass)",
+            "warm": {"avg_launch_us": round(ms * 1e3, 2), "achieved": round(gb(ms), 2), "frac": round(gb(ms) / HBM_PEAK_GBS, 4),
+                     "cache_state": "back-to-back passes (Infinity Cache holds what fits of the layout)"},
+            "traffic": None,
+            "layout": {k: tinfo[k] for k in ("tile_bits", "tiles", "items", "entries", "vec", "k", "bytes")},
+            "csr_pull_us": round(ms0 * 1e3, 2), "csr_pull_GBps": round(gb(ms0), 2)}
 
 
 def strong_scaling_base(ctx, engine, args, scale=26, steps=32, warmup=8):
@@ -389,6 +527,8 @@ def strong_scaling_base(ctx, engine, args, scale=26, steps=32, warmup=8):
            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "build_seconds": round(t_build, 2)}
     for p in plans:
         p.free()
+    if not args.no_roofline:
+        out["spmv_full_pass"] = spmv_pass(ctx, engine, At, scale, iters=12)
     At.free()
     A.free()
     return out
@@ -413,13 +553,15 @@ def pmc_child(args):
     engine.bench_spmv(ctx, At, which=2, iters=4)
     plan.free(); At.free(); A.free()
     if not args.no_khop:
-        K, dp, dm = khop_inputs(ctx, args.khop_scale, args.edge_factor)
+        K, dp, dm, _ = khop_inputs(ctx, args.khop_scale, args.edge_factor)
         srcs = p_label_sources(K.nrows)
         for i in range(3):
             b = srcs[i * 1024:(i + 1) * 1024]
             engine.expand_count(ctx, b, [K] * 3)
             if i:
                 engine.expand_count(ctx, b, [K] * 3, [dp] * 3, [dm] * 3)
+                m_, _ = engine.expand_mat(ctx, b, [K] * 2)          # the emitting path (bp_rows_kernel count / emit)
+                m_.free()
     ctx.sync()
     ctx.close()
 
@@ -439,8 +581,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (fgpu_set_option)")
     ap.add_argument("--no-khop", action="store_true", help="skip the k-hop MATCH leg (BASELINE config 3)")
-    ap.add_argument("--khop-scale", type=int, default=24)
+    ap.add_argument("--khop-scale", type=int, default=24, help="scale of the k-hop leg that carries the kernel table / PMC traffic")
     ap.add_argument("--khop-batches", type=int, default=32, help="1024-source batches of the :P set to time (0 = all)")
+    ap.add_argument("--khop-extra-scales", default="22,26", help="further scales of the same leg (BASELINE metric: 22 / 26), fewer batches")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle checks of the k-hop legs")
+    ap.add_argument("--no-varlen", action="store_true", help="skip the config-5 stand-in leg ([*1..4] reach sets, sources sharded over the ranks)")
     ap.add_argument("--no-scale-base", action="store_true", help="skip the RMAT-26 single-GPU base point of the scaling curve")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (traffic = committed / null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -656,15 +801,7 @@ def main():
                                 "kernel of this path is the full-pass boolean SpMV reported in spmv_full_pass"}
         # the north-star full-matrix boolean SpMV pass (dense frontier, no mask, no early exit)
         # (LDS-tiled layout, tiled.hip) with the CSR pull kernel's figure beside it
-        tinfo = At.build_tiles()
-        ms, ab = engine.bench_spmv(ctx, At, which=2, iters=50)
-        g = ab / (ms * 1e-3) / 1e9
-        ms0, _ = engine.bench_spmv(ctx, At, which=0, iters=10)
-        spmv = {"kernel": "tiled_mxv_kernel", "avg_launch_us": round(ms * 1e3, 2), "alg_bytes": int(ab),
-                "achieved": round(g, 2), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(g / HBM_PEAK_GBS, 4),
-                "traffic": None,
-                "layout": {k: tinfo[k] for k in ("tile_bits", "tiles", "items", "entries", "vec", "k", "bytes")},
-                "csr_pull_us": round(ms0 * 1e3, 2), "csr_pull_GBps": round(ab / (ms0 * 1e-3) / 1e9, 2)}
+        spmv = spmv_pass(ctx, engine, At, scale)
 
     # ---- CPU baseline on this box's host cores, bounded sample, rank 0 / N=1 only -------------------
     # The reference's path is LAGraph's push/pull BFS over SuiteSparse:GraphBLAS with OpenMP inside every
@@ -681,37 +818,22 @@ def main():
         if not use_dist and scale < 25:          # RMAT-25+ (17 GB of host arrays with the transpose): push-only baseline
             trp, tci, _ = At.export_csr()
             at = oracle.CSR(n, n, trp, tci)
-        # thread count: the box reports every hardware thread of the host, but a job usually owns fewer
-        # (cgroup quota) and an oversubscribed OpenMP team is slower than one thread — calibrate on one root
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        quota = _cgroup_cpus()
-        cap = min(ncpu, max(1, int(quota * 2))) if quota else ncpu     # a team beyond the CFS quota only gets throttled
-        oracle.bfs_omp(a, at, roots[0], -1, threads=1)                  # warm-up: page faults
-        best = (0.0, 1)
-        calib = {}
-        for th in sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, cap) if t <= cap}):
-            rates = []
-            for rep in range(3):                                        # median of three: single probes are noisy on a shared host
-                t1 = time.perf_counter()
-                _, e = oracle.bfs_omp(a, at, roots[rep % len(roots)], -1, threads=th)
-                rates.append(e / (time.perf_counter() - t1))
-            rate = sorted(rates)[1]
-            calib[th] = round(rate / 1e6, 1)
-            if rate > best[0]:
-                best = (rate, th)
-            elif rate < 0.25 * best[0]:
-                break                                                  # far past the knee: stop trying larger teams
-        threads = best[1]
-        oracle.bfs_omp(a, at, roots[0], -1, threads=threads)
+        # thread count = the job's CPU quota (cpu_threads): a team beyond it is throttled and its rate is noise
+        threads, ncpu, quota = cpu_threads()
+        oracle.bfs_omp(a, at, roots[0], -1, threads=threads)           # warm-up: page faults, thread team
         e_cpu, t_cpu, k = 0, 0.0, 0
+        rates = []
         budget = args.cpu_seconds * 0.7
-        while t_cpu <= budget:                                          # cycle the 64 roots until the budget is spent
+        while t_cpu <= budget or k < 5:                                 # cycle the 64 roots until the budget is spent
             r = roots[k % len(roots)]
             t1 = time.perf_counter()
             _, e = oracle.bfs_omp(a, at, r, -1, threads=threads)
-            t_cpu += time.perf_counter() - t1
+            d1 = time.perf_counter() - t1
+            t_cpu += d1
             e_cpu += e
+            rates.append(e / d1)
             k += 1
+        rates.sort()
         e_ser, t_ser, ks = 0, 0.0, 0
         for r in roots:
             t1 = time.perf_counter()
@@ -721,13 +843,15 @@ def main():
             ks += 1
             if t_ser > args.cpu_seconds * 0.3:
                 break
-        cpu = {"value": round(e_cpu / t_cpu, 1), "unit": "TEPS", "cores": threads, "kind": "port",
-               "sample": f"{k} BFS runs cycling the 64 roots of the same RMAT-{scale} graph, {t_cpu:.1f} s, OpenMP "
+        cpu = {"value": round(rates[len(rates) // 2], 1), "unit": "TEPS", "cores": threads, "kind": "port",
+               "sample": f"median over {k} BFS runs cycling the 64 roots of the same RMAT-{scale} graph ({t_cpu:.1f} s; aggregate "
+                         f"{e_cpu / t_cpu / 1e9:.2f} GTEPS, quartiles {rates[len(rates) // 4] / 1e9:.2f} / "
+                         f"{rates[(3 * len(rates)) // 4] / 1e9:.2f}), OpenMP "
                          f"{'push/pull' if at is not None else 'push-only (no transposed copy on the host at this size)'} BFS "
-                         f"(oracle/oracle_omp.c orc_bfs_omp) on {threads} threads; CPU stand-in for "
+                         f"(oracle/oracle_omp.c orc_bfs_omp) on {threads} threads = the job's CPU quota; CPU stand-in for "
                          f"LAGraph + SuiteSparse:GraphBLAS, which are absent from this image",
                "reference_libs_probe": probe_reference_libs(),
-               "threads_calibration_MTEPS": calib, "host_cpus_visible": ncpu, "cgroup_cpu_quota": quota,
+               "host_cpus_visible": ncpu, "cgroup_cpu_quota": quota,
                "serial": {"value": round(e_ser / t_ser, 1), "cores": 1,
                           "sample": f"{ks} roots, {t_ser:.1f} s, serial queue BFS (oracle/oracle.c orc_bfs)"}}
 
@@ -736,14 +860,59 @@ def main():
     if world == 1 and not use_dist and scale == 22 and not args.no_scale_base:
         base26 = strong_scaling_base(ctx, engine, args)
 
-    # ---- BASELINE config 3: k-hop MATCH leg (own graph, own roofline, own CPU baseline) ------------------
+    # ---- the fgpu_bfs ABI entry itself (host level[] array) beside the plan API the timed region uses -----------
+    bfs_host = None
+    if not use_dist and rank == 0 and world == 1:
+        k = min(args.steps, 16)
+        engine.bfs(ctx, A, At, roots[0], -1, want_parent=False)
+        t1 = time.perf_counter()
+        e_h = 0
+        for i in range(k):
+            _, _, e = engine.bfs(ctx, A, At, roots[i % len(roots)], -1, want_parent=False)
+            e_h += e
+        dth = time.perf_counter() - t1
+        bfs_host = {"entry": "fgpu_bfs (level[] returned in a host array, one call per search, nothing pipelined)",
+                    "steps": k, "ms_per_step": round(dth / k * 1e3, 4), "TEPS": round(e_h / dth, 1),
+                    "note": "the timed region uses the plan API (results stay on the device, two plans pipelined)"}
+
+    # ---- BASELINE config 3 / the metric's "k-hop MATCH, RMAT scale-22/26": k-hop legs -----------------------------
     khop = None
+    khop_scales = {}
+    khop_emit = None
     if not args.no_khop and not use_dist and rank == 0:
-        khop, (KA, Kdp, Kdm, kbatches) = khop_leg(ctx, engine, args)
-        if not args.no_cpu_baseline:
-            khop["cpu_baseline"] = khop_cpu_baseline(engine, ctx, KA, kbatches[0], cpu["cores"] if cpu else 1,
-                                                     args.cpu_seconds * 0.6)
+        khop, (KA, Kdp, Kdm, Khost, kbatches) = khop_leg(ctx, engine, args, args.khop_scale, args.khop_batches)
+        if not args.no_roofline:
+            KAt = KA.transpose()
+            khop["spmv_full_pass"] = spmv_pass(ctx, engine, KAt, args.khop_scale, iters=20)
+            KAt.free()
+        khop_emit = khop_emit_leg(ctx, engine, args, KA, Khost, kbatches)
         Kdp.free(); Kdm.free(); KA.free()
+        del Khost
+        for sc in [int(x) for x in args.khop_extra_scales.split(",") if x.strip()]:
+            # the same leg at the other scales BASELINE's metric names; scale 26: fewer batches, the oracle takes the
+            # first 128 rows of batch 0 (its chain for 1024 rows is ~1 minute of CPU at that size)
+            leg, (a_, dp_, dm_, _, _) = khop_leg(ctx, engine, args, sc, 8 if sc <= 24 else 4,
+                                                 parity_rows=1024 if sc <= 24 else 128)
+            dp_.free(); dm_.free(); a_.free()
+            leg.pop("kernels", None)
+            khop_scales[str(sc)] = leg
+
+    # ---- BASELINE config 5's stand-in: [*1..4] reach sets, sources sharded over the ranks, no collective ----------
+    varlen = None
+    if not args.no_varlen and (world > 1 or (not use_dist and not args.no_khop)):
+        fl_v, dt_v, nb_v, un_v = varlen_leg(ctx, engine, args, rank, world)
+        if world > 1:
+            tv = torch.tensor([float(fl_v), dt_v, float(nb_v), float(un_v)], dtype=torch.float64, device=dev)
+            mx = tv.clone()
+            td.all_reduce(tv, op=td.ReduceOp.SUM)
+            td.all_reduce(mx, op=td.ReduceOp.MAX)
+            fl_v, nb_v, un_v, dt_v = tv[0].item(), tv[2].item(), tv[3].item(), mx[1].item()
+        varlen = {"workload": "BASELINE config 5 stand-in (LDBC SF100 is not available offline): R-MAT scale 19, edge factor 38 "
+                              "(0.5 M vertices, ~20 M edges), `[*1..4]` reach sets (fgpu_expand_levels: per-hop frontiers + the "
+                              "DISTINCT union) from 1024-source batches of label :P, 0.1 % tombstones + pending adds on every hop",
+                  "sharding": f"source batches round-robin over {world} rank(s), adjacency replicated, no collective",
+                  "batches": int(nb_v), "TEPS": round(fl_v / dt_v, 1), "ms_per_batch_per_rank": round(dt_v / max(nb_v / world, 1) * 1e3, 3),
+                  "distinct_pairs": int(un_v), "scaling": "weak"}
 
     # ---- HBM traffic per launch, measured now: rocprofv3 --pmc passes over a reduced replay -------------
     pmc = None
@@ -773,9 +942,55 @@ def main():
             khop["roofline"]["traffic"] = hbm(khop["roofline"]["kernel"])
             khop["roofline"]["traffic_source"] = src
             khop["pmc"] = {k: v for k, v in pmc.items() if k.startswith("bp_")} if "error" not in pmc else pmc
+        if khop_emit:
+            for leg in khop_emit.values():
+                for kk in leg["kernels"]:
+                    kk["traffic"] = hbm(kk["kernel"])
 
     if rank == 0:
         st0 = stats_by_root[roots[0]]
+        # what BASELINE.json's metric names — k-hop MATCH TEPS at RMAT-22 / 24 / 26 and the fraction of the HBM roofline of the
+        # kernels on the path — in the keys the driver keeps (`config`, `roofline`); the full objects follow below
+        khop_summary = None
+        secondary = []
+        if khop:
+            def brief(leg):
+                return {"clean_TEPS": leg["clean"]["TEPS"], "clean_ms_per_batch": leg["clean"]["ms_per_batch"],
+                        "dirty_TEPS": leg["dirty"]["TEPS"], "dirty_ms_per_batch": leg["dirty"]["ms_per_batch"],
+                        "out_nnz_per_batch": leg["clean"]["out_nnz"] // leg["batches_timed"],
+                        "batches": leg["batches_timed"], "parity_checked": bool(leg["parity"].get("checked")),
+                        "parity_ok": leg["parity"].get("ok"), "parity_rows": leg["parity"].get("rows"),
+                        "cpu_TEPS": (leg.get("cpu_baseline") or {}).get("value")}
+            khop_summary = {"metric": "TEPS = traversed edges (sum over hops of flops) / wall time of fgpu_expand_count, 3-hop MATCH, "
+                                      "1024-source batches of label :P, RMAT scale -> figures",
+                            str(args.khop_scale): brief(khop)}
+            for sc, leg in khop_scales.items():
+                khop_summary[sc] = brief(leg)
+            if khop_emit:
+                khop_summary["materialised"] = {k: {"ms_per_batch": v["ms_per_batch"], "TEPS": v["TEPS"],
+                                                    "out_nnz_per_batch": v["out_nnz_per_batch"],
+                                                    "parity_ok": (v.get("parity") or {}).get("ok")}
+                                                for k, v in khop_emit.items()}
+            if khop.get("roofline"):
+                r_ = khop["roofline"]
+                secondary.append({"kernel": r_["kernel"], "workload": f"RMAT-{args.khop_scale} 3-hop MATCH, hop 3 (count)",
+                                  "achieved": r_["achieved"], "unit": "GB/s", "frac": r_["frac"], "traffic": r_["traffic"],
+                                  "alg_bytes_per_launch": r_["alg_bytes_per_launch"], "avg_launch_us": r_["avg_launch_us"]})
+            if khop_emit:
+                for nm, leg in khop_emit.items():
+                    for kk in leg["kernels"]:
+                        if kk["kernel"].startswith("bp_rows_kernel"):
+                            secondary.append({"kernel": kk["kernel"], "workload": f"RMAT-{args.khop_scale} {nm} emission (ballot transpose)",
+                                              "achieved": kk["GBps"], "unit": "GB/s", "frac": kk["frac"], "traffic": kk.get("traffic"),
+                                              "alg_bytes_per_launch": kk["alg_bytes_per_launch"], "avg_launch_us": kk["avg_launch_us"]})
+        for sp in (spmv, (khop or {}).get("spmv_full_pass"), (base26 or {}).get("spmv_full_pass")):
+            if sp:
+                secondary.append({"kernel": "tiled_mxv_kernel", "workload": f"RMAT-{sp['scale']} full-matrix boolean SpMV pass (north-star case)",
+                                  "achieved": sp["achieved"], "unit": "GB/s", "frac": sp["frac"], "frac_warm": sp["warm"]["frac"],
+                                  "traffic": sp.get("traffic"), "alg_bytes_per_launch": sp["alg_bytes"],
+                                  "avg_launch_us": sp["avg_launch_us"], "cache_state": "cold"})
+        if roofline is not None:
+            roofline["secondary"] = secondary
         out = {
             "metric": "traversed edges/sec (TEPS) on BFS (boolean vxm frontier loop), synthetic R-MAT",
             "value": round(teps, 1),
@@ -802,12 +1017,18 @@ def main():
                 "device": info["name"], "build_seconds": round(t_build, 2),
                 "root0_levels": st0["levels"], "root0_push_levels": st0["push_levels"],
                 "root0_pull_levels": st0["pull_levels"],
+                "khop_match": khop_summary,
+                "config5_varlen": ({"TEPS": varlen["TEPS"], "batches": varlen["batches"]} if varlen else None),
             },
             "roofline": roofline,
             "time_split": dist_split,
             "spmv_full_pass": spmv,
             "rmat26_single_gpu": base26,
+            "bfs_host_arrays": bfs_host,
             "khop_match": khop,
+            "khop_match_other_scales": khop_scales or None,
+            "khop_materialised": khop_emit,
+            "config5_varlen": varlen,
             "cpu_baseline": cpu,
             "pmc": ({k: v for k, v in pmc.items() if not k.startswith("bp_")} if pmc else None),
         }

@@ -719,55 +719,79 @@ __global__ __launch_bounds__(256) void bp_flops_kernel(CsrView a, u32 w, u32 ws,
 }
 
 // ---------------------------------------------------------------------------------
-// Y -> CSR over the source rows.  A wavefront owns (chunk of 4096 vertices, word w): per block of
-// 64 vertices lane l holds word w of vertex v0 + l; ballot over bit b = the 64-vertex mask of source
-// row 64 w + b.  Pass 1 counts per (row, chunk); a flat exclusive scan of cnt[row][chunk] IS the
-// CSR position of every (row, chunk) run, so pass 2 writes ascending dest ids with no sort.
+// Y -> CSR over the source rows (the north_star's "ballot / prefix-scan output compaction").  A workgroup owns
+// (chunk of 4096 vertices, block of <= 64 words): 64 vertices at a time, their rows are read COALESCED into an LDS tile
+// (row stride padded by one word: the transposed reads below are then bank-conflict free), then wavefront k takes words
+// k, k + 4, ...: lane l holds word wi of vertex v0 + l, and a ballot over bit b is the 64-vertex mask of source row
+// 64 wi + b — only the bit columns that occur in the block are visited (a wave-wide OR of the words names them; a 2-hop
+// state holds ~7 set bits per 64 x 64 block).  Pass 1 counts per (row, chunk); a flat exclusive scan of cnt[row][chunk]
+// IS the CSR position of every (row, chunk) run, so pass 2 writes ascending dest ids with no sort.
+// (The first version gave a wavefront one word COLUMN of a chunk: lane l read 8 bytes of row v0 + l, i.e. one 128-byte
+// line per lane for 8 useful bytes — PMC showed 30.8 GB fetched per launch for a 2.1 GB state, 4.5 ms per pass.)
 // ---------------------------------------------------------------------------------
+constexpr u32 BP_ROWS_WB = 64;   // words per word block (a row of more than 64 words is emitted block by block)
 template <bool EMIT>
 __global__ __launch_bounds__(256) void bp_rows_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws, u32 nchunks,
                                                      const u64* __restrict__ label, u32* __restrict__ cnt,
                                                      const u64* __restrict__ off, u32* __restrict__ col) {
+    extern __shared__ u64 s_rows[];
+    const u32 nwb = (w + BP_ROWS_WB - 1) / BP_ROWS_WB;
+    const u32 c = blockIdx.x / nwb, wb = blockIdx.x % nwb;
+    const u32 w0 = wb * BP_ROWS_WB;
+    const u32 W = (w - w0 < BP_ROWS_WB) ? (w - w0) : BP_ROWS_WB;   // words of this block
+    const u32 stride = W + 1;                                       // LDS row stride in words
+    u64* tile = s_rows;                                             // 64 x stride
+    u32* acc = reinterpret_cast<u32*>(s_rows + 64 * stride);        // W x 64: count / write position of row 64 (w0 + wi) + bit
     const u32 lane = lane_id();
-    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-    const u32 nwaves = (gridDim.x * 256) >> 6;
-    const u32 total = nchunks * w;
-    for (u32 t = wave; t < total; t += nwaves) {
-        const u32 c = t / w, wi = t % w;
-        const u32 row = wi * 64 + lane;  // the source row this lane accounts for
-        u32 mycnt = 0;
-        u64 mypos = 0;
-        if (EMIT) mypos = off[(size_t)row * nchunks + c];
-        for (u32 vb = 0; vb < BP_VCHUNK / 64; ++vb) {
-            const u32 v0 = c * BP_VCHUNK + vb * 64;
-            if (v0 >= n) break;
-            const u32 v = v0 + lane;
-            u64 word = (v < n) ? y[(size_t)v * ws + wi] : 0ull;
-            if (label) {
-                const u64 lw = label[v0 >> 6];
-                if (!((lw >> lane) & 1ull)) word = 0ull;
-            }
-            if (__ballot(word != 0ull) == 0ull) continue;
+    const u32 wave = threadIdx.x >> 6;
+    for (u32 i = threadIdx.x; i < W * 64; i += 256) {
+        const u32 row = (w0 + (i >> 6)) * 64 + (i & 63);
+        acc[i] = EMIT ? (u32)off[(size_t)row * nchunks + c] : 0u;
+    }
+    const u64 below = (1ull << lane) - 1ull;
+    for (u32 vb = 0; vb < BP_VCHUNK / 64; ++vb) {
+        const u32 v0 = c * BP_VCHUNK + vb * 64;
+        if (v0 >= n) break;                                         // (block-uniform)
+        __syncthreads();                                            // previous tile consumed (and acc initialised)
+        const u64 lw = label ? label[v0 >> 6] : ~0ull;
+        u64 any = 0ull;
+        for (u32 i = threadIdx.x; i < 64 * W; i += 256) {
+            const u32 r = i / W, k = i - r * W;
+            u64 word = 0ull;
+            if (v0 + r < n && ((lw >> r) & 1ull)) word = y[(size_t)(v0 + r) * ws + w0 + k];
+            tile[r * stride + k] = word;
+            any |= word;
+        }
+        if (!__syncthreads_or(any != 0ull)) continue;              // the 64 rows are empty (a barrier: the tile is complete)
+        for (u32 wi = wave; wi < W; wi += 4) {
+            const u64 word = tile[lane * stride + wi];
+            u64 cols = word;                                        // bit columns that occur among the 64 vertices
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) cols |= __shfl_xor(cols, d, 64);
+            if (cols == 0ull) continue;                             // (wave-uniform)
+            u32 pos = acc[wi * 64 + lane];                          // lane b: count / position of row 64 (w0 + wi) + b
             const u32 lo = (u32)word, hi = (u32)(word >> 32);
-#pragma unroll 4
-            for (u32 bbit = 0; bbit < 64; ++bbit) {
+            while (cols) {
+                const u32 bbit = (u32)__builtin_ctzll(cols);        // (wave-uniform)
+                cols &= cols - 1ull;
                 const u32 half = bbit < 32 ? lo : hi;
                 const u64 m = __ballot((half >> (bbit & 31)) & 1u);
-                if (m == 0ull) continue;  // wave-uniform
                 const u32 pc = (u32)__popcll(m);
                 if (EMIT) {
-                    // position of row (64 wi + bbit) lives in lane bbit
-                    const u32 plo = (u32)__builtin_amdgcn_readlane((int)(u32)mypos, (int)bbit);
-                    const u32 phi = (u32)__builtin_amdgcn_readlane((int)(u32)(mypos >> 32), (int)bbit);
-                    const u64 p = ((u64)phi << 32) | plo;
-                    if ((m >> lane) & 1ull) col[p + (u32)__popcll(m & ((1ull << lane) - 1ull))] = v;
-                    if (lane == bbit) mypos += pc;
-                } else {
-                    if (lane == bbit) mycnt += pc;
+                    const u32 p = (u32)__builtin_amdgcn_readlane((int)pos, (int)bbit);
+                    if ((m >> lane) & 1ull) col[(size_t)p + (u32)__popcll(m & below)] = v0 + lane;
                 }
+                if (lane == bbit) pos += pc;
             }
+            acc[wi * 64 + lane] = pos;
         }
-        if (!EMIT) cnt[(size_t)row * nchunks + c] = mycnt;
+    }
+    if (!EMIT) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < W * 64; i += 256) {
+            const u32 row = (w0 + (i >> 6)) * 64 + (i & 63);
+            cnt[(size_t)row * nchunks + c] = acc[i];
+        }
     }
 }
 
@@ -1294,13 +1318,26 @@ fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu
     FGPU_TRY(cnt.alloc(ctx, ncnt + 1));
     FGPU_TRY(off.alloc(ctx, ncnt + 1));
     FGPU_HIP(hipMemsetAsync(cnt.p + ncnt, 0, sizeof(u32), ctx->stream()));
-    const u32 total = nchunks * s.w;
-    u32 grid = cdiv(total, 4);
-    if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-    hipLaunchKernelGGL(bp_rows_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n, s.w, s.ws,
-                       nchunks, label_dev, cnt.p, (const u64*)nullptr, (u32*)nullptr);
-    FGPU_HIP(hipGetLastError());
-    FGPU_TRY(scan_u32_to_u64(ctx, cnt.p, off.p, ncnt + 1, nullptr));
+    const u32 nwb = (s.w + BP_ROWS_WB - 1) / BP_ROWS_WB;
+    const u32 grid = nchunks * nwb;
+    const u32 wmax = s.w < BP_ROWS_WB ? s.w : BP_ROWS_WB;
+    const size_t lds_rows = (size_t)64 * (wmax + 1) * sizeof(u64) + (size_t)wmax * 64 * sizeof(u32);
+    if (lds_rows > 48 * 1024) {
+        FGPU_HIP(hipFuncSetAttribute((const void*)bp_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+        FGPU_HIP(hipFuncSetAttribute((const void*)bp_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+    }
+    // algorithmic bytes of the emission (the north_star's "ballot / prefix-scan output compaction"): the bit state is
+    // read once per pass (n rows of w words), the counts / offsets table once, and 4 B per emitted destination id
+    {
+        ProfScope ps(ctx, "bp_rows_kernel<count>", (u64)s.n * s.w * 8 + 4 * (u64)ncnt);
+        hipLaunchKernelGGL(bp_rows_kernel<false>, dim3(grid), dim3(256), lds_rows, ctx->stream(), (const u64*)s.x.p, s.n, s.w, s.ws,
+                           nchunks, label_dev, cnt.p, (const u64*)nullptr, (u32*)nullptr);
+        FGPU_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps(ctx, "scan (row x chunk counts)", 12 * (u64)ncnt);
+        FGPU_TRY(scan_u32_to_u64(ctx, cnt.p, off.p, ncnt + 1, nullptr));
+    }
     u64 nnz = 0;
     FGPU_TRY(read_u64(ctx, off.p + ncnt, &nnz));
     FGPU_REQUIRE(nnz < 0xFFFFFFFFull, FGPU_OOM,
@@ -1312,7 +1349,8 @@ fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu
     hipLaunchKernelGGL(bp_rowptr_kernel, dim3(cdiv((u64)s.nsrc + 1, 256)), dim3(256), 0, ctx->stream(),
                        (const u64*)off.p, s.nsrc, nchunks, o->rowptr);
     if (nnz) {
-        hipLaunchKernelGGL(bp_rows_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n, s.w,
+        ProfScope ps(ctx, "bp_rows_kernel<emit>", (u64)s.n * s.w * 8 + 8 * (u64)ncnt + 4 * nnz);
+        hipLaunchKernelGGL(bp_rows_kernel<true>, dim3(grid), dim3(256), lds_rows, ctx->stream(), (const u64*)s.x.p, s.n, s.w,
                            s.ws, nchunks, label_dev, (u32*)nullptr, (const u64*)off.p, o->colidx);
     }
     hipError_t e = hipGetLastError();

@@ -542,6 +542,20 @@ fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, con
     return i;
 }
 
+fgpu_info fgpu_expand_mat(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                          const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                          const uint64_t* dst_label_bitmap, fgpu_mat** out, uint64_t* flops) {
+    FGPU_REQUIRE(ctx && out, FGPU_NULL_POINTER, "fgpu_expand_mat: NULL argument");
+    FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_mat: NULL src_ids");
+    if (flops) *flops = 0;
+    fgpu_mat* r = nullptr;
+    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
+    fgpu_info i = ctx->publish();   // the new handle may go to another thread
+    if (i != FGPU_OK) { mat_release(r); return i; }
+    *out = r;
+    return FGPU_OK;
+}
+
 fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
                             const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
                             const uint64_t* dst_label_bitmap, uint64_t* out_nnz, uint64_t* checksum,

@@ -316,6 +316,20 @@ def expand(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
     return rowptr, dest, flops.value
 
 
+def expand_mat(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
+    """fgpu_expand_mat: the same chain with F left on the device as a matrix handle (cond_traverse.rs:602-608).
+    Returns (Mat with len(src_ids) rows, flops)."""
+    src = _u64(src_ids)
+    am = _hop_arrays(m)
+    adp = _hop_arrays(dp) if dp is not None else None
+    adm = _hop_arrays(dm) if dm is not None else None
+    lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
+    h = C.c_void_p()
+    flops = C.c_uint64()
+    check(ctx.lib.fgpu_expand_mat(ctx._h, _p(src), len(src), am, adp, adm, len(m), _p(lab), C.byref(h), C.byref(flops)))
+    return Mat(ctx, h), flops.value
+
+
 def expand_count(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None, want_checksum=True):
     """fgpu_expand_count: (nnz, checksum, flops) of the k-hop result without materialising it on the host;
     want_checksum=False skips the per-entry hashing (count only: `RETURN count(c)`), checksum comes back 0."""

@@ -222,6 +222,16 @@ fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
                       uint64_t** out_rowptr, uint64_t** out_dest, uint64_t* out_nnz,
                       uint64_t* flops);
 
+/* Same chain, the result F left on the device as a matrix handle — what the reference holds between
+ * `F = delta_lmxm(...)` and `F.iter(...)` (cond_traverse.rs:602-608: F IS a Matrix<bool>; its rows are then walked
+ * with the row iterator, :644).  *out is a BOOL snapshot with nsrc rows (row i = source i), dest ascending and unique
+ * per row, already filtered by `dst_label_bitmap`; read it with fgpu_mat_extract / fgpu_mat_export_csr, release it with
+ * fgpu_mat_free.  fgpu_expand = this + one export of the whole result into host arrays. */
+fgpu_info fgpu_expand_mat(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                          const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                          const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                          fgpu_mat** out, uint64_t* flops);
+
 /* Same as fgpu_expand but the result stays on device and only its size and an
  * order-independent checksum come back (full-size configs whose output would not
  * fit a host buffer): checksum = sum over the (row, dest) entries of
@@ -409,7 +419,9 @@ fgpu_info fgpu_bfs_dist_times(fgpu_bfs_plan* plan, double* level_ms, double* col
 /* Time `iters` launches of one named kernel with HIP events on the ctx stream.
  * which: 0 = full-pass boolean pull SpMV over the CSR of the matrix passed (dense frontier, no
  * mask, no early exit), 1 = push over A with a dense frontier, 2 = the same full pass as 0 over
- * the LDS-tile layout (the "RMAT-22 boolean SpMV" roofline case).  Returns avg ms per launch and algorithmic bytes per launch
+ * the LDS-tile layout (the "RMAT-22 boolean SpMV" roofline case), 3 = as 2 with the caches flushed before every timed
+ * launch (a 512 MiB scratch buffer is read between launches: the 256 MiB Infinity Cache holds none of the
+ * layout when the pass starts, and no write-back is pending).  Returns avg ms per launch and algorithmic bytes per launch
  * (SURVEY.md §8d formulas). */
 fgpu_info fgpu_bench_spmv(fgpu_ctx* ctx, const fgpu_mat* A, int which, int iters,
                           double* avg_ms, uint64_t* alg_bytes);
