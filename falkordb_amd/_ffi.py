@@ -102,6 +102,9 @@ SIGNATURES = {
     "fgpu_comm_finalize": (C.c_int32, [vp]),
     "fgpu_comm_info": (C.c_int32, [vp, i32p, i32p]),
     "fgpu_mat_balanced_splits": (C.c_int32, [vp, vp, C.c_int, u64p]),
+    "fgpu_splits_shift": (C.c_uint32, [C.c_uint64]),
+    "fgpu_balanced_splits_from_hist": (C.c_int32, [u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, u64p]),
+    "fgpu_slab_layout": (C.c_int32, [u64p, C.c_uint64, C.c_int, u64p, u64p, u64p, u64p]),
     "fgpu_bfs_plan_create_slab": (C.c_int32, [vp, vpp, vp, vp, C.c_int, C.c_int, u64p]),
     "fgpu_bfs_dist_run": (C.c_int32, [vpp, C.c_int, C.c_uint64, C.c_int64, C.c_int]),
     "fgpu_bfs_dist_times": (C.c_int32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p]),

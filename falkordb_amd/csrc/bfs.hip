@@ -1543,6 +1543,10 @@ struct fgpu_bfs_plan {
     bool levels_masked = false;  // level[] already holds -1 for unreached vertices (set by fgpu_bfs_fetch)
     const u64* mask_visited = nullptr;  // the visited bitmap fgpu_bfs_fetch masks level[] with (fused paths)
     u64* slab_send[2] = {nullptr, nullptr};  // fused slab path: double-buffered send slabs (caller-owned)
+    u64* slab_glob[2] = {nullptr, nullptr};  // the gathered frontier launch L reads = slab_glob[L & 1]: one buffer twice, except in
+                                             // the peer exchange of a single-process gang, where peers write level L + 1's bitmap
+                                             // while a slower rank may still be reading level L's
+    u64* dist_glob2 = nullptr;               // (library-owned second bitmap of that mode)
     const u32* gdeg = nullptr;               // fused slab path: global out-degrees (caller-owned, nullable)
     u32 launch = 0;                          // fused slab path: level launches since begin
     int last_levels = 0;         // levels the previous search of this plan took (sizes the next blind batch)
@@ -1626,6 +1630,7 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->dist_send[0]);
     c->dev_free(p->dist_send[1]);
     c->dev_free(p->dist_glob);
+    c->dev_free(p->dist_glob2);
     c->dev_free(p->dist_deg);
     for (hipEvent_t e : p->dist_ev) (void)hipEventDestroy(e);
     if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
@@ -1687,13 +1692,15 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         p->slabw = p->slab / 64;
         p->nw = (u32)(splits[nranks] / 64);
     } else {
-        u64 per = (A->nrows + nranks - 1) / nranks;
-        per = (per + 4095) & ~4095ull;
-        p->slab = (u32)per;
+        // equal slabs: the one definition of the rounding lives in fgpu_slab_layout (dist.hip)
+        std::vector<u64> lo(nranks), hi(nranks);
+        fgpu_info li = fgpu_slab_layout(nullptr, A->nrows, nranks, lo.data(), hi.data(), nullptr, nullptr);
+        if (li != FGPU_OK) { delete p; return li; }
+        p->lo = (u32)lo[rank];
+        p->hi = (u32)hi[rank];
+        p->slab = p->hi - p->lo;
         p->slabw = p->slab / 64;
         p->nw = p->slabw * nranks;
-        p->lo = p->slab * rank;
-        p->hi = p->lo + p->slab;
     }
     fgpu_info i = FGPU_OK;
     const size_t wb = (size_t)p->nw * sizeof(u64);
@@ -1822,6 +1829,7 @@ fgpu_info fgpu_bfs_slab_set_buffers(fgpu_bfs_plan* p, void* send0, void* send1, 
     p->external_bufs = true;
     p->nxt_global = (u64*)global_words;
     p->nxt_local = p->nxt_global;
+    p->slab_glob[0] = p->slab_glob[1] = p->nxt_global;
     p->slab_send[0] = (u64*)send0;
     p->slab_send[1] = (u64*)send1;
     return FGPU_OK;
@@ -1839,6 +1847,7 @@ static BfsArgs slab_args(fgpu_bfs_plan* p) {
     a.slabw = p->slabw;
     a.slab_nxt = p->slab_send[p->launch & 1];
     a.slab_zero = p->slab_send[(p->launch + 1) & 1];
+    if (p->slab_glob[0]) a.nxt_global = p->slab_glob[p->launch & 1];
     a.gdeg = p->gdeg;
     a.host_done = p->d_done;
     return a;
@@ -1910,6 +1919,29 @@ static fgpu_info dist_setup(fgpu_bfs_plan* const* P, int np) {
         FGPU_TRY(fgpu_mat_row_degrees(c, p->A, p->dist_deg));
     }
     const bool rccl = P[0]->ctx->comm != nullptr && P[0]->nranks > 1;
+    if (!rccl && np > 1) {   // peer exchange: a second frontier bitmap per rank (see slab_glob), peer access between the devices
+        FGPU_REQUIRE(np <= 16, FGPU_INVALID, "fgpu_bfs_dist_run: the peer exchange of a single-process gang takes at most 16 ranks");
+        for (int k = 0; k < np; ++k)
+            for (int j = 0; j < np; ++j) {
+                if (P[k]->ctx->device == P[j]->ctx->device) continue;
+                (void)P[k]->ctx->lane();   // device k current
+                const hipError_t pe = hipDeviceEnablePeerAccess(P[j]->ctx->device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                    (void)hipGetLastError();
+                    set_error("fgpu_bfs_dist_run: no peer access from device %d to device %d (%s)", P[k]->ctx->device,
+                              P[j]->ctx->device, hipGetErrorString(pe));
+                    return FGPU_DEVICE;
+                }
+                (void)hipGetLastError();
+            }
+    }
+    if (!rccl && np > 1)
+        for (int k = 0; k < np; ++k) {
+            fgpu_bfs_plan* p = P[k];
+            if (!p->dist_glob2) FGPU_TRY(p->ctx->dev_alloc((void**)&p->dist_glob2, ((size_t)p->nw + 1) * sizeof(u64)));
+            p->slab_glob[0] = p->dist_glob;
+            p->slab_glob[1] = p->dist_glob2;
+        }
     if (rccl) {
         if (np > 1) FGPU_TRY(comm_group_begin());
         for (int k = 0; k < np; ++k) FGPU_TRY(comm_allreduce_sum_u32(P[k]->ctx, P[k]->dist_deg, P[k]->n));
@@ -1941,19 +1973,26 @@ static fgpu_info dist_setup(fgpu_bfs_plan* const* P, int np) {
     return FGPU_OK;
 }
 
-// word offsets / counts of every rank's slab in the global bitmap
-static void slab_layout(const fgpu_bfs_plan* p, std::vector<u64>& offs, std::vector<u64>& cnts) {
+// word offsets / counts of every rank's slab in the global bitmap (fgpu_slab_layout, dist.hip: the same arithmetic the
+// launchers and the CPU tests see)
+static fgpu_info slab_layout(const fgpu_bfs_plan* p, std::vector<u64>& offs, std::vector<u64>& cnts) {
     offs.resize(p->nranks);
     cnts.resize(p->nranks);
-    for (int r = 0; r < p->nranks; ++r) {
-        if (!p->splits.empty()) {
-            offs[r] = p->splits[r] / 64;
-            cnts[r] = (p->splits[r + 1] - p->splits[r]) / 64;
-        } else {
-            offs[r] = (u64)p->slabw * r;
-            cnts[r] = p->slabw;
-        }
-    }
+    return fgpu_slab_layout(p->splits.empty() ? nullptr : p->splits.data(), p->n, p->nranks, nullptr, nullptr, offs.data(),
+                            cnts.data());
+}
+
+// Peer exchange of a single-process gang (no communicator): ONE launch per source rank stores its owned words into the
+// global frontier bitmap of EVERY rank through peer-enabled pointers (16-byte stores, a destination per blockIdx.y) —
+// instead of nranks - 1 host-enqueued copies per rank and level.  Ordering stays with stream events: the launch follows
+// the level kernel that filled `send` on the source's stream, and a destination's next level waits for every source.
+struct PeerDsts { u64* p[16]; };
+__global__ __launch_bounds__(256) void dist_scatter_kernel(const u64* __restrict__ send, u64 words, PeerDsts d) {
+    u64* __restrict__ out = d.p[blockIdx.y];
+    const u64 pairs = words >> 1;       // slabs are multiples of 4096 vertices = 64 words: always even, 16-byte aligned
+    const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(send);
+    uint4* __restrict__ o4 = reinterpret_cast<uint4*>(out);
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (u64)gridDim.x * 256) o4[i] = s4[i];
 }
 
 static fgpu_info dist_event(fgpu_bfs_plan* p, size_t idx) {
@@ -1985,16 +2024,15 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
                  FGPU_INVALID, "fgpu_bfs_dist_run: the plan's rank / size differ from its context's communicator");
     FGPU_TRY(dist_setup(plans, nplans));
     std::vector<u64> offs, cnts;
-    slab_layout(p0, offs, cnts);
+    FGPU_TRY(slab_layout(p0, offs, cnts));
     for (int k = 0; k < nplans; ++k) FGPU_TRY(fgpu_bfs_slab_begin(plans[k], src, max_level, want_parent));
-    std::vector<hipEvent_t> lvl_done(nplans, nullptr), copied(nplans, nullptr);   // peer mode only
+    std::vector<hipEvent_t> copied(nplans, nullptr);   // peer mode only: "rank s has delivered its words of this level"
     const bool peer = !rccl && nplans > 1;
     fgpu_info rc = FGPU_OK;
     if (peer)
         for (int k = 0; k < nplans && rc == FGPU_OK; ++k) {
             (void)plans[k]->ctx->lane();   // events of plan k live on plan k's device
-            if (hipEventCreateWithFlags(&lvl_done[k], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&copied[k], hipEventDisableTiming) != hipSuccess) {
+            if (hipEventCreateWithFlags(&copied[k], hipEventDisableTiming) != hipSuccess) {
                 set_error("fgpu_bfs_dist_run: event creation failed");
                 rc = FGPU_DEVICE;
             }
@@ -2015,22 +2053,25 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
                                              cnts.data()));
             if (rccl && nplans > 1) FGPU_TRY(comm_group_end());
         } else {
-            // every rank's slab goes to every rank's bitmap; a copy waits for the level that produced its source, and
-            // the next level of a rank (which clears the send buffer it is about to reuse) waits for every copy
-            for (int s = 0; s < nplans; ++s) FGPU_HIP(hipEventRecord(lvl_done[s], plans[s]->ctx->stream()));
-            for (int d = 0; d < nplans; ++d) {
-                hipStream_t st = plans[d]->ctx->stream();
-                for (int s = 0; s < nplans; ++s) {
-                    if (s != d) FGPU_HIP(hipStreamWaitEvent(st, lvl_done[s], 0));
-                    if (cnts[s])
-                        FGPU_HIP(hipMemcpyAsync(plans[d]->dist_glob + offs[s], plans[s]->dist_send[idx[s]],
-                                                cnts[s] * sizeof(u64), hipMemcpyDefault, st));
+            // every rank's slab goes to every rank's bitmap: one scatter launch per SOURCE rank on its own stream (right
+            // behind the level kernel that produced the words); a rank's next level — which reads its whole bitmap and
+            // clears the send buffer it is about to reuse — waits for every source's scatter
+            for (int s = 0; s < nplans; ++s) {
+                if (cnts[s]) {
+                    (void)plans[s]->ctx->lane();
+                    PeerDsts pd;
+                    for (int d = 0; d < nplans; ++d) pd.p[d] = plans[d]->slab_glob[plans[d]->launch & 1] + offs[s];   // what the NEXT launch reads
+                    u32 gx = (u32)((cnts[s] / 2 + 255) / 256);
+                    if (gx > 64) gx = 64;
+                    hipLaunchKernelGGL(dist_scatter_kernel, dim3(gx ? gx : 1, nplans), dim3(256), 0, plans[s]->ctx->stream(),
+                                       (const u64*)plans[s]->dist_send[idx[s]], cnts[s], pd);
+                    FGPU_HIP(hipGetLastError());
                 }
-                FGPU_HIP(hipEventRecord(copied[d], st));
+                FGPU_HIP(hipEventRecord(copied[s], plans[s]->ctx->stream()));
             }
-            for (int s = 0; s < nplans; ++s)
-                for (int d = 0; d < nplans; ++d)
-                    if (s != d) FGPU_HIP(hipStreamWaitEvent(plans[s]->ctx->stream(), copied[d], 0));
+            for (int d = 0; d < nplans; ++d)
+                for (int s = 0; s < nplans; ++s)
+                    if (s != d) FGPU_HIP(hipStreamWaitEvent(plans[d]->ctx->stream(), copied[s], 0));
         }
         for (int k = 0; k < nplans; ++k) FGPU_TRY(dist_event(plans[k], 3 * nlev + 2));
         ++nlev;
@@ -2046,7 +2087,6 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
         budget = 2;
     }
     for (int k = 0; k < nplans; ++k) {
-        if (lvl_done[k]) (void)hipEventDestroy(lvl_done[k]);
         if (copied[k]) (void)hipEventDestroy(copied[k]);
     }
     if (rc != FGPU_OK) return rc;

@@ -37,6 +37,7 @@ struct Rccl {
     decltype(&::ncclBroadcast) Broadcast = nullptr;
     decltype(&::ncclAllReduce) AllReduce = nullptr;
     decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+    bool loopback = false;   // the bound library declares itself an in-process loop-back (tests/stub_rccl): ranks may share a device
     std::string error;
 };
 Rccl g_rccl;
@@ -45,9 +46,17 @@ std::once_flag g_rccl_once;
 const Rccl* rccl() {
     std::call_once(g_rccl_once, [] {
         Rccl& r = g_rccl;
+        // FGPU_RCCL_LIB: bind another implementation of the same eleven entry points (a site's own build of RCCL; the
+        // tests' in-process loop-back, which lets the multi-rank branch of the exchange run on a one-GPU box)
+        const char* forced = getenv("FGPU_RCCL_LIB");
+        if (forced && *forced) {
+            r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) { r.error = std::string("FGPU_RCCL_LIB=") + forced + ": " + (dlerror() ? dlerror() : "dlopen failed"); return; }
+            r.loopback = dlsym(r.handle, "fgpu_stub_rccl_loopback") != nullptr;
+        }
         for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.handle) break;
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!r.handle) { r.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
         bool ok = true;
@@ -171,11 +180,13 @@ fgpu_info fgpu_comm_init_all(fgpu_ctx* const* ctxs, int n) {
     for (int i = 0; i < n; ++i) {
         FGPU_REQUIRE(ctxs[i] && !ctxs[i]->comm, FGPU_INVALID, "fgpu_comm_init_all: context %d is NULL or already in a communicator", i);
         devs[i] = ctxs[i]->device;
-        for (int j = 0; j < i; ++j)
-            FGPU_REQUIRE(devs[j] != devs[i], FGPU_INVALID,
-                         "fgpu_comm_init_all: contexts %d and %d share device %d (RCCL wants one rank per GPU)", j, i, devs[i]);
     }
     FGPU_RCCL_OR_FAIL(R);
+    if (!R->loopback)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < i; ++j)
+                FGPU_REQUIRE(devs[j] != devs[i], FGPU_INVALID,
+                             "fgpu_comm_init_all: contexts %d and %d share device %d (RCCL wants one rank per GPU)", j, i, devs[i]);
     std::vector<ncclComm_t> comms(n, nullptr);
     FGPU_NCCL(R->CommInitAll(comms.data(), n, devs.data()));
     for (int i = 0; i < n; ++i) {
@@ -205,15 +216,61 @@ fgpu_info fgpu_comm_info(fgpu_ctx* ctx, int32_t* rank, int32_t* nranks) {
     return FGPU_OK;
 }
 
+/* ---- the partition arithmetic, host-only and pure: one definition for the library, the launchers and the CPU tests ---- */
+
+uint32_t fgpu_splits_shift(uint64_t ncols) {
+    u32 shift = 12;
+    while (((ncols + (1ull << shift) - 1) >> shift) > 8192) ++shift;
+    return shift;
+}
+
+fgpu_info fgpu_balanced_splits_from_hist(const uint64_t* block_counts, uint64_t nblocks, uint32_t shift, uint64_t ncols,
+                                         int nparts, uint64_t* splits) {
+    FGPU_REQUIRE(splits && (block_counts || nblocks == 0), FGPU_NULL_POINTER, "fgpu_balanced_splits_from_hist: NULL argument");
+    FGPU_REQUIRE(nparts >= 1 && shift >= 12 && shift < 40, FGPU_INVALID, "fgpu_balanced_splits_from_hist: bad nparts / shift");
+    const u64 top = (((ncols + 4095) >> 12) << 12);   // the padded vertex count every plan uses
+    // boundary k sits at the block edge whose entry prefix is nearest to k * nnz / nparts (edges never move backwards)
+    std::vector<u64> pre(nblocks + 1, 0);
+    for (u64 b = 0; b < nblocks; ++b) pre[b + 1] = pre[b] + block_counts[b];
+    const u64 nnz = pre[nblocks];
+    splits[0] = 0;
+    u64 j = 0;
+    for (int k = 1; k < nparts; ++k) {
+        const double t = (double)nnz * (double)k / (double)nparts;
+        while (j < nblocks && fabs((double)pre[j + 1] - t) <= fabs((double)pre[j] - t)) ++j;
+        const u64 edge = j << shift;
+        splits[k] = edge < top ? edge : top;
+    }
+    splits[nparts] = top;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_slab_layout(const uint64_t* splits, uint64_t n, int nranks, uint64_t* lo, uint64_t* hi, uint64_t* word_off,
+                           uint64_t* word_cnt) {
+    FGPU_REQUIRE(nranks >= 1, FGPU_INVALID, "fgpu_slab_layout: nranks must be >= 1");
+    // equal slabs (fgpu_bfs_plan_create): ceil(n / nranks) rounded up to 4096 vertices per rank
+    const u64 per = (n + (u64)nranks - 1) / (u64)nranks;
+    const u64 slab = (per + 4095) & ~4095ull;
+    for (int r = 0; r < nranks; ++r) {
+        const u64 l = splits ? splits[r] : slab * (u64)r;
+        const u64 h = splits ? splits[r + 1] : slab * (u64)(r + 1);
+        FGPU_REQUIRE(h >= l && l % 4096 == 0 && h % 4096 == 0, FGPU_INVALID,
+                     "fgpu_slab_layout: boundaries must ascend in multiples of 4096");
+        if (lo) lo[r] = l;
+        if (hi) hi[r] = h;
+        if (word_off) word_off[r] = l / 64;
+        if (word_cnt) word_cnt[r] = (h - l) / 64;
+    }
+    return FGPU_OK;
+}
+
 fgpu_info fgpu_mat_balanced_splits(fgpu_ctx* ctx, const fgpu_mat* a, int nparts, uint64_t* splits) {
     FGPU_REQUIRE(ctx && a && splits, FGPU_NULL_POINTER, "fgpu_mat_balanced_splits: NULL argument");
     FGPU_REQUIRE(nparts >= 1, FGPU_INVALID, "fgpu_mat_balanced_splits: nparts must be >= 1");
     // in-degree per block of 2^shift columns; boundaries are block boundaries (>= 4096 so that they stay word-aligned
     // for every bitmap and level kernel), chosen where the running entry count crosses k * nnz / nparts
-    u32 shift = 12;
-    while (((a->ncols + (1ull << shift) - 1) >> shift) > 8192) ++shift;
+    const u32 shift = fgpu_splits_shift(a->ncols);
     const u32 nblocks = (u32)((a->ncols + (1ull << shift) - 1) >> shift);
-    const u64 top = (((a->ncols + 4095) >> 12) << 12);   // the padded vertex count every plan uses
     std::vector<unsigned long long> h(nblocks, 0);
     if (a->nnz) {
         DevBuf<unsigned long long> dh;
@@ -227,19 +284,8 @@ fgpu_info fgpu_mat_balanced_splits(fgpu_ctx* ctx, const fgpu_mat* a, int nparts,
         FGPU_TRY(ctx->d2h(h.data(), dh.p, (size_t)nblocks * sizeof(unsigned long long)));
         FGPU_HIP(hipStreamSynchronize(ctx->stream()));
     }
-    // boundary k sits at the block edge whose entry prefix is nearest to k * nnz / nparts (edges never move backwards)
-    std::vector<u64> pre(nblocks + 1, 0);
-    for (u32 b = 0; b < nblocks; ++b) pre[b + 1] = pre[b] + h[b];
-    splits[0] = 0;
-    u32 j = 0;
-    for (int k = 1; k < nparts; ++k) {
-        const double t = (double)a->nnz * (double)k / (double)nparts;
-        while (j < nblocks && fabs((double)pre[j + 1] - t) <= fabs((double)pre[j] - t)) ++j;
-        const u64 edge = (u64)j << shift;
-        splits[k] = edge < top ? edge : top;
-    }
-    splits[nparts] = top;
-    return FGPU_OK;
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram words are 64-bit");
+    return fgpu_balanced_splits_from_hist((const uint64_t*)h.data(), nblocks, shift, a->ncols, nparts, splits);
 }
 
 }  // extern "C"

@@ -21,54 +21,67 @@ from __future__ import annotations
 from typing import Callable
 
 
+def _lib():
+    from . import _ffi
+    return _ffi.load(), _ffi
+
+
+def slab_layout(n: int, nranks: int, splits=None):
+    """fgpu_slab_layout (dist.hip) — the library's own partition arithmetic, a pure host function: per rank the vertex
+    range [lo, hi) and its (word offset, word count) in the global frontier bitmap.  splits=None: the equal slabs of
+    fgpu_bfs_plan_create."""
+    import ctypes as C
+
+    import numpy as np
+    lib, ffi = _lib()
+    lo, hi, off, cnt = (np.zeros(nranks, dtype=np.uint64) for _ in range(4))
+    sp = np.ascontiguousarray(splits, dtype=np.uint64) if splits is not None else None
+    p = lambda x: x.ctypes.data_as(C.POINTER(C.c_uint64)) if x is not None else None
+    ffi.check(lib.fgpu_slab_layout(p(sp), int(n), int(nranks), p(lo), p(hi), p(off), p(cnt)))
+    return lo.tolist(), hi.tolist(), off.tolist(), cnt.tolist()
+
+
 def slab_range(n: int, rank: int, nranks: int) -> tuple[int, int, int]:
-    """(lo, hi, slab) with the same rounding as fgpu_bfs_plan_create (bfs.hip)."""
-    per = (n + nranks - 1) // nranks
-    slab = (per + 4095) & ~4095
-    return rank * slab, (rank + 1) * slab, slab
+    """(lo, hi, slab) of an equal-slab partition: fgpu_slab_layout with no splits (= fgpu_bfs_plan_create's rounding)."""
+    lo, hi, _, _ = slab_layout(n, nranks)
+    return int(lo[rank]), int(hi[rank]), int(hi[rank] - lo[rank])
 
 
 def balanced_splits(block_counts, n: int, nparts: int, shift: int = 12):
-    """Python twin of fgpu_mat_balanced_splits (dist.hip): `block_counts[b]` = entries whose column lies in block b of
-    2**shift columns; boundary k is the block edge whose entry prefix is nearest to k * nnz / nparts; boundaries are
-    multiples of 4096, start at 0 and end at n rounded up to 4096."""
-    top = ((n + 4095) >> 12) << 12
-    pre = [0]
-    for c in block_counts:
-        pre.append(pre[-1] + int(c))
-    nnz, nblocks = pre[-1], len(block_counts)
-    splits, j = [0], 0
-    for k in range(1, nparts):
-        t = nnz * k / nparts
-        while j < nblocks and abs(pre[j + 1] - t) <= abs(pre[j] - t):
-            j += 1
-        splits.append(min(j << shift, top))
-    splits.append(top)
-    return splits
+    """fgpu_balanced_splits_from_hist (dist.hip): the host half of fgpu_mat_balanced_splits — `block_counts[b]` = entries
+    whose column lies in block b of 2**shift columns; boundary k is the block edge whose entry prefix is nearest to
+    k * nnz / nparts; boundaries are multiples of 4096, start at 0 and end at n rounded up to 4096."""
+    import ctypes as C
+
+    import numpy as np
+    lib, ffi = _lib()
+    h = np.ascontiguousarray(block_counts, dtype=np.uint64)
+    out = np.zeros(nparts + 1, dtype=np.uint64)
+    u64p = C.POINTER(C.c_uint64)
+    ffi.check(lib.fgpu_balanced_splits_from_hist(h.ctypes.data_as(u64p), len(h), int(shift), int(n), int(nparts),
+                                                 out.ctypes.data_as(u64p)))
+    return [int(x) for x in out]
 
 
 def allgatherv_words(glob, piece, splits, rank: int, nranks: int, all_gather):
     """The frontier exchange of fgpu_bfs_dist_run (dist.hip comm_allgatherv_u64) for launchers whose collective only
-    takes equal pieces (gloo in the CPU tests): rank r's words live at word splits[r] / 64 of the global bitmap.
+    takes equal pieces (gloo in the CPU tests): rank r's words live at the offset fgpu_slab_layout gives.
     `all_gather(out, inp)` = all_gather_into_tensor of equal-size tensors; pieces are padded to the widest slab."""
     import torch
-    words = [(int(splits[r + 1]) - int(splits[r])) // 64 for r in range(nranks)]
+    _, _, offs, words = slab_layout(int(splits[nranks]), nranks, splits)
     wmax = max(max(words), 1)
     pad = torch.zeros(wmax, dtype=glob.dtype, device=glob.device)
     pad[:words[rank]] = piece[:words[rank]]
     out = torch.zeros(wmax * nranks, dtype=glob.dtype, device=glob.device)
     all_gather(out, pad)
     for r in range(nranks):
-        off = int(splits[r]) // 64
-        glob[off:off + words[r]] = out[r * wmax:r * wmax + words[r]]
+        glob[offs[r]:offs[r] + words[r]] = out[r * wmax:r * wmax + words[r]]
 
 
 def splits_shift(ncols: int) -> int:
-    """Block size fgpu_mat_balanced_splits uses for `ncols` columns (at most 8192 blocks of >= 4096 columns)."""
-    shift = 12
-    while ((ncols + (1 << shift) - 1) >> shift) > 8192:
-        shift += 1
-    return shift
+    """fgpu_splits_shift: block size fgpu_mat_balanced_splits uses for `ncols` columns (at most 8192 blocks of >= 4096)."""
+    lib, _ = _lib()
+    return int(lib.fgpu_splits_shift(int(ncols)))
 
 
 def run_levels(backend, gather: Callable[[], None], src: int, max_level: int = -1, first_batch: int = 6,

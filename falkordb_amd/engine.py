@@ -521,6 +521,14 @@ class BfsPlan:
         return bool(d.value), l.value
 
 
+def comm_init_all(ctxs):
+    """fgpu_comm_init_all: one communicator over the contexts of ONE process (rank i = ctxs[i]) — the single-process
+    gang form of the multi-GPU BFS (ncclCommInitAll inside libfgpu.so)."""
+    ctxs = list(ctxs)
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    check(ctxs[0].lib.fgpu_comm_init_all(arr, len(ctxs)))
+
+
 def bfs_dist_run(plans, src: int, max_level: int = -1, want_parent: bool = False):
     """fgpu_bfs_dist_run: one whole search over a column-slab partition, level loop and frontier exchange inside the
     library.  `plans` = this process' ranks: one BfsPlan (one process per GPU, RCCL communicator on its context) or

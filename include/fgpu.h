@@ -399,6 +399,18 @@ fgpu_info fgpu_comm_info(fgpu_ctx* ctx, int32_t* rank, int32_t* nranks);
  * vertex count rounded up to 4096, every boundary a multiple of 4096, part k holding ~ nnz / nparts of A's entries
  * (prefix sum of in-degrees; R-MAT skew otherwise overloads the parts that own the hubs). */
 fgpu_info fgpu_mat_balanced_splits(fgpu_ctx* ctx, const fgpu_mat* a, int nparts, uint64_t* splits /* nparts + 1 */);
+/* The partition arithmetic on its own — pure host functions (no device, no context), so that a launcher, the host layer and
+ * the CPU tests all use the ONE definition the level loop uses:
+ *   fgpu_splits_shift             log2 of the column-block width fgpu_mat_balanced_splits histograms with (>= 12);
+ *   fgpu_balanced_splits_from_hist the boundary choice from per-block entry counts (the host half of the call above);
+ *   fgpu_slab_layout              rank r's vertex range [lo, hi) and its words (offset, count) in the global frontier
+ *                                 bitmap = what the per-level all-gather-v moves; splits == NULL: the equal slabs of
+ *                                 fgpu_bfs_plan_create (ceil(n / nranks) rounded up to 4096).  Outputs are nullable. */
+uint32_t fgpu_splits_shift(uint64_t ncols);
+fgpu_info fgpu_balanced_splits_from_hist(const uint64_t* block_counts, uint64_t nblocks, uint32_t shift, uint64_t ncols,
+                                         int nparts, uint64_t* splits /* nparts + 1 */);
+fgpu_info fgpu_slab_layout(const uint64_t* splits /* nullable: nranks + 1 */, uint64_t n, int nranks, uint64_t* lo,
+                           uint64_t* hi, uint64_t* word_off, uint64_t* word_cnt);
 /* fgpu_bfs_plan_create with caller-chosen slab boundaries: rank owns destinations [splits[rank], splits[rank+1]);
  * A_slab = A[:, slab], At_slab = A'[slab, :] (fgpu_mat_col_slab + fgpu_mat_transpose), global ids. */
 fgpu_info fgpu_bfs_plan_create_slab(fgpu_ctx* ctx, fgpu_bfs_plan** plan, const fgpu_mat* A_slab,

@@ -233,3 +233,47 @@ def test_shard_rows_cover_batch_in_order():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(nranks - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- the partition arithmetic itself: libfgpu.so's pure host functions (no device needed) ------------------------------
+
+def test_slab_layout_of_the_library_covers_the_bitmap_exactly():
+    """fgpu_slab_layout is what fgpu_bfs_plan_create, the per-level exchange (comm_allgatherv_u64 / the peer scatter) and
+    every launcher use: ranges ascend in multiples of 4096, the words tile [0, nw) with no gap or overlap — for equal
+    slabs and for caller-chosen, uneven and EMPTY ones."""
+    for n, nranks in [(1 << 14, 1), (1 << 14, 2), (1 << 14, 3), (100_000, 8), (4096, 4), (5, 3)]:
+        lo, hi, off, cnt = fdist.slab_layout(n, nranks)
+        per = -(-n // nranks)
+        slab = (per + 4095) // 4096 * 4096
+        assert lo == [r * slab for r in range(nranks)] and hi == [(r + 1) * slab for r in range(nranks)]
+        assert off == [x // 64 for x in lo] and cnt == [slab // 64] * nranks
+        assert fdist.slab_range(n, nranks - 1, nranks) == (lo[-1], hi[-1], slab)
+    splits = [0, 8192, 8192, 12288, 16384]            # rank 1 owns nothing
+    lo, hi, off, cnt = fdist.slab_layout(16000, 4, splits)
+    assert (lo, hi) == (splits[:-1], splits[1:])
+    assert cnt == [128, 0, 64, 64] and off == [0, 128, 128, 192] and sum(cnt) == 16384 // 64
+    with pytest.raises(Exception):
+        fdist.slab_layout(16000, 2, [0, 100, 16384])   # not a multiple of 4096
+
+
+def test_balanced_splits_host_half_balances_a_skewed_histogram():
+    """fgpu_balanced_splits_from_hist on a hub-heavy column histogram: every part holds its share of the entries to
+    within one block, boundaries are block edges, nothing moves backwards; one part and more parts than blocks."""
+    rng = np.random.default_rng(11)
+    n, shift = 1 << 18, 12
+    counts = (rng.pareto(1.2, n >> shift) * 1000).astype(np.uint64) + 1
+    counts[:4] *= 50                                      # hubs cluster in the low ids (unscrambled R-MAT, real graphs)
+    nnz = int(counts.sum())
+    assert fdist.splits_shift(n) == 12 and fdist.splits_shift(1 << 26) == 13
+    for nparts in (1, 2, 3, 8):
+        sp = fdist.balanced_splits(counts, n, nparts, shift)
+        assert sp[0] == 0 and sp[-1] == n and all(x % 4096 == 0 for x in sp) and sp == sorted(sp)
+        pre = np.concatenate([[0], np.cumsum(counts)])
+        per = [int(pre[b >> shift] - pre[a >> shift]) for a, b in zip(sp, sp[1:])]
+        assert sum(per) == nnz
+        for k in range(1, nparts):                        # each boundary is the nearest block edge to its target
+            t = nnz * k / nparts
+            e = sp[k] >> shift
+            assert abs(int(pre[e]) - t) <= min(abs(int(pre[max(e - 1, 0)]) - t), abs(int(pre[min(e + 1, len(pre) - 1)]) - t)) + 1e-9
+    sp = fdist.balanced_splits(counts[:2], 8192, 8, shift)   # 2 blocks, 8 parts: empty slabs, still a valid partition
+    assert sp[0] == 0 and sp[-1] == 8192 and sp == sorted(sp) and len(sp) == 9

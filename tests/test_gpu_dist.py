@@ -143,7 +143,18 @@ def test_balanced_splits_follow_the_in_degree_prefix(ctx, scale, nparts):
     A = ctx.mat_rmat(scale)
     got = A.balanced_splits(nparts).tolist()
     shift = fdist.splits_shift(a.ncols)
-    assert got == fdist.balanced_splits(_col_block_counts(a, shift), a.ncols, nparts, shift)
+    # the device histogram + the library's boundary choice against an independent restatement of the rule: boundary k is
+    # the block edge whose entry prefix is nearest to k * nnz / nparts (ties go to the later edge), never moving back
+    pre = np.concatenate([[0], np.cumsum(_col_block_counts(a, shift))])
+    want, j = [0], 0
+    for k in range(1, nparts):
+        t = a.nnz * k / nparts
+        while j < len(pre) - 1 and abs(pre[j + 1] - t) <= abs(pre[j] - t):
+            j += 1
+        want.append(min(j << shift, ((a.ncols + 4095) >> 12) << 12))
+    want.append(((a.ncols + 4095) >> 12) << 12)
+    assert got == want
+    assert got == fdist.balanced_splits(_col_block_counts(a, shift), a.ncols, nparts, shift)   # the host half on its own
     assert got[0] == 0 and got[-1] == ((a.ncols + 4095) >> 12) << 12 and all(x % 4096 == 0 for x in got)
     assert all(x <= y for x, y in zip(got, got[1:]))
     # every part holds its share of the entries, to within one 4096-column block of in-edges
@@ -226,3 +237,100 @@ def test_in_library_loop_over_an_rccl_communicator_of_one(ctx):
         assert ctx2.comm_info() == (0, 1)
     finally:
         ctx2.close()
+
+
+# ---- the multi-rank RCCL branch of the exchange, executed on one GPU through the loop-back library -------------------
+
+_STUB_SCRIPT = r"""
+import ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["FGPU_TEST_ROOT"])
+import oracle
+from falkordb_amd import engine
+
+scale = 14
+a = oracle.rmat_csr(scale)
+n = a.nrows
+deg = np.diff(a.rowptr)
+report = []
+for nranks, splits_kind, coll in [(2, "balanced", 0), (3, "balanced", 0), (3, "balanced", 1), (4, "empty", 0), (4, "empty", 1),
+                                  (4, "balanced", 0)]:
+    ctxs = [engine.Context(0) for _ in range(nranks)]          # one context per "rank", all on device 0
+    engine.comm_init_all(ctxs)                                 # ncclCommInitAll through libfgpu.so
+    assert [c.comm_info() for c in ctxs] == [(r, nranks) for r in range(nranks)]
+    mats = [c.mat_rmat(scale) for c in ctxs]
+    if splits_kind == "balanced":
+        splits = mats[0].balanced_splits(nranks)
+    else:                                                      # rank 1 owns nothing: counts[1] == 0 on every side
+        splits = np.array([0, 8192, 8192, 12288, 16384], dtype=np.uint64)
+    plans, keep = [], []
+    for r, (c, A) in enumerate(zip(ctxs, mats)):
+        c.set_option("dist_collective", coll)
+        lo, hi = int(splits[r]), int(min(splits[r + 1], n))
+        a_slab = A.col_slab(lo, max(hi, lo))
+        at_slab = a_slab.transpose()
+        keep += [a_slab, at_slab]
+        plans.append(engine.BfsPlan(c, a_slab, at_slab, r, nranks, splits=splits))
+    for force in (0, 1, 2):
+        for p in plans:
+            p.tune(force_direction=force)
+        for src in [int(np.argmax(deg)), 5, int(np.nonzero(deg > 0)[0][-1])]:
+            for max_level in (-1, 2):
+                engine.bfs_dist_run(plans, src, max_level, want_parent=True)
+                ref, _, ref_edges = oracle.bfs(a, src, max_level)
+                level = np.full(n, -1, dtype=np.int32)
+                parent = np.full(n, -1, dtype=np.int64)
+                for r, p in enumerate(plans):
+                    lv, par = p.fetch(want_parent=True)
+                    lo, hi = int(splits[r]), int(min(splits[r + 1], n))
+                    level[lo:hi] = lv[lo:hi]
+                    parent[lo:hi] = par[lo:hi]
+                assert np.array_equal(level, ref), (nranks, splits_kind, coll, force, src, max_level)
+                reached = np.nonzero(ref > 0)[0]
+                assert (ref[parent[reached]] + 1 == ref[reached]).all() and parent[src] == src
+                if max_level < 0:
+                    st = [p.stats() for p in plans]
+                    assert sum(x["reached"] for x in st) == int((ref >= 0).sum())
+                    assert sum(x["edges_traversed"] for x in st) == ref_edges      # needs the all-reduced global degrees
+    stub = ctypes.CDLL(os.environ["FGPU_RCCL_LIB"])
+    cnt = (ctypes.c_long * 4)()
+    stub.fgpu_stub_rccl_counters(cnt)
+    report.append({"nranks": nranks, "splits": splits_kind, "collective": coll, "counters": list(cnt)})
+    for p in plans:
+        p.free()
+    for c in ctxs:
+        c.comm_finalize()
+        c.close()
+print("STUB_REPORT " + json.dumps(report))
+"""
+
+
+def test_in_library_dist_loop_over_the_multi_rank_communicator_branch(tmp_path):
+    """the `nranks > 1` branch of the exchange had never executed anywhere (1-GPU boxes).  libfgpu.so binds
+    its eleven RCCL entry points with dlopen; FGPU_RCCL_LIB points it at tests/stub_rccl (an in-process loop-back:
+    ranks = communicators of one process on one device), and fgpu_comm_init_all + fgpu_bfs_dist_run then run the real
+    multi-rank code — group nesting for the gang, grouped ncclSend / ncclRecv per peer pair (dist_collective 0) and
+    ncclBroadcast per rank (1), the ncclAllReduce of the degree vectors, uneven and EMPTY slabs — against the oracle,
+    for 2 / 3 / 4 ranks and every direction mode.  Runs in a child process: the binding is once per process, and this
+    one already holds the real RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = os.path.join(root, "tests", "stub_rccl", "libstub_rccl.so")
+    if not os.path.exists(stub):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC",
+                        os.path.join(root, "tests", "stub_rccl", "stub_rccl.hip"), "-o", stub], check=True)
+    env = dict(os.environ, FGPU_RCCL_LIB=stub, FGPU_TEST_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", _STUB_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("STUB_REPORT ")][-1]
+    rep = json.loads(line[len("STUB_REPORT "):])
+    assert len(rep) == 6
+    sends = [x["counters"][0] for x in rep]
+    bcasts = [x["counters"][1] for x in rep]
+    allred = [x["counters"][2] for x in rep]
+    assert sends[0] > 0 and sends[1] > sends[0]                 # send/recv pairs ran (dist_collective 0)
+    assert bcasts[2] > bcasts[1] and bcasts[4] > bcasts[3]      # broadcasts ran (dist_collective 1)
+    assert allred == sorted(allred) and allred[0] >= 1 and allred[-1] >= 6   # one degree all-reduce per partition
