@@ -97,6 +97,28 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     return HOST_LIB
 
 
+SHIM_LIB = os.path.join(LIBDIR, "libgraphblas.so")
+
+
+def build_shim(force: bool = False, verbose: bool = False) -> str:
+    """libgraphblas.so: the tier-2 GraphBLAS-named shim (falkordb_amd/shim/) over the host layer — the GrB_* / GxB_* symbols
+    the reference's matrix.rs binds, for BOOL / UINT64 + ANY_PAIR, on this engine."""
+    build_host(force=False, verbose=verbose)
+    src = os.path.join(HERE, "shim", "graphblas_shim.cpp")
+    deps = [src, os.path.join(HOST_DIR, "host.hpp"), HOST_LIB]
+    if not force and os.path.exists(SHIM_LIB) and not any(_newer(d, SHIM_LIB) for d in deps):
+        return SHIM_LIB
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", SHIM_LIB, src,
+           "-L" + LIBDIR, "-lfalkor_host", "-lfgpu", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"graphblas shim build failed:\n{r.stderr}")
+    return SHIM_LIB
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
+    print(build_shim(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,100 @@
+"""Tier 2 of the boundary: falkordb_amd/lib/libgraphblas.so exports the GrB_* / GxB_* symbols the
+reference's matrix.rs binds.  tests/shim/replay_matrix_rs.c — a C program written ONLY against declarations transcribed
+from the reference's bindgen output (tests/shim/graphblas_subset.h cites mod.rs line by line) — replays Matrix::new /
+build / delta_lmxm / Iter call for call; its output must be the oracle's delta_lmxm chain (oracle.expand_omp, the
+restatement of matrix.rs:1317-1402 pinned by tests/test_oracle_golden.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "falkordb_amd", "lib")
+
+
+@pytest.fixture(scope="module")
+def replay_exe(tmp_path_factory):
+    from falkordb_amd import build as fb
+    fb.build_shim()
+    exe = str(tmp_path_factory.mktemp("shim") / "replay_matrix_rs")
+    subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "tests", "shim"),
+                    os.path.join(ROOT, "tests", "shim", "replay_matrix_rs.c"), "-o", exe, "-L" + LIBDIR, "-lgraphblas",
+                    "-Wl,-rpath," + LIBDIR], check=True)
+    return exe
+
+
+def _write(path, n, nsrc, nhops, valued, m, dp, dm, src, vals_of):
+    with open(path, "w") as f:
+        f.write(f"{n} {nsrc} {nhops} {1 if valued else 0}\n")
+        for layer, with_vals in ((m, valued), (dp, valued), (dm, False)):
+            r, c = layer.pairs()
+            if layer is m and len(r) > 50:      # duplicates in the COO stream: build collapses them (matrix.rs:1686-1695)
+                r, c = np.concatenate([r, r[:50]]), np.concatenate([c, c[:50]])
+            f.write(f"{len(r)}\n")
+            for i, j in zip(r.tolist(), c.tolist()):
+                f.write(f"{i} {j} {vals_of(i, j)}\n" if with_vals else f"{i} {j}\n")
+        f.write(" ".join(str(int(s)) for s in src) + "\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("valued", [False, True])
+@pytest.mark.parametrize("dirty", [False, True])
+@pytest.mark.parametrize("nhops", [1, 3])
+def test_matrix_rs_call_sequences_through_the_graphblas_abi_match_the_oracle(replay_exe, tmp_path, valued, dirty, nhops):
+    scale = 11
+    a = oracle.rmat_csr(scale)
+    n = a.nrows
+    rng = np.random.default_rng(17 + nhops)
+    rows, cols = a.pairs()
+    if dirty:
+        pick = rng.choice(len(rows), 300, replace=False)
+        dm = oracle.build_csr(n, n, rows[pick], cols[pick])
+        raw = oracle.build_csr(n, n, rng.integers(0, n, 300).astype(np.uint64), rng.integers(0, n, 300).astype(np.uint64))
+        dp = oracle.merge(raw, None, a)                    # dp ∩ m = ∅ (versioned_matrix.rs:214-235)
+    else:
+        dm = dp = oracle.empty(n, n)
+    src = rng.integers(0, n, 40).astype(np.uint64)
+    vals_of = lambda i, j: (i * 1315423911 + j * 2654435761) & 0x7FFFFFFFFFFFFFFF
+    inp = tmp_path / "case.txt"
+    _write(inp, n, len(src), nhops, valued, a, dp, dm, src, vals_of)
+    env = dict(os.environ, LD_LIBRARY_PATH=LIBDIR + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([replay_exe, str(inp)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.split("\n")
+    assert lines[0].startswith("nvals ")
+    nvals = int(lines[0].split()[1])
+    got = [tuple(int(x) for x in l.split()) for l in lines[1:1 + nvals]]
+    c, _, _ = oracle.expand_omp(src, [(a, dp if dirty else None, dm if dirty else None)] * nhops)
+    cr, cc = c.pairs()
+    assert nvals == c.nnz
+    assert got == list(zip(cr.tolist(), cc.tolist()))       # ascending (row, col): the iterator's order (matrix.rs:1572-1605)
+    probes = [l.split() for l in lines[1 + nvals:] if l.startswith("probe")]
+    first = (0, 0) in a.to_set()
+    assert int(probes[0][1]) == (0 if first else 1)         # GrB_SUCCESS / GrB_NO_VALUE
+    if first and valued:
+        assert int(probes[0][2]) == vals_of(0, 0)
+    assert int(probes[1][1]) == (0 if (n - 1, n - 1) in a.to_set() else 1)
+    assert int(probes[2][1]) == -4                          # GrB_INVALID_INDEX for a row past the end
+
+
+def test_shim_exports_every_symbol_the_wrapper_imports():
+    """The import list of matrix.rs:79-102 that belongs to the traversal path, checked against the built library."""
+    from falkordb_amd import build as fb
+    so = fb.build_shim()
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    have = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    want = """GrB_BOOL GrB_UINT64 GxB_ANY_PAIR_BOOL GxB_ANY_BOOL GrB_SECOND_UINT64 GxB_ONE_BOOL GxB_ANY_UINT64 GrB_GLOBAL
+        GrB_DESC_C GrB_DESC_RC GrB_DESC_RCT0 GrB_DESC_RSC GrB_DESC_T0 GrB_DESC_T1 GrB_DESC_R GrB_DESC_S GrB_DESC_RSCT0T1
+        GxB_init GrB_finalize GrB_Global_set_INT32 GrB_Matrix_new GrB_Matrix_free GrB_Matrix_dup GrB_Matrix_nrows GrB_Matrix_ncols
+        GrB_Matrix_nvals GrB_Matrix_wait GrB_Matrix_clear GrB_Matrix_resize GrB_Matrix_get_INT32 GrB_Matrix_set_INT32
+        GxB_Matrix_type GxB_Matrix_build_Scalar GrB_Matrix_build_UINT64 GrB_Matrix_setElement_BOOL GrB_Matrix_setElement_UINT64
+        GrB_Matrix_removeElement GrB_Matrix_extractElement_BOOL GrB_Matrix_extractElement_UINT64 GxB_Matrix_isStoredElement
+        GrB_mxm GrB_Matrix_eWiseAdd_BinaryOp GrB_Matrix_eWiseMult_Semiring GrB_Matrix_apply GrB_transpose GrB_Scalar_new
+        GrB_Scalar_setElement_BOOL GrB_Scalar_free GxB_Iterator_new GxB_Iterator_free GxB_Iterator_get_UINT64
+        GxB_rowIterator_attach GxB_rowIterator_seekRow GxB_rowIterator_nextRow GxB_rowIterator_nextCol
+        GxB_rowIterator_getRowIndex GxB_rowIterator_getColIndex GxB_rowIterator_kount""".split()
+    missing = [s for s in want if s not in have]
+    assert not missing, missing
