@@ -68,6 +68,8 @@ struct fgpu_options {  // fgpu_set_option
     int expand_mode = 0;       // 0 auto, 1 sorted-CSR products only, 2 bit-parallel from the first hop
     int expand_row_groups = 1; // sparse mid-chain pull: a wavefront per 32-row group (0 = a wavefront per row item)
     int expand_fuse_count = 1; // fgpu_expand_count: the last bit-parallel hop counts its rows in place (0 = separate count pass)
+    int tiled_layout = 0;      // full-pass pull layout: 0 = pick by size, 1 = LDS x tiles + global atomics (tiled.hip), 2 = x tile
+                               // and output window both in LDS (blocked.hip)
     int bfs_wgs_per_cu = 6;    // grid of the fused BFS level kernel, workgroups per CU
     int bfs_tiny = 2;          // consecutive tiny BFS levels in one single-workgroup launch (bfs_tiny_kernel): 0 off, 1 on,
                                // 2 = when the plan's previous search took more than 12 levels
@@ -259,6 +261,11 @@ struct fgpu_tiles {
     uint32_t* entries = nullptr;     // packed: bits 0..25 column - tile base (bit tile_bits = pad), 26..31 row & 63
     uint32_t* tile_item = nullptr;   // ntiles + 1 (device)
     uint64_t* row_has = nullptr;     // ngroups words: bit set = row has at least one entry
+    // blocked layout (blocked.hip: output windows in LDS as well; what scales past RMAT-22): kind == 1
+    uint32_t kind = 0;
+    uint32_t bk_wbits = 0, bk_nwindows = 0, bk_nsplit = 1;
+    uint32_t* bk_seg_off = nullptr;  // nblocks + 1 block offsets (entries, multiples of 256)
+    uint32_t* bk_entries = nullptr;
 };
 
 namespace fgpu {
@@ -378,6 +385,9 @@ fgpu_info comm_group_end();
 void tiles_release(fgpu_tiles* t);
 // tiled.hip: build the LDS-tile layout of `m` (0 = automatic parameter) / run out = m (x) x & ~mask
 fgpu_info tiles_build(fgpu_ctx* ctx, const fgpu_mat* m, int tile_bits, int vec, int k, bool rebuild);
+fgpu_info blocked_build(fgpu_ctx* ctx, const fgpu_mat* m, CsrView mv, fgpu_tiles* t);
+fgpu_info blocked_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 x_words64, const u64* mask_dev, u64* out_dev);
+void blocked_release(fgpu_ctx* ctx, fgpu_tiles* t);
 fgpu_info tiles_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 x_words64, const u64* mask_dev,
                     u64* out_dev, bool zero_out);
 

@@ -518,6 +518,9 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.expand_row_groups = value != 0;
     } else if (!strcmp(name, "expand_fuse_count")) {
         ctx->opt.expand_fuse_count = value != 0;
+    } else if (!strcmp(name, "tiled_layout")) {
+        FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "tiled_layout must be 0 (auto), 1 (tiled) or 2 (blocked)");
+        ctx->opt.tiled_layout = (int)value;
     } else if (!strcmp(name, "bfs_tiny")) {
         FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "bfs_tiny must be 0, 1 or 2");
         ctx->opt.bfs_tiny = (int)value;

@@ -49,6 +49,7 @@ void tiles_release(fgpu_tiles* t) {
         t->ctx->dev_free(t->entries);
         t->ctx->dev_free(t->tile_item);
         t->ctx->dev_free(t->row_has);
+        blocked_release(t->ctx, t);
     }
     delete t;
 }
@@ -398,6 +399,7 @@ static tiled_fn pick_kernel(u32 vec, u32 k, int U, bool nt) {
 fgpu_info tiles_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 x_words64, const u64* mask_dev,
                     u64* out_dev, bool zero_out) {
     if (zero_out) FGPU_HIP(hipMemsetAsync(out_dev, 0, (size_t)t->ngroups * sizeof(u64), ctx->stream()));
+    if (t->kind == 1) return blocked_mxv(ctx, t, x_dev, x_words64, mask_dev, out_dev);
     if (t->nitems == 0) return FGPU_OK;
     tiled_fn fn = pick_kernel(t->vec, t->k, ctx->opt.tiled_u, ctx->opt.tiled_nt != 0);
     const size_t lds = ((size_t)1 << t->tile_bits) / 8 + 16;
@@ -431,6 +433,30 @@ fgpu_info tiles_build(fgpu_ctx* ctx, const fgpu_mat* m, int tile_bits, int vec, 
     std::lock_guard<std::mutex> idx_guard(m->idx_mu);
     if (m->tiles && !rebuild) return FGPU_OK;
     FGPU_REQUIRE(m->nrows >= 1 && m->ncols >= 1, FGPU_INVALID, "tiles: empty matrix");
+    // layout choice: explicit parameters ask for the tiled one (the measurement hook's sweeps); otherwise the option, and
+    // by default the blocked layout once a (tile, 64-row group) slot of the tiled one would hold fewer than ~128 entries
+    {
+        const bool explicit_tiled = tile_bits > 0 || vec > 0 || k > 0;
+        const double slot = (double)m->nnz / ((double)((m->nrows + 63) / 64) * (double)((m->ncols + (1u << 20) - 1) >> 20));
+        const int lay = ctx->opt.tiled_layout;
+        if (!explicit_tiled && (lay == 2 || (lay == 0 && slot < 128.0))) {
+            CsrView bv = view_of(m);
+            DevBuf<u32> drp;
+            if (m->is_hyper()) {
+                FGPU_TRY(dense_rowptr(ctx, m, drp));
+                bv.rowptr = drp.p; bv.hrows = nullptr; bv.nvec = (u32)m->nrows;
+            }
+            fgpu_tiles* bt = new (std::nothrow) fgpu_tiles();
+            FGPU_REQUIRE(bt, FGPU_OOM, "out of host memory");
+            bt->ctx = ctx;
+            bt->ngroups = (u32)((m->nrows + 63) / 64);
+            fgpu_info bi = blocked_build(ctx, m, bv, bt);
+            if (bi != FGPU_OK) { tiles_release(bt); return bi; }
+            tiles_release(m->tiles);
+            m->tiles = bt;
+            return FGPU_OK;
+        }
+    }
     if (tile_bits <= 0) {
         tile_bits = 7;
         while (tile_bits < 20 && ((u64)1 << tile_bits) < m->ncols) ++tile_bits;
@@ -529,6 +555,7 @@ fgpu_info fgpu_mat_tiles_info(const fgpu_mat* m, uint64_t info[8]) {
     info[0] = t->tile_bits; info[1] = t->ntiles; info[2] = t->ngroups; info[3] = t->nitems;
     info[4] = t->nentries; info[5] = t->vec; info[6] = t->k;
     info[7] = (uint64_t)t->nentries * 4 + (uint64_t)t->nitems * 8 + (uint64_t)t->ngroups * 8;
+    if (t->kind == 1) info[7] = (uint64_t)t->nentries * 4 + (uint64_t)t->nitems * 4;   // entries + block offsets
     return FGPU_OK;
 }
 

@@ -97,3 +97,72 @@ def test_tiled_full_pass_rmat22_matches_csr_pull(ctx):
     rp, _, _ = At.export_csr()
     has_in = np.diff(rp.astype(np.int64)) > 0
     np.testing.assert_array_equal(oracle.ids_from_bits(got, n), np.nonzero(has_in)[0])
+
+
+# ---- blocked layout (blocked.hip): x tile AND output window in LDS -----------------------------------------------------
+
+@pytest.fixture
+def blocked(ctx):
+    ctx.set_option("tiled_layout", 2)
+    yield
+    ctx.set_option("tiled_layout", 0)
+
+
+@pytest.mark.parametrize("scale", [10, 13, 16])
+def test_blocked_vxm_matches_oracle(ctx, blocked, scale):
+    a = oracle.rmat_csr(scale)
+    n = a.nrows
+    rng = np.random.default_rng(scale)
+    A = up(ctx, a)
+    At = A.transpose()
+    info = At.build_tiles()
+    assert info["entries"] >= a.nnz and info["entries"] % 4 == 0 and info["tile_bits"] == 18
+    for nf in (1, 37, 500, n // 2, n):
+        f = oracle.bits_from_ids(n, rng.choice(n, nf, replace=False))
+        mask = oracle.bits_from_ids(n, rng.choice(n, n // 3, replace=False))
+        for mk in (None, mask):
+            want = oracle.vxm(a, f, mk)
+            for _ in range(3):
+                np.testing.assert_array_equal(engine.vxm(ctx, f, mk, A, At, 3), want)
+
+
+def test_blocked_vxm_ragged_hubs_and_empty(ctx, blocked):
+    # n not a multiple of 64 (nor of the window), empty rows, a hub row spanning several chunks, duplicates of one output
+    # word inside a segment (rows 7 and 7 + 32 k share bits only across segments; row 7's 900 entries hit one word 900 times)
+    n = 1000
+    rows = np.concatenate([np.full(900, 7), np.arange(0, 200, 2), [999]]).astype(np.uint64)
+    cols = np.concatenate([np.arange(900) + 50, np.arange(0, 200, 2) + 1, [0]]).astype(np.uint64)
+    a = oracle.build_csr(n, n, rows, cols)
+    A = up(ctx, a)
+    At = A.transpose()
+    At.build_tiles()
+    rng = np.random.default_rng(5)
+    for nf in (1, 10, 400, n):
+        f = oracle.bits_from_ids(n, rng.choice(n, nf, replace=False))
+        np.testing.assert_array_equal(engine.vxm(ctx, f, None, A, At, 3), oracle.vxm(a, f, None))
+    # the same through the transposed roles (a 900-entry ROW of the matrix being streamed)
+    np.testing.assert_array_equal(engine.vxm(ctx, oracle.bits_from_ids(n, np.arange(n)), None, At, A, 3),
+                                  oracle.vxm(oracle.transpose(a), oracle.bits_from_ids(n, np.arange(n)), None))
+    e = ctx.mat_new(256, 256)
+    info = e.build_tiles()
+    assert info["entries"] == 0
+
+
+@pytest.mark.parametrize("scale", [22, 24])
+def test_blocked_full_pass_matches_csr_pull(ctx, blocked, scale):
+    """BASELINE sizes: the blocked pass against the CSR pull kernel of the same library (itself pinned on the oracle
+    above), random and dense frontiers, with and without a mask."""
+    A = ctx.mat_rmat(scale)
+    At = A.transpose()
+    n = A.nrows
+    info = At.build_tiles()
+    assert info["tile_bits"] == 18
+    rng = np.random.default_rng(scale)
+    f = oracle.bits_from_ids(n, rng.choice(n, n // 5, replace=False))
+    mask = oracle.bits_from_ids(n, rng.choice(n, n // 2, replace=False))
+    for mk in (None, mask):
+        np.testing.assert_array_equal(engine.vxm(ctx, f, mk, A, At, 3), engine.vxm(ctx, f, mk, A, At, 2))
+    full = oracle.bits_from_ids(n, np.arange(n))
+    got = engine.vxm(ctx, full, None, A, At, 3)
+    rp, _, _ = At.export_csr()
+    np.testing.assert_array_equal(oracle.ids_from_bits(got, n), np.nonzero(np.diff(rp.astype(np.int64)) > 0)[0])

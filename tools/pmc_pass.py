@@ -21,6 +21,8 @@ SETS = [
     ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_WRREQ_64B_sum"],
     ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES",
      "SQ_BUSY_CYCLES"],
+    ["SQ_INSTS_SALU", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INST_CYCLES_VMEM",
+     "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU"],
     ["FETCH_SIZE"], ["WRITE_SIZE"],
 ]
 
