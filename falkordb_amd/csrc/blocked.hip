@@ -268,16 +268,15 @@ fgpu_info blocked_mxv(fgpu_ctx* ctx, const fgpu_tiles* t, const u64* x_dev, u32 
     const size_t lds = ((size_t)BK_TILE_WORDS + ow) * sizeof(u32);
     FGPU_REQUIRE((int)lds <= ctx->opt.lds_limit, FGPU_INVALID, "blocked kernel needs %zu B of LDS", lds);
     typedef void (*bk_fn)(BlockedView, const u32*, u32, const u64*, u64*, u32);
-    // "tiled_u" (1 / 2 / 4 / 8) picks the variant here as it picks the items in flight of the tiled kernel.  Measured (cold
-    // pass, RMAT-22 / 24 / 26, fraction of the 8 TB/s peak): 3 trips in flight, two workgroups per CU 0.49 / 0.56 / 0.57
-    // (default); 2 trips 0.50 / 0.58 / 0.54; 4 trips with registers unconstrained (one workgroup per CU) 0.44 / 0.47 / 0.41;
-    // 4 trips squeezed into 64 VGPRs (13 spilled) 0.31 / 0.35 / 0.23
+    // option "blocked_variant".  Measured (cold pass, RMAT-22 / 24 / 26, fraction of the 8 TB/s peak): 0 (default) = 3 trips in
+    // flight, two workgroups per CU 0.49 / 0.56 / 0.57; 1 = 2 trips 0.50 / 0.58 / 0.54; 2 = 4 trips with registers
+    // unconstrained (one workgroup per CU) 0.44 / 0.47 / 0.41; 3 = 4 trips squeezed into 64 VGPRs (13 spilled) 0.31 / 0.35 / 0.23
     bk_fn fn = blocked_mxv_kernel<3, 8>;
     u32 max_per_cu = 2;
-    switch (ctx->opt.tiled_u) {
-        case 8: fn = blocked_mxv_kernel<4, 4>; max_per_cu = 1; break;
-        case 2: fn = blocked_mxv_kernel<2, 8>; break;
-        case 1: fn = blocked_mxv_kernel<4, 8>; break;
+    switch (ctx->opt.blocked_variant) {
+        case 1: fn = blocked_mxv_kernel<2, 8>; break;
+        case 2: fn = blocked_mxv_kernel<4, 4>; max_per_cu = 1; break;
+        case 3: fn = blocked_mxv_kernel<4, 8>; break;
         default: break;
     }
     if (lds > 48 * 1024)
