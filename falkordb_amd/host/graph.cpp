@@ -214,7 +214,7 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
     };
     // FH_TIMING=1: phase times of every call on stderr (tools/bench_paths.py host)
     static const bool timing = getenv("FH_TIMING") != nullptr;
-    auto tp = std::chrono::steady_clock::now();
+    auto tp = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();   // no clock reads on the hot path
     auto lap = [&](const char* what) {
         if (!timing) return;
         const auto now = std::chrono::steady_clock::now();
@@ -617,49 +617,53 @@ void ExpandIntoOp::expand_batch(const Graph& g, const std::vector<u64>& srcs, co
 // libfgpu.so (RCCL when the contexts were joined by fgpu_comm_init_all, event-ordered peer copies otherwise).
 // Everything goes through include/fgpu.h.  Slabs that live on another context travel through the host once per
 // call (no cross-device snapshot copy in the ABI yet; a cache keyed on the adjacency snapshot is the obvious next step).
-static void bfs_partitioned(const Graph& g, const std::vector<Context*>& gang, const Matrix& adj, u64 source,
-                            int64_t max_depth, bool want_edges, std::vector<int32_t>& level, std::vector<int64_t>& parent) {
+static void bfs_partitioned(const Graph& g, const std::vector<Context*>& gang, const Matrix& adj, const std::string& key,
+                            u64 source, int64_t max_depth, bool want_edges, std::vector<int32_t>& level,
+                            std::vector<int64_t>& parent) {
     const int nr = (int)gang.size();
     fgpu_ctx* c0 = g.ctx().raw();
-    std::vector<u64> splits((size_t)nr + 1);
-    check(fgpu_mat_balanced_splits(c0, adj.snapshot(), nr, splits.data()), "fgpu_mat_balanced_splits");
-    std::vector<fgpu_mat*> slabs(nr, nullptr), slabs_t(nr, nullptr);
-    std::vector<fgpu_bfs_plan*> plans(nr, nullptr);
-    auto cleanup = [&]() {
-        for (auto* p : plans) if (p) fgpu_bfs_plan_free(p);
-        for (auto* m : slabs_t) if (m) fgpu_mat_free(m);
-        for (auto* m : slabs) if (m) fgpu_mat_free(m);
-    };
-    try {
+    std::vector<fgpu_ctx*> raw(nr);
+    for (int r = 0; r < nr; ++r) raw[r] = gang[r]->raw();
+    std::shared_ptr<Graph::BfsGangCache> gc = g.bfs_gang_cache_;
+    if (!gc || gc->key != key || gc->gang != raw || gc->plans.empty() || gc->adj.snapshot() != adj.snapshot()) {
+        // a new adjacency, filter or gang: cut the slabs again (the previous set is released with its last user)
+        gc = std::make_shared<Graph::BfsGangCache>(adj);
+        gc->key = key;
+        gc->gang = raw;
+        gc->splits.assign((size_t)nr + 1, 0);
+        gc->slabs.assign(nr, nullptr);
+        gc->slabs_t.assign(nr, nullptr);
+        gc->plans.assign(nr, nullptr);
+        check(fgpu_mat_balanced_splits(c0, adj.snapshot(), nr, gc->splits.data()), "fgpu_mat_balanced_splits");
         const u64 n = g.node_cap();
         for (int r = 0; r < nr; ++r) {
-            fgpu_ctx* cr = gang[r]->raw();
+            fgpu_ctx* cr = raw[r];
             fgpu_mat* local = nullptr;
-            check(fgpu_mat_col_slab(c0, &local, adj.snapshot(), splits[r], splits[r + 1] < n ? splits[r + 1] : n), "fgpu_mat_col_slab");
+            check(fgpu_mat_col_slab(c0, &local, adj.snapshot(), gc->splits[r], gc->splits[r + 1] < n ? gc->splits[r + 1] : n),
+                  "fgpu_mat_col_slab");
             if (cr == c0) {
-                slabs[r] = local;
+                gc->slabs[r] = local;
             } else {
                 u64 *rp = nullptr, *ci = nullptr, nnz = 0;
                 fgpu_info i = fgpu_mat_export_csr(c0, local, &rp, &ci, nullptr, &nnz);
                 fgpu_mat_free(local);
                 check(i, "GxB_unload_Matrix_into_Container");
-                i = fgpu_mat_from_csr(cr, &slabs[r], n, n, nnz, rp, 64, ci, 64, nullptr, nullptr, 0);
+                i = fgpu_mat_from_csr(cr, &gc->slabs[r], n, n, nnz, rp, 64, ci, 64, nullptr, nullptr, 0);
                 fgpu_free(c0, rp);
                 fgpu_free(c0, ci);
                 check(i, "GxB_load_Matrix_from_Container");
             }
-            check(fgpu_mat_transpose(cr, &slabs_t[r], slabs[r]), "GrB_transpose");
-            check(fgpu_bfs_plan_create_slab(cr, &plans[r], slabs[r], slabs_t[r], r, nr, splits.data()), "fgpu_bfs_plan_create_slab");
+            check(fgpu_mat_transpose(cr, &gc->slabs_t[r], gc->slabs[r]), "GrB_transpose");
+            check(fgpu_bfs_plan_create_slab(cr, &gc->plans[r], gc->slabs[r], gc->slabs_t[r], r, nr, gc->splits.data()),
+                  "fgpu_bfs_plan_create_slab");
         }
-        check(fgpu_bfs_dist_run(plans.data(), nr, source, max_depth < 0 ? -1 : max_depth, want_edges ? 1 : 0),
-              "LAGr_BreadthFirstSearch (partitioned)");
-        for (int r = 0; r < nr; ++r)   // every rank fills its own range [splits[r], splits[r+1])
-            check(fgpu_bfs_fetch(plans[r], level.data(), want_edges ? parent.data() : nullptr), "fgpu_bfs_fetch");
-    } catch (...) {
-        cleanup();
-        throw;
+        g.bfs_gang_cache_ = gc;            // (an exception above leaves the old cache in place; gc frees what it built)
+        Graph::register_gang_cache(gc);
     }
-    cleanup();
+    check(fgpu_bfs_dist_run(gc->plans.data(), nr, source, max_depth < 0 ? -1 : max_depth, want_edges ? 1 : 0),
+          "LAGr_BreadthFirstSearch (partitioned)");
+    for (int r = 0; r < nr; ++r)   // every rank fills its own range [splits[r], splits[r+1])
+        check(fgpu_bfs_fetch(gc->plans[r], level.data(), want_edges ? parent.data() : nullptr), "fgpu_bfs_fetch");
 }
 
 BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
@@ -679,7 +683,7 @@ BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
     std::vector<int32_t> level(n);
     std::vector<int64_t> parent(want_edges ? n : 0);
     const bool partitioned = gang && gang->size() > 1 && adj.nvals() > 0;
-    if (partitioned) bfs_partitioned(g, *gang, adj, *source, max_depth, want_edges, level, parent);
+    if (partitioned) bfs_partitioned(g, *gang, adj, key, *source, max_depth, want_edges, level, parent);
     std::shared_ptr<Graph::BfsPlanCache> pc = partitioned ? nullptr : g.bfs_cache_;
     if (!partitioned && (!pc || pc->key != key || pc->adj.snapshot() != adj.snapshot())) {
         // a new adjacency (the layers changed, or another type): new plan; a clean committed graph keeps handing

@@ -373,6 +373,32 @@ class Graph {
         ~BfsPlanCache() { if (plan) fgpu_bfs_plan_free(plan); }
     };
     mutable std::shared_ptr<BfsPlanCache> bfs_cache_;
+    // the same for a partitioned search over a gang of contexts: balanced splits, one column slab (+ transpose) and one
+    // slab plan per device — building them costs far more than a search, so they live as long as the
+    // adjacency snapshot, the relationship filter and the gang stay the same
+    struct BfsGangCache {
+        Matrix adj;                         // keeps the snapshot the slabs were cut from alive (and comparable)
+        std::string key;
+        std::vector<fgpu_ctx*> gang;
+        std::vector<u64> splits;
+        std::vector<fgpu_mat*> slabs, slabs_t;
+        std::vector<fgpu_bfs_plan*> plans;
+        std::mutex mu;
+        explicit BfsGangCache(Matrix a) : adj(std::move(a)) {}
+        // frees the device objects (idempotent).  Called by the destructor and by Context::~Context of ANY context of the
+        // gang, BEFORE that context is finalised: the slabs and plans of a gang live in several contexts, and none of them
+        // may be touched once one of those is gone
+        void release() {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto* p : plans) if (p) fgpu_bfs_plan_free(p);
+            for (auto* m : slabs_t) if (m) fgpu_mat_free(m);
+            for (auto* m : slabs) if (m) fgpu_mat_free(m);
+            plans.clear(); slabs_t.clear(); slabs.clear(); gang.clear();
+        }
+        ~BfsGangCache() { release(); }
+    };
+    static void register_gang_cache(const std::shared_ptr<BfsGangCache>& c);   // (matrix.cpp, next to Context::~Context)
+    mutable std::shared_ptr<BfsGangCache> bfs_gang_cache_;
 };
 
 // A bound value of one batch row, reduced to what the traversal operators inspect.

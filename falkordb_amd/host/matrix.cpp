@@ -18,8 +18,34 @@ Context::Context(int device) {
     // matrix::init propagates failure as Err(String) so the module refuses to load (matrix.rs:109-134)
     check(fgpu_init(&ctx_, device, nullptr, nullptr), "matrix::init");
 }
+// partitioned-BFS caches (Graph::BfsGangCache) hold slabs and plans in SEVERAL contexts: a context that goes away first
+// releases every cache it takes part in
+namespace {
+std::mutex g_gang_mu;
+std::vector<std::weak_ptr<Graph::BfsGangCache>> g_gang_caches;
+}  // namespace
+void Graph::register_gang_cache(const std::shared_ptr<BfsGangCache>& c) {
+    std::lock_guard<std::mutex> g(g_gang_mu);
+    size_t k = 0;
+    for (auto& w : g_gang_caches)
+        if (!w.expired()) g_gang_caches[k++] = w;
+    g_gang_caches.resize(k);
+    g_gang_caches.push_back(c);
+}
 Context::~Context() {
-    if (ctx_) fgpu_finalize(ctx_);
+    if (!ctx_) return;
+    std::vector<std::shared_ptr<Graph::BfsGangCache>> mine;
+    {
+        std::lock_guard<std::mutex> g(g_gang_mu);
+        for (auto& w : g_gang_caches)
+            if (auto c = w.lock()) {
+                std::lock_guard<std::mutex> cg(c->mu);
+                for (fgpu_ctx* x : c->gang)
+                    if (x == ctx_) { mine.push_back(c); break; }
+            }
+    }
+    for (auto& c : mine) c->release();
+    fgpu_finalize(ctx_);
 }
 
 // ---- Matrix state ----------------------------------------------------------------------------
