@@ -730,6 +730,7 @@ __global__ __launch_bounds__(256) void bp_flops_kernel(CsrView a, u32 w, u32 ws,
 // line per lane for 8 useful bytes — PMC showed 30.8 GB fetched per launch for a 2.1 GB state, 4.5 ms per pass.)
 // ---------------------------------------------------------------------------------
 constexpr u32 BP_ROWS_WB = 64;   // words per word block (a row of more than 64 words is emitted block by block)
+constexpr u32 BP_ROWS_NB = 2;    // 64-vertex blocks per LDS tile (one barrier pair and one round of loads per 128 rows)
 template <bool EMIT>
 __global__ __launch_bounds__(256) void bp_rows_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws, u32 nchunks,
                                                      const u64* __restrict__ label, u32* __restrict__ cnt,
@@ -741,8 +742,8 @@ __global__ __launch_bounds__(256) void bp_rows_kernel(const u64* __restrict__ y,
     const u32 w0 = wb * BP_ROWS_WB;
     const u32 W = (w - w0 < BP_ROWS_WB) ? (w - w0) : BP_ROWS_WB;   // words of this block
     const u32 stride = W + 1;                                       // LDS row stride in words
-    u64* tile = s_rows;                                             // 64 x stride
-    u32* acc = reinterpret_cast<u32*>(s_rows + 64 * stride);        // W x 64: count / write position of row 64 (w0 + wi) + bit
+    u64* tile = s_rows;                                             // BP_ROWS_NB x 64 rows x stride
+    u32* acc = reinterpret_cast<u32*>(s_rows + BP_ROWS_NB * 64 * stride);   // W x 64: count / write position of row 64 (w0 + wi) + bit
     const u32 lane = lane_id();
     const u32 wave = threadIdx.x >> 6;
     for (u32 i = threadIdx.x; i < W * 64; i += 256) {
@@ -750,45 +751,56 @@ __global__ __launch_bounds__(256) void bp_rows_kernel(const u64* __restrict__ y,
         acc[i] = EMIT ? (u32)off[(size_t)row * nchunks + c] : 0u;
     }
     const u64 below = (1ull << lane) - 1ull;
-    for (u32 vb = 0; vb < BP_VCHUNK / 64; ++vb) {
+    // the byte flags of the state ("row may hold a bit") for the whole chunk, once: after a hop from a light frontier four
+    // rows in five are empty (3.7 M of 16.7 M at RMAT-24) and their 128 bytes are never read; having them in LDS also takes
+    // one dependent memory round trip (flags -> rows) out of every tile
+    uint8_t* s_flag = reinterpret_cast<uint8_t*>(acc + W * 64);     // BP_VCHUNK bytes
+    for (u32 i = threadIdx.x; i < BP_VCHUNK; i += 256) {
+        const u32 v = c * BP_VCHUNK + i;
+        s_flag[i] = (v < n && (!flag || flag[v])) ? 1 : 0;
+    }
+    constexpr u32 NB = BP_ROWS_NB;                                  // 64-vertex blocks staged per tile
+    for (u32 vb = 0; vb < BP_VCHUNK / 64; vb += NB) {
         const u32 v0 = c * BP_VCHUNK + vb * 64;
         if (v0 >= n) break;                                         // (block-uniform)
-        __syncthreads();                                            // previous tile consumed (and acc initialised)
-        u64 lw = label ? label[v0 >> 6] : ~0ull;
-        if (flag) {
-            // the byte flags of the state ("row may hold a bit"): after a hop from a light frontier four rows in five are
-            // empty (3.7 M of 16.7 M at RMAT-24) — their 128 bytes are not read at all (flag = 64 bytes per block)
-            const u32 fl = (v0 + lane < n) ? flag[v0 + lane] : 0u;   // every wavefront reads the block's 64 flags (one line)
-            lw &= __ballot(fl != 0);
+        __syncthreads();                                            // previous tile consumed (acc, flags initialised)
+        u64 lw[NB];
+#pragma unroll
+        for (u32 q = 0; q < NB; ++q) {
+            const u32 vq = v0 + q * 64;
+            lw[q] = __ballot(s_flag[(vb + q) * 64 + lane] != 0);
+            if (label && vq < n) lw[q] &= label[vq >> 6];
         }
         u64 any = 0ull;
-        for (u32 i = threadIdx.x; i < 64 * W; i += 256) {
-            const u32 r = i / W, k = i - r * W;
+        for (u32 i = threadIdx.x; i < NB * 64 * W; i += 256) {
+            const u32 r = i / W, k = i - r * W;                     // r < NB * 64
             u64 word = 0ull;
-            if (v0 + r < n && ((lw >> r) & 1ull)) word = y[(size_t)(v0 + r) * ws + w0 + k];
+            if ((lw[(r >> 6) % NB] >> (r & 63u)) & 1ull) word = y[(size_t)(v0 + r) * ws + w0 + k];
             tile[r * stride + k] = word;
             any |= word;
         }
-        if (!__syncthreads_or(any != 0ull)) continue;              // the 64 rows are empty (a barrier: the tile is complete)
+        if (!__syncthreads_or(any != 0ull)) continue;              // the rows are empty (a barrier: the tile is complete)
         for (u32 wi = wave; wi < W; wi += 4) {
-            const u64 word = tile[lane * stride + wi];
-            u64 cols = word;                                        // bit columns that occur among the 64 vertices
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) cols |= __shfl_xor(cols, d, 64);
-            if (cols == 0ull) continue;                             // (wave-uniform)
             u32 pos = acc[wi * 64 + lane];                          // lane b: count / position of row 64 (w0 + wi) + b
-            const u32 lo = (u32)word, hi = (u32)(word >> 32);
-            while (cols) {
-                const u32 bbit = (u32)__builtin_ctzll(cols);        // (wave-uniform)
-                cols &= cols - 1ull;
-                const u32 half = bbit < 32 ? lo : hi;
-                const u64 m = __ballot((half >> (bbit & 31)) & 1u);
-                const u32 pc = (u32)__popcll(m);
-                if (EMIT) {
-                    const u32 p = (u32)__builtin_amdgcn_readlane((int)pos, (int)bbit);
-                    if ((m >> lane) & 1ull) col[(size_t)p + (u32)__popcll(m & below)] = v0 + lane;
+#pragma unroll
+            for (u32 q = 0; q < NB; ++q) {                          // sub-blocks in vertex order: positions stay ascending
+                const u64 word = tile[(q * 64 + lane) * stride + wi];
+                u64 cols = word;                                    // bit columns that occur among the 64 vertices
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) cols |= __shfl_xor(cols, d, 64);
+                const u32 lo = (u32)word, hi = (u32)(word >> 32);
+                while (cols) {
+                    const u32 bbit = (u32)__builtin_ctzll(cols);    // (wave-uniform)
+                    cols &= cols - 1ull;
+                    const u32 half = bbit < 32 ? lo : hi;
+                    const u64 m = __ballot((half >> (bbit & 31)) & 1u);
+                    const u32 pc = (u32)__popcll(m);
+                    if (EMIT) {
+                        const u32 p = (u32)__builtin_amdgcn_readlane((int)pos, (int)bbit);
+                        if ((m >> lane) & 1ull) col[(size_t)p + (u32)__popcll(m & below)] = v0 + q * 64 + lane;
+                    }
+                    if (lane == bbit) pos += pc;
                 }
-                if (lane == bbit) pos += pc;
             }
             acc[wi * 64 + lane] = pos;
         }
@@ -1328,7 +1340,7 @@ fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu
     const u32 nwb = (s.w + BP_ROWS_WB - 1) / BP_ROWS_WB;
     const u32 grid = nchunks * nwb;
     const u32 wmax = s.w < BP_ROWS_WB ? s.w : BP_ROWS_WB;
-    const size_t lds_rows = (size_t)64 * (wmax + 1) * sizeof(u64) + (size_t)wmax * 64 * sizeof(u32);
+    const size_t lds_rows = (size_t)BP_ROWS_NB * 64 * (wmax + 1) * sizeof(u64) + (size_t)wmax * 64 * sizeof(u32) + BP_VCHUNK;
     if (lds_rows > 48 * 1024) {
         FGPU_HIP(hipFuncSetAttribute((const void*)bp_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
         FGPU_HIP(hipFuncSetAttribute((const void*)bp_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
