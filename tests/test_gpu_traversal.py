@@ -108,6 +108,23 @@ def test_expand_chain_with_label_filter_and_skipped_rows(ctx):
     assert flops == flops_ref
     nnz, cs, fl2 = engine.expand_count(ctx, src, [A, A, A], [DP, DP, DP], [DM, DM, DM], label)
     assert nnz == ref.nnz and cs == oracle.checksum(ref) and fl2 == flops_ref
+    # fgpu_expand_mat: the same F left on the device as a matrix handle (cond_traverse.rs:602-608) — whole export, a row
+    # window through fgpu_mat_extract (what F.iter(min_row, max_row) walks, :644), point probes, in every expand_mode
+    for mode in (0, 1, 2):
+        try:
+            ctx.set_option("expand_mode", mode)
+            Fm, fl3 = engine.expand_mat(ctx, src, [A, A, A], [DP, DP, DP], [DM, DM, DM], label)
+        finally:
+            ctx.set_option("expand_mode", 0)
+        assert fl3 == flops_ref and (Fm.nrows, Fm.ncols, Fm.nvals) == (k, n, ref.nnz)
+        frp, fci, _ = Fm.export_csr()
+        np.testing.assert_array_equal(frp, ref.rowptr)
+        np.testing.assert_array_equal(fci, ref.colidx)
+        wr, wc, _ = Fm.extract(40, 99)
+        lo, hi = int(ref.rowptr[40]), int(ref.rowptr[100])
+        np.testing.assert_array_equal(wc, ref.colidx[lo:hi])
+        np.testing.assert_array_equal(wr, np.repeat(np.arange(40, 100, dtype=U64), np.diff(ref.rowptr[40:101]).astype(np.int64)))
+        Fm.free()
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
