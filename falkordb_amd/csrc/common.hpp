@@ -68,6 +68,7 @@ struct fgpu_options {  // fgpu_set_option
     int expand_mode = 0;       // 0 auto, 1 sorted-CSR products only, 2 bit-parallel from the first hop
     int expand_row_groups = 1; // sparse mid-chain pull: a wavefront per 32-row group (0 = a wavefront per row item)
     int expand_fuse_count = 1; // fgpu_expand_count: the last bit-parallel hop counts its rows in place (0 = separate count pass)
+    int expand_bits_ratio = 28; // fgpu_expand, expand_mode 0: a hop goes to bit form when its traversed edges T exceed nnz / ratio
     int blocked_variant = 0;   // blocked.hip kernel variant (trips in flight / workgroups per CU), see blocked_mxv
     int tiled_layout = 0;      // full-pass pull layout: 0 = pick by size, 1 = LDS x tiles + global atomics (tiled.hip), 2 = x tile
                                // and output window both in LDS (blocked.hip)

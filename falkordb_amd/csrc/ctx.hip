@@ -518,6 +518,9 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.expand_row_groups = value != 0;
     } else if (!strcmp(name, "expand_fuse_count")) {
         ctx->opt.expand_fuse_count = value != 0;
+    } else if (!strcmp(name, "expand_bits_ratio")) {
+        FGPU_REQUIRE(value >= 1 && value <= 1024, FGPU_INVALID, "expand_bits_ratio out of range");
+        ctx->opt.expand_bits_ratio = (int)value;
     } else if (!strcmp(name, "blocked_variant")) {
         FGPU_REQUIRE(value >= 0 && value <= 3, FGPU_INVALID, "blocked_variant must be 0..3");
         ctx->opt.blocked_variant = (int)value;

@@ -350,16 +350,18 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         const fgpu_mat* dmh = dm ? dm[h] : nullptr;
         if (!bits && mode != 1 && !mh->is_hyper() && mh->nnz && mh->nnz < 0x7FFFFFFFull && f->nnz) {
             const u64 w = (nsrc + 63) / 64;
-            const u64 row_bytes = w * 8 > 64 ? w * 8 : 64;
             const u64 mem = 2ull * (mh->nrows > mh->ncols ? mh->nrows : mh->ncols) * (w <= 64 ? 2 * w : w + 64) * 8;
             bool go = (mode == 2);
             u64 T = 0;
             if ((mode == 0 && mem < (64ull << 30)) || go) {
                 fgpu_info i = mxm_flops(ctx, f, mh, &T);
                 if (i != FGPU_OK) { mat_release(f); return i; }
-                // measured on RMAT-22 / 1024 rows: a sorted-CSR hop costs ~0.16 ns per gathered entry
-                // (6 ms at T = 36 M), a bit hop ~2.7 ms per 65 M matrix entries at 128 B rows
-                if (mode == 0) go = T * 1024 > mh->nnz * row_bytes;
+                // measured: a sorted-CSR hop costs ~0.12-0.16 ns per gathered entry (RMAT-22: 6 ms at T = 36 M; RMAT-26:
+                // 12 ms at T ~ 100 M), the first bit hop — the sparse pull, a flag probe per entry of A' — 5.5-6 ps per matrix
+                // entry whatever the row width (1.45 ms at RMAT-24, 6.2 ms at RMAT-26): the chain leaves the CSR form once
+                // T exceeds ~ nnz / 28.  (The round-1 rule, T * 1024 > nnz * row_bytes = nnz / 8 at 1024 rows, dated from a
+                // 41 ps-per-entry pull and kept RMAT-26 batches in an 8.7 ms sort.)
+                if (mode == 0) go = T * ctx->opt.expand_bits_ratio > mh->nnz;
             }
             if (go) {
                 // leaving the CSR form: a frontier whose out-edges are FEW beside the matrix is pushed into the bit state

@@ -45,7 +45,7 @@ def main():
     ap.add_argument("sweeps", nargs="*")
     a = ap.parse_args()
     ctx = engine.Context(0)
-    A, dp, dm = bench.khop_inputs(ctx, a.scale, 16)
+    A, dp, dm, _ = bench.khop_inputs(ctx, a.scale, 16)
     srcs = bench.p_label_sources(A.nrows)
     batches = [srcs[i * 1024:(i + 1) * 1024] for i in range(a.batches)]
     layers = ([A] * 3, [dp] * 3, [dm] * 3) if a.dirty else ([A] * 3,)
