@@ -90,6 +90,8 @@ struct fgpu_lane {  // one per host thread using the context
     void* pinned = nullptr;              // small pinned staging block for control read-backs
     size_t pinned_bytes = 0;
     std::multimap<size_t, void*> pool;   // free device blocks by capacity, recycled in this lane's stream order (ctx->mu)
+    void* zero_block = nullptr;          // a block of `pool` whose first zero_bytes are known to be zero (dev_free_zeroed); the
+    size_t zero_bytes = 0;               // mark is dropped as soon as the block leaves the pool for anything else
     hipEvent_t fence = nullptr;          // recorded on `stream` by a thread that frees a shared object (fence_mu)
     std::mutex fence_mu;
     bool bound = false;                  // a live thread holds it (ctx->mu)
@@ -138,6 +140,11 @@ struct fgpu_ctx {
     // wait for the work that produced it (single-lane contexts stay asynchronous).
     fgpu_info publish();
     fgpu_info dev_alloc(void** p, size_t bytes);
+    // a block whose first `bytes` are zero: the lane's marked block when it fits exactly (no memset), else a fresh block
+    // that *was_zero = false tells the caller to clear.  dev_free_zeroed returns a block the caller has re-zeroed (on this
+    // lane's stream) and marks it — a k-hop batch hands its 2 GiB bit state to the next batch this way instead of a memset.
+    fgpu_info dev_alloc_zeroed(void** p, size_t bytes, bool* was_zero);
+    void dev_free_zeroed(void* p, size_t bytes);
     void dev_free(void* p);
     // Bulk transfers between CALLER memory and the device always go through the lane's pinned halves: a
     // hipMemcpyAsync on pageable memory makes the runtime pin / unpin the caller's pages, and once a process had

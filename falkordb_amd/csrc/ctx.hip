@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <iterator>
+
 #include "common.hpp"
 
 namespace fgpu {
@@ -181,9 +183,15 @@ fgpu_info fgpu_ctx::dev_alloc(void** p, size_t bytes) {
     if (ln) {
         std::lock_guard<std::mutex> g(mu);
         auto it = ln->pool.lower_bound(cap);
+        // (a block marked "zero" is left for dev_alloc_zeroed while another one of the same class is free)
+        if (it != ln->pool.end() && it->second == ln->zero_block) {
+            auto nx = std::next(it);
+            if (nx != ln->pool.end() && nx->first <= cap + (cap >> 2)) it = nx;
+        }
         if (it != ln->pool.end() && it->first <= cap + (cap >> 2)) {
             *p = it->second;
             size_t c = it->first;
+            if (*p == ln->zero_block) { ln->zero_block = nullptr; ln->zero_bytes = 0; }   // about to be overwritten
             ln->pool.erase(it);
             live[*p] = c;
             bytes_pooled -= c;
@@ -208,6 +216,40 @@ fgpu_info fgpu_ctx::dev_alloc(void** p, size_t bytes) {
     bytes_in_use += cap;
     *p = q;
     return FGPU_OK;
+}
+
+fgpu_info fgpu_ctx::dev_alloc_zeroed(void** p, size_t bytes, bool* was_zero) {
+    *was_zero = false;
+    fgpu_lane* ln = lane();
+    if (ln) {
+        std::lock_guard<std::mutex> g(mu);
+        if (ln->zero_block && ln->zero_bytes >= bytes) {
+            const size_t cap = size_class(bytes);
+            for (auto it = ln->pool.lower_bound(cap); it != ln->pool.end() && it->first <= cap + (cap >> 2); ++it) {
+                if (it->second != ln->zero_block) continue;
+                *p = it->second;
+                const size_t c = it->first;
+                ln->pool.erase(it);
+                ln->zero_block = nullptr; ln->zero_bytes = 0;
+                live[*p] = c;
+                bytes_pooled -= c;
+                bytes_in_use += c;
+                *was_zero = true;
+                return FGPU_OK;
+            }
+        }
+    }
+    return dev_alloc(p, bytes);
+}
+
+void fgpu_ctx::dev_free_zeroed(void* p, size_t bytes) {
+    if (!p) return;
+    dev_free(p);
+    fgpu_lane* ln = lane();
+    if (!ln) return;
+    std::lock_guard<std::mutex> g(mu);
+    for (auto it = ln->pool.begin(); it != ln->pool.end(); ++it)
+        if (it->second == p) { ln->zero_block = p; ln->zero_bytes = bytes; return; }   // (not pooled: freed outright)
 }
 
 void fgpu_ctx::dev_free(void* p) {
@@ -235,6 +277,7 @@ void fgpu_ctx::trim() {
         for (fgpu_lane* l : lanes) {
             for (auto& kv : l->pool) old.push_back(kv.second);
             l->pool.clear();
+            l->zero_block = nullptr; l->zero_bytes = 0;
         }
         bytes_pooled = 0;
         ls = lanes;
