@@ -737,6 +737,7 @@ def main():
     if use_dist:
         lm = cm = 0.0
         nl = sc = rl = 0
+        ctx.set_option("dist_timing", 1)                     # event pairs per level: only in this untimed replay
         for i in range(min(args.steps, len(roots))):         # untimed replay: per-search event sums + scan counters
             run_one(roots[i])
             a_, b_, c_ = plan.dist_times()
@@ -744,6 +745,7 @@ def main():
             lm += a_; cm += b_; nl += c_
             sc += st["scanned_push"] + st["scanned_pull"]
             rl += st["reached"]
+        ctx.set_option("dist_timing", 0)
         k = min(args.steps, len(roots))
         nw_bytes = ((n + 4095) // 4096 * 4096) // 8
         alg = 4 * sc + 2 * nw_bytes * nl + 20 * rl           # column ids examined + both bitmaps per level + level/deg of owned discoveries

@@ -447,7 +447,30 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
     // (a chunk holds `qchunk` entries: few when the frontier's rows are long, so that a handful of
     // near-hub vertices does not land on one workgroup)
     const u32 nblk = CONCAT ? 1u : (qmode ? QSHARDS * ((qmax + qchunk - 1) / qchunk) : (a.n + PUSH_VPB - 1) / PUSH_VPB);
-    for (u32 item = blockIdx.x; item < nblk; item += nwg) {
+    // bitmap mode: a workgroup owns nblk / nwg items (36 at RMAT-26) and most of them are empty on a light level; testing
+    // them one after the other is a dependent load + barrier each (30 us of a 44 us level there).  A thread per item
+    // tests 256 of them in one round of loads, then only the live ones are expanded.
+    const bool bmode = !CONCAT && !qmode;
+    __shared__ u32 s_live[256];
+    __shared__ u32 s_nlive;
+    for (u32 r0 = blockIdx.x; r0 < nblk; r0 += (bmode ? nwg * 256u : nwg)) {
+      u32 nlive = 1;
+      if (bmode) {
+          if (t == 0) s_nlive = 0;
+          __syncthreads();
+          const u64 it = (u64)r0 + (u64)t * nwg;
+          if (it < nblk) {
+              const u32 w0 = (u32)it * (PUSH_VPB / 64);
+              u64 any = 0;
+#pragma unroll
+              for (u32 j = 0; j < PUSH_VPB / 64; ++j) any |= (w0 + j < a.nw) ? frontier[w0 + j] : 0ull;
+              if (any) s_live[atomicAdd(&s_nlive, 1u)] = (u32)it;
+          }
+          __syncthreads();
+          nlive = s_nlive;
+      }
+      for (u32 li = 0; li < nlive; ++li) {
+        const u32 item = bmode ? s_live[li] : r0;
         u32 vid[4], rb[4], re[4];
         if (CONCAT) {
             u32 qoff[QSHARDS + 1];
@@ -577,6 +600,8 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
         }
         if (t == 0) acc.scanned += total;
         __syncthreads();
+      }
+      if (bmode) __syncthreads();   // s_live is rewritten by the next round
     }
     // Hub rows (>= PUSH_HUB_DEG): this workgroup's share of the static chunk list is TESTED in parallel (a thread per
     // item: one round of loads instead of a dependent triple + bit probe per item in sequence — the list has tens of
@@ -2040,11 +2065,14 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
     int budget = p0->last_levels ? (p0->last_levels + 1 > 4 ? p0->last_levels + 1 : 4) : 6;
     u64 nlev = 0;
     std::vector<int> idx(nplans, 0);
+    // three timing events per rank and level keep the stream waiting ~20 us a level (measured: 6 + 10 us of gaps around
+    // the exchange at RMAT-26): they are recorded only when the "dist_timing" option asks for the time split
+    const bool timed = p0->ctx->opt.dist_timing != 0;
     auto one_level = [&]() -> fgpu_info {
         for (int k = 0; k < nplans; ++k) {
-            FGPU_TRY(dist_event(plans[k], 3 * nlev));
+            if (timed) FGPU_TRY(dist_event(plans[k], 3 * nlev));
             FGPU_TRY(fgpu_bfs_slab_level(plans[k], &idx[k]));
-            FGPU_TRY(dist_event(plans[k], 3 * nlev + 1));
+            if (timed) FGPU_TRY(dist_event(plans[k], 3 * nlev + 1));
         }
         if (!peer) {
             if (rccl && nplans > 1) FGPU_TRY(comm_group_begin());
@@ -2073,7 +2101,8 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
                 for (int s = 0; s < nplans; ++s)
                     if (s != d) FGPU_HIP(hipStreamWaitEvent(plans[d]->ctx->stream(), copied[s], 0));
         }
-        for (int k = 0; k < nplans; ++k) FGPU_TRY(dist_event(plans[k], 3 * nlev + 2));
+        if (timed)
+            for (int k = 0; k < nplans; ++k) FGPU_TRY(dist_event(plans[k], 3 * nlev + 2));
         ++nlev;
         return FGPU_OK;
     };
@@ -2095,7 +2124,7 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
         FGPU_HIP(hipStreamSynchronize(p->ctx->stream()));
         p->last_levels = (int)p0->h_ctrl->level;
         double lm = 0, cm = 0;
-        for (u64 l = 0; l < nlev; ++l) {
+        for (u64 l = 0; timed && l < nlev; ++l) {
             float a = 0, b = 0;
             if (hipEventElapsedTime(&a, p->dist_ev[3 * l], p->dist_ev[3 * l + 1]) == hipSuccess) lm += a;
             if (hipEventElapsedTime(&b, p->dist_ev[3 * l + 1], p->dist_ev[3 * l + 2]) == hipSuccess) cm += b;

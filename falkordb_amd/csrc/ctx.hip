@@ -577,6 +577,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.bfs_prof_split = value != 0;
     } else if (!strcmp(name, "bfs_hub_first")) {
         ctx->opt.bfs_hub_first = value != 0;
+    } else if (!strcmp(name, "dist_timing")) {
+        ctx->opt.dist_timing = value != 0;
     } else if (!strcmp(name, "dist_collective")) {
         FGPU_REQUIRE(value == 0 || value == 1, FGPU_INVALID, "dist_collective must be 0 (send/recv) or 1 (broadcasts)");
         ctx->opt.dist_collective = (int)value;

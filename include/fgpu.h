@@ -90,7 +90,9 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * 0 = entry-parallel with the base layer's keep bits cleared from the delta side, 1 = one wavefront per row, pattern
  * layers only, 2 = entry-parallel with every base entry of a touched row searching the deltas), "bfs_tiny" (consecutive tiny BFS levels in one single-workgroup launch: 0 off, 1 on,
  * 2 = when the plan's previous search took more than 12 levels), "dist_collective" (frontier exchange of
- * fgpu_bfs_dist_run: 0 = grouped ncclSend / ncclRecv, 1 = one ncclBroadcast per rank), "bfs_prof_split" (1 = a profiled plan launches
+ * fgpu_bfs_dist_run: 0 = grouped ncclSend / ncclRecv, 1 = one ncclBroadcast per rank), "dist_timing" (1 = fgpu_bfs_dist_run
+ * records HIP events around every level kernel and exchange for fgpu_bfs_dist_times; off by default, the events cost
+ * ~20 us of stream idle time per level), "bfs_prof_split" (1 = a profiled plan launches
  * the push / pull twins of the level kernel so rocprofv3 can tell them apart by name), "bfs_hub_first" (1 = BFS plans
  * read the pull direction from a copy of At whose rows are reordered by descending out-degree class). */
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
@@ -423,7 +425,8 @@ fgpu_info fgpu_bfs_plan_create_slab(fgpu_ctx* ctx, fgpu_bfs_plan** plan, const f
 fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t src, int64_t max_level,
                             int want_parent);
 /* Time split of the plan's last fgpu_bfs_dist_run: HIP-event sums over its level kernels and over its exchanges
- * (an exchange includes the wait for the slowest rank), and the number of level launches. */
+ * (an exchange includes the wait for the slowest rank) — zero unless the "dist_timing" option was on during the run —
+ * and the number of level launches. */
 fgpu_info fgpu_bfs_dist_times(fgpu_bfs_plan* plan, double* level_ms, double* collective_ms, uint64_t* launches);
 
 /* ---- measurement hooks (bench.py; not reference APIs) --------------------- */
