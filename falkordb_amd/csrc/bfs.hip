@@ -1572,6 +1572,11 @@ struct fgpu_bfs_plan {
                                              // the peer exchange of a single-process gang, where peers write level L + 1's bitmap
                                              // while a slower rank may still be reading level L's
     u64* dist_glob2 = nullptr;               // (library-owned second bitmap of that mode)
+    // in-place exchange (RCCL / one rank): three global bitmaps in rotation — level L reads ring[L % 3], ORs its owned
+    // words straight into ring[(L + 1) % 3] (which the exchange then completes with the peers' words) and zeroes its
+    // owned words of ring[(L + 2) % 3]: no send buffers, no copy of the rank's own words per level
+    u64* slab_ring[3] = {nullptr, nullptr, nullptr};
+    bool inplace = false;
     const u32* gdeg = nullptr;               // fused slab path: global out-degrees (caller-owned, nullable)
     u32 launch = 0;                          // fused slab path: level launches since begin
     int last_levels = 0;         // levels the previous search of this plan took (sizes the next blind batch)
@@ -1596,6 +1601,7 @@ struct fgpu_bfs_plan {
     u32* dist_deg = nullptr;
     bool dist_ready = false;
     std::vector<hipEvent_t> dist_ev;    // 3 per level: before the level kernel, after it, after the collective
+    hipEvent_t dist_copied = nullptr;   // peer exchange: "this rank has delivered its words of the level" (kept across searches)
     double dist_level_ms = 0, dist_coll_ms = 0;
     u64 dist_levels = 0;
 };
@@ -1656,8 +1662,11 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->dist_send[1]);
     c->dev_free(p->dist_glob);
     c->dev_free(p->dist_glob2);
+    c->dev_free(p->slab_ring[1]);
+    c->dev_free(p->slab_ring[2]);
     c->dev_free(p->dist_deg);
     for (hipEvent_t e : p->dist_ev) (void)hipEventDestroy(e);
+    if (p->dist_copied) (void)hipEventDestroy(p->dist_copied);
     if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
     if (p->h_done) (void)hipHostFree(p->h_done);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -1873,6 +1882,12 @@ static BfsArgs slab_args(fgpu_bfs_plan* p) {
     a.slab_nxt = p->slab_send[p->launch & 1];
     a.slab_zero = p->slab_send[(p->launch + 1) & 1];
     if (p->slab_glob[0]) a.nxt_global = p->slab_glob[p->launch & 1];
+    if (p->inplace) {
+        const u64 L = p->launch;
+        a.nxt_global = p->slab_ring[L % 3];
+        a.slab_nxt = p->slab_ring[(L + 1) % 3] + (p->lo >> 6);
+        a.slab_zero = p->slab_ring[(L + 2) % 3] + (p->lo >> 6);
+    }
     a.gdeg = p->gdeg;
     a.host_done = p->d_done;
     return a;
@@ -1890,8 +1905,9 @@ fgpu_info fgpu_bfs_slab_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level,
     p->mask_visited = p->visited;
     *(volatile u32*)p->h_done = 0;
     BfsArgs a = slab_args(p);
-    hipLaunchKernelGGL(bfs_slab_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), a, p->slab_send[0],
-                       p->slab_send[1], (u32)src, ml, p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha,
+    u64* z0 = p->inplace ? p->slab_ring[1] + (p->lo >> 6) : p->slab_send[0];
+    u64* z1 = p->inplace ? p->slab_ring[2] + (p->lo >> 6) : p->slab_send[1];
+    hipLaunchKernelGGL(bfs_slab_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), a, z0, z1, (u32)src, ml, p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha,
                        p->At ? p->At->nnz : 0ull);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
@@ -1960,6 +1976,14 @@ static fgpu_info dist_setup(fgpu_bfs_plan* const* P, int np) {
                 (void)hipGetLastError();
             }
     }
+    if (rccl || np == 1)
+        for (int k = 0; k < np; ++k) {
+            fgpu_bfs_plan* p = P[k];
+            p->slab_ring[0] = p->dist_glob;
+            for (int j = 1; j < 3; ++j)
+                if (!p->slab_ring[j]) FGPU_TRY(p->ctx->dev_alloc((void**)&p->slab_ring[j], ((size_t)p->nw + 1) * sizeof(u64)));
+            p->inplace = true;
+        }
     if (!rccl && np > 1)
         for (int k = 0; k < np; ++k) {
             fgpu_bfs_plan* p = P[k];
@@ -2053,15 +2077,15 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
     for (int k = 0; k < nplans; ++k) FGPU_TRY(fgpu_bfs_slab_begin(plans[k], src, max_level, want_parent));
     std::vector<hipEvent_t> copied(nplans, nullptr);   // peer mode only: "rank s has delivered its words of this level"
     const bool peer = !rccl && nplans > 1;
-    fgpu_info rc = FGPU_OK;
     if (peer)
-        for (int k = 0; k < nplans && rc == FGPU_OK; ++k) {
-            (void)plans[k]->ctx->lane();   // events of plan k live on plan k's device
-            if (hipEventCreateWithFlags(&copied[k], hipEventDisableTiming) != hipSuccess) {
-                set_error("fgpu_bfs_dist_run: event creation failed");
-                rc = FGPU_DEVICE;
+        for (int k = 0; k < nplans; ++k) {
+            if (!plans[k]->dist_copied) {
+                (void)plans[k]->ctx->lane();   // events of plan k live on plan k's device
+                FGPU_HIP(hipEventCreateWithFlags(&plans[k]->dist_copied, hipEventDisableTiming));
             }
+            copied[k] = plans[k]->dist_copied;
         }
+    fgpu_info rc = FGPU_OK;
     int budget = p0->last_levels ? (p0->last_levels + 1 > 4 ? p0->last_levels + 1 : 4) : 6;
     u64 nlev = 0;
     std::vector<int> idx(nplans, 0);
@@ -2076,9 +2100,13 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
         }
         if (!peer) {
             if (rccl && nplans > 1) FGPU_TRY(comm_group_begin());
-            for (int k = 0; k < nplans; ++k)
-                FGPU_TRY(comm_allgatherv_u64(plans[k]->ctx, plans[k]->dist_send[idx[k]], plans[k]->dist_glob, offs.data(),
-                                             cnts.data()));
+            for (int k = 0; k < nplans; ++k) {
+                fgpu_bfs_plan* p = plans[k];
+                // in place: the level just wrote its owned words where the gathered bitmap keeps them (launch was advanced)
+                u64* g = p->inplace ? p->slab_ring[p->launch % 3] : p->dist_glob;
+                const u64* snd = p->inplace ? g + offs[p->rank] : p->dist_send[idx[k]];
+                FGPU_TRY(comm_allgatherv_u64(p->ctx, snd, g, offs.data(), cnts.data()));
+            }
             if (rccl && nplans > 1) FGPU_TRY(comm_group_end());
         } else {
             // every rank's slab goes to every rank's bitmap: one scatter launch per SOURCE rank on its own stream (right
@@ -2106,30 +2134,58 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
         ++nlev;
         return FGPU_OK;
     };
+    // Termination: the level that empties the frontier raises every plan's pinned flag (fused_ctrl, slab branch; the
+    // decision is the same on every rank), so the host polls a host word instead of paying a D2H copy + stream sync
+    // per search (~80 us of idle stream between two searches at RMAT-26); the stream is queried now and then so that a
+    // search needing more levels than were enqueued — or a failed launch — is noticed.
+    auto wait_flag = [&](fgpu_bfs_plan* p, bool* done) -> fgpu_info {
+        volatile u32* flag = (volatile u32*)p->h_done;
+        (void)p->ctx->lane();
+        for (u32 spin = 0; (*flag & 0x80000000u) == 0; ++spin) {
+            if ((spin & 0x3FFu) == 0x3FFu) {
+                hipError_t q = hipStreamQuery(p->ctx->stream());
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) {
+                    set_error("fgpu_bfs_dist_run: stream failed: %s", hipGetErrorString(q));
+                    return FGPU_DEVICE;
+                }
+            }
+        }
+        *done = (*flag & 0x80000000u) != 0;
+        return FGPU_OK;
+    };
     while (rc == FGPU_OK) {
         for (int k = 0; k < budget && rc == FGPU_OK; ++k) rc = one_level();
         if (rc != FGPU_OK) break;
-        for (int k = 1; k < nplans; ++k)
-            if (hipStreamSynchronize(plans[k]->ctx->stream()) != hipSuccess) { set_error("fgpu_bfs_dist_run: stream failed"); rc = FGPU_DEVICE; }
-        if (rc == FGPU_OK) rc = fetch_ctrl(p0);
+        bool done = false;
+        rc = wait_flag(p0, &done);
+        if (rc != FGPU_OK || done) break;
+        rc = fetch_ctrl(p0);   // stream drained without the flag: not done yet, or done without a level having run (max_level 0)
         if (rc != FGPU_OK || p0->h_ctrl->done) break;
         budget = 2;
     }
-    for (int k = 0; k < nplans; ++k) {
-        if (copied[k]) (void)hipEventDestroy(copied[k]);
-    }
     if (rc != FGPU_OK) return rc;
+    const u32 fl0 = *(volatile u32*)p0->h_done;
+    const int levels_taken = (fl0 & 0x80000000u) ? (int)(fl0 & 0xFFFFFFu) : (int)p0->h_ctrl->level;
     for (int k = 0; k < nplans; ++k) {
         fgpu_bfs_plan* p = plans[k];
-        FGPU_HIP(hipStreamSynchronize(p->ctx->stream()));
-        p->last_levels = (int)p0->h_ctrl->level;
-        double lm = 0, cm = 0;
-        for (u64 l = 0; timed && l < nlev; ++l) {
-            float a = 0, b = 0;
-            if (hipEventElapsedTime(&a, p->dist_ev[3 * l], p->dist_ev[3 * l + 1]) == hipSuccess) lm += a;
-            if (hipEventElapsedTime(&b, p->dist_ev[3 * l + 1], p->dist_ev[3 * l + 2]) == hipSuccess) cm += b;
+        bool done = false;
+        if (k) {   // every rank of the gang finishes at the same level
+            FGPU_TRY(wait_flag(p, &done));
+            if (!done) FGPU_HIP(hipStreamSynchronize(p->ctx->stream()));
         }
-        (void)hipGetLastError();
+        p->last_levels = levels_taken;
+        double lm = 0, cm = 0;
+        if (timed) {
+            (void)p->ctx->lane();
+            FGPU_HIP(hipStreamSynchronize(p->ctx->stream()));
+            for (u64 l = 0; l < nlev; ++l) {
+                float a = 0, b = 0;
+                if (hipEventElapsedTime(&a, p->dist_ev[3 * l], p->dist_ev[3 * l + 1]) == hipSuccess) lm += a;
+                if (hipEventElapsedTime(&b, p->dist_ev[3 * l + 1], p->dist_ev[3 * l + 2]) == hipSuccess) cm += b;
+            }
+            (void)hipGetLastError();
+        }
         p->dist_level_ms = lm;
         p->dist_coll_ms = cm;
         p->dist_levels = nlev;
