@@ -82,6 +82,7 @@ struct BfsArgs {
     CsrView A, At;
     const u32* hubA;  u32 n_hubA;
     const u32* hubAt; u32 n_hubAt;
+    const uint2* head;   // fused pull levels: the first PULL_H in-neighbours of every row of A' (plan-owned, see pull_fused)
     const u32* hubP;  u32 n_hubP;   // A's finer list (PUSH_HUB_DEG / PUSH_HUB_CHUNK): fused push levels
     u32 n;        // global vertex count
     u32 lo, hi;   // owned destination range (hi <= n_pad)
@@ -642,7 +643,9 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
 }
 
 typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-constexpr int PULL_A = 4;  // in-neighbours probed per row before the cooperative phase
+constexpr int PULL_A = 4;  // in-neighbours probed per row before the cooperative phase (pull_body, the step kernel)
+constexpr int PULL_H = 2;  // fused levels: leading in-neighbours kept in the plan's head array (8 B per row)
+constexpr u32 HEAD_HUB = 0xFFFFFFFEu;   // head[v].x of a row the hub section owns (>= HUB_DEG in-edges)
 constexpr int PULL_R = 4;  // 64-row words per wavefront trip (memory-level parallelism: the level is
                            // latency-bound, so one wave keeps 4 x (rowptr, 4 colidx, 4 probes) in flight)
 
@@ -671,62 +674,79 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
             live |= (mword[r] != ~0ull);
         }
         if (!live) continue;
-        u32 rb[PULL_R], re[PULL_R];
+        // Leading entries first: head[v] holds the row's first two in-neighbours (hub-first order: the likely parents),
+        // ~0 where the row is shorter, HEAD_HUB for rows the hub section owns.  One coalesced 8 B load per row replaces
+        // the row pointer pair AND the 16 B gather into the column ids — which, taken for every unvisited row, dragged
+        // the whole array through (rows are adjacent: 64 B of every ~64): the heavy pull level streamed all of A'.
+        uint2 hd[PULL_R];
 #pragma unroll
         for (int r = 0; r < PULL_R; ++r) {
             const u32 v = ((G * PULL_R + r) << 6) + lane;
-            const u32 vc = v < a.n ? v : a.n;
             const bool want = (mword[r] != ~0ull);
-            rb[r] = want ? a.At.rowptr[vc] : 0u;
-            re[r] = want ? a.At.rowptr[(vc + 1 <= a.n) ? (vc + 1) : a.n] : 0u;
+            hd[r] = want ? a.head[v] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // head is padded to whole words
         }
         bool need[PULL_R], found[PULL_R];
         u32 par[PULL_R];
-        u32 c[PULL_R][PULL_A];
+        {
+            bool h0[PULL_R], h1[PULL_R];
 #pragma unroll
-        for (int r = 0; r < PULL_R; ++r) {
-            const u32 v = ((G * PULL_R + r) << 6) + lane;
-            const u32 deg = re[r] - rb[r];
-            need[r] = (v < a.n) && !((mword[r] >> lane) & 1ull) && deg > 0;
-            found[r] = false;
-            par[r] = 0;
-            // the level is bound by the CU's address rate (one divergent lane-address per clock), not by bytes:
-            // the row's first four in-neighbours come in ONE dword-aligned 16 B load instead of four
-            const bool tail = rb[r] + PULL_A > at_nnz;   // last rows of the array: 16 B would overrun it
-            const u32x4_a4 q4 = *(const u32x4_a4*)(col + ((need[r] && !tail) ? rb[r] : 0u));
+            for (int r = 0; r < PULL_R; ++r) {
+                const u32 v = ((G * PULL_R + r) << 6) + lane;
+                need[r] = (v < a.n) && !((mword[r] >> lane) & 1ull) && hd[r].x < HEAD_HUB;
+                const u32 x0 = hd[r].x, x1 = hd[r].y;
+                h0[r] = need[r] && ((f32[x0 >> 5] >> (x0 & 31)) & 1u);
+                h1[r] = need[r] && x1 != 0xFFFFFFFFu && ((f32[x1 >> 5] >> (x1 & 31)) & 1u);
+            }
 #pragma unroll
-            for (int j = 0; j < PULL_A; ++j) c[r][j] = (need[r] && !tail && (u32)j < deg) ? q4[j] : 0xFFFFFFFFu;
-            if (__ballot(need[r] && tail)) {
-#pragma unroll
-                for (int j = 0; j < PULL_A; ++j)
-                    if (need[r] && tail && (u32)j < deg) c[r][j] = col[rb[r] + j];
+            for (int r = 0; r < PULL_R; ++r) {
+                found[r] = h0[r] || h1[r];
+                par[r] = h0[r] ? hd[r].x : hd[r].y;
+                if (need[r]) acc.scanned += (hd[r].y != 0xFFFFFFFFu) ? 2u : 1u;
             }
         }
-        // ... and the frontier probes stop at the first hit: two rounds of two (hub-first order makes the first
-        // in-neighbour the likely parent), the second round only for rows still open
+        // rows still open that hold a second entry may hold more: only these read their row pointers
+        u32 rb[PULL_R], re[PULL_R];
+        bool open_any = false;
 #pragma unroll
-        for (int half = 0; half < PULL_A; half += 2) {
-            bool h[PULL_R][2];
+        for (int r = 0; r < PULL_R; ++r) {
+            const bool open = need[r] && !found[r] && hd[r].y != 0xFFFFFFFFu;
+            open_any |= open;
+            const u32 v = ((G * PULL_R + r) << 6) + lane;
+            rb[r] = open ? a.At.rowptr[v] : 0u;
+            re[r] = open ? a.At.rowptr[v + 1] : 0u;
+        }
+        if (__ballot(open_any) != 0ull) {
+            // phase A2: entries 2 .. 5 of the open rows in one dword-aligned 16 B load per lane
+            u32 c[PULL_R][4];
+#pragma unroll
+            for (int r = 0; r < PULL_R; ++r) {
+                const u32 deg = re[r] - rb[r];
+                const bool go = deg > (u32)PULL_H && deg < HUB_DEG;
+                const bool tail = rb[r] + PULL_H + 4u > at_nnz;   // last rows of the array: 16 B would overrun it
+                const u32x4_a4 q4 = *(const u32x4_a4*)(col + ((go && !tail) ? rb[r] + PULL_H : 0u));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[r][j] = (go && !tail && (u32)(PULL_H + j) < deg) ? q4[j] : 0xFFFFFFFFu;
+                if (__ballot(go && tail)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (go && tail && (u32)(PULL_H + j) < deg) c[r][j] = col[rb[r] + PULL_H + j];
+                }
+                if (go) acc.scanned += (deg - PULL_H < 4u) ? (deg - PULL_H) : 4u;
+            }
+            bool h[PULL_R][4];
 #pragma unroll
             for (int r = 0; r < PULL_R; ++r) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const u32 x = c[r][half + j];
-                    h[r][j] = (x != 0xFFFFFFFFu) && !found[r] && ((f32[x >> 5] >> (x & 31)) & 1u);
+                for (int j = 0; j < 4; ++j) {
+                    const u32 x = c[r][j];
+                    h[r][j] = (x != 0xFFFFFFFFu) && ((f32[x >> 5] >> (x & 31)) & 1u);
                 }
             }
 #pragma unroll
             for (int r = 0; r < PULL_R; ++r) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (h[r][j] && !found[r]) { found[r] = true; par[r] = c[r][half + j]; }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < PULL_R; ++r) {
-            if (need[r]) {
-                const u32 deg = re[r] - rb[r];
-                acc.scanned += deg < (u32)PULL_A ? deg : (u32)PULL_A;
+                for (int j = 0; j < 4; ++j)
+                    if (h[r][j] && !found[r]) { found[r] = true; par[r] = c[r][j]; }
             }
         }
 #pragma unroll
@@ -734,15 +754,15 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
             const u32 g = G * PULL_R + r;
             if (g >= nwords) continue;  // wave-uniform
             const u32 v = (g << 6) + lane;
-            const u32 deg = re[r] - rb[r];
+            const u32 deg = re[r] - rb[r];   // 0 unless the row went past its head entries
             // a word that holds a hub row (visited or not) is published with atomics: the hub section of a
             // workgroup that ran ahead may already have set that row's visited AND next-frontier bits, and a
             // plain store of this wave's word would wipe the hub out of the next frontier
-            const bool hub_here = __ballot(v < a.n && deg >= HUB_DEG) != 0ull;
+            const bool hub_here = __ballot(hd[r].x == HEAD_HUB) != 0ull;
             // phase B: rows still open are scanned by the whole wave — FOUR rows per trip, 64 coalesced
             // elements each (most open rows are shorter than that; four independent gathers and probes in
             // flight instead of one row's 256).  Slot state is wave-uniform and lives in SGPRs (v_readlane).
-            u64 pend = __ballot(need[r] && !found[r] && deg > (u32)PULL_A && deg < HUB_DEG);
+            u64 pend = __ballot(need[r] && !found[r] && deg > (u32)(PULL_H + 4) && deg < HUB_DEG);
             while (pend) {
                 int sl[4];
                 u32 sb[4], se[4], shc[4];
@@ -753,7 +773,7 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
                     if (pend) {
                         sl[k] = (int)__builtin_ctzll(pend);
                         pend &= pend - 1ull;
-                        sb[k] = (u32)__builtin_amdgcn_readlane((int)rb[r], sl[k]) + PULL_A;
+                        sb[k] = (u32)__builtin_amdgcn_readlane((int)rb[r], sl[k]) + (u32)(PULL_H + 4);
                         se[k] = (u32)__builtin_amdgcn_readlane((int)re[r], sl[k]);
                     }
                 }
@@ -1517,6 +1537,24 @@ __global__ void pull_seg_kernel(const u32* __restrict__ rowptr, u32 nrows, u64* 
     }
 }
 
+// head[v] = the first PULL_H column ids of row v of A' (in the order the pull levels read them), ~0 where the row is
+// shorter; rows of >= HUB_DEG entries carry HEAD_HUB (the hub section owns them); rows past n are empty.
+__global__ void pull_head_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ col, u32 n, u32 n_pad,
+                                 uint2* __restrict__ head) {
+    for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n_pad; v += gridDim.x * 256) {
+        uint2 h = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (v < n) {
+            const u32 rb = rowptr[v], re = rowptr[v + 1];
+            if (re - rb >= HUB_DEG) h.x = HEAD_HUB;
+            else {
+                if (re > rb) h.x = col[rb];
+                if (re - rb > 1) h.y = col[rb + 1];
+            }
+        }
+        head[v] = h;
+    }
+}
+
 static fgpu_info ensure_pull_order(fgpu_ctx* ctx, const fgpu_mat* At, const fgpu_mat* A) {
     std::lock_guard<std::mutex> idx_guard(At->idx_mu);
     if (At->pull_col || At->nnz == 0 || At->nnz >= 0xFFFFFFFFull) return FGPU_OK;
@@ -1577,6 +1615,8 @@ struct fgpu_bfs_plan {
     // owned words of ring[(L + 2) % 3]: no send buffers, no copy of the rank's own words per level
     u64* slab_ring[3] = {nullptr, nullptr, nullptr};
     bool inplace = false;
+    const u32* pull_colidx = nullptr;        // the column ids of A' the pull levels read (hub-first copy or the matrix's own), fixed at creation
+    uint2* pull_head = nullptr;              // leading PULL_H entries of every row of that array, nw * 64 rows (owned)
     const u32* gdeg = nullptr;               // fused slab path: global out-degrees (caller-owned, nullable)
     u32 launch = 0;                          // fused slab path: level launches since begin
     int last_levels = 0;         // levels the previous search of this plan took (sizes the next blind batch)
@@ -1611,9 +1651,10 @@ static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
     a.A = view_of(p->A);
     if (p->At) {
         a.At = view_of(p->At);
-        if (p->At->pull_col && p->ctx->opt.bfs_hub_first) a.At.colidx = p->At->pull_col;
+        if (p->pull_colidx) a.At.colidx = p->pull_colidx;
     }
     else { a.At.rowptr = nullptr; a.At.colidx = nullptr; a.At.hrows = nullptr; a.At.nvec = 0; a.At.nrows = 0; }
+    a.head = p->pull_head;
     a.hubA = p->A->hub_chunks; a.n_hubA = p->A->n_hub_chunks;
     a.hubP = p->A->push_chunks; a.n_hubP = p->A->n_push_chunks;
     a.hubAt = p->At ? p->At->hub_chunks : nullptr; a.n_hubAt = p->At ? p->At->n_hub_chunks : 0;
@@ -1662,6 +1703,7 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->dist_send[1]);
     c->dev_free(p->dist_glob);
     c->dev_free(p->dist_glob2);
+    c->dev_free(p->pull_head);
     c->dev_free(p->slab_ring[1]);
     c->dev_free(p->slab_ring[2]);
     c->dev_free(p->dist_deg);
@@ -1749,6 +1791,13 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         if ((i = ctx->dev_alloc((void**)&p->ctrl, sizeof(BfsCtrl))) != FGPU_OK) break;
         if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->bm_block, 4 * wb)) != FGPU_OK) break;
         if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->queue_block, 2 * (size_t)QCAP * sizeof(u32))) != FGPU_OK) break;
+        if (At) {
+            p->pull_colidx = (At->pull_col && ctx->opt.bfs_hub_first) ? At->pull_col : At->colidx;
+            if ((i = ctx->dev_alloc((void**)&p->pull_head, (size_t)p->nw * 64 * sizeof(uint2))) != FGPU_OK) break;
+            hipLaunchKernelGGL(pull_head_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream(), (const u32*)At->rowptr,
+                               p->pull_colidx, p->n, p->nw * 64, p->pull_head);
+            if (hipGetLastError() != hipSuccess) { set_error("bfs plan: head build failed"); i = FGPU_DEVICE; break; }
+        }
     } while (0);
     if (i == FGPU_OK) {
         hipError_t e = hipHostMalloc((void**)&p->h_ctrl, sizeof(BfsCtrl), hipHostMallocDefault);
@@ -2515,6 +2564,7 @@ static void vxm_args(BfsArgs& a, const fgpu_mat* A, const fgpu_mat* At, u32 n, u
     a.hubA = A->hub_chunks; a.n_hubA = A->n_hub_chunks;
     a.hubP = A->push_chunks; a.n_hubP = A->n_push_chunks;
     a.hubAt = At ? At->hub_chunks : nullptr; a.n_hubAt = At ? At->n_hub_chunks : 0;
+    a.head = nullptr;
     a.n = n; a.lo = 0; a.hi = nw * 64;
     a.nxt_local = out_words; a.nxt_global = out_words;
     a.nw = nw;
