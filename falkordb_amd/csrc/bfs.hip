@@ -27,6 +27,8 @@
 
 namespace fgpu {
 
+constexpr int PULL_H = 1;  // fused pull levels: leading in-neighbours kept in the plan's head array (4 B each per row)
+typedef u32 headv __attribute__((ext_vector_type(PULL_H)));
 constexpr int STAT_SLOTS = 64;
 constexpr unsigned QSHARDS = 8;          // the frontier queue is appended in 8 independent segments
 constexpr unsigned QCAP = 1u << 16;      // capacity of a frontier queue (vertex ids), all segments
@@ -82,7 +84,7 @@ struct BfsArgs {
     CsrView A, At;
     const u32* hubA;  u32 n_hubA;
     const u32* hubAt; u32 n_hubAt;
-    const uint2* head;   // fused pull levels: the first PULL_H in-neighbours of every row of A' (plan-owned, see pull_fused)
+    const headv* head;   // fused pull levels: the first PULL_H in-neighbours of every row of A' (plan-owned, see pull_fused)
     const u32* hubP;  u32 n_hubP;   // A's finer list (PUSH_HUB_DEG / PUSH_HUB_CHUNK): fused push levels
     u32 n;        // global vertex count
     u32 lo, hi;   // owned destination range (hi <= n_pad)
@@ -644,7 +646,6 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
 
 typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int PULL_A = 4;  // in-neighbours probed per row before the cooperative phase (pull_body, the step kernel)
-constexpr int PULL_H = 2;  // fused levels: leading in-neighbours kept in the plan's head array (8 B per row)
 constexpr u32 HEAD_HUB = 0xFFFFFFFEu;   // head[v].x of a row the hub section owns (>= HUB_DEG in-edges)
 constexpr int PULL_R = 4;  // 64-row words per wavefront trip (memory-level parallelism: the level is
                            // latency-bound, so one wave keeps 4 x (rowptr, 4 colidx, 4 probes) in flight)
@@ -674,42 +675,56 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
             live |= (mword[r] != ~0ull);
         }
         if (!live) continue;
-        // Leading entries first: head[v] holds the row's first two in-neighbours (hub-first order: the likely parents),
+        // Leading entries first: head[v] holds the row's first PULL_H in-neighbours (hub-first order: the likely parents),
         // ~0 where the row is shorter, HEAD_HUB for rows the hub section owns.  One coalesced 8 B load per row replaces
         // the row pointer pair AND the 16 B gather into the column ids — which, taken for every unvisited row, dragged
         // the whole array through (rows are adjacent: 64 B of every ~64): the heavy pull level streamed all of A'.
-        uint2 hd[PULL_R];
+        headv hd[PULL_R];
 #pragma unroll
         for (int r = 0; r < PULL_R; ++r) {
             const u32 v = ((G * PULL_R + r) << 6) + lane;
             const bool want = (mword[r] != ~0ull);
-            hd[r] = want ? a.head[v] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // head is padded to whole words
+            if (want) hd[r] = a.head[v];   // head is padded to whole words
+            else {
+#pragma unroll
+                for (int j = 0; j < PULL_H; ++j) hd[r][j] = 0xFFFFFFFFu;
+            }
         }
         bool need[PULL_R], found[PULL_R];
         u32 par[PULL_R];
         {
-            bool h0[PULL_R], h1[PULL_R];
+            bool h[PULL_R][PULL_H];
 #pragma unroll
             for (int r = 0; r < PULL_R; ++r) {
                 const u32 v = ((G * PULL_R + r) << 6) + lane;
-                need[r] = (v < a.n) && !((mword[r] >> lane) & 1ull) && hd[r].x < HEAD_HUB;
-                const u32 x0 = hd[r].x, x1 = hd[r].y;
-                h0[r] = need[r] && ((f32[x0 >> 5] >> (x0 & 31)) & 1u);
-                h1[r] = need[r] && x1 != 0xFFFFFFFFu && ((f32[x1 >> 5] >> (x1 & 31)) & 1u);
+                need[r] = (v < a.n) && !((mword[r] >> lane) & 1ull) && hd[r][0] < HEAD_HUB;
+#pragma unroll
+                for (int j = 0; j < PULL_H; ++j) {
+                    const u32 x = hd[r][j];
+                    h[r][j] = need[r] && x != 0xFFFFFFFFu && ((f32[x >> 5] >> (x & 31)) & 1u);
+                }
             }
 #pragma unroll
             for (int r = 0; r < PULL_R; ++r) {
-                found[r] = h0[r] || h1[r];
-                par[r] = h0[r] ? hd[r].x : hd[r].y;
-                if (need[r]) acc.scanned += (hd[r].y != 0xFFFFFFFFu) ? 2u : 1u;
+                found[r] = false;
+                par[r] = 0;
+#pragma unroll
+                for (int j = PULL_H - 1; j >= 0; --j)
+                    if (h[r][j]) { found[r] = true; par[r] = hd[r][j]; }
+                if (need[r]) {
+                    u32 cnt = 0;
+#pragma unroll
+                    for (int j = 0; j < PULL_H; ++j) cnt += (hd[r][j] != 0xFFFFFFFFu) ? 1u : 0u;
+                    acc.scanned += cnt;
+                }
             }
         }
-        // rows still open that hold a second entry may hold more: only these read their row pointers
+        // rows still open whose head is full may hold more: only these read their row pointers
         u32 rb[PULL_R], re[PULL_R];
         bool open_any = false;
 #pragma unroll
         for (int r = 0; r < PULL_R; ++r) {
-            const bool open = need[r] && !found[r] && hd[r].y != 0xFFFFFFFFu;
+            const bool open = need[r] && !found[r] && hd[r][PULL_H - 1] != 0xFFFFFFFFu;
             open_any |= open;
             const u32 v = ((G * PULL_R + r) << 6) + lane;
             rb[r] = open ? a.At.rowptr[v] : 0u;
@@ -758,7 +773,7 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
             // a word that holds a hub row (visited or not) is published with atomics: the hub section of a
             // workgroup that ran ahead may already have set that row's visited AND next-frontier bits, and a
             // plain store of this wave's word would wipe the hub out of the next frontier
-            const bool hub_here = __ballot(hd[r].x == HEAD_HUB) != 0ull;
+            const bool hub_here = __ballot(hd[r][0] == HEAD_HUB) != 0ull;
             // phase B: rows still open are scanned by the whole wave — FOUR rows per trip, 64 coalesced
             // elements each (most open rows are shorter than that; four independent gathers and probes in
             // flight instead of one row's 256).  Slot state is wave-uniform and lives in SGPRs (v_readlane).
@@ -1540,15 +1555,18 @@ __global__ void pull_seg_kernel(const u32* __restrict__ rowptr, u32 nrows, u64* 
 // head[v] = the first PULL_H column ids of row v of A' (in the order the pull levels read them), ~0 where the row is
 // shorter; rows of >= HUB_DEG entries carry HEAD_HUB (the hub section owns them); rows past n are empty.
 __global__ void pull_head_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ col, u32 n, u32 n_pad,
-                                 uint2* __restrict__ head) {
+                                 headv* __restrict__ head) {
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n_pad; v += gridDim.x * 256) {
-        uint2 h = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        headv h;
+#pragma unroll
+        for (int j = 0; j < PULL_H; ++j) h[j] = 0xFFFFFFFFu;
         if (v < n) {
             const u32 rb = rowptr[v], re = rowptr[v + 1];
-            if (re - rb >= HUB_DEG) h.x = HEAD_HUB;
+            if (re - rb >= HUB_DEG) h[0] = HEAD_HUB;
             else {
-                if (re > rb) h.x = col[rb];
-                if (re - rb > 1) h.y = col[rb + 1];
+#pragma unroll
+                for (int j = 0; j < PULL_H; ++j)
+                    if (rb + (u32)j < re) h[j] = col[rb + j];
             }
         }
         head[v] = h;
@@ -1616,7 +1634,7 @@ struct fgpu_bfs_plan {
     u64* slab_ring[3] = {nullptr, nullptr, nullptr};
     bool inplace = false;
     const u32* pull_colidx = nullptr;        // the column ids of A' the pull levels read (hub-first copy or the matrix's own), fixed at creation
-    uint2* pull_head = nullptr;              // leading PULL_H entries of every row of that array, nw * 64 rows (owned)
+    headv* pull_head = nullptr;              // leading PULL_H entries of every row of that array, nw * 64 rows (owned)
     const u32* gdeg = nullptr;               // fused slab path: global out-degrees (caller-owned, nullable)
     u32 launch = 0;                          // fused slab path: level launches since begin
     int last_levels = 0;         // levels the previous search of this plan took (sizes the next blind batch)
@@ -1793,7 +1811,7 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->queue_block, 2 * (size_t)QCAP * sizeof(u32))) != FGPU_OK) break;
         if (At) {
             p->pull_colidx = (At->pull_col && ctx->opt.bfs_hub_first) ? At->pull_col : At->colidx;
-            if ((i = ctx->dev_alloc((void**)&p->pull_head, (size_t)p->nw * 64 * sizeof(uint2))) != FGPU_OK) break;
+            if ((i = ctx->dev_alloc((void**)&p->pull_head, (size_t)p->nw * 64 * sizeof(headv))) != FGPU_OK) break;
             hipLaunchKernelGGL(pull_head_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream(), (const u32*)At->rowptr,
                                p->pull_colidx, p->n, p->nw * 64, p->pull_head);
             if (hipGetLastError() != hipSuccess) { set_error("bfs plan: head build failed"); i = FGPU_DEVICE; break; }
