@@ -36,8 +36,21 @@ constexpr unsigned QSEG = QCAP / QSHARDS;
 constexpr unsigned long long QGATE = 1ull << 17;  // a level appends only when it can discover at most this many
 
 struct StatSlot { u64 count, mf, indeg, scan; u64 pad[12]; };
+constexpr unsigned HUBCAP = 1024;     // hub rows of a frontier the fused push level can take from a list (else: static chunk walk)
+constexpr unsigned WG_HUBCAP = 1024;  // ... and that one workgroup can report per level
 constexpr unsigned TICK_PAD = 32;   // u32 words between ticket counters (128 B)
 
+// Phase stamps of the fused level kernel (build with -DFGPU_BFS_STAMPS; tools/experiments/bfs_stamps.py reads them): per
+// workgroup, wall_clock64 at entry / after the push items / after the hub section / after the level work / after the
+// ticket / at exit, and the hardware placement (HW_ID, XCC_ID).  Not part of the product build.
+#ifdef FGPU_BFS_STAMPS
+__device__ unsigned long long* g_bfs_dbg = nullptr;
+#define DBG_STAMP(k) do { if (g_bfs_dbg && threadIdx.x == 0) g_bfs_dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define FUSED_BOUNDS __launch_bounds__(256, 6)   // the stamps must not cost the kernel a resident workgroup
+#else
+#define DBG_STAMP(k) do { } while (0)
+#define FUSED_BOUNDS __launch_bounds__(256)
+#endif
 struct BfsCtrl {
     i32 level;       // level of the frontier in `cur` (source = 0)
     i32 done;
@@ -76,7 +89,8 @@ struct BfsCtrl {
                        // level runs on a few dozen, the rest return at once and skip the end-of-level ticket
     u32 tick_top;
     u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
-    u32 tick_pad[31];
+    u32 hubn[2];       // hub rows listed in hubrows[parity] for the current / next frontier (> HUBCAP: list incomplete)
+    u32 tick_pad[29];
     u32 tick[64 * TICK_PAD];
 };
 
@@ -86,6 +100,7 @@ struct BfsArgs {
     const u32* hubAt; u32 n_hubAt;
     const headv* head;   // fused pull levels: the first PULL_H in-neighbours of every row of A' (plan-owned, see pull_fused)
     const u32* hubP;  u32 n_hubP;   // A's finer list (PUSH_HUB_DEG / PUSH_HUB_CHUNK): fused push levels
+    u32* hubrows;     // fused single-rank path: 2 x HUBCAP vertex ids, the hub rows discovered into the current / next frontier
     u32 n;        // global vertex count
     u32 lo, hi;   // owned destination range (hi <= n_pad)
     u64* cur;         // global frontier bitmap (n_pad bits)
@@ -381,6 +396,8 @@ struct QueueCtx {
     u32* q;     // this workgroup's segment of the next queue
     u32* qlen;  // its length counter
     u32* hubs;
+    u32* s_hl;  // LDS: hub rows this workgroup discovered (nullable: not collected)
+    u32* s_hn;  // LDS: their count
     bool open;  // level-uniform
 };
 
@@ -409,6 +426,12 @@ __device__ __forceinline__ void note_discovery(const BfsArgs& a, QueueCtx& qc, u
     // thousands of same-address atomics or write-through stores (every discovered row >= 1024) serialise at the
     // memory side (a heavy level went from 80 to 120 us with a per-discovery atomic, to 350 us with a store)
     acc.hub |= (rowdeg >= PUSH_HUB_DEG) ? 1u : 0u;
+    // ... and the row itself goes on the workgroup's list: the next push level expands the listed rows' chunks
+    // round-robin over the workgroups instead of walking the static chunk list (see push_fused)
+    if (rowdeg >= PUSH_HUB_DEG && qc.s_hn) {
+        const u32 i = atomicAdd(qc.s_hn, 1u);
+        if (i < WG_HUBCAP) qc.s_hl[i] = u;
+    }
 }
 
 template <bool PARENT>
@@ -436,7 +459,8 @@ template <bool PARENT, bool CONCAT = false>
 __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, const u32* __restrict__ qcur,
                            const u32* __restrict__ qcur_len, u32 qmax, u32 qchunk, bool hubs_present,
                            u64* __restrict__ visited,
-                           u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc, u32 nwg) {
+                           u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc, u32 nwg,
+                           const u32* __restrict__ hublist = nullptr, u32 hubn = 0) {
     __shared__ u32 s_off[PUSH_VPB];
     __shared__ u32 s_start[PUSH_VPB];
     __shared__ u32 s_vid[PUSH_VPB];
@@ -610,7 +634,87 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
     // item: one round of loads instead of a dependent triple + bit probe per item in sequence — the list has tens of
     // thousands of items at RMAT-22 and a level that holds a single hub walks all of it), then only the chunks whose
     // row is in the frontier are expanded, one workgroup trip each.
-    if (hubs_present && a.n_hubP) {
+    DBG_STAMP(1);
+#ifdef FGPU_BFS_STAMPS
+    if (g_bfs_dbg && threadIdx.x == 0)
+        g_bfs_dbg[blockIdx.x * 8 + 6] = (hubs_present ? 1ull : 0ull) | ((unsigned long long)hubn << 8) | ((unsigned long long)(hublist != nullptr) << 4);
+#endif
+    // When the frontier's hub rows are LISTED (the levels that discovered them reported them, at most HUBCAP), their
+    // chunks are numbered through a prefix over the list and dealt round-robin: every workgroup runs ceil(T / nwg)
+    // trips.  The static walk below gives a workgroup the active chunks that happen to sit at its positions of the
+    // list — 930 active chunks over 1536 workgroups left a few of them four or five trips (10-15 us each) while the
+    // mean was 0.6: the heavy push level of an R-MAT search took 76-93 us for 0.95 M edges.
+    if (hubs_present && hublist && hubn && hubn <= HUBCAP) {
+        // s_off / s_start / s_vid (PUSH_VPB = HUBCAP entries each) are free again here: row, first edge, chunk prefix
+        __syncthreads();
+        u32 nch[4], tsum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 i = 4 * t + j;
+            u32 row = 0, rb = 0, re = 0;
+            if (i < hubn) {
+                row = hublist[i];
+                rb = a.A.rowptr[row];
+                re = a.A.rowptr[row + 1];
+            }
+            s_vid[i] = row;
+            s_start[i] = rb;
+            nch[j] = (re - rb + PUSH_HUB_CHUNK - 1) / PUSH_HUB_CHUNK;
+            tsum += nch[j];
+        }
+        u32 total, ex;
+        {
+            const u32 lane = lane_id();
+            u32 inc = tsum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                u32 y = __shfl_up(inc, d, 64);
+                if (lane >= (u32)d) inc += y;
+            }
+            if (lane == 63) s_wave[t >> 6] = inc;
+            __syncthreads();
+            u32 wbase = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32 x = s_wave[i];
+                if ((u32)i < (t >> 6)) wbase += x;
+                tot += x;
+            }
+            total = tot;
+            ex = wbase + inc - tsum;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s_off[4 * t + j] = ex;
+            ex += nch[j];
+        }
+        __syncthreads();
+        const u32 first = (blockIdx.x + nwg - nblk % nwg) % nwg;   // items follow the regular ones
+        for (u32 k = first; k < total; k += nwg) {   // block-uniform
+            u32 lo = 0, hi = hubn;
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (s_off[mid] <= k) lo = mid; else hi = mid;
+            }
+            const u32 row = s_vid[lo];
+            const u32 b = s_start[lo] + (k - s_off[lo]) * PUSH_HUB_CHUNK;
+            const u32 rend = a.A.rowptr[row + 1];
+            const u32 e = b + PUSH_HUB_CHUNK < rend ? b + PUSH_HUB_CHUNK : rend;
+            u32 u[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const u32 i = b + t + 256 * kk;
+                u[kk] = (i < e) ? a.A.colidx[i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {   // whole waves reach queue_append
+                const bool won = (u[kk] != 0xFFFFFFFFu) &&
+                                 fused_visit<PARENT>(a, vis32, nxt32, newlevel, u[kk], row, qc, acc);
+                queue_append(qc, won, u[kk]);
+            }
+            if (t == 0) acc.scanned += e - b;
+        }
+    } else if (hubs_present && a.n_hubP) {
         __shared__ u32 s_act[256];
         __shared__ u32 s_nact;
         const u32 first = (blockIdx.x + nwg - nblk % nwg) % nwg;   // items follow the regular ones
@@ -642,10 +746,10 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
             __syncthreads();
         }
     }
+    DBG_STAMP(2);
 }
 
 typedef u32 u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-constexpr int PULL_A = 4;  // in-neighbours probed per row before the cooperative phase (pull_body, the step kernel)
 constexpr u32 HEAD_HUB = 0xFFFFFFFEu;   // head[v].x of a row the hub section owns (>= HUB_DEG in-edges)
 constexpr int PULL_R = 4;  // 64-row words per wavefront trip (memory-level parallelism: the level is
                            // latency-bound, so one wave keeps 4 x (rowptr, 4 colidx, 4 probes) in flight)
@@ -906,65 +1010,51 @@ __device__ __forceinline__ u32 done_word(const BfsCtrl* c) {
     return 0x80000000u | (tl << 24) | lv;
 }
 
+__device__ __forceinline__ u32 done_word_of(u32 heavy_begin, u32 heavy_end, i32 level) {
+    const u32 hv = heavy_begin ? heavy_end - heavy_begin + 1u : 0u;
+    const u32 tl = hv < 127u ? hv : 127u;
+    const u32 lv = (u32)level < 0xFFFFFFu ? (u32)level : 0xFFFFFFu;
+    return 0x80000000u | (tl << 24) | lv;
+}
+
 // End-of-level control, run by the first wavefront of the LAST workgroup to finish (ticket below):
 // sums the statistic slots, advances level / rotation / queue, applies the push<->pull rule and
 // raises `done`.  Same arithmetic as bfs_ctrl_kernel (the multi-rank path keeps that kernel).
+// Every field it needs is loaded BEFORE its first store: written as read-modify-write statements on `c` the function was a
+// chain of dependent load -> store -> load round trips (the stores may alias the loads as far as the compiler knows) and
+// took 5.4 us of every level, after the last workgroup's ticket (tools/experiments/bfs_stamps.py); one round of loads,
+// register arithmetic and one round of stores is ~1.5 us.
 __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
     const u32 t = threadIdx.x;  // 0..63
+    // ---- loads (header snapshot: uniform; slots / queue lengths: per lane) ------------------------------------------
+    const u32 rot = c->rot;
+    const i32 dir0 = c->direction, level0 = c->level, max_level = c->max_level;
+    const u32 tiny0 = c->tiny, hb0 = c->heavy_begin, he0 = c->heavy_end;
+    const u64 reached0 = c->reached, et0 = c->edges_traversed;
+    const u64 sp0 = c->scanned_push, spl0 = c->scanned_pull;
+    const u32 pl0 = c->push_levels, pll0 = c->pull_levels;
+    const u32 q_open0 = c->q_open, force_dir = c->force_dir, has_at = c->has_at;
+    const u64 n_total = c->n_total, nnz_at = c->nnz_at;
+    const float alpha = c->alpha;
     u64 v0 = __hip_atomic_load(&c->slot[t].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v1 = __hip_atomic_load(&c->slot[t].mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v3 = __hip_atomic_load(&c->slot[t].scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v2 = slab ? __hip_atomic_load(&c->slot[t].indeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    u32 ql = 0;   // lanes 0..7: lengths of the segments appended this level
+    if (!slab && t < QSHARDS)
+        ql = __hip_atomic_load(&c->qlen[(rot + 1) & 1][t * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- per-lane stores ---------------------------------------------------------------------------------------------
     if (v0) c->slot[t].count = 0;
     if (v1) c->slot[t].mf = 0;
     if (v3) c->slot[t].scan = 0;
     if (v2) c->slot[t].indeg = 0;
+    if (!slab && t < QSHARDS) c->qlen[rot & 1][t * 16] = 0;  // the old current queue is the next level's append target
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         v0 += __shfl_xor(v0, d, 64);
         v1 += __shfl_xor(v1, d, 64);
         v3 += __shfl_xor(v3, d, 64);
         v2 += __shfl_xor(v2, d, 64);
-    }
-    if (slab) {
-        // Slab plans (one rank of a multi-GPU search): every counter here is LOCAL — the vertices this rank
-        // discovered (v0), their global out-degrees (v1) — except v2 = |frontier just consumed|, popcounted
-        // from the gathered bitmap and therefore identical on every rank.  Termination uses v2 only, so all
-        // ranks stop at the same launch; the direction of the next level is this rank's own Beamer rule on its
-        // own share (a rank's push work ~ sum of the global degrees of ITS discoveries when ids are scrambled,
-        // its pull work ~ its unvisited share of A' rows).  Either direction yields the same owned bits.
-        if (t != 0) return;
-        if (c->direction == 1) { c->scanned_push += v3; c->push_levels += 1; }
-        else { c->scanned_pull += v3; c->pull_levels += 1; }
-        c->level += 1;
-        c->n_frontier = v2;
-        c->m_frontier = v1;
-        c->reached += v0;
-        c->edges_traversed += v1;
-        c->rot += 1;
-        const bool done = (v2 == 0) || (c->max_level >= 0 && c->level >= c->max_level);
-        c->done = done ? 1 : 0;
-        if (done && host_done)
-            __hip_atomic_store(host_done, done_word(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        int nd = 1;
-        if (c->force_dir == 1 || !c->has_at) nd = 1;
-        else if (c->force_dir == 2) nd = 2;
-        else {
-            const double un = (double)(c->n_total > c->reached ? c->n_total - c->reached : 0);
-            const u64 m_u = (u64)((double)c->nnz_at * un / (double)(c->n_total ? c->n_total : 1));
-            nd = ((double)v1 * (double)c->alpha > (double)m_u) ? 2 : 1;
-        }
-        c->direction = nd;
-        c->use_queue = 0;
-        c->q_open = 0;
-        return;
-    }
-    const u32 rot = c->rot;
-    // lanes 0..7: lengths of the segments appended this level
-    u32 ql = 0;
-    if (t < QSHARDS) {
-        ql = __hip_atomic_load(&c->qlen[(rot + 1) & 1][t * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c->qlen[rot & 1][t * 16] = 0;  // the old current queue is the next level's append target
     }
     u32 qn = ql, qmx = ql;
 #pragma unroll
@@ -974,54 +1064,89 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
         qmx = o > qmx ? o : qmx;
     }
     if (t != 0) return;
-    if (c->direction == 1) { c->scanned_push += v3; c->push_levels += 1; }
-    else { c->scanned_pull += v3; c->pull_levels += 1; }
-    c->level += 1;
-    if (!c->tiny) {   // c->tiny still describes the level that just ran
-        if (!c->heavy_begin) c->heavy_begin = (u32)c->level;
-        c->heavy_end = (u32)c->level;
-    }
-    c->n_frontier = v0;
+    // ---- lane 0: register arithmetic, then stores only -----------------------------------------------------------------
+    if (dir0 == 1) { c->scanned_push = sp0 + v3; c->push_levels = pl0 + 1; }
+    else { c->scanned_pull = spl0 + v3; c->pull_levels = pll0 + 1; }
+    const i32 level = level0 + 1;
+    c->level = level;
     c->m_frontier = v1;
-    c->reached += v0;
-    c->edges_traversed += v1;
+    c->edges_traversed = et0 + v1;
     c->rot = rot + 1;
+    if (slab) {
+        // Slab plans (one rank of a multi-GPU search): every counter here is LOCAL — the vertices this rank
+        // discovered (v0), their global out-degrees (v1) — except v2 = |frontier just consumed|, popcounted
+        // from the gathered bitmap and therefore identical on every rank.  Termination uses v2 only, so all
+        // ranks stop at the same launch; the direction of the next level is this rank's own Beamer rule on its
+        // own share (a rank's push work ~ sum of the global degrees of ITS discoveries when ids are scrambled,
+        // its pull work ~ its unvisited share of A' rows).  Either direction yields the same owned bits.
+        const u64 reached = reached0 + v0;
+        c->n_frontier = v2;
+        c->reached = reached;
+        const bool done = (v2 == 0) || (max_level >= 0 && level >= max_level);
+        c->done = done ? 1 : 0;
+        if (done && host_done)
+            __hip_atomic_store(host_done, done_word_of(hb0, he0, level), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        int nd = 1;
+        if (force_dir == 1 || !has_at) nd = 1;
+        else if (force_dir == 2) nd = 2;
+        else {
+            const double un = (double)(n_total > reached ? n_total - reached : 0);
+            const u64 m_u = (u64)((double)nnz_at * un / (double)(n_total ? n_total : 1));
+            nd = ((double)v1 * (double)alpha > (double)m_u) ? 2 : 1;
+        }
+        c->direction = nd;
+        c->use_queue = 0;
+        c->q_open = 0;
+        return;
+    }
+    u32 hb = hb0, he = he0;
+    if (!tiny0) {   // tiny0 still describes the level that just ran
+        if (!hb) hb = (u32)level;
+        he = (u32)level;
+        c->heavy_begin = hb;
+        c->heavy_end = he;
+    }
+    const u64 reached = reached0 + v0;
+    c->n_frontier = v0;
+    c->reached = reached;
     // queue[(rot+1)&1] becomes the current one; it lists the whole frontier iff this level appended
     // and no segment overflowed
-    c->use_queue = (c->q_open && v0 == (u64)qn && qmx <= QSEG) ? 1u : 0u;
+    const u32 use_queue = (q_open0 && v0 == (u64)qn && qmx <= QSEG) ? 1u : 0u;
+    c->use_queue = use_queue;
     c->qmax = qmx;
+    u32 qchunk = PUSH_VPB;
     {   // aim at ~8K edges per workgroup
         const u64 avg = v0 ? (v1 / v0) : 1;
-        u32 ch = PUSH_VPB;
-        while (ch > 4 && (u64)ch * (avg ? avg : 1) > 8192ull) ch >>= 1;
-        c->qchunk = ch;
+        while (qchunk > 4 && (u64)qchunk * (avg ? avg : 1) > 8192ull) qchunk >>= 1;
+        c->qchunk = qchunk;
     }
     c->hubs[rot & 1] = 0;
-    const bool done = (v0 == 0) || (c->max_level >= 0 && c->level >= c->max_level);
+    c->hubn[rot & 1] = 0;
+    const bool done = (v0 == 0) || (max_level >= 0 && level >= max_level);
     c->done = done ? 1 : 0;
     if (done && host_done)  // the host polls this word instead of paying a D2H copy + stream sync
-        __hip_atomic_store(host_done, done_word(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_done, done_word_of(hb, he, level), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int nd = 1;
-    if (c->force_dir == 1 || !c->has_at) nd = 1;
-    else if (c->force_dir == 2) nd = 2;
+    if (force_dir == 1 || !has_at) nd = 1;
+    else if (force_dir == 2) nd = 2;
     else {
-        const double un = (double)(c->n_total > c->reached ? c->n_total - c->reached : 0);
-        const u64 m_u = (u64)((double)c->nnz_at * un / (double)c->n_total);
-        nd = ((double)v1 * (double)c->alpha > (double)m_u) ? 2 : 1;
+        const double un = (double)(n_total > reached ? n_total - reached : 0);
+        const u64 m_u = (u64)((double)nnz_at * un / (double)n_total);
+        nd = ((double)v1 * (double)alpha > (double)m_u) ? 2 : 1;
     }
     c->direction = nd;
     // the next level may append its discoveries only if it is light: a push examines m_frontier
     // edges, a pull can discover at most the unvisited vertices
-    const u64 unv = c->n_total > c->reached ? c->n_total - c->reached : 0;
+    const u64 unv = n_total > reached ? n_total - reached : 0;
     c->q_open = ((nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u;
     // workgroups the next launch needs: twice its work items (queue chunks + one per 1024 hub-row edges), at least 64
     u32 na = 0;
-    if (nd == 1 && c->use_queue && !done) {
-        const u64 items = (u64)QSHARDS * ((qmx + c->qchunk - 1) / c->qchunk) + v1 / PUSH_HUB_CHUNK + 1;
+    if (nd == 1 && use_queue && !done) {
+        const u64 items = (u64)QSHARDS * ((qmx + qchunk - 1) / qchunk) + v1 / PUSH_HUB_CHUNK + 1;
         na = items * 2 < 64 ? 64u : (items * 2 > 60000ull ? 0u : (u32)(items * 2));
     }
     c->nact = na;
-    c->tiny = (!done && nd == 1 && c->use_queue && v1 <= TINY_EDGES && v0 <= TINY_VERTS) ? 1u : 0u;
+    c->tiny = (!done && nd == 1 && use_queue && v1 <= TINY_EDGES && v0 <= TINY_VERTS) ? 1u : 0u;
     c->zr_dirty = 1;   // bfs_tiny_kernel resets it after its own levels
 }
 
@@ -1041,7 +1166,7 @@ __device__ __forceinline__ bool take_ticket(BfsCtrl* c, u32 nwg) {
 // DIRHINT only names the launch for profilers (0 = blind level loop; 1 / 2 = the profiled pass knows the
 // level is a push / pull); the direction taken is always the control block's.
 template <bool PARENT, int DIRHINT>
-__global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
+__global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
     BfsCtrl* c = a.ctrl;
     if (c->done) return;
     // a light level (queue-mode push over a few thousand edges) is run by c->nact workgroups only: the end-of-level
@@ -1073,11 +1198,28 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
     qc.qlen = &c->qlen[(rot + 1) & 1][(blockIdx.x % QSHARDS) * 16];
     qc.hubs = &c->hubs[(rot + 1) & 1];
     qc.open = !slab && c->q_open != 0;
+    __shared__ u32 s_hl[WG_HUBCAP];
+    __shared__ u32 s_hn;
+    qc.s_hl = (!slab && a.hubrows) ? s_hl : nullptr;
+    qc.s_hn = (!slab && a.hubrows) ? &s_hn : nullptr;
+    const u32 hubn = slab ? 0u : c->hubn[rot & 1];
+    if (threadIdx.x == 0) s_hn = 0;
+    __syncthreads();
+    DBG_STAMP(0);
+#ifdef FGPU_BFS_STAMPS
+    if (g_bfs_dbg && threadIdx.x == 0) {
+        unsigned hw = 0, xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_bfs_dbg[blockIdx.x * 8 + 7] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+#endif
     if (dir == 1)
         push_fused<PARENT>(a, cur, use_q ? a.queue[rot & 1] : nullptr, &c->qlen[rot & 1][0], qmax, qchunk, hubs_present,
-                           a.visited, nxt, newlevel, qc, acc, nwg);
+                           a.visited, nxt, newlevel, qc, acc, nwg, a.hubrows ? a.hubrows + (rot & 1) * HUBCAP : nullptr, hubn);
     else
         pull_fused<PARENT>(a, cur, a.visited, nxt, newlevel, qc, acc);
+    DBG_STAMP(3);
     // block reduction of the per-thread statistics, one atomic triple per workgroup
     u64 cnt = acc.count, mf = acc.mf, sc = acc.scanned, sn = acc.seen;
 #pragma unroll
@@ -1113,10 +1255,21 @@ __global__ __launch_bounds__(256) void bfs_fused_kernel(BfsArgs a) {
         if (s_acc[3]) r3 = atomicAdd((unsigned long long*)&c->slot[slot].indeg, s_acc[3]);
         asm volatile("" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3));
         if (s_hub) *qc.hubs = 1u;   // read by the next launch
+        if (qc.s_hn && s_hn) {
+            // this workgroup's hub discoveries join the next frontier's list (a handful per workgroup and level; a
+            // count past the capacity — here or in total — only tells the next push level to walk the static list)
+            const u32 mine = s_hn;
+            const u32 add = mine <= WG_HUBCAP ? mine : HUBCAP + 1u;
+            const u32 base = atomicAdd(&c->hubn[(rot + 1) & 1], add);
+            u32* __restrict__ out = a.hubrows + ((rot + 1) & 1) * HUBCAP;
+            for (u32 i = 0; i < mine && i < WG_HUBCAP && base + i < HUBCAP; ++i) out[base + i] = s_hl[i];
+        }
         s_last = take_ticket(c, nwg) ? 1u : 0u;
     }
     __syncthreads();
+    DBG_STAMP(4);
     if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done, slab);
+    DBG_STAMP(5);
 }
 
 // Tiny levels — the first two and the last two or three of an R-MAT search, every level of a chain — cost a
@@ -1162,6 +1315,8 @@ __global__ __launch_bounds__(256) void bfs_tiny_kernel(BfsArgs a) {
         qc.q = a.queue[(rot + 1) & 1] + (t >> 6) * QSEG;          // a wavefront per segment: four of the eight are used
         qc.qlen = &c->qlen[(rot + 1) & 1][(t >> 6) * 16];
         qc.hubs = &c->hubs[(rot + 1) & 1];
+        qc.s_hl = nullptr;   // a hub discovered here is only flagged: the next (fused) level walks the static chunk list
+        qc.s_hn = nullptr;
         qc.open = q_open != 0;
         __syncthreads();
         push_fused<PARENT, true>(a, cur, a.queue[rot & 1], &c->qlen[rot & 1][0], qmax, qchunk, false, a.visited, nxt,
@@ -1194,7 +1349,10 @@ __global__ __launch_bounds__(256) void bfs_tiny_kernel(BfsArgs a) {
             __hip_atomic_store(&c->slot[0].count, (u64)s_acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&c->slot[0].mf, (u64)s_acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&c->slot[0].scan, (u64)s_acc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (s_hub) __hip_atomic_store(qc.hubs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s_hub) {
+                __hip_atomic_store(qc.hubs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c->hubn[(rot + 1) & 1], HUBCAP + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
@@ -1428,6 +1586,7 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     c->qchunk = PUSH_VPB;
     c->use_queue = 1;
     c->hubs[0] = (mf >= PUSH_HUB_DEG) ? 1u : 0u;
+    if (mf >= PUSH_HUB_DEG && a.hubrows) { a.hubrows[0] = src; c->hubn[0] = 1; }
     c->done = (max_level == 0) ? 1 : 0;
     if (max_level == 0 && a.host_done)
         __hip_atomic_store(a.host_done, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1618,6 +1777,7 @@ struct fgpu_bfs_plan {
     bool external_bufs = false;
     u64* bm_block = nullptr;  // single-rank fused path: [bm0 | bm1 | bm2 | visited] in one allocation
     u32* queue_block = nullptr;  // single-rank fused path: two frontier queues of QCAP ids
+    u32* hubrows = nullptr;      // single-rank fused path: 2 x HUBCAP hub rows of the current / next frontier
     u32* h_done = nullptr;       // pinned host word the last level writes (host view)
     u32* d_done = nullptr;       // the same word as the device sees it
     int enqueued = 0;            // levels enqueued since the last begin
@@ -1691,16 +1851,26 @@ static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
         a.cur = a.bm[0];
         a.queue[0] = p->queue_block;
         a.queue[1] = p->queue_block + QCAP;
+        a.hubrows = p->hubrows;
         a.host_done = p->d_done;
     } else {
         a.bm[0] = a.bm[1] = a.bm[2] = nullptr;
         a.queue[0] = a.queue[1] = nullptr;
+        a.hubrows = nullptr;
         a.host_done = nullptr;
     }
     return a;
 }
 
 extern "C" {
+
+#ifdef FGPU_BFS_STAMPS
+fgpu_info fgpu_debug_bfs_stamps(void* devbuf) {
+    unsigned long long* q = (unsigned long long*)devbuf;
+    FGPU_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bfs_dbg), &q, sizeof(q)));
+    return FGPU_OK;
+}
+#endif
 
 fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     if (!p) return FGPU_OK;
@@ -1722,6 +1892,7 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->dist_glob);
     c->dev_free(p->dist_glob2);
     c->dev_free(p->pull_head);
+    c->dev_free(p->hubrows);
     c->dev_free(p->slab_ring[1]);
     c->dev_free(p->slab_ring[2]);
     c->dev_free(p->dist_deg);
@@ -1809,6 +1980,7 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         if ((i = ctx->dev_alloc((void**)&p->ctrl, sizeof(BfsCtrl))) != FGPU_OK) break;
         if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->bm_block, 4 * wb)) != FGPU_OK) break;
         if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->queue_block, 2 * (size_t)QCAP * sizeof(u32))) != FGPU_OK) break;
+        if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->hubrows, 2 * (size_t)HUBCAP * sizeof(u32))) != FGPU_OK) break;
         if (At) {
             p->pull_colidx = (At->pull_col && ctx->opt.bfs_hub_first) ? At->pull_col : At->colidx;
             if ((i = ctx->dev_alloc((void**)&p->pull_head, (size_t)p->nw * 64 * sizeof(headv))) != FGPU_OK) break;
@@ -1847,6 +2019,13 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         u64 fg = (u64)ctx->cus * (u64)ctx->opt.bfs_wgs_per_cu;
         if (fg > g) fg = g;
         p->fgrid = (u32)fg;
+        if (getenv("FGPU_BFS_OCC")) {
+            int nb0 = 0, nb1 = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, bfs_fused_kernel<false, 0>, 256, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, bfs_fused_kernel<true, 0>, 256, 0);
+            fprintf(stderr, "bfs_fused_kernel residency (workgroups per CU): %d without / %d with parents; grid %u = %u per CU\n",
+                    nb0, nb1, p->fgrid, p->fgrid / (u32)ctx->cus);
+        }
     }
     // Default push -> pull switch factor.  A pull level probes the N-bit frontier bitmap once per scanned in-edge: while
     // the bitmap sits in every XCD's 4 MiB L2 (<= 2 MiB: up to 2^24 vertices) pulling early pays, alpha = 32 (RMAT-22:
@@ -2583,6 +2762,7 @@ static void vxm_args(BfsArgs& a, const fgpu_mat* A, const fgpu_mat* At, u32 n, u
     a.hubP = A->push_chunks; a.n_hubP = A->n_push_chunks;
     a.hubAt = At ? At->hub_chunks : nullptr; a.n_hubAt = At ? At->n_hub_chunks : 0;
     a.head = nullptr;
+    a.hubrows = nullptr;
     a.n = n; a.lo = 0; a.hi = nw * 64;
     a.nxt_local = out_words; a.nxt_global = out_words;
     a.nw = nw;
