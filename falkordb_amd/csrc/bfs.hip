@@ -36,8 +36,6 @@ constexpr unsigned QSEG = QCAP / QSHARDS;
 constexpr unsigned long long QGATE = 1ull << 17;  // a level appends only when it can discover at most this many
 
 struct StatSlot { u64 count, mf, indeg, scan; u64 pad[12]; };
-constexpr unsigned HUBCAP = 1024;     // hub rows of a frontier the fused push level can take from a list (else: static chunk walk)
-constexpr unsigned WG_HUBCAP = 1024;  // ... and that one workgroup can report per level
 constexpr unsigned TICK_PAD = 32;   // u32 words between ticket counters (128 B)
 
 // Phase stamps of the fused level kernel (build with -DFGPU_BFS_STAMPS; tools/experiments/bfs_stamps.py reads them): per
@@ -89,8 +87,7 @@ struct BfsCtrl {
                        // level runs on a few dozen, the rest return at once and skip the end-of-level ticket
     u32 tick_top;
     u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
-    u32 hubn[2];       // hub rows listed in hubrows[parity] for the current / next frontier (> HUBCAP: list incomplete)
-    u32 tick_pad[29];
+    u32 tick_pad[31];
     u32 tick[64 * TICK_PAD];
 };
 
@@ -100,7 +97,6 @@ struct BfsArgs {
     const u32* hubAt; u32 n_hubAt;
     const headv* head;   // fused pull levels: the first PULL_H in-neighbours of every row of A' (plan-owned, see pull_fused)
     const u32* hubP;  u32 n_hubP;   // A's finer list (PUSH_HUB_DEG / PUSH_HUB_CHUNK): fused push levels
-    u32* hubrows;     // fused single-rank path: 2 x HUBCAP vertex ids, the hub rows discovered into the current / next frontier
     u32 n;        // global vertex count
     u32 lo, hi;   // owned destination range (hi <= n_pad)
     u64* cur;         // global frontier bitmap (n_pad bits)
@@ -396,8 +392,6 @@ struct QueueCtx {
     u32* q;     // this workgroup's segment of the next queue
     u32* qlen;  // its length counter
     u32* hubs;
-    u32* s_hl;  // LDS: hub rows this workgroup discovered (nullable: not collected)
-    u32* s_hn;  // LDS: their count
     bool open;  // level-uniform
 };
 
@@ -426,12 +420,6 @@ __device__ __forceinline__ void note_discovery(const BfsArgs& a, QueueCtx& qc, u
     // thousands of same-address atomics or write-through stores (every discovered row >= 1024) serialise at the
     // memory side (a heavy level went from 80 to 120 us with a per-discovery atomic, to 350 us with a store)
     acc.hub |= (rowdeg >= PUSH_HUB_DEG) ? 1u : 0u;
-    // ... and the row itself goes on the workgroup's list: the next push level expands the listed rows' chunks
-    // round-robin over the workgroups instead of walking the static chunk list (see push_fused)
-    if (rowdeg >= PUSH_HUB_DEG && qc.s_hn) {
-        const u32 i = atomicAdd(qc.s_hn, 1u);
-        if (i < WG_HUBCAP) qc.s_hl[i] = u;
-    }
 }
 
 template <bool PARENT>
@@ -459,8 +447,7 @@ template <bool PARENT, bool CONCAT = false>
 __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, const u32* __restrict__ qcur,
                            const u32* __restrict__ qcur_len, u32 qmax, u32 qchunk, bool hubs_present,
                            u64* __restrict__ visited,
-                           u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc, u32 nwg,
-                           const u32* __restrict__ hublist = nullptr, u32 hubn = 0) {
+                           u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc, u32 nwg) {
     __shared__ u32 s_off[PUSH_VPB];
     __shared__ u32 s_start[PUSH_VPB];
     __shared__ u32 s_vid[PUSH_VPB];
@@ -635,86 +622,7 @@ __device__ void push_fused(const BfsArgs& a, const u64* __restrict__ frontier, c
     // thousands of items at RMAT-22 and a level that holds a single hub walks all of it), then only the chunks whose
     // row is in the frontier are expanded, one workgroup trip each.
     DBG_STAMP(1);
-#ifdef FGPU_BFS_STAMPS
-    if (g_bfs_dbg && threadIdx.x == 0)
-        g_bfs_dbg[blockIdx.x * 8 + 6] = (hubs_present ? 1ull : 0ull) | ((unsigned long long)hubn << 8) | ((unsigned long long)(hublist != nullptr) << 4);
-#endif
-    // When the frontier's hub rows are LISTED (the levels that discovered them reported them, at most HUBCAP), their
-    // chunks are numbered through a prefix over the list and dealt round-robin: every workgroup runs ceil(T / nwg)
-    // trips.  The static walk below gives a workgroup the active chunks that happen to sit at its positions of the
-    // list — 930 active chunks over 1536 workgroups left a few of them four or five trips (10-15 us each) while the
-    // mean was 0.6: the heavy push level of an R-MAT search took 76-93 us for 0.95 M edges.
-    if (hubs_present && hublist && hubn && hubn <= HUBCAP) {
-        // s_off / s_start / s_vid (PUSH_VPB = HUBCAP entries each) are free again here: row, first edge, chunk prefix
-        __syncthreads();
-        u32 nch[4], tsum = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u32 i = 4 * t + j;
-            u32 row = 0, rb = 0, re = 0;
-            if (i < hubn) {
-                row = hublist[i];
-                rb = a.A.rowptr[row];
-                re = a.A.rowptr[row + 1];
-            }
-            s_vid[i] = row;
-            s_start[i] = rb;
-            nch[j] = (re - rb + PUSH_HUB_CHUNK - 1) / PUSH_HUB_CHUNK;
-            tsum += nch[j];
-        }
-        u32 total, ex;
-        {
-            const u32 lane = lane_id();
-            u32 inc = tsum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                u32 y = __shfl_up(inc, d, 64);
-                if (lane >= (u32)d) inc += y;
-            }
-            if (lane == 63) s_wave[t >> 6] = inc;
-            __syncthreads();
-            u32 wbase = 0, tot = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u32 x = s_wave[i];
-                if ((u32)i < (t >> 6)) wbase += x;
-                tot += x;
-            }
-            total = tot;
-            ex = wbase + inc - tsum;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s_off[4 * t + j] = ex;
-            ex += nch[j];
-        }
-        __syncthreads();
-        const u32 first = (blockIdx.x + nwg - nblk % nwg) % nwg;   // items follow the regular ones
-        for (u32 k = first; k < total; k += nwg) {   // block-uniform
-            u32 lo = 0, hi = hubn;
-            while (hi - lo > 1) {
-                const u32 mid = (lo + hi) >> 1;
-                if (s_off[mid] <= k) lo = mid; else hi = mid;
-            }
-            const u32 row = s_vid[lo];
-            const u32 b = s_start[lo] + (k - s_off[lo]) * PUSH_HUB_CHUNK;
-            const u32 rend = a.A.rowptr[row + 1];
-            const u32 e = b + PUSH_HUB_CHUNK < rend ? b + PUSH_HUB_CHUNK : rend;
-            u32 u[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const u32 i = b + t + 256 * kk;
-                u[kk] = (i < e) ? a.A.colidx[i] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {   // whole waves reach queue_append
-                const bool won = (u[kk] != 0xFFFFFFFFu) &&
-                                 fused_visit<PARENT>(a, vis32, nxt32, newlevel, u[kk], row, qc, acc);
-                queue_append(qc, won, u[kk]);
-            }
-            if (t == 0) acc.scanned += e - b;
-        }
-    } else if (hubs_present && a.n_hubP) {
+    if (hubs_present && a.n_hubP) {
         __shared__ u32 s_act[256];
         __shared__ u32 s_nact;
         const u32 first = (blockIdx.x + nwg - nblk % nwg) % nwg;   // items follow the regular ones
@@ -1121,7 +1029,6 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
         c->qchunk = qchunk;
     }
     c->hubs[rot & 1] = 0;
-    c->hubn[rot & 1] = 0;
     const bool done = (v0 == 0) || (max_level >= 0 && level >= max_level);
     c->done = done ? 1 : 0;
     if (done && host_done)  // the host polls this word instead of paying a D2H copy + stream sync
@@ -1198,13 +1105,6 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
     qc.qlen = &c->qlen[(rot + 1) & 1][(blockIdx.x % QSHARDS) * 16];
     qc.hubs = &c->hubs[(rot + 1) & 1];
     qc.open = !slab && c->q_open != 0;
-    __shared__ u32 s_hl[WG_HUBCAP];
-    __shared__ u32 s_hn;
-    qc.s_hl = (!slab && a.hubrows) ? s_hl : nullptr;
-    qc.s_hn = (!slab && a.hubrows) ? &s_hn : nullptr;
-    const u32 hubn = slab ? 0u : c->hubn[rot & 1];
-    if (threadIdx.x == 0) s_hn = 0;
-    __syncthreads();
     DBG_STAMP(0);
 #ifdef FGPU_BFS_STAMPS
     if (g_bfs_dbg && threadIdx.x == 0) {
@@ -1216,7 +1116,7 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
 #endif
     if (dir == 1)
         push_fused<PARENT>(a, cur, use_q ? a.queue[rot & 1] : nullptr, &c->qlen[rot & 1][0], qmax, qchunk, hubs_present,
-                           a.visited, nxt, newlevel, qc, acc, nwg, a.hubrows ? a.hubrows + (rot & 1) * HUBCAP : nullptr, hubn);
+                           a.visited, nxt, newlevel, qc, acc, nwg);
     else
         pull_fused<PARENT>(a, cur, a.visited, nxt, newlevel, qc, acc);
     DBG_STAMP(3);
@@ -1255,15 +1155,6 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
         if (s_acc[3]) r3 = atomicAdd((unsigned long long*)&c->slot[slot].indeg, s_acc[3]);
         asm volatile("" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3));
         if (s_hub) *qc.hubs = 1u;   // read by the next launch
-        if (qc.s_hn && s_hn) {
-            // this workgroup's hub discoveries join the next frontier's list (a handful per workgroup and level; a
-            // count past the capacity — here or in total — only tells the next push level to walk the static list)
-            const u32 mine = s_hn;
-            const u32 add = mine <= WG_HUBCAP ? mine : HUBCAP + 1u;
-            const u32 base = atomicAdd(&c->hubn[(rot + 1) & 1], add);
-            u32* __restrict__ out = a.hubrows + ((rot + 1) & 1) * HUBCAP;
-            for (u32 i = 0; i < mine && i < WG_HUBCAP && base + i < HUBCAP; ++i) out[base + i] = s_hl[i];
-        }
         s_last = take_ticket(c, nwg) ? 1u : 0u;
     }
     __syncthreads();
@@ -1315,8 +1206,6 @@ __global__ __launch_bounds__(256) void bfs_tiny_kernel(BfsArgs a) {
         qc.q = a.queue[(rot + 1) & 1] + (t >> 6) * QSEG;          // a wavefront per segment: four of the eight are used
         qc.qlen = &c->qlen[(rot + 1) & 1][(t >> 6) * 16];
         qc.hubs = &c->hubs[(rot + 1) & 1];
-        qc.s_hl = nullptr;   // a hub discovered here is only flagged: the next (fused) level walks the static chunk list
-        qc.s_hn = nullptr;
         qc.open = q_open != 0;
         __syncthreads();
         push_fused<PARENT, true>(a, cur, a.queue[rot & 1], &c->qlen[rot & 1][0], qmax, qchunk, false, a.visited, nxt,
@@ -1349,10 +1238,7 @@ __global__ __launch_bounds__(256) void bfs_tiny_kernel(BfsArgs a) {
             __hip_atomic_store(&c->slot[0].count, (u64)s_acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&c->slot[0].mf, (u64)s_acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&c->slot[0].scan, (u64)s_acc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (s_hub) {
-                __hip_atomic_store(qc.hubs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&c->hubn[(rot + 1) & 1], HUBCAP + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (s_hub) __hip_atomic_store(qc.hubs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
@@ -1586,7 +1472,6 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     c->qchunk = PUSH_VPB;
     c->use_queue = 1;
     c->hubs[0] = (mf >= PUSH_HUB_DEG) ? 1u : 0u;
-    if (mf >= PUSH_HUB_DEG && a.hubrows) { a.hubrows[0] = src; c->hubn[0] = 1; }
     c->done = (max_level == 0) ? 1 : 0;
     if (max_level == 0 && a.host_done)
         __hip_atomic_store(a.host_done, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1777,7 +1662,6 @@ struct fgpu_bfs_plan {
     bool external_bufs = false;
     u64* bm_block = nullptr;  // single-rank fused path: [bm0 | bm1 | bm2 | visited] in one allocation
     u32* queue_block = nullptr;  // single-rank fused path: two frontier queues of QCAP ids
-    u32* hubrows = nullptr;      // single-rank fused path: 2 x HUBCAP hub rows of the current / next frontier
     u32* h_done = nullptr;       // pinned host word the last level writes (host view)
     u32* d_done = nullptr;       // the same word as the device sees it
     int enqueued = 0;            // levels enqueued since the last begin
@@ -1851,12 +1735,10 @@ static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
         a.cur = a.bm[0];
         a.queue[0] = p->queue_block;
         a.queue[1] = p->queue_block + QCAP;
-        a.hubrows = p->hubrows;
         a.host_done = p->d_done;
     } else {
         a.bm[0] = a.bm[1] = a.bm[2] = nullptr;
         a.queue[0] = a.queue[1] = nullptr;
-        a.hubrows = nullptr;
         a.host_done = nullptr;
     }
     return a;
@@ -1892,7 +1774,6 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->dist_glob);
     c->dev_free(p->dist_glob2);
     c->dev_free(p->pull_head);
-    c->dev_free(p->hubrows);
     c->dev_free(p->slab_ring[1]);
     c->dev_free(p->slab_ring[2]);
     c->dev_free(p->dist_deg);
@@ -1980,7 +1861,6 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         if ((i = ctx->dev_alloc((void**)&p->ctrl, sizeof(BfsCtrl))) != FGPU_OK) break;
         if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->bm_block, 4 * wb)) != FGPU_OK) break;
         if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->queue_block, 2 * (size_t)QCAP * sizeof(u32))) != FGPU_OK) break;
-        if (nranks == 1 && (i = ctx->dev_alloc((void**)&p->hubrows, 2 * (size_t)HUBCAP * sizeof(u32))) != FGPU_OK) break;
         if (At) {
             p->pull_colidx = (At->pull_col && ctx->opt.bfs_hub_first) ? At->pull_col : At->colidx;
             if ((i = ctx->dev_alloc((void**)&p->pull_head, (size_t)p->nw * 64 * sizeof(headv))) != FGPU_OK) break;
@@ -2762,7 +2642,6 @@ static void vxm_args(BfsArgs& a, const fgpu_mat* A, const fgpu_mat* At, u32 n, u
     a.hubP = A->push_chunks; a.n_hubP = A->n_push_chunks;
     a.hubAt = At ? At->hub_chunks : nullptr; a.n_hubAt = At ? At->n_hub_chunks : 0;
     a.head = nullptr;
-    a.hubrows = nullptr;
     a.n = n; a.lo = 0; a.hi = nw * 64;
     a.nxt_local = out_words; a.nxt_global = out_words;
     a.nw = nw;
