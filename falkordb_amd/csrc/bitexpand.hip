@@ -906,6 +906,9 @@ static void bp_recycle_state(fgpu_ctx* ctx, BitState& s) {
     s.flag.release();
 }
 
+// for the chain drivers (spgemm.hip): the state has been read for the last time
+void bp_finish(fgpu_ctx* ctx, BitState& s) { bp_recycle_state(ctx, s); }
+
 static fgpu_info bp_alloc_flags(fgpu_ctx* ctx, BitState& s) {
     FGPU_TRY(s.flag.alloc(ctx, (size_t)s.n + 1));
     FGPU_HIP(hipMemsetAsync(s.flag.p, 0, (size_t)s.n + 1, ctx->stream()));

@@ -434,6 +434,9 @@ fgpu_info bp_hop_count(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu
                        const u64* label_dev, u64* nnz, u64* checksum);
 // u |= x (u is allocated, zeroed, on first use): DISTINCT union over the hops of a [*1..k] pattern
 fgpu_info bp_accumulate(fgpu_ctx* ctx, BitState& u, const BitState& x);
+// The chain is done with `s`: its block goes back to the pool, re-zeroed by its flagged rows and marked "zero" when that is
+// cheaper than the memset the next batch's state would otherwise pay (bp_recycle_state).
+void bp_finish(fgpu_ctx* ctx, BitState& s);
 
 constexpr u32 HUB_DEG = 4096;    // rows at least this long are expanded by the hub kernel
 constexpr u32 HUB_CHUNK = 4096;  // edges per hub work item

@@ -425,12 +425,15 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
             FGPU_TRY(bm.alloc(ctx, nw + 1));
             FGPU_TRY(ctx->h2d(bm.p, dst_label_bitmap, nw * sizeof(u64)));
         }
+        fgpu_info ri;
         if (count_only) {
             *result = nullptr;
-            return bp_count(ctx, bs, dst_label_bitmap ? bm.p : nullptr, &count_only[0],
-                            want_checksum ? &count_only[1] : nullptr);
+            ri = bp_count(ctx, bs, dst_label_bitmap ? bm.p : nullptr, &count_only[0], want_checksum ? &count_only[1] : nullptr);
+        } else {
+            ri = bp_to_csr(ctx, bs, dst_label_bitmap ? bm.p : nullptr, result);
         }
-        return bp_to_csr(ctx, bs, dst_label_bitmap ? bm.p : nullptr, result);
+        if (ri == FGPU_OK) bp_finish(ctx, bs);   // the next batch's state finds a zeroed block instead of a 2 GiB memset
+        return ri;
     }
     if (dst_label_bitmap) {
         const u64 nc = f->ncols, nw = (nc + 63) / 64;
@@ -644,6 +647,7 @@ fgpu_info fgpu_expand_levels(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t ns
         if (union_nnz) *union_nnz = n;
         if (union_checksum) *union_checksum = cs;
     }
+    bp_finish(ctx, bs);
     return FGPU_OK;
 }
 
