@@ -2618,8 +2618,34 @@ fgpu_info fgpu_bfs(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, uint64_
         i = mat_merge_entries(ctx, &dAt, At, nullptr, nullptr, false, At->nrows, At->ncols, true);
         At = dAt;
     }
+    // The plan of the previous call over the same (A, At) is kept on A (common.hpp: bfs_plan): a caller that cannot hold a
+    // plan — the reference's procedure call is one function — pays plan creation once per snapshot pair.  A second thread
+    // searching the same adjacency at the same time, and the re-emitted hypersparse forms, take a plan of their own.
     fgpu_bfs_plan* p = nullptr;
-    if (i == FGPU_OK) i = fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1);
+    bool cached = false;
+    std::unique_lock<std::mutex> lk(A->bfs_mu, std::defer_lock);
+    if (i == FGPU_OK && !dA && !dAt && lk.try_lock()) {
+        const uint64_t epoch = ctx->opt_epoch.load(std::memory_order_relaxed);
+        if (A->bfs_plan && (A->bfs_plan_at != At || A->bfs_plan->ctx != ctx || A->bfs_plan_epoch != epoch)) mat_drop_bfs_plan(A);
+        if (!A->bfs_plan) {
+            if (At && At->bfs_cached_in && At->bfs_cached_in != A) {   // the transpose serves one cached plan at a time
+                const fgpu_mat* other = At->bfs_cached_in;
+                std::unique_lock<std::mutex> lo(other->bfs_mu, std::try_to_lock);
+                if (lo.owns_lock() && other->bfs_plan_at == At) mat_drop_bfs_plan(other);
+            }
+            if (!At || !At->bfs_cached_in) {
+                i = fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1);
+                if (i == FGPU_OK) {
+                    A->bfs_plan = p;
+                    A->bfs_plan_at = At;
+                    A->bfs_plan_epoch = epoch;
+                    if (At) At->bfs_cached_in = A;
+                }
+            }
+        }
+        if (A->bfs_plan) { p = A->bfs_plan; cached = true; }
+    }
+    if (i == FGPU_OK && !p) i = fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1);
     if (i == FGPU_OK) i = fgpu_bfs_run(p, src, max_level, parent != nullptr);
     if (i == FGPU_OK) i = fgpu_bfs_fetch(p, level, parent);
     if (i == FGPU_OK && edges_traversed) {
@@ -2627,7 +2653,7 @@ fgpu_info fgpu_bfs(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, uint64_
         i = fgpu_bfs_stats(p, st);
         *edges_traversed = st[2];
     }
-    if (p) fgpu_bfs_plan_free(p);
+    if (p && !cached) fgpu_bfs_plan_free(p);
     if (dA) mat_release(dA);
     if (dAt) mat_release(dAt);
     return i;

@@ -114,6 +114,7 @@ struct fgpu_ctx {
     int device = 0;
     uint64_t id = 0;           // unique over the process lifetime (thread-local lane caches key on it)
     fgpu_options opt;
+    std::atomic<uint64_t> opt_epoch{0};   // bumped by fgpu_set_option: cached BFS plans (fgpu_bfs) are rebuilt when it moved
     void* (*mal)(size_t) = nullptr;
     void (*fre)(void*) = nullptr;
     int cus = 0;
@@ -246,6 +247,15 @@ struct fgpu_mat {
     mutable uint32_t* pull_col = nullptr; // bfs.hip: column ids with every row reordered hub-first, for the pull levels (lazy, owned)
     mutable uint32_t* wordrow = nullptr;  // merge.hip: stored-row index of entry 64 w, for w in [0, ceil(nnz/64)] (lazy, owned)
     mutable fgpu_tiles* tiles = nullptr;  // built on demand by fgpu_mat_build_tiles; owned by the matrix
+    // fgpu_bfs (the one-call entry): the plan of the last (this, At) search is kept on the adjacency so that repeated calls
+    // do not pay plan creation (pinned allocations, events, head array: 1.3 ms of a 2.2 ms call at RMAT-22).  `bfs_mu`
+    // serialises its users; the transpose remembers which adjacency holds a plan over it (one at a time) so that releasing
+    // either matrix drops the plan first.
+    mutable std::mutex bfs_mu;
+    mutable struct fgpu_bfs_plan* bfs_plan = nullptr;
+    mutable const fgpu_mat* bfs_plan_at = nullptr;
+    mutable uint64_t bfs_plan_epoch = 0;
+    mutable const fgpu_mat* bfs_cached_in = nullptr;
     // bit-parallel expansion (bitexpand.hip): cached pattern transpose of this matrix, and (on that
     // transpose) its rows cut into items of <= 256 entries
     mutable fgpu_mat* tcache = nullptr;
@@ -353,6 +363,7 @@ fgpu_info compact_segments(fgpu_ctx* ctx, const u32* data, const u64* off, const
 // ---- matrix helpers (mat.hip) ---------------------------------------------------
 // free a snapshot no other thread has seen (temporaries, failed builds); fgpu_mat_free adds the cross-lane fence
 void mat_release(fgpu_mat* m);
+void mat_drop_bfs_plan(const fgpu_mat* a);   // caller holds a->bfs_mu
 fgpu_info mat_alloc(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, u64 nnz, bool with_vals,
                     u32 nvec_hyper, bool hyper);
 // (m \ dm) U dp, pattern only, on device (K3/K6).

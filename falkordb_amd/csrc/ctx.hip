@@ -544,6 +544,7 @@ fgpu_info fgpu_prof_read(fgpu_ctx* ctx, const char** names, double* ms, uint64_t
 
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     FGPU_REQUIRE(ctx && name, FGPU_NULL_POINTER, "fgpu_set_option: NULL argument");
+    ctx->opt_epoch.fetch_add(1, std::memory_order_relaxed);
     if (!strcmp(name, "tiled_u")) {
         FGPU_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, FGPU_INVALID,
                      "tiled_u must be 1, 2, 4 or 8");

@@ -17,8 +17,26 @@ namespace fgpu {
 // ---------------------------------------------------------------------------------
 // allocation / finalisation
 // ---------------------------------------------------------------------------------
+// the cached one-call BFS plan (fgpu_bfs, bfs.hip) goes before either of its matrices does
+void mat_drop_bfs_plan(const fgpu_mat* a) {
+    if (!a->bfs_plan) return;
+    (void)fgpu_bfs_plan_free(a->bfs_plan);
+    if (a->bfs_plan_at && a->bfs_plan_at->bfs_cached_in == a) a->bfs_plan_at->bfs_cached_in = nullptr;
+    a->bfs_plan = nullptr;
+    a->bfs_plan_at = nullptr;
+}
+
 void mat_release(fgpu_mat* m) {
     if (!m) return;
+    {
+        std::lock_guard<std::mutex> g(m->bfs_mu);
+        mat_drop_bfs_plan(m);
+    }
+    if (const fgpu_mat* owner = m->bfs_cached_in) {   // m is the transpose of a cached plan
+        std::lock_guard<std::mutex> g(owner->bfs_mu);
+        if (owner->bfs_plan_at == m) mat_drop_bfs_plan(owner);
+        m->bfs_cached_in = nullptr;
+    }
     fgpu_ctx* c = m->ctx;
     if (c) {
         c->dev_free(m->rowptr);

@@ -298,7 +298,9 @@ fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, co
  * binding lagraphx_bindings.rs:585-594).  level[n] (int32, -1 = unreached, source = 0),
  * parent[n] (nullable, int64, -1 = none, parent[src] = src) are HOST arrays.
  * max_level < 0 => unlimited.  At may be NULL (push only).  edges_traversed
- * (nullable) = sum of out-degrees of reached vertices (TEPS numerator). */
+ * (nullable) = sum of out-degrees of reached vertices (TEPS numerator).
+ * The search plan of the last call over the same (A, At) pair stays attached to A (released with either matrix, rebuilt
+ * after fgpu_set_option), so repeated calls pay the search and the 4 N-byte copy-out, not plan creation. */
 fgpu_info fgpu_bfs(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, uint64_t src,
                    int64_t max_level, int32_t* level, int64_t* parent,
                    uint64_t* edges_traversed);
