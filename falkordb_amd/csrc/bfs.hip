@@ -1912,7 +1912,10 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
     // 286.6 GTEPS at 32, 283.3 at 24, 278.5 at 20; RMAT-24 flat from 16 to 32); once it does not (RMAT-26: 8 MiB) the same
     // probes miss L2 and a push of the same frontier is the cheaper level for longer: 460 GTEPS at 32, 489 at 24, 498 at 20,
     // 495 at 12, 455 at 8.  fgpu_bfs_plan_tune overrides.
-    p->alpha = ((size_t)p->nw * sizeof(u64) > (2u << 20)) ? 20.0 : 32.0;
+    // Round 3 (the pull's first probe comes from the 4-byte head array, so an early pull is cheaper than it was): 48 while the
+    // bitmap fits L2 — RMAT-22 0.2052 ms at 48, 0.2071 at 32, 0.2101 at 24, 0.2055 at 64; RMAT-24 0.5156 / 0.5182 / 0.5209 /
+    // 0.5283 — and still 20 beyond (RMAT-26: 1.903 ms at 20, 1.914 at 16, 1.916 at 24, 2.05 at 32 and above).
+    p->alpha = ((size_t)p->nw * sizeof(u64) > (2u << 20)) ? 20.0 : 48.0;
     p->prof = {{"bfs_fused_kernel<false, 1> (push level)"}, {"bfs_fused_kernel<false, 2> (pull level)"}};
     *out = p;
     return FGPU_OK;
