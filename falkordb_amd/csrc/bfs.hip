@@ -36,6 +36,12 @@ constexpr unsigned QSEG = QCAP / QSHARDS;
 constexpr unsigned long long QGATE = 1ull << 17;  // a level appends only when it can discover at most this many
 
 struct StatSlot { u64 count, mf, indeg, scan; u64 pad[12]; };
+// Fused levels: every slot word carries, above bit 52, the number of workgroups that have added to it this level.  The
+// `count` word is the slot's TICKET (its add is the one returning atomic a workgroup issues); the other words are added
+// without waiting, and the control step checks their arrival fields before it trusts the sums.
+constexpr unsigned SLOT_ARR_SHIFT = 52;
+constexpr unsigned long long SLOT_ARR = 1ull << SLOT_ARR_SHIFT;
+constexpr unsigned long long SLOT_VAL = SLOT_ARR - 1ull;
 constexpr unsigned TICK_PAD = 32;   // u32 words between ticket counters (128 B)
 
 // Phase stamps of the fused level kernel (build with -DFGPU_BFS_STAMPS; tools/experiments/bfs_stamps.py reads them): per
@@ -88,7 +94,7 @@ struct BfsCtrl {
     u32 tick_top;
     u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
     u32 tick_pad[31];
-    u32 tick[64 * TICK_PAD];
+    u32 tick[64 * TICK_PAD];   // (round-2 ticket counters; the slot words carry the tickets now — kept for the layout)
 };
 
 struct BfsArgs {
@@ -932,7 +938,7 @@ __device__ __forceinline__ u32 done_word_of(u32 heavy_begin, u32 heavy_end, i32 
 // chain of dependent load -> store -> load round trips (the stores may alias the loads as far as the compiler knows) and
 // took 5.4 us of every level, after the last workgroup's ticket (tools/experiments/bfs_stamps.py); one round of loads,
 // register arithmetic and one round of stores is ~1.5 us.
-__device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
+__device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
     const u32 t = threadIdx.x;  // 0..63
     // ---- loads (header snapshot: uniform; slots / queue lengths: per lane) ------------------------------------------
     const u32 rot = c->rot;
@@ -948,6 +954,17 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
     u64 v1 = __hip_atomic_load(&c->slot[t].mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v3 = __hip_atomic_load(&c->slot[t].scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v2 = slab ? __hip_atomic_load(&c->slot[t].indeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    if (nwg) {
+        // the tickets vouch for the `count` words; the adds nobody waited for may still be in flight — each word says how
+        // many workgroups it has heard from, and a short one is read again (rare: they were issued before the ticket)
+        const u64 expect = t < nwg ? (u64)((nwg + (STAT_SLOTS - 1) - t) >> 6) : 0ull;
+        while ((v1 >> SLOT_ARR_SHIFT) != expect)
+            v1 = __hip_atomic_load(&c->slot[t].mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((v3 >> SLOT_ARR_SHIFT) != expect)
+            v3 = __hip_atomic_load(&c->slot[t].scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (slab && (v2 >> SLOT_ARR_SHIFT) != expect)
+            v2 = __hip_atomic_load(&c->slot[t].indeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     u32 ql = 0;   // lanes 0..7: lengths of the segments appended this level
     if (!slab && t < QSHARDS)
         ql = __hip_atomic_load(&c->qlen[(rot + 1) & 1][t * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -956,6 +973,7 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
     if (v1) c->slot[t].mf = 0;
     if (v3) c->slot[t].scan = 0;
     if (v2) c->slot[t].indeg = 0;
+    v0 &= SLOT_VAL; v1 &= SLOT_VAL; v3 &= SLOT_VAL; v2 &= SLOT_VAL;
     if (!slab && t < QSHARDS) c->qlen[rot & 1][t * 16] = 0;  // the old current queue is the next level's append target
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -1057,19 +1075,6 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab) {
     c->zr_dirty = 1;   // bfs_tiny_kernel resets it after its own levels
 }
 
-// One ticket per workgroup, sharded over 64 counters so no word sees more than grid/64 arrivals;
-// returns true in exactly one workgroup of the launch, after every other one has arrived.
-__device__ __forceinline__ bool take_ticket(BfsCtrl* c, u32 nwg) {
-    const u32 s = blockIdx.x & 63u;
-    const u32 expect = (nwg + 63u - s) >> 6;
-    if (atomicAdd(&c->tick[s * TICK_PAD], 1u) + 1u != expect) return false;
-    c->tick[s * TICK_PAD] = 0;
-    const u32 nshards = nwg < 64u ? nwg : 64u;
-    if (atomicAdd(&c->tick_top, 1u) + 1u != nshards) return false;
-    c->tick_top = 0;
-    return true;
-}
-
 // DIRHINT only names the launch for profilers (0 = blind level loop; 1 / 2 = the profiled pass knows the
 // level is a push / pull); the direction taken is always the control block's.
 template <bool PARENT, int DIRHINT>
@@ -1145,21 +1150,24 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
     __syncthreads();  // also drains every wave's outstanding queue / hub atomics (vmcnt(0) before the barrier)
     if (threadIdx.x == 0) {
         const u32 slot = blockIdx.x & (STAT_SLOTS - 1);
-        // returning atomics whose results are consumed: the sums have landed before the ticket is taken
-        unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        if (s_acc[0]) {
-            r0 = atomicAdd((unsigned long long*)&c->slot[slot].count, s_acc[0]);
-            r1 = atomicAdd((unsigned long long*)&c->slot[slot].mf, s_acc[1]);
-        }
-        if (s_acc[2]) r2 = atomicAdd((unsigned long long*)&c->slot[slot].scan, s_acc[2]);
-        if (s_acc[3]) r3 = atomicAdd((unsigned long long*)&c->slot[slot].indeg, s_acc[3]);
-        asm volatile("" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3));
+        const u32 expect = (nwg + (STAT_SLOTS - 1) - slot) >> 6;   // workgroups of this launch that share the slot
         if (s_hub) *qc.hubs = 1u;   // read by the next launch
-        s_last = take_ticket(c, nwg) ? 1u : 0u;
+        // ONE round trip ends the level for a workgroup: three adds nobody waits for and the returning add on `count`,
+        // whose arrival field is the slot's ticket (it used to be two: returning slot adds, then a ticket counter)
+        atomicAdd((unsigned long long*)&c->slot[slot].mf, SLOT_ARR | s_acc[1]);
+        atomicAdd((unsigned long long*)&c->slot[slot].scan, SLOT_ARR | s_acc[2]);
+        if (slab) atomicAdd((unsigned long long*)&c->slot[slot].indeg, SLOT_ARR | s_acc[3]);
+        const unsigned long long old = atomicAdd((unsigned long long*)&c->slot[slot].count, SLOT_ARR | s_acc[0]);
+        bool last = false;
+        if ((u32)(old >> SLOT_ARR_SHIFT) + 1u == expect) {   // last of the slot: one more ticket among the slots
+            const u32 nshards = nwg < (u32)STAT_SLOTS ? nwg : (u32)STAT_SLOTS;
+            if (atomicAdd(&c->tick_top, 1u) + 1u == nshards) { c->tick_top = 0; last = true; }
+        }
+        s_last = last ? 1u : 0u;
     }
     __syncthreads();
     DBG_STAMP(4);
-    if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done, slab);
+    if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done, slab, nwg);
     DBG_STAMP(5);
 }
 
@@ -1243,7 +1251,7 @@ __global__ __launch_bounds__(256) void bfs_tiny_kernel(BfsArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (t < 64) {
-            fused_ctrl(c, a.host_done, false);
+            fused_ctrl(c, a.host_done, false, 0u);   // slot 0 holds this workgroup's plain sums: no arrival fields
             if (t == 0) {
                 c->zr_dirty = 0;
                 c->tiny_levels += 1;
