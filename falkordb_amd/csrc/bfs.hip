@@ -23,6 +23,8 @@
 //  * multi-GPU: column-slab partition (rank owns destinations [lo,hi) and holds A[:,lo:hi)
 //    + A'[lo:hi,:]); the only exchange is an all-gather of the owned new-frontier words,
 //    issued by the host loop between step() and commit() (RCCL over xGMI).
+#include <chrono>
+
 #include "common.hpp"
 
 namespace fgpu {
@@ -1699,6 +1701,7 @@ struct fgpu_bfs_plan {
     bool want_parent = false;
     bool profile = false;
     int last_heavy = -1;  // span of the non-tiny levels of the previous search (-1: no search yet)
+    double last_wait_us = 0;  // how long fgpu_bfs_wait polled last time (sets when the next wait starts querying the stream)
     std::vector<ProfSlot> prof;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     u32 grid = 0;   // multi-rank step kernel
@@ -2275,11 +2278,18 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
     // decision is the same on every rank), so the host polls a host word instead of paying a D2H copy + stream sync
     // per search (~80 us of idle stream between two searches at RMAT-26); the stream is queried now and then so that a
     // search needing more levels than were enqueued — or a failed launch — is noticed.
+    const auto wt0 = std::chrono::steady_clock::now();
+    auto waited_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - wt0).count(); };
+    double quiet_us = 2.0 * p0->last_wait_us + 100.0;   // no stream query before this (fgpu_bfs_wait says why)
+    if (quiet_us > 100.0 + 30.0 * budget) quiet_us = 100.0 + 30.0 * budget;
+    bool querying = false;
+    int topup = 2;
     auto wait_flag = [&](fgpu_bfs_plan* p, bool* done) -> fgpu_info {
         volatile u32* flag = (volatile u32*)p->h_done;
         (void)p->ctx->lane();
         for (u32 spin = 0; (*flag & 0x80000000u) == 0; ++spin) {
-            if ((spin & 0x3FFu) == 0x3FFu) {
+            if (!querying && (spin & 0x3Fu) == 0x3Fu) querying = waited_us() > quiet_us;
+            if (querying && (spin & 0x3FFu) == 0x3FFu) {
                 hipError_t q = hipStreamQuery(p->ctx->stream());
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) {
@@ -2299,9 +2309,12 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
         if (rc != FGPU_OK || done) break;
         rc = fetch_ctrl(p0);   // stream drained without the flag: not done yet, or done without a level having run (max_level 0)
         if (rc != FGPU_OK || p0->h_ctrl->done) break;
-        budget = 2;
+        querying = true;
+        budget = topup;                      // short of levels: 2 more, then 4, 8, ...
+        if (topup < 512) topup *= 2;
     }
     if (rc != FGPU_OK) return rc;
+    p0->last_wait_us = waited_us();
     const u32 fl0 = *(volatile u32*)p0->h_done;
     const int levels_taken = (fl0 & 0x80000000u) ? (int)(fl0 & 0xFFFFFFu) : (int)p0->h_ctrl->level;
     for (int k = 0; k < nplans; ++k) {
@@ -2497,11 +2510,23 @@ fgpu_info fgpu_bfs_wait(fgpu_bfs_plan* p) {
     FGPU_REQUIRE(p, FGPU_NULL_POINTER, "fgpu_bfs_wait: NULL plan");
     FGPU_REQUIRE(p->nranks == 1 && p->enqueued > 0, FGPU_INVALID, "fgpu_bfs_wait: no search in flight");
     volatile u32* flag = (volatile u32*)p->h_done;
+    // The last level raises the pinned flag.  It is polled WITHOUT touching the stream for as long as a search may
+    // reasonably take (twice the previous wait + 100 us): a hipStreamQuery makes the runtime put a system-scope fence on the
+    // next dispatch of the stream — 5.6-5.8 us of idle stream in front of every search when the query sat in the poll loop
+    // (rocprofv3 kernel trace, tools/trace_levels.py).  Past that budget the stream is looked at now and then, so a search
+    // that needs more levels than were enqueued (or a failed launch) is noticed.
+    const auto t0 = std::chrono::steady_clock::now();
+    auto waited_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    // ... twice the previous wait, but no more than 30 us per enqueued level (a level of an R-MAT search averages 20 us at
+    // scale 22, 200 us at scale 26 — there a 6 us fence no longer matters), and not at all once a top-up was needed
+    double quiet_us = 2.0 * p->last_wait_us + 100.0;
+    if (quiet_us > 100.0 + 30.0 * p->enqueued) quiet_us = 100.0 + 30.0 * p->enqueued;
+    int topup = 4;
+    bool querying = false;
     for (;;) {
-        // the last level raises the pinned flag; poll it, and look at the stream now and then so a
-        // search that needs more levels than were enqueued (or a failed launch) is noticed
         for (u32 spin = 0; (*flag & 0x80000000u) == 0; ++spin) {
-            if ((spin & 0x3FFu) == 0x3FFu) {
+            if (!querying && (spin & 0x3Fu) == 0x3Fu) querying = waited_us() > quiet_us;
+            if (querying && (spin & 0x3FFu) == 0x3FFu) {
                 hipError_t q = hipStreamQuery(p->ctx->stream());
                 if (q == hipSuccess) break;
                 if (q != hipErrorNotReady) {
@@ -2513,17 +2538,22 @@ fgpu_info fgpu_bfs_wait(fgpu_bfs_plan* p) {
         if (*flag & 0x80000000u) {
             p->last_levels = (int)(*flag & 0xFFFFFFu);
             p->last_heavy = (int)((*flag >> 24) & 0x7Fu);
+            p->last_wait_us = waited_us();
             return FGPU_OK;
         }
         FGPU_TRY(fetch_ctrl(p));  // stream drained without the flag: not done yet (or it raced the poll)
         if (p->h_ctrl->done) {
             p->last_levels = (int)p->h_ctrl->level;
             p->last_heavy = p->h_ctrl->heavy_begin ? (int)(p->h_ctrl->heavy_end - p->h_ctrl->heavy_begin + 1) : 0;
+            p->last_wait_us = waited_us();
             return FGPU_OK;
         }
+        // short of levels: top up, twice as many each time (a first search over a high-diameter graph)
+        querying = true;
         if (p->ctx->opt.bfs_tiny) FGPU_TRY(tiny_levels(p));
-        for (int k = 0; k < 4; ++k) FGPU_TRY(fused_level(p));
-        p->enqueued += 4;
+        for (int k = 0; k < topup; ++k) FGPU_TRY(fused_level(p));
+        p->enqueued += topup;
+        if (topup < 1024) topup *= 2;
     }
 }
 
