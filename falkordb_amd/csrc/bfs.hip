@@ -687,11 +687,19 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
     const u32 at_nnz = a.At.rowptr[a.n];
     for (u32 G = w_lo / PULL_R + wave; G < nsuper; G += nwaves) {
         u64 mword[PULL_R];
+        headv hd[PULL_R];
         bool live = false;
 #pragma unroll
         for (int r = 0; r < PULL_R; ++r) {
             const u32 g = G * PULL_R + r;
             mword[r] = (g < nwords) ? visited[g] : ~0ull;
+            // the heads ride with the visited words (one round trip, not two: at a pull level nearly every word is live;
+            // head is padded to whole words)
+            if (g < nwords) hd[r] = a.head[(g << 6) + lane];
+            else {
+#pragma unroll
+                for (int j = 0; j < PULL_H; ++j) hd[r][j] = 0xFFFFFFFFu;
+            }
             live |= (mword[r] != ~0ull);
         }
         if (!live) continue;
@@ -699,17 +707,6 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
         // ~0 where the row is shorter, HEAD_HUB for rows the hub section owns.  One coalesced 8 B load per row replaces
         // the row pointer pair AND the 16 B gather into the column ids — which, taken for every unvisited row, dragged
         // the whole array through (rows are adjacent: 64 B of every ~64): the heavy pull level streamed all of A'.
-        headv hd[PULL_R];
-#pragma unroll
-        for (int r = 0; r < PULL_R; ++r) {
-            const u32 v = ((G * PULL_R + r) << 6) + lane;
-            const bool want = (mword[r] != ~0ull);
-            if (want) hd[r] = a.head[v];   // head is padded to whole words
-            else {
-#pragma unroll
-                for (int j = 0; j < PULL_H; ++j) hd[r][j] = 0xFFFFFFFFu;
-            }
-        }
         bool need[PULL_R], found[PULL_R];
         u32 par[PULL_R];
         {
