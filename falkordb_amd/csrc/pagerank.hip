@@ -75,8 +75,9 @@ __device__ __forceinline__ double block_sum_256(double x, double* s_red) {
 __global__ __launch_bounds__(256) void pr_prep_kernel(const float* __restrict__ t, const float* __restrict__ d,
                                                      const unsigned char* __restrict__ sink,
                                                      const u64* __restrict__ act, u32 n, float* __restrict__ w,
-                                                     double* __restrict__ part) {
+                                                     double* __restrict__ part, const int* __restrict__ stop) {
     __shared__ double s_red[4];
+    if (*stop) return;   // converged earlier in this blind batch of iterations (fgpu_pagerank): the scores stay as they are
     const u32 v = blockIdx.x * 256 + threadIdx.x;
     double rs = 0.0;
     if (v < n) {
@@ -89,13 +90,25 @@ __global__ __launch_bounds__(256) void pr_prep_kernel(const float* __restrict__ 
 }
 
 // out[0] = base + scale * sum(part[0..np))  — one workgroup, fixed order
+// `state` = {stop, iterations done}: the reduction that closes an iteration (`closing`) counts it and raises `stop` once the
+// 1-norm of the change is within tol — the test LAGr_PageRank makes on the host, made here so that the host reads the
+// state once per batch of iterations instead of synchronising after every one.
 __global__ __launch_bounds__(256) void pr_reduce_kernel(const double* __restrict__ part, u32 np, float base, float scale,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, int* __restrict__ state, int closing,
+                                                       float tol) {
     __shared__ double s_red[4];
+    if (state[0]) return;
     double x = 0.0;
     for (u32 i = threadIdx.x; i < np; i += 256) x += part[i];
     const double tot = block_sum_256(x, s_red);
-    if (threadIdx.x == 0) out[0] = (float)((double)base + (double)scale * tot);
+    if (threadIdx.x == 0) {
+        const float o = (float)((double)base + (double)scale * tot);
+        out[0] = o;
+        if (closing) {
+            state[1] += 1;
+            if (!(o > tol)) state[0] = 1;
+        }
+    }
 }
 
 // r[v] = teleport + sum_{u in in(v)} w[u]   (rows < HUB_DEG; hub rows get teleport only, the chunks add the rest).
@@ -108,8 +121,9 @@ __global__ __launch_bounds__(256) void pr_reduce_kernel(const double* __restrict
 __global__ __launch_bounds__(256) void pr_spmv_kernel(CsrView at, const u64* __restrict__ act, u32 n,
                                                      const float* __restrict__ w, const float* __restrict__ tele,
                                                      const float* __restrict__ t, float* __restrict__ r,
-                                                     double* __restrict__ part) {
+                                                     double* __restrict__ part, const int* __restrict__ stop) {
     __shared__ double s_red[4];
+    if (*stop) return;
     __shared__ u32 s_off[4][65];     // exclusive prefix of the word's effective row lengths
     __shared__ u32 s_rb[4][64];      // first entry of each row
     __shared__ double s_acc[4][64];  // FP64 row sums (ds_add_f64): the order of the adds stops mattering at FP32
@@ -176,8 +190,9 @@ __global__ __launch_bounds__(256) void pr_spmv_kernel(CsrView at, const u64* __r
 // partial goes to hpart[h] (no atomics: every chunk has its own slot)
 __global__ __launch_bounds__(256) void pr_hub_kernel(const u32* __restrict__ hub, u32 n_hub, const u32* __restrict__ col,
                                                     const u64* __restrict__ act, const float* __restrict__ w,
-                                                    double* __restrict__ hpart) {
+                                                    double* __restrict__ hpart, const int* __restrict__ stop) {
     __shared__ double s_red[4];
+    if (*stop) return;
     for (u32 h = blockIdx.x; h < n_hub; h += gridDim.x) {
         const u32 row = hub[3 * h], b = hub[3 * h + 1], e = hub[3 * h + 2];
         double s = 0.0;
@@ -195,8 +210,9 @@ __global__ __launch_bounds__(256) void pr_hub_finish_kernel(const u32* __restric
                                                            const u32* __restrict__ rowptr, const u64* __restrict__ act,
                                                            const double* __restrict__ hpart, const float* __restrict__ tele,
                                                            const float* __restrict__ t, float* __restrict__ r,
-                                                           double* __restrict__ part) {
+                                                           double* __restrict__ part, const int* __restrict__ stop) {
     __shared__ double s_red[4];
+    if (*stop) return;
     const float tp = tele[0];
     double x = 0.0;
     for (u32 h = threadIdx.x; h < n_hub; h += 256) {
@@ -307,43 +323,60 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
         FGPU_HIP(hipGetLastError());
         const float teleport0 = (1.0f - damping) / fn, damp_over_n = damping / fn;
         const CsrView vat = view_of(At);
-        float rdiff = 1.0f;
+        // Iterations are enqueued blind, PR_BATCH at a time; every kernel returns at once when the device-side `stop` is up,
+        // and the closing reduction of an iteration counts it and raises `stop` on convergence (same test, same order of
+        // operations as a host loop that reads rdiff after every iteration: the scores are bit-identical) — one
+        // synchronisation per batch instead of one per iteration.
+        constexpr int PR_BATCH = 4;
+        DevBuf<int> state;
+        FGPU_TRY(state.alloc(ctx, 2));
+        FGPU_HIP(hipMemsetAsync(state.p, 0, 2 * sizeof(int), ctx->stream()));
         int it = 0;
+        bool stopped = !(1.0f > tol);   // (the host loop started from rdiff = 1)
         float* rp = r.p;   // current scores
         float* tp = t.p;   // previous scores
         const bool timing = getenv("FGPU_PR_TIMING") != nullptr;
         hipEvent_t ev[6];
         float acc_ms[5] = {0, 0, 0, 0, 0};
         if (timing) for (auto& e : ev) (void)hipEventCreate(&e);
-        for (; it < itermax && rdiff > tol; ++it) {
-            float* tmp = tp; tp = rp; rp = tmp;   // t = old r
-            if (timing) (void)hipEventRecord(ev[0], ctx->stream());
-            hipLaunchKernelGGL(pr_prep_kernel, dim3(nb), dim3(256), 0, ctx->stream(), (const float*)tp,
-                               (const float*)d.p, (const unsigned char*)sink.p, (const u64*)act.p, n, w.p, part.p);
-            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part.p, nb,
-                               teleport0, damp_over_n, scal.p);
-            if (timing) (void)hipEventRecord(ev[1], ctx->stream());
-            hipLaunchKernelGGL(pr_spmv_kernel, dim3(grid), dim3(256), 0, ctx->stream(), vat, (const u64*)act.p, n,
-                               (const float*)w.p, (const float*)scal.p, (const float*)tp, rp, part2.p + 1);
-            if (timing) (void)hipEventRecord(ev[2], ctx->stream());
-            if (At->n_hub_chunks) {
-                const u32 hg = At->n_hub_chunks < (u32)ctx->cus * 8 ? At->n_hub_chunks : (u32)ctx->cus * 8;
-                hipLaunchKernelGGL(pr_hub_kernel, dim3(hg), dim3(256), 0, ctx->stream(), (const u32*)At->hub_chunks,
-                                   At->n_hub_chunks, (const u32*)At->colidx, (const u64*)act.p, (const float*)w.p, hpart.p);
-                hipLaunchKernelGGL(pr_hub_finish_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const u32*)At->hub_chunks,
-                                   At->n_hub_chunks, (const u32*)At->rowptr, (const u64*)act.p, (const double*)hpart.p,
-                                   (const float*)scal.p, (const float*)tp, rp, part2.p);
-            } else {
-                FGPU_HIP(hipMemsetAsync(part2.p, 0, sizeof(double), ctx->stream()));
+        while (it < itermax && !stopped) {
+            const int batch = timing ? 1 : (itermax - it < PR_BATCH ? itermax - it : PR_BATCH);
+            for (int bi = 0; bi < batch; ++bi) {
+                float* tmp = tp; tp = rp; rp = tmp;   // t = old r
+                if (timing) (void)hipEventRecord(ev[0], ctx->stream());
+                hipLaunchKernelGGL(pr_prep_kernel, dim3(nb), dim3(256), 0, ctx->stream(), (const float*)tp,
+                                   (const float*)d.p, (const unsigned char*)sink.p, (const u64*)act.p, n, w.p, part.p,
+                                   (const int*)state.p);
+                hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part.p, nb,
+                                   teleport0, damp_over_n, scal.p, state.p, 0, 0.0f);
+                if (timing) (void)hipEventRecord(ev[1], ctx->stream());
+                hipLaunchKernelGGL(pr_spmv_kernel, dim3(grid), dim3(256), 0, ctx->stream(), vat, (const u64*)act.p, n,
+                                   (const float*)w.p, (const float*)scal.p, (const float*)tp, rp, part2.p + 1,
+                                   (const int*)state.p);
+                if (timing) (void)hipEventRecord(ev[2], ctx->stream());
+                if (At->n_hub_chunks) {
+                    const u32 hg = At->n_hub_chunks < (u32)ctx->cus * 8 ? At->n_hub_chunks : (u32)ctx->cus * 8;
+                    hipLaunchKernelGGL(pr_hub_kernel, dim3(hg), dim3(256), 0, ctx->stream(), (const u32*)At->hub_chunks,
+                                       At->n_hub_chunks, (const u32*)At->colidx, (const u64*)act.p, (const float*)w.p, hpart.p,
+                                       (const int*)state.p);
+                    hipLaunchKernelGGL(pr_hub_finish_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const u32*)At->hub_chunks,
+                                       At->n_hub_chunks, (const u32*)At->rowptr, (const u64*)act.p, (const double*)hpart.p,
+                                       (const float*)scal.p, (const float*)tp, rp, part2.p, (const int*)state.p);
+                } else {
+                    FGPU_HIP(hipMemsetAsync(part2.p, 0, sizeof(double), ctx->stream()));
+                }
+                if (timing) (void)hipEventRecord(ev[3], ctx->stream());
+                hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part2.p, grid + 1,
+                                   0.0f, 1.0f, scal.p + 1, state.p, 1, tol);
+                if (timing) (void)hipEventRecord(ev[4], ctx->stream());
+                FGPU_HIP(hipGetLastError());
             }
-            if (timing) (void)hipEventRecord(ev[3], ctx->stream());
-            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part2.p, grid + 1,
-                               0.0f, 1.0f, scal.p + 1);
-            if (timing) (void)hipEventRecord(ev[4], ctx->stream());
-            FGPU_HIP(hipGetLastError());
-            FGPU_HIP(hipMemcpyAsync(ctx->pinned(), scal.p + 1, sizeof(float), hipMemcpyDeviceToHost, ctx->stream()));
+            int hstate[2] = {0, 0};
+            FGPU_HIP(hipMemcpyAsync(ctx->pinned(), state.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream()));
             FGPU_HIP(hipStreamSynchronize(ctx->stream()));
-            memcpy(&rdiff, ctx->pinned(), sizeof(float));
+            memcpy(hstate, ctx->pinned(), sizeof(hstate));
+            stopped = hstate[0] != 0;
+            it = hstate[1];
             if (timing) {
                 for (int k = 0; k < 4; ++k) {
                     float ms = 0;
@@ -352,6 +385,8 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
                 }
             }
         }
+        // the scores of iteration `it` sit in t's buffer after an odd number of executed iterations, in r's after an even one
+        rp = (it & 1) ? t.p : r.p;
         if (timing) {
             fprintf(stderr, "fgpu_pagerank timing over %d iterations (ms): prep+reduce %.3f  spmv %.3f  hubs %.3f  "
                             "final reduce %.3f  (n_hub_chunks %u)\n", it, acc_ms[0], acc_ms[1], acc_ms[2], acc_ms[3],

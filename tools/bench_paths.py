@@ -169,7 +169,7 @@ def bench_pagerank(ctx, scale):
                       "GBps": round(b_alg * it / dt / 1e9, 1), "frac_hbm": round(b_alg * it / dt / 8e12, 4),
                       "default_run": {"tol": 1e-4, "iterations": it2, "ms": round(dt2 * 1e3, 3)},
                       "sum": round(float(scores.astype(np.float64).sum()), 6),
-                      "note": "whole fgpu_pagerank call incl. one host sync per iteration and the D2H of the scores"}), flush=True)
+                      "note": "whole fgpu_pagerank call incl. one host sync per four iterations and the D2H of the scores"}), flush=True)
 
 
 def bench_host(scale):
