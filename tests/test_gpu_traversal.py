@@ -400,6 +400,47 @@ def test_bfs_max_level(ctx, max_level):
     check_bfs(a, level, parent, src, ref_level)
 
 
+def test_one_call_bfs_keeps_and_replaces_its_plan(ctx):
+    """fgpu_bfs (the reference's one-function entry) keeps the plan of the last (A, At) pair on A: repeated calls, a call
+    with parents after one without, another transpose handle, no transpose, an option change, a second adjacency over the
+    same transpose and the release of the transpose before the adjacency all answer like the oracle."""
+    a = oracle.rmat_csr(13)
+    A = up(ctx, a)
+    At = A.transpose()
+    deg = np.diff(a.rowptr)
+    roots = [int(x) for x in np.nonzero(deg > 0)[0][:4]]
+
+    def check(A_, At_, src, want_parent, max_level=-1):
+        ref_level, _, ref_edges = oracle.bfs(a, src, max_level)
+        level, parent, edges = engine.bfs(ctx, A_, At_, src, max_level, want_parent=want_parent)
+        if want_parent:
+            check_bfs(a, level, parent, src, ref_level)
+        else:
+            np.testing.assert_array_equal(level, ref_level)
+        if max_level < 0:
+            assert edges == ref_edges
+
+    for i, src in enumerate(roots):                 # same pair: the plan is reused, with and without parents
+        check(A, At, src, want_parent=bool(i & 1))
+    check(A, At, roots[0], True, max_level=2)
+    At2 = A.transpose()                             # another handle of the transpose: the plan is rebuilt over it
+    check(A, At2, roots[1], True)
+    check(A, None, roots[2], False)                 # push only
+    check(A, At, roots[3], True)
+    ctx.set_option("bfs_hub_first", 0)              # options are read at plan creation: the cached plan must not survive
+    check(A, At, roots[0], True)
+    ctx.set_option("bfs_hub_first", 1)
+    check(A, At, roots[1], False)
+    B = up(ctx, a)                                  # a second adjacency over the same transpose takes the link over
+    check(B, At, roots[2], True)
+    check(A, At, roots[3], True)
+    At.free()                                       # the transpose goes first: A's (or B's) plan is dropped with it
+    check(A, At2, roots[0], True)
+    check(B, None, roots[1], False)
+    At2.free()
+    check(A, None, roots[2], False)
+
+
 def test_bfs_push_only_without_transpose(ctx):
     a = oracle.rmat_csr(12)
     A = up(ctx, a)
