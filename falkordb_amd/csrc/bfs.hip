@@ -401,6 +401,8 @@ struct QueueCtx {
     u32* qlen;  // its length counter
     u32* hubs;
     bool open;  // level-uniform
+    bool nohint;  // level-uniform: a light level (a few thousand edges) goes straight to the atomic — the visited hint is a
+                  // round trip of its own, worth it only where it saves the memory side many atomics
 };
 
 // must be reached by all 64 lanes together
@@ -435,7 +437,7 @@ __device__ __forceinline__ bool fused_visit(const BfsArgs& a, u32* __restrict__ 
                                             i32 newlevel, u32 u, u32 v, QueueCtx& qc, LevelAcc& acc) {
     const u32 bit = 1u << (u & 31);
     const u32 w = u >> 5;
-    if (vis32[w] & bit) return false;  // possibly stale: worst case one redundant atomic
+    if (!qc.nohint && (vis32[w] & bit)) return false;  // possibly stale: worst case one redundant atomic
     const u32 old = atomicOr(&vis32[w], bit);
     if (old & bit) return false;
     a.level[u] = newlevel;
@@ -1109,6 +1111,7 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
     qc.qlen = &c->qlen[(rot + 1) & 1][(blockIdx.x % QSHARDS) * 16];
     qc.hubs = &c->hubs[(rot + 1) & 1];
     qc.open = !slab && c->q_open != 0;
+    qc.nohint = use_q != 0 && c->m_frontier <= 16384ull;
     DBG_STAMP(0);
 #ifdef FGPU_BFS_STAMPS
     if (g_bfs_dbg && threadIdx.x == 0) {
@@ -1214,6 +1217,7 @@ __global__ __launch_bounds__(256) void bfs_tiny_kernel(BfsArgs a) {
         qc.qlen = &c->qlen[(rot + 1) & 1][(t >> 6) * 16];
         qc.hubs = &c->hubs[(rot + 1) & 1];
         qc.open = q_open != 0;
+        qc.nohint = true;
         __syncthreads();
         push_fused<PARENT, true>(a, cur, a.queue[rot & 1], &c->qlen[rot & 1][0], qmax, qchunk, false, a.visited, nxt,
                                  newlevel, qc, acc, 1u);
