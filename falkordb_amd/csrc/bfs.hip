@@ -932,7 +932,7 @@ __device__ __forceinline__ u32 done_word_of(u32 heavy_begin, u32 heavy_end, i32 
     return 0x80000000u | (tl << 24) | lv;
 }
 
-// End-of-level control, run by the first wavefront of the LAST workgroup to finish (ticket below):
+// End-of-level control, run by the first wavefront of the LAST workgroup to finish (the slot tickets, see the end of bfs_fused_kernel):
 // sums the statistic slots, advances level / rotation / queue, applies the push<->pull rule and
 // raises `done`.  Same arithmetic as bfs_ctrl_kernel (the multi-rank path keeps that kernel).
 // Every field it needs is loaded BEFORE its first store: written as read-modify-write statements on `c` the function was a
@@ -1089,8 +1089,9 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
     if (blockIdx.x >= nwg) return;
     const u32 rot = c->rot;
     const bool slab = a.slab_mode != 0;
-    // slab plans read the frontier the all-gather just delivered and write their owned words of the next one
-    // into this level's send buffer (pointer pre-offset so that GLOBAL word indices work)
+    // slab plans read the frontier the exchange just delivered and write their owned words of the next one into this
+    // level's send buffer — or, for an in-place plan, straight into the next gathered bitmap (fgpu_bfs_plan::slab_ring) —
+    // through a pointer pre-offset so that GLOBAL word indices work
     const u64* cur = slab ? a.nxt_global : a.bm[rot % 3];
     u64* nxt = slab ? (a.slab_nxt - (a.lo >> 6)) : a.bm[(rot + 1) % 3];
     u64* zr = slab ? a.slab_zero : a.bm[(rot + 2) % 3];
