@@ -1,26 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — TEPS of the boolean-vxm BFS and of the k-hop MATCH chain on synthetic R-MAT graphs (BASELINE.json metric).
+"""bench.py — BASELINE.json's metric: traversed edges/sec (TEPS) on k-hop MATCH over synthetic R-MAT graphs, with the
+fraction of the HBM roofline of the dominant kernel.
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" is one whole BFS (the GrB_vxm frontier loop behind algo.BFS) from one of the 64
-Graph500-style roots of a synthetic R-MAT graph resident in HBM.  N=1 runs BASELINE.json
-configs[1] (RMAT scale-22, edge factor 16).  N>1 runs the same path on a column-slab partition
-balanced by nnz (one process per GPU, one frontier all-gather-v over RCCL/xGMI per level).
+A "step" is ONE 1024-source batch of `MATCH (a:P)-->()-->()-->(c)` through the device core of
+CondTraverseOp::expand_batch (cond_traverse.rs:452-751: F = build(sources); F = delta_lmxm(F; hop) for each of the three
+hops, matrix.rs:1317-1402) = one fgpu_expand_count call (count + order-independent checksum of the (row, dest) result,
+H2D of the sources and D2H of the result included, adjacency and its cached transpose resident in HBM).  The graph is
+R-MAT scale 22 (edge factor 16, directed, deduplicated; `--scale` changes it), sources = the synthetic label :P
+(hash(id) % 16 == 0) in ascending id order, clean layers.  W untimed batches, then exactly K timed ones between two
+fences (barrier + torch.cuda.synchronize()); `value` = sum over the K steps (and over the ranks) of the traversed edges
+(sum over hops of flops) / max-over-ranks wall time.
 
-N > 1 runs RMAT-26 (BASELINE config 4: the same graph at every N, strong scaling, `--gpus 1 --scale 26` is the base
-point); the level loop and the per-level frontier exchange run inside libfgpu.so (fgpu_bfs_dist_run over an RCCL
-communicator the library owns), torch.distributed only launches the ranks, carries the communicator id and fences.
+N > 1: the source batches are sharded round-robin over the ranks (rank r takes batches r, r + N, ...), the adjacency is
+replicated, no collective on the data path (k-hop MATCH shards its source rows) — weak scaling.  The
+RMAT-26 BFS over column slabs with one RCCL frontier all-gather-v per level (BASELINE config 4) runs as a secondary leg
+of the same line (`secondary.bfs26_dist`; its single-GPU base point is `secondary.bfs26` of the N = 1 line).
 
-Rank 0 prints ONE JSON line; `value` = total traversed edges (sum over BFS runs of the
-out-degrees of reached vertices) / max-over-ranks wall time of the K steps.
-Extra objects: `roofline` (dominant kernel, HIP-event timed in a second pass over the same
-roots), `spmv_full_pass` (the north-star "RMAT-22 boolean SpMV" full-matrix pass), `khop_match`
-(BASELINE config 3: RMAT-24 3-hop MATCH as a masked GrB_mxm chain — CondTraverseOp::expand_batch's
-device core, cond_traverse.rs:452-751 / matrix.rs:1317-1402 — clean and dirty layers, with its own
-roofline object and CPU baseline) and `cpu_baseline` (the CPU oracle's BFS timed on this box's host
-cores, bounded sample).  `traffic` figures are HBM bytes per launch from rocprofv3 --pmc passes that
-bench.py runs over a reduced replay of the same workload (`--pmc-child`) at the end of the run.
+Rank 0 prints TWO lines: `DETAIL {...}` (every leg in full; also written to bench_detail.json) and then, LAST, the
+compact bench line (< 4 KB, asserted): metric / value / config of the headline, `roofline` of its dominant kernel
+(bp_pull_kernel<dense, count>: HIP-event average over the timed batches replayed, algorithmic bytes per launch, live PMC
+traffic), `cpu_baseline` (the oracle's OpenMP Gustavson chain on this box's host cores, bounded sample, quartiles),
+in-run `parity` against the oracle, and `secondary`: numbers only for BFS 22 / 26, boolean SpMV 22 / 24 / 26, k-hop
+24 / 26, dirty layers, the materialised form, the host-array entries and the config-5 stand-in.
 """
 from __future__ import annotations
 
@@ -104,8 +107,8 @@ def live_pmc(args, timeout_s=420):
         return {"error": "rocprofv3 not found"}
     out = tempfile.mkdtemp(prefix="fgpu_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--scale", str(args.scale or 22),
-             "--khop-scale", str(args.khop_scale)]
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--scale", str(args.scale or 22)] + \
+            (["--no-bfs"] if args.no_bfs else [])
     raw = {}
     t0 = time.time()
     try:
@@ -537,63 +540,403 @@ def strong_scaling_base(ctx, engine, args, scale=26, steps=32, warmup=8):
 
 
 def pmc_child(args):
-    """Reduced replay of the bench workloads for the rocprofv3 --pmc passes (live_pmc): no timing, no JSON line."""
+    """Reduced replay of the bench workloads for the rocprofv3 --pmc passes (live_pmc): no timing, no JSON line.  One
+    graph (the headline scale): three k-hop batches clean, two dirty, the emitting path, then BFS searches with the
+    direction-named instantiations and the full-pass SpMV."""
     from falkordb_amd import engine
     ctx = engine.Context(0)
     scale = args.scale or 22
-    A = ctx.mat_rmat(scale, args.edge_factor, 0x5EED1234 + scale)
-    At = A.transpose()
-    roots = pick_roots(A, 8)
-    plan = engine.BfsPlan(ctx, A, At)
-    plan.run(roots[0], -1, False)
-    ctx.set_option("bfs_prof_split", 1)          # name push / pull launches for the profiler
-    plan.profile(True)
-    for r in roots:
-        plan.run(r, -1, False)
-    plan.profile(False)
-    At.build_tiles()
-    engine.bench_spmv(ctx, At, which=2, iters=4)
-    plan.free(); At.free(); A.free()
-    if not args.no_khop:
-        K, dp, dm, _ = khop_inputs(ctx, args.khop_scale, args.edge_factor)
-        srcs = p_label_sources(K.nrows)
-        for i in range(3):
-            b = srcs[i * 1024:(i + 1) * 1024]
-            engine.expand_count(ctx, b, [K] * 3)
-            if i:
-                engine.expand_count(ctx, b, [K] * 3, [dp] * 3, [dm] * 3)
-                m_, _ = engine.expand_mat(ctx, b, [K] * 2)          # the emitting path (bp_rows_kernel count / emit)
-                m_.free()
-        Kt = K.transpose()                                           # the blocked full-pass layout (scales past RMAT-22)
-        Kt.build_tiles()
-        engine.bench_spmv(ctx, Kt, which=2, iters=3)
-        Kt.free()
+    A, dp, dm, _ = khop_inputs(ctx, scale, args.edge_factor)
+    srcs = p_label_sources(A.nrows)
+    for i in range(3):
+        b = srcs[i * 1024:(i + 1) * 1024]
+        engine.expand_count(ctx, b, [A] * 3)
+        if i:
+            engine.expand_count(ctx, b, [A] * 3, [dp] * 3, [dm] * 3)
+            m_, _ = engine.expand_mat(ctx, b, [A] * 2)          # the emitting path (bp_rows_kernel count / emit)
+            m_.free()
+    if not args.no_bfs:
+        At = A.transpose()
+        roots = pick_roots(A, 8)
+        plan = engine.BfsPlan(ctx, A, At)
+        plan.run(roots[0], -1, False)
+        ctx.set_option("bfs_prof_split", 1)          # name push / pull launches for the profiler
+        plan.profile(True)
+        for r in roots:
+            plan.run(r, -1, False)
+        plan.profile(False)
+        At.build_tiles()
+        engine.bench_spmv(ctx, At, which=2, iters=4)
+        plan.free(); At.free()
+    dp.free(); dm.free(); A.free()
     ctx.sync()
     ctx.close()
+
+
+def _kernel_rows(prof, top=10):
+    return [{"kernel": k["kernel"], "ms_total": round(k["ms"], 3), "launches": k["launches"],
+             "avg_launch_us": round(k["ms"] / max(k["launches"], 1) * 1e3, 2),
+             "alg_bytes_per_launch": int(k["alg_bytes"] / max(k["launches"], 1)),
+             "GBps": round(k["alg_bytes"] / max(k["ms"], 1e-9) / 1e6, 1),
+             "frac": round(k["alg_bytes"] / max(k["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+            for k in sorted(prof, key=lambda k: -k["ms"])[:top]]
+
+
+def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, reduce_sum):
+    """THE timed region of the bench line (module docstring): K 1024-source batches of the 3-hop MATCH, clean layers,
+    fgpu_expand_count with the checksum, W untimed batches before.  Returns (line fields, detail, graph tuple)."""
+    hops, B = 3, 1024
+    t0 = time.time()
+    want_host = rank == 0 and not args.no_parity
+    A, dp, dm, host = khop_inputs(ctx, scale, args.edge_factor, want_host=want_host)
+    ctx.sync()
+    t_build = time.time() - t0
+    n, nnz = A.nrows, A.nvals
+    srcs = p_label_sources(n)
+    nb_all = len(srcs) // B
+
+    def batch(i):                                   # this rank's i-th batch: round-robin over the ranks, cycling the :P set
+        j = (rank + i * world) % nb_all
+        return srcs[j * B:(j + 1) * B]
+    clean = ([A] * hops, None, None)
+    dirty = ([A] * hops, [dp] * hops, [dm] * hops)
+    # snapshot preparation (untimed, once per matrix version like the upload itself): the cached transpose of A, the pull
+    # item lists and the device pools are built by the first call that needs them
+    engine.expand_count(ctx, batch(0), *clean)
+    for i in range(args.warmup):
+        engine.expand_count(ctx, batch(i), *clean)
+    timed = [batch(i) for i in range(args.steps)]
+    fence()
+    t1 = time.perf_counter()
+    tot_f = tot_n = 0
+    cs = 0
+    first = None
+    for b in timed:
+        nn, c, f = engine.expand_count(ctx, b, *clean)
+        if first is None:
+            first = (nn, c, f)
+        tot_n += nn
+        tot_f += f
+        cs = (cs + c) & 0xFFFFFFFFFFFFFFFF
+    fence()
+    dt = reduce_max(time.perf_counter() - t1)
+    flops_all = reduce_sum(tot_f)
+    nnz_all = reduce_sum(tot_n)
+    line = {"value": round(flops_all / dt, 1), "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4)}
+    det = {"workload": f"RMAT scale-{scale} {hops}-hop MATCH (a:P)-->()-->()-->(c), CondTraverse expand_batch core (masked "
+                       f"GrB_mxm ANY_PAIR chain), sources = label :P (hash(id) % 16 == 0) in batches of {B}, clean layers",
+           "scale": scale, "vertices": int(n), "edges": int(nnz), "hops": hops, "batch_rows": B,
+           "label_P_sources": int(len(srcs)), "batches_in_P": nb_all, "build_seconds": round(t_build, 2),
+           "nnz_dp": int(dp.nvals), "nnz_dm": int(dm.nvals),
+           "timed": {"steps": args.steps, "warmup": args.warmup, "seconds": round(dt, 5), "flops": int(flops_all),
+                     "out_nnz": int(nnz_all), "rank0_checksum": f"{cs:016x}", "TEPS": line["value"]}}
+    if rank != 0:
+        return line, det, (A, dp, dm, host, timed, None)
+    # ---- the same batches again, untimed legs: count only, dirty layers, kernel table ------------------------------
+    ks = timed[:min(len(timed), 32)] or [batch(0)]
+
+    def run(bl, layers, cs_=True):
+        ctx.sync()
+        t = time.perf_counter()
+        fl = 0
+        for b in bl:
+            fl += engine.expand_count(ctx, b, *layers, want_checksum=cs_)[2]
+        d = time.perf_counter() - t
+        return {"ms_per_batch": round(d / len(bl) * 1e3, 3), "TEPS": round(fl / d, 1), "batches": len(bl)}
+    det["count_only"] = run(ks, clean, False)
+    for b in ks[:2]:
+        engine.expand_count(ctx, b, *dirty)
+    det["dirty"] = run(ks, dirty)
+    det["dirty_count_only"] = run(ks, dirty, False)
+    ctx.prof_enable(True)
+    for b in timed:
+        engine.expand_count(ctx, b, *clean)
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    det["kernels"] = _kernel_rows(prof)
+    roofline = None
+    kern = sorted(prof, key=lambda k: -k["ms"])
+    if kern:
+        d = kern[0]
+        ach = d["alg_bytes"] / max(d["ms"], 1e-9) / 1e6
+        roofline = {"bound": "hbm", "kernel": d["kernel"], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_launch": int(d["alg_bytes"] / d["launches"]),
+                    "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches": int(d["launches"]),
+                    "share_of_kernel_time": round(d["ms"] / max(sum(k["ms"] for k in kern), 1e-9), 3),
+                    "timing": "HIP events on the launching stream around each launch (fgpu_prof_*), the K timed batches replayed"}
+    lv = engine.expand_levels(ctx, timed[0], *clean)
+    det["batch0_hop_nnz"] = [int(x) for x in lv["hop_nnz"]]
+    return line, det, (A, dp, dm, host, timed, (first, roofline))
+
+
+def khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, batch0, gpu_first, scale):
+    """In-run parity of batch 0 (clean: the timed call's own result; dirty: one more call) against the oracle's delta_lmxm
+    chain, and the CPU baseline from that same oracle run: per 64-row chunk rates give the quartiles."""
+    import oracle
+    hops = 3
+    a, hdp, hdm = host
+    threads, ncpu, quota = cpu_threads()
+    rows = batch0
+    chunks = []
+    t1 = time.perf_counter()
+    ref_clean = oracle.expand_summary_omp(rows, [(a, None, None)] * hops, chunk=64, threads=threads, per_chunk=chunks)
+    t_clean = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    ref_dirty = oracle.expand_summary_omp(rows, [(a, hdp, hdm)] * hops, chunk=64, threads=threads)
+    t_dirty = time.perf_counter() - t1
+    gpu_dirty = engine.expand_count(ctx, rows, [A] * hops, [dp] * hops, [dm] * hops)
+    ok = tuple(gpu_first) == tuple(ref_clean[:3]) and tuple(gpu_dirty) == tuple(ref_dirty[:3])
+    parity = {"checked": True, "ok": bool(ok), "rows": int(len(rows)),
+              "what": "(nnz, checksum, flops) of timed batch 0, clean and dirty layers, fgpu_expand_count vs the oracle's "
+                      "delta_lmxm chain (oracle.expand_summary_omp; matrix.rs:1317-1402)",
+              "clean": {"nnz": int(ref_clean[0]), "checksum": f"{ref_clean[1]:016x}", "flops": int(ref_clean[2])},
+              "dirty": {"nnz": int(ref_dirty[0]), "checksum": f"{ref_dirty[1]:016x}", "flops": int(ref_dirty[2])}}
+    if not ok:
+        raise SystemExit(f"bench.py: k-hop parity FAILED at scale {scale}: gpu {gpu_first} / {gpu_dirty} vs oracle clean "
+                         f"{ref_clean[:3]} dirty {ref_dirty[:3]}")
+    rates = sorted(f / max(t, 1e-9) for f, t in chunks if f)
+    q = [rates[len(rates) // 4], rates[len(rates) // 2], rates[(3 * len(rates)) // 4]] if rates else [0, 0, 0]
+    cpu = {"value": round(ref_clean[2] / t_clean, 1), "unit": "TEPS", "cores": threads, "kind": "port",
+           "quartiles": [round(x, 1) for x in q],
+           "sample": f"timed batch 0 (1024 :P sources, 3 hops, clean layers, count + checksum): {t_clean:.1f} s of row-parallel "
+                     f"OpenMP Gustavson ANY_PAIR products (oracle/oracle_omp.c) on {threads} threads = the job's CPU quota "
+                     f"({ncpu} hardware threads visible); quartiles over its sixteen 64-row chunks; stand-in for "
+                     f"SuiteSparse:GraphBLAS GrB_mxm, absent from this image",
+           "dirty_TEPS": round(ref_dirty[2] / t_dirty, 1)}
+    return parity, cpu
+
+
+def bfs_single_leg(ctx, engine, args, scale, A=None, steps=64, warmup=8, want_prof=True, want_spmv=True):
+    """BASELINE config 2 (RMAT-22) / the base point of config 4 (RMAT-26): whole BFS searches (the boolean GrB_vxm frontier
+    loop behind algo.BFS) from the 64 Graph500-style roots, two plans pipelined, results on the device.  TEPS = sum of
+    out-degrees of reached vertices / wall time; per-direction kernel table from a level-synchronous replay."""
+    t0 = time.time()
+    own = A is None
+    if own:
+        A = ctx.mat_rmat(scale, args.edge_factor, 0x5EED1234 + scale)
+    At = A.transpose()
+    roots = pick_roots(A, 64)
+    plans = [engine.BfsPlan(ctx, A, At), engine.BfsPlan(ctx, A, At)]
+    for p in plans:
+        p.tune(alpha=args.alpha, force_direction=args.force_dir)
+    ctx.sync()
+    t_build = time.time() - t0
+    edges, st0 = {}, None
+    for r in roots:
+        plans[0].run(r, -1, False)
+        st = plans[0].stats()
+        edges[r] = st["edges_traversed"]
+        st0 = st0 or st
+
+    def pipelined(srcs):
+        for i, src in enumerate(srcs):
+            plans[i % 2].run_async(src, -1, False, 0)   # levels=0: one more than this plan's previous search took
+            if i > 0:
+                plans[(i - 1) % 2].wait()
+        if srcs:
+            plans[(len(srcs) - 1) % 2].wait()
+    pipelined([roots[i % len(roots)] for i in range(warmup)])
+    ctx.sync()
+    t1 = time.perf_counter()
+    pipelined([roots[i % len(roots)] for i in range(steps)])
+    ctx.sync()
+    dt = time.perf_counter() - t1
+    tot = sum(edges[roots[i % len(roots)]] for i in range(steps))
+    out = {"workload": f"RMAT scale-{scale} BFS (boolean GrB_vxm frontier loop), 64 Graph500-style roots, plan API (results on "
+                       f"the device, two plans pipelined)",
+           "scale": scale, "vertices": int(A.nrows), "edges": int(A.nvals), "TEPS": round(tot / dt, 1), "steps": steps,
+           "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "build_seconds": round(t_build, 2),
+           "root0": {k: st0[k] for k in ("levels", "push_levels", "pull_levels")}}
+    if want_prof:
+        plan = plans[0]
+        plan.profile(True)
+        for i in range(steps):
+            plan.run(roots[i % len(roots)], -1, False)
+        prof = [p for p in plan.profile_read() if p["launches"]]
+        plan.profile(False)
+        if prof:
+            launches = sum(p["launches"] for p in prof)
+            tot_ms = sum(p["ms"] for p in prof)
+            tot_b = sum(p["alg_bytes"] for p in prof)
+            for p in prof:
+                p["kernel"] = "bfs_fused_kernel " + p["kernel"].split(" ", 2)[-1]    # "(push level)" / "(pull level)"
+            out["roofline"] = {"kernel": "bfs_fused_kernel (every BFS level: push and pull launches)",
+                               "achieved": round(tot_b / tot_ms / 1e6, 2), "unit": "GB/s",
+                               "frac": round(tot_b / tot_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                               "alg_bytes_per_launch": int(tot_b / launches), "avg_launch_us": round(tot_ms / launches * 1e3, 2),
+                               "launches": int(launches), "levels_per_search": round(launches / steps, 2),
+                               "timing": "HIP events around each level launch of a level-synchronous replay of the same "
+                                         "roots (same kernel instantiation as the timed blind loop)",
+                               "by_direction": [dict(r, traffic=None) for r in _kernel_rows(prof)]}
+    # the fgpu_bfs ABI entry itself (host level[] array, one call per search) beside the plan API
+    k = min(steps, 16)
+    engine.bfs(ctx, A, At, roots[0], -1, want_parent=False)
+    t1 = time.perf_counter()
+    e_h = 0
+    for i in range(k):
+        _, _, e = engine.bfs(ctx, A, At, roots[i % len(roots)], -1, want_parent=False)
+        e_h += e
+    dth = time.perf_counter() - t1
+    out["host_arrays"] = {"entry": "fgpu_bfs (level[] returned in a host array, one call per search, nothing pipelined)",
+                          "steps": k, "ms_per_step": round(dth / k * 1e3, 4), "TEPS": round(e_h / dth, 1)}
+    for p in plans:
+        p.free()
+    if want_spmv and not args.no_roofline:
+        out["spmv_full_pass"] = spmv_pass(ctx, engine, At, scale, iters=50 if scale <= 22 else 12)
+    return out, A, At, roots, own
+
+
+def cpu_bfs_baseline(args, A, At, roots, scale, seconds):
+    """The oracle's OpenMP direction-optimising BFS on this box's host cores (CPU stand-in for LAGraph + SuiteSparse), a
+    bounded sample cycling the 64 roots; median + quartiles."""
+    import oracle
+    n = A.nrows
+    a = oracle.CSR(n, n, *A.export_csr()[:2])
+    at = oracle.CSR(n, n, *At.export_csr()[:2]) if At is not None and scale < 25 else None
+    threads, ncpu, quota = cpu_threads()
+    oracle.bfs_omp(a, at, roots[0], -1, threads=threads)
+    rates, t_cpu, k = [], 0.0, 0
+    while t_cpu <= seconds or k < 5:
+        r = roots[k % len(roots)]
+        t1 = time.perf_counter()
+        _, e = oracle.bfs_omp(a, at, r, -1, threads=threads)
+        d1 = time.perf_counter() - t1
+        t_cpu += d1
+        rates.append(e / d1)
+        k += 1
+    rates.sort()
+    return {"value": round(rates[len(rates) // 2], 1), "unit": "TEPS", "cores": threads, "kind": "port",
+            "quartiles": [round(rates[len(rates) // 4], 1), round(rates[(3 * len(rates)) // 4], 1)],
+            "sample": f"median over {k} searches cycling the 64 roots of RMAT-{scale} ({t_cpu:.1f} s), OpenMP push/pull BFS "
+                      f"(oracle/oracle_omp.c) on {threads} threads", "host_cpus_visible": ncpu, "cgroup_cpu_quota": quota}
+
+
+def bfs_dist_leg(ctx, engine, args, scale, rank, world, dev, td, torch, steps, warmup):
+    """BASELINE config 4: RMAT-<scale> BFS over a column-slab partition balanced by nnz, one rank per GPU, per level one
+    kernel per rank + one all-gather-v of the owned frontier words (grouped ncclSend / ncclRecv over RCCL/xGMI), loop and
+    collective inside libfgpu.so (fgpu_bfs_dist_run).  Strong scaling: the same graph at every N."""
+    t_build = time.time()
+    A_full = ctx.mat_rmat(scale, args.edge_factor, 0x5EED1234 + scale)
+    n, nnz = A_full.nrows, A_full.nvals
+    roots = pick_roots(A_full, 64)
+    splits = A_full.balanced_splits(world)
+    A = A_full.col_slab(int(splits[rank]), int(min(splits[rank + 1], n)))
+    A_full.free()
+    At = A.transpose()
+    uid = [ctx.comm_unique_id() if rank == 0 else None]
+    td.broadcast_object_list(uid, src=0, device=dev)
+    ctx.comm_init_rank(world, rank, uid[0])              # the communicator lives inside libfgpu.so
+    plan = engine.BfsPlan(ctx, A, At, rank, world, splits=splits)
+    plan.tune(alpha=args.alpha, force_direction=args.force_dir)
+    t = torch.zeros(world, dtype=torch.int64, device=dev)
+    t[rank] = A.nvals
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    slab_nnz = [int(x) for x in t.tolist()]
+    ctx.sync()
+    t_build = time.time() - t_build
+
+    def run_one(src):
+        engine.bfs_dist_run([plan], src, -1, False)
+    edges = {}
+    for r in roots:
+        run_one(r)
+        edges[r] = plan.stats()["edges_traversed"]
+    t = torch.tensor([edges[r] for r in roots], dtype=torch.int64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.SUM)                 # slab-local out-degree sums -> global
+    edges = {r: int(v) for r, v in zip(roots, t.tolist())}
+    for i in range(warmup):
+        run_one(roots[i % len(roots)])
+    td.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run_one(roots[i % len(roots)])
+    td.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    td.all_reduce(tt, op=td.ReduceOp.MAX)
+    dt = float(tt.item())
+    tot = sum(edges[roots[i % len(roots)]] for i in range(steps))
+    # time split of the same searches (HIP event pairs per level inside fgpu_bfs_dist_run), untimed replay
+    lm = cm = 0.0
+    nl = sc = rl = 0
+    ctx.set_option("dist_timing", 1)
+    k = min(steps, len(roots))
+    for i in range(k):
+        run_one(roots[i])
+        a_, b_, c_ = plan.dist_times()
+        st = plan.stats()
+        lm += a_; cm += b_; nl += c_
+        sc += st["scanned_push"] + st["scanned_pull"]
+        rl += st["reached"]
+    ctx.set_option("dist_timing", 0)
+    nw_bytes = ((n + 4095) // 4096 * 4096) // 8
+    alg = 4 * sc + 2 * nw_bytes * nl + 20 * rl           # column ids examined + both bitmaps per level + level/deg of owned discoveries
+    tt = torch.tensor([lm, cm], dtype=torch.float64, device=dev)
+    gathered = [torch.zeros_like(tt) for _ in range(world)]
+    td.all_gather(gathered, tt)
+    per_rank = [[float(x) for x in g.tolist()] for g in gathered]
+    out = {"workload": f"RMAT scale-{scale} BFS, adjacency in {world} column slab(s) balanced by nnz, one rank per GPU, one "
+                       f"RCCL all-gather-v of the frontier per level inside libfgpu.so",
+           "scale": scale, "vertices": int(n), "edges": int(nnz), "ranks": world, "TEPS": round(tot / dt, 1),
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "scaling": "strong",
+           "build_seconds": round(t_build, 2), "slab_splits": [int(x) for x in splits], "slab_nnz": slab_nnz,
+           "per_search_ms": {"level_kernels": round(lm / k, 4), "frontier_exchange": round(cm / k, 4)},
+           "per_rank_ms_per_search": [{"rank": r, "level_kernels": round(x[0] / k, 4), "frontier_exchange": round(x[1] / k, 4)}
+                                      for r, x in enumerate(per_rank)],
+           "levels_per_search": round(nl / k, 2), "frontier_bitmap_bytes": int(nw_bytes),
+           "rank0_level_kernel": {"alg_bytes_per_launch": int(alg / max(nl, 1)), "avg_launch_us": round(lm / max(nl, 1) * 1e3, 2),
+                                  "frac": round(alg / max(lm, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}}
+    plan.free(); At.free(); A.free()
+    return out
+
+
+def emit(line, detail):
+    """DETAIL line + sidecar first, the compact bench line LAST (the driver keeps the tail of stdout)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)        # RCCL's banner goes through C stdio: flush it before the JSON lines
+    except Exception:
+        pass
+    blob = json.dumps(detail)
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT, "/tmp"):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(blob)
+                break
+        except OSError:
+            continue
+    print("DETAIL " + blob, flush=True)
+    txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) < 4096, f"bench line is {len(txt)} bytes; the driver keeps only the tail of stdout"
+    print(txt, flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--scale", type=int, default=0, help="R-MAT scale (default: 22 on one GPU, 26 on several)")
+    ap.add_argument("--steps", type=int, default=64, help="timed 1024-source batches of the k-hop MATCH (per rank)")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed batches before them")
+    ap.add_argument("--scale", type=int, default=0, help="R-MAT scale of the headline leg (default 22)")
+    ap.add_argument("--leg", default="khop", choices=("khop", "bfs"),
+                    help="khop (default): the bench line.  bfs: only the BFS leg at --scale, its TEPS as `value` (tools; with "
+                         "--force-dist the multi-rank slab path on one rank)")
     ap.add_argument("--edge-factor", type=int, default=16)
-    ap.add_argument("--alpha", type=float, default=0.0, help="push->pull switch factor (0 = library default)")
-    ap.add_argument("--force-dir", type=int, default=0, help="0 auto, 1 push only, 2 pull only")
+    ap.add_argument("--alpha", type=float, default=0.0, help="BFS push->pull switch factor (0 = library default)")
+    ap.add_argument("--force-dir", type=int, default=0, help="BFS: 0 auto, 1 push only, 2 pull only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of the secondary CPU BFS baseline")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="--leg bfs: run the multi-rank code path even with one rank")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (fgpu_set_option)")
-    ap.add_argument("--no-khop", action="store_true", help="skip the k-hop MATCH leg (BASELINE config 3)")
-    ap.add_argument("--khop-scale", type=int, default=24, help="scale of the k-hop leg that carries the kernel table / PMC traffic")
-    ap.add_argument("--khop-batches", type=int, default=32, help="1024-source batches of the :P set to time (0 = all)")
-    ap.add_argument("--khop-extra-scales", default="22,26", help="further scales of the same leg (BASELINE metric: 22 / 26), fewer batches")
-    ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle checks of the k-hop legs")
-    ap.add_argument("--no-varlen", action="store_true", help="skip the config-5 stand-in leg ([*1..4] reach sets, sources sharded over the ranks)")
-    ap.add_argument("--no-scale-base", action="store_true", help="skip the RMAT-26 single-GPU base point of the scaling curve")
+    ap.add_argument("--quick", action="store_true", help="headline + parity + CPU baseline only (no secondary legs, no PMC)")
+    ap.add_argument("--khop-extra-scales", default="24,26", help="further scales of the k-hop leg (secondary)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle checks")
+    ap.add_argument("--no-bfs", action="store_true", help="skip the BFS / SpMV secondary legs")
+    ap.add_argument("--no-varlen", action="store_true", help="skip the config-5 stand-in leg")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (traffic = committed / null)")
+    ap.add_argument("--bfs-steps", type=int, default=64)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -609,16 +952,14 @@ def main():
 
     import torch
 
-    from falkordb_amd import dist as fdist
     from falkordb_amd import engine
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # --force-dist: drive the multi-rank code path (process group, column slab, slab backend, collectives)
-    # with world_size 1 — a smoke test of the N > 1 path on a 1-GPU box, not a benchmark configuration
     use_dist = world > 1 or args.force_dist
+    td = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -626,433 +967,192 @@ def main():
         import torch.distributed as td
         td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    # N = 1: BASELINE config 2 (RMAT-22).  N > 1: BASELINE config 4 / north_star's scaling curve — RMAT-26, the SAME
-    # graph at every N (strong scaling); `--gpus 1 --scale 26` gives the curve's base point on one device.
-    scale = args.scale or (26 if world > 1 else 22)
-    seed = 0x5EED1234 + scale
+    def fence():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_sum(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        return int(t.item())
+
     ctx = engine.Context(local_rank)
     info = ctx.device_info()
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
+    base = {"n_gpus": world, "higher_is_better": True, "vs_baseline": None, "dtype": "u32", "data": "synthetic"}
 
-    # ---- synthetic input, resident in HBM before anything is timed ----------------------
-    t_build = time.time()
-    A_full = ctx.mat_rmat(scale, args.edge_factor, seed)
-    n, nnz = A_full.nrows, A_full.nvals
-    roots = pick_roots(A_full, 64)
-    splits, slab_nnz = None, None
-    if use_dist:
-        # column-slab partition, boundaries balanced by nnz (prefix sum of in-degrees, multiples of 4096): rank r owns
-        # destinations [splits[r], splits[r+1]) and holds A[:, slab] (push) and A'[slab, :] (pull)
-        splits = A_full.balanced_splits(world)
-        A = A_full.col_slab(int(splits[rank]), int(min(splits[rank + 1], n)))
-        A_host = None
-        if rank == 0 and not args.no_cpu_baseline:
-            A_host = A_full.export_csr()[:2]       # the CPU baseline needs the whole graph; taken before it is freed
-        A_full.free()
-        At = A.transpose()
-        # the communicator lives inside libfgpu.so (fgpu_comm_*): the launcher's channel only carries the unique id
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        td.broadcast_object_list(uid, src=0, device=dev)
-        ctx.comm_init_rank(world, rank, uid[0])
-        plan = engine.BfsPlan(ctx, A, At, rank, world, splits=splits)
-        t = torch.zeros(world, dtype=torch.int64, device=dev)
-        t[rank] = A.nvals
-        td.all_reduce(t, op=td.ReduceOp.SUM)
-        slab_nnz = [int(x) for x in t.tolist()]
-    else:
-        A = A_full
-        At = A.transpose()
-        plan = engine.BfsPlan(ctx, A, At)
-    plan.tune(alpha=args.alpha, force_direction=args.force_dir)
-    ctx.sync()
-    t_build = time.time() - t_build
-
-    def run_one(src):
+    # ================= --leg bfs: the BFS leg alone (tools; --force-dist = the slab path on one rank) =================
+    if args.leg == "bfs":
+        scale = args.scale or (26 if world > 1 else 22)
         if use_dist:
-            engine.bfs_dist_run([plan], src, -1, False)   # level loop + frontier exchange inside the library
+            d = bfs_dist_leg(ctx, engine, args, scale, rank, world, dev, td, torch, args.steps, args.warmup)
         else:
-            plan.run(src, -1, False)
-
-    # single GPU: two plans (workspaces) over the same matrices, so the host enqueues search i+1
-    # while search i runs; every step is still one complete BFS and the stream executes them in order
-    plans = [plan] if use_dist else [plan, engine.BfsPlan(ctx, A, At)]
-    if not use_dist:
-        plans[1].tune(alpha=args.alpha, force_direction=args.force_dir)
-
-    def run_pipelined(srcs):
-        for i, src in enumerate(srcs):
-            plans[i % 2].run_async(src, -1, False, 0)   # levels=0: one more than this plan's previous search took
-            if i > 0:
-                plans[(i - 1) % 2].wait()
-        if srcs:
-            plans[(len(srcs) - 1) % 2].wait()
-
-    # ---- untimed pass over every distinct root: per-root traversed-edge counts + warm-up --
-    edges_by_root = {}
-    stats_by_root = {}
-    for r in roots:
-        run_one(r)
-        st = plan.stats()
-        edges_by_root[r] = st["edges_traversed"]
-        stats_by_root[r] = st
-    if use_dist:
-        t = torch.tensor([edges_by_root[r] for r in roots], dtype=torch.int64, device=dev)
-        td.all_reduce(t, op=td.ReduceOp.SUM)  # slab-local out-degree sums -> global
-        for r, v in zip(roots, t.tolist()):
-            edges_by_root[r] = int(v)
-    if use_dist:
-        for i in range(args.warmup):
-            run_one(roots[i % len(roots)])
-    else:
-        run_pipelined([roots[i % len(roots)] for i in range(args.warmup)])
-
-    # ---- timed region: exactly K steps ------------------------------------------------------
-    def fence():
+            d, A, At, roots, _ = bfs_single_leg(ctx, engine, args, scale, steps=args.steps, warmup=args.warmup)
+        if rank == 0:
+            line = dict(base, metric="traversed edges/sec (TEPS) on BFS (boolean vxm frontier loop), synthetic R-MAT",
+                        value=d["TEPS"], unit="TEPS", steps=args.steps, warmup=args.warmup, ms_per_step=d["ms_per_step"],
+                        scaling="strong" if world > 1 else "weak",
+                        config={"workload": d["workload"], "scale": scale, "device": info["name"]},
+                        roofline=None, cpu_baseline=None)
+            r = d.get("roofline")
+            if r:
+                line["roofline"] = {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": r["frac"], "traffic": None,
+                                    "alg_bytes_per_launch": r["alg_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"]}
+            emit(line, {"bfs": d})
         if use_dist:
             td.barrier()
-        torch.cuda.synchronize()
+            td.destroy_process_group()
+        return
 
-    fence()
-    t0 = time.perf_counter()
-    if use_dist:
-        for i in range(args.steps):
-            run_one(roots[i % len(roots)])
-    else:
-        run_pipelined([roots[i % len(roots)] for i in range(args.steps)])
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        dt = float(tt.item())
-    total_edges = sum(edges_by_root[roots[i % len(roots)]] for i in range(args.steps))
-    teps = total_edges / dt
-
-    # ---- multi-rank: time split of the timed searches (HIP events inside fgpu_bfs_dist_run), rank 0's view ---
-    roofline = None
-    spmv = None
-    dist_split = None
-    if use_dist:
-        lm = cm = 0.0
-        nl = sc = rl = 0
-        ctx.set_option("dist_timing", 1)                     # event pairs per level: only in this untimed replay
-        for i in range(min(args.steps, len(roots))):         # untimed replay: per-search event sums + scan counters
-            run_one(roots[i])
-            a_, b_, c_ = plan.dist_times()
-            st = plan.stats()
-            lm += a_; cm += b_; nl += c_
-            sc += st["scanned_push"] + st["scanned_pull"]
-            rl += st["reached"]
-        ctx.set_option("dist_timing", 0)
-        k = min(args.steps, len(roots))
-        nw_bytes = ((n + 4095) // 4096 * 4096) // 8
-        alg = 4 * sc + 2 * nw_bytes * nl + 20 * rl           # column ids examined + both bitmaps per level + level/deg of owned discoveries
-        tt = torch.tensor([lm, cm, float(alg), float(nl)], dtype=torch.float64, device=dev)
-        gathered = [torch.zeros_like(tt) for _ in range(world)]
-        td.all_gather(gathered, tt)
-        per_rank = [[float(x) for x in g.tolist()] for g in gathered]
-        if rank == 0:
-            ach = alg / max(lm, 1e-9) / 1e6
-            roofline = {"bound": "hbm", "kernel": "bfs_fused_kernel (slab mode: every BFS level of rank 0's column slab)",
-                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": None, "alg_bytes_per_launch": int(alg / max(nl, 1)),
-                        "avg_launch_us": round(lm / max(nl, 1) * 1e3, 2), "launches": int(nl),
-                        "timing": "HIP events around every level kernel and every frontier exchange inside "
-                                  "fgpu_bfs_dist_run, replay of the first roots after the timed region"}
-            dist_split = {"searches": k, "per_search_ms": {"level_kernels": round(lm / k, 4), "frontier_exchange": round(cm / k, 4)},
-                          "exchange": "all-gather-v of the ranks' owned frontier words into every rank's bitmap: grouped "
-                                      "ncclSend / ncclRecv over RCCL (xGMI), inside libfgpu.so; includes the wait for the slowest rank",
-                          "per_rank_ms_per_search": [{"rank": r, "level_kernels": round(x[0] / k, 4),
-                                                      "frontier_exchange": round(x[1] / k, 4)} for r, x in enumerate(per_rank)],
-                          "frontier_bitmap_bytes": int(nw_bytes), "levels_per_search": round(nl / k, 2)}
-
-    if not args.no_roofline and not use_dist:
-        plan.profile(True)
-        for i in range(args.steps):
-            plan.run(roots[i % len(roots)], -1, False)
-        prof = plan.profile_read()
-        plan.profile(False)
-        steps = [p for p in prof if p["launches"]]
-        if steps:
-            # The dominant kernel of the workload is bfs_fused_kernel: ONE kernel runs every level, and this pass
-            # launches the same instantiation (<.., 0>) as the timed blind level loop, one level at a time with
-            # the direction read back from the control block.  `roofline` is that kernel over all its level
-            # launches; the split by direction (push levels are latency / atomic bound, pull levels stream
-            # column ids) is in `by_direction`.  `traffic` is filled in by the live PMC passes at the end.
-            launches = sum(p["launches"] for p in steps)
-            tot_ms = sum(p["ms"] for p in steps)
-            tot_bytes = sum(p["alg_bytes"] for p in steps)
-            per_launch_bytes = tot_bytes / launches
-            per_launch_ms = tot_ms / launches
-            ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-            for p in steps:
-                p["kernel"] = "bfs_fused_kernel " + p["kernel"].split(" ", 2)[-1]    # "(push level)" / "(pull level)"
-            roofline = {"bound": "hbm", "kernel": "bfs_fused_kernel (every BFS level: push and pull launches)",
-                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": None,
-                        "alg_bytes_per_launch": int(per_launch_bytes), "avg_launch_us": round(per_launch_ms * 1e3, 2),
-                        "launches": int(launches),
-                        "timing": "HIP events on the ctx stream around each level launch of a second, level-synchronous "
-                                  "pass over the same roots (same kernel instantiation as the timed blind loop)",
-                        "by_direction": [{"kernel": p["kernel"], "ms_total": round(p["ms"], 4),
-                                          "launches": int(p["launches"]),
-                                          "avg_launch_us": round(p["ms"] / p["launches"] * 1e3, 2),
-                                          "alg_bytes_per_launch": int(p["alg_bytes"] / p["launches"]),
-                                          "traffic": None,
-                                          "GBps": round(p["alg_bytes"] / max(p["ms"], 1e-9) / 1e6, 2),
-                                          "frac": round(p["alg_bytes"] / max(p["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
-                                         for p in steps],
-                        "note": "BFS levels are latency / L2-line bound (bitmap probes, atomics); the HBM-bound "
-                                "kernel of this path is the full-pass boolean SpMV reported in spmv_full_pass"}
-        # the north-star full-matrix boolean SpMV pass (dense frontier, no mask, no early exit)
-        # (LDS-tiled layout, tiled.hip) with the CSR pull kernel's figure beside it
-        spmv = spmv_pass(ctx, engine, At, scale)
-
-    # ---- CPU baseline on this box's host cores, bounded sample, rank 0 / N=1 only -------------------
-    # The reference's path is LAGraph's push/pull BFS over SuiteSparse:GraphBLAS with OpenMP inside every
-    # vxm / mxv; neither library exists in this image, so the stand-in is the oracle's OpenMP
-    # direction-optimizing BFS (oracle/oracle_omp.c, same algorithm family) on every host core, with the
-    # serial queue BFS (oracle/oracle.c) beside it.  Baseline only: the roofline fraction is the quality bar.
-    cpu = None
-    if not args.no_cpu_baseline and rank == 0:
-        import oracle
-        rp, ci = A_host if use_dist else A.export_csr()[:2]
-        a = oracle.CSR(n, n, rp, ci)
-        A_host = None
-        at = None
-        if not use_dist and scale < 25:          # RMAT-25+ (17 GB of host arrays with the transpose): push-only baseline
-            trp, tci, _ = At.export_csr()
-            at = oracle.CSR(n, n, trp, tci)
-        # thread count = the job's CPU quota (cpu_threads): a team beyond it is throttled and its rate is noise
-        threads, ncpu, quota = cpu_threads()
-        oracle.bfs_omp(a, at, roots[0], -1, threads=threads)           # warm-up: page faults, thread team
-        e_cpu, t_cpu, k = 0, 0.0, 0
-        rates = []
-        budget = args.cpu_seconds * 0.7
-        while t_cpu <= budget or k < 5:                                 # cycle the 64 roots until the budget is spent
-            r = roots[k % len(roots)]
-            t1 = time.perf_counter()
-            _, e = oracle.bfs_omp(a, at, r, -1, threads=threads)
-            d1 = time.perf_counter() - t1
-            t_cpu += d1
-            e_cpu += e
-            rates.append(e / d1)
-            k += 1
-        rates.sort()
-        e_ser, t_ser, ks = 0, 0.0, 0
-        for r in roots:
-            t1 = time.perf_counter()
-            _, _, e = oracle.bfs(a, r, -1, want_parent=False)
-            t_ser += time.perf_counter() - t1
-            e_ser += e
-            ks += 1
-            if t_ser > args.cpu_seconds * 0.3:
-                break
-        cpu = {"value": round(rates[len(rates) // 2], 1), "unit": "TEPS", "cores": threads, "kind": "port",
-               "sample": f"median over {k} BFS runs cycling the 64 roots of the same RMAT-{scale} graph ({t_cpu:.1f} s; aggregate "
-                         f"{e_cpu / t_cpu / 1e9:.2f} GTEPS, quartiles {rates[len(rates) // 4] / 1e9:.2f} / "
-                         f"{rates[(3 * len(rates)) // 4] / 1e9:.2f}), OpenMP "
-                         f"{'push/pull' if at is not None else 'push-only (no transposed copy on the host at this size)'} BFS "
-                         f"(oracle/oracle_omp.c orc_bfs_omp) on {threads} threads = the job's CPU quota; CPU stand-in for "
-                         f"LAGraph + SuiteSparse:GraphBLAS, which are absent from this image",
-               "reference_libs_probe": probe_reference_libs(),
-               "host_cpus_visible": ncpu, "cgroup_cpu_quota": quota,
-               "serial": {"value": round(e_ser / t_ser, 1), "cores": 1,
-                          "sample": f"{ks} roots, {t_ser:.1f} s, serial queue BFS (oracle/oracle.c orc_bfs)"}}
-
-    # ---- base point of the strong-scaling curve the N > 1 runs measure (RMAT-26 on this one GPU) ----------
-    base26 = None
-    if world == 1 and not use_dist and scale == 22 and not args.no_scale_base:
-        base26 = strong_scaling_base(ctx, engine, args)
-
-    # ---- the fgpu_bfs ABI entry itself (host level[] array) beside the plan API the timed region uses -----------
-    bfs_host = None
-    if not use_dist and rank == 0 and world == 1:
-        k = min(args.steps, 16)
-        engine.bfs(ctx, A, At, roots[0], -1, want_parent=False)
-        t1 = time.perf_counter()
-        e_h = 0
-        for i in range(k):
-            _, _, e = engine.bfs(ctx, A, At, roots[i % len(roots)], -1, want_parent=False)
-            e_h += e
-        dth = time.perf_counter() - t1
-        bfs_host = {"entry": "fgpu_bfs (level[] returned in a host array, one call per search, nothing pipelined)",
-                    "steps": k, "ms_per_step": round(dth / k * 1e3, 4), "TEPS": round(e_h / dth, 1),
-                    "note": "the timed region uses the plan API (results stay on the device, two plans pipelined)"}
-
-    # ---- BASELINE config 3 / the metric's "k-hop MATCH, RMAT scale-22/26": k-hop legs -----------------------------
-    khop = None
-    khop_scales = {}
-    khop_emit = None
-    if not args.no_khop and not use_dist and rank == 0:
-        khop, (KA, Kdp, Kdm, Khost, kbatches) = khop_leg(ctx, engine, args, args.khop_scale, args.khop_batches)
-        if not args.no_roofline:
-            KAt = KA.transpose()
-            khop["spmv_full_pass"] = spmv_pass(ctx, engine, KAt, args.khop_scale, iters=20)
-            KAt.free()
-        khop_emit = khop_emit_leg(ctx, engine, args, KA, Khost, kbatches)
-        Kdp.free(); Kdm.free(); KA.free()
-        del Khost
-        for sc in [int(x) for x in args.khop_extra_scales.split(",") if x.strip()]:
-            # the same leg at the other scales BASELINE's metric names; scale 26: fewer batches, the oracle takes the
-            # first 128 rows of batch 0 (its chain for 1024 rows is ~1 minute of CPU at that size)
-            leg, (a_, dp_, dm_, _, _) = khop_leg(ctx, engine, args, sc, 8 if sc <= 24 else 4,
-                                                 parity_rows=1024 if sc <= 24 else 128)
-            dp_.free(); dm_.free(); a_.free()
-            leg.pop("kernels", None)
-            khop_scales[str(sc)] = leg
-
-    # ---- BASELINE config 5's stand-in: [*1..4] reach sets, sources sharded over the ranks, no collective ----------
-    varlen = None
-    if not args.no_varlen and (world > 1 or (not use_dist and not args.no_khop)):
-        fl_v, dt_v, nb_v, un_v = varlen_leg(ctx, engine, args, rank, world)
-        if world > 1:
-            tv = torch.tensor([float(fl_v), dt_v, float(nb_v), float(un_v)], dtype=torch.float64, device=dev)
-            mx = tv.clone()
-            td.all_reduce(tv, op=td.ReduceOp.SUM)
-            td.all_reduce(mx, op=td.ReduceOp.MAX)
-            fl_v, nb_v, un_v, dt_v = tv[0].item(), tv[2].item(), tv[3].item(), mx[1].item()
-        varlen = {"workload": "BASELINE config 5 stand-in (LDBC SF100 is not available offline): R-MAT scale 19, edge factor 38 "
-                              "(0.5 M vertices, ~20 M edges), `[*1..4]` reach sets (fgpu_expand_levels: per-hop frontiers + the "
-                              "DISTINCT union) from 1024-source batches of label :P, 0.1 % tombstones + pending adds on every hop",
-                  "sharding": f"source batches round-robin over {world} rank(s), adjacency replicated, no collective",
-                  "batches": int(nb_v), "TEPS": round(fl_v / dt_v, 1), "ms_per_batch_per_rank": round(dt_v / max(nb_v / world, 1) * 1e3, 3),
-                  "distinct_pairs": int(un_v), "scaling": "weak"}
-
-    # ---- HBM traffic per launch, measured now: rocprofv3 --pmc passes over a reduced replay -------------
-    pmc = None
-    if not args.no_pmc and not args.no_roofline and not use_dist and rank == 0:
-        pmc = live_pmc(args)
-
-        def hbm(name):
-            e = pmc.get(name) if isinstance(pmc, dict) else None
-            return e["hbm_bytes_per_dispatch"] if e else None
-        src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py over `--pmc-child` (reduced replay, "
-               "same graphs and kernels); FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes per launch")
-        if "error" in pmc:
-            src = f"live PMC passes failed ({pmc['error']}); committed profiles/traffic.json used where its source hash matches"
-        if roofline:
-            tot, cnt = 0, 0
-            for d in roofline["by_direction"]:                     # per direction, then weighted by this run's launches
-                d["traffic"] = hbm(d["kernel"])
-                if d["traffic"] is not None:
-                    tot += d["traffic"] * d["launches"]
-                    cnt += d["launches"]
-            roofline["traffic"] = int(tot / cnt) if cnt == roofline["launches"] and cnt else \
-                committed_traffic("bfs_fused_kernel", scale)
-            roofline["traffic_source"] = src
-        if spmv:
-            spmv["traffic"] = hbm(spmv["kernel"]) or committed_traffic("tiled_mxv_kernel", scale)
-            if khop and khop.get("spmv_full_pass"):
-                khop["spmv_full_pass"]["traffic"] = hbm(khop["spmv_full_pass"]["kernel"])
-        if khop and khop.get("roofline"):
-            khop["roofline"]["traffic"] = hbm(khop["roofline"]["kernel"])
-            khop["roofline"]["traffic_source"] = src
-            khop["pmc"] = {k: v for k, v in pmc.items() if k.startswith("bp_")} if "error" not in pmc else pmc
-        if khop_emit:
-            for leg in khop_emit.values():
-                for kk in leg["kernels"]:
-                    kk["traffic"] = hbm(kk["kernel"])
-
+    # ================= the bench line: k-hop MATCH =====================================================================
+    scale = args.scale or 22
+    line, head, (A, dp, dm, host, timed, extra) = khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max,
+                                                                reduce_sum)
+    detail = {"headline": head, "device": info}
+    sec = {}
+    roofline = parity = cpu = None
     if rank == 0:
-        st0 = stats_by_root[roots[0]]
-        # what BASELINE.json's metric names — k-hop MATCH TEPS at RMAT-22 / 24 / 26 and the fraction of the HBM roofline of the
-        # kernels on the path — in the keys the driver keeps (`config`, `roofline`); the full objects follow below
-        khop_summary = None
-        secondary = []
-        if khop:
-            def brief(leg):
-                return {"clean_TEPS": leg["clean"]["TEPS"], "clean_ms_per_batch": leg["clean"]["ms_per_batch"],
-                        "dirty_TEPS": leg["dirty"]["TEPS"], "dirty_ms_per_batch": leg["dirty"]["ms_per_batch"],
-                        "out_nnz_per_batch": leg["clean"]["out_nnz"] // leg["batches_timed"],
-                        "batches": leg["batches_timed"], "parity_checked": bool(leg["parity"].get("checked")),
-                        "parity_ok": leg["parity"].get("ok"), "parity_rows": leg["parity"].get("rows"),
-                        "cpu_TEPS": (leg.get("cpu_baseline") or {}).get("value")}
-            khop_summary = {"metric": "TEPS = traversed edges (sum over hops of flops) / wall time of fgpu_expand_count, 3-hop MATCH, "
-                                      "1024-source batches of label :P, RMAT scale -> figures",
-                            str(args.khop_scale): brief(khop)}
-            for sc, leg in khop_scales.items():
-                khop_summary[sc] = brief(leg)
-            if khop_emit:
-                khop_summary["materialised"] = {k: {"ms_per_batch": v["ms_per_batch"], "TEPS": v["TEPS"],
-                                                    "out_nnz_per_batch": v["out_nnz_per_batch"],
-                                                    "parity_ok": (v.get("parity") or {}).get("ok")}
-                                                for k, v in khop_emit.items()}
-            if khop.get("roofline"):
-                r_ = khop["roofline"]
-                secondary.append({"kernel": r_["kernel"], "workload": f"RMAT-{args.khop_scale} 3-hop MATCH, hop 3 (count)",
-                                  "achieved": r_["achieved"], "unit": "GB/s", "frac": r_["frac"], "traffic": r_["traffic"],
-                                  "alg_bytes_per_launch": r_["alg_bytes_per_launch"], "avg_launch_us": r_["avg_launch_us"]})
-            if khop_emit:
-                for nm, leg in khop_emit.items():
-                    for kk in leg["kernels"]:
-                        if kk["kernel"].startswith("bp_rows_kernel"):
-                            secondary.append({"kernel": kk["kernel"], "workload": f"RMAT-{args.khop_scale} {nm} emission (ballot transpose)",
-                                              "achieved": kk["GBps"], "unit": "GB/s", "frac": kk["frac"], "traffic": kk.get("traffic"),
-                                              "alg_bytes_per_launch": kk["alg_bytes_per_launch"], "avg_launch_us": kk["avg_launch_us"]})
-        for sp in (spmv, (khop or {}).get("spmv_full_pass"), (base26 or {}).get("spmv_full_pass")):
+        first, roofline = extra
+        sec["khop%d" % scale] = {"count_only_TEPS": head["count_only"]["TEPS"], "count_only_ms": head["count_only"]["ms_per_batch"],
+                                 "dirty_TEPS": head["dirty"]["TEPS"], "dirty_ms": head["dirty"]["ms_per_batch"]}
+        if not args.no_parity and host is not None:
+            parity, cpu = khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, timed[0], first, scale)
+            detail["parity"] = parity
+            if args.no_cpu_baseline:
+                cpu = None
+    host = None
+    full = rank == 0 and world == 1 and not args.quick
+    pmc = None
+    bfs22 = None
+    if full:
+        # ---- BFS + boolean SpMV at the headline scale (BASELINE config 2 when it is 22), on the same adjacency -------
+        if not args.no_bfs:
+            bfs22, _, At, roots, _ = bfs_single_leg(ctx, engine, args, scale, A=A, steps=args.bfs_steps, warmup=8)
+            if not args.no_cpu_baseline:
+                bfs22["cpu_baseline"] = cpu_bfs_baseline(args, A, At, roots, scale, args.cpu_seconds)
+            At.free()
+            detail["bfs%d" % scale] = bfs22
+    dp.free(); dm.free(); A.free()
+    if full:
+        # ---- k-hop at the other scales (BASELINE config 3 = RMAT-24; the metric's RMAT-26) ---------------------------
+        for sc in [int(x) for x in args.khop_extra_scales.split(",") if x.strip() and int(x) != scale]:
+            leg, (KA, Kdp, Kdm, Khost, kb) = khop_leg(ctx, engine, args, sc, 16 if sc <= 24 else 4,
+                                                      parity_rows=1024 if sc <= 24 else 128)
+            if sc == 24:
+                if not args.no_roofline:
+                    KAt = KA.transpose()
+                    leg["spmv_full_pass"] = spmv_pass(ctx, engine, KAt, sc, iters=20)
+                    KAt.free()
+                detail["khop_materialised"] = khop_emit_leg(ctx, engine, args, KA, Khost, kb)
+            Kdp.free(); Kdm.free(); KA.free()
+            del Khost
+            detail["khop%d" % sc] = leg
+            r_ = leg.get("roofline") or {}
+            sec["khop%d" % sc] = {"TEPS": leg["clean"]["TEPS"], "ms": leg["clean"]["ms_per_batch"],
+                                  "count_only_TEPS": leg["clean"]["count_only"]["TEPS"],
+                                  "dirty_TEPS": leg["dirty"]["TEPS"], "dirty_ms": leg["dirty"]["ms_per_batch"],
+                                  "batches": leg["batches_timed"], "hop3_frac": r_.get("frac"), "hop3_us": r_.get("avg_launch_us"),
+                                  "parity_ok": leg["parity"].get("ok"), "parity_rows": leg["parity"].get("rows"),
+                                  "cpu_TEPS": (leg.get("cpu_baseline") or {}).get("value")}
+        # ---- RMAT-26 BFS on this one GPU: base point of the multi-GPU curve (BASELINE config 4) ----------------------
+        if not args.no_bfs and scale != 26:
+            b26, A26, At26, _, _ = bfs_single_leg(ctx, engine, args, 26, steps=32, warmup=8, want_prof=False)
+            At26.free(); A26.free()
+            detail["bfs26"] = b26
+        # ---- BASELINE config 5's stand-in -----------------------------------------------------------------------------
+        if not args.no_varlen:
+            fl_v, dt_v, nb_v, un_v = varlen_leg(ctx, engine, args, 0, 1)
+            detail["config5_varlen"] = {
+                "workload": "BASELINE config 5 stand-in (LDBC SF100 is not available offline): R-MAT scale 19, edge factor 38 "
+                            "(0.5 M vertices, ~20 M edges), `[*1..4]` reach sets (fgpu_expand_levels) from 1024-source batches "
+                            "of label :P, 0.1 % tombstones + pending adds on every hop",
+                "batches": int(nb_v), "TEPS": round(fl_v / dt_v, 1), "ms_per_batch": round(dt_v / max(nb_v, 1) * 1e3, 3),
+                "distinct_pairs": int(un_v)}
+            sec["config5_varlen_TEPS"] = detail["config5_varlen"]["TEPS"]
+        # ---- HBM traffic per launch, measured now: rocprofv3 --pmc passes over a reduced replay -----------------------
+        if not args.no_pmc and not args.no_roofline:
+            pmc = live_pmc(args)
+            detail["pmc"] = pmc
+
+            def hbm(name):
+                e = pmc.get(name) if isinstance(pmc, dict) else None
+                return e["hbm_bytes_per_dispatch"] if e else None
+            if roofline:
+                roofline["traffic"] = hbm(roofline["kernel"])
+                roofline["traffic_source"] = ("live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --pmc-child` (same "
+                                              "graph and kernels); FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes per launch"
+                                              if "error" not in pmc else "live PMC passes failed: " + str(pmc["error"])[:120])
+            if bfs22 and bfs22.get("roofline"):
+                for d in bfs22["roofline"]["by_direction"]:
+                    d["traffic"] = hbm(d["kernel"])
+            if bfs22 and bfs22.get("spmv_full_pass"):
+                bfs22["spmv_full_pass"]["traffic"] = hbm(bfs22["spmv_full_pass"]["kernel"])
+    elif world > 1:
+        # ---- N > 1: BASELINE config 4 as a secondary leg of the same line ---------------------------------------------
+        if not args.no_bfs:
+            d = bfs_dist_leg(ctx, engine, args, 26, rank, world, dev, td, torch, 32, 8)
+            detail["bfs26_dist"] = d
+            sec["bfs26_dist"] = {"TEPS": d["TEPS"], "ms": d["ms_per_step"], "ranks": world, "scaling": "strong",
+                                 "level_kernels_ms": d["per_search_ms"]["level_kernels"],
+                                 "frontier_exchange_ms": d["per_search_ms"]["frontier_exchange"]}
+    if rank == 0:
+        if bfs22:
+            r = bfs22.get("roofline") or {}
+            dirs = {("push" if "push" in d["kernel"] else "pull"): d for d in r.get("by_direction", [])}
+            sec["bfs%d" % scale] = {"TEPS": bfs22["TEPS"], "ms": bfs22["ms_per_step"],
+                                    "push_frac": (dirs.get("push") or {}).get("frac"), "pull_frac": (dirs.get("pull") or {}).get("frac"),
+                                    "push_traffic": (dirs.get("push") or {}).get("traffic"),
+                                    "host_arrays_ms": bfs22["host_arrays"]["ms_per_step"],
+                                    "cpu_TEPS": (bfs22.get("cpu_baseline") or {}).get("value"),
+                                    "cpu_quartiles": (bfs22.get("cpu_baseline") or {}).get("quartiles")}
+        if detail.get("bfs26"):
+            sec["bfs26"] = {"TEPS": detail["bfs26"]["TEPS"], "ms": detail["bfs26"]["ms_per_step"],
+                            "host_arrays_ms": detail["bfs26"]["host_arrays"]["ms_per_step"]}
+        spm = {}
+        for key in ("bfs%d" % scale, "khop24", "bfs26"):
+            sp = (detail.get(key) or {}).get("spmv_full_pass")
             if sp:
-                secondary.append({"kernel": sp["kernel"], "workload": f"RMAT-{sp['scale']} full-matrix boolean SpMV pass (north-star case)",
-                                  "achieved": sp["achieved"], "unit": "GB/s", "frac": sp["frac"], "frac_warm": sp["warm"]["frac"],
-                                  "traffic": sp.get("traffic"), "alg_bytes_per_launch": sp["alg_bytes"],
-                                  "avg_launch_us": sp["avg_launch_us"], "cache_state": "cold"})
-        if roofline is not None:
-            roofline["secondary"] = secondary
-        out = {
-            "metric": "traversed edges/sec (TEPS) on BFS (boolean vxm frontier loop), synthetic R-MAT",
-            "value": round(teps, 1),
-            "unit": "TEPS",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 5),
-            "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"RMAT scale-{scale} BFS (boolean GrB_vxm frontier loop), edge factor {args.edge_factor}, "
-                            f"64 Graph500-style roots, directed, deduplicated",
-                "scale": scale, "vertices": int(n), "edges": int(nnz),
-                "parallelism": ("1 GPU" if not use_dist else
-                                f"{world} column slabs balanced by nnz, one rank per GPU; per level one kernel per rank + one "
-                                f"all-gather-v of the frontier bitmap over RCCL/xGMI, loop and collective inside libfgpu.so"),
-                "slab_splits": [int(x) for x in splits] if splits is not None else None,
-                "slab_nnz": slab_nnz,
-                "direction": {0: "auto push/pull", 1: "push only", 2: "pull only"}[args.force_dir],
-                "device": info["name"], "build_seconds": round(t_build, 2),
-                "root0_levels": st0["levels"], "root0_push_levels": st0["push_levels"],
-                "root0_pull_levels": st0["pull_levels"],
-                "khop_match": khop_summary,
-                "config5_varlen": ({"TEPS": varlen["TEPS"], "batches": varlen["batches"]} if varlen else None),
-            },
-            "roofline": roofline,
-            "time_split": dist_split,
-            "spmv_full_pass": spmv,
-            "rmat26_single_gpu": base26,
-            "bfs_host_arrays": bfs_host,
-            "khop_match": khop,
-            "khop_match_other_scales": khop_scales or None,
-            "khop_materialised": khop_emit,
-            "config5_varlen": varlen,
-            "cpu_baseline": cpu,
-            "pmc": ({k: v for k, v in pmc.items() if not k.startswith("bp_")} if pmc else None),
-        }
-        try:
-            # RCCL writes its version banner through C stdio, which would otherwise be flushed at exit — AFTER the JSON
-            # line; flush it first so that the bench line is the last line of stdout
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+                spm[str(sp["scale"])] = {"kernel": sp["kernel"].split("_")[0], "frac_cold": sp["frac"], "frac_warm": sp["warm"]["frac"],
+                                         "us_cold": sp["avg_launch_us"], "traffic": sp.get("traffic")}
+        if spm:
+            sec["spmv_full_pass"] = spm
+        em = detail.get("khop_materialised")
+        if em:
+            sec["materialised24"] = {k: {"ms_device": v["ms_per_batch"], "ms_host_arrays": v["host_arrays_ms_first_batch"],
+                                         "entries": v["out_nnz_per_batch"], "parity_ok": (v.get("parity") or {}).get("ok")}
+                                     for k, v in em.items()}
+        out = dict(base, metric=BASELINE_METRIC, value=line["value"], unit="TEPS", steps=args.steps, warmup=args.warmup,
+                   ms_per_step=line["ms_per_step"], scaling="weak",
+                   config={"workload": f"RMAT scale-{scale} 3-hop MATCH (a:P)-->()-->()-->(c), 1024-source batches, clean layers, "
+                                       f"count + checksum on device (fgpu_expand_count)",
+                           "scale": scale, "vertices": head["vertices"], "edges": head["edges"], "hops": 3, "batch_rows": 1024,
+                           "edge_factor": args.edge_factor, "device": info["name"],
+                           "parallelism": ("1 GPU" if world == 1 else f"{world} GPUs: source batches round-robin over the ranks, "
+                                                                      f"adjacency replicated, no collective")},
+                   roofline=roofline, cpu_baseline=cpu,
+                   parity=({"ok": parity["ok"], "rows": parity["rows"], "what": "timed batch 0 (nnz, checksum, flops), clean + dirty, "
+                            "vs oracle delta_lmxm chain"} if parity else {"checked": False}),
+                   secondary=sec, detail="DETAIL line above / bench_detail.json")
+        emit(out, detail)
     if use_dist:
         td.barrier()
         td.destroy_process_group()
+
+
+BASELINE_METRIC = "traversed edges/sec (TEPS) on k-hop MATCH, RMAT scale-22/26; % HBM roofline"
 
 
 if __name__ == "__main__":

@@ -35,6 +35,11 @@ SIGNATURES = {
     "fgpu_finalize": (C.c_int32, [vp]),
     "fgpu_last_error": (C.c_char_p, []),
     "fgpu_free": (None, [vp, vp]),
+    "fgpu_host_alloc": (C.c_int32, [vp, C.c_uint64, vpp]),
+    "fgpu_expand_stream_open": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, C.c_uint64, C.c_int, vpp,
+                                            u64p, u64p]),
+    "fgpu_expand_stream_next": (C.c_int32, [vp, u64p, u64p, C.POINTER(u64p), vpp]),
+    "fgpu_expand_stream_close": (C.c_int32, [vp]),
     "fgpu_set_stream": (C.c_int32, [vp, vp]),
     "fgpu_sync": (C.c_int32, [vp]),
     "fgpu_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int64]),

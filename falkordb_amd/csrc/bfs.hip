@@ -1547,6 +1547,13 @@ __global__ __launch_bounds__(256) void bfs_slab_begin_kernel(BfsArgs a, u64* sen
 }
 
 // level[v] = -1 wherever the search did not reach v (fused single-rank path, see bfs_fused_begin_kernel)
+// fgpu_bfs_fetch: the caller's parent[] (int64, -1 = none) from the stored u32 parents and the level vector
+__global__ __launch_bounds__(256) void bfs_parent_out_kernel(const u32* __restrict__ parent, const i32* __restrict__ level,
+                                                             long long* __restrict__ out, u32 n) {
+    for (u32 v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)
+        out[v] = level[v] >= 0 ? (long long)parent[v] : -1ll;
+}
+
 __global__ void bfs_mask_levels_kernel(i32* __restrict__ level, const u64* __restrict__ visited, u32 n_pad) {
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n_pad; v += gridDim.x * 256)
         if (!((visited[v >> 6] >> (v & 63)) & 1ull)) level[v] = -1;
@@ -2587,24 +2594,19 @@ fgpu_info fgpu_bfs_fetch(fgpu_bfs_plan* p, int32_t* level, int64_t* parent) {
         FGPU_HIP(hipGetLastError());
         p->levels_masked = true;
     }
-    std::vector<i32> lv;
-    const i32* lvp = level ? level + lo : nullptr;
-    if (level) {
-        FGPU_TRY(ctx->d2h(level + lo, p->level + lo, (size_t)(hi - lo) * sizeof(i32)));
-    } else if (parent) {
-        lv.resize(hi - lo);
-        FGPU_TRY(ctx->d2h(lv.data(), p->level + lo, (size_t)(hi - lo) * sizeof(i32)));
-        lvp = lv.data();
-    }
-    std::vector<u32> par;
+    if (level) FGPU_TRY(ctx->d2h(level + lo, p->level + lo, (size_t)(hi - lo) * sizeof(i32)));   // (one DMA when level[] is pinned)
     if (parent) {
         FGPU_REQUIRE(p->want_parent, FGPU_INVALID, "the last run did not track parents");
-        par.resize(hi - lo);
-        FGPU_TRY(ctx->d2h(par.data(), p->parent + lo, (size_t)(hi - lo) * sizeof(u32)));
+        // parent[v] = the stored u32 parent for reached vertices, -1 otherwise: widened on the device, then copied out like
+        // level[] (DMA into pinned memory, the staging ring into pageable memory)
+        DevBuf<long long> wide;
+        FGPU_TRY(wide.alloc(ctx, hi - lo));
+        hipLaunchKernelGGL(bfs_parent_out_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream(), p->parent + lo, p->level + lo,
+                           wide.p, hi - lo);
+        FGPU_HIP(hipGetLastError());
+        FGPU_TRY(ctx->d2h(parent + lo, wide.p, (size_t)(hi - lo) * sizeof(int64_t)));
     }
     FGPU_HIP(hipStreamSynchronize(ctx->stream()));
-    if (parent)
-        for (u32 v = lo; v < hi; ++v) parent[v] = (lvp[v - lo] >= 0) ? (int64_t)par[v - lo] : -1;
     return FGPU_OK;
 }
 
@@ -2667,26 +2669,42 @@ fgpu_info fgpu_bfs(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, uint64_
     fgpu_bfs_plan* p = nullptr;
     bool cached = false;
     std::unique_lock<std::mutex> lk(A->bfs_mu, std::defer_lock);
-    if (i == FGPU_OK && !dA && !dAt && lk.try_lock()) {
-        const uint64_t epoch = ctx->opt_epoch.load(std::memory_order_relaxed);
-        if (A->bfs_plan && (A->bfs_plan_at != At || A->bfs_plan->ctx != ctx || A->bfs_plan_epoch != epoch)) mat_drop_bfs_plan(A);
-        if (!A->bfs_plan) {
-            if (At && At->bfs_cached_in && At->bfs_cached_in != A) {   // the transpose serves one cached plan at a time
-                const fgpu_mat* other = At->bfs_cached_in;
-                std::unique_lock<std::mutex> lo(other->bfs_mu, std::try_to_lock);
-                if (lo.owns_lock() && other->bfs_plan_at == At) mat_drop_bfs_plan(other);
-            }
-            if (!At || !At->bfs_cached_in) {
-                i = fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1);
-                if (i == FGPU_OK) {
-                    A->bfs_plan = p;
-                    A->bfs_plan_at = At;
-                    A->bfs_plan_epoch = epoch;
-                    if (At) At->bfs_cached_in = A;
+    if (i == FGPU_OK && !dA && !dAt) {
+        // links change under the process-wide link mutex (taken before any matrix' bfs_mu, released before the search)
+        std::lock_guard<std::mutex> link(bfs_link_mu());
+        if (lk.try_lock()) {
+            const uint64_t epoch = ctx->opt_epoch.load(std::memory_order_relaxed);
+            if (A->bfs_plan && (A->bfs_plan_at != At || A->bfs_plan->ctx != ctx || A->bfs_plan_epoch != epoch)) mat_drop_bfs_plan(A);
+            if (!A->bfs_plan) {
+                if (At && At->bfs_cached_in && At->bfs_cached_in != A) {   // the transpose serves one cached plan at a time
+                    const fgpu_mat* other = At->bfs_cached_in;
+                    std::unique_lock<std::mutex> lo(other->bfs_mu, std::try_to_lock);
+                    if (lo.owns_lock() && other->bfs_plan_at == At) mat_drop_bfs_plan(other);
+                }
+                // one cached plan per context: the previous owner's goes first (left alone if a search is using it —
+                // this call then runs on a plan of its own)
+                bool room = true;
+                if (const fgpu_mat* prev = ctx->bfs_cache_owner) {
+                    if (prev != A) {
+                        std::unique_lock<std::mutex> lo(prev->bfs_mu, std::try_to_lock);
+                        if (lo.owns_lock()) mat_drop_bfs_plan(prev); else room = false;
+                    }
+                }
+                if (room && (!At || !At->bfs_cached_in)) {
+                    i = fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1);
+                    if (i == FGPU_OK) {
+                        A->bfs_plan = p;
+                        A->bfs_plan_at = At;
+                        A->bfs_plan_epoch = epoch;
+                        if (At) At->bfs_cached_in = A;
+                        A->bfs_plan_ctx = ctx;
+                        ctx->bfs_cache_owner = A;
+                    }
                 }
             }
+            if (A->bfs_plan) { p = A->bfs_plan; cached = true; }
+            else lk.unlock();
         }
-        if (A->bfs_plan) { p = A->bfs_plan; cached = true; }
     }
     if (i == FGPU_OK && !p) i = fgpu_bfs_plan_create(ctx, &p, A, At, 0, 1);
     if (i == FGPU_OK) i = fgpu_bfs_run(p, src, max_level, parent != nullptr);

@@ -1406,6 +1406,8 @@ fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu
     const u32 grid = nchunks * nwb;
     const u32 wmax = s.w < BP_ROWS_WB ? s.w : BP_ROWS_WB;
     const size_t lds_rows = (size_t)BP_ROWS_NB * 64 * (wmax + 1) * sizeof(u64) + (size_t)wmax * 64 * sizeof(u32) + BP_VCHUNK;
+    FGPU_REQUIRE(lds_rows <= (size_t)ctx->opt.lds_limit, FGPU_INVALID,
+                 "emission tile of a %u-word row needs %zu B of LDS, the device / lds_limit allows %d", s.w, lds_rows, ctx->opt.lds_limit);
     if (lds_rows > 48 * 1024) {
         FGPU_HIP(hipFuncSetAttribute((const void*)bp_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
         FGPU_HIP(hipFuncSetAttribute((const void*)bp_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));

@@ -83,6 +83,9 @@ struct fgpu_options {  // fgpu_set_option
                                // (all-gather-v, direct peer-to-peer over xGMI), 1 one ncclBroadcast per rank in a group
     int transpose_mode = 0;    // pattern transpose: 0 counting transpose (no sort), 1 COO rebuild through the sorter (A/B)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
+    int pinned_results = 1;    // result arrays >= 256 KiB come from the context's pinned-host pool and are filled by DMA (0 = the
+                               // caller's allocator / malloc + staged copies, the round-3 path; A/B)
+    int pinned_pool_mb = 4096; // pinned blocks kept for reuse after fgpu_free (beyond it they go back to the OS)
 };
 
 struct fgpu_lane {  // one per host thread using the context
@@ -96,11 +99,13 @@ struct fgpu_lane {  // one per host thread using the context
     hipEvent_t fence = nullptr;          // recorded on `stream` by a thread that frees a shared object (fence_mu)
     std::mutex fence_mu;
     bool bound = false;                  // a live thread holds it (ctx->mu)
-    // transfer staging (h2d / d2h): two pinned halves, allocated on the lane's first bulk transfer
+    // transfer staging (h2d / d2h to pageable caller memory): a ring of XFER_SLOTS pinned chunks, allocated on the lane's
+    // first bulk transfer; up to XFER_SLOTS - 1 device copies are on the link while the host drains the oldest
+    static constexpr int XFER_SLOTS = 4;
     void* xfer = nullptr;
-    size_t xfer_half = 0;
-    hipEvent_t xfer_ev[2] = {nullptr, nullptr};
-    bool xfer_busy[2] = {false, false};
+    size_t xfer_half = 0;                // bytes per slot
+    hipEvent_t xfer_ev[XFER_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool xfer_busy[XFER_SLOTS] = {false, false, false, false};
     int xfer_next = 0;
 };
 
@@ -115,6 +120,7 @@ struct fgpu_ctx {
     uint64_t id = 0;           // unique over the process lifetime (thread-local lane caches key on it)
     fgpu_options opt;
     std::atomic<uint64_t> opt_epoch{0};   // bumped by fgpu_set_option: cached BFS plans (fgpu_bfs) are rebuilt when it moved
+    const fgpu_mat* bfs_cache_owner = nullptr;   // the adjacency holding this context's one cached fgpu_bfs plan (under bfs_link_mu())
     void* (*mal)(size_t) = nullptr;
     void (*fre)(void*) = nullptr;
     int cus = 0;
@@ -122,6 +128,11 @@ struct fgpu_ctx {
     std::vector<fgpu_lane*> lanes;
     std::map<void*, size_t> live;       // capacity of live blocks
     uint64_t bytes_in_use = 0, bytes_pooled = 0;
+    // pinned-host result blocks ("outputs are pinned-host buffers owned by the caller until fgpu_free"):
+    // hipHostMalloc costs ~0.1 ms per MiB, so freed blocks are kept by capacity and handed out again
+    std::multimap<size_t, void*> pin_pool;
+    std::map<const void*, size_t> pin_live;   // block start -> capacity, for every block handed out
+    uint64_t pin_pooled = 0;
     // multi-GPU: this context's rank in an RCCL communicator (dist.hip); nullptr = not part of one
     void* comm = nullptr;               // ncclComm_t
     int comm_rank = 0, comm_nranks = 1;
@@ -156,8 +167,13 @@ struct fgpu_ctx {
     fgpu_info h2d(void* dev, const void* host, size_t bytes);
     fgpu_info d2h(void* host, const void* dev, size_t bytes);
     fgpu_info d2h_widen(uint64_t* host, const uint32_t* dev, size_t count);   // u32 on the device, u64 for the caller
-    void* host_alloc(size_t bytes);
-    void host_free(void* p);
+    // d2h / d2h_widen take the direct route — one DMA into `host`, the widening done by a kernel — when `host` is pinned
+    // (a block of the pool below, or memory the caller registered with HIP); pageable memory goes through the staging ring.
+    bool dma_able(const void* host, size_t bytes);
+    void* host_alloc(size_t bytes);     // the caller's allocator (small results, control data)
+    void* result_alloc(size_t bytes);   // result arrays: pinned pool from 256 KiB up, host_alloc below
+    void* pinned_alloc(size_t bytes);   // a block of the pinned pool (nullptr: out of memory)
+    void host_free(void* p);            // releases either kind
     void trim();
 };
 
@@ -174,6 +190,8 @@ struct ProfScope {
 };
 // add bytes to a record whose size is only known after a later read-back (e.g. the non-zero output rows of a hop)
 void prof_add_bytes(fgpu_ctx* ctx, int idx, uint64_t extra);
+// out_dev[i] = in_dev[i] for i < n on the calling lane's stream (u32 ids of the device -> the caller's u64 GrB_Index)
+fgpu_info widen_on_device(fgpu_ctx* ctx, uint64_t* out_dev, const uint32_t* in_dev, size_t n);
 }  // namespace fgpu
 
 namespace fgpu {
@@ -250,11 +268,13 @@ struct fgpu_mat {
     // fgpu_bfs (the one-call entry): the plan of the last (this, At) search is kept on the adjacency so that repeated calls
     // do not pay plan creation (pinned allocations, events, head array: 1.3 ms of a 2.2 ms call at RMAT-22).  `bfs_mu`
     // serialises its users; the transpose remembers which adjacency holds a plan over it (one at a time) so that releasing
-    // either matrix drops the plan first.
+    // either matrix drops the plan first.  The links are only changed under bfs_link_mu(); a context keeps ONE cached plan
+    // (fgpu_ctx::bfs_cache_owner): caching one on another adjacency drops the previous one.
     mutable std::mutex bfs_mu;
     mutable struct fgpu_bfs_plan* bfs_plan = nullptr;
     mutable const fgpu_mat* bfs_plan_at = nullptr;
     mutable uint64_t bfs_plan_epoch = 0;
+    mutable struct fgpu_ctx* bfs_plan_ctx = nullptr;   // the context whose one cached plan this is
     mutable const fgpu_mat* bfs_cached_in = nullptr;
     // bit-parallel expansion (bitexpand.hip): cached pattern transpose of this matrix, and (on that
     // transpose) its rows cut into items of <= 256 entries
@@ -363,7 +383,10 @@ fgpu_info compact_segments(fgpu_ctx* ctx, const u32* data, const u64* off, const
 // ---- matrix helpers (mat.hip) ---------------------------------------------------
 // free a snapshot no other thread has seen (temporaries, failed builds); fgpu_mat_free adds the cross-lane fence
 void mat_release(fgpu_mat* m);
-void mat_drop_bfs_plan(const fgpu_mat* a);   // caller holds a->bfs_mu
+void mat_drop_bfs_plan(const fgpu_mat* a);   // caller holds bfs_link_mu() and a->bfs_mu
+// One process-wide mutex orders every change of the (adjacency <-> transpose) plan links (bfs_plan / bfs_plan_at /
+// bfs_cached_in / fgpu_ctx::bfs_cache_owner): taken BEFORE any matrix' bfs_mu, released before a search runs.
+std::mutex& bfs_link_mu();
 fgpu_info mat_alloc(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, u64 nnz, bool with_vals,
                     u32 nvec_hyper, bool hyper);
 // (m \ dm) U dp, pattern only, on device (K3/K6).

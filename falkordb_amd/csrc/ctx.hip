@@ -85,7 +85,7 @@ fgpu_lane* lane_create() {
 void lane_destroy(fgpu_lane* l) {
     if (!l) return;
     if (l->fence) (void)hipEventDestroy(l->fence);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < fgpu_lane::XFER_SLOTS; ++k)
         if (l->xfer_ev[k]) (void)hipEventDestroy(l->xfer_ev[k]);
     if (l->xfer) (void)hipHostFree(l->xfer);
     if (l->pinned) (void)hipHostFree(l->pinned);
@@ -320,14 +320,17 @@ void prof_add_bytes(fgpu_ctx* ctx, int idx, uint64_t extra) {
 
 // ---- staged transfers ---------------------------------------------------------------------------
 namespace {
-constexpr size_t XFER_HALF = 2u << 20;   // 2 MiB per half (4 MiB pinned per lane): ~40 us on the link per chunk, and a host thread
-                                         // copies 2 MiB out in ~200 us, so the link is never what is waited for
+constexpr size_t XFER_HALF = 2u << 20;   // 2 MiB per slot (8 MiB pinned per lane): ~40 us on the link per chunk; a host thread
+                                         // copies 2 MiB out in ~200 us, so with three chunks in flight the link is never waited for
+constexpr int XS = fgpu_lane::XFER_SLOTS;
+constexpr size_t DMA_MIN = 64u << 10;    // below this the staging ring is as fast as a direct DMA and needs no pointer query
+constexpr size_t PIN_MIN = 256u << 10;   // result arrays from this size up come from the pinned pool
 
 fgpu_info xfer_ready(fgpu_lane* l) {
     if (l->xfer) return FGPU_OK;
     void* p = nullptr;
-    FGPU_HIP(hipHostMalloc(&p, 2 * XFER_HALF, hipHostMallocDefault));
-    for (int k = 0; k < 2; ++k) {
+    FGPU_HIP(hipHostMalloc(&p, XS * XFER_HALF, hipHostMallocDefault));
+    for (int k = 0; k < XS; ++k) {
         if (hipEventCreateWithFlags(&l->xfer_ev[k], hipEventDisableTiming) != hipSuccess) {
             (void)hipHostFree(p);
             set_error("transfer staging: hipEventCreate failed");
@@ -339,7 +342,7 @@ fgpu_info xfer_ready(fgpu_lane* l) {
     return FGPU_OK;
 }
 
-// wait until the device copy that last used half k has finished
+// wait until the device copy that last used slot k has finished
 fgpu_info xfer_wait(fgpu_lane* l, int k) {
     if (l->xfer_busy[k]) {
         FGPU_HIP(hipEventSynchronize(l->xfer_ev[k]));
@@ -347,7 +350,30 @@ fgpu_info xfer_wait(fgpu_lane* l, int k) {
     }
     return FGPU_OK;
 }
+
+// u32 ids of the device -> the u64 ids of the caller (GrB_Index), 4 per thread: one 16-byte load, two 16-byte stores
+__global__ __launch_bounds__(256) void widen_u32_u64_kernel(const u32* __restrict__ in, u64* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+        reinterpret_cast<ulonglong2*>(out)[2 * i] = make_ulonglong2(v.x, v.y);
+        reinterpret_cast<ulonglong2*>(out)[2 * i + 1] = make_ulonglong2(v.z, v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = in[n4 * 4 + threadIdx.x];
+}
 }  // namespace
+
+namespace fgpu {
+fgpu_info widen_on_device(fgpu_ctx* ctx, u64* out_dev, const u32* in_dev, size_t n) {
+    if (!n) return FGPU_OK;
+    size_t grid = (n / 4 + 255) / 256;
+    if (grid > (size_t)ctx->cus * 16) grid = (size_t)ctx->cus * 16;
+    hipLaunchKernelGGL(widen_u32_u64_kernel, dim3(grid ? (u32)grid : 1), dim3(256), 0, ctx->stream(), in_dev, out_dev, n);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+}  // namespace fgpu
 
 fgpu_info fgpu_ctx::h2d(void* dev, const void* host, size_t bytes) {
     if (bytes == 0) return FGPU_OK;
@@ -358,7 +384,7 @@ fgpu_info fgpu_ctx::h2d(void* dev, const void* host, size_t bytes) {
     for (size_t off = 0; off < bytes; off += l->xfer_half) {
         const size_t n = bytes - off < l->xfer_half ? bytes - off : l->xfer_half;
         const int k = l->xfer_next;
-        l->xfer_next ^= 1;
+        l->xfer_next = (k + 1) % XS;
         FGPU_TRY(xfer_wait(l, k));
         char* half = (char*)l->xfer + (size_t)k * l->xfer_half;
         memcpy(half, src + off, n);
@@ -370,42 +396,82 @@ fgpu_info fgpu_ctx::h2d(void* dev, const void* host, size_t bytes) {
 }
 
 namespace {
-// the common loop of d2h / d2h_widen: `unit` device bytes per element, `emit(half, first_element, count)` moves a
-// finished chunk into the caller's buffer while the next chunk is on the link
+// the common loop of the staged d2h / d2h_widen: `unit` device bytes per element, `emit(slot, first_element, count)`
+// moves a finished chunk into the caller's buffer while the next XS - 1 chunks are on the link
 template <class Emit>
 fgpu_info d2h_loop(fgpu_lane* l, const char* dev, size_t count, size_t unit, Emit emit) {
     if (count == 0) return FGPU_OK;
     FGPU_TRY(xfer_ready(l));
     const size_t per = l->xfer_half / unit;
-    size_t pend_first = 0, pend_n = 0;
-    int pend_k = -1;
+    struct Pend { int k; size_t first, n; } pend[XS];
+    int np = 0, head = 0;
+    auto drain_one = [&]() -> fgpu_info {
+        Pend& q = pend[head];
+        FGPU_TRY(xfer_wait(l, q.k));
+        emit((const char*)l->xfer + (size_t)q.k * l->xfer_half, q.first, q.n);
+        head = (head + 1) % XS;
+        --np;
+        return FGPU_OK;
+    };
     for (size_t first = 0; first < count; first += per) {
         const size_t n = count - first < per ? count - first : per;
+        if (np == XS - 1) FGPU_TRY(drain_one());          // the slot about to be reused is the oldest pending one's successor
         const int k = l->xfer_next;
-        l->xfer_next ^= 1;
-        FGPU_TRY(xfer_wait(l, k));   // (an earlier h2d may still be reading this half)
+        l->xfer_next = (k + 1) % XS;
+        FGPU_TRY(xfer_wait(l, k));   // (an earlier h2d may still be reading this slot)
         char* half = (char*)l->xfer + (size_t)k * l->xfer_half;
         FGPU_HIP(hipMemcpyAsync(half, dev + first * unit, n * unit, hipMemcpyDeviceToHost, l->stream));
         FGPU_HIP(hipEventRecord(l->xfer_ev[k], l->stream));
         l->xfer_busy[k] = true;
-        if (pend_k >= 0) {
-            FGPU_TRY(xfer_wait(l, pend_k));
-            emit((const char*)l->xfer + (size_t)pend_k * l->xfer_half, pend_first, pend_n);
-        }
-        pend_k = k; pend_first = first; pend_n = n;
+        pend[(head + np) % XS] = {k, first, n};
+        ++np;
     }
-    FGPU_TRY(xfer_wait(l, pend_k));
-    emit((const char*)l->xfer + (size_t)pend_k * l->xfer_half, pend_first, pend_n);
+    while (np) FGPU_TRY(drain_one());
     return FGPU_OK;
 }
 }  // namespace
 
+bool fgpu_ctx::dma_able(const void* host, size_t bytes) {
+    if (!host || bytes < DMA_MIN || !opt.pinned_results) return false;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = pin_live.upper_bound(host);
+        if (it != pin_live.begin()) {
+            --it;
+            const char* b = (const char*)it->first;
+            if ((const char*)host >= b && (const char*)host + bytes <= b + it->second) return true;
+        }
+    }
+    // memory the caller pinned itself (hipHostMalloc / hipHostRegister, a torch pinned tensor)
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
 fgpu_info fgpu_ctx::d2h(void* host, const void* dev, size_t bytes) {
+    if (dma_able(host, bytes)) {
+        FGPU_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream()));
+        FGPU_HIP(hipStreamSynchronize(stream()));
+        return FGPU_OK;
+    }
     char* out = (char*)host;
     return d2h_loop(lane(), (const char*)dev, bytes, 1, [&](const char* half, size_t first, size_t n) { memcpy(out + first, half, n); });
 }
 
 fgpu_info fgpu_ctx::d2h_widen(uint64_t* host, const uint32_t* dev, size_t count) {
+    if (dma_able(host, count * sizeof(u64))) {
+        // widened by a kernel, then ONE DMA into the caller's pinned array: no host thread touches the entries
+        void* tmp = nullptr;
+        FGPU_TRY(dev_alloc(&tmp, count * sizeof(u64)));
+        fgpu_info i = fgpu::widen_on_device(this, (u64*)tmp, dev, count);
+        if (i == FGPU_OK && hipMemcpyAsync(host, tmp, count * sizeof(u64), hipMemcpyDeviceToHost, stream()) != hipSuccess) {
+            set_error("d2h_widen: hipMemcpyAsync failed");
+            i = FGPU_DEVICE;
+        }
+        if (i == FGPU_OK && hipStreamSynchronize(stream()) != hipSuccess) { set_error("d2h_widen: stream failed"); i = FGPU_DEVICE; }
+        dev_free(tmp);
+        return i;
+    }
     return d2h_loop(lane(), (const char*)dev, count, sizeof(u32), [&](const char* half, size_t first, size_t n) {
         const u32* s = (const u32*)half;
         u64* d = host + first;
@@ -417,8 +483,77 @@ void* fgpu_ctx::host_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
     return mal ? mal(bytes) : malloc(bytes);
 }
+
+void* fgpu_ctx::pinned_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    // capacity classes: eighths of a power of two (<= 12.5 % slack), so that results of similar size share blocks
+    size_t cap = PIN_MIN;
+    while (cap < bytes) cap <<= 1;
+    if (cap > PIN_MIN) {
+        const size_t step = cap >> 4;                       // sixteenths of cap = eighths of cap / 2
+        cap = ((bytes + step - 1) / step) * step;
+    }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = pin_pool.lower_bound(cap);
+        if (it != pin_pool.end() && it->first <= cap + cap / 4) {
+            void* p = it->second;
+            pin_pooled -= it->first;
+            pin_live[p] = it->first;
+            pin_pool.erase(it);
+            return p;
+        }
+    }
+    (void)lane();                                            // (device current)
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        // make room: give the pooled blocks back and try once more
+        std::vector<void*> old;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (auto& kv : pin_pool) old.push_back(kv.second);
+            pin_pool.clear();
+            pin_pooled = 0;
+        }
+        for (void* q : old) (void)hipHostFree(q);
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    std::lock_guard<std::mutex> g(mu);
+    pin_live[p] = cap;
+    return p;
+}
+
+void* fgpu_ctx::result_alloc(size_t bytes) {
+    // (arrays beyond 1 GiB — an exported RMAT-26 adjacency — stay pageable: pinning them costs more than staging saves)
+    if (opt.pinned_results && bytes >= PIN_MIN && bytes <= ((size_t)1 << 30)) {
+        void* p = pinned_alloc(bytes);
+        if (p) return p;
+    }
+    return host_alloc(bytes);
+}
+
 void fgpu_ctx::host_free(void* p) {
     if (!p) return;
+    size_t cap = 0;
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = pin_live.find(p);
+        if (it != pin_live.end()) {
+            cap = it->second;
+            pin_live.erase(it);
+            if (pin_pooled + cap <= (uint64_t)opt.pinned_pool_mb << 20) {
+                pin_pool.emplace(cap, p);
+                pin_pooled += cap;
+                keep = true;
+            }
+        }
+    }
+    if (cap) {
+        if (!keep) (void)hipHostFree(p);
+        return;
+    }
     if (fre) fre(p); else free(p);
 }
 
@@ -477,6 +612,9 @@ fgpu_info fgpu_finalize(fgpu_ctx* ctx) {
     // live blocks still owned by un-freed matrices are released here too
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     ctx->live.clear();
+    for (auto& kv : ctx->pin_pool) (void)hipHostFree(kv.second);
+    for (auto& kv : ctx->pin_live) (void)hipHostFree(const_cast<void*>(kv.first));   // result arrays the caller never freed
+    ctx->pin_pool.clear(); ctx->pin_live.clear();
     for (auto& e : ctx->prof) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     for (hipEvent_t e : ctx->prof_free) (void)hipEventDestroy(e);
     for (fgpu_lane* l : ctx->lanes) lane_destroy(l);
@@ -491,6 +629,13 @@ fgpu_info fgpu_finalize(fgpu_ctx* ctx) {
 void fgpu_free(fgpu_ctx* ctx, void* p) {
     if (!p) return;
     if (ctx) ctx->host_free(p); else free(p);
+}
+
+fgpu_info fgpu_host_alloc(fgpu_ctx* ctx, uint64_t bytes, void** out) {
+    FGPU_REQUIRE(ctx && out, FGPU_NULL_POINTER, "fgpu_host_alloc: NULL argument");
+    *out = ctx->pinned_alloc((size_t)bytes);
+    FGPU_REQUIRE(*out, FGPU_OOM, "fgpu_host_alloc: %llu B of pinned host memory are not available", (unsigned long long)bytes);
+    return FGPU_OK;
 }
 
 fgpu_info fgpu_set_stream(fgpu_ctx* ctx, void* hip_stream) {
@@ -580,6 +725,11 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.bfs_hub_first = value != 0;
     } else if (!strcmp(name, "dist_timing")) {
         ctx->opt.dist_timing = value != 0;
+    } else if (!strcmp(name, "pinned_results")) {
+        ctx->opt.pinned_results = value != 0;
+    } else if (!strcmp(name, "pinned_pool_mb")) {
+        FGPU_REQUIRE(value >= 0 && value <= (1 << 20), FGPU_INVALID, "pinned_pool_mb out of range");
+        ctx->opt.pinned_pool_mb = (int)value;
     } else if (!strcmp(name, "dist_collective")) {
         FGPU_REQUIRE(value == 0 || value == 1, FGPU_INVALID, "dist_collective must be 0 (send/recv) or 1 (broadcasts)");
         ctx->opt.dist_collective = (int)value;

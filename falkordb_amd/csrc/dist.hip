@@ -51,14 +51,22 @@ const Rccl* rccl() {
         const char* forced = getenv("FGPU_RCCL_LIB");
         if (forced && *forced) {
             r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
-            if (!r.handle) { r.error = std::string("FGPU_RCCL_LIB=") + forced + ": " + (dlerror() ? dlerror() : "dlopen failed"); return; }
+            if (!r.handle) {
+                const char* e = dlerror();                  // (one call: dlerror() clears the message it returns)
+                r.error = std::string("FGPU_RCCL_LIB=") + forced + ": " + (e ? e : "dlopen failed");
+                return;
+            }
             r.loopback = dlsym(r.handle, "fgpu_stub_rccl_loopback") != nullptr;
         }
         for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
             if (r.handle) break;
             r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
-        if (!r.handle) { r.error = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
+        if (!r.handle) {
+            const char* e = dlerror();
+            r.error = std::string("librccl.so.1 not found: ") + (e ? e : "dlopen failed");
+            return;
+        }
         bool ok = true;
         auto bind = [&](auto& fn, const char* sym) {
             fn = (std::remove_reference_t<decltype(fn)>)dlsym(g_rccl.handle, sym);

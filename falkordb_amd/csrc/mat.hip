@@ -17,25 +17,38 @@ namespace fgpu {
 // ---------------------------------------------------------------------------------
 // allocation / finalisation
 // ---------------------------------------------------------------------------------
+std::mutex& bfs_link_mu() {
+    static std::mutex mu;
+    return mu;
+}
+
 // the cached one-call BFS plan (fgpu_bfs, bfs.hip) goes before either of its matrices does
 void mat_drop_bfs_plan(const fgpu_mat* a) {
     if (!a->bfs_plan) return;
+    fgpu_ctx* pc = a->bfs_plan_ctx;
     (void)fgpu_bfs_plan_free(a->bfs_plan);
     if (a->bfs_plan_at && a->bfs_plan_at->bfs_cached_in == a) a->bfs_plan_at->bfs_cached_in = nullptr;
+    if (pc && pc->bfs_cache_owner == a) pc->bfs_cache_owner = nullptr;
     a->bfs_plan = nullptr;
     a->bfs_plan_at = nullptr;
+    a->bfs_plan_ctx = nullptr;
 }
 
 void mat_release(fgpu_mat* m) {
     if (!m) return;
     {
-        std::lock_guard<std::mutex> g(m->bfs_mu);
-        mat_drop_bfs_plan(m);
-    }
-    if (const fgpu_mat* owner = m->bfs_cached_in) {   // m is the transpose of a cached plan
-        std::lock_guard<std::mutex> g(owner->bfs_mu);
-        if (owner->bfs_plan_at == m) mat_drop_bfs_plan(owner);
-        m->bfs_cached_in = nullptr;
+        // link mutex first, then the matrices' own: the owner of a back-link cannot be released (its own mat_release needs
+        // the link mutex) between reading m->bfs_cached_in and locking it
+        std::lock_guard<std::mutex> link(bfs_link_mu());
+        {
+            std::lock_guard<std::mutex> g(m->bfs_mu);
+            mat_drop_bfs_plan(m);
+        }
+        if (const fgpu_mat* owner = m->bfs_cached_in) {   // m is the transpose of a cached plan
+            std::lock_guard<std::mutex> g(owner->bfs_mu);
+            if (owner->bfs_plan_at == m) mat_drop_bfs_plan(owner);
+            m->bfs_cached_in = nullptr;
+        }
     }
     fgpu_ctx* c = m->ctx;
     if (c) {
@@ -788,9 +801,10 @@ static fgpu_info download_mat(fgpu_ctx* ctx, const fgpu_mat* m, std::vector<u32>
 fgpu_info fgpu_mat_export_csr(fgpu_ctx* ctx, const fgpu_mat* m, uint64_t** rowptr, uint64_t** colidx,
                               uint64_t** vals, uint64_t* nnz) {
     FGPU_REQUIRE(ctx && m && rowptr && colidx && nnz, FGPU_NULL_POINTER, "fgpu_mat_export_csr: NULL argument");
-    u64* orp = (u64*)ctx->host_alloc((m->nrows + 1) * sizeof(u64));
-    u64* oci = (u64*)ctx->host_alloc((m->nnz ? m->nnz : 1) * sizeof(u64));
-    u64* ov = (vals && m->vals) ? (u64*)ctx->host_alloc((m->nnz ? m->nnz : 1) * sizeof(u64)) : nullptr;
+    // (large arrays come pinned from the context's pool and are filled by one DMA each: ctx.hip result_alloc / d2h_widen)
+    u64* orp = (u64*)ctx->result_alloc((m->nrows + 1) * sizeof(u64));
+    u64* oci = (u64*)ctx->result_alloc((m->nnz ? m->nnz : 1) * sizeof(u64));
+    u64* ov = (vals && m->vals) ? (u64*)ctx->result_alloc((m->nnz ? m->nnz : 1) * sizeof(u64)) : nullptr;
     if (!orp || !oci || (vals && m->vals && !ov)) {
         ctx->host_free(orp); ctx->host_free(oci); ctx->host_free(ov);
         set_error("fgpu_mat_export_csr: host allocation failed");

@@ -547,6 +547,141 @@ fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, con
     return i;
 }
 
+// ---- streamed result (include/fgpu.h fgpu_expand_stream_*) ----------------------------------------------------------
+struct fgpu_expand_stream {
+    static constexpr int NS = 4;
+    fgpu_ctx* ctx = nullptr;
+    hipStream_t st = nullptr;        // the opening thread's lane
+    fgpu_mat* r = nullptr;           // F on the device
+    std::vector<u32> rp;             // its row pointers (nsrc + 1)
+    u64 nsrc = 0, chunk_rows = 0;
+    int width = 8;                   // bytes per destination id handed out
+    size_t cap = 0;                  // entries per slot
+    struct Slot {
+        void* host = nullptr;        // pinned, cap * width bytes
+        u64* wide = nullptr;         // device staging of the widened ids (width 8)
+        std::vector<u64> rowptr;     // relative offsets of the chunk's rows
+        hipEvent_t ev = nullptr;
+        u64 first = 0, nrows = 0;
+    } slot[NS];
+    u64 enq_row = 0;                 // first row not yet enqueued
+    int head = 0, inflight = 0;      // slot of the oldest enqueued chunk; chunks enqueued and not yet handed out
+    bool held = false;               // the caller is reading slot (head - 1)
+};
+
+static fgpu_info stream_enqueue(fgpu_expand_stream* s, int k) {
+    auto& sl = s->slot[k];
+    const u64 first = s->enq_row;
+    const u64 nr = s->nsrc - first < s->chunk_rows ? s->nsrc - first : s->chunk_rows;
+    const u64 b = s->rp[first], e = s->rp[first + nr], n = e - b;
+    sl.first = first; sl.nrows = nr;
+    sl.rowptr.resize(nr + 1);
+    for (u64 i = 0; i <= nr; ++i) sl.rowptr[i] = (u64)s->rp[first + i] - b;
+    if (n) {
+        if (s->width == 8) {
+            FGPU_TRY(fgpu::widen_on_device(s->ctx, sl.wide, s->r->colidx + b, n));
+            FGPU_HIP(hipMemcpyAsync(sl.host, sl.wide, n * 8, hipMemcpyDeviceToHost, s->st));
+        } else {
+            FGPU_HIP(hipMemcpyAsync(sl.host, s->r->colidx + b, n * 4, hipMemcpyDeviceToHost, s->st));
+        }
+    }
+    FGPU_HIP(hipEventRecord(sl.ev, s->st));
+    s->enq_row = first + nr;
+    ++s->inflight;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_expand_stream_close(fgpu_expand_stream* s) {
+    if (!s) return FGPU_OK;
+    fgpu_ctx* ctx = s->ctx;
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    for (auto& sl : s->slot) {
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+        if (sl.host) ctx->host_free(sl.host);
+        if (sl.wide) ctx->dev_free(sl.wide);
+    }
+    if (s->r) mat_release(s->r);
+    delete s;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_expand_stream_open(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                                  const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                                  const uint64_t* dst_label_bitmap, uint64_t chunk_rows, int dest_bits,
+                                  fgpu_expand_stream** out, uint64_t* nnz, uint64_t* flops) {
+    FGPU_REQUIRE(ctx && out, FGPU_NULL_POINTER, "fgpu_expand_stream_open: NULL argument");
+    FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_stream_open: NULL src_ids");
+    FGPU_REQUIRE(dest_bits == 32 || dest_bits == 64, FGPU_INVALID, "fgpu_expand_stream_open: dest_bits must be 32 or 64");
+    FGPU_REQUIRE(chunk_rows >= 1, FGPU_INVALID, "fgpu_expand_stream_open: chunk_rows must be >= 1");
+    *out = nullptr;
+    if (flops) *flops = 0;
+    fgpu_mat* r = nullptr;
+    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
+    fgpu_expand_stream* s = new (std::nothrow) fgpu_expand_stream();
+    if (!s) { mat_release(r); set_error("fgpu_expand_stream_open: out of host memory"); return FGPU_OOM; }
+    s->ctx = ctx; s->st = ctx->stream(); s->r = r; s->nsrc = nsrc; s->chunk_rows = chunk_rows; s->width = dest_bits / 8;
+    fgpu_info i = FGPU_OK;
+    s->rp.assign(nsrc + 1, 0);
+    if (r->nnz) {
+        if (r->is_hyper()) {          // (expand_device returns one stored row per source row; guard the other form)
+            std::vector<u32> hr(r->nvec), srp((size_t)r->nvec + 1);
+            i = ctx->d2h(srp.data(), r->rowptr, srp.size() * sizeof(u32));
+            if (i == FGPU_OK && r->nvec) i = ctx->d2h(hr.data(), r->hrows, (size_t)r->nvec * sizeof(u32));
+            if (i == FGPU_OK) {
+                for (u32 k = 0; k < r->nvec; ++k) s->rp[hr[k] + 1] = srp[k + 1] - srp[k];
+                for (u64 q = 0; q < nsrc; ++q) s->rp[q + 1] += s->rp[q];
+            }
+        } else {
+            i = ctx->d2h(s->rp.data(), r->rowptr, (nsrc + 1) * sizeof(u32));
+        }
+    }
+    if (i == FGPU_OK) {
+        for (u64 f = 0; f < nsrc; f += chunk_rows) {
+            const u64 l = f + chunk_rows < nsrc ? f + chunk_rows : nsrc;
+            const size_t n = (size_t)s->rp[l] - s->rp[f];
+            if (n > s->cap) s->cap = n;
+        }
+        const u64 nchunks = nsrc ? (nsrc + chunk_rows - 1) / chunk_rows : 0;
+        const int use = nchunks < (u64)fgpu_expand_stream::NS ? (int)nchunks : fgpu_expand_stream::NS;
+        for (int k = 0; k < use && i == FGPU_OK; ++k) {
+            auto& sl = s->slot[k];
+            sl.host = ctx->pinned_alloc((s->cap ? s->cap : 1) * s->width);
+            if (!sl.host) { set_error("fgpu_expand_stream_open: pinned host memory exhausted"); i = FGPU_OOM; break; }
+            if (s->width == 8) i = ctx->dev_alloc((void**)&sl.wide, (s->cap ? s->cap : 1) * 8);
+            if (i == FGPU_OK && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) {
+                set_error("fgpu_expand_stream_open: hipEventCreate failed");
+                i = FGPU_DEVICE;
+            }
+        }
+        for (int k = 0; k < use && i == FGPU_OK && s->enq_row < nsrc; ++k) i = stream_enqueue(s, k);
+    }
+    if (i != FGPU_OK) { fgpu_expand_stream_close(s); return i; }
+    if (nnz) *nnz = r->nnz;
+    *out = s;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_expand_stream_next(fgpu_expand_stream* s, uint64_t* first_row, uint64_t* nrows, const uint64_t** rowptr,
+                                  const void** dest) {
+    FGPU_REQUIRE(s && first_row && nrows && rowptr && dest, FGPU_NULL_POINTER, "fgpu_expand_stream_next: NULL argument");
+    FGPU_REQUIRE(s->ctx->stream() == s->st, FGPU_INVALID, "fgpu_expand_stream_next: a stream belongs to the thread that opened it");
+    constexpr int NS = fgpu_expand_stream::NS;
+    if (s->held) {                         // the chunk handed out last is done with: its slot takes the next one
+        s->held = false;
+        const int freed = (s->head + NS - 1) % NS;
+        if (s->enq_row < s->nsrc) FGPU_TRY(stream_enqueue(s, freed));
+    }
+    *nrows = 0; *first_row = s->nsrc; *rowptr = nullptr; *dest = nullptr;
+    if (s->inflight == 0) return FGPU_NO_VALUE;
+    auto& sl = s->slot[s->head];
+    FGPU_HIP(hipEventSynchronize(sl.ev));
+    *first_row = sl.first; *nrows = sl.nrows; *rowptr = sl.rowptr.data(); *dest = sl.host;
+    s->head = (s->head + 1) % NS;
+    --s->inflight;
+    s->held = true;
+    return FGPU_OK;
+}
+
 fgpu_info fgpu_expand_mat(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
                           const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
                           const uint64_t* dst_label_bitmap, fgpu_mat** out, uint64_t* flops) {

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import weakref
+
 import numpy as np
 
 from . import _ffi
@@ -104,13 +106,30 @@ class Context:
 
     # ---- helpers to pull caller-owned host buffers back into numpy ----
     def _take(self, ptr, n, dtype=U64):
+        """A numpy VIEW of a result array the library handed out (no copy: the arrays of a k-hop batch are hundreds of
+        MB); fgpu_free runs when the array — and every view derived from it — is gone."""
         if not ptr or n == 0:
             if ptr:
                 self.lib.fgpu_free(self._h, C.cast(ptr, C.c_void_p))
             return np.zeros(0, dtype=dtype)
-        arr = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
-        self.lib.fgpu_free(self._h, C.cast(ptr, C.c_void_p))
+        addr = C.cast(ptr, C.c_void_p).value
+        buf = (C.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(addr)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(n))
+        me = weakref.ref(self)
+
+        def release():
+            c = me()
+            if c is not None and c._h:          # (a closed context has already released its pinned blocks)
+                c.lib.fgpu_free(c._h, C.c_void_p(addr))
+        weakref.finalize(buf, release)
         return arr
+
+    def host_array(self, n, dtype):
+        """fgpu_host_alloc: a pinned host array from the context's pool, for outputs the caller provides (level[] /
+        parent[] of fgpu_bfs): the library fills it by DMA instead of staging + a host copy."""
+        p = C.c_void_p()
+        check(self.lib.fgpu_host_alloc(self._h, int(n) * np.dtype(dtype).itemsize, C.byref(p)))
+        return self._take(p, n, dtype)
 
     # ---- matrix factories ----
     def mat_new(self, nrows, ncols) -> "Mat":
@@ -316,6 +335,52 @@ def expand(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
     return rowptr, dest, flops.value
 
 
+class ExpandStream:
+    """fgpu_expand_stream_*: the chain's result handed over in chunks of whole source rows while later chunks are still
+    on the link.  Iterating yields (first_row, rowptr, dest) — views valid until the next step."""
+
+    def __init__(self, ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None, chunk_rows=64, dest_bits=64):
+        src = _u64(src_ids)
+        am = _hop_arrays(m)
+        adp = _hop_arrays(dp) if dp is not None else None
+        adm = _hop_arrays(dm) if dm is not None else None
+        lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
+        self.ctx, self._h, self.dest_bits = ctx, C.c_void_p(), dest_bits
+        nnz, flops = C.c_uint64(), C.c_uint64()
+        check(ctx.lib.fgpu_expand_stream_open(ctx._h, _p(src), len(src), am, adp, adm, len(m), _p(lab), chunk_rows, dest_bits,
+                                              C.byref(self._h), C.byref(nnz), C.byref(flops)))
+        self.nnz, self.flops = nnz.value, flops.value
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        first, nrows = C.c_uint64(), C.c_uint64()
+        rp, dest = u64p(), C.c_void_p()
+        code = self.ctx.lib.fgpu_expand_stream_next(self._h, C.byref(first), C.byref(nrows), C.byref(rp), C.byref(dest))
+        if code == _ffi.FGPU_NO_VALUE:
+            raise StopIteration
+        check(code)
+        rowptr = np.ctypeslib.as_array(rp, shape=(nrows.value + 1,))
+        n = int(rowptr[-1])
+        dt = np.uint64 if self.dest_bits == 64 else np.uint32
+        d = np.ctypeslib.as_array(C.cast(dest, C.POINTER(C.c_uint64 if self.dest_bits == 64 else C.c_uint32)), shape=(n,)) \
+            if n else np.zeros(0, dtype=dt)
+        return first.value, rowptr, d
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.fgpu_expand_stream_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.close()
+        except Exception:
+            pass
+
+
 def expand_mat(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
     """fgpu_expand_mat: the same chain with F left on the device as a matrix handle (cond_traverse.rs:602-608).
     Returns (Mat with len(src_ids) rows, flops)."""
@@ -385,10 +450,13 @@ def vxm(ctx: Context, f_bits, mask_bits, A: Mat, At: Mat | None = None, directio
     return w
 
 
-def bfs(ctx: Context, A: Mat, At: Mat | None, src: int, max_level: int = -1, want_parent: bool = True):
+def bfs(ctx: Context, A: Mat, At: Mat | None, src: int, max_level: int = -1, want_parent: bool = True, level_out=None,
+        parent_out=None):
+    """fgpu_bfs.  level_out / parent_out: arrays to fill instead of fresh numpy ones — pass Context.host_array() blocks
+    (pinned) and the library DMAs into them."""
     n = A.nrows
-    level = np.zeros(n, dtype=np.int32)
-    parent = np.zeros(n, dtype=np.int64) if want_parent else None
+    level = level_out if level_out is not None else np.zeros(n, dtype=np.int32)
+    parent = (parent_out if parent_out is not None else np.zeros(n, dtype=np.int64)) if want_parent else None
     edges = C.c_uint64()
     check(ctx.lib.fgpu_bfs(ctx._h, A._h, At._h if At else None, src, max_level, _p(level, i32p),
                            _p(parent, i64p), C.byref(edges)))

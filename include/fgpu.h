@@ -72,6 +72,17 @@ fgpu_info fgpu_init(fgpu_ctx** ctx, int device, void* (*mal)(size_t), void (*fre
 fgpu_info fgpu_finalize(fgpu_ctx* ctx);
 const char* fgpu_last_error(void);
 void fgpu_free(fgpu_ctx* ctx, void* p);
+/* Result arrays (`T**` outputs) of 256 KiB and more are PINNED host blocks from a pool the context keeps (SURVEY.md
+ * §8b: "outputs are pinned-host buffers owned by the caller until fgpu_free"): the device fills them with one DMA, ids
+ * widened to 64 bits by a kernel, and fgpu_free returns them to the pool (the first result of a size pays the pinning,
+ * ~0.1 ms per MiB; later ones do not).  Smaller outputs come from `mal`.  fgpu_host_alloc hands the caller a block of
+ * the same pool for the arrays the CALLER provides (level[] / parent[] of fgpu_bfs and fgpu_bfs_fetch, centrality[] of
+ * fgpu_pagerank): entry points that write into caller memory check whether it is pinned (a pool block, or memory the
+ * caller registered with HIP) and then DMA straight into it; pageable memory goes through a ring of four 2 MiB pinned
+ * chunks and a host copy.  Release with fgpu_free.  (The reference's GrB_Vector results live in GraphBLAS-owned memory
+ * and are read element by element, algo_procedures.rs:1096-1160; a maintainer's binding would allocate its level
+ * vector here.) */
+fgpu_info fgpu_host_alloc(fgpu_ctx* ctx, uint64_t bytes, void** out);
 /* Run all subsequent work of the CALLING THREAD's lane on an externally owned hipStream_t
  * (plumbing for torch.distributed: pass torch.cuda.current_stream().cuda_stream).
  * NULL restores the lane's own stream. */
@@ -234,6 +245,28 @@ fgpu_info fgpu_expand_mat(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
                           const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
                           fgpu_mat** out, uint64_t* flops);
 
+/* The same chain with the result STREAMED to the host in chunks of whole source rows — the shape in which
+ * CondTraverseOp::expand_batch consumes it (cond_traverse.rs:644-751: walk (row_i, dest) ascending, emit an output batch
+ * every 1024 pairs): the chain runs once, F stays on the device, and chunks of at most `chunk_rows` consecutive source
+ * rows are copied into a ring of four pinned buffers, three copies on the link while the caller walks the fourth.
+ *   open : runs the chain; *nnz / *flops (nullable) as fgpu_expand.  dest_bits = 64 (GrB_Index ids, widened on the device)
+ *          or 32 (half the bytes on the link; node ids fit 32 bits, tensor.rs:154-163).
+ *   next : blocks until the next chunk has landed; *first_row / *nrows name its source rows, rowptr[0 .. nrows] are entry
+ *          offsets relative to the chunk (rowptr[0] = 0), dest[0 .. rowptr[nrows]) the destinations (uint64_t or
+ *          uint32_t per dest_bits), ascending and unique per row.  The arrays stay valid until the next call on the
+ *          stream.  Returns FGPU_NO_VALUE (and *nrows = 0) after the last chunk.
+ *   close: releases the device result and the ring (valid at any point).
+ * A stream belongs to the thread that opened it. */
+typedef struct fgpu_expand_stream fgpu_expand_stream;
+fgpu_info fgpu_expand_stream_open(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                                  const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                                  const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                                  uint64_t chunk_rows, int dest_bits, fgpu_expand_stream** out,
+                                  uint64_t* nnz, uint64_t* flops);
+fgpu_info fgpu_expand_stream_next(fgpu_expand_stream* s, uint64_t* first_row, uint64_t* nrows,
+                                  const uint64_t** rowptr, const void** dest);
+fgpu_info fgpu_expand_stream_close(fgpu_expand_stream* s);
+
 /* Same as fgpu_expand but the result stays on device and only its size and an
  * order-independent checksum come back (full-size configs whose output would not
  * fit a host buffer): checksum = sum over the (row, dest) entries of
@@ -296,7 +329,8 @@ fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, co
 /* Level-synchronous BFS: replaces LAGr_BreadthFirstSearch_Extended(level, parent, G,
  * src, max_level, -1, false) as called by algo.BFS (algo_procedures.rs:1079-1088;
  * binding lagraphx_bindings.rs:585-594).  level[n] (int32, -1 = unreached, source = 0),
- * parent[n] (nullable, int64, -1 = none, parent[src] = src) are HOST arrays.
+ * parent[n] (nullable, int64, -1 = none, parent[src] = src) are HOST arrays (pinned ones — fgpu_host_alloc — are
+ * filled by DMA: 0.3 ms for the 16 MiB level[] of RMAT-22 instead of 0.9 ms through staging into pageable memory).
  * max_level < 0 => unlimited.  At may be NULL (push only).  edges_traversed
  * (nullable) = sum of out-degrees of reached vertices (TEPS numerator).
  * The search plan of the last call over the same (A, At) pair stays attached to A (released with either matrix, rebuilt

@@ -274,13 +274,15 @@ def expand_omp(src_ids, layers, threads: int = 0, n: int | None = None):
     return f, flops, hop_nnz
 
 
-def expand_summary_omp(src_ids, layers, chunk: int = 64, threads: int = 0, n: int | None = None, seconds: float | None = None):
+def expand_summary_omp(src_ids, layers, chunk: int = 64, threads: int = 0, n: int | None = None, seconds: float | None = None,
+                       per_chunk: list | None = None):
     """(nnz, checksum, flops, per-hop nnz) of expand_omp() for result sets too large to hold at once (RMAT-24, 1024
     sources: 1.5 G entries): the sources go through the same chain `chunk` rows at a time — F keeps all len(src_ids)
     rows, only the chunk's rows are non-empty, so every (row, dest) pair is hashed with its row index in the whole
     batch and the partial checksums simply add (the checksum is a sum over the result set, oracle.c orc_checksum).
     With `seconds`, stops after the first chunk that crosses the budget and also returns how many sources were done
-    (bench.py's bounded CPU baseline); otherwise returns the 4-tuple for the whole batch."""
+    (bench.py's bounded CPU baseline); otherwise returns the 4-tuple for the whole batch.  `per_chunk`, if a list, receives
+    one (flops, seconds) pair per chunk (the quartiles of bench.py's cpu_baseline)."""
     src_ids = np.asarray(src_ids, dtype=U64)
     n = n if n is not None else layers[0][0].nrows
     import time as _time
@@ -289,6 +291,7 @@ def expand_summary_omp(src_ids, layers, chunk: int = 64, threads: int = 0, n: in
     done, t0 = 0, _time.perf_counter()
     while done < len(src_ids):
         hi = min(done + chunk, len(src_ids))
+        tc, fc = _time.perf_counter(), flops
         f = build_csr(len(src_ids), n, np.arange(done, hi, dtype=U64), src_ids[done:hi])
         for k, (m, dp, dm) in enumerate(layers):
             f, fl = delta_lmxm_omp(f, m, dp, dm, threads)
@@ -297,6 +300,8 @@ def expand_summary_omp(src_ids, layers, chunk: int = 64, threads: int = 0, n: in
         nnz += f.nnz
         cs = (cs + checksum_omp(f, threads)) & 0xFFFFFFFFFFFFFFFF
         done = hi
+        if per_chunk is not None:
+            per_chunk.append((flops - fc, _time.perf_counter() - tc))
         if seconds is not None and _time.perf_counter() - t0 > seconds:
             break
     if seconds is not None:

@@ -502,6 +502,10 @@ def test_tensor_v19_payload_with_multi_edges(hctx):
     assert rd(off) == sb["edge_count"] and rd(off + 8) == 3          # total edges, multi pairs in the base group
     assert (rd(off + 16), rd(off + 24)) == (5, 6)                    # first pair in (row, col) order
     assert payload[-8:] == _frame_u(0)                               # empty delta-plus group
+    # the u64 before the groups is only tested for > 0 by the reference's decoder (tensor.rs:1169-1170): a writer that
+    # stores the number of TENSORS there (3) instead of the number of edges decodes to the same tensor
+    alt, _ = host.Tensor.decode(hctx, payload[:off] + _frame_u(3) + payload[off + 8:])
+    assert alt.state()["edge_count"] == sb["edge_count"] and alt.get(5, 6) == [5, 500, 501] and alt.get(0, 1) == [0]
     # an empty tensor: three empty containers and a zero count, nothing else
     e = host.Tensor(hctx, 10, 10)
     pe = e.encode()

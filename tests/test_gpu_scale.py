@@ -90,12 +90,11 @@ def test_khop_rmat20_full_rows_match_the_oracle(ctx, rmat20):
     assert np.array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=c.nrows))]).astype(U64))
 
 
-def test_khop_rmat24_clean_matches_the_oracle(ctx):
+def test_khop_rmat24_clean_matches_the_oracle(ctx, bench_graphs):
     """BASELINE config 3 at full size (RMAT-24, 268 M edges, 3 hops, clean layers): 64 sources of the :P set —
     nnz, checksum and flops of fgpu_expand_count against the oracle, plus the per-hop sizes through
     fgpu_expand_levels."""
-    A = ctx.mat_rmat(24)
-    a = host_csr(A)
+    A, _, a = bench_graphs(24)
     src = p_sources(a.nrows, 64)
     c, flops, hop_nnz = oracle.expand_omp(src, [(a, None, None)] * 3)
     ref = (c.nnz, oracle.checksum_omp(c), flops)
@@ -116,27 +115,91 @@ def hypersparse(ctx, m):
     return ctx.mat_from_csr(m.nrows, m.ncols, short, ci, hyper_rows=rows)
 
 
-@pytest.fixture(scope="module")
-def rmat24_bench(ctx):
-    """Exactly what bench.py's khop_match leg times (bench.py khop_inputs): RMAT-24, dm = fgpu_mat_sample(0xD3170 + 24,
-    1000), dp = seeded random coordinates outside A, both hypersparse; batch 0 = the first 1024 :P sources.  The oracle
-    chains (clean, dirty) are computed once, 64 source rows at a time (oracle.expand_summary_omp)."""
-    scale = 24
-    A = ctx.mat_rmat(scale, 16, 0x5EED1234 + scale)
-    n = A.nrows
-    dm0 = A.sample(0xD3170 + scale, 1000)
-    rng = np.random.default_rng(0xADD5 + scale)
-    k = max(1, A.nvals // 1000)
-    raw = ctx.mat_from_coo(n, n, rng.integers(0, n, k, dtype=np.uint64), rng.integers(0, n, k, dtype=np.uint64))
-    dp0 = raw.merge(None, A)
-    raw.free()
-    a, hdp, hdm = host_csr(A), host_csr(dp0), host_csr(dm0)
-    dp, dm = hypersparse(ctx, dp0), hypersparse(ctx, dm0)
-    dp0.free(); dm0.free()
-    src = p_sources(n, 1024)
+def bench_batch(ctx, bench_graphs, scale, rows):
+    """Exactly what bench.py times at this scale (bench.py khop_inputs / khop_headline): the session's RMAT-<scale> graph,
+    dm = fgpu_mat_sample(0xD3170 + scale, 1000), dp = seeded random coordinates outside A, both hypersparse; the first
+    `rows` :P sources of batch 0.  The oracle chains (clean, dirty) are computed once, 64 source rows at a time."""
+    A, _, a = bench_graphs(scale)
+    dp, dm, hdp, hdm = bench_graphs.khop_layers(scale)
+    src = p_sources(A.nrows, 1024)[:rows]
     ref_clean = oracle.expand_summary_omp(src, [(a, None, None)] * 3)
     ref_dirty = oracle.expand_summary_omp(src, [(a, hdp, hdm)] * 3)
     return A, dp, dm, src, ref_clean, ref_dirty, (a, hdp, hdm)
+
+
+@pytest.fixture(scope="module")
+def rmat24_bench(ctx, bench_graphs):
+    return bench_batch(ctx, bench_graphs, 24, 1024)
+
+
+@pytest.fixture(scope="module")
+def rmat22_bench(ctx, bench_graphs):
+    return bench_batch(ctx, bench_graphs, 22, 1024)
+
+
+@pytest.fixture(scope="module")
+def rmat26_bench(ctx, bench_graphs):
+    return bench_batch(ctx, bench_graphs, 26, 128)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("dirty", [False, True])
+def test_khop_rmat22_headline_batch_matches_the_oracle(ctx, rmat22_bench, mode, dirty):
+    """The bench line's own workload (BASELINE metric: k-hop MATCH at RMAT scale 22): timed batch 0 = the first 1024 :P
+    sources, 3 hops, clean and dirty layers, expand_mode auto and bit-parallel — (nnz, checksum, flops) of
+    fgpu_expand_count, the count-only form and the per-hop sizes against the oracle's delta_lmxm chain
+    (matrix.rs:1317-1402 driven as cond_traverse.rs:600-651 drives it)."""
+    A, dp, dm, src, ref_clean, ref_dirty, _ = rmat22_bench
+    ref = ref_dirty if dirty else ref_clean
+    layers = ([A] * 3, [dp] * 3, [dm] * 3) if dirty else ([A] * 3,)
+    try:
+        ctx.set_option("expand_mode", mode)
+        got = engine.expand_count(ctx, src, *layers)
+        nn, _, fl = engine.expand_count(ctx, src, *layers, want_checksum=False)
+        lv = engine.expand_levels(ctx, src, *layers)
+    finally:
+        ctx.set_option("expand_mode", 0)
+    assert got == ref[:3], (mode, dirty, got, ref)
+    assert (nn, fl) == (ref[0], ref[2])
+    assert list(lv["hop_nnz"]) == ref[3] and lv["flops"] == ref[2]
+    assert ref[0] > 300_000_000
+
+
+@pytest.mark.parametrize("dirty", [False, True])
+def test_khop_rmat26_batch_rows_match_the_oracle(ctx, rmat26_bench, dirty):
+    """The metric's other scale (RMAT-26, 1.06 G edges): the first 128 rows of batch 0 (the oracle's chain for 1024 rows
+    is a minute of CPU at this size), 3 hops, clean and dirty, auto and bit-parallel modes."""
+    A, dp, dm, src, ref_clean, ref_dirty, _ = rmat26_bench
+    ref = ref_dirty if dirty else ref_clean
+    layers = ([A] * 3, [dp] * 3, [dm] * 3) if dirty else ([A] * 3,)
+    for mode in (0, 2):
+        try:
+            ctx.set_option("expand_mode", mode)
+            got = engine.expand_count(ctx, src, *layers)
+            lv = engine.expand_levels(ctx, src, *layers)
+        finally:
+            ctx.set_option("expand_mode", 0)
+        assert got == ref[:3], (mode, dirty, got, ref)
+        assert list(lv["hop_nnz"]) == ref[3] and lv["flops"] == ref[2]
+    assert ref[0] > 100_000_000
+
+
+def test_khop_rmat24_two_hop_host_arrays_match_the_oracle(ctx, rmat24_bench):
+    """What the operator consumes (cond_traverse.rs:608, 644-751): the (row_i, dest) arrays of fgpu_expand in HOST memory
+    for the 1024-row 2-hop batch bench.py's materialised leg times (30.8 M entries at RMAT-24), entry for entry against
+    the oracle's chain — and the same result as a device matrix (fgpu_expand_mat)."""
+    A, dp, dm, src, _, _, (a, hdp, hdm) = rmat24_bench
+    c, flops, _ = oracle.expand_omp(src, [(a, None, None)] * 2)
+    rowptr, dest, fl = engine.expand(ctx, src, [A] * 2)
+    assert fl == flops and len(dest) == c.nnz > 20_000_000
+    assert np.array_equal(rowptr, c.rowptr) and np.array_equal(dest, c.colidx)
+    m, fl = engine.expand_mat(ctx, src, [A] * 2)
+    rp, ci, _ = m.export_csr()
+    m.free()
+    assert fl == flops and np.array_equal(rp, c.rowptr) and np.array_equal(ci, c.colidx)
+    c, flops, _ = oracle.expand_omp(src, [(a, hdp, hdm)] * 2)
+    rowptr, dest, fl = engine.expand(ctx, src, [A] * 2, [dp] * 2, [dm] * 2)
+    assert fl == flops and np.array_equal(rowptr, c.rowptr) and np.array_equal(dest, c.colidx)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
@@ -198,14 +261,13 @@ def test_varlen_reach_config5_standin_matches_the_oracle(ctx):
     assert got["union_nnz"] == union.nnz and got["union_checksum"] == oracle.checksum_omp(union)
 
 
-def test_bfs_rmat26_levels_are_the_bfs_levels(ctx):
+def test_bfs_rmat26_levels_are_the_bfs_levels(ctx, bench_graphs):
     """BASELINE config 4's graph (RMAT-26, 1.06 G edges) on one device: two roots through the plan API, checked by the
     properties that pin a BFS level vector uniquely — level[src] = 0; no edge (u, v) with u reached skips a level
     (level[v] <= level[u] + 1, v reached); every reached v != src has a parent one level up joined to it by a stored
     edge; reached / edges_traversed agree with the level vector.  The edges are streamed back in row windows so the
     host never holds more than ~3 GB."""
-    A = ctx.mat_rmat(26)
-    At = A.transpose()
+    A, At, _ = bench_graphs(26)
     n = A.nrows
     plan = engine.BfsPlan(ctx, A, At)
     first = A.extract(0, 4095)[0]
@@ -248,15 +310,12 @@ def bench_roots(A, want=64):
     return [int(r) for r in np.unique(rows)[:want]]
 
 
-def test_bfs_rmat22_all_bench_roots_match_the_oracle_levels(ctx):
+def test_bfs_rmat22_all_bench_roots_match_the_oracle_levels(ctx, bench_graphs):
     """BASELINE config 2 exactly as bench.py times it: RMAT-22, the 64 roots of the bench, every level vector and
     traversed-edge count against the oracle's BFS (oracle_omp.c orc_bfs_omp, held equal to the serial restatement by
     tests/test_oracle_golden.py) — through the plan API the bench uses (synchronous and the pipelined two-plan loop)
     and through the host-array ABI entry fgpu_bfs."""
-    A = ctx.mat_rmat(22)
-    At = A.transpose()
-    rp, ci, _ = A.export_csr()
-    a = oracle.CSR(A.nrows, A.ncols, rp, ci)
+    A, At, a = bench_graphs(22)
     trp, tci, _ = At.export_csr()
     at = oracle.CSR(A.nrows, A.ncols, trp, tci)
     roots = bench_roots(A)
@@ -287,14 +346,10 @@ def test_bfs_rmat22_all_bench_roots_match_the_oracle_levels(ctx):
         assert (level[parent[others]] + 1 == level[others]).all()
 
 
-def test_bfs_rmat26_two_roots_match_the_oracle_levels(ctx):
+def test_bfs_rmat26_two_roots_match_the_oracle_levels(ctx, bench_graphs):
     """BASELINE config 4's graph on one device, level for level against the oracle (push-only OpenMP BFS: the host
     never holds the transposed copy of the 1.06 G-edge graph)."""
-    A = ctx.mat_rmat(26)
-    At = A.transpose()
-    rp, ci, _ = A.export_csr()
-    a = oracle.CSR(A.nrows, A.ncols, rp, ci)
-    del rp, ci
+    A, At, a = bench_graphs(26)
     plan = engine.BfsPlan(ctx, A, At)
     for r in bench_roots(A, 2):
         ref_level, ref_edges = oracle.bfs_omp(a, None, r, -1)

@@ -79,24 +79,33 @@ def test_tiled_vxm_ragged_and_empty(ctx):
     assert info["items"] == 0 and info["tiles"] == 2
 
 
-def test_tiled_full_pass_rmat22_matches_csr_pull(ctx):
-    """BASELINE.json configs[1] size: both layouts must produce the same next-frontier words, and a
-    dense frontier must reach exactly the vertices with an in-edge."""
-    A = ctx.mat_rmat(22)
-    At = A.transpose()
+def full_pass_cases(n, seed):
+    """Frontiers / masks of the full-size passes: a random fifth of the vertices, with and without a random-half mask, and
+    the dense frontier (the north-star "full-matrix pass": every stored entry is examined)."""
+    rng = np.random.default_rng(seed)
+    f = oracle.bits_from_ids(n, rng.choice(n, n // 5, replace=False))
+    mask = oracle.bits_from_ids(n, rng.choice(n, n // 2, replace=False))
+    full = oracle.bits_from_ids(n, np.arange(n))
+    return [(f, None), (f, mask), (full, None), (full, mask)]
+
+
+def test_tiled_full_pass_rmat22_matches_the_oracle(ctx, bench_graphs):
+    """BASELINE.json configs[1] size, the layout whose roofline fraction bench.py quotes (tiled_mxv_kernel, RMAT-22): the
+    next-frontier words of the LDS-tiled pass against oracle.vxm (GrB_vxm, graphblas/mod.rs:11173) over the same 65 M
+    edges — random, masked and dense frontiers — and, as a second check, against the CSR pull kernel of the library."""
+    A, At, a = bench_graphs(22)
     n = A.nrows
     info = At.build_tiles()
     assert info["tiles"] == 4 and info["tile_bits"] == 20
-    rng = np.random.default_rng(22)
-    f = oracle.bits_from_ids(n, rng.choice(n, n // 5, replace=False))
-    mask = oracle.bits_from_ids(n, rng.choice(n, n // 2, replace=False))
-    for mk in (None, mask):
-        np.testing.assert_array_equal(engine.vxm(ctx, f, mk, A, At, 3), engine.vxm(ctx, f, mk, A, At, 2))
+    for f, mk in full_pass_cases(n, 22):
+        want = oracle.vxm(a, f, mk)
+        got = engine.vxm(ctx, f, mk, A, At, 3)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(engine.vxm(ctx, f, mk, A, At, 2), want)
     full = oracle.bits_from_ids(n, np.arange(n))
-    got = engine.vxm(ctx, full, None, A, At, 3)
     rp, _, _ = At.export_csr()
     has_in = np.diff(rp.astype(np.int64)) > 0
-    np.testing.assert_array_equal(oracle.ids_from_bits(got, n), np.nonzero(has_in)[0])
+    np.testing.assert_array_equal(oracle.ids_from_bits(engine.vxm(ctx, full, None, A, At, 3), n), np.nonzero(has_in)[0])
 
 
 # ---- blocked layout (blocked.hip): x tile AND output window in LDS -----------------------------------------------------
@@ -148,21 +157,17 @@ def test_blocked_vxm_ragged_hubs_and_empty(ctx, blocked):
     assert info["entries"] == 0
 
 
-@pytest.mark.parametrize("scale", [22, 24])
-def test_blocked_full_pass_matches_csr_pull(ctx, blocked, scale):
-    """BASELINE sizes: the blocked pass against the CSR pull kernel of the same library (itself pinned on the oracle
-    above), random and dense frontiers, with and without a mask."""
-    A = ctx.mat_rmat(scale)
-    At = A.transpose()
+@pytest.mark.parametrize("scale", [22, 24, 26])
+def test_blocked_full_pass_matches_the_oracle(ctx, blocked, bench_graphs, scale):
+    """BASELINE sizes, the layout whose roofline fractions bench.py quotes at RMAT-24 / 26 (blocked_mxv_kernel): the blocked
+    pass against oracle.vxm over the same graph (65 M / 263 M / 1.06 G edges) — random, masked and dense frontiers; the CSR
+    pull kernel of the library is held to the same words as a second check."""
+    A, At, a = bench_graphs(scale)
     n = A.nrows
     info = At.build_tiles()
     assert info["tile_bits"] == 18
-    rng = np.random.default_rng(scale)
-    f = oracle.bits_from_ids(n, rng.choice(n, n // 5, replace=False))
-    mask = oracle.bits_from_ids(n, rng.choice(n, n // 2, replace=False))
-    for mk in (None, mask):
-        np.testing.assert_array_equal(engine.vxm(ctx, f, mk, A, At, 3), engine.vxm(ctx, f, mk, A, At, 2))
-    full = oracle.bits_from_ids(n, np.arange(n))
-    got = engine.vxm(ctx, full, None, A, At, 3)
-    rp, _, _ = At.export_csr()
-    np.testing.assert_array_equal(oracle.ids_from_bits(got, n), np.nonzero(np.diff(rp.astype(np.int64)) > 0)[0])
+    for f, mk in full_pass_cases(n, scale):
+        want = oracle.vxm(a, f, mk)
+        np.testing.assert_array_equal(engine.vxm(ctx, f, mk, A, At, 3), want)
+        if scale < 26 or mk is None:
+            np.testing.assert_array_equal(engine.vxm(ctx, f, mk, A, At, 2), want)

@@ -646,3 +646,91 @@ def test_bfs_tiny_kernel_modes(ctx, tiny):
                     check_bfs(a, level, parent, src, ref)
     finally:
         ctx.set_option("bfs_tiny", 2)
+
+
+# ---- the result path of the two ABI entries the reference would call (ctx.hip: pinned pool, DMA, streamed chunks) ----------
+
+@pytest.fixture(scope="module")
+def rmat18(ctx):
+    a = oracle.rmat_csr(18)
+    return up(ctx, a), a
+
+
+@pytest.mark.parametrize("pinned", [1, 0])
+def test_expand_host_arrays_pinned_and_staged_paths_agree_with_the_oracle(ctx, rmat18, pinned):
+    """fgpu_expand hands back (rowptr, dest) in host memory: pinned pool blocks filled by one DMA each, ids widened on the
+    device (pinned_results = 1), or the caller's allocator + the staging ring (0, the round-3 path).  Both against the
+    oracle's chain, a result large enough (> 256 KiB) for the pinned route to be the one taken."""
+    A, a = rmat18
+    src = np.arange(11, a.nrows, 997, dtype=U64)
+    c, flops, _ = oracle.expand_omp(src, [(a, None, None)] * 2)
+    assert c.nnz * 8 > (1 << 20)
+    try:
+        ctx.set_option("pinned_results", pinned)
+        for _ in range(3):                                   # the second and third results reuse the first one's blocks
+            rowptr, dest, fl = engine.expand(ctx, src, [A, A])
+            assert fl == flops
+            np.testing.assert_array_equal(rowptr, c.rowptr)
+            np.testing.assert_array_equal(dest, c.colidx)
+            del rowptr, dest
+    finally:
+        ctx.set_option("pinned_results", 1)
+
+
+@pytest.mark.parametrize("chunk_rows,dest_bits", [(1, 64), (7, 32), (64, 64), (4096, 32)])
+def test_expand_stream_chunks_concatenate_to_the_oracle_result(ctx, rmat18, chunk_rows, dest_bits):
+    """fgpu_expand_stream_*: what CondTraverseOp::expand_batch walks (cond_traverse.rs:644-751), chunk by chunk — the
+    chunks cover the source rows in order, their relative row pointers and destinations concatenate to the oracle's
+    (rowptr, dest), for chunk sizes below, at and above the batch size and both id widths; empty rows included."""
+    A, a = rmat18
+    src = np.arange(5, a.nrows, 1531, dtype=U64)
+    c, flops, _ = oracle.expand_omp(src, [(a, None, None)] * 2)
+    st = engine.ExpandStream(ctx, src, [A, A], chunk_rows=chunk_rows, dest_bits=dest_bits)
+    assert st.nnz == c.nnz and st.flops == flops
+    nxt, dest, rowptr = 0, [], [np.zeros(1, dtype=U64)]
+    for first, rp, d in st:
+        assert first == nxt and 1 <= len(rp) - 1 <= chunk_rows and rp[0] == 0
+        assert d.dtype == (np.uint64 if dest_bits == 64 else np.uint32)
+        rowptr.append(rp[1:].astype(U64) + rowptr[-1][-1])
+        dest.append(d.astype(U64))                            # copied: the views die with the next step
+        nxt = first + len(rp) - 1
+    st.close()
+    assert nxt == len(src)
+    np.testing.assert_array_equal(np.concatenate(rowptr), c.rowptr)
+    np.testing.assert_array_equal(np.concatenate(dest) if dest else np.zeros(0, dtype=U64), c.colidx)
+    # closing early, and a batch with no result at all
+    st = engine.ExpandStream(ctx, src, [A, A], chunk_rows=3)
+    next(st)
+    st.close()
+    e = ctx.mat_new(a.nrows, a.nrows)
+    st = engine.ExpandStream(ctx, src[:5], [e])
+    got = list(st)
+    assert st.nnz == 0 and sum(len(rp) - 1 for _, rp, _ in got) == 5 and all(len(d) == 0 for _, _, d in got)
+    st.close()
+
+
+def test_bfs_into_pinned_caller_arrays_matches_the_oracle(ctx, rmat18):
+    """fgpu_bfs with level[] / parent[] in pinned memory from fgpu_host_alloc (DMA, the parent widened on the device)
+    against the same call into pageable numpy arrays (staging ring) and the oracle's levels."""
+    A, a = rmat18
+    At = A.transpose()
+    n = a.nrows
+    level_p, parent_p = ctx.host_array(n, np.int32), ctx.host_array(n, np.int64)
+    for src in (int(np.argmax(np.diff(a.rowptr))), 3):
+        ref_level, _, ref_edges = oracle.bfs(a, src, -1)
+        level_p[:] = 77
+        parent_p[:] = 77
+        lv, par, e = engine.bfs(ctx, A, At, src, -1, True, level_out=level_p, parent_out=parent_p)
+        assert lv is level_p and e == ref_edges
+        np.testing.assert_array_equal(level_p, ref_level)
+        lv2, par2, _ = engine.bfs(ctx, A, At, src, -1, True)
+        np.testing.assert_array_equal(lv2, ref_level)
+        reached = ref_level > 0
+        for par_ in (parent_p, par2):                          # any valid parent (SURVEY.md §8c): one level up, -1 if unreached
+            assert (ref_level[par_[reached]] + 1 == ref_level[reached]).all() and (par_[ref_level < 0] == -1).all()
+            assert par_[src] == src
+    del level_p, parent_p
+    # the pool hands the block back
+    again = ctx.host_array(n, np.int32)
+    again[:] = 1
+    assert int(again.sum()) == n
