@@ -496,7 +496,7 @@ void* fgpu_ctx::pinned_alloc(size_t bytes) {
     {
         std::lock_guard<std::mutex> g(mu);
         auto it = pin_pool.lower_bound(cap);
-        if (it != pin_pool.end() && it->first <= cap + cap / 4) {
+        if (it != pin_pool.end() && it->first <= 2 * cap) {   // (k-hop results of one query shape vary by tens of per cent)
             void* p = it->second;
             pin_pooled -= it->first;
             pin_live[p] = it->first;

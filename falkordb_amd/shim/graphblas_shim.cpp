@@ -12,11 +12,15 @@
 // extractElement / isStoredElement for an absent entry, the row iterator's SUCCESS / NO_VALUE / EXHAUSTED protocol
 // (matrix.rs:1500-1605 drives it row by row), duplicate collapse in build (SECOND for UINT64).
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../host/host.hpp"
@@ -34,7 +38,8 @@ enum {
 };
 typedef int GrB_Info;
 
-struct GB_Type_opaque { int code; };            // 0 = BOOL, 1 = UINT64
+struct GB_Type_opaque { int code; const char* name; size_t size; };   // 0 = BOOL, 1 = UINT64; 2.. = the integer types a
+                                                                       // GxB_Container's p / h / i / b vectors come in
 struct GB_BinaryOp_opaque { int code; };        // 0 = ANY_BOOL, 1 = SECOND_UINT64, 2 = ANY_UINT64
 struct GB_UnaryOp_opaque { int code; };         // 0 = ONE_BOOL
 struct GB_Semiring_opaque { int code; };        // 0 = ANY_PAIR_BOOL
@@ -47,7 +52,21 @@ struct GB_Matrix_opaque {
     int32_t orientation = 0;        // GrB_ROWMAJOR
     explicit GB_Matrix_opaque(Matrix mm) : m(std::move(mm)) {}
 };
+// GrB_Vector as the wrapper uses it (vector.rs): (a) a sparse BOOL / UINT64 vector filled by setElement and walked by the
+// vector iterator (the id list of a multi-edge pair, tensor.rs:1111-1120: indices = edge ids), serialised as a blob;
+// (b) the dense array a GxB_Container field holds, moved in and out with GxB_Vector_load / _unload (vector.rs:241-420).
+struct GB_Vector_opaque {
+    GB_Type_opaque* type = nullptr;
+    GrB_Index n = 0;                         // length
+    std::map<GrB_Index, uint64_t> s;         // (a) stored entries
+    void* data = nullptr;                    // (b) adopted array: n entries of type->size bytes (iso vectors: 1 entry)
+    uint64_t nbytes = 0;
+    uint64_t nstored = 0;                    // entries `data` holds (n, or 1 for an iso array)
+    int handling = 0;
+};
 struct GB_Iterator_opaque {
+    GB_Vector_opaque* vec = nullptr;                                  // vector mode (GxB_Vector_Iterator_*)
+    std::map<GrB_Index, uint64_t>::const_iterator vit;
     std::unique_ptr<Matrix> m;       // keeps the handle's state alive (the wrapper holds an Arc as well, matrix.rs:1472)
     GrB_Index nrows = 0, row = 0;    // current row; == nrows when exhausted
     GrB_Index w_lo = 1, w_hi = 0;    // rows covered by `buf` (empty window when w_lo > w_hi)
@@ -64,9 +83,83 @@ typedef GB_Global_opaque* GrB_Global;
 typedef GB_Scalar_opaque* GrB_Scalar;
 typedef GB_Matrix_opaque* GrB_Matrix;
 typedef GB_Iterator_opaque* GxB_Iterator;
+typedef GB_Vector_opaque* GrB_Vector;
+
+// GxB_Container_struct, field for field as bindgen lays it out (mod.rs:14165-14188; 608 bytes, the wrapper copies it raw,
+// matrix.rs:451-456, 517-520)
+struct GxB_Container_struct {
+    uint64_t nrows, ncols;
+    int64_t nrows_nonempty, ncols_nonempty;
+    uint64_t nvals;
+    uint64_t u64_future[11];
+    int32_t format, orientation, header_arena;
+    uint32_t u32_future[13];
+    GrB_Vector p, h, b, i, x;
+    GrB_Vector vector_future[11];
+    GrB_Matrix Y;
+    GrB_Matrix matrix_future[15];
+    bool iso, jumbled;
+    bool bool_future[30];
+    void* void_future[16];
+};
+static_assert(sizeof(GxB_Container_struct) == 608, "GxB_Container_struct must match the bindgen layout (mod.rs:14190)");
+typedef GxB_Container_struct* GxB_Container;
 
 namespace {
-GB_Type_opaque t_bool{0}, t_u64{1};
+GB_Type_opaque t_bool{0, "GrB_BOOL", 1}, t_u64{1, "GrB_UINT64", 8}, t_u32{2, "GrB_UINT32", 4}, t_i32{3, "GrB_INT32", 4},
+    t_i64{4, "GrB_INT64", 8}, t_i8{5, "GrB_INT8", 1}, t_u8{6, "GrB_UINT8", 1}, t_u16{7, "GrB_UINT16", 2}, t_i16{8, "GrB_INT16", 2};
+GB_Type_opaque* const all_types[] = {&t_bool, &t_u64, &t_u32, &t_i32, &t_i64, &t_i8, &t_u8, &t_u16, &t_i16};
+
+// the allocator GxB_init was handed (matrix.rs:116-185 passes Redis'): arrays that change owner across the ABI — what
+// GxB_Vector_unload / GxB_Vector_serialize give out, what GxB_Vector_load adopts — are allocated and released with it
+void* (*g_malloc)(size_t) = nullptr;
+void (*g_free)(void*) = nullptr;
+void* shim_malloc(size_t n) { return g_malloc ? g_malloc(n ? n : 1) : malloc(n ? n : 1); }
+void shim_free(void* p) { if (!p) return; if (g_free) g_free(p); else free(p); }
+
+void vec_drop_array(GB_Vector_opaque* v) { shim_free(v->data); v->data = nullptr; v->nbytes = 0; v->nstored = 0; }
+GB_Vector_opaque* vec_new(GB_Type_opaque* t, GrB_Index n) {
+    GB_Vector_opaque* v = new GB_Vector_opaque();
+    v->type = t; v->n = n;
+    return v;
+}
+void vec_set_array(GB_Vector_opaque* v, GB_Type_opaque* t, const void* bytes, uint64_t nbytes, uint64_t n_entries) {
+    vec_drop_array(v);
+    v->s.clear();
+    v->type = t; v->n = n_entries; v->nstored = t->size ? nbytes / t->size : 0; v->nbytes = nbytes;
+    if (nbytes) { v->data = shim_malloc(nbytes); memcpy(v->data, bytes, nbytes); }
+}
+GB_Type_opaque* type_by_name(const char* name) {
+    for (GB_Type_opaque* t : all_types)
+        if (!strcmp(t->name, name)) return t;
+    // the C type names GraphBLAS also accepts (GxB_Type_from_name)
+    static const struct { const char* c; GB_Type_opaque* t; } alias[] = {{"bool", &t_bool}, {"uint64_t", &t_u64}, {"uint32_t", &t_u32},
+        {"int32_t", &t_i32}, {"int64_t", &t_i64}, {"int8_t", &t_i8}, {"uint8_t", &t_u8}, {"uint16_t", &t_u16}, {"int16_t", &t_i16}};
+    for (auto& a : alias)
+        if (!strcmp(a.c, name)) return a.t;
+    return nullptr;
+}
+// the five vectors of a container in the Vector<bool> wire form (vector.rs:241-309) — the form serialize.cpp parses
+void put_vector(falkor::ByteWriter& w, const GB_Vector_opaque* v) {
+    static const char none[] = "GrB_INT8";
+    const char* tn = (v && v->type) ? v->type->name : none;
+    w.write_buffer(v ? v->data : nullptr, v ? v->nbytes : 0);
+    w.write_buffer(tn, strlen(tn) + 1);
+    w.write_unsigned(v ? v->n : 0);
+    w.write_unsigned(v ? v->nbytes : 0);
+    w.write_signed(0);
+}
+void take_vector(falkor::ByteReader& r, GB_Vector_opaque* v) {
+    std::vector<uint8_t> bytes = r.read_buffer(), name = r.read_buffer();
+    const uint64_t n = r.read_unsigned();
+    (void)r.read_unsigned();
+    (void)r.read_signed();
+    GB_Type_opaque* t = name.empty() ? nullptr : type_by_name((const char*)name.data());
+    if (!t) throw falkor::GrbError(FGPU_INVALID, "container vector of an unknown type");
+    vec_set_array(v, t, bytes.data(), bytes.size(), n);
+}
+constexpr char BLOB_IDS[8] = {'F', 'G', 'I', 'D', 'L', 'S', 'T', '1'};   // = serialize.cpp PLAIN_MAGIC: BOOL vector, the set indices
+constexpr char BLOB_U64[8] = {'F', 'G', 'V', 'E', 'C', 'U', '6', '4'};   // UINT64 vector: length, count, (index, value) pairs
 GB_BinaryOp_opaque op_any_bool{0}, op_second_u64{1}, op_any_u64{2};
 GB_UnaryOp_opaque op_one_bool{0};
 GB_Semiring_opaque sr_any_pair_bool{0};
@@ -173,7 +266,7 @@ SHIM_DESC(RSC, 1, 1, 1, 0, 0) SHIM_DESC(RSCT1, 1, 1, 1, 0, 1) SHIM_DESC(RSCT0, 1
 
 // ---- init / options (matrix.rs:116-221) ---------------------------------------------------------------------------
 GrB_Info GxB_init(int mode, void* (*mal)(size_t), void* (*cal)(size_t, size_t), void* (*rea)(void*, size_t), void (*fre)(void*)) {
-    (void)cal; (void)rea; (void)mal; (void)fre;   // results are handed out through the GrB calls' own out-parameters
+    (void)cal; (void)rea;
     if (mode != 0 && mode != 1) return GrB_INVALID_VALUE;
     std::lock_guard<std::mutex> g(g_mu);
     if (g_ctx) return GrB_INVALID_VALUE;          // initialised twice
@@ -181,6 +274,7 @@ GrB_Info GxB_init(int mode, void* (*mal)(size_t), void* (*cal)(size_t, size_t), 
         int dev = 0;
         if (const char* e = getenv("FGPU_DEVICE")) dev = atoi(e);
         g_ctx.reset(new falkor::Context(dev));   // throws without a HIP device: no CPU fallback behind this ABI either
+        g_malloc = mal; g_free = fre;            // ownership-changing arrays (GxB_Vector_load / _unload / _serialize) use these
     } catch (...) {
         return GrB_PANIC;                         // the wrapper turns this into Err(String): Redis refuses the module
     }
@@ -474,7 +568,272 @@ GrB_Index GxB_rowIterator_getRowIndex(GxB_Iterator it) { return it ? it->row : 0
 GrB_Index GxB_rowIterator_getColIndex(GxB_Iterator it) {
     return (it && it->pos < it->row_end) ? it->buf[it->pos].col : 0;
 }
-uint64_t GxB_Iterator_get_UINT64(GxB_Iterator it) { return (it && it->pos < it->row_end) ? it->buf[it->pos].val : 0; }
+uint64_t GxB_Iterator_get_UINT64(GxB_Iterator it) {
+    if (it && it->vec) return it->vit != it->vec->s.end() ? it->vit->second : 0;
+    return (it && it->pos < it->row_end) ? it->buf[it->pos].val : 0;
+}
 bool GxB_Iterator_get_BOOL(GxB_Iterator it) { return it && it->pos < it->row_end && it->buf[it->pos].val != 0; }
+
+
+// ---- what matrix.rs imports beside the traversal path (matrix.rs:79-102) ------------------------------------------------
+GrB_Info GrB_Matrix_build_BOOL(GrB_Matrix C, const GrB_Index* I, const GrB_Index* J, const bool* X, GrB_Index nvals, GrB_BinaryOp dup) {
+    if (!C || (nvals && (!I || !J || !X))) return GrB_NULL_POINTER;
+    if (C->m.type() != Type::Bool) return GrB_DOMAIN_MISMATCH;
+    if (dup && dup != GxB_ANY_BOOL) return GrB_NOT_IMPLEMENTED;
+    for (GrB_Index k = 0; k < nvals; ++k)
+        if (!X[k]) return GrB_NOT_IMPLEMENTED;     // a stored FALSE: the graph's boolean matrices are patterns (matrix.rs:1709-1775)
+    return guarded([&]() -> GrB_Info {
+        if (C->m.nvals()) return GrB_OUTPUT_NOT_EMPTY;
+        C->m.build(std::vector<uint64_t>(I, I + nvals), std::vector<uint64_t>(J, J + nvals));
+        return GrB_SUCCESS;
+    });
+}
+// every BOOL matrix of this engine is a pattern (iso TRUE); UINT64 matrices carry a value per entry
+GrB_Info GxB_Matrix_iso(bool* iso, GrB_Matrix A) {
+    if (!iso || !A) return GrB_NULL_POINTER;
+    *iso = A->m.type() == Type::Bool;
+    return GrB_SUCCESS;
+}
+// the device bytes of the wait()ed snapshot: row pointers + column ids (+ values), 32-bit ids (fgpu.h)
+GrB_Info GxB_Matrix_memoryUsage(size_t* size, GrB_Matrix A) {
+    if (!size || !A) return GrB_NULL_POINTER;
+    return guarded([&]() -> GrB_Info {
+        const uint64_t nv = A->m.nvals();
+        *size = sizeof(GB_Matrix_opaque) + (size_t)(A->m.nrows() + 1) * 4 + (size_t)nv * (A->m.type() == Type::UInt64 ? 12 : 4);
+        return GrB_SUCCESS;
+    });
+}
+GrB_Info GxB_Matrix_fprint(GrB_Matrix A, const char* name, int pr, FILE* f) {
+    if (!A) return GrB_NULL_POINTER;
+    if (pr <= 0) return GrB_SUCCESS;               // GxB_SILENT
+    return guarded([&]() -> GrB_Info {
+        FILE* o = f ? f : stdout;
+        const uint64_t nv = A->m.nvals();
+        fprintf(o, "\n  %llu x %llu GraphBLAS %s matrix, sparse by row\n  %s, %llu entr%s\n", (unsigned long long)A->m.nrows(),
+                (unsigned long long)A->m.ncols(), A->m.type() == Type::UInt64 ? "uint64_t" : "bool", name ? name : "", (unsigned long long)nv,
+                nv == 1 ? "y" : "ies");
+        if (pr >= 2 && nv) {                         // GxB_SHORT: the first 30 entries; GxB_COMPLETE: all of them
+            uint64_t shown = 0;
+            const uint64_t cap = pr >= 3 ? nv : 30, nr = A->m.nrows();
+            for (uint64_t lo = 0; lo < nr && shown < cap; lo += 4096) {
+                for (auto& e : A->m.iter(lo, lo + 4095 < nr ? lo + 4095 : nr - 1)) {
+                    if (shown++ >= cap) break;
+                    fprintf(o, "    (%llu,%llu)   %llu\n", (unsigned long long)e.row, (unsigned long long)e.col, (unsigned long long)e.val);
+                }
+            }
+            if (shown < nv) fprintf(o, "    ...\n");
+        }
+        return GrB_SUCCESS;
+    });
+}
+
+// ---- GrB_Vector (vector.rs:43-60) -------------------------------------------------------------------------------------
+GrB_Info GrB_Vector_new(GrB_Vector* v, GrB_Type type, GrB_Index n) {
+    if (!v || !type) return GrB_NULL_POINTER;
+    *v = vec_new(type, n);
+    return GrB_SUCCESS;
+}
+GrB_Info GrB_Vector_free(GrB_Vector* v) {
+    if (v && *v) { vec_drop_array(*v); delete *v; *v = nullptr; }
+    return GrB_SUCCESS;
+}
+GrB_Info GrB_Vector_clear(GrB_Vector v) { if (!v) return GrB_NULL_POINTER; v->s.clear(); vec_drop_array(v); return GrB_SUCCESS; }
+GrB_Info GrB_Vector_size(GrB_Index* n, GrB_Vector v) { if (!n || !v) return GrB_NULL_POINTER; *n = v->n; return GrB_SUCCESS; }
+GrB_Info GrB_Vector_nvals(GrB_Index* n, GrB_Vector v) {
+    if (!n || !v) return GrB_NULL_POINTER;
+    *n = v->data ? v->n : v->s.size();
+    return GrB_SUCCESS;
+}
+GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index n) {
+    if (!v) return GrB_NULL_POINTER;
+    if (v->data) return GrB_NOT_IMPLEMENTED;       // a loaded array is moved, not resized (the wrapper never does)
+    v->s.erase(v->s.lower_bound(n), v->s.end());
+    v->n = n;
+    return GrB_SUCCESS;
+}
+GrB_Info GrB_Vector_wait(GrB_Vector v, int) { return v ? GrB_SUCCESS : GrB_NULL_POINTER; }
+static GrB_Info vec_set(GrB_Vector v, uint64_t x, GrB_Index i) {
+    if (!v) return GrB_NULL_POINTER;
+    if (v->data) return GrB_NOT_IMPLEMENTED;
+    if (i >= v->n) return GrB_INVALID_INDEX;
+    return guarded([&]() -> GrB_Info { v->s[i] = x; return GrB_SUCCESS; });
+}
+GrB_Info GrB_Vector_setElement_BOOL(GrB_Vector v, bool x, GrB_Index i) { return vec_set(v, x ? 1 : 0, i); }
+GrB_Info GrB_Vector_setElement_UINT64(GrB_Vector v, uint64_t x, GrB_Index i) { return vec_set(v, x, i); }
+GrB_Info GrB_Vector_removeElement(GrB_Vector v, GrB_Index i) {
+    if (!v) return GrB_NULL_POINTER;
+    if (v->data) return GrB_NOT_IMPLEMENTED;
+    if (i >= v->n) return GrB_INVALID_INDEX;
+    v->s.erase(i);
+    return GrB_SUCCESS;
+}
+GrB_Info GrB_Type_get_String(GrB_Type type, char* value, int field) {
+    if (!type || !value) return GrB_NULL_POINTER;
+    if (field != 10 /* GrB_NAME (mod.rs GxB_Option_Field) */) return GrB_INVALID_VALUE;
+    strcpy(value, type->name);                     // (the caller's buffer holds GxB_MAX_NAME_LEN = 128 bytes, vector.rs:267)
+    return GrB_SUCCESS;
+}
+GrB_Info GxB_Type_from_name(GrB_Type* type, const char* name) {
+    if (!type || !name) return GrB_NULL_POINTER;
+    *type = type_by_name(name);
+    return *type ? GrB_SUCCESS : GrB_INVALID_VALUE;
+}
+// vector iterator (vector.rs:525-606): attach, seek(0), then getIndex / get_UINT64 / next until GxB_EXHAUSTED
+GrB_Info GxB_Vector_Iterator_attach(GxB_Iterator it, GrB_Vector v, GrB_Descriptor) {
+    if (!it || !v) return GrB_NULL_POINTER;
+    if (v->data) return GrB_NOT_IMPLEMENTED;
+    it->vec = v;
+    it->vit = v->s.begin();
+    return GrB_SUCCESS;
+}
+GrB_Info GxB_Vector_Iterator_seek(GxB_Iterator it, GrB_Index p) {
+    if (!it || !it->vec) return GrB_NULL_POINTER;
+    it->vit = it->vec->s.begin();
+    for (GrB_Index k = 0; k < p && it->vit != it->vec->s.end(); ++k) ++it->vit;   // p-th stored entry
+    return it->vit == it->vec->s.end() ? GxB_EXHAUSTED : GrB_SUCCESS;
+}
+GrB_Info GxB_Vector_Iterator_next(GxB_Iterator it) {
+    if (!it || !it->vec) return GrB_NULL_POINTER;
+    if (it->vit != it->vec->s.end()) ++it->vit;
+    return it->vit == it->vec->s.end() ? GxB_EXHAUSTED : GrB_SUCCESS;
+}
+GrB_Index GxB_Vector_Iterator_getIndex(GxB_Iterator it) { return (it && it->vec && it->vit != it->vec->s.end()) ? it->vit->first : 0; }
+// GxB_Vector_load / _unload (vector.rs:241-420): the array changes owner; *X is NULL afterwards on load, the vector is
+// empty (length 0) afterwards on unload
+GrB_Info GxB_Vector_load(GrB_Vector v, void** X, GrB_Type type, uint64_t n, uint64_t X_memsize, int handling, GrB_Descriptor) {
+    if (!v || !X || !type) return GrB_NULL_POINTER;
+    if (n && X_memsize / type->size < 1) return GrB_INVALID_VALUE;      // (an iso array holds one entry for n of them)
+    vec_drop_array(v);
+    v->s.clear();
+    v->type = type; v->n = n; v->data = *X; v->nbytes = X_memsize; v->nstored = X_memsize / type->size; v->handling = handling;
+    *X = nullptr;
+    return GrB_SUCCESS;
+}
+GrB_Info GxB_Vector_unload(GrB_Vector v, void** X, GrB_Type* type, uint64_t* n, uint64_t* X_memsize, int* handling, GrB_Descriptor) {
+    if (!v || !X || !type || !n || !X_memsize || !handling) return GrB_NULL_POINTER;
+    if (!v->data && !v->s.empty()) {
+        // a sparse vector can only be unloaded when it is full (GraphBLAS' rule): materialise it then
+        if (v->s.size() != v->n) return GrB_INVALID_VALUE;
+        const size_t sz = v->type->size;
+        char* a = (char*)shim_malloc(v->n * sz);
+        GrB_Index k = 0;
+        for (auto& kv : v->s) { memcpy(a + (k++) * sz, &kv.second, sz); }     // little-endian: the low bytes are the value
+        v->s.clear();
+        v->data = a; v->nbytes = v->n * sz; v->nstored = v->n;
+    }
+    *X = v->data; *type = v->type; *n = v->n; *X_memsize = v->nbytes; *handling = v->handling;
+    v->data = nullptr; v->nbytes = 0; v->nstored = 0; v->n = 0;
+    return GrB_SUCCESS;
+}
+// GxB_Vector_serialize / _deserialize (vector.rs:150-239): SuiteSparse's own blob format is not restated (it belongs to
+// the un-vendored library, and no fixture of it exists in the reference tree — DESIGN.md §9); the blob written here is the
+// plain little-endian list serialize.cpp's Tensor codec writes, so payloads of the two tiers read each other.  The blob is
+// allocated with the GxB_init allocator: the wrapper releases it itself (vector.rs:166-167).
+GrB_Info GxB_Vector_serialize(void** blob, GrB_Index* blob_size, GrB_Vector u, GrB_Descriptor) {
+    if (!blob || !blob_size || !u) return GrB_NULL_POINTER;
+    if (u->data) return GrB_NOT_IMPLEMENTED;
+    const bool ids = u->type == GrB_BOOL;
+    const uint64_t cnt = u->s.size();
+    const size_t sz = ids ? 16 + 8 * cnt : 24 + 16 * cnt;
+    uint8_t* b = (uint8_t*)shim_malloc(sz);
+    if (!b) return GrB_OUT_OF_MEMORY;
+    memcpy(b, ids ? BLOB_IDS : BLOB_U64, 8);
+    uint8_t* q = b + 8;
+    if (!ids) { memcpy(q, &u->n, 8); q += 8; }
+    memcpy(q, &cnt, 8); q += 8;
+    for (auto& kv : u->s) {
+        if (ids && !kv.second) { shim_free(b); return GrB_NOT_IMPLEMENTED; }   // a stored FALSE has no place in an id list
+        memcpy(q, &kv.first, 8); q += 8;
+        if (!ids) { memcpy(q, &kv.second, 8); q += 8; }
+    }
+    *blob = b; *blob_size = sz;
+    return GrB_SUCCESS;
+}
+GrB_Info GxB_Vector_deserialize(GrB_Vector* w, GrB_Type type, const void* blob, GrB_Index blob_size, GrB_Descriptor) {
+    if (!w || !blob) return GrB_NULL_POINTER;
+    const uint8_t* b = (const uint8_t*)blob;
+    if (blob_size < 16) return GrB_INVALID_OBJECT;
+    const bool ids = !memcmp(b, BLOB_IDS, 8);
+    if (!ids && memcmp(b, BLOB_U64, 8)) return GrB_INVALID_OBJECT;             // e.g. a real GxB_Vector_serialize blob
+    if (type && type != (ids ? GrB_BOOL : GrB_UINT64)) return GrB_DOMAIN_MISMATCH;
+    return guarded([&]() -> GrB_Info {
+        uint64_t n = (1ull << 60) - 1, cnt = 0;                                 // GrB_INDEX_MAX: the length of an id-list vector (tensor.rs:1115)
+        const uint8_t* q = b + 8;
+        if (!ids) { if (blob_size < 24) return GrB_INVALID_OBJECT; memcpy(&n, q, 8); q += 8; }
+        memcpy(&cnt, q, 8); q += 8;
+        if ((blob_size - (size_t)(q - b)) / (ids ? 8 : 16) < cnt) return GrB_INVALID_OBJECT;
+        std::unique_ptr<GB_Vector_opaque> v(vec_new(ids ? GrB_BOOL : GrB_UINT64, n));
+        for (uint64_t k = 0; k < cnt; ++k) {
+            uint64_t i = 0, x = 1;
+            memcpy(&i, q, 8); q += 8;
+            if (!ids) { memcpy(&x, q, 8); q += 8; }
+            if (i >= n) return GrB_INVALID_OBJECT;
+            v->s[i] = x;
+        }
+        *w = v.release();
+        return GrB_SUCCESS;
+    });
+}
+
+// ---- GxB_Container (matrix.rs:428-546: Decode<19> / Encode<19> of a Matrix) ------------------------------------------------
+GrB_Info GxB_Container_new(GxB_Container* c) {
+    if (!c) return GrB_NULL_POINTER;
+    GxB_Container_struct* k = (GxB_Container_struct*)calloc(1, sizeof(GxB_Container_struct));
+    if (!k) return GrB_OUT_OF_MEMORY;
+    k->p = vec_new(&t_u32, 0); k->h = vec_new(&t_u32, 0); k->b = vec_new(&t_i8, 0); k->i = vec_new(&t_u32, 0); k->x = vec_new(&t_bool, 0);
+    k->format = 2 /* GxB_SPARSE */; k->orientation = 0 /* GrB_ROWMAJOR */; k->iso = false; k->jumbled = false;
+    k->nrows_nonempty = k->ncols_nonempty = -1;
+    *c = k;
+    return GrB_SUCCESS;
+}
+GrB_Info GxB_Container_free(GxB_Container* c) {
+    if (!c || !*c) return GrB_SUCCESS;
+    GxB_Container_struct* k = *c;
+    for (GrB_Vector* v : {&k->p, &k->h, &k->b, &k->i, &k->x}) GrB_Vector_free(v);   // (NULL fields — the decoder nullifies and refills them — are skipped)
+    if (k->Y) GrB_Matrix_free(&k->Y);
+    free(k);
+    *c = nullptr;
+    return GrB_SUCCESS;
+}
+// A -> container: the wait()ed CSR moves into the container's vectors (x iso BOOL / UINT64, h, p, i, b) and A is left
+// without entries until a load puts content back (the encoder reloads the same container, matrix.rs:527-528)
+GrB_Info GxB_unload_Matrix_into_Container(GrB_Matrix A, GxB_Container C, GrB_Descriptor) {
+    if (!A || !C) return GrB_NULL_POINTER;
+    SHIM_REQUIRE_INIT();
+    return guarded([&]() -> GrB_Info {
+        falkor::ByteWriter w;
+        A->m.encode(w);                                               // serialize.cpp: struct bytes + x, h, p, i, b
+        falkor::ByteReader r(w.buf.data(), w.buf.size());
+        std::vector<uint8_t> st = r.read_buffer();
+        GrB_Vector keep[5] = {C->p, C->h, C->b, C->i, C->x};
+        GrB_Matrix y = C->Y;
+        memcpy(C, st.data(), sizeof(GxB_Container_struct));
+        C->p = keep[0]; C->h = keep[1]; C->b = keep[2]; C->i = keep[3]; C->x = keep[4]; C->Y = y;
+        for (GrB_Vector* v : {&C->x, &C->h, &C->p, &C->i, &C->b}) {
+            if (!*v) *v = vec_new(&t_i8, 0);
+            take_vector(r, *v);
+        }
+        A->m = Matrix(*ctx(), A->m.type(), A->m.nrows(), A->m.ncols());
+        return GrB_SUCCESS;
+    });
+}
+// container -> A: the arrays go to the device as they are (fgpu_mat_from_csr behind Matrix::decode); A takes the type of the
+// value vector (the decoder creates A as a 0 x 0 BOOL matrix first, matrix.rs:470-478); the container's vectors are left empty
+GrB_Info GxB_load_Matrix_from_Container(GrB_Matrix A, GxB_Container C, GrB_Descriptor) {
+    if (!A || !C) return GrB_NULL_POINTER;
+    SHIM_REQUIRE_INIT();
+    return guarded([&]() -> GrB_Info {
+        falkor::ByteWriter w;
+        GxB_Container_struct raw = *C;
+        raw.p = raw.h = raw.b = raw.i = raw.x = nullptr; raw.Y = nullptr;          // (pointers are not content)
+        w.write_buffer(&raw, sizeof(raw));
+        for (GrB_Vector v : {C->x, C->h, C->p, C->i, C->b}) put_vector(w, v);
+        falkor::ByteReader r(w.buf.data(), w.buf.size());
+        A->m = Matrix::decode(*ctx(), r);
+        for (GrB_Vector v : {C->x, C->h, C->p, C->i, C->b})
+            if (v) { vec_drop_array(v); v->s.clear(); v->n = 0; }
+        return GrB_SUCCESS;
+    });
+}
 
 }  // extern "C"
