@@ -28,6 +28,26 @@ typedef struct GB_Descriptor_opaque* GrB_Descriptor;         /* mod.rs:310 */
 typedef struct GB_Scalar_opaque* GrB_Scalar;                 /* mod.rs:352 */
 typedef struct GB_Matrix_opaque* GrB_Matrix;                 /* mod.rs:364 */
 typedef struct GB_Iterator_opaque* GxB_Iterator;             /* mod.rs:383 */
+typedef struct GB_Vector_opaque* GrB_Vector;                 /* mod.rs:358 */
+enum { GrB_NAME = 10 };                                       /* mod.rs:2879 */
+enum { GxB_MAX_NAME_LEN = 128 };                              /* mod.rs:158 */
+#define GrB_INDEX_MAX ((1ull << 60) - 1)                      /* tensor.rs:143 */
+typedef struct {                                              /* GxB_Container_struct, mod.rs:14165-14188 (608 bytes) */
+    uint64_t nrows, ncols;
+    int64_t nrows_nonempty, ncols_nonempty;
+    uint64_t nvals;
+    uint64_t u64_future[11];
+    int32_t format, orientation, header_arena;
+    uint32_t u32_future[13];
+    GrB_Vector p, h, b, i, x;
+    GrB_Vector vector_future[11];
+    GrB_Matrix Y;
+    GrB_Matrix matrix_future[15];
+    bool iso, jumbled;
+    bool bool_future[30];
+    void* void_future[16];
+} GxB_Container_struct;
+typedef GxB_Container_struct* GxB_Container;
 
 extern GrB_Type GrB_BOOL, GrB_UINT64;                         /* mod.rs:520, 544 */
 extern GrB_UnaryOp GxB_ONE_BOOL;                              /* mod.rs:721 */
@@ -79,4 +99,36 @@ GrB_Info GxB_rowIterator_nextCol(GxB_Iterator iterator);                        
 GrB_Index GxB_rowIterator_getRowIndex(GxB_Iterator iterator);                                 /* mod.rs:14903 */
 GrB_Index GxB_rowIterator_getColIndex(GxB_Iterator iterator);                                 /* mod.rs:14906 */
 uint64_t GxB_Iterator_get_UINT64(GxB_Iterator iterator);                                      /* mod.rs:15024 */
+/* the rest of matrix.rs:79-102's import list, and vector.rs:43-60's */
+GrB_Info GrB_Matrix_build_BOOL(GrB_Matrix C, const GrB_Index* I, const GrB_Index* J, const bool* X, GrB_Index nvals,
+                               GrB_BinaryOp dup);                                             /* mod.rs:9509 */
+GrB_Info GxB_Matrix_memoryUsage(size_t* size, GrB_Matrix A);                                  /* mod.rs:9497 */
+GrB_Info GxB_Matrix_iso(bool* iso, GrB_Matrix A);
+GrB_Info GxB_Matrix_fprint(GrB_Matrix A, const char* name, int pr, void* f);                  /* mod.rs:14132 */
+GrB_Info GxB_Container_new(GxB_Container* Container);                                         /* mod.rs:14240 */
+GrB_Info GxB_Container_free(GxB_Container* object);                                           /* mod.rs:15081 */
+GrB_Info GxB_load_Matrix_from_Container(GrB_Matrix A, GxB_Container Container, GrB_Descriptor desc);     /* mod.rs:14250 */
+GrB_Info GxB_unload_Matrix_into_Container(GrB_Matrix A, GxB_Container Container, GrB_Descriptor desc);   /* mod.rs:14264 */
+GrB_Info GrB_Vector_new(GrB_Vector* v, GrB_Type type, GrB_Index n);                           /* mod.rs:8894 */
+GrB_Info GrB_Vector_free(GrB_Vector* object);                                                 /* mod.rs:15069 */
+GrB_Info GrB_Vector_clear(GrB_Vector v);                                                      /* mod.rs:8924 */
+GrB_Info GrB_Vector_size(GrB_Index* n, GrB_Vector v);                                         /* mod.rs:8927 */
+GrB_Info GrB_Vector_resize(GrB_Vector w, GrB_Index nrows_new);                                /* mod.rs:14062 */
+GrB_Info GrB_Vector_wait(GrB_Vector object, int waitmode);                                    /* mod.rs:11072 */
+GrB_Info GrB_Vector_setElement_BOOL(GrB_Vector w, bool x, GrB_Index i);                       /* mod.rs:9102 */
+GrB_Info GrB_Vector_setElement_UINT64(GrB_Vector w, uint64_t x, GrB_Index i);                 /* mod.rs:9158 */
+GrB_Info GrB_Vector_removeElement(GrB_Vector v, GrB_Index i);                                 /* mod.rs:9318 */
+GrB_Info GrB_Type_get_String(GrB_Type object, char* value, int field);                        /* mod.rs:10503 */
+GrB_Info GxB_Type_from_name(GrB_Type* type, const char* type_name);                           /* mod.rs:8075 */
+GrB_Info GxB_Vector_Iterator_attach(GxB_Iterator iterator, GrB_Vector v, GrB_Descriptor desc);   /* mod.rs:14972 */
+GrB_Info GxB_Vector_Iterator_seek(GxB_Iterator iterator, GrB_Index p);                        /* mod.rs:14985 */
+GrB_Info GxB_Vector_Iterator_next(GxB_Iterator iterator);                                     /* mod.rs:14991 */
+GrB_Index GxB_Vector_Iterator_getIndex(GxB_Iterator iterator);                                /* mod.rs:14997 */
+GrB_Info GxB_Vector_load(GrB_Vector V, void** X, GrB_Type type, uint64_t n, uint64_t X_memsize, int handling,
+                         GrB_Descriptor desc);                                                /* mod.rs:14278 */
+GrB_Info GxB_Vector_unload(GrB_Vector V, void** X, GrB_Type* type, uint64_t* n, uint64_t* X_memsize, int* handling,
+                           GrB_Descriptor desc);                                              /* mod.rs:14289 */
+GrB_Info GxB_Vector_serialize(void** blob_handle, GrB_Index* blob_size, GrB_Vector u, GrB_Descriptor desc);   /* mod.rs:14717 */
+GrB_Info GxB_Vector_deserialize(GrB_Vector* w, GrB_Type type, const void* blob, GrB_Index blob_size,
+                                GrB_Descriptor desc);                                         /* mod.rs:14768 */
 #endif

@@ -72,6 +72,16 @@ def test_matrix_rs_call_sequences_through_the_graphblas_abi_match_the_oracle(rep
     assert nvals == c.nnz
     assert got == list(zip(cr.tolist(), cc.tolist()))       # ascending (row, col): the iterator's order (matrix.rs:1572-1605)
     probes = [l.split() for l in lines[1 + nvals:] if l.startswith("probe")]
+    # Encode<19> / Decode<19> through GxB_Container + GxB_Vector_load / _unload (matrix.rs:428-546, vector.rs:241-420)
+    cont = {l.split()[1]: l.split()[2:] for l in lines if l.startswith("container ")}
+    assert int(cont["m"][0]) == a.nnz and cont["m"][3] == "1", cont
+    assert cont["m"][2] == ("0" if valued else "1")                        # iso: BOOL matrices are patterns, UINT64 ones are not
+    assert int(cont["dm"][0]) == dm.nnz and cont["dm"][3] == "1", cont
+    # the multi-edge id list (tensor.rs:1111-1120) and a Vector<u64> through serialize / deserialize / the vector iterator
+    assert [l for l in lines if l.startswith("ids ")] == [f"ids 1 5 500 501 {1 << 40}"]
+    assert [l for l in lines if l.startswith("u64vec")] == [f"u64vec 3:{1 << 63} 9:77"]
+    mem = [l.split() for l in lines if l.startswith("mem ")][0]
+    assert int(mem[1]) >= 4 * (n + 1 + a.nnz) and mem[3] == ("0" if valued else "1")
     first = (0, 0) in a.to_set()
     assert int(probes[0][1]) == (0 if first else 1)         # GrB_SUCCESS / GrB_NO_VALUE
     if first and valued:
@@ -81,20 +91,19 @@ def test_matrix_rs_call_sequences_through_the_graphblas_abi_match_the_oracle(rep
 
 
 def test_shim_exports_every_symbol_the_wrapper_imports():
-    """The import list of matrix.rs:79-102 that belongs to the traversal path, checked against the built library."""
+    """Link completeness, checked mechanically: tests/golden/shim_symbols.json is GENERATED (tests/golden/
+    make_shim_symbols.py, run in the build container) from the `use super::{...}` import lists of the reference's
+    matrix.rs:79-102, vector.rs:43-60, tensor.rs and versioned_matrix.rs, keeping the names bindgen declares as extern
+    functions / statics — every one of them must be a defined dynamic symbol of libgraphblas.so."""
+    import json
     from falkordb_amd import build as fb
     so = fb.build_shim()
     out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
     have = {l.split()[-1] for l in out.splitlines() if l.strip()}
-    want = """GrB_BOOL GrB_UINT64 GxB_ANY_PAIR_BOOL GxB_ANY_BOOL GrB_SECOND_UINT64 GxB_ONE_BOOL GxB_ANY_UINT64 GrB_GLOBAL
-        GrB_DESC_C GrB_DESC_RC GrB_DESC_RCT0 GrB_DESC_RSC GrB_DESC_T0 GrB_DESC_T1 GrB_DESC_R GrB_DESC_S GrB_DESC_RSCT0T1
-        GxB_init GrB_finalize GrB_Global_set_INT32 GrB_Matrix_new GrB_Matrix_free GrB_Matrix_dup GrB_Matrix_nrows GrB_Matrix_ncols
-        GrB_Matrix_nvals GrB_Matrix_wait GrB_Matrix_clear GrB_Matrix_resize GrB_Matrix_get_INT32 GrB_Matrix_set_INT32
-        GxB_Matrix_type GxB_Matrix_build_Scalar GrB_Matrix_build_UINT64 GrB_Matrix_setElement_BOOL GrB_Matrix_setElement_UINT64
-        GrB_Matrix_removeElement GrB_Matrix_extractElement_BOOL GrB_Matrix_extractElement_UINT64 GxB_Matrix_isStoredElement
-        GrB_mxm GrB_Matrix_eWiseAdd_BinaryOp GrB_Matrix_eWiseMult_Semiring GrB_Matrix_apply GrB_transpose GrB_Scalar_new
-        GrB_Scalar_setElement_BOOL GrB_Scalar_free GxB_Iterator_new GxB_Iterator_free GxB_Iterator_get_UINT64
-        GxB_rowIterator_attach GxB_rowIterator_seekRow GxB_rowIterator_nextRow GxB_rowIterator_nextCol
-        GxB_rowIterator_getRowIndex GxB_rowIterator_getColIndex GxB_rowIterator_kount""".split()
-    missing = [s for s in want if s not in have]
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "shim_symbols.json")))
+    assert len(want["functions"]) >= 60 and len(want["globals"]) >= 35
+    for must in ("GrB_Matrix_build_BOOL", "GxB_Container_new", "GxB_load_Matrix_from_Container", "GxB_unload_Matrix_into_Container",
+                 "GxB_Matrix_memoryUsage", "GxB_Matrix_fprint", "GrB_Vector_new", "GxB_Vector_serialize", "GxB_Vector_load"):
+        assert must in want["functions"], must               # (the generator still sees the lists it was written for)
+    missing = [s for s in want["functions"] + want["globals"] if s not in have]
     assert not missing, missing
