@@ -707,6 +707,14 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.expand_row_groups = value != 0;
     } else if (!strcmp(name, "expand_fuse_count")) {
         ctx->opt.expand_fuse_count = value != 0;
+    } else if (!strcmp(name, "expand_hot")) {
+        ctx->opt.expand_hot = value != 0;
+    } else if (!strcmp(name, "expand_hot_rows")) {
+        FGPU_REQUIRE(value >= 64 && value <= (1 << 20), FGPU_INVALID, "expand_hot_rows out of range");
+        ctx->opt.expand_hot_rows = (int)value;
+    } else if (!strcmp(name, "expand_hot_min")) {
+        FGPU_REQUIRE(value >= 1 && value <= (1 << 20), FGPU_INVALID, "expand_hot_min out of range");
+        ctx->opt.expand_hot_min = (int)value;
     } else if (!strcmp(name, "expand_bits_ratio")) {
         FGPU_REQUIRE(value >= 1 && value <= 1024, FGPU_INVALID, "expand_bits_ratio out of range");
         ctx->opt.expand_bits_ratio = (int)value;

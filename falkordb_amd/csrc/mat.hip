@@ -65,6 +65,7 @@ void mat_release(fgpu_mat* m) {
     if (c) c->dev_free(m->bp_items);
     if (c) c->dev_free(m->bp_sitems);
     if (c) c->dev_free(m->bp_split_bits);
+    if (m->bp_hot) bp_hot_release(c, m->bp_hot);
     if (m->tcache) mat_release(m->tcache);
     delete m;
 }

@@ -71,6 +71,46 @@ def test_khop_rmat20_dirty_layers_match_the_oracle(ctx, rmat20, mode):
     assert ref[0] > 20_000_000            # the case is not trivially small
 
 
+@pytest.fixture(scope="module")
+def rmat20_refs(rmat20):
+    A, dp, dm, a, hdp, hdm = rmat20
+    src = p_sources(a.nrows, 1024)[:640]                      # 10 words per row -> ws = 16: the bench's row width
+    refs = {}
+    for dirty in (False, True):
+        c, flops, _ = oracle.expand_omp(src, [(a, hdp, hdm) if dirty else (a, None, None)] * 3)
+        refs[dirty] = (c.nnz, oracle.checksum_omp(c), flops)
+        del c
+    return src, refs
+
+
+@pytest.mark.parametrize("hot_rows,hot_min", [(0, 0), (64, 1), (64, 32), (1024, 8), (16384, 32)])
+def test_khop_rmat20_count_hop_with_xcd_partitioned_hot_rows(ctx, rmat20, rmat20_refs, hot_rows, hot_min):
+    """The dense count hop with the hot rows of X partitioned over the XCDs (bitexpand.hip BpHotPlan): whatever the hot
+    set (64 rows per partition ... the default 16384) and the bar a row of A' must pass to join the hot pass (1 hot entry:
+    almost every row is cut into partial rows; 32: the in-hubs), clean and dirty layers, count-only and checksum forms give
+    the oracle's (nnz, checksum, flops); hot_rows = 0 is the plain pull (expand_hot off — the default: the hot pass measured
+    slower than the plain pull at every setting; it stays in the library as the experiment it was)."""
+    A, dp, dm, a, hdp, hdm = rmat20
+    src, refs = rmat20_refs
+    try:
+        ctx.set_option("expand_mode", 2)
+        ctx.set_option("expand_hot", 1 if hot_rows else 0)
+        if hot_rows:
+            ctx.set_option("expand_hot_rows", hot_rows)
+            ctx.set_option("expand_hot_min", hot_min)
+        for dirty in (False, True):
+            layers = ([A] * 3, [dp] * 3, [dm] * 3) if dirty else ([A] * 3,)
+            for _ in range(2):                                 # the second call reuses the plan (and the recycled state)
+                assert engine.expand_count(ctx, src, *layers) == refs[dirty], (hot_rows, hot_min, dirty)
+            nn, _, fl = engine.expand_count(ctx, src, *layers, want_checksum=False)
+            assert (nn, fl) == (refs[dirty][0], refs[dirty][2])
+    finally:
+        ctx.set_option("expand_mode", 0)
+        ctx.set_option("expand_hot", 0)
+        ctx.set_option("expand_hot_rows", 16384)
+        ctx.set_option("expand_hot_min", 32)
+
+
 def test_khop_rmat20_full_rows_match_the_oracle(ctx, rmat20):
     """The same chain with the whole (row, dest) result compared entry by entry (fgpu_expand, what the operator emits),
     clean and dirty layers, with a destination-label bitmap on the dirty run."""
