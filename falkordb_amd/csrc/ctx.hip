@@ -5,6 +5,8 @@
 
 #include <iterator>
 
+#include <chrono>
+
 #include "common.hpp"
 
 namespace fgpu {
@@ -19,18 +21,51 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
-fgpu_info read_u32(fgpu_ctx* ctx, const u32* dev, u32* host) {
+// ---- scalar read-backs ----------------------------------------------------------------------------------------------
+__global__ void publish_words_kernel(const u32* __restrict__ src, int nwords, u32* __restrict__ dst, u32 seq) {
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < nwords; ++w) __hip_atomic_store(dst + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // after the words: release
+    }
+}
+
+fgpu_info read_words(fgpu_ctx* ctx, const u32* dev, int nwords, u32* host) {   // nwords <= 14
     fgpu_lane* l = ctx->lane();
-    FGPU_HIP(hipMemcpyAsync(l->pinned, dev, sizeof(u32), hipMemcpyDeviceToHost, l->stream));
-    FGPU_HIP(hipStreamSynchronize(l->stream));
-    *host = *(u32*)l->pinned;
+    if (!l->pub_host) {                                       // (mapping failed at lane creation: the runtime copy)
+        FGPU_HIP(hipMemcpyAsync(l->pinned, dev, (size_t)nwords * sizeof(u32), hipMemcpyDeviceToHost, l->stream));
+        FGPU_HIP(hipStreamSynchronize(l->stream));
+        memcpy(host, l->pinned, (size_t)nwords * sizeof(u32));
+        return FGPU_OK;
+    }
+    const u32 seq = ++l->pub_seq ? l->pub_seq : ++l->pub_seq;   // never 0 (the line's initial content)
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, l->stream, dev, nwords, l->pub_dev, seq);
+    FGPU_HIP(hipGetLastError());
+    volatile u32* flag = (volatile u32*)(l->pub_host + 15);
+    // spin without touching the stream (a hipStreamQuery costs the next dispatch a system-scope fence); past
+    // 2 ms look at the stream now and then so that a failed launch is reported instead of waited for
+    const auto t0 = std::chrono::steady_clock::now();
+    for (u32 spin = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spin) {
+        if ((spin & 0xFFFu) == 0xFFFu &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+            const hipError_t q = hipStreamQuery(l->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+                FGPU_HIP(hipStreamSynchronize(l->stream));
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { set_error("scalar read-back: the publish kernel did not run"); return FGPU_DEVICE; }
+                break;
+            }
+            if (q != hipErrorNotReady) { set_error("scalar read-back: stream failed: %s", hipGetErrorString(q)); return FGPU_DEVICE; }
+        }
+    }
+    for (int w = 0; w < nwords; ++w) host[w] = ((volatile u32*)l->pub_host)[w];
     return FGPU_OK;
 }
+
+fgpu_info read_u32(fgpu_ctx* ctx, const u32* dev, u32* host) { return read_words(ctx, dev, 1, host); }
 fgpu_info read_u64(fgpu_ctx* ctx, const u64* dev, u64* host) {
-    fgpu_lane* l = ctx->lane();
-    FGPU_HIP(hipMemcpyAsync(l->pinned, dev, sizeof(u64), hipMemcpyDeviceToHost, l->stream));
-    FGPU_HIP(hipStreamSynchronize(l->stream));
-    *host = *(u64*)l->pinned;
+    u32 w[2] = {0, 0};
+    FGPU_TRY(read_words(ctx, (const u32*)dev, 2, w));
+    *host = (u64)w[0] | ((u64)w[1] << 32);
     return FGPU_OK;
 }
 
@@ -79,6 +114,19 @@ fgpu_lane* lane_create() {
         delete l;
         return nullptr;
     }
+    // the read-back line (optional: read_words falls back to the runtime copy without it)
+    void* pub = nullptr;
+    if (hipHostMalloc(&pub, 128, hipHostMallocMapped) == hipSuccess) {
+        void* dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, pub, 0) == hipSuccess) {
+            memset(pub, 0, 128);
+            l->pub_host = (uint32_t*)pub;
+            l->pub_dev = (uint32_t*)dv;
+        } else {
+            (void)hipHostFree(pub);
+        }
+    }
+    (void)hipGetLastError();
     return l;
 }
 
@@ -89,6 +137,7 @@ void lane_destroy(fgpu_lane* l) {
         if (l->xfer_ev[k]) (void)hipEventDestroy(l->xfer_ev[k]);
     if (l->xfer) (void)hipHostFree(l->xfer);
     if (l->pinned) (void)hipHostFree(l->pinned);
+    if (l->pub_host) (void)hipHostFree(l->pub_host);
     if (l->own_stream) (void)hipStreamDestroy(l->own_stream);
     delete l;
 }
@@ -496,7 +545,9 @@ void* fgpu_ctx::pinned_alloc(size_t bytes) {
     {
         std::lock_guard<std::mutex> g(mu);
         auto it = pin_pool.lower_bound(cap);
-        if (it != pin_pool.end() && it->first <= 2 * cap) {   // (k-hop results of one query shape vary by tens of per cent)
+        // (k-hop results of one query shape vary by tens of per cent; from 32 MiB up ANY pooled block that is large enough is
+        // taken — pinning costs ~40 us per MiB, as much as the staged copy it is meant to replace)
+        if (it != pin_pool.end() && (it->first <= 2 * cap || cap >= ((size_t)32 << 20))) {
             void* p = it->second;
             pin_pooled -= it->first;
             pin_live[p] = it->first;
