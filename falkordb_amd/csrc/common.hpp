@@ -83,6 +83,7 @@ struct fgpu_options {  // fgpu_set_option
                                // (all-gather-v, direct peer-to-peer over xGMI), 1 one ncclBroadcast per rank in a group
     int transpose_mode = 0;    // pattern transpose: 0 counting transpose (no sort), 1 COO rebuild through the sorter (A/B)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
+    int expand_first_hop = 1;  // fgpu_expand*: a clean first hop from one-entry rows copies the source rows (0 = the general product; A/B)
     int expand_hot = 0;        // dense count hop of the bit-parallel chain: 1 = hot rows of X are gathered by the XCD that owns them
                                // (bitexpand.hip BpHotPlan; measured slower than the plain pull at every setting, DESIGN.md §4.3 — kept
                                // as the experiment), 0 = every workgroup gathers from the whole of X

@@ -758,6 +758,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.expand_row_groups = value != 0;
     } else if (!strcmp(name, "expand_fuse_count")) {
         ctx->opt.expand_fuse_count = value != 0;
+    } else if (!strcmp(name, "expand_first_hop")) {
+        ctx->opt.expand_first_hop = value != 0;
     } else if (!strcmp(name, "expand_hot")) {
         ctx->opt.expand_hot = value != 0;
     } else if (!strcmp(name, "expand_hot_rows")) {

@@ -328,6 +328,123 @@ static fgpu_info check_hops(const fgpu_mat* const* m, const fgpu_mat* const* dp,
     return FGPU_OK;
 }
 
+// ---- first hop from one-entry rows over a clean layer --------------------------------------------------------------------
+// F0 has at most one entry per row (cond_traverse.rs:600-601: F[i, src_i] = 1), so F0 x m is "row i = row src_i of m": the
+// rows are copied as they are — sorted, unique, nothing to sort or collapse.  The general product (degrees per entry, two
+// scans, row offsets, gather, segment lengths, compaction: ~14 launches and three read-backs) is replaced by ONE workgroup that
+// scans the <= 4096 source degrees, one read-back of the size, and one copy kernel that also sums the NEXT hop's traversed
+// edges (sum over the copied entries of deg_next(col): what mxm_flops would compute for the form decision of hop 2).
+constexpr u32 FH_MAX_ROWS = 4096;
+__global__ __launch_bounds__(1024) void first_hop_scan_kernel(CsrView f, CsrView m, u32 k, u32* __restrict__ rp, u32* __restrict__ total) {
+    __shared__ u32 s_wave[16];
+    __shared__ u32 s_base;
+    u32 d[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                 // thread t owns rows 4 t .. 4 t + 3 (consecutive: the scan stays in order)
+        const u32 i = threadIdx.x * 4 + j;
+        u32 dg = 0;
+        if (i < k && f.rowptr[i + 1] > f.rowptr[i]) {
+            u32 b, e;
+            row_range(m, f.colidx[f.rowptr[i]], b, e);
+            dg = e - b;
+        }
+        d[j] = dg;
+        sum += dg;
+    }
+    u32 inc = sum;                                 // inclusive scan of the per-thread sums inside the wavefront
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = (u32)__shfl_up((int)inc, o, 64); if ((int)lane_id() >= o) inc += v; }
+    if (lane_id() == 63) s_wave[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int w = 0; w < 16; ++w) { const u32 v = s_wave[w]; s_wave[w] = run; run += v; }
+        s_base = run;
+    }
+    __syncthreads();
+    u32 off = s_wave[threadIdx.x >> 6] + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = threadIdx.x * 4 + j;
+        if (i <= k) rp[i] = off;
+        off += d[j];
+    }
+    if (threadIdx.x == 0) total[0] = s_base;
+}
+// a wavefront per source row: copy the row of m, sum deg_next over its column ids (nxt.rowptr nullable)
+__global__ __launch_bounds__(256) void first_hop_copy_kernel(CsrView f, CsrView m, u32 k, const u32* __restrict__ rp, u32* __restrict__ col,
+                                                             const u32* __restrict__ next_rowptr, u32 next_rows,
+                                                             unsigned long long* __restrict__ tnext) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    u64 t = 0;
+    for (u32 i = wave; i < k; i += nwaves) {
+        if (f.rowptr[i + 1] == f.rowptr[i]) continue;
+        u32 b, e;
+        row_range(m, f.colidx[f.rowptr[i]], b, e);
+        const u32 o = rp[i];
+        for (u32 q = b + lane; q < e; q += 64) {
+            const u32 c = m.colidx[q];
+            col[o + (q - b)] = c;
+            if (next_rowptr && c < next_rows) t += next_rowptr[c + 1] - next_rowptr[c];
+        }
+    }
+    if (tnext) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (lane == 0 && t) atomicAdd(&tnext[(wave & 63u) * 16u], (unsigned long long)t);   // 64 slots, a 128-byte line apart
+    }
+}
+__global__ void first_hop_fold_kernel(unsigned long long* __restrict__ tnext) {
+    u64 v = tnext[(size_t)threadIdx.x * 16];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (threadIdx.x == 0) tnext[1] = v;
+}
+
+// *out = F0 x m for a clean hop (no dp / dm); *T0 = its traversed edges; *Tnext (when `next` is a plain CSR) = the traversed
+// edges of the following hop over `next`.  Returns FGPU_NO_VALUE when the shortcut does not apply (the caller takes the general path).
+static fgpu_info first_hop_rows(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* next, fgpu_mat** out,
+                                u64* T0, u64* Tnext, bool* have_next) {
+    *have_next = false;
+    const u32 k = (u32)f->nrows;
+    if (k == 0 || k > FH_MAX_ROWS || f->is_hyper() || f->nnz > f->nrows || m->nnz == 0 || f->nnz == 0) return FGPU_NO_VALUE;
+    DevBuf<u32> rp, tot;
+    FGPU_TRY(rp.alloc(ctx, (size_t)k + 1));
+    FGPU_TRY(tot.alloc(ctx, 1));
+    hipLaunchKernelGGL(first_hop_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream(), view_of(f), view_of(m), k, rp.p, tot.p);
+    FGPU_HIP(hipGetLastError());
+    u32 nnz = 0;
+    FGPU_TRY(read_u32(ctx, tot.p, &nnz));
+    *T0 = nnz;
+    fgpu_mat* c = nullptr;
+    FGPU_TRY(mat_alloc(ctx, &c, k, m->ncols, nnz, false, 0, false));
+    const bool sum_next = next && !next->is_hyper() && next->nnz && nnz;
+    DevBuf<u64> tn;
+    fgpu_info i = FGPU_OK;
+    if (sum_next) {
+        i = tn.alloc(ctx, 64 * 16);
+        if (i == FGPU_OK && hipMemsetAsync(tn.p, 0, 64 * 16 * sizeof(u64), ctx->stream()) != hipSuccess) i = FGPU_DEVICE;
+    }
+    if (i == FGPU_OK && hipMemcpyAsync(c->rowptr, rp.p, ((size_t)k + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()) != hipSuccess)
+        i = FGPU_DEVICE;
+    if (i == FGPU_OK && nnz) {
+        u32 grid = cdiv(k, 4);
+        hipLaunchKernelGGL(first_hop_copy_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(f), view_of(m), k, (const u32*)rp.p,
+                           c->colidx, sum_next ? (const u32*)next->rowptr : (const u32*)nullptr, sum_next ? (u32)next->nrows : 0u,
+                           sum_next ? (unsigned long long*)tn.p : (unsigned long long*)nullptr);
+        if (hipGetLastError() != hipSuccess) i = FGPU_DEVICE;
+    }
+    if (i == FGPU_OK && sum_next) {
+        hipLaunchKernelGGL(first_hop_fold_kernel, dim3(1), dim3(64), 0, ctx->stream(), (unsigned long long*)tn.p);
+        i = read_u64(ctx, tn.p + 1, Tnext);
+        *have_next = i == FGPU_OK;
+    }
+    if (i != FGPU_OK) { mat_release(c); if (i == FGPU_DEVICE) set_error("first hop: device call failed"); return i; }
+    *out = c;
+    return FGPU_OK;
+}
+
 // shared front half of fgpu_expand / fgpu_expand_count: result stays on device
 static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
                                const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
@@ -344,17 +461,38 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
     const int mode = ctx->opt.expand_mode;
     bool bits = false;
     BitState bs;
+    u64 T_known = 0;                      // traversed edges of f over T_for, when an earlier step already summed them
+    const fgpu_mat *T_for = nullptr, *T_f = nullptr;
     for (int h = 0; h < nhops; ++h) {
         const fgpu_mat* mh = m[h];
         const fgpu_mat* dph = dp ? dp[h] : nullptr;
         const fgpu_mat* dmh = dm ? dm[h] : nullptr;
+        if (h == 0 && mode != 2 && ctx->opt.expand_first_hop && !(dph && dph->nnz) && !(dmh && dmh->nnz)) {
+            // clean first hop from one-entry rows: the source rows of m, copied (first_hop_rows above)
+            fgpu_mat* c = nullptr;
+            u64 T0 = 0, Tn = 0;
+            bool have = false;
+            const fgpu_info fi = first_hop_rows(ctx, f, mh, nhops > 1 ? m[1] : nullptr, &c, &T0, &Tn, &have);
+            if (fi == FGPU_OK) {
+                // (a first hop heavy enough for the bit form — T0 * ratio > nnz — is a batch of hub sources; it is still
+                // correct as a copy, and the next hop's decision sees its true volume)
+                if (flops) *flops += T0;
+                mat_release(f);
+                f = c;
+                if (have) { T_known = Tn; T_for = m[1]; T_f = f; }
+                continue;
+            }
+            if (fi != FGPU_NO_VALUE) { mat_release(f); return fi; }
+        }
         if (!bits && mode != 1 && !mh->is_hyper() && mh->nnz && mh->nnz < 0x7FFFFFFFull && f->nnz) {
             const u64 w = (nsrc + 63) / 64;
             const u64 mem = 2ull * (mh->nrows > mh->ncols ? mh->nrows : mh->ncols) * (w <= 64 ? 2 * w : w + 64) * 8;
             bool go = (mode == 2);
             u64 T = 0;
             if ((mode == 0 && mem < (64ull << 30)) || go) {
-                fgpu_info i = mxm_flops(ctx, f, mh, &T);
+                fgpu_info i = FGPU_OK;
+                if (T_for == mh && T_f == f) T = T_known;          // summed while the first hop's rows were copied
+                else i = mxm_flops(ctx, f, mh, &T);
                 if (i != FGPU_OK) { mat_release(f); return i; }
                 // measured: a sorted-CSR hop costs ~0.12-0.16 ns per gathered entry (RMAT-22: 6 ms at T = 36 M; RMAT-26:
                 // 12 ms at T ~ 100 M), the first bit hop — the sparse pull, a flag probe per entry of A' — 5.5-6 ps per matrix
