@@ -83,6 +83,8 @@ struct fgpu_options {  // fgpu_set_option
                                // (all-gather-v, direct peer-to-peer over xGMI), 1 one ncclBroadcast per rank in a group
     int transpose_mode = 0;    // pattern transpose: 0 counting transpose (no sort), 1 COO rebuild through the sorter (A/B)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
+    int pagerank_parts = 1;    // PageRank SpMV: 1 = A' in 8 column ranges, range k gathered by XCD k out of its own L2 (when the score
+                               // vector exceeds one L2), 2 = always, 0 = the one-pass pull over the whole vector (A/B)
     int expand_first_hop = 1;  // fgpu_expand*: a clean first hop from one-entry rows copies the source rows (0 = the general product; A/B)
     int expand_hot = 0;        // dense count hop of the bit-parallel chain: 1 = hot rows of X are gathered by the XCD that owns them
                                // (bitexpand.hip BpHotPlan; measured slower than the plain pull at every setting, DESIGN.md §4.3 — kept
@@ -256,7 +258,7 @@ struct fgpu_tiles;  // tiled.hip: LDS-staged frontier-tile edge layout (accelera
 // below are built lazily on first use; every such build happens under `idx_mu`, is complete on the device
 // (stream synchronised) before its pointer is published, and is never replaced afterwards — concurrent readers
 // on other lanes either see no index (and take the lock) or a finished one.
-namespace fgpu { struct BpHotPlan; }   // bitexpand.hip
+namespace fgpu { struct BpHotPlan; struct PrParts; }   // bitexpand.hip, pagerank.hip
 struct fgpu_mat {
     fgpu_ctx* ctx = nullptr;
     mutable std::mutex idx_mu;
@@ -297,6 +299,7 @@ struct fgpu_mat {
     mutable uint32_t* bp_sitems = nullptr; // the items of split rows only (rows of more than BP_ITEM entries)
     mutable uint32_t n_bp_sitems = 0;
     mutable uint64_t* bp_split_bits = nullptr;  // on the cached transpose: bit v set <=> row v is cut into several items
+    mutable fgpu::PrParts* pr_parts = nullptr;  // pagerank.hip: this matrix split into 8 column ranges (one per XCD), lazily, owned
     mutable fgpu::BpHotPlan* bp_hot = nullptr; // on the cached transpose: the XCD-partitioned hot-row plan of the dense count hop
                                                 // (bitexpand.hip, built on the first such hop; released by bp_hot_release)
     bool is_hyper() const { return hrows != nullptr; }
@@ -399,6 +402,7 @@ fgpu_info compact_segments(fgpu_ctx* ctx, const u32* data, const u64* off, const
 // free a snapshot no other thread has seen (temporaries, failed builds); fgpu_mat_free adds the cross-lane fence
 void mat_release(fgpu_mat* m);
 void bp_hot_release(fgpu_ctx* ctx, BpHotPlan* h);   // bitexpand.hip
+void pr_parts_release(fgpu_ctx* ctx, PrParts* p);   // pagerank.hip
 void mat_drop_bfs_plan(const fgpu_mat* a);   // caller holds bfs_link_mu() and a->bfs_mu
 // One process-wide mutex orders every change of the (adjacency <-> transpose) plan links (bfs_plan / bfs_plan_at /
 // bfs_cached_in / fgpu_ctx::bfs_cache_owner): taken BEFORE any matrix' bfs_mu, released before a search runs.

@@ -66,6 +66,7 @@ void mat_release(fgpu_mat* m) {
     if (c) c->dev_free(m->bp_sitems);
     if (c) c->dev_free(m->bp_split_bits);
     if (m->bp_hot) bp_hot_release(c, m->bp_hot);
+    if (m->pr_parts) pr_parts_release(c, m->pr_parts);
     if (m->tcache) mat_release(m->tcache);
     delete m;
 }

@@ -218,18 +218,196 @@ __global__ __launch_bounds__(256) void pr_hub_finish_kernel(const u32* __restric
     for (u32 h = threadIdx.x; h < n_hub; h += 256) {
         const u32 row = hub[3 * h];
         if (hub[3 * h + 1] != rowptr[row]) continue;        // not the row's first chunk
-        const u32 re = rowptr[row + 1];
+        // the row's chunks are consecutive list entries of one size (hub_scan_kernel, mat.hip): their number follows from the
+        // row length, so the partials are added — in the same ascending order as ever — from independent loads (walking the
+        // list entry by entry was a chain of dependent loads: 63 us for a 100-chunk hub row, a twelfth of an iteration)
+        const u32 b0 = hub[3 * h + 1], re = rowptr[row + 1], cs = hub[3 * h + 2] - b0;
+        u32 cnt = cs ? (re - b0 + cs - 1) / cs : 0u;
+        if (cnt > n_hub - h) cnt = n_hub - h;
         double s = 0.0;
-        for (u32 k = h; k < n_hub && hub[3 * k] == row; ++k) {
-            s += hpart[k];
-            if (hub[3 * k + 2] == re) break;
-        }
+        for (u32 k = 0; k < cnt; ++k) s += hpart[h + k];
         const float rv = pr_active(act, row) ? (float)((double)tp + s) : 0.0f;
         r[row] = rv;
         x += fabs((double)t[row] - (double)rv);
     }
     const double tot = block_sum_256(x, s_red);
     if (threadIdx.x == 0) part[0] = tot;
+}
+
+// ---- the SpMV by column ranges, one per XCD (round 4) ------------------------------------------------------------------------
+// What bounds the pull is the random 4-byte gather of w[col]: 65 M of them per iteration at RMAT-22 from a 16 MB vector that
+// every XCD's 4 MiB L2 caches a different quarter of — ~80-100 G gathers/s.  Workgroups are dealt to the XCDs round-robin, and
+// the same gathers run at ~255 G/s when workgroup b only touches column range b mod 8 (tools/micro/xcdgather.hip: a 16.8 MB
+// table, 2.1 MB per range — up to 4 MB per range at that rate, 8 MB at half of it).  So A' is split ONCE per snapshot into 8
+// matrices by column range (rows keep their order inside a range: a row's entries are sorted, a range is a contiguous piece),
+// stored range-major with one row-pointer array per range; per iteration workgroup (k, block) sums range k's entries of a block
+// of PR_RB rows into FP64 accumulators in LDS — entry-parallel, the row of an entry by a search over the block's offsets in LDS;
+// a wavefront whose 64 entries share one row (a hub row) adds them up with shuffles first — and stores the block's partial sums;
+// a second kernel adds the 8 partials of a row in range order, rounds to FP32 once, and accounts |t - r|.  No hub list, no
+// hub passes.  (FP64 sums of FP32 terms: as before they are exact unless a row's terms span more than 2^29, so the order in which
+// a range's terms meet does not show; across ranges the order is fixed.)
+constexpr u32 PR_NPARTS = 8;
+constexpr u32 PR_RB = 1024;       // rows per workgroup block
+struct PrParts {
+    u32* prp = nullptr;            // PR_NPARTS x (n + 1) offsets into pcol, range-major
+    u32* pcol = nullptr;           // column ids, range-major
+    u32 pw = 0;                    // columns per range
+    u32 n = 0;
+};
+void pr_parts_release(fgpu_ctx* ctx, PrParts* p) {
+    if (!p) return;
+    if (ctx) { ctx->dev_free(p->prp); ctx->dev_free(p->pcol); }
+    delete p;
+}
+
+// entries of row v in each column range (7 lower bounds in the sorted row)
+__global__ void pr_part_count_kernel(CsrView at, u32 n, u32 pw, u32* __restrict__ cnt) {
+    const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > n) return;
+    u32 prev = 0, b = 0, e = 0;
+    if (v < n) { b = at.rowptr[v]; e = at.rowptr[v + 1]; prev = b; }
+    for (u32 p = 0; p < PR_NPARTS; ++p) {
+        u32 hi = e;
+        if (v < n && p + 1 < PR_NPARTS) {
+            const u64 bound = (u64)(p + 1) * pw;              // first column of the next range
+            u32 lo = prev;
+            while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u64)at.colidx[mid] < bound) lo = mid + 1; else hi = mid; }
+            hi = lo;
+        }
+        cnt[(size_t)p * (n + 1) + v] = v < n ? hi - prev : 0u;
+        prev = hi;
+    }
+}
+// a wavefront per row: its entries to their ranges' arrays (a range's piece of the row is contiguous in both)
+__global__ __launch_bounds__(256) void pr_part_fill_kernel(CsrView at, u32 n, u32 pw, const u32* __restrict__ prp, u32* __restrict__ pcol) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    for (u32 v = wave; v < n; v += nwaves) {
+        const u32 b = at.rowptr[v], e = at.rowptr[v + 1];
+        if (b == e) continue;
+        // lane p < 8: where range p's piece of the row starts in the row (prefix of the lengths) and in pcol
+        u32 len = 0, dst = 0;
+        if (lane < PR_NPARTS) { dst = prp[(size_t)lane * (n + 1) + v]; len = prp[(size_t)lane * (n + 1) + v + 1] - dst; }
+        u32 inc = len;
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) { const u32 y = (u32)__shfl_up((int)inc, d, 64); if (lane >= (u32)d) inc += y; }
+        const u32 start = inc - len;                           // exclusive prefix (lanes 0..7)
+        for (u32 q0 = b; q0 < e; q0 += 64) {                   // (the shuffles below read lanes 0..7: every lane stays in the loop)
+            const u32 q = q0 + lane;
+            const bool valid = q < e;
+            const u32 c = valid ? at.colidx[q] : 0u;
+            const u32 p = c / pw < PR_NPARTS ? c / pw : PR_NPARTS - 1;
+            const u32 s0 = (u32)__shfl((int)start, (int)p, 64), d0 = (u32)__shfl((int)dst, (int)p, 64);
+            if (valid) pcol[d0 + (q - b - s0)] = c;
+        }
+    }
+}
+
+static fgpu_info pr_parts_build(fgpu_ctx* ctx, const fgpu_mat* At, const PrParts** out) {
+    std::lock_guard<std::mutex> idx_guard(At->idx_mu);
+    if (At->pr_parts) { *out = At->pr_parts; return FGPU_OK; }
+    const u32 n = (u32)At->nrows;
+    PrParts* pp = new (std::nothrow) PrParts();
+    FGPU_REQUIRE(pp, FGPU_OOM, "out of host memory");
+    pp->n = n;
+    pp->pw = (u32)(((u64)At->ncols + PR_NPARTS - 1) / PR_NPARTS);
+    if (pp->pw == 0) pp->pw = 1;
+    const size_t words = (size_t)PR_NPARTS * (n + 1);
+    fgpu_info i = ctx->dev_alloc((void**)&pp->prp, (words + 1) * sizeof(u32));
+    if (i == FGPU_OK) i = ctx->dev_alloc((void**)&pp->pcol, (size_t)(At->nnz ? At->nnz : 1) * sizeof(u32));
+    if (i == FGPU_OK) {
+        hipLaunchKernelGGL(pr_part_count_kernel, dim3(cdiv((u64)n + 1, 256)), dim3(256), 0, ctx->stream(), view_of(At), n, pp->pw, pp->prp);
+        if (hipGetLastError() != hipSuccess) i = FGPU_DEVICE;
+    }
+    // one exclusive scan over the range-major counts IS the layout: range p's rows follow range p - 1's (the extra slot per
+    // range holds 0, so prp[p][n] = prp[p + 1][0])
+    if (i == FGPU_OK) i = scan_u32(ctx, pp->prp, pp->prp, words, nullptr);
+    if (i == FGPU_OK && At->nnz) {
+        u32 grid = cdiv(n, 4);
+        if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+        hipLaunchKernelGGL(pr_part_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(At), n, pp->pw, (const u32*)pp->prp, pp->pcol);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream()) != hipSuccess) i = FGPU_DEVICE;
+    }
+    if (i != FGPU_OK) { pr_parts_release(ctx, pp); if (i == FGPU_DEVICE) set_error("pagerank: column-range layout build failed"); return i; }
+    At->pr_parts = pp;
+    *out = pp;
+    return FGPU_OK;
+}
+
+// workgroup j: range k = j & 7 (dealt to XCD k), row block j >> 3.  part[k][v] = sum over range k's entries of row v of w[col].
+__global__ __launch_bounds__(256) void pr_part_spmv_kernel(const u32* __restrict__ prp, const u32* __restrict__ pcol, u32 n,
+                                                          const float* __restrict__ w, double* __restrict__ part,
+                                                          const int* __restrict__ stop) {
+    __shared__ u32 s_off[PR_RB + 1];
+    __shared__ double s_acc[PR_RB];
+    if (*stop) return;
+    const u32 k = blockIdx.x & 7u, blk = blockIdx.x >> 3;
+    const u32 v0 = blk * PR_RB;
+    const u32 rows = n - v0 < PR_RB ? n - v0 : PR_RB;
+    const u32* __restrict__ rp = prp + (size_t)k * (n + 1) + v0;
+    // (the streams — offsets, column ids, partial sums — are loaded / stored non-temporally: the XCD's L2 is for range k of w)
+    for (u32 i = threadIdx.x; i <= PR_RB; i += 256) s_off[i] = __builtin_nontemporal_load(&rp[i < rows ? i : rows]);
+    for (u32 i = threadIdx.x; i < PR_RB; i += 256) s_acc[i] = 0.0;
+    __syncthreads();
+    const u32 e0 = s_off[0], e1 = s_off[rows];
+    const u32 lane = lane_id();
+    // a wavefront takes 64 consecutive entries per trip, FOUR trips' loads in flight (column ids, then the gathers): a block
+    // holds ~2 K entries of its range, and one trip at a time made the kernel a chain of round trips (0.48 ms per pass)
+    for (u32 eb = e0 + (threadIdx.x & ~63u); eb < e1; eb += 1024) {
+        u32 c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 e = eb + 256 * j + lane;
+            c[j] = e < e1 ? __builtin_nontemporal_load(&pcol[e]) : 0xFFFFFFFFu;
+        }
+        float wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = c[j] != 0xFFFFFFFFu ? w[c[j]] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 e = eb + 256 * j + lane;
+            const bool on = e < e1;
+            if (__ballot(on) == 0ull) break;                            // (wave-uniform: later trips are past the end too)
+            u32 lo = 0, hi = rows;                                        // largest lo with s_off[lo] <= e (rows may be empty)
+            if (on) {
+                while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_off[mid] <= e) lo = mid; else hi = mid; }
+            }
+            double x = (double)wv[j];
+            // a trip inside ONE row (hub rows: thousands of entries): 64 same-address LDS atomics would be served one by one
+            const u32 r0 = (u32)__builtin_amdgcn_readfirstlane((int)lo);
+            if (__ballot(on && lo != r0) == 0ull) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+                if (lane == 0) atomicAdd(&s_acc[r0], x);
+            } else if (on) {
+                atomicAdd(&s_acc[lo], x);
+            }
+        }
+    }
+    __syncthreads();
+    double* __restrict__ dst = part + (size_t)k * n + v0;
+    for (u32 i = threadIdx.x; i < rows; i += 256) __builtin_nontemporal_store(s_acc[i], &dst[i]);
+}
+
+// r[v] = teleport + the 8 range partials in range order; |t - r| partials per workgroup
+__global__ __launch_bounds__(256) void pr_part_combine_kernel(const double* __restrict__ part, const u64* __restrict__ act, u32 n,
+                                                             const float* __restrict__ tele, const float* __restrict__ t,
+                                                             float* __restrict__ r, double* __restrict__ dpart,
+                                                             const int* __restrict__ stop) {
+    __shared__ double s_red[4];
+    if (*stop) return;
+    const float tp = tele[0];
+    double diff = 0.0;
+    for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) {
+        double s = 0.0;
+#pragma unroll
+        for (u32 p = 0; p < PR_NPARTS; ++p) s += part[(size_t)p * n + v];
+        const float rv = pr_active(act, v) ? (float)((double)tp + s) : 0.0f;
+        r[v] = rv;
+        diff += fabs((double)t[v] - (double)rv);
+    }
+    const double tot = block_sum_256(diff, s_red);
+    if (threadIdx.x == 0) dpart[blockIdx.x] = tot;
 }
 
 }  // namespace fgpu
@@ -310,7 +488,14 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
         FGPU_TRY(d.alloc(ctx, n));
         FGPU_TRY(sink.alloc(ctx, n));
         FGPU_TRY(part.alloc(ctx, nb));
-        FGPU_TRY(part2.alloc(ctx, (size_t)grid + 1));
+        // the column-range form (PrParts above) when the score vector does not fit one XCD's L2 next to the stream
+        const PrParts* parts = nullptr;
+        if (ctx->opt.pagerank_parts == 2 || (ctx->opt.pagerank_parts == 1 && (u64)n * sizeof(float) > (2ull << 20)))
+            FGPU_TRY(pr_parts_build(ctx, At, &parts));
+        const u32 cgrid = parts ? ((u32)ctx->cus * 8 < nb ? (u32)ctx->cus * 8 : nb) : 0u;
+        DevBuf<double> ppart;
+        if (parts) FGPU_TRY(ppart.alloc(ctx, (size_t)PR_NPARTS * n));
+        FGPU_TRY(part2.alloc(ctx, (size_t)(grid > cgrid ? grid : cgrid) + 1));
         FGPU_TRY(scal.alloc(ctx, 2));
         FGPU_TRY(hpart.alloc(ctx, (size_t)At->n_hub_chunks + 1));
         if (n_act == 0) {
@@ -350,6 +535,20 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
                 hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part.p, nb,
                                    teleport0, damp_over_n, scal.p, state.p, 0, 0.0f);
                 if (timing) (void)hipEventRecord(ev[1], ctx->stream());
+                if (parts) {
+                    const u32 nblk = cdiv(n, PR_RB);
+                    hipLaunchKernelGGL(pr_part_spmv_kernel, dim3(nblk * PR_NPARTS), dim3(256), 0, ctx->stream(), (const u32*)parts->prp,
+                                       (const u32*)parts->pcol, n, (const float*)w.p, ppart.p, (const int*)state.p);
+                    if (timing) (void)hipEventRecord(ev[2], ctx->stream());
+                    hipLaunchKernelGGL(pr_part_combine_kernel, dim3(cgrid), dim3(256), 0, ctx->stream(), (const double*)ppart.p,
+                                       (const u64*)act.p, n, (const float*)scal.p, (const float*)tp, rp, part2.p, (const int*)state.p);
+                    if (timing) (void)hipEventRecord(ev[3], ctx->stream());
+                    hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part2.p, cgrid,
+                                       0.0f, 1.0f, scal.p + 1, state.p, 1, tol);
+                    if (timing) (void)hipEventRecord(ev[4], ctx->stream());
+                    FGPU_HIP(hipGetLastError());
+                    continue;
+                }
                 hipLaunchKernelGGL(pr_spmv_kernel, dim3(grid), dim3(256), 0, ctx->stream(), vat, (const u64*)act.p, n,
                                    (const float*)w.p, (const float*)scal.p, (const float*)tp, rp, part2.p + 1,
                                    (const int*)state.p);

@@ -27,6 +27,16 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True, params=[0, 2], ids=["one-pass-pull", "xcd-column-ranges"])
+def spmv_form(request, ctx):
+    """Every test runs through both forms of the SpMV: the one-pass pull over the whole score vector (with the hub chunk
+    passes) and A' split into 8 column ranges, range k gathered by XCD k out of its own L2 (pagerank.hip PrParts; the
+    default picks it once the vector exceeds one L2 — forced here, the test graphs are small)."""
+    ctx.set_option("pagerank_parts", request.param)
+    yield
+    ctx.set_option("pagerank_parts", 1)
+
+
 def up(ctx, a):
     return ctx.mat_from_csr(a.nrows, a.ncols, a.rowptr, a.colidx)
 
