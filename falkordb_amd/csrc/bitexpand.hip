@@ -227,13 +227,17 @@ __global__ void bp_flag_count_kernel(const uint8_t* __restrict__ flag, u32 n, un
 // from the bit state — fgpu_expand_count needs no CSR.  One lane per (vertex, word).
 // tab[k][j][x] = sum of row_hash(64 k + 4 j + b) over the set bits b of the nibble x: 16 look-ups per word replace a
 // loop over its set bits (divergent: a wavefront ran as long as its fullest word) with two 64-bit multiplies each.
-__global__ void bp_cs_table_kernel(u32 w, u64* __restrict__ tab) {
+// (rowmap, nullable: bit i of a row stands for source row rowmap[i], i < nsrc — a chain over compacted source rows)
+__global__ void bp_cs_table_kernel(u32 w, u64* __restrict__ tab, const u32* __restrict__ rowmap, u32 nsrc) {
     const u32 t = blockIdx.x * 256 + threadIdx.x;     // (k, j, x)
     if (t >= w * 256) return;
     const u32 k = t >> 8, j = (t >> 4) & 15, x = t & 15;
     u64 s = 0;
     for (u32 b = 0; b < 4; ++b)
-        if ((x >> b) & 1u) s += cs_row_hash((u64)k * 64 + 4 * j + b);
+        if ((x >> b) & 1u) {
+            const u32 bit = k * 64 + 4 * j + b;
+            s += cs_row_hash(rowmap ? (bit < nsrc ? (u64)rowmap[bit] : 0ull) : (u64)bit);   // (bits >= nsrc are never set)
+        }
     tab[t] = s;
 }
 
@@ -1080,7 +1084,7 @@ fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* 
         if (grid > cap) grid = cap;
         if (checksum) {
             FGPU_TRY(tab.alloc(ctx, (size_t)s.w * 256));
-            hipLaunchKernelGGL(bp_cs_table_kernel, dim3(s.w), dim3(256), 0, ctx->stream(), s.w, tab.p);
+            hipLaunchKernelGGL(bp_cs_table_kernel, dim3(s.w), dim3(256), 0, ctx->stream(), s.w, tab.p, (const u32*)s.rowmap.p, s.nsrc);
             if (lds > 48 * 1024)
                 FGPU_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(bp_count_kernel<true>, dim3(grid), dim3(256), lds, ctx->stream(), (const u64*)s.x.p, s.n,
@@ -1570,7 +1574,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
                          "expand checksum: %u source rows need %zu B of LDS tables (limit %d); batch the sources", s.nsrc, lds,
                          ctx->opt.lds_limit);
             FGPU_TRY(tab.alloc(ctx, (size_t)s.w * 256));
-            hipLaunchKernelGGL(bp_cs_table_kernel, dim3(s.w), dim3(256), 0, ctx->stream(), s.w, tab.p);
+            hipLaunchKernelGGL(bp_cs_table_kernel, dim3(s.w), dim3(256), 0, ctx->stream(), s.w, tab.p, (const u32*)s.rowmap.p, s.nsrc);
         }
         fin = BpFinal{tbits.p, tpref.p, ca->label, tab.p, (unsigned long long*)acc.p, s.w};
     } else {

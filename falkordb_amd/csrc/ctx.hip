@@ -758,6 +758,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.expand_row_groups = value != 0;
     } else if (!strcmp(name, "expand_fuse_count")) {
         ctx->opt.expand_fuse_count = value != 0;
+    } else if (!strcmp(name, "expand_compact")) {
+        ctx->opt.expand_compact = value != 0;
     } else if (!strcmp(name, "pagerank_parts")) {
         FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "pagerank_parts must be 0 (off), 1 (by size) or 2 (always)");
         ctx->opt.pagerank_parts = (int)value;

@@ -445,6 +445,61 @@ static fgpu_info first_hop_rows(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat
     return FGPU_OK;
 }
 
+// ---- dropping the empty source rows of a count-only chain before it goes to bits ------------------------------------------
+// A source without out-edges (half of the vertices of an R-MAT graph, half of a `:P` batch) leaves an empty row after the
+// first hop and can never contribute again, but keeps its bit in every 128-byte row of the bit state.  When the live rows
+// fit HALF the words (1024 sources, 499 live: 16 -> 8 words per vertex) the frontier is renumbered to the live rows only:
+// the dense last hop gathers 64-byte rows (-6 % — a gather is priced per line, not per byte), the middle hop writes half
+// the bytes.  Only counts need no way back (the checksum's row hashes go through `map`): chains that emit rows keep all rows.
+__global__ void cr_flag_kernel(const u32* __restrict__ rowptr, u32 k, u32* __restrict__ flag) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= k) flag[i] = (i < k && rowptr[i + 1] > rowptr[i]) ? 1u : 0u;
+}
+__global__ void cr_build_kernel(const u32* __restrict__ rowptr, u32 k, const u32* __restrict__ flag, const u32* __restrict__ rank,
+                                u32* __restrict__ new_rowptr, u32* __restrict__ map, u32 nlive) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k && flag[i]) { new_rowptr[rank[i]] = rowptr[i]; map[rank[i]] = i; }
+    if (i == k) new_rowptr[nlive] = rowptr[k];
+}
+static u32 bits_stride(u32 rows) {                         // = bp_layout's row stride for `rows` source rows
+    u32 w = (rows + 63) / 64;
+    if (w == 0) w = 1;
+    if (w > 64) return ((w + 63) / 64) * 64;
+    u32 p = 1;
+    while (p < w) p <<= 1;
+    return p;
+}
+// *out = f without its empty rows (nullptr: nothing to gain, f stays), map[new row] = old row
+static fgpu_info compact_source_rows(fgpu_ctx* ctx, const fgpu_mat* f, fgpu_mat** out, DevBuf<u32>& map) {
+    *out = nullptr;
+    const u32 k = (u32)f->nrows;
+    if (f->is_hyper() || k < 128 || f->nnz == 0) return FGPU_OK;
+    DevBuf<u32> flag, rank;
+    FGPU_TRY(flag.alloc(ctx, (size_t)k + 1));
+    FGPU_TRY(rank.alloc(ctx, (size_t)k + 1));
+    hipLaunchKernelGGL(cr_flag_kernel, dim3(cdiv((u64)k + 1, 256)), dim3(256), 0, ctx->stream(), (const u32*)f->rowptr, k, flag.p);
+    FGPU_HIP(hipGetLastError());
+    FGPU_TRY(scan_u32(ctx, flag.p, rank.p, (u64)k + 1, nullptr));
+    u32 nlive = 0;
+    FGPU_TRY(read_u32(ctx, rank.p + k, &nlive));
+    if (nlive == 0 || bits_stride(nlive) >= bits_stride(k)) return FGPU_OK;
+    fgpu_mat* c = nullptr;
+    FGPU_TRY(mat_alloc(ctx, &c, nlive, f->ncols, f->nnz, false, 0, false));
+    fgpu_info i = map.alloc(ctx, nlive);
+    if (i == FGPU_OK) {
+        hipLaunchKernelGGL(cr_build_kernel, dim3(cdiv((u64)k + 1, 256)), dim3(256), 0, ctx->stream(), (const u32*)f->rowptr, k,
+                           (const u32*)flag.p, (const u32*)rank.p, c->rowptr, map.p, nlive);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(c->colidx, f->colidx, (size_t)f->nnz * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()) != hipSuccess) {
+            set_error("compact_source_rows: device call failed");
+            i = FGPU_DEVICE;
+        }
+    }
+    if (i != FGPU_OK) { mat_release(c); return i; }
+    *out = c;
+    return FGPU_OK;
+}
+
 // shared front half of fgpu_expand / fgpu_expand_count: result stays on device
 static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
                                const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
@@ -500,6 +555,13 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 // T exceeds ~ nnz / 28.  (The round-1 rule, T * 1024 > nnz * row_bytes = nnz / 8 at 1024 rows, dated from a
                 // 41 ps-per-entry pull and kept RMAT-26 batches in an 8.7 ms sort.)
                 if (mode == 0) go = T * ctx->opt.expand_bits_ratio > mh->nnz;
+            }
+            if (go && count_only && ctx->opt.expand_compact) {
+                // a count-only chain: its empty source rows stay behind (compact_source_rows above)
+                fgpu_mat* fc = nullptr;
+                fgpu_info i = compact_source_rows(ctx, f, &fc, bs.rowmap);
+                if (i != FGPU_OK) { mat_release(f); return i; }
+                if (fc) { mat_release(f); f = fc; }
             }
             if (go) {
                 // leaving the CSR form: a frontier whose out-edges are FEW beside the matrix is pushed into the bit state
