@@ -831,6 +831,10 @@ __global__ __launch_bounds__(256) void bp_rows_kernel(const u64* __restrict__ y,
     }
 }
 
+__global__ void bp_rowptr_full_kernel(const u32* __restrict__ rp_live, const u32* __restrict__ rank, u32 nfull, u32* __restrict__ rowptr) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= nfull) rowptr[i] = rp_live[rank[i]];
+}
 __global__ void bp_rowptr_kernel(const u64* __restrict__ off, u32 k, u32 nchunks, u32* __restrict__ rowptr) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= k) rowptr[i] = (u32)off[(size_t)i * nchunks];
@@ -1885,8 +1889,21 @@ fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu
                  "expand: %llu result entries exceed the 32-bit row-pointer space; batch the source rows",
                  (unsigned long long)nnz);
     fgpu_mat* o = nullptr;
-    FGPU_TRY(mat_alloc(ctx, &o, s.nsrc, s.n, nnz, false, 0, false));
+    const u32 out_rows = s.nsrc_full ? s.nsrc_full : s.nsrc;
+    FGPU_TRY(mat_alloc(ctx, &o, out_rows, s.n, nnz, false, 0, false));
     // rows >= nsrc are empty, so off[nsrc * nchunks] == nnz already
+    if (s.nsrc_full) {
+        // compacted source rows: row i of the result is live row rowrank[i] (an empty source row starts — and ends — where
+        // the next live one starts); the entries themselves are emitted in live-row order, which IS the order of the rows
+        DevBuf<u32> rp_live;
+        fgpu_info ai = rp_live.alloc(ctx, (size_t)s.nsrc + 1);
+        if (ai != FGPU_OK) { mat_release(o); return ai; }
+        hipLaunchKernelGGL(bp_rowptr_kernel, dim3(cdiv((u64)s.nsrc + 1, 256)), dim3(256), 0, ctx->stream(),
+                           (const u64*)off.p, s.nsrc, nchunks, rp_live.p);
+        hipLaunchKernelGGL(bp_rowptr_full_kernel, dim3(cdiv((u64)out_rows + 1, 256)), dim3(256), 0, ctx->stream(),
+                           (const u32*)rp_live.p, (const u32*)s.rowrank.p, out_rows, o->rowptr);
+        if (hipStreamSynchronize(ctx->stream()) != hipSuccess) { mat_release(o); set_error("bit-parallel emission failed"); return FGPU_DEVICE; }
+    } else
     hipLaunchKernelGGL(bp_rowptr_kernel, dim3(cdiv((u64)s.nsrc + 1, 256)), dim3(256), 0, ctx->stream(),
                        (const u64*)off.p, s.nsrc, nchunks, o->rowptr);
     if (nnz) {

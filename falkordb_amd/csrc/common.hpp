@@ -83,7 +83,7 @@ struct fgpu_options {  // fgpu_set_option
                                // (all-gather-v, direct peer-to-peer over xGMI), 1 one ncclBroadcast per rank in a group
     int transpose_mode = 0;    // pattern transpose: 0 counting transpose (no sort), 1 COO rebuild through the sorter (A/B)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
-    int expand_compact = 1;    // fgpu_expand_count: source rows that are empty after the CSR hops (sources without out-edges: half of an
+    int expand_compact = 1;    // fgpu_expand*: source rows that are empty after the CSR hops (sources without out-edges: half of an
                                // R-MAT batch) are dropped before the chain goes to bits when that halves the row width (0 = keep; A/B)
     int pagerank_parts = 1;    // PageRank SpMV: 1 = A' in 8 column ranges, range k gathered by XCD k out of its own L2 (when the score
                                // vector exceeds one L2), 2 = always, 0 = the one-pass pull over the whole vector (A/B)
@@ -474,9 +474,11 @@ struct BitState {
     // rows of x are defined only where flag != 0 (bp_from_csr of a light frontier zeroes just the rows it scatters into
     // instead of the whole 2 GiB state; every reader of such a state goes through the flags)
     bool lazy = false;
-    // a count-only chain whose EMPTY source rows were dropped before it went to bits (spgemm.hip compact_source_rows): bit i
-    // stands for source row rowmap[i] — only the checksum's row hashes need to know (nullptr: bit i = row i)
+    // a chain whose EMPTY source rows were dropped before it went to bits (spgemm.hip compact_source_rows): bit i stands for
+    // source row rowmap[i] — the checksum's row hashes and the emitted row pointers need to know (nullptr: bit i = row i)
     DevBuf<u32> rowmap;
+    DevBuf<u32> rowrank;   // nsrc_full + 1 entries: live rows before source row i (the way back for chains that emit rows)
+    u32 nsrc_full = 0;     // source rows before the compaction (0: not compacted)
 };
 fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f);
 // one hop from a CSR frontier into bit form by pushing (the hop at which a chain leaves the sorted-CSR products)

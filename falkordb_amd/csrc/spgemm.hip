@@ -449,8 +449,9 @@ static fgpu_info first_hop_rows(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat
 // A source without out-edges (half of the vertices of an R-MAT graph, half of a `:P` batch) leaves an empty row after the
 // first hop and can never contribute again, but keeps its bit in every 128-byte row of the bit state.  When the live rows
 // fit HALF the words (1024 sources, 499 live: 16 -> 8 words per vertex) the frontier is renumbered to the live rows only:
-// the dense last hop gathers 64-byte rows (-6 % — a gather is priced per line, not per byte), the middle hop writes half
-// the bytes.  Only counts need no way back (the checksum's row hashes go through `map`): chains that emit rows keep all rows.
+// the dense last hop gathers 64-byte rows (two vertices per line, a state that fits the Infinity Cache at RMAT-22: -13 %),
+// the middle hop writes half the bytes (-27 %).  The way back: the checksum's row hashes go through `map`, the emitted
+// row pointers through `rank` (bp_to_csr).
 __global__ void cr_flag_kernel(const u32* __restrict__ rowptr, u32 k, u32* __restrict__ flag) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= k) flag[i] = (i < k && rowptr[i + 1] > rowptr[i]) ? 1u : 0u;
@@ -470,7 +471,7 @@ static u32 bits_stride(u32 rows) {                         // = bp_layout's row 
     return p;
 }
 // *out = f without its empty rows (nullptr: nothing to gain, f stays), map[new row] = old row
-static fgpu_info compact_source_rows(fgpu_ctx* ctx, const fgpu_mat* f, fgpu_mat** out, DevBuf<u32>& map) {
+static fgpu_info compact_source_rows(fgpu_ctx* ctx, const fgpu_mat* f, fgpu_mat** out, DevBuf<u32>& map, DevBuf<u32>& rank_out) {
     *out = nullptr;
     const u32 k = (u32)f->nrows;
     if (f->is_hyper() || k < 128 || f->nnz == 0) return FGPU_OK;
@@ -496,6 +497,7 @@ static fgpu_info compact_source_rows(fgpu_ctx* ctx, const fgpu_mat* f, fgpu_mat*
         }
     }
     if (i != FGPU_OK) { mat_release(c); return i; }
+    rank_out = std::move(rank);        // rank[i] = live rows before source row i, rank[k] = nlive: the way back (bp_to_csr)
     *out = c;
     return FGPU_OK;
 }
@@ -556,12 +558,13 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 // 41 ps-per-entry pull and kept RMAT-26 batches in an 8.7 ms sort.)
                 if (mode == 0) go = T * ctx->opt.expand_bits_ratio > mh->nnz;
             }
-            if (go && count_only && ctx->opt.expand_compact) {
-                // a count-only chain: its empty source rows stay behind (compact_source_rows above)
+            if (go && ctx->opt.expand_compact) {
+                // the empty source rows stay behind (compact_source_rows above); bp_to_csr finds the way back
                 fgpu_mat* fc = nullptr;
-                fgpu_info i = compact_source_rows(ctx, f, &fc, bs.rowmap);
+                const u32 k_full = (u32)f->nrows;
+                fgpu_info i = compact_source_rows(ctx, f, &fc, bs.rowmap, bs.rowrank);
                 if (i != FGPU_OK) { mat_release(f); return i; }
-                if (fc) { mat_release(f); f = fc; }
+                if (fc) { mat_release(f); f = fc; bs.nsrc_full = k_full; }
             }
             if (go) {
                 // leaving the CSR form: a frontier whose out-edges are FEW beside the matrix is pushed into the bit state
