@@ -43,22 +43,6 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def committed_traffic(kernel, scale):
-    """Fallback when the live PMC passes cannot run: HBM bytes per launch from the committed rocprofv3 --pmc passes
-    of this same command (profiles/traffic.json, tools/prof_bench.sh) — only if that file was taken from the
-    kernel sources as they are now (it records their hash)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("_csrc_sha256") != csrc_hash():
-            return None
-        e = t.get(f"rmat{scale}", {}).get(kernel)
-        return int(e["hbm_bytes_per_dispatch"]) if e else None
-    except (OSError, ValueError, KeyError):
-        return None
-
-
 def csrc_hash():
     import hashlib
     h = hashlib.sha256()

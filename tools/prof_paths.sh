@@ -11,7 +11,7 @@ cd $root
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python tools/bench_paths.py all > $out/bench_paths_under_rocprof.jsonl 2> $out/err_rocprof.txt
 cp $out/trace/t_kernel_stats.csv $out/kernel_stats.csv
 python tools/bench_paths.py all > $out/bench_paths.jsonl 2> $out/err.txt
-python bench.py --scale 24 --steps 16 --warmup 4 --no-khop --no-scale-base --no-cpu-baseline --no-pmc > $out/bench_scale24.json 2>> $out/err.txt
+python bench.py --leg bfs --scale 24 --steps 16 --warmup 4 > $out/bench_scale24.json 2>> $out/err.txt
 python tools/time_transpose.py 22 > $out/transpose22.txt 2>> $out/err.txt
 cut -c1-60,100-230 $out/kernel_stats.csv | head -40
 cat $out/bench_paths.jsonl | cut -c1-700
