@@ -264,13 +264,18 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
     if (!last_dst->empty()) bitmap = g.label_bitmap(*last_dst);         // dst label filter of the LAST hop (:647-651)
     lap("source labels, bitmap");
 
+    // The chain runs once on the device; its (row_i, dest) stream comes back in chunks of 64 source rows through the ring of
+    // pinned buffers of fgpu_expand_stream_* — the walk below (what cond_traverse.rs:644-751 does with F.iter()) consumes a
+    // chunk while the next three are on the link.
     fgpu_ctx* ctx = g.ctx().raw();
-    u64 *rowptr = nullptr, *dest = nullptr, nnz = 0, fl = 0;
-    check(fgpu_expand(ctx, src_ids.data(), k, hl.m.data(), hl.dp.data(), hl.dm.data(), (int)hops.size(),
-                      bitmap.empty() ? nullptr : bitmap.data(), &rowptr, &dest, &nnz, &fl),
+    u64 nnz = 0, fl = 0;
+    fgpu_expand_stream* st = nullptr;
+    check(fgpu_expand_stream_open(ctx, src_ids.data(), k, hl.m.data(), hl.dp.data(), hl.dm.data(), (int)hops.size(),
+                                  bitmap.empty() ? nullptr : bitmap.data(), 64, 64, &st, &nnz, &fl),
           "CondTraverse::expand_batch");
+    struct StreamGuard { fgpu_expand_stream* s; ~StreamGuard() { if (s) fgpu_expand_stream_close(s); } } guard{st};
     if (flops) *flops = fl;
-    lap("fgpu_expand");
+    lap("fgpu_expand_stream_open");
 
     std::vector<uint8_t> matched(k, 0);
     const bool want_edge = bind_relationship && hops.size() == 1;
@@ -279,20 +284,29 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
     bool any_pinned = false;
     if (to_bound)
         for (u64 i = 0; i < k && !any_pinned; ++i) any_pinned = (*to_bound)[i].kind == Value::Node;
-    if (!any_pinned) {
-        // nothing to filter: the device result IS the (row, dest) stream — one block copy and one run per row
-        // (the per-entry loop below was 10 of the 16 ms of a 4.9 M-row batch)
-        rows.dest.assign(dest, dest + nnz);
-        for (u64 i = 0; i < k; ++i) rows.active_row.insert(rows.active_row.end(), rowptr[i + 1] - rowptr[i], i);
-    } else {
-        for (u64 i = 0; i < k; ++i) {
+    for (;;) {
+        u64 first = 0, nr = 0;
+        const u64* rowptr = nullptr;
+        const void* dv = nullptr;
+        const fgpu_info si = fgpu_expand_stream_next(st, &first, &nr, &rowptr, &dv);
+        if (si == FGPU_NO_VALUE) break;
+        check(si, "CondTraverse::expand_batch (stream)");
+        const u64* dest = (const u64*)dv;
+        if (!any_pinned) {
+            // nothing to filter: the chunk IS the (row, dest) stream — one block copy and one run per row
+            rows.dest.insert(rows.dest.end(), dest, dest + rowptr[nr]);
+            for (u64 r = 0; r < nr; ++r) rows.active_row.insert(rows.active_row.end(), rowptr[r + 1] - rowptr[r], first + r);
+            continue;
+        }
+        for (u64 r = 0; r < nr; ++r) {
+            const u64 i = first + r;
             const bool pinned = (*to_bound)[i].kind == Value::Node;
             if (!pinned) {
-                rows.dest.insert(rows.dest.end(), dest + rowptr[i], dest + rowptr[i + 1]);
-                rows.active_row.insert(rows.active_row.end(), rowptr[i + 1] - rowptr[i], i);
+                rows.dest.insert(rows.dest.end(), dest + rowptr[r], dest + rowptr[r + 1]);
+                rows.active_row.insert(rows.active_row.end(), rowptr[r + 1] - rowptr[r], i);
                 continue;
             }
-            for (u64 p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+            for (u64 p = rowptr[r]; p < rowptr[r + 1]; ++p) {
                 if ((*to_bound)[i].id != dest[p]) continue;                              // :657-661
                 rows.active_row.push_back(i);
                 rows.dest.push_back(dest[p]);
@@ -300,8 +314,8 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
         }
     }
     lap("result columns");
-    fgpu_free(ctx, rowptr);
-    fgpu_free(ctx, dest);
+    fgpu_expand_stream_close(st);
+    guard.s = nullptr;
     lap("free");
     if (want_edge) {
         // representative edge: first id found scanning the types in order (:663-695), batched per type
@@ -680,10 +694,17 @@ BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
     if (rel_type) types.push_back(*rel_type);
     Matrix adj = g.build_adjacency_matrix(types);                        // graph.rs:3870-3894
     const std::string key = rel_type ? *rel_type : std::string();
-    std::vector<int32_t> level(n);
-    std::vector<int64_t> parent(want_edges ? n : 0);
+    std::vector<int32_t> level_v;
+    std::vector<int64_t> parent_v;
+    const int32_t* level = nullptr;                    // what the result loop reads: the vectors, or the plan cache's pinned blocks
+    const int64_t* parent = nullptr;
     const bool partitioned = gang && gang->size() > 1 && adj.nvals() > 0;
-    if (partitioned) bfs_partitioned(g, *gang, adj, key, *source, max_depth, want_edges, level, parent);
+    if (partitioned) {
+        level_v.resize(n);
+        parent_v.resize(want_edges ? n : 0);
+        bfs_partitioned(g, *gang, adj, key, *source, max_depth, want_edges, level_v, parent_v);
+        level = level_v.data(); parent = parent_v.data();
+    }
     std::shared_ptr<Graph::BfsPlanCache> pc = partitioned ? nullptr : g.bfs_cache_;
     if (!partitioned && (!pc || pc->key != key || pc->adj.snapshot() != adj.snapshot())) {
         // a new adjacency (the layers changed, or another type): new plan; a clean committed graph keeps handing
@@ -701,13 +722,27 @@ BfsResult algo_bfs(const Graph& g, std::optional<u64> source, int64_t max_depth,
     if (partitioned) {
         // levels / parents were assembled from the ranks above
     } else if (pc) {
+        fgpu_ctx* raw = g.ctx().raw();
+        if (pc->pin_rows < n) {                                          // (a new cache entry, or the node capacity grew)
+            if (pc->level_pin) { fgpu_free(pc->raw, pc->level_pin); pc->level_pin = nullptr; }
+            if (pc->parent_pin) { fgpu_free(pc->raw, pc->parent_pin); pc->parent_pin = nullptr; }
+            pc->raw = raw;
+            pc->pin_rows = 0;
+            check(fgpu_host_alloc(raw, n * sizeof(int32_t), (void**)&pc->level_pin), "fgpu_host_alloc");
+            pc->pin_rows = n;
+        }
+        if (want_edges && !pc->parent_pin) check(fgpu_host_alloc(raw, pc->pin_rows * sizeof(int64_t), (void**)&pc->parent_pin), "fgpu_host_alloc");
         check(fgpu_bfs_run(pc->plan, *source, max_depth < 0 ? -1 : max_depth, want_edges ? 1 : 0), "LAGr_BreadthFirstSearch");
-        check(fgpu_bfs_fetch(pc->plan, level.data(), want_edges ? parent.data() : nullptr), "LAGr_BreadthFirstSearch");
+        check(fgpu_bfs_fetch(pc->plan, pc->level_pin, want_edges ? pc->parent_pin : nullptr), "LAGr_BreadthFirstSearch");
+        level = pc->level_pin; parent = pc->parent_pin;
     } else {
+        level_v.resize(n);
+        parent_v.resize(want_edges ? n : 0);
         Matrix adj_t = adj.transpose();
         check(fgpu_bfs(g.ctx().raw(), adj.snapshot(), adj_t.snapshot(), *source, max_depth < 0 ? -1 : max_depth,
-                       level.data(), want_edges ? parent.data() : nullptr, nullptr),
+                       level_v.data(), want_edges ? parent_v.data() : nullptr, nullptr),
               "LAGr_BreadthFirstSearch");
+        level = level_v.data(); parent = parent_v.data();
     }
     std::vector<u64> ps, pd;
     for (u64 v = 0; v < n; ++v) {

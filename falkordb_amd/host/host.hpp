@@ -369,8 +369,18 @@ class Graph {
         Matrix adj, adj_t;                 // keep the snapshots (and their cached indexes) alive
         fgpu_bfs_plan* plan = nullptr;
         std::string key;                   // relationship types the adjacency was built for
+        // level[] / parent[] in pinned blocks of the context's pool (fgpu_host_alloc): fgpu_bfs_fetch DMAs into them — the
+        // procedure reads the vectors element by element afterwards (algo_procedures.rs:1096-1160), it never needs a copy
+        fgpu_ctx* raw = nullptr;
+        int32_t* level_pin = nullptr;
+        int64_t* parent_pin = nullptr;
+        u64 pin_rows = 0;
         BfsPlanCache(Matrix a, Matrix at) : adj(std::move(a)), adj_t(std::move(at)) {}
-        ~BfsPlanCache() { if (plan) fgpu_bfs_plan_free(plan); }
+        ~BfsPlanCache() {
+            if (plan) fgpu_bfs_plan_free(plan);
+            if (level_pin) fgpu_free(raw, level_pin);
+            if (parent_pin) fgpu_free(raw, parent_pin);
+        }
     };
     mutable std::shared_ptr<BfsPlanCache> bfs_cache_;
     // the same for a partitioned search over a gang of contexts: balanced splits, one column slab (+ transpose) and one
