@@ -959,6 +959,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # smoke test of the N > 1 control flow on a ONE-GPU box (tests / tools only, never a measurement): every rank on device
+    # 0, torch collectives over gloo with host tensors, the RCCL BFS leg skipped (RCCL refuses two ranks on one device)
+    one_device = os.environ.get("FGPU_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
@@ -979,7 +984,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as td
-        td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if one_device:
+            td.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    rdev = torch.device("cpu") if one_device else dev       # where the reduction tensors live
 
     def fence():
         if world > 1:
@@ -989,14 +998,14 @@ def main():
     def reduce_max(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=rdev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         return float(t.item())
 
     def reduce_sum(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.int64, device=dev)
+        t = torch.tensor([x], dtype=torch.int64, device=rdev)
         td.all_reduce(t, op=td.ReduceOp.SUM)
         return int(t.item())
 
@@ -1116,7 +1125,7 @@ def main():
                 bfs22["spmv_full_pass"]["traffic"] = hbm(bfs22["spmv_full_pass"]["kernel"])
     elif world > 1:
         # ---- N > 1: BASELINE config 4 as a secondary leg of the same line ---------------------------------------------
-        if not args.no_bfs:
+        if not args.no_bfs and not one_device:
             d = bfs_dist_leg(ctx, engine, args, 26, rank, world, dev, td, torch, 32, 8)
             detail["bfs26_dist"] = d
             sec["bfs26_dist"] = {"TEPS": d["TEPS"], "ms": d["ms_per_step"], "ranks": world, "scaling": "strong",

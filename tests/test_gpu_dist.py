@@ -2,6 +2,8 @@
 plans side by side and doing the frontier all-gather by hand (device copies into each plan's
 gather buffer).  The control flow is falkordb_amd.dist.run_levels — the same loop bench.py runs
 over RCCL — so this pins the partitioned step / commit kernels against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -336,3 +338,29 @@ def test_in_library_dist_loop_over_the_multi_rank_communicator_branch(tmp_path):
     assert sends[0] > 0 and sends[1] > sends[0]                 # send/recv pairs ran (dist_collective 0)
     assert bcasts[2] > bcasts[1] and bcasts[4] > bcasts[3]      # broadcasts ran (dist_collective 1)
     assert allred == sorted(allred) and allred[0] >= 1 and allred[-1] >= 6   # one degree all-reduce per partition
+
+
+def test_bench_line_with_two_ranks_on_one_device(tmp_path):
+    """The N > 1 control flow of bench.py — source batches sharded round-robin over the ranks, adjacency replicated, per-rank
+    timed loops between fences, flops summed and time max-reduced over the ranks, rank 0 printing the line — launched the way
+    the driver launches it (torch.distributed.run, one process per rank) with both ranks on the one GPU of a test box and the
+    launcher's collectives over gloo (FGPU_BENCH_ONE_DEVICE: RCCL refuses two ranks on one device, so the RCCL BFS leg is
+    skipped).  Not a measurement: it pins that the line of a multi-rank run parses, names 2 GPUs, and carries twice the
+    traversed edges of the same steps on one rank's share."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FGPU_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--scale", "18",
+           "--no-cpu-baseline", "--no-pmc", "--no-varlen"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "TEPS"
+    assert d["metric"].startswith("traversed edges/sec (TEPS) on k-hop MATCH")
+    assert d["parity"]["ok"] is True and d["value"] > 0
+    assert "2 GPUs" in d["config"]["parallelism"]
