@@ -775,6 +775,9 @@ def bfs_single_leg(ctx, engine, args, scale, A=None, steps=64, warmup=8, want_pr
                                "frac": round(tot_b / tot_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
                                "alg_bytes_per_launch": int(tot_b / launches), "avg_launch_us": round(tot_ms / launches * 1e3, 2),
                                "launches": int(launches), "levels_per_search": round(launches / steps, 2),
+                               # the replay is level-synchronous (an event pair per level): its per-launch time exceeds what a
+                               # level costs inside the blind loop of the timed region, whose upper bound is wall time / levels
+                               "blind_loop_us_per_level_upper_bound": round(dt / steps * 1e6 / max(launches / steps, 1e-9), 2),
                                "timing": "HIP events around each level launch of a level-synchronous replay of the same "
                                          "roots (same kernel instantiation as the timed blind loop)",
                                "by_direction": [dict(r, traffic=None) for r in _kernel_rows(prof)]}
