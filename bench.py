@@ -408,14 +408,14 @@ def khop_emit_leg(ctx, engine, args, A, host, batches):
         ctx.prof_enable(False)
         # the host-array entry (fgpu_expand: pinned result blocks filled by DMA, ids widened on the device): the first call pays
         # the pinning of its result blocks, later ones reuse them (fgpu_free returns them to the context's pool)
-        t_first, t_host = None, []
+        t_first_host, t_host = None, []
         for rep in range(2):                       # pass 0 sizes the pool (results of a batch differ by tens of per cent), pass 1 is timed
             for b in bl[:5]:
                 t1 = time.perf_counter()
                 r_ = engine.expand(ctx, b, [A] * hops)
                 d1 = time.perf_counter() - t1
                 if rep == 0 and b is bl[0]:
-                    t_first = d1
+                    t_first_host = d1
                     rp, dest = r_[0].copy(), r_[1].copy()
                 if rep == 1:
                     t_host.append(d1)
@@ -434,7 +434,7 @@ def khop_emit_leg(ctx, engine, args, A, host, batches):
         assert seen == len(dest)
         rec = {"hops": hops, "rows": rows, "batches": nb, "ms_per_batch": round(dt / nb * 1e3, 3),
                "TEPS": round(tot_f / dt, 1), "out_nnz_per_batch": int(tot_n // nb),
-               "host_arrays_ms_first_batch": round(t_first * 1e3, 3),
+               "host_arrays_ms_first_batch": round(t_first_host * 1e3, 3),
                "host_arrays_ms": round(sorted(t_host)[len(t_host) // 2] * 1e3, 3),
                "stream_ms": {"first_chunk": round(t_first * 1e3, 3), "all_chunks": round(t_stream * 1e3, 3), "chunk_rows": 64},
                "kernels": [{"kernel": k["kernel"], "ms_total": round(k["ms"], 3), "launches": k["launches"],
