@@ -34,7 +34,9 @@ def test_host_layer_reaches_the_engine_only_through_the_c_abi():
                                                                         "libfalkor_host.so")],
                          capture_output=True, text=True, check=True).stdout
     used = set(re.findall(r" U (fgpu_[a-z0-9_]+)", out))
-    assert {"fgpu_init", "fgpu_expand", "fgpu_bfs", "fgpu_mat_merge", "fgpu_mat_probe", "fgpu_delta_lmxm"} <= used
+    # (expand_batch consumes the chain's result through the streamed form since round 4, algo_bfs fetches into pinned blocks)
+    assert {"fgpu_init", "fgpu_expand_stream_open", "fgpu_expand_stream_next", "fgpu_expand_stream_close", "fgpu_host_alloc",
+            "fgpu_bfs", "fgpu_mat_merge", "fgpu_mat_probe", "fgpu_delta_lmxm"} <= used
     assert not re.search(r" U hip[A-Z]", out), "host layer must not call HIP directly"
 
 
