@@ -77,6 +77,8 @@ struct fgpu_options {  // fgpu_set_option
                                // 2 = when the plan's previous search took more than 12 levels
     int bfs_hub_first = 1;     // pull levels read A' rows reordered hub-first (bfs.hip ensure_pull_order)
     int bfs_prof_split = 0;    // profiled BFS pass launches the <.., 1|2> twins that name a level push / pull (PMC passes)
+    int merge_items = 1;       // Delta merge scatter: 1 = shifted copy by 2048-entry items with the dp insertion positions as events
+                               // (merge.hip), 0 = the per-word / per-entry scatter (A/B)
     int merge_mode = 0;        // Delta merge: 0 entry-parallel (merge.hip), 1 one wavefront per row (pattern only)
     int dist_timing = 0;       // fgpu_bfs_dist_run records HIP events around every level kernel and exchange (fgpu_bfs_dist_times)
     int dist_collective = 0;   // frontier exchange of the in-library multi-GPU BFS: 0 grouped ncclSend/ncclRecv

@@ -802,6 +802,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "transpose_mode")) {
         FGPU_REQUIRE(value == 0 || value == 1, FGPU_INVALID, "transpose_mode must be 0 (counting) or 1 (COO rebuild)");
         ctx->opt.transpose_mode = (int)value;
+    } else if (!strcmp(name, "merge_items")) {
+        ctx->opt.merge_items = value != 0;
     } else if (!strcmp(name, "merge_mode")) {
         FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID,
                      "merge_mode must be 0 (entry-parallel), 1 (row-wave) or 2 (entry-parallel, base layer marked entry by entry)");

@@ -299,6 +299,101 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(Layer x, Layer other
     }
 }
 
+// ---- the scatter as a shifted copy with a handful of events per 2048 entries (round 4) ----------------------------------------
+// out = the merged (row, col)-ordered sequence, so a kept entry p of m lands at  kept_before(p) + I(p),  I(p) = the number of
+// dp entries inserted at or before p — and with 0.1 % deltas I changes every ~1000 entries.  merge_scatter_kernel asks the
+// question per entry from m's side (row of the entry, the other layer's row, a search in it, two kept-rank look-ups: a dozen
+// dependent loads for every entry of every word that shares a row with a delta — half of an R-MAT layer, whose hub rows always
+// hold a tombstone) and stayed at 0.5 ms of the 0.72 ms merge through five rewrites.  Here the delta side answers once:
+// Q[k] = the position in m before which dp entry k goes (one search per dp entry, ascending by construction); an item of
+// MS_ITEM consecutive entries of m loads the <= 64 events that fall into it ONCE (ibase[item] = their first index) and every
+// lane ranks its entries among them with shuffles — no row look-up at all; kb / ks words are read coalesced, 32 per item.
+// dp entry k itself lands at kept_before(Q[k]) + k.  (Without dm_masks_dp every dp entry is kept; a coordinate stored in both
+// m and dp has lost its keep bit in m already, merge_unmark_kernel.)
+constexpr u32 MS_ITEM = 2048;
+__global__ __launch_bounds__(256) void merge_qpos_kernel(Layer dp, Layer m, u32* __restrict__ Q) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 nwords = (dp.nnz + 63) >> 6;
+    for (u32 w = wave; w < nwords; w += nwaves) {
+        const u32 q = (w << 6) + lane;
+        if (q >= dp.nnz) continue;
+        u32 i, r;
+        lane_row(dp, w, q, true, i, r);
+        u32 pos = m.nnz;                                        // a row past m's last one: behind everything
+        if (r < m.v.nrows) {
+            const u32 b = m.v.rowptr[r], e = m.v.rowptr[r + 1];  // (m is not hypersparse here: an empty row still has its place)
+            pos = lower_bound_col(m.v.colidx, b, e, dp.v.colidx[q]);
+        }
+        Q[q] = pos;
+    }
+}
+// ibase[it] = number of events before the item's first entry
+__global__ void merge_ibase_kernel(const u32* __restrict__ Q, u32 nQ, u32 nitems, u32* __restrict__ ibase) {
+    const u32 it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= nitems) return;
+    const u32 p0 = it * MS_ITEM;
+    u32 lo = 0, hi = nQ;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (Q[mid] < p0) lo = mid + 1; else hi = mid; }
+    ibase[it] = lo;
+}
+__global__ __launch_bounds__(256) void merge_copy_items_kernel(Layer m, const u64* __restrict__ kb, const u32* __restrict__ ks,
+                                                              const u32* __restrict__ Q, u32 nQ, const u32* __restrict__ ibase,
+                                                              u32 nitems, u32* __restrict__ out_col, u64* __restrict__ out_val) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u32 nwaves = (gridDim.x * 256) >> 6;
+    constexpr u32 WPI = MS_ITEM / 64;                          // words per item: 32
+    for (u32 it = wave; it < nitems; it += nwaves) {
+        const u32 p0 = it * MS_ITEM;
+        const u32 w0 = p0 >> 6;
+        const u32 base = ibase[it];
+        // the item's metadata in one round of loads: keep word + kept prefix of word w0 + lane (lanes < 32), events base + lane
+        const u32 nwords = (m.nnz + 63) >> 6;
+        const u64 kbw = (lane < WPI && w0 + lane < nwords) ? kb[w0 + lane] : 0ull;
+        const u32 ksw = (lane < WPI && w0 + lane < nwords) ? ks[w0 + lane] : 0u;
+        const u32 ev = base + lane < nQ ? Q[base + lane] : 0xFFFFFFFFu;
+        const u32 last = p0 + MS_ITEM - 1;
+        const bool dense = (u32)__builtin_amdgcn_readlane((int)ev, 63) <= last;   // more than 64 events in this item (wave-uniform)
+#pragma unroll 4
+        for (u32 t = 0; t < WPI; ++t) {
+            const u64 mask = (u64)__shfl((long long)kbw, (int)t, 64);
+            if (mask == 0ull) continue;                          // wave-uniform
+            const u32 p = p0 + 64 * t + lane;
+            const u32 own = (u32)__shfl((int)ksw, (int)t, 64) + (u32)__popcll(lane ? (mask & ((1ull << lane) - 1ull)) : 0ull);
+            u32 ins;
+            if (!dense) {                                        // events <= p among the 64 loaded ones (sorted): 6 shuffle steps
+                u32 lo = 0, hi = 64;
+#pragma unroll
+                for (int st = 0; st < 7; ++st) {
+                    const u32 mid = (lo + hi) >> 1;
+                    const u32 v = (u32)__shfl((int)ev, (int)(mid & 63u), 64);
+                    if (lo < hi) { if (v <= p) lo = mid + 1; else hi = mid; }
+                }
+                ins = base + lo;
+            } else {                                             // a dense run of insertions: rank in the whole list
+                u32 lo = base, hi = nQ;
+                while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (Q[mid] <= p) lo = mid + 1; else hi = mid; }
+                ins = lo;
+            }
+            if ((mask >> lane) & 1ull) {
+                const u32 pos = own + ins;
+                out_col[pos] = m.v.colidx[p];
+                if (out_val) out_val[pos] = m.val ? m.val[p] : 1ull;
+            }
+        }
+    }
+}
+__global__ void merge_dp_place_kernel(Layer dp, const u32* __restrict__ Q, const u64* __restrict__ kbm, const u32* __restrict__ ksm,
+                                      u32* __restrict__ out_col, u64* __restrict__ out_val) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= dp.nnz) return;
+    const u32 pos = kept_before(kbm, ksm, Q[k]) + k;
+    out_col[pos] = dp.v.colidx[k];
+    if (out_val) out_val[pos] = dp.val ? dp.val[k] : 1ull;
+}
+
 // the wordrow index of a snapshot: built on first use, owned (and freed) by the matrix
 fgpu_info mat_wordrow(fgpu_ctx* ctx, const fgpu_mat* a, const u32** out) {
     *out = nullptr;
@@ -370,7 +465,8 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
         FGPU_HIP(hipMemsetAsync(rowbits.p, 0, nb * sizeof(u32), ctx->stream()));
         if (has_dp) {
             hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream(), lp.v, rowbits.p);
-            if (has_dm) {   // the rows dp stores, on their own: only they need a cross-rank lookup when m is scattered
+            if (has_dm && !(ctx->opt.merge_items && !clip && ctx->opt.merge_mode != 2 && !dm_masks_dp && !m->is_hyper())) {
+                // the rows dp stores, on their own: only they need a cross-rank lookup when m is scattered by merge_scatter_kernel
                 FGPU_TRY(rowbits_dp.alloc(ctx, nb));
                 FGPU_HIP(hipMemsetAsync(rowbits_dp.p, 0, nb * sizeof(u32), ctx->stream()));
                 hipLaunchKernelGGL(rowbits_kernel, dim3(cdiv(dp->nvec, 256)), dim3(256), 0, ctx->stream(), lp.v, rowbits_dp.p);
@@ -420,14 +516,33 @@ fgpu_info mat_merge_entries(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* m, co
     FGPU_TRY(mat_alloc(ctx, &o, out_nrows, out_ncols, nnz, with_vals, 0, false));
     hipError_t e = hipMemcpyAsync(o->rowptr, orp.p, (out_nrows + 1) * sizeof(u32), hipMemcpyDeviceToDevice,
                                   ctx->stream());
-    if (e == hipSuccess && lm.nnz && nnz) {
+    // shifted-copy scatter (above) for the common shape: same dims, a plain CSR base, every dp entry kept
+    const bool by_items = ctx->opt.merge_items && !clip && ctx->opt.merge_mode != 2 && !dm_masks_dp && !m->is_hyper() && lm.nnz && nnz;
+    DevBuf<u32> Q, ibase;
+    if (e == hipSuccess && by_items) {
+        const u32 nQ = has_dp ? lp.nnz : 0u;
+        const u32 nitems = cdiv(lm.nnz, MS_ITEM);
+        fgpu_info ai = Q.alloc(ctx, (size_t)nQ + 64);
+        if (ai == FGPU_OK) ai = ibase.alloc(ctx, (size_t)nitems + 1);
+        if (ai != FGPU_OK) { mat_release(o); return ai; }
+        if (nQ) hipLaunchKernelGGL(merge_qpos_kernel, dim3(entry_grid(ctx, nQ)), dim3(256), 0, ctx->stream(), lp, lm, Q.p);
+        hipLaunchKernelGGL(merge_ibase_kernel, dim3(cdiv(nitems, 256)), dim3(256), 0, ctx->stream(), (const u32*)Q.p, nQ, nitems, ibase.p);
+        u32 grid = cdiv(nitems, 4);
+        if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+        hipLaunchKernelGGL(merge_copy_items_kernel, dim3(grid), dim3(256), 0, ctx->stream(), lm, (const u64*)km.kb.p, (const u32*)km.ks.p,
+                           (const u32*)Q.p, nQ, (const u32*)ibase.p, nitems, o->colidx, o->vals);
+        if (nQ) hipLaunchKernelGGL(merge_dp_place_kernel, dim3(cdiv(nQ, 256)), dim3(256), 0, ctx->stream(), lp, (const u32*)Q.p,
+                                   (const u64*)km.kb.p, (const u32*)km.ks.p, o->colidx, o->vals);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !by_items && lm.nnz && nnz) {
         hipLaunchKernelGGL(merge_scatter_kernel<true>, dim3(entry_grid(ctx, lm.nnz)), dim3(256), 0, ctx->stream(), lm,
                            lp, has_dp, (const u32*)rowbits.p, (const u64*)km.kb.p, (const u32*)km.ks.p,
                            (const u64*)kp.kb.p, (const u32*)kp.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip,
                            (const u32*)rowbits_dp.p);
         e = hipGetLastError();
     }
-    if (e == hipSuccess && has_dp && nnz) {
+    if (e == hipSuccess && !by_items && has_dp && nnz) {
         hipLaunchKernelGGL(merge_scatter_kernel<false>, dim3(entry_grid(ctx, lp.nnz)), dim3(256), 0, ctx->stream(), lp,
                            lm, lm.nnz != 0, (const u32*)rowbits.p, (const u64*)kp.kb.p, (const u32*)kp.ks.p,
                            (const u64*)km.kb.p, (const u32*)km.ks.p, (const u32*)o->rowptr, o->colidx, o->vals, clip,

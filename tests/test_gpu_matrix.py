@@ -167,14 +167,24 @@ def test_merge_rmat_hub_rows_both_kernels(ctx, mode):
     pc = np.concatenate([pc, rng.integers(0, n, 3000, dtype=np.uint64)])
     ctx.set_option("merge_mode", mode)
     try:
-        for masks_dp in (False, True):
-            got = ctx.mat_rmat(14).merge(ctx.mat_from_coo(n, n, pr, pc), ctx.mat_from_coo(n, n, dr, dc),
-                                         dm_masks_dp=masks_dp)
-            assert_same(got, oracle.merge(a, oracle.build_csr(n, n, pr, pc), oracle.build_csr(n, n, dr, dc), masks_dp))
-        assert_same(ctx.mat_rmat(14).merge(None, None), a)
-        assert_same(ctx.mat_new(n, n).merge(ctx.mat_from_coo(n, n, pr, pc), None), oracle.build_csr(n, n, pr, pc))
+        # merge_items: the scatter as a shifted copy by 2048-entry items with the dp insertion positions as events (the
+        # default; the 3000 insertions into the hub row are its dense-events branch) / the per-word, per-entry scatter
+        for items in ((1, 0) if mode == 0 else (1,)):
+            ctx.set_option("merge_items", items)
+            for masks_dp in (False, True):
+                got = ctx.mat_rmat(14).merge(ctx.mat_from_coo(n, n, pr, pc), ctx.mat_from_coo(n, n, dr, dc),
+                                             dm_masks_dp=masks_dp)
+                assert_same(got, oracle.merge(a, oracle.build_csr(n, n, pr, pc), oracle.build_csr(n, n, dr, dc), masks_dp))
+            assert_same(ctx.mat_rmat(14).merge(None, None), a)
+            assert_same(ctx.mat_new(n, n).merge(ctx.mat_from_coo(n, n, pr, pc), None), oracle.build_csr(n, n, pr, pc))
+            # rows appended behind the base's last row (a grown Delta layer): they land behind every base entry
+            grown = ctx.mat_rmat(14).merge(ctx.mat_from_coo(n, n, np.array([n - 1, n - 1], dtype=np.uint64),
+                                                            np.array([0, n - 1], dtype=np.uint64)), None)
+            assert_same(grown, oracle.merge(a, oracle.build_csr(n, n, np.array([n - 1, n - 1], dtype=np.uint64),
+                                                                np.array([0, n - 1], dtype=np.uint64)), None))
     finally:
         ctx.set_option("merge_mode", 0)
+        ctx.set_option("merge_items", 1)
 
 
 @pytest.mark.parametrize("n_tuples", [900, 40000])
