@@ -653,6 +653,32 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
         d = time.perf_counter() - t
         return {"ms_per_batch": round(d / len(bl) * 1e3, 3), "TEPS": round(fl / d, 1), "batches": len(bl)}
     det["count_only"] = run(ks, clean, False)
+
+    def run_lanes(bl, layers, lanes):
+        """The same batches from `lanes` query threads at once — the reference's worker pool (threadpool.rs:89-128) calling
+        into one context, every thread on its own lane (stream + scratch): one batch's small launches and read-backs run
+        under the other's pulls."""
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        gate = threading.Barrier(lanes)
+
+        def warm(b):
+            gate.wait()                              # one warm batch on EVERY worker thread: its lane's pools exist afterwards
+            return engine.expand_count(ctx, b, *layers)
+        with ThreadPoolExecutor(lanes) as ex:
+            list(ex.map(warm, bl[:lanes]))
+            t = time.perf_counter()
+            res = list(ex.map(lambda b: engine.expand_count(ctx, b, *layers), bl))
+            d = time.perf_counter() - t
+        fl = sum(r[2] for r in res)
+        cs2 = 0
+        for r in res:
+            cs2 = (cs2 + r[1]) & 0xFFFFFFFFFFFFFFFF
+        return {"lanes": lanes, "ms_per_batch": round(d / len(bl) * 1e3, 3), "TEPS": round(fl / d, 1), "batches": len(bl),
+                "checksum": f"{cs2:016x}"}
+    if not args.no_lanes_sweep:
+        det["query_threads"] = [run_lanes(timed, clean, k) for k in (2, 3, 4)]
+        det["query_threads_checksum_matches_timed"] = all(q["checksum"] == f"{cs:016x}" for q in det["query_threads"])
     for b in ks[:2]:
         engine.expand_count(ctx, b, *dirty)
     det["dirty"] = run(ks, dirty)
@@ -949,6 +975,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (fgpu_set_option)")
     ap.add_argument("--quick", action="store_true", help="headline + parity + CPU baseline only (no secondary legs, no PMC)")
     ap.add_argument("--khop-extra-scales", default="24,26", help="further scales of the k-hop leg (secondary)")
+    ap.add_argument("--no-lanes-sweep", action="store_true", help="skip the run of the timed batches from 2 / 3 / 4 query threads")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle checks")
     ap.add_argument("--no-bfs", action="store_true", help="skip the BFS / SpMV secondary legs")
     ap.add_argument("--no-varlen", action="store_true", help="skip the config-5 stand-in leg")
@@ -1054,6 +1081,10 @@ def main():
         first, roofline = extra
         sec["khop%d" % scale] = {"count_only_TEPS": head["count_only"]["TEPS"], "count_only_ms": head["count_only"]["ms_per_batch"],
                                  "dirty_TEPS": head["dirty"]["TEPS"], "dirty_ms": head["dirty"]["ms_per_batch"]}
+        if head.get("query_threads"):                 # the timed batches again from 4 query threads (4 lanes of the one context)
+            q = head["query_threads"][-1]
+            sec["khop%d" % scale].update({"threads%d_TEPS" % q["lanes"]: q["TEPS"], "threads%d_ms" % q["lanes"]: q["ms_per_batch"],
+                                          "threads_checksum_ok": head["query_threads_checksum_matches_timed"]})
         if not args.no_parity and host is not None:
             parity, cpu = khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, timed[0], first, scale)
             detail["parity"] = parity

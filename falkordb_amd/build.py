@@ -98,6 +98,8 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
 
 
 SHIM_LIB = os.path.join(LIBDIR, "libgraphblas.so")
+LAGRAPH_LIB = os.path.join(LIBDIR, "liblagraph.so")
+LAGRAPHX_LIB = os.path.join(LIBDIR, "liblagraphx.so")
 
 
 def build_shim(force: bool = False, verbose: bool = False) -> str:
@@ -106,15 +108,27 @@ def build_shim(force: bool = False, verbose: bool = False) -> str:
     build_host(force=False, verbose=verbose)
     src = os.path.join(HERE, "shim", "graphblas_shim.cpp")
     deps = [src, os.path.join(HOST_DIR, "host.hpp"), HOST_LIB]
-    if not force and os.path.exists(SHIM_LIB) and not any(_newer(d, SHIM_LIB) for d in deps):
-        return SHIM_LIB
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", SHIM_LIB, src,
-           "-L" + LIBDIR, "-lfalkor_host", "-lfgpu", "-Wl,-rpath,$ORIGIN"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"graphblas shim build failed:\n{r.stderr}")
+    deps.append(os.path.join(HERE, "shim", "shim_internal.hpp"))
+    if force or not os.path.exists(SHIM_LIB) or any(_newer(d, SHIM_LIB) for d in deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", SHIM_LIB, src,
+               "-L" + LIBDIR, "-lfalkor_host", "-lfgpu", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"graphblas shim build failed:\n{r.stderr}")
+    # the LAGraph-named libraries over it (build.rs:50-52 links lagraphx, lagraph, graphblas): one source, two outputs
+    lsrc = os.path.join(HERE, "shim", "lagraph_shim.cpp")
+    for lib, defs in ((LAGRAPH_LIB, []), (LAGRAPHX_LIB, ["-DFG_LAGRAPHX"])):
+        if not force and os.path.exists(lib) and not any(_newer(d, lib) for d in deps + [lsrc, SHIM_LIB]):
+            continue
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", *defs, "-o", lib, lsrc,
+               "-L" + LIBDIR, "-lgraphblas", "-lfalkor_host", "-lfgpu", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"lagraph shim build failed:\n{r.stderr}")
     return SHIM_LIB
 
 

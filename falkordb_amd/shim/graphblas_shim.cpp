@@ -11,104 +11,13 @@
 // GrB_Matrix_wait / a reading call), in-place output with C aliasing an input (matrix.rs:935-943), GrB_NO_VALUE from
 // extractElement / isStoredElement for an absent entry, the row iterator's SUCCESS / NO_VALUE / EXHAUSTED protocol
 // (matrix.rs:1500-1605 drives it row by row), duplicate collapse in build (SECOND for UINT64).
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <map>
-#include <memory>
-#include <mutex>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../host/host.hpp"
-
-using falkor::Matrix;
-using falkor::Type;
-typedef uint64_t GrB_Index;
-
-// GrB_Info (mod.rs:274-296)
-enum {
-    GrB_SUCCESS = 0, GrB_NO_VALUE = 1, GxB_EXHAUSTED = 7089, GrB_UNINITIALIZED_OBJECT = -1, GrB_NULL_POINTER = -2,
-    GrB_INVALID_VALUE = -3, GrB_INVALID_INDEX = -4, GrB_DOMAIN_MISMATCH = -5, GrB_DIMENSION_MISMATCH = -6,
-    GrB_OUTPUT_NOT_EMPTY = -7, GrB_NOT_IMPLEMENTED = -8, GrB_PANIC = -101, GrB_OUT_OF_MEMORY = -102,
-    GrB_INVALID_OBJECT = -104, GrB_INDEX_OUT_OF_BOUNDS = -105,
-};
-typedef int GrB_Info;
-
-struct GB_Type_opaque { int code; const char* name; size_t size; };   // 0 = BOOL, 1 = UINT64; 2.. = the integer types a
-                                                                       // GxB_Container's p / h / i / b vectors come in
-struct GB_BinaryOp_opaque { int code; };        // 0 = ANY_BOOL, 1 = SECOND_UINT64, 2 = ANY_UINT64
-struct GB_UnaryOp_opaque { int code; };         // 0 = ONE_BOOL
-struct GB_Semiring_opaque { int code; };        // 0 = ANY_PAIR_BOOL
-struct GB_Descriptor_opaque { bool replace, structural, complement, t0, t1; };
-struct GB_Global_opaque { int dummy; };
-struct GB_Scalar_opaque { bool has; bool value; };
-struct GB_Matrix_opaque {
-    Matrix m;
-    int32_t sparsity_control = 3;   // GxB_HYPERSPARSE | GxB_SPARSE
-    int32_t orientation = 0;        // GrB_ROWMAJOR
-    explicit GB_Matrix_opaque(Matrix mm) : m(std::move(mm)) {}
-};
-// GrB_Vector as the wrapper uses it (vector.rs): (a) a sparse BOOL / UINT64 vector filled by setElement and walked by the
-// vector iterator (the id list of a multi-edge pair, tensor.rs:1111-1120: indices = edge ids), serialised as a blob;
-// (b) the dense array a GxB_Container field holds, moved in and out with GxB_Vector_load / _unload (vector.rs:241-420).
-struct GB_Vector_opaque {
-    GB_Type_opaque* type = nullptr;
-    GrB_Index n = 0;                         // length
-    std::map<GrB_Index, uint64_t> s;         // (a) stored entries
-    void* data = nullptr;                    // (b) adopted array: n entries of type->size bytes (iso vectors: 1 entry)
-    uint64_t nbytes = 0;
-    uint64_t nstored = 0;                    // entries `data` holds (n, or 1 for an iso array)
-    int handling = 0;
-};
-struct GB_Iterator_opaque {
-    GB_Vector_opaque* vec = nullptr;                                  // vector mode (GxB_Vector_Iterator_*)
-    std::map<GrB_Index, uint64_t>::const_iterator vit;
-    std::unique_ptr<Matrix> m;       // keeps the handle's state alive (the wrapper holds an Arc as well, matrix.rs:1472)
-    GrB_Index nrows = 0, row = 0;    // current row; == nrows when exhausted
-    GrB_Index w_lo = 1, w_hi = 0;    // rows covered by `buf` (empty window when w_lo > w_hi)
-    std::vector<falkor::Entry> buf;  // entries of rows [w_lo, w_hi], ascending (row, col)
-    size_t pos = 0, row_end = 0;     // current entry, end of the current row's run in buf
-};
-
-typedef GB_Type_opaque* GrB_Type;
-typedef GB_BinaryOp_opaque* GrB_BinaryOp;
-typedef GB_UnaryOp_opaque* GrB_UnaryOp;
-typedef GB_Semiring_opaque* GrB_Semiring;
-typedef GB_Descriptor_opaque* GrB_Descriptor;
-typedef GB_Global_opaque* GrB_Global;
-typedef GB_Scalar_opaque* GrB_Scalar;
-typedef GB_Matrix_opaque* GrB_Matrix;
-typedef GB_Iterator_opaque* GxB_Iterator;
-typedef GB_Vector_opaque* GrB_Vector;
-
-// GxB_Container_struct, field for field as bindgen lays it out (mod.rs:14165-14188; 608 bytes, the wrapper copies it raw,
-// matrix.rs:451-456, 517-520)
-struct GxB_Container_struct {
-    uint64_t nrows, ncols;
-    int64_t nrows_nonempty, ncols_nonempty;
-    uint64_t nvals;
-    uint64_t u64_future[11];
-    int32_t format, orientation, header_arena;
-    uint32_t u32_future[13];
-    GrB_Vector p, h, b, i, x;
-    GrB_Vector vector_future[11];
-    GrB_Matrix Y;
-    GrB_Matrix matrix_future[15];
-    bool iso, jumbled;
-    bool bool_future[30];
-    void* void_future[16];
-};
-static_assert(sizeof(GxB_Container_struct) == 608, "GxB_Container_struct must match the bindgen layout (mod.rs:14190)");
-typedef GxB_Container_struct* GxB_Container;
+#include "shim_internal.hpp"
 
 namespace {
 GB_Type_opaque t_bool{0, "GrB_BOOL", 1}, t_u64{1, "GrB_UINT64", 8}, t_u32{2, "GrB_UINT32", 4}, t_i32{3, "GrB_INT32", 4},
-    t_i64{4, "GrB_INT64", 8}, t_i8{5, "GrB_INT8", 1}, t_u8{6, "GrB_UINT8", 1}, t_u16{7, "GrB_UINT16", 2}, t_i16{8, "GrB_INT16", 2};
-GB_Type_opaque* const all_types[] = {&t_bool, &t_u64, &t_u32, &t_i32, &t_i64, &t_i8, &t_u8, &t_u16, &t_i16};
+    t_i64{4, "GrB_INT64", 8}, t_i8{5, "GrB_INT8", 1}, t_u8{6, "GrB_UINT8", 1}, t_u16{7, "GrB_UINT16", 2}, t_i16{8, "GrB_INT16", 2},
+    t_f32{9, "GrB_FP32", 4}, t_f64{10, "GrB_FP64", 8};     // (the types LAGraph's results come in: level / parent / centrality)
+GB_Type_opaque* const all_types[] = {&t_bool, &t_u64, &t_u32, &t_i32, &t_i64, &t_i8, &t_u8, &t_u16, &t_i16, &t_f32, &t_f64};
 
 // the allocator GxB_init was handed (matrix.rs:116-185 passes Redis'): arrays that change owner across the ABI — what
 // GxB_Vector_unload / GxB_Vector_serialize give out, what GxB_Vector_load adopts — are allocated and released with it
@@ -117,7 +26,50 @@ void (*g_free)(void*) = nullptr;
 void* shim_malloc(size_t n) { return g_malloc ? g_malloc(n ? n : 1) : malloc(n ? n : 1); }
 void shim_free(void* p) { if (!p) return; if (g_free) g_free(p); else free(p); }
 
-void vec_drop_array(GB_Vector_opaque* v) { shim_free(v->data); v->data = nullptr; v->nbytes = 0; v->nstored = 0; }
+void vec_drop_array(GB_Vector_opaque* v) {
+    if (v->pinned_owner) (void)fgpu_free(v->pinned_owner, v->data); else shim_free(v->data);
+    v->data = nullptr; v->nbytes = 0; v->nstored = 0; v->pinned_owner = nullptr; v->absent = 0; v->stored_count = -1;
+}
+// entry i of a dense array as a signed / floating value (results of the engine are INT32 / INT64 / FP32; container
+// arrays are the unsigned index types)
+inline int64_t dense_i64(const GB_Vector_opaque* v, GrB_Index i) {
+    const char* p = (const char*)v->data + (v->nstored == 1 ? 0 : i * v->type->size);
+    switch (v->type->code) {
+        case 3: { int32_t x; memcpy(&x, p, 4); return x; }
+        case 4: { int64_t x; memcpy(&x, p, 8); return x; }
+        case 2: { uint32_t x; memcpy(&x, p, 4); return x; }
+        case 1: { uint64_t x; memcpy(&x, p, 8); return (int64_t)x; }
+        case 5: return *(const int8_t*)p;
+        case 6: case 0: return *(const uint8_t*)p;
+        case 7: { uint16_t x; memcpy(&x, p, 2); return x; }
+        case 8: { int16_t x; memcpy(&x, p, 2); return x; }
+        case 9: { float x; memcpy(&x, p, 4); return (int64_t)x; }
+        case 10: { double x; memcpy(&x, p, 8); return (int64_t)x; }
+    }
+    return 0;
+}
+inline double dense_f64(const GB_Vector_opaque* v, GrB_Index i) {
+    const char* p = (const char*)v->data + (v->nstored == 1 ? 0 : i * v->type->size);
+    if (v->type->code == 9) { float x; memcpy(&x, p, 4); return x; }
+    if (v->type->code == 10) { double x; memcpy(&x, p, 8); return x; }
+    if (v->type->code == 1) { uint64_t x; memcpy(&x, p, 8); return (double)x; }
+    return (double)dense_i64(v, i);
+}
+inline bool dense_present(const GB_Vector_opaque* v, GrB_Index i) {
+    if (!v->absent) return true;
+    if (v->type->code == 9 || v->type->code == 10) return v->absent == 1 ? dense_f64(v, i) >= 0 : dense_f64(v, i) != 0;
+    const int64_t x = dense_i64(v, i);
+    return v->absent == 1 ? x >= 0 : x != 0;
+}
+uint64_t dense_count(GB_Vector_opaque* v) {
+    if (!v->absent) return v->n;
+    if (v->stored_count < 0) {
+        int64_t c = 0;
+        for (GrB_Index i = 0; i < v->n; ++i) c += dense_present(v, i) ? 1 : 0;
+        v->stored_count = c;
+    }
+    return (uint64_t)v->stored_count;
+}
 GB_Vector_opaque* vec_new(GB_Type_opaque* t, GrB_Index n) {
     GB_Vector_opaque* v = new GB_Vector_opaque();
     v->type = t; v->n = n;
@@ -134,7 +86,8 @@ GB_Type_opaque* type_by_name(const char* name) {
         if (!strcmp(t->name, name)) return t;
     // the C type names GraphBLAS also accepts (GxB_Type_from_name)
     static const struct { const char* c; GB_Type_opaque* t; } alias[] = {{"bool", &t_bool}, {"uint64_t", &t_u64}, {"uint32_t", &t_u32},
-        {"int32_t", &t_i32}, {"int64_t", &t_i64}, {"int8_t", &t_i8}, {"uint8_t", &t_u8}, {"uint16_t", &t_u16}, {"int16_t", &t_i16}};
+        {"int32_t", &t_i32}, {"int64_t", &t_i64}, {"int8_t", &t_i8}, {"uint8_t", &t_u8}, {"uint16_t", &t_u16}, {"int16_t", &t_i16},
+        {"float", &t_f32}, {"double", &t_f64}};
     for (auto& a : alias)
         if (!strcmp(a.c, name)) return a.t;
     return nullptr;
@@ -235,6 +188,19 @@ GrB_Info it_at(GB_Iterator_opaque* it, GrB_Index row) {
 }
 }  // namespace
 
+namespace fgshim {
+falkor::Context* context() { return ctx(); }
+GB_Type_opaque* type_int32() { return &t_i32; }
+GB_Type_opaque* type_int64() { return &t_i64; }
+GB_Type_opaque* type_fp32() { return &t_f32; }
+GB_Vector_opaque* vector_over_pinned(GB_Type_opaque* type, GrB_Index n, void* pinned, int absent) {
+    GB_Vector_opaque* v = vec_new(type, n);
+    v->data = pinned; v->nbytes = n * type->size; v->nstored = n; v->absent = absent;
+    v->pinned_owner = ctx()->raw();
+    return v;
+}
+}  // namespace fgshim
+
 #define SHIM_REQUIRE_INIT() do { if (!ctx()) return GrB_PANIC; } while (0)
 
 extern "C" {
@@ -248,6 +214,10 @@ GrB_BinaryOp GxB_ANY_UINT64 = &op_any_u64;
 GrB_UnaryOp GxB_ONE_BOOL = &op_one_bool;
 GrB_Semiring GxB_ANY_PAIR_BOOL = &sr_any_pair_bool;
 GrB_Global GrB_GLOBAL = &global_obj;
+GrB_Type GrB_INT32 = &t_i32;       // types of the vectors LAGraph hands back (lagraph_shim.cpp)
+GrB_Type GrB_INT64 = &t_i64;
+GrB_Type GrB_FP32 = &t_f32;
+GrB_Type GrB_FP64 = &t_f64;
 
 // the 31 predefined descriptors (mod.rs:424-612; matrix.rs:313-351 maps all of them): R = replace, S = structural mask,
 // C = complemented mask, T0 / T1 = transpose the first / second input
@@ -641,7 +611,7 @@ GrB_Info GrB_Vector_clear(GrB_Vector v) { if (!v) return GrB_NULL_POINTER; v->s.
 GrB_Info GrB_Vector_size(GrB_Index* n, GrB_Vector v) { if (!n || !v) return GrB_NULL_POINTER; *n = v->n; return GrB_SUCCESS; }
 GrB_Info GrB_Vector_nvals(GrB_Index* n, GrB_Vector v) {
     if (!n || !v) return GrB_NULL_POINTER;
-    *n = v->data ? v->n : v->s.size();
+    *n = v->data ? dense_count(v) : v->s.size();
     return GrB_SUCCESS;
 }
 GrB_Info GrB_Vector_resize(GrB_Vector v, GrB_Index n) {
@@ -666,6 +636,41 @@ GrB_Info GrB_Vector_removeElement(GrB_Vector v, GrB_Index i) {
     if (i >= v->n) return GrB_INVALID_INDEX;
     v->s.erase(i);
     return GrB_SUCCESS;
+}
+// GrB_Vector_extractTuples_INT64 / _FP64 (mod.rs; algo_procedures.rs:415-447 reads level / parent / centrality with them):
+// entries in ascending index order, values typecast to the requested type, *nvals in = room, out = entries written
+}  // extern "C"
+template <typename T, typename Get>
+static GrB_Info vec_extract(GrB_Index* I, T* X, GrB_Index* nvals, GrB_Vector v, Get get_dense) {
+    if (!nvals || !v) return GrB_NULL_POINTER;
+    return guarded([&]() -> GrB_Info {
+        const uint64_t have = v->data ? dense_count(v) : v->s.size();
+        if (*nvals < have) return GrB_INSUFFICIENT_SPACE;
+        uint64_t k = 0;
+        if (v->data) {
+            for (GrB_Index i = 0; i < v->n; ++i) {
+                if (!dense_present(v, i)) continue;
+                if (I) I[k] = i;
+                if (X) X[k] = get_dense(v, i);
+                ++k;
+            }
+        } else {
+            for (auto& kv : v->s) {
+                if (I) I[k] = kv.first;
+                if (X) X[k] = (T)kv.second;
+                ++k;
+            }
+        }
+        *nvals = k;
+        return GrB_SUCCESS;
+    });
+}
+extern "C" {
+GrB_Info GrB_Vector_extractTuples_INT64(GrB_Index* I, int64_t* X, GrB_Index* nvals, GrB_Vector v) {
+    return vec_extract<int64_t>(I, X, nvals, v, dense_i64);
+}
+GrB_Info GrB_Vector_extractTuples_FP64(GrB_Index* I, double* X, GrB_Index* nvals, GrB_Vector v) {
+    return vec_extract<double>(I, X, nvals, v, dense_f64);
 }
 GrB_Info GrB_Type_get_String(GrB_Type type, char* value, int field) {
     if (!type || !value) return GrB_NULL_POINTER;
@@ -720,6 +725,15 @@ GrB_Info GxB_Vector_unload(GrB_Vector v, void** X, GrB_Type* type, uint64_t* n, 
         for (auto& kv : v->s) { memcpy(a + (k++) * sz, &kv.second, sz); }     // little-endian: the low bytes are the value
         v->s.clear();
         v->data = a; v->nbytes = v->n * sz; v->nstored = v->n;
+    }
+    if (v->pinned_owner) {                       // an engine result: the caller gets an array of ITS allocator, the pinned block goes back
+        if (v->absent) return GrB_INVALID_VALUE;  // (not full: same rule as above)
+        void* a = shim_malloc(v->nbytes);
+        if (!a) return GrB_OUT_OF_MEMORY;
+        memcpy(a, v->data, v->nbytes);
+        const uint64_t nb = v->nbytes, ns = v->nstored;
+        vec_drop_array(v);
+        v->data = a; v->nbytes = nb; v->nstored = ns;
     }
     *X = v->data; *type = v->type; *n = v->n; *X_memsize = v->nbytes; *handling = v->handling;
     v->data = nullptr; v->nbytes = 0; v->nstored = 0; v->n = 0;

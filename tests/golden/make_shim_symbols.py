@@ -30,8 +30,21 @@ for fn in ("matrix.rs", "vector.rs", "tensor.rs", "versioned_matrix.rs"):
     out["files"][fn] = {"functions": f, "globals": s}
     allf |= set(f)
     alls |= set(s)
+# LAGraph: the entry points matrix.rs (init / shutdown) and algo_procedures.rs call, split by the binding file that declares them
+algo = open(os.path.join(ref, "graph", "src", "runtime", "functions", "algo_procedures.rs")).read()
+matrix_rs = open(os.path.join(gb, "matrix.rs")).read()
+for key, fn in (("lagraph", "lagraph_bindings.rs"), ("lagraphx", "lagraphx_bindings.rs")):
+    declared = set(re.findall(r"pub fn (LAGr\w*_\w+)\s*\(", open(os.path.join(gb, fn)).read()))
+    used = set(re.findall(key + r"_bindings::(LAGr\w*_\w+)", algo))
+    if key == "lagraph":
+        used |= set(re.findall(r"\b(LAGraph_\w+)\b", matrix_rs))
+    out[key] = sorted(used & declared)
+# the GraphBLAS calls inside the algo.BFS (:1017-1165) and algo.pageRank (:687-783) procedures and their helpers (:385-447)
+lines = algo.split("\n")
+span = "\n".join(lines[384:447] + lines[686:783] + lines[1016:1165])
+out["algo_bfs_pagerank_graphblas"] = sorted(set(re.findall(r"\b((?:GrB|GxB)_\w+)\b", span)) & functions)
 out["functions"] = sorted(allf)
 out["globals"] = sorted(alls)
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shim_symbols.json")
 json.dump(out, open(dst, "w"), indent=1)
-print(f"{len(allf)} functions, {len(alls)} globals -> {dst}")
+print(f"{len(allf)} functions, {len(alls)} globals, {len(out['lagraph'])} + {len(out['lagraphx'])} LAGraph entry points -> {dst}")

@@ -1,0 +1,168 @@
+/* replay_algo_rs.c — the call sequences of the reference's algo.BFS and algo.pageRank procedures, issued call for call
+ * through the GraphBLAS + LAGraph C ABI (declarations: lagraph_subset.h / graphblas_subset.h, transcribed from the bindgen
+ * output) against falkordb_amd/lib/{liblagraphx,liblagraph,libgraphblas}.so:
+ *   - matrix::init (matrix.rs:116-185): GxB_init with the caller's allocator, then LAGraph_Init; shutdown (:215-221):
+ *     LAGraph_Finalize only;
+ *   - algo.BFS (algo_procedures.rs:1060-1165): LAGraph_New over the BORROWED adjacency (:389-405), LAGr_BreadthFirstSearch_
+ *     Extended(&level, want_edges ? &parent : NULL, G, src, max_level, -1, false), GrB_Vector_nvals + GrB_Vector_extractTuples_
+ *     INT64 on the vectors (:431-447), GrB_Vector_free, then G->A = NULL and LAGraph_Delete (:409-413);
+ *   - algo.pageRank (:718-760): GrB_Matrix_dup + GrB_Matrix_resize of the adjacency, LAGraph_New taking ownership,
+ *     LAGraph_Cached_AT + LAGraph_Cached_OutDegree, LAGr_PageRank(0.85, 1e-4, 100), GrB_Vector_extractTuples_FP64 (:415-429),
+ *     GrB_Vector_free, LAGraph_Delete (frees the duplicate);
+ *   - the error paths a caller relies on: LAGr_PageRank without the cached properties (LAGRAPH_NOT_CACHED), a source past
+ *     the end, and an algorithm outside the engine's path (GrB_NOT_IMPLEMENTED with a message).
+ * Input (text, argv[1]): n nnz, nnz "row col" pairs, then commands: "bfs <src> <max_level> <want_edges>" | "pagerank <n_resized>"
+ * | "errors".  Output: one block per command (see the printf calls); tests/test_gpu_shim.py compares with the oracle. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "lagraph_subset.h"
+
+#define OK(call)                                                                       \
+    do {                                                                               \
+        int info_ = (int)(call);                                                       \
+        if (info_ != 0) { fprintf(stderr, "%s -> %d (line %d)\n", #call, info_, __LINE__); exit(2); } \
+    } while (0)
+
+static size_t live_blocks = 0;                                /* the allocator matrix::init hands to GxB_init */
+static void* my_malloc(size_t n) { ++live_blocks; return malloc(n); }
+static void* my_calloc(size_t a, size_t b) { ++live_blocks; return calloc(a, b); }
+static void* my_realloc(void* p, size_t n) { if (!p) ++live_blocks; return realloc(p, n); }
+static void my_free(void* p) { if (p) --live_blocks; free(p); }
+
+static void run_bfs(GrB_Matrix adj, GrB_Index src, int64_t max_level, int want_edges) {
+    char msg[LAGRAPH_MSG_LEN];
+    LAGraph_Graph g = NULL;
+    GrB_Matrix borrowed = adj;                                                   /* :397 `let mut adj_mut = adj;` */
+    OK(LAGraph_New(&g, &borrowed, LAGraph_ADJACENCY_DIRECTED, msg));
+    if (!g || borrowed != NULL || g->A != adj) { fprintf(stderr, "LAGraph_New did not move the matrix into G\n"); exit(2); }
+    GrB_Vector level = NULL, parent = NULL;
+    OK(LAGr_BreadthFirstSearch_Extended(&level, want_edges ? &parent : NULL, g, src, max_level, -1, false, msg));
+    GrB_Index nvals = 0;
+    OK(GrB_Vector_nvals(&nvals, level));
+    GrB_Index* idx = malloc((nvals + 1) * sizeof(GrB_Index));
+    int64_t* val = malloc((nvals + 1) * sizeof(int64_t));
+    GrB_Index got = nvals;
+    OK(GrB_Vector_extractTuples_INT64(idx, val, &got, level));
+    printf("bfs %llu %lld %d level %llu\n", (unsigned long long)src, (long long)max_level, want_edges, (unsigned long long)got);
+    for (GrB_Index k = 0; k < got; ++k) printf("%llu %lld\n", (unsigned long long)idx[k], (long long)val[k]);
+    if (want_edges) {
+        GrB_Index pn = 0;
+        OK(GrB_Vector_nvals(&pn, parent));
+        GrB_Index* pidx = malloc((pn + 1) * sizeof(GrB_Index));
+        int64_t* pval = malloc((pn + 1) * sizeof(int64_t));
+        GrB_Index pgot = pn;
+        OK(GrB_Vector_extractTuples_INT64(pidx, pval, &pgot, parent));
+        printf("parent %llu\n", (unsigned long long)pgot);
+        for (GrB_Index k = 0; k < pgot; ++k) printf("%llu %lld\n", (unsigned long long)pidx[k], (long long)pval[k]);
+        free(pidx); free(pval);
+        OK(GrB_Vector_free(&parent));
+    }
+    free(idx); free(val);
+    OK(GrB_Vector_free(&level));
+    g->A = NULL;                                                                  /* :409-413: detach, then delete */
+    OK(LAGraph_Delete(&g, msg));
+    if (g != NULL) { fprintf(stderr, "LAGraph_Delete left the handle\n"); exit(2); }
+}
+
+static void run_pagerank(GrB_Matrix adj, GrB_Index n_resized) {
+    char msg[LAGRAPH_MSG_LEN];
+    GrB_Matrix raw = NULL;
+    OK(GrB_Matrix_dup(&raw, adj));                                                /* :720-723 */
+    OK(GrB_Matrix_resize(raw, n_resized, n_resized));
+    LAGraph_Graph g = NULL;
+    OK(LAGraph_New(&g, &raw, LAGraph_ADJACENCY_DIRECTED, msg));                   /* create_lagraph_graph: G owns the duplicate */
+    OK(LAGraph_Cached_AT(g, msg));
+    OK(LAGraph_Cached_OutDegree(g, msg));
+    if (!g->AT || !g->out_degree) { fprintf(stderr, "cached properties missing\n"); exit(2); }
+    GrB_Index deg_n = 0;
+    OK(GrB_Vector_nvals(&deg_n, g->out_degree));
+    GrB_Vector centrality = NULL;
+    int iters = 0;
+    OK(LAGr_PageRank(&centrality, &iters, g, 0.85f, 1e-4f, 100, msg));
+    GrB_Index nvals = 0;
+    OK(GrB_Vector_nvals(&nvals, centrality));
+    GrB_Index* idx = malloc((nvals + 1) * sizeof(GrB_Index));
+    double* val = malloc((nvals + 1) * sizeof(double));
+    GrB_Index got = nvals;
+    OK(GrB_Vector_extractTuples_FP64(idx, val, &got, centrality));
+    printf("pagerank %llu iters %d nvals %llu rows_with_out_edges %llu\n", (unsigned long long)n_resized, iters,
+           (unsigned long long)got, (unsigned long long)deg_n);
+    for (GrB_Index k = 0; k < got; ++k) printf("%llu %.9g\n", (unsigned long long)idx[k], val[k]);
+    free(idx); free(val);
+    OK(GrB_Vector_free(&centrality));
+    OK(LAGraph_Delete(&g, msg));
+}
+
+static void run_errors(GrB_Matrix adj, GrB_Index n) {
+    char msg[LAGRAPH_MSG_LEN];
+    LAGraph_Graph g = NULL;
+    GrB_Matrix borrowed = adj;
+    OK(LAGraph_New(&g, &borrowed, LAGraph_ADJACENCY_DIRECTED, msg));
+    GrB_Vector v = NULL, w = NULL;
+    int iters = 0;
+    int r = LAGr_PageRank(&v, &iters, g, 0.85f, 1e-4f, 100, msg);                 /* nothing cached yet */
+    printf("errors not_cached %d %d\n", r, v == NULL);
+    r = LAGr_BreadthFirstSearch_Extended(&v, &w, g, n + 5, -1, -1, false, msg);
+    printf("errors bad_source %d %d\n", r, v == NULL && w == NULL);
+    r = LAGr_ConnectedComponents(&v, g, msg);
+    printf("errors off_path %d %d %s\n", r, v == NULL, strlen(msg) ? "message" : "silent");
+    r = LAGr_BreadthFirstSearch_Extended(&v, NULL, NULL, 0, -1, -1, false, msg);
+    printf("errors null_graph %d\n", r);
+    g->A = NULL;
+    r = LAGr_BreadthFirstSearch_Extended(&v, NULL, g, 0, -1, -1, false, msg);
+    printf("errors no_matrix %d\n", r);
+    OK(LAGraph_Delete(&g, msg));
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 1;
+    FILE* f = fopen(argv[1], "r");
+    if (!f) return 1;
+    unsigned long long n = 0, nnz = 0;
+    if (fscanf(f, "%llu %llu", &n, &nnz) != 2) return 3;
+    char msg[LAGRAPH_MSG_LEN];
+    OK(GxB_init(GrB_NONBLOCKING, my_malloc, my_calloc, my_realloc, my_free));    /* matrix.rs:126-135 */
+    OK(LAGraph_Init(msg));                                                        /* matrix.rs:174-183 */
+    GrB_Index* I = malloc((nnz + 1) * sizeof(GrB_Index));
+    GrB_Index* J = malloc((nnz + 1) * sizeof(GrB_Index));
+    for (unsigned long long k = 0; k < nnz; ++k) {
+        unsigned long long i, j;
+        if (fscanf(f, "%llu %llu", &i, &j) != 2) return 3;
+        I[k] = i; J[k] = j;
+    }
+    GrB_Matrix adj = NULL;
+    OK(GrB_Matrix_new(&adj, GrB_BOOL, n, n));
+    GrB_Scalar s = NULL;
+    OK(GrB_Scalar_new(&s, GrB_BOOL));
+    OK(GrB_Scalar_setElement_BOOL(s, true));
+    OK(GxB_Matrix_build_Scalar(adj, I, J, s, nnz));
+    OK(GrB_Scalar_free(&s));
+    OK(GrB_Matrix_wait(adj, GrB_MATERIALIZE));
+    free(I); free(J);
+    char cmd[32];
+    while (fscanf(f, "%31s", cmd) == 1) {
+        if (!strcmp(cmd, "bfs")) {
+            unsigned long long src; long long max_level; int want;
+            if (fscanf(f, "%llu %lld %d", &src, &max_level, &want) != 3) return 3;
+            run_bfs(adj, src, max_level, want);
+        } else if (!strcmp(cmd, "pagerank")) {
+            unsigned long long nr;
+            if (fscanf(f, "%llu", &nr) != 1) return 3;
+            run_pagerank(adj, nr);
+        } else if (!strcmp(cmd, "errors")) {
+            run_errors(adj, n);
+        } else {
+            return 3;
+        }
+    }
+    GrB_Index still = 0;
+    OK(GrB_Matrix_nvals(&still, adj));                                            /* the borrowed adjacency survived every LAGraph_Delete */
+    printf("adjacency %llu\n", (unsigned long long)still);
+    OK(GrB_Matrix_free(&adj));
+    OK(LAGraph_Finalize(msg));                                                    /* matrix.rs:215-221 */
+    printf("allocator_blocks %llu\n", (unsigned long long)live_blocks);
+    fclose(f);
+    return 0;
+}

@@ -90,6 +90,112 @@ def test_matrix_rs_call_sequences_through_the_graphblas_abi_match_the_oracle(rep
     assert int(probes[2][1]) == -4                          # GrB_INVALID_INDEX for a row past the end
 
 
+@pytest.fixture(scope="module")
+def replay_algo_exe(tmp_path_factory):
+    from falkordb_amd import build as fb
+    fb.build_shim()
+    exe = str(tmp_path_factory.mktemp("shim") / "replay_algo_rs")
+    subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "tests", "shim"),
+                    os.path.join(ROOT, "tests", "shim", "replay_algo_rs.c"), "-o", exe, "-L" + LIBDIR, "-llagraphx", "-llagraph",
+                    "-lgraphblas", "-Wl,-rpath," + LIBDIR], check=True)                 # the three names build.rs:50-52 links
+    return exe
+
+
+def _blocks(lines):
+    """replay_algo_rs output -> list of (header words, rows of ints / floats)."""
+    out = []
+    for l in lines:
+        w = l.split()
+        if not w:
+            continue
+        if w[0][0].isalpha():
+            out.append((w, []))
+        else:
+            out[-1][1].append(w)
+    return out
+
+
+@pytest.mark.gpu
+def test_algo_rs_call_sequences_through_the_lagraph_abi_match_the_oracle(replay_algo_exe, tmp_path):
+    """algo.BFS and algo.pageRank exactly as algo_procedures.rs:1060-1165 / :718-760 issue them — LAGraph_New over a
+    borrowed adjacency, LAGr_BreadthFirstSearch_Extended, GrB_Vector_extractTuples_INT64, LAGraph_Delete; LAGraph_Cached_AT
+    + _OutDegree, LAGr_PageRank, extractTuples_FP64 — against oracle.bfs (the LAGr_BreadthFirstSearch_Extended contract,
+    pinned by tests/test_oracle_golden.py) and oracle/pagerank.py."""
+    from oracle import pagerank as opr
+    scale = 11
+    a = oracle.rmat_csr(scale)
+    n = a.nrows
+    rows, cols = a.pairs()
+    deg = np.diff(a.rowptr.astype(np.int64))
+    src = int(np.argmax(deg))
+    lone = int(np.nonzero(deg == 0)[0][0])                    # a vertex without out-edges: reaches only itself
+    cases = [(src, -1, 1), (src, 2, 0), (src, 1, 1), (lone, -1, 1), (5, 0, 0)]
+    grown = n + 7                                             # deleted ids stay as isolated vertices (:722-723)
+    inp = tmp_path / "algo.txt"
+    with open(inp, "w") as f:
+        f.write(f"{n} {len(rows)}\n")
+        for i, j in zip(rows.tolist(), cols.tolist()):
+            f.write(f"{i} {j}\n")
+        for c in cases:
+            f.write("bfs %d %d %d\n" % c)
+        f.write(f"pagerank {grown}\nerrors\n")
+        f.write("bfs %d %d %d\n" % cases[0])                  # again after the PageRank run: the borrowed matrix is intact
+    env = dict(os.environ, LD_LIBRARY_PATH=LIBDIR + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([replay_algo_exe, str(inp)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = _blocks(r.stdout.split("\n"))
+    edge_set = a.to_set()
+    bi = 0
+    for (s0, max_level, want) in cases + [cases[0]]:
+        head, body = blocks[bi]
+        bi += 1
+        assert head[:4] == ["bfs", str(s0), str(max_level), str(want)]
+        level_ref, _, _ = oracle.bfs(a, s0, max_level, True)
+        reached = np.nonzero(level_ref >= 0)[0]
+        assert int(head[5]) == len(reached)
+        got_idx = np.array([int(w[0]) for w in body], dtype=np.int64)
+        got_lvl = np.array([int(w[1]) for w in body], dtype=np.int64)
+        assert (got_idx == reached).all()                      # ascending indices, exactly the reached set
+        assert (got_lvl == level_ref[reached]).all()
+        if want:
+            head, body = blocks[bi]
+            bi += 1
+            assert head == ["parent", str(len(reached))]
+            pidx = np.array([int(w[0]) for w in body], dtype=np.int64)
+            par = np.array([int(w[1]) for w in body], dtype=np.int64)
+            assert (pidx == reached).all()
+            for v, p in zip(pidx.tolist(), par.tolist()):      # any valid BFS tree (LAGraph's parent is one of them)
+                if v == s0:
+                    assert p == s0
+                else:
+                    assert level_ref[p] == level_ref[v] - 1 and (p, v) in edge_set
+        if (s0, max_level, want) == cases[-1] and bi < len(blocks) and blocks[bi][0][0] == "pagerank":
+            head, body = blocks[bi]
+            bi += 1
+            big = oracle.build_csr(grown, grown, rows, cols)
+            ref, it_ref = opr.pagerank(big)
+            assert int(head[1]) == grown and int(head[5]) == grown         # a full vector: one score per vertex
+            assert int(head[7]) == int((deg > 0).sum())                    # out_degree stores the non-zero degrees only
+            it = int(head[3])
+            got = np.array([float(w[1]) for w in body], dtype=np.float32)
+            assert [int(w[0]) for w in body] == list(range(grown))
+            assert abs(it - it_ref) <= 1
+            if it == it_ref:
+                np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0)    # north_star: 1e-6 rel for PLUS_TIMES float semirings
+            else:
+                assert float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).sum()) <= 2e-4
+            errs = {}
+            while blocks[bi][0][0] == "errors":
+                errs[blocks[bi][0][1]] = blocks[bi][0][2:]
+                bi += 1
+            assert errs["not_cached"] == ["-1003", "1"]                    # LAGRAPH_NOT_CACHED (lagraph_bindings.rs:26)
+            assert errs["bad_source"] == ["-4", "1"]                       # GrB_INVALID_INDEX
+            assert errs["off_path"] == ["-8", "1", "message"]              # GrB_NOT_IMPLEMENTED, loudly
+            assert errs["null_graph"] == ["-2"] and errs["no_matrix"] == ["-1000"]
+    assert blocks[bi][0] == ["adjacency", str(a.nnz)]
+    assert blocks[bi + 1][0] == ["allocator_blocks", "0"]      # nothing of the caller's allocator is left behind
+
+
 def test_shim_exports_every_symbol_the_wrapper_imports():
     """Link completeness, checked mechanically: tests/golden/shim_symbols.json is GENERATED (tests/golden/
     make_shim_symbols.py, run in the build container) from the `use super::{...}` import lists of the reference's
@@ -107,3 +213,13 @@ def test_shim_exports_every_symbol_the_wrapper_imports():
         assert must in want["functions"], must               # (the generator still sees the lists it was written for)
     missing = [s for s in want["functions"] + want["globals"] if s not in have]
     assert not missing, missing
+    # the LAGraph half: every LAGraph_* / LAGr_* entry point matrix.rs and algo_procedures.rs call is defined by
+    # liblagraph.so / liblagraphx.so (split as the reference's two binding files split them), and the GraphBLAS calls
+    # algo.BFS / algo.pageRank make on top of the wrapper's own list are defined by libgraphblas.so
+    for lib, key in (("liblagraph.so", "lagraph"), ("liblagraphx.so", "lagraphx")):
+        out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(LIBDIR, lib)], capture_output=True, text=True, check=True).stdout
+        got = {l.split()[-1] for l in out.splitlines() if l.strip()}
+        assert want[key], key
+        assert not [s for s in want[key] if s not in got], (lib, [s for s in want[key] if s not in got])
+    assert "LAGr_BreadthFirstSearch_Extended" in want["lagraphx"] and "LAGr_PageRank" in want["lagraph"]
+    assert not [s for s in want["algo_bfs_pagerank_graphblas"] if s not in have]
