@@ -676,6 +676,27 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
             cs2 = (cs2 + r[1]) & 0xFFFFFFFFFFFFFFFF
         return {"lanes": lanes, "ms_per_batch": round(d / len(bl) * 1e3, 3), "TEPS": round(fl / d, 1), "batches": len(bl),
                 "checksum": f"{cs2:016x}"}
+    # wider batches: half of a :P batch's sources have no out-edges and are compacted out of the bit state, so 2048 sources
+    # fill the 128-byte rows the last hop gathers at the same rate as 64-byte ones (the reference's operator feeds <= 1024
+    # rows, batch.rs:81 — a host layer that coalesces two child batches gets this; secondary figure, same sources)
+    if not args.no_lanes_sweep and nb_all >= 4:
+        wide = [srcs[j * 2 * B:(j + 1) * 2 * B] for j in range(min(nb_all // 2, max(args.steps // 2, 2)))]
+        engine.expand_count(ctx, wide[0], *clean)
+        ctx.sync()
+        t = time.perf_counter()
+        wn = wf = 0
+        for b in wide:
+            nn, _, f = engine.expand_count(ctx, b, *clean)
+            wn += nn
+            wf += f
+        d = time.perf_counter() - t
+        ref_n = ref_f = 0                                # the same sources as 1024-row batches: rows are independent
+        for j in range(2 * len(wide)):
+            nn, _, f = engine.expand_count(ctx, srcs[j * B:(j + 1) * B], *clean)
+            ref_n += nn
+            ref_f += f
+        det["batch_2048"] = {"batches": len(wide), "ms_per_batch": round(d / len(wide) * 1e3, 3), "TEPS": round(wf / d, 1),
+                             "agrees_with_1024_row_batches": bool(wn == ref_n and wf == ref_f)}
     if not args.no_lanes_sweep:
         det["query_threads"] = [run_lanes(timed, clean, k) for k in (2, 3, 4)]
         det["query_threads_checksum_matches_timed"] = all(q["checksum"] == f"{cs:016x}" for q in det["query_threads"])
@@ -1081,6 +1102,9 @@ def main():
         first, roofline = extra
         sec["khop%d" % scale] = {"count_only_TEPS": head["count_only"]["TEPS"], "count_only_ms": head["count_only"]["ms_per_batch"],
                                  "dirty_TEPS": head["dirty"]["TEPS"], "dirty_ms": head["dirty"]["ms_per_batch"]}
+        if head.get("batch_2048"):
+            sec["khop%d" % scale].update({"b2048_TEPS": head["batch_2048"]["TEPS"], "b2048_ms": head["batch_2048"]["ms_per_batch"],
+                                          "b2048_ok": head["batch_2048"]["agrees_with_1024_row_batches"]})
         if head.get("query_threads"):                 # the timed batches again from 4 query threads (4 lanes of the one context)
             q = head["query_threads"][-1]
             sec["khop%d" % scale].update({"threads%d_TEPS" % q["lanes"]: q["TEPS"], "threads%d_ms" % q["lanes"]: q["ms_per_batch"],

@@ -54,22 +54,39 @@ static fgpu_info bp_acc_alloc(fgpu_ctx* ctx, DevBuf<u64>& acc) {
     FGPU_HIP(hipMemsetAsync(acc.p, 0, BP_ACC_WORDS * sizeof(u64), ctx->stream()));
     return FGPU_OK;
 }
-// the slots summed by one workgroup into slot 0's spare words, then both sums in ONE scalar read-back
-__global__ __launch_bounds__(256) void bp_acc_fold_kernel(unsigned long long* __restrict__ acc) {
+// the slots summed by one workgroup; thread 0 then publishes both sums into the lane's mapped line itself (ctx.hip pub_begin /
+// pub_wait) — ONE dispatch and one scalar round trip per read-back; without a mapped line the sums go to slot 0's spare words
+// and read_words fetches them
+__global__ __launch_bounds__(256) void bp_acc_fold_kernel(unsigned long long* __restrict__ acc, u32* __restrict__ pub, u32 seq) {
     __shared__ u64 s_a[4], s_b[4];
     u64 a = acc[(size_t)threadIdx.x * BP_ACC_STRIDE], b = acc[(size_t)threadIdx.x * BP_ACC_STRIDE + 1];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
     if (lane_id() == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
     __syncthreads();
-    if (threadIdx.x == 0) { acc[2] = s_a[0] + s_a[1] + s_a[2] + s_a[3]; acc[3] = s_b[0] + s_b[1] + s_b[2] + s_b[3]; }
+    if (threadIdx.x == 0) {
+        const u64 sa = s_a[0] + s_a[1] + s_a[2] + s_a[3], sb = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+        if (pub) {
+            __hip_atomic_store(pub + 0, (u32)sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub + 1, (u32)(sa >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub + 2, (u32)sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub + 3, (u32)(sb >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // after the words: release
+        } else {
+            acc[2] = sa; acc[3] = sb;
+        }
+    }
 }
 static_assert(BP_ACC_SLOTS == 256 && BP_ACC_STRIDE >= 4, "bp_acc_fold_kernel: one thread per slot, sums in words 2 and 3 of slot 0");
 static fgpu_info bp_acc_read(fgpu_ctx* ctx, u64* acc, u64* a, u64* b) {
-    hipLaunchKernelGGL(bp_acc_fold_kernel, dim3(1), dim3(256), 0, ctx->stream(), (unsigned long long*)acc);
+    u32* pub = nullptr;
+    u32 seq = 0;
+    const bool mapped = pub_begin(ctx, &pub, &seq);
+    hipLaunchKernelGGL(bp_acc_fold_kernel, dim3(1), dim3(256), 0, ctx->stream(), (unsigned long long*)acc, mapped ? pub : (u32*)nullptr, seq);
     FGPU_HIP(hipGetLastError());
     u32 w[4] = {0, 0, 0, 0};
-    FGPU_TRY(read_words(ctx, (const u32*)(acc + 2), 4, w));
+    if (mapped) FGPU_TRY(pub_wait(ctx, seq, 4, w));
+    else FGPU_TRY(read_words(ctx, (const u32*)(acc + 2), 4, w));
     if (a) *a = (u64)w[0] | ((u64)w[1] << 32);
     if (b) *b = (u64)w[2] | ((u64)w[3] << 32);
     return FGPU_OK;

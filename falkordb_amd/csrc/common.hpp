@@ -442,6 +442,12 @@ fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncol
 // read one u32 / u64 from device on the ctx stream (synchronises).
 fgpu_info read_u32(fgpu_ctx* ctx, const u32* dev, u32* host);
 fgpu_info read_words(fgpu_ctx* ctx, const u32* dev, int nwords, u32* host);   // up to 14 consecutive 32-bit words, one round trip
+// the two halves of read_words for a kernel that publishes its own result (saves the separate one-thread dispatch):
+// pub_begin hands out the lane's mapped line and the sequence number the kernel must store — the words first, then
+// `seq` into word 15 with a system-scope release — or returns false when the lane has no mapped line (use read_words then);
+// pub_wait spins until that sequence number shows and copies the words out
+bool pub_begin(fgpu_ctx* ctx, u32** dst_dev, u32* seq);
+fgpu_info pub_wait(fgpu_ctx* ctx, u32 seq, int nwords, u32* host);
 fgpu_info read_u64(fgpu_ctx* ctx, const u64* dev, u64* host);
 
 // dist.hip: frontier exchange over the context's communicator.  Rank r's `counts[r]` words live at `buf + offs[r]` on

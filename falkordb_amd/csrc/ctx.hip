@@ -37,9 +37,24 @@ fgpu_info read_words(fgpu_ctx* ctx, const u32* dev, int nwords, u32* host) {   /
         memcpy(host, l->pinned, (size_t)nwords * sizeof(u32));
         return FGPU_OK;
     }
-    const u32 seq = ++l->pub_seq ? l->pub_seq : ++l->pub_seq;   // never 0 (the line's initial content)
-    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, l->stream, dev, nwords, l->pub_dev, seq);
+    u32* dst = nullptr;
+    u32 seq = 0;
+    (void)pub_begin(ctx, &dst, &seq);
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, l->stream, dev, nwords, dst, seq);
     FGPU_HIP(hipGetLastError());
+    return pub_wait(ctx, seq, nwords, host);
+}
+
+bool pub_begin(fgpu_ctx* ctx, u32** dst_dev, u32* seq) {
+    fgpu_lane* l = ctx->lane();
+    if (!l->pub_host) return false;
+    *seq = ++l->pub_seq ? l->pub_seq : ++l->pub_seq;   // never 0 (the line's initial content)
+    *dst_dev = l->pub_dev;
+    return true;
+}
+
+fgpu_info pub_wait(fgpu_ctx* ctx, u32 seq, int nwords, u32* host) {
+    fgpu_lane* l = ctx->lane();
     volatile u32* flag = (volatile u32*)(l->pub_host + 15);
     // spin without touching the stream (a hipStreamQuery costs the next dispatch a system-scope fence); past
     // 2 ms look at the stream now and then so that a failed launch is reported instead of waited for

@@ -395,11 +395,20 @@ __global__ __launch_bounds__(256) void first_hop_copy_kernel(CsrView f, CsrView 
         if (lane == 0 && t) atomicAdd(&tnext[(wave & 63u) * 16u], (unsigned long long)t);   // 64 slots, a 128-byte line apart
     }
 }
-__global__ void first_hop_fold_kernel(unsigned long long* __restrict__ tnext) {
+// the 64 slots summed; lane 0 publishes the sum into the lane's mapped line itself when there is one (ctx.hip pub_begin)
+__global__ void first_hop_fold_kernel(unsigned long long* __restrict__ tnext, u32* __restrict__ pub, u32 seq) {
     u64 v = tnext[(size_t)threadIdx.x * 16];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    if (threadIdx.x == 0) tnext[1] = v;
+    if (threadIdx.x == 0) {
+        if (pub) {
+            __hip_atomic_store(pub + 0, (u32)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub + 1, (u32)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            tnext[1] = v;
+        }
+    }
 }
 
 // *out = F0 x m for a clean hop (no dp / dm); *T0 = its traversed edges; *Tnext (when `next` is a plain CSR) = the traversed
@@ -436,8 +445,17 @@ static fgpu_info first_hop_rows(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat
         if (hipGetLastError() != hipSuccess) i = FGPU_DEVICE;
     }
     if (i == FGPU_OK && sum_next) {
-        hipLaunchKernelGGL(first_hop_fold_kernel, dim3(1), dim3(64), 0, ctx->stream(), (unsigned long long*)tn.p);
-        i = read_u64(ctx, tn.p + 1, Tnext);
+        u32* pub = nullptr;
+        u32 seq = 0;
+        const bool mapped = pub_begin(ctx, &pub, &seq);
+        hipLaunchKernelGGL(first_hop_fold_kernel, dim3(1), dim3(64), 0, ctx->stream(), (unsigned long long*)tn.p, mapped ? pub : (u32*)nullptr, seq);
+        if (mapped) {
+            u32 w[2] = {0, 0};
+            i = hipGetLastError() == hipSuccess ? pub_wait(ctx, seq, 2, w) : FGPU_DEVICE;
+            *Tnext = (u64)w[0] | ((u64)w[1] << 32);
+        } else {
+            i = read_u64(ctx, tn.p + 1, Tnext);
+        }
         *have_next = i == FGPU_OK;
     }
     if (i != FGPU_OK) { mat_release(c); if (i == FGPU_DEVICE) set_error("first hop: device call failed"); return i; }

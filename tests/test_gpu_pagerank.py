@@ -114,6 +114,27 @@ def test_hub_rows_and_random_label_mask(ctx):
     assert (got[~active] == 0).all()
 
 
+def test_rows_of_every_length_class(ctx):
+    """Rows with 0 .. 9 in-edges from one column range, a star of 20000 in-edges into vertex 3 (thousands of entries per
+    column range: whole trips of a wavefront inside one row, folded with shuffles before the LDS add), one of 700 into
+    vertex 5 — three runs identical, both SpMV forms (the fixture)."""
+    n = 20000
+    rng = np.random.default_rng(21)
+    star = np.setdiff1d(np.arange(n), [3])
+    rows = [star, rng.choice(n, 700, replace=False), np.arange(n)]
+    cols = [np.full(len(star), 3), np.full(700, 5), (np.arange(n) + 1) % n]
+    for d in range(10):                                        # vertex 100 + d: d in-edges, all from the first range
+        rows.append(np.arange(10, 10 + d))
+        cols.append(np.full(d, 100 + d))
+    a = oracle.build_csr(n, n, np.concatenate(rows).astype(U64), np.concatenate(cols).astype(U64))
+    A = up(ctx, a)
+    ref, it_ref = opr.pagerank(a)
+    runs = [engine.pagerank(ctx, A) for _ in range(3)]
+    compare(runs[0][0], runs[0][1], ref, it_ref)
+    assert all(np.array_equal(s.view(np.uint32), runs[0][0].view(np.uint32)) and it == runs[0][1] for s, it in runs)
+    assert int(np.argmax(runs[0][0])) == 3
+
+
 def test_scores_are_reproducible_bit_for_bit(ctx):
     """Hub rows (in-degree >= 4096) included: three runs of the same call return identical bits, and the measured
     worst relative deviation from the oracle is reported (and far inside RTOL)."""
