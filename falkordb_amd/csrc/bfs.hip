@@ -423,9 +423,11 @@ __device__ __forceinline__ void queue_append(QueueCtx& qc, bool won, u32 v) {
 }
 
 __device__ __forceinline__ void note_discovery(const BfsArgs& a, QueueCtx& qc, u32 u, LevelAcc& acc) {
-    const u32 rowdeg = a.A.rowptr[u + 1] - a.A.rowptr[u];
+    // slab plans: the owner accounts the vertex's GLOBAL out-degree (a column slab of A only holds its share of the row) — ONE
+    // 4-byte read per discovery there, not the degree array on top of the row-pointer pair
+    const u32 rowdeg = a.gdeg ? a.gdeg[u] : a.A.rowptr[u + 1] - a.A.rowptr[u];
     acc.count += 1;
-    acc.mf += a.gdeg ? a.gdeg[u] : rowdeg;   // slab plans: the owner accounts the vertex's GLOBAL out-degree
+    acc.mf += rowdeg;
     // census for the NEXT launch: kept in a register and published once per workgroup at the end of the level —
     // thousands of same-address atomics or write-through stores (every discovered row >= 1024) serialise at the
     // memory side (a heavy level went from 80 to 120 us with a per-discovery atomic, to 350 us with a store)
@@ -1721,6 +1723,7 @@ struct fgpu_bfs_plan {
     u64* dist_send[2] = {nullptr, nullptr};
     u64* dist_glob = nullptr;
     u32* dist_deg = nullptr;
+    u32* own_deg = nullptr;                  // single-rank plans: out-degree of every vertex (one 4-byte read per discovery)
     bool dist_ready = false;
     std::vector<hipEvent_t> dist_ev;    // 3 per level: before the level kernel, after it, after the collective
     hipEvent_t dist_copied = nullptr;   // peer exchange: "this rank has delivered its words of the level" (kept across searches)
@@ -1746,7 +1749,7 @@ static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
     a.parent = p->want_parent ? p->parent : nullptr;
     a.ctrl = p->ctrl;
     a.nw = p->nw;
-    a.slab_mode = 0; a.slabw = p->slabw; a.slab_nxt = nullptr; a.slab_zero = nullptr; a.gdeg = nullptr;
+    a.slab_mode = 0; a.slabw = p->slabw; a.slab_nxt = nullptr; a.slab_zero = nullptr; a.gdeg = p->own_deg;
     if (p->bm_block && fused) {
         a.bm[0] = p->bm_block;
         a.bm[1] = p->bm_block + p->nw;
@@ -1797,6 +1800,7 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->slab_ring[1]);
     c->dev_free(p->slab_ring[2]);
     c->dev_free(p->dist_deg);
+    c->dev_free(p->own_deg);
     for (hipEvent_t e : p->dist_ev) (void)hipEventDestroy(e);
     if (p->dist_copied) (void)hipEventDestroy(p->dist_copied);
     if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
@@ -1902,6 +1906,12 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         if (e == hipSuccess && nranks > 1)
             e = hipMemsetAsync(p->nxt_local, 0, (size_t)p->slabw * sizeof(u64), ctx->stream());
         if (e != hipSuccess) { set_error("bfs plan setup failed: %s", hipGetErrorString(e)); i = FGPU_DEVICE; }
+    }
+    // the degree a discovery adds to the next frontier's edge count: read from a 4-byte array (measured at RMAT-26: the slab path,
+    // which always had one, ran its heavy levels faster than the row-pointer pair of the single-rank path once it stopped reading both)
+    if (i == FGPU_OK && nranks == 1) {
+        i = ctx->dev_alloc((void**)&p->own_deg, ((size_t)p->n + 1) * sizeof(u32));
+        if (i == FGPU_OK) i = fgpu_mat_row_degrees(ctx, A, p->own_deg);
     }
     if (i != FGPU_OK) { fgpu_bfs_plan_free(p); return i; }
     memset(p->h_ctrl, 0, sizeof(BfsCtrl));
