@@ -43,6 +43,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+STALLED_THREADS = []          # legs whose helper threads never came back: main() must not wait for them at exit
+
+
 def csrc_hash():
     import hashlib
     h = hashlib.sha256()
@@ -130,6 +133,25 @@ def live_pmc(args, timeout_s=420):
                          "hbm_bytes_per_dispatch": int(2 * f + w), "dispatches": nf}
     res["_seconds"] = round(time.time() - t0, 1)
     return res
+
+
+def bfs_threads_child(args, scale, threads=2, steps=128, warmup=16, timeout_s=150):
+    """The BFS leg from `threads` query threads (each its own lane and pair of plans), run in a CHILD process with a timeout:
+    host threads that spin on device flags cannot be cancelled, so a stall there must not take the bench line with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--leg", "bfs", "--no-roofline", "--scale", str(scale), "--steps", str(steps),
+           "--warmup", str(warmup), "--bfs-threads", str(threads), "--edge-factor", str(args.edge_factor)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        if r.returncode != 0:
+            return {"error": f"child exited {r.returncode}: {r.stderr[-200:]}"}
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        q = (line.get("query_threads") or [{}])[0]
+        return dict(q, single_thread_ms_in_child=line.get("ms_per_step"))
+    except subprocess.TimeoutExpired:
+        return {"error": f"child exceeded {timeout_s} s"}
+    except (OSError, ValueError, IndexError) as e:
+        return {"error": repr(e)}
 
 
 def probe_reference_libs():
@@ -698,8 +720,22 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
         det["batch_2048"] = {"batches": len(wide), "ms_per_batch": round(d / len(wide) * 1e3, 3), "TEPS": round(wf / d, 1),
                              "agrees_with_1024_row_batches": bool(wn == ref_n and wf == ref_f)}
     if not args.no_lanes_sweep:
-        det["query_threads"] = [run_lanes(timed, clean, k) for k in (2, 3, 4)]
-        det["query_threads_checksum_matches_timed"] = all(q["checksum"] == f"{cs:016x}" for q in det["query_threads"])
+        # (behind a deadline: host threads spinning on device flags cannot be cancelled — if the sweep stalls, the line is still
+        # printed and main() leaves through os._exit)
+        import threading
+        box = {}
+
+        def sweep():
+            box["q"] = [run_lanes(timed, clean, k) for k in (2, 3, 4)]
+        th = threading.Thread(target=sweep, daemon=True)
+        th.start()
+        th.join(120)
+        if th.is_alive():
+            det["query_threads_error"] = "the query-thread sweep did not finish within 120 s"
+            STALLED_THREADS.append("khop query threads")
+        else:
+            det["query_threads"] = box["q"]
+            det["query_threads_checksum_matches_timed"] = all(q["checksum"] == f"{cs:016x}" for q in det["query_threads"])
     for b in ks[:2]:
         engine.expand_count(ctx, b, *dirty)
     det["dirty"] = run(ks, dirty)
@@ -804,6 +840,55 @@ def bfs_single_leg(ctx, engine, args, scale, A=None, steps=64, warmup=8, want_pr
            "scale": scale, "vertices": int(A.nrows), "edges": int(A.nvals), "TEPS": round(tot / dt, 1), "steps": steps,
            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "build_seconds": round(t_build, 2),
            "root0": {k: st0[k] for k in ("levels", "push_levels", "pull_levels")}}
+    if getattr(args, "bfs_threads", 0) > 1:
+        # the same searches from two query threads, each with its own pair of plans on its own lane (stream): one search's
+        # light levels — a few microseconds of work under a ~10 us level floor — run under the other's heavy ones
+        import threading
+
+        def threads_run(k):
+            gate = threading.Barrier(k + 1)
+            errs = []
+
+            def work(t):
+                try:
+                    ps = [engine.BfsPlan(ctx, A, At), engine.BfsPlan(ctx, A, At)]
+                    for p_ in ps:
+                        p_.tune(alpha=args.alpha, force_direction=args.force_dir)
+
+                    def pipe(srcs):
+                        for i, src in enumerate(srcs):
+                            ps[i % 2].run_async(src, -1, False, 0)
+                            if i > 0:
+                                ps[(i - 1) % 2].wait()
+                        if srcs:
+                            ps[(len(srcs) - 1) % 2].wait()
+                    pipe([roots[i % len(roots)] for i in range(t, warmup * k, k)])
+                    ctx.sync()
+                    gate.wait()
+                    pipe([roots[i % len(roots)] for i in range(t, steps, k)])
+                    ctx.sync()
+                    gate.wait()
+                    for p_ in ps:
+                        p_.free()
+                except BaseException as e:   # noqa: BLE001
+                    errs.append(repr(e))
+                    gate.abort()
+            ths = [threading.Thread(target=work, args=(t,)) for t in range(k)]
+            for th in ths:
+                th.start()
+            try:
+                gate.wait()
+                t2 = time.perf_counter()
+                gate.wait()
+                dt2 = time.perf_counter() - t2
+            except threading.BrokenBarrierError:
+                dt2 = None
+            for th in ths:
+                th.join()
+            if dt2 and not errs:
+                return {"threads": k, "ms_per_step": round(dt2 / steps * 1e3, 4), "TEPS": round(tot / dt2, 1), "steps": steps}
+            return {"threads": k, "error": errs[:1]}
+        out["query_threads"] = [threads_run(args.bfs_threads)]
     if want_prof:
         plan = plans[0]
         plan.profile(True)
@@ -975,6 +1060,10 @@ def emit(line, detail):
     txt = json.dumps(line, separators=(",", ":"))
     assert len(txt) < 4096, f"bench line is {len(txt)} bytes; the driver keeps only the tail of stdout"
     print(txt, flush=True)
+    if STALLED_THREADS:                       # threads still spinning inside the library: do not join them at interpreter exit
+        sys.stderr.write("bench.py: leaving through os._exit, stalled: %s\n" % ", ".join(STALLED_THREADS))
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def main():
@@ -996,6 +1085,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (fgpu_set_option)")
     ap.add_argument("--quick", action="store_true", help="headline + parity + CPU baseline only (no secondary legs, no PMC)")
     ap.add_argument("--khop-extra-scales", default="24,26", help="further scales of the k-hop leg (secondary)")
+    ap.add_argument("--bfs-threads", type=int, default=0, help="--leg bfs: also run the searches from this many query threads")
     ap.add_argument("--no-lanes-sweep", action="store_true", help="skip the run of the timed batches from 2 / 3 / 4 query threads")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle checks")
     ap.add_argument("--no-bfs", action="store_true", help="skip the BFS / SpMV secondary legs")
@@ -1080,6 +1170,8 @@ def main():
                         scaling="strong" if world > 1 else "weak",
                         config={"workload": d["workload"], "scale": scale, "device": info["name"]},
                         roofline=None, cpu_baseline=None)
+            if d.get("query_threads"):
+                line["query_threads"] = d["query_threads"]
             r = d.get("roofline")
             if r:
                 line["roofline"] = {"bound": "hbm", "kernel": r["kernel"], "achieved": r["achieved"], "peak": HBM_PEAK_GBS,
@@ -1199,6 +1291,11 @@ def main():
                                     "host_arrays_ms": bfs22["host_arrays"]["ms_per_step"],
                                     "cpu_TEPS": (bfs22.get("cpu_baseline") or {}).get("value"),
                                     "cpu_quartiles": (bfs22.get("cpu_baseline") or {}).get("quartiles")}
+            if not args.no_lanes_sweep:
+                q2 = bfs_threads_child(args, scale)
+                detail["bfs%d_query_threads" % scale] = q2
+                if q2.get("TEPS"):
+                    sec["bfs%d" % scale].update({"threads%d_TEPS" % q2["threads"]: q2["TEPS"], "threads%d_ms" % q2["threads"]: q2["ms_per_step"]})
         if detail.get("bfs26"):
             sec["bfs26"] = {"TEPS": detail["bfs26"]["TEPS"], "ms": detail["bfs26"]["ms_per_step"],
                             "host_arrays_ms": detail["bfs26"]["host_arrays"]["ms_per_step"]}

@@ -55,7 +55,7 @@ __device__ unsigned long long* g_bfs_dbg = nullptr;
 #define FUSED_BOUNDS __launch_bounds__(256, 6)   // the stamps must not cost the kernel a resident workgroup
 #else
 #define DBG_STAMP(k) do { } while (0)
-#define FUSED_BOUNDS __launch_bounds__(256)
+#define FUSED_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(80)))
 #endif
 struct BfsCtrl {
     i32 level;       // level of the frontier in `cur` (source = 0)
@@ -91,11 +91,15 @@ struct BfsCtrl {
     u32 q_open;        // this level appends its discoveries to queue[(rot + 1) & 1]
     u32 qmax;          // longest shard of the current queue
     u32 qchunk;        // queue entries expanded per workgroup this level (power of two, 4..1024)
-    u32 nact;          // workgroups that take part in the next fused launch (0 = the whole grid): a light queue-mode
-                       // level runs on a few dozen, the rest return at once and skip the end-of-level ticket
     u32 tick_top;
+    u32 pad_nact;
+    // low word: workgroups that take part in the next fused launch (0 = the whole grid) — a light queue-mode level runs on a
+    // few dozen, the rest return at once and skip the end-of-level ticket; high word: fused launches of this search that have
+    // run their control step.  ONE 64-bit word, stored once per control step and loaded once per workgroup: a workgroup that
+    // starts after its launch's control step (see the head of bfs_fused_kernel) must see both halves of the same step
+    unsigned long long nact_seq;
     u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
-    u32 tick_pad[31];
+    u32 tick_pad[28];
     u32 tick[64 * TICK_PAD];   // (round-2 ticket counters; the slot words carry the tickets now — kept for the layout)
 };
 
@@ -679,7 +683,8 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
                            u64* __restrict__ nxt, i32 newlevel, QueueCtx& qc, LevelAcc& acc) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const u32 nwaves = (gridDim.x * 256) >> 6;
+    const u32 grid = gridDim.x & ~1u;   // (the low bit of the grid size is the launch's parity, see bfs_fused_kernel)
+    const u32 nwaves = (grid * 256) >> 6;
     // a slab plan only owns (and only holds in-edges of) the destinations [lo, hi): words [lo/64, hi/64)
     const u32 nwords_all = (a.n + 63) >> 6;
     const u32 w_lo = a.slab_mode ? (a.lo >> 6) : 0u;
@@ -879,7 +884,7 @@ __device__ void pull_fused(const BfsArgs& a, const u64* __restrict__ frontier, u
         __shared__ u32 s_skip;
         u32* __restrict__ vis32 = (u32*)visited;
         u32* __restrict__ nxt32 = (u32*)nxt;
-        for (u32 h = blockIdx.x; h < a.n_hubAt; h += gridDim.x) {
+        for (u32 h = blockIdx.x; h < a.n_hubAt; h += grid) {
             const u32 row = a.hubAt[3 * h], b = a.hubAt[3 * h + 1], e2 = a.hubAt[3 * h + 2];
             // visited may change under us (other waves publish): one thread samples it for the block
             if (threadIdx.x == 0) {
@@ -1073,7 +1078,10 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
         const u64 items = (u64)QSHARDS * ((qmx + qchunk - 1) / qchunk) + v1 / PUSH_HUB_CHUNK + 1;
         na = items * 2 < 64 ? 64u : (items * 2 > 60000ull ? 0u : (u32)(items * 2));
     }
-    c->nact = na;
+    {   // (the tiny kernel's control steps — nwg == 0 — are not fused launches: the count stays)
+        const unsigned long long seq = (__hip_atomic_load(&c->nact_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + (nwg ? 1ull : 0ull);
+        __hip_atomic_store(&c->nact_seq, (seq << 32) | (unsigned long long)na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     c->tiny = (!done && nd == 1 && use_queue && v1 <= TINY_EDGES && v0 <= TINY_VERTS) ? 1u : 0u;
     c->zr_dirty = 1;   // bfs_tiny_kernel resets it after its own levels
 }
@@ -1086,8 +1094,23 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
     if (c->done) return;
     // a light level (queue-mode push over a few thousand edges) is run by c->nact workgroups only: the end-of-level
     // ticket costs ~9 us with 7 workgroups per CU arriving and < 1 us with a few dozen (tools/micro/levelfloor.hip)
-    u32 nwg = c->nact;
-    if (nwg == 0 || nwg > gridDim.x) nwg = gridDim.x;
+    // ... which means the control step can run while workgroups of this launch that take no part have not STARTED yet (other
+    // streams' kernels hold the CUs: three query threads driving plans at once).  Such a latecomer would read the NEXT level's
+    // nact / rot / direction, take itself for a participant of it and add to slots and tickets the next launch counts on —
+    // that launch's last workgroup then waits for arrivals for ever (tools/experiments/bfs_threads_hang.py).  So launch k of a
+    // search is made with grid size G | (k & 1) — G even, the workgroup past it leaves at once: the launch number's parity at
+    // no cost in arguments or registers (79 VGPRs / 100 SGPRs: one more of either costs the kernel a resident workgroup; two
+    // instantiations taking turns cost 0.5 us per level in instruction fetch) — and the control step publishes (launches done,
+    // nact) as one word: a workgroup whose parity is no longer current has nothing to do.  The next launch cannot start before
+    // every workgroup of this one has left, so one bit is enough.  Slab plans run the whole grid on every level: no latecomers.
+    // (a plain load: it rides with the other control words in the scalar loads below.  Whichever version a latecomer gets —
+    // a line its CU cached when the launch began, or the control step's new word — both halves are of ONE step.)
+    const unsigned long long ns = c->nact_seq;
+    const u32 grid = gridDim.x & ~1u;
+    if (a.slab_mode == 0 && ((((u32)(ns >> 32)) ^ gridDim.x) & 1u)) return;
+    if (blockIdx.x >= grid) return;
+    u32 nwg = (u32)ns;
+    if (nwg == 0 || nwg > grid) nwg = grid;
     if (blockIdx.x >= nwg) return;
     const u32 rot = c->rot;
     const bool slab = a.slab_mode != 0;
@@ -1500,7 +1523,7 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     c->q_open = ((nd == 1 ? mf : (u64)a.n) <= QGATE) ? 1u : 0u;
     {   // level 1 expands one vertex: a few dozen workgroups unless it is a hub
         const u64 items = (u64)QSHARDS + mf / PUSH_HUB_CHUNK + 1;
-        c->nact = (nd != 1) ? 0u : (items * 2 < 64 ? 64u : (items * 2 > 60000ull ? 0u : (u32)(items * 2)));
+        c->nact_seq = (nd != 1) ? 0ull : (items * 2 < 64 ? 64ull : (items * 2 > 60000ull ? 0ull : (items * 2)));   // (launches done: 0)
     }
     c->tiny = (nd == 1 && max_level != 0 && mf <= TINY_EDGES) ? 1u : 0u;   // zr_dirty = tiny_levels = 0 (cleared above)
 }
@@ -1545,7 +1568,7 @@ __global__ __launch_bounds__(256) void bfs_slab_begin_kernel(BfsArgs a, u64* sen
     if (max_level == 0 && a.host_done)
         __hip_atomic_store(a.host_done, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     c->direction = (force_dir == 2 && has_at) ? 2 : 1;   // a one-vertex frontier is pushed
-    c->nact = 0;   // slab plans always run the whole grid (the frontier is global, there is no queue)
+    c->nact_seq = 0;   // slab plans always run the whole grid (the frontier is global, there is no queue)
 }
 
 // level[v] = -1 wherever the search did not reach v (fused single-rank path, see bfs_fused_begin_kernel)
@@ -1723,6 +1746,7 @@ struct fgpu_bfs_plan {
     u64* dist_send[2] = {nullptr, nullptr};
     u64* dist_glob = nullptr;
     u32* dist_deg = nullptr;
+    u32 fused_idx = 0;                       // fused launches enqueued since fused_begin: launch k runs the instantiation of parity k & 1
     u32* own_deg = nullptr;                  // single-rank plans: out-degree of every vertex (one 4-byte read per discovery)
     bool dist_ready = false;
     std::vector<hipEvent_t> dist_ev;    // 3 per level: before the level kernel, after it, after the collective
@@ -1803,8 +1827,8 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->own_deg);
     for (hipEvent_t e : p->dist_ev) (void)hipEventDestroy(e);
     if (p->dist_copied) (void)hipEventDestroy(p->dist_copied);
-    if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
-    if (p->h_done) (void)hipHostFree(p->h_done);
+    c->flag_release(p->h_ctrl);   // (pooled: a plan never calls hipHostFree, see fgpu_ctx::flag_alloc)
+    c->flag_release(p->h_done);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -1894,12 +1918,12 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         }
     } while (0);
     if (i == FGPU_OK) {
-        hipError_t e = hipHostMalloc((void**)&p->h_ctrl, sizeof(BfsCtrl), hipHostMallocDefault);
-        if (e == hipSuccess) {
-            e = hipHostMalloc((void**)&p->h_done, 64, hipHostMallocMapped);
-            if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->d_done, p->h_done, 0);
-            if (e == hipSuccess) *(volatile u32*)p->h_done = 0;
-        }
+        static_assert(sizeof(BfsCtrl) <= 32768, "a plan's control block copy lives in one flag_alloc block");
+        p->h_ctrl = (BfsCtrl*)ctx->flag_alloc();
+        p->h_done = (u32*)ctx->flag_alloc();
+        hipError_t e = (p->h_ctrl && p->h_done) ? hipSuccess : hipErrorOutOfMemory;
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&p->d_done, p->h_done, 0);
+        if (e == hipSuccess) *(volatile u32*)p->h_done = 0;
         if (e == hipSuccess) e = hipEventCreate(&p->ev0);
         if (e == hipSuccess) e = hipEventCreate(&p->ev1);
         if (e == hipSuccess) e = hipMemsetAsync(p->nxt_global, 0, wb, ctx->stream());
@@ -1928,7 +1952,8 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         // SGPR count (MI355X_MICROARCH.md "Residency"), a grid just above that runs a near-empty second round
         u64 fg = (u64)ctx->cus * (u64)ctx->opt.bfs_wgs_per_cu;
         if (fg > g) fg = g;
-        p->fgrid = (u32)fg;
+        p->fgrid = (u32)fg & ~1u;                     // even: the low bit of a launch's grid size is its parity
+        if (p->fgrid == 0) p->fgrid = 2;
         if (getenv("FGPU_BFS_OCC")) {
             int nb0 = 0, nb1 = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, bfs_fused_kernel<false, 0>, 256, 0);
@@ -2378,6 +2403,7 @@ static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) 
     BfsArgs a = make_args(p, true);
     *(volatile u32*)p->h_done = 0;
     p->enqueued = 0;
+    p->fused_idx = 0;
     p->levels_masked = false;
     p->mask_visited = p->bm_block + 3 * (size_t)p->nw;
     hipLaunchKernelGGL(bfs_fused_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), a, (u32)src, ml,
@@ -2398,10 +2424,11 @@ static fgpu_info tiny_levels(fgpu_bfs_plan* p) {
 
 static fgpu_info fused_level(fgpu_bfs_plan* p) {
     BfsArgs a = make_args(p, true);
+    const u32 grid = p->fgrid | (p->fused_idx++ & 1u);   // launch k carries its parity in the grid size (see the head of bfs_fused_kernel)
     if (p->want_parent)
-        hipLaunchKernelGGL((bfs_fused_kernel<true, 0>), dim3(p->fgrid), dim3(256), 0, p->ctx->stream(), a);
+        hipLaunchKernelGGL((bfs_fused_kernel<true, 0>), dim3(grid), dim3(256), 0, p->ctx->stream(), a);
     else
-        hipLaunchKernelGGL((bfs_fused_kernel<false, 0>), dim3(p->fgrid), dim3(256), 0, p->ctx->stream(), a);
+        hipLaunchKernelGGL((bfs_fused_kernel<false, 0>), dim3(grid), dim3(256), 0, p->ctx->stream(), a);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
@@ -2460,19 +2487,20 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     const u64 nf = p->h_ctrl->n_frontier, reached0 = p->h_ctrl->reached;
     float ms = 0;
     BfsArgs a = make_args(p, true);
+    const u32 pgrid = p->fgrid | (p->fused_idx++ & 1u);
     FGPU_HIP(hipEventRecord(p->ev0, ctx->stream()));
     // The events bracket the SAME instantiation the blind (timed) level loop launches, <.., 0>; only under
     // "bfs_prof_split" (rocprofv3 PMC passes, which can tell launches apart by kernel name alone) does the pass
     // launch the <.., 1> / <.., 2> twins that name a launch push / pull.
     const int hint = ctx->opt.bfs_prof_split ? dir : 0;
     if (p->want_parent) {
-        if (hint == 1) hipLaunchKernelGGL((bfs_fused_kernel<true, 1>), dim3(p->fgrid), dim3(256), 0, ctx->stream(), a);
-        else if (hint == 2) hipLaunchKernelGGL((bfs_fused_kernel<true, 2>), dim3(p->fgrid), dim3(256), 0, ctx->stream(), a);
-        else hipLaunchKernelGGL((bfs_fused_kernel<true, 0>), dim3(p->fgrid), dim3(256), 0, ctx->stream(), a);
+        if (hint == 1) hipLaunchKernelGGL((bfs_fused_kernel<true, 1>), dim3(pgrid), dim3(256), 0, ctx->stream(), a);
+        else if (hint == 2) hipLaunchKernelGGL((bfs_fused_kernel<true, 2>), dim3(pgrid), dim3(256), 0, ctx->stream(), a);
+        else hipLaunchKernelGGL((bfs_fused_kernel<true, 0>), dim3(pgrid), dim3(256), 0, ctx->stream(), a);
     } else {
-        if (hint == 1) hipLaunchKernelGGL((bfs_fused_kernel<false, 1>), dim3(p->fgrid), dim3(256), 0, ctx->stream(), a);
-        else if (hint == 2) hipLaunchKernelGGL((bfs_fused_kernel<false, 2>), dim3(p->fgrid), dim3(256), 0, ctx->stream(), a);
-        else hipLaunchKernelGGL((bfs_fused_kernel<false, 0>), dim3(p->fgrid), dim3(256), 0, ctx->stream(), a);
+        if (hint == 1) hipLaunchKernelGGL((bfs_fused_kernel<false, 1>), dim3(pgrid), dim3(256), 0, ctx->stream(), a);
+        else if (hint == 2) hipLaunchKernelGGL((bfs_fused_kernel<false, 2>), dim3(pgrid), dim3(256), 0, ctx->stream(), a);
+        else hipLaunchKernelGGL((bfs_fused_kernel<false, 0>), dim3(pgrid), dim3(256), 0, ctx->stream(), a);
     }
     FGPU_HIP(hipEventRecord(p->ev1, ctx->stream()));
     FGPU_HIP(hipEventSynchronize(p->ev1));

@@ -151,6 +151,8 @@ struct fgpu_ctx {
     std::multimap<size_t, void*> pin_pool;
     std::map<const void*, size_t> pin_live;   // block start -> capacity, for every block handed out
     uint64_t pin_pooled = 0;
+    std::vector<void*> flag_free_list;        // 32 KiB pinned blocks for control words (flag_alloc), kept until fgpu_finalize
+    std::vector<void*> flag_all;
     // multi-GPU: this context's rank in an RCCL communicator (dist.hip); nullptr = not part of one
     void* comm = nullptr;               // ncclComm_t
     int comm_rank = 0, comm_nranks = 1;
@@ -192,6 +194,12 @@ struct fgpu_ctx {
     void* result_alloc(size_t bytes);   // result arrays: pinned pool from 256 KiB up, host_alloc below
     void* pinned_alloc(size_t bytes);   // a block of the pinned pool (nullptr: out of memory)
     void host_free(void* p);            // releases either kind
+    // a 32 KiB block of pinned host memory for control words a device writes and a host thread polls (a search plan's done
+    // flag, its control block copy).  Pooled for the life of the context: hipHostMalloc / hipHostFree synchronise the whole
+    // device inside the runtime, and a thread sitting in one while another thread polls its stream (hipStreamQuery) is how
+    // three query threads driving BFS plans stopped (tools/experiments/bfs_threads_hang.py) — so no plan frees host memory
+    void* flag_alloc();
+    void flag_release(void* p);
     void trim();
 };
 

@@ -548,6 +548,31 @@ void* fgpu_ctx::host_alloc(size_t bytes) {
     return mal ? mal(bytes) : malloc(bytes);
 }
 
+constexpr size_t FLAG_BLOCK = 32768;
+void* fgpu_ctx::flag_alloc() {
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (!flag_free_list.empty()) {
+            void* p = flag_free_list.back();
+            flag_free_list.pop_back();
+            memset(p, 0, FLAG_BLOCK);
+            return p;
+        }
+    }
+    (void)lane();                                            // (device current)
+    void* p = nullptr;
+    if (hipHostMalloc(&p, FLAG_BLOCK, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    memset(p, 0, FLAG_BLOCK);
+    std::lock_guard<std::mutex> g(mu);
+    flag_all.push_back(p);
+    return p;
+}
+void fgpu_ctx::flag_release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu);
+    flag_free_list.push_back(p);
+}
+
 void* fgpu_ctx::pinned_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
     // capacity classes: eighths of a power of two (<= 12.5 % slack), so that results of similar size share blocks
@@ -678,6 +703,8 @@ fgpu_info fgpu_finalize(fgpu_ctx* ctx) {
     // live blocks still owned by un-freed matrices are released here too
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     ctx->live.clear();
+    for (void* q : ctx->flag_all) (void)hipHostFree(q);
+    ctx->flag_all.clear(); ctx->flag_free_list.clear();
     for (auto& kv : ctx->pin_pool) (void)hipHostFree(kv.second);
     for (auto& kv : ctx->pin_live) (void)hipHostFree(const_cast<void*>(kv.first));   // result arrays the caller never freed
     ctx->pin_pool.clear(); ctx->pin_live.clear();

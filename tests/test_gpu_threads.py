@@ -181,3 +181,34 @@ def test_threads_come_and_go(ctx):
         run_threads(worker, 6)
     in_use, pooled = ctx.device_bytes()
     assert in_use > 0
+
+
+@pytest.mark.timeout(180)
+def test_search_plans_driven_from_many_threads_at_once(ctx):
+    """Six query threads, each pipelining searches over its own pair of plans (run_async / wait, the bench's pattern) on one
+    shared graph.  With the CUs shared between streams a light level's control step can run before workgroups of the same
+    launch that take no part have started; such a latecomer used to join the NEXT level and strand its ticket (three threads
+    stalled for ever — tools/experiments/bfs_threads_hang.py).  Every search must finish and equal the oracle."""
+    a = oracle.rmat_csr(18)
+    A = up(ctx, a)
+    At = A.transpose()
+    deg = np.diff(a.rowptr)
+    roots = [int(r) for r in np.nonzero(deg > 0)[0][:12]]
+    ref = {r: oracle.bfs(a, r, -1)[0] for r in roots}
+
+    def worker(t):
+        plans = [engine.BfsPlan(ctx, A, At), engine.BfsPlan(ctx, A, At)]
+        mine = [roots[(t + i) % len(roots)] for i in range(40)]
+        for i, r in enumerate(mine):
+            plans[i % 2].run_async(r, -1, False, 0)
+            if i > 0:
+                plans[(i - 1) % 2].wait()
+                if i % 7 == 0:                                   # (fetching costs a 1 MB copy: a sample, and the last two below)
+                    assert np.array_equal(plans[(i - 1) % 2].fetch()[0], ref[mine[i - 1]]), ("search", t, i - 1)
+        plans[(len(mine) - 1) % 2].wait()
+        assert np.array_equal(plans[(len(mine) - 1) % 2].fetch()[0], ref[mine[-1]]), ("last search", t)
+        assert np.array_equal(plans[(len(mine) - 2) % 2].fetch()[0], ref[mine[-2]]), ("last but one", t)
+        for p in plans:
+            p.free()
+
+    run_threads(worker, 6)
