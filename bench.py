@@ -135,7 +135,7 @@ def live_pmc(args, timeout_s=420):
     return res
 
 
-def bfs_threads_child(args, scale, threads=2, steps=128, warmup=16, timeout_s=150):
+def bfs_threads_child(args, scale, threads=3, steps=128, warmup=16, timeout_s=150):
     """The BFS leg from `threads` query threads (each its own lane and pair of plans), run in a CHILD process with a timeout:
     host threads that spin on device flags cannot be cancelled, so a stall there must not take the bench line with it."""
     import subprocess

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $root
 run() {  # name, bench args...
   name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name -o t -- python bench.py --no-cpu-baseline --no-parity --no-pmc "$@" > $out/$name.out 2> $out/$name.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name -o t -- python bench.py --no-cpu-baseline --no-parity --no-pmc --no-lanes-sweep "$@" > $out/$name.out 2> $out/$name.err
   cp $out/$name/*/t_kernel_stats.csv $out/${name}_kernel_stats.csv 2>/dev/null || cp $out/$name/t_kernel_stats.csv $out/${name}_kernel_stats.csv
   tail -1 $out/$name.out | cut -c1-400
   head -6 $out/${name}_kernel_stats.csv | cut -c1-160
