@@ -205,6 +205,22 @@ def test_khop_rmat22_headline_batch_matches_the_oracle(ctx, rmat22_bench, mode, 
     assert ref[0] > 300_000_000
 
 
+def test_khop_rmat22_2048_source_batch_matches_the_oracle(ctx, bench_graphs):
+    """bench.py's secondary figure `b2048`: 2048 :P sources per call (about 1000 of them live: the compacted bit state fills
+    the 128-byte rows) — (nnz, checksum, flops) and the per-hop sizes against the oracle's chain over the same 2048 rows,
+    and 3000 sources (rows wider than one 128-byte block) likewise."""
+    A22, _, a22 = bench_graphs(22)
+    a18 = oracle.rmat_csr(18)
+    A18 = ctx.mat_from_csr(a18.nrows, a18.ncols, a18.rowptr, a18.colidx)
+    for A, a, count in ((A22, a22, 2048), (A18, a18, 3000)):    # (the oracle's chain over 3000 rows of RMAT-22 is half a minute)
+        src = p_sources(A.nrows, count)
+        ref = oracle.expand_summary_omp(src, [(a, None, None)] * 3)
+        got = engine.expand_count(ctx, src, [A] * 3)
+        lv = engine.expand_levels(ctx, src, [A] * 3)
+        assert got == ref[:3], (count, got, ref[:3])
+        assert list(lv["hop_nnz"]) == ref[3] and lv["flops"] == ref[2]
+
+
 @pytest.mark.parametrize("dirty", [False, True])
 def test_khop_rmat26_batch_rows_match_the_oracle(ctx, rmat26_bench, dirty):
     """The metric's other scale (RMAT-26, 1.06 G edges): the first 128 rows of batch 0 (the oracle's chain for 1024 rows
