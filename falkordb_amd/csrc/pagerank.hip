@@ -234,19 +234,22 @@ __global__ __launch_bounds__(256) void pr_hub_finish_kernel(const u32* __restric
     if (threadIdx.x == 0) part[0] = tot;
 }
 
-// ---- the SpMV by column ranges, one per XCD (round 4) ------------------------------------------------------------------------
+// ---- the SpMV by column ranges, each cached by its own XCDs (round 4) ----------------------------------------------------------
 // What bounds the pull is the random 4-byte gather of w[col]: 65 M of them per iteration at RMAT-22 from a 16 MB vector that
 // every XCD's 4 MiB L2 caches a different quarter of — ~80-100 G gathers/s.  Workgroups are dealt to the XCDs round-robin, and
 // the same gathers run at ~255 G/s when workgroup b only touches column range b mod 8 (tools/micro/xcdgather.hip: a 16.8 MB
-// table, 2.1 MB per range — up to 4 MB per range at that rate, 8 MB at half of it).  So A' is split ONCE per snapshot into 8
-// matrices by column range (rows keep their order inside a range: a row's entries are sorted, a range is a contiguous piece),
+// table, 2.1 MB per range — up to 4 MB per range at that rate, 8 MB at half of it).  So A' is split ONCE per snapshot into
+// PR_NPARTS matrices by column range (rows keep their order inside a range: a row's entries are sorted, a range is a contiguous
+// piece) — FOUR ranges, range k on XCDs k and k + 4: at RMAT-22 a quarter of w is the 4 MB one L2 still gathers at full rate,
+// and half the partial sums and offsets of eight ranges (SpMV 0.456 -> 0.443 ms, the combine 0.066 -> 0.039; RMAT-24 equal) —
 // stored range-major with one row-pointer array per range; per iteration workgroup (k, block) sums range k's entries of a block
 // of PR_RB rows into FP64 accumulators in LDS — entry-parallel, the row of an entry by a search over the block's offsets in LDS;
 // a wavefront whose 64 entries share one row (a hub row) adds them up with shuffles first — and stores the block's partial sums;
-// a second kernel adds the 8 partials of a row in range order, rounds to FP32 once, and accounts |t - r|.  No hub list, no
+// a second kernel adds the partials of a row in range order, rounds to FP32 once, and accounts |t - r|.  No hub list, no
 // hub passes.  (FP64 sums of FP32 terms: as before they are exact unless a row's terms span more than 2^29, so the order in which
 // a range's terms meet does not show; across ranges the order is fixed.)
-constexpr u32 PR_NPARTS = 8;
+constexpr u32 PR_NPARTS = 4;      // a power of two that divides 8 (the XCDs)
+constexpr u32 PR_PSHIFT = 2;      // log2(PR_NPARTS)
 constexpr u32 PR_RB = 1024;       // rows per workgroup block
 struct PrParts {
     u32* prp = nullptr;            // PR_NPARTS x (n + 1) offsets into pcol, range-major
@@ -334,14 +337,15 @@ static fgpu_info pr_parts_build(fgpu_ctx* ctx, const fgpu_mat* At, const PrParts
     return FGPU_OK;
 }
 
-// workgroup j: range k = j & 7 (dealt to XCD k), row block j >> 3.  part[k][v] = sum over range k's entries of row v of w[col].
+// workgroup j: range k = j mod PR_NPARTS (dealt to XCDs k and k + 4), row block j / PR_NPARTS.  part[k][v] = sum over range k's
+// entries of row v of w[col].
 __global__ __launch_bounds__(256) void pr_part_spmv_kernel(const u32* __restrict__ prp, const u32* __restrict__ pcol, u32 n,
                                                           const float* __restrict__ w, double* __restrict__ part,
                                                           const int* __restrict__ stop) {
     __shared__ u32 s_off[PR_RB + 1];
     __shared__ double s_acc[PR_RB];
     if (*stop) return;
-    const u32 k = blockIdx.x & 7u, blk = blockIdx.x >> 3;
+    const u32 k = blockIdx.x & (PR_NPARTS - 1u), blk = blockIdx.x >> PR_PSHIFT;
     const u32 v0 = blk * PR_RB;
     const u32 rows = n - v0 < PR_RB ? n - v0 : PR_RB;
     const u32* __restrict__ rp = prp + (size_t)k * (n + 1) + v0;
