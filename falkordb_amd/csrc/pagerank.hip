@@ -393,25 +393,52 @@ __global__ __launch_bounds__(256) void pr_part_spmv_kernel(const u32* __restrict
     for (u32 i = threadIdx.x; i < rows; i += 256) __builtin_nontemporal_store(s_acc[i], &dst[i]);
 }
 
-// r[v] = teleport + the 8 range partials in range order; |t - r| partials per workgroup
+// r[v] = teleport + the range partials in range order; |t - r| partials per workgroup.  The same pass prepares the NEXT
+// iteration — w = r ./ d and the workgroup's share of the sink mass (what pr_prep_kernel does from t) — so an iteration of the
+// range form is three launches (SpMV, this, one reduction of both partial arrays) instead of five.
 __global__ __launch_bounds__(256) void pr_part_combine_kernel(const double* __restrict__ part, const u64* __restrict__ act, u32 n,
                                                              const float* __restrict__ tele, const float* __restrict__ t,
-                                                             float* __restrict__ r, double* __restrict__ dpart,
+                                                             const float* __restrict__ d, const unsigned char* __restrict__ sink,
+                                                             float* __restrict__ r, float* __restrict__ w,
+                                                             double* __restrict__ dpart, double* __restrict__ spart,
                                                              const int* __restrict__ stop) {
     __shared__ double s_red[4];
     if (*stop) return;
     const float tp = tele[0];
-    double diff = 0.0;
+    double diff = 0.0, rs = 0.0;
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) {
         double s = 0.0;
 #pragma unroll
         for (u32 p = 0; p < PR_NPARTS; ++p) s += part[(size_t)p * n + v];
-        const float rv = pr_active(act, v) ? (float)((double)tp + s) : 0.0f;
+        const bool on = pr_active(act, v);
+        const float rv = on ? (float)((double)tp + s) : 0.0f;
         r[v] = rv;
         diff += fabs((double)t[v] - (double)rv);
+        w[v] = on ? rv / d[v] : 0.0f;
+        rs += sink[v] ? (double)rv : 0.0;
     }
     const double tot = block_sum_256(diff, s_red);
-    if (threadIdx.x == 0) dpart[blockIdx.x] = tot;
+    const double stot = block_sum_256(rs, s_red);
+    if (threadIdx.x == 0) { dpart[blockIdx.x] = tot; spart[blockIdx.x] = stot; }
+}
+// closes an iteration of the range form: rdiff -> `stop` and the iteration count (as pr_reduce_kernel with `closing`), and the
+// next iteration's teleport from the sink mass
+__global__ __launch_bounds__(256) void pr_reduce2_kernel(const double* __restrict__ dpart, const double* __restrict__ spart, u32 np,
+                                                        float teleport0, float damp_over_n, float* __restrict__ scal,
+                                                        int* __restrict__ state, float tol) {
+    __shared__ double s_red[4];
+    if (state[0]) return;
+    double x = 0.0, y = 0.0;
+    for (u32 i = threadIdx.x; i < np; i += 256) { x += dpart[i]; y += spart[i]; }
+    const double tx = block_sum_256(x, s_red);
+    const double ty = block_sum_256(y, s_red);
+    if (threadIdx.x == 0) {
+        const float o = (float)(0.0 + 1.0 * tx);
+        scal[1] = o;
+        scal[0] = (float)((double)teleport0 + (double)damp_over_n * ty);
+        state[1] += 1;
+        if (!(o > tol)) state[0] = 1;
+    }
 }
 
 }  // namespace fgpu
@@ -528,31 +555,42 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
         hipEvent_t ev[6];
         float acc_ms[5] = {0, 0, 0, 0, 0};
         if (timing) for (auto& e : ev) (void)hipEventCreate(&e);
+        if (parts && itermax > 0 && !stopped) {
+            // the range form prepares iteration i + 1 inside iteration i's combine pass: only the first w / teleport come from here
+            hipLaunchKernelGGL(pr_prep_kernel, dim3(nb), dim3(256), 0, ctx->stream(), (const float*)rp,
+                               (const float*)d.p, (const unsigned char*)sink.p, (const u64*)act.p, n, w.p, part.p,
+                               (const int*)state.p);
+            hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part.p, nb,
+                               teleport0, damp_over_n, scal.p, state.p, 0, 0.0f);
+            FGPU_HIP(hipGetLastError());
+        }
         while (it < itermax && !stopped) {
             const int batch = timing ? 1 : (itermax - it < PR_BATCH ? itermax - it : PR_BATCH);
             for (int bi = 0; bi < batch; ++bi) {
                 float* tmp = tp; tp = rp; rp = tmp;   // t = old r
                 if (timing) (void)hipEventRecord(ev[0], ctx->stream());
+                if (parts) {
+                    if (timing) (void)hipEventRecord(ev[1], ctx->stream());
+                    const u32 nblk = cdiv(n, PR_RB);
+                    hipLaunchKernelGGL(pr_part_spmv_kernel, dim3(nblk * PR_NPARTS), dim3(256), 0, ctx->stream(), (const u32*)parts->prp,
+                                       (const u32*)parts->pcol, n, (const float*)w.p, ppart.p, (const int*)state.p);
+                    if (timing) (void)hipEventRecord(ev[2], ctx->stream());
+                    hipLaunchKernelGGL(pr_part_combine_kernel, dim3(cgrid), dim3(256), 0, ctx->stream(), (const double*)ppart.p,
+                                       (const u64*)act.p, n, (const float*)scal.p, (const float*)tp, (const float*)d.p,
+                                       (const unsigned char*)sink.p, rp, w.p, part2.p, part.p, (const int*)state.p);
+                    if (timing) (void)hipEventRecord(ev[3], ctx->stream());
+                    hipLaunchKernelGGL(pr_reduce2_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part2.p,
+                                       (const double*)part.p, cgrid, teleport0, damp_over_n, scal.p, state.p, tol);
+                    if (timing) (void)hipEventRecord(ev[4], ctx->stream());
+                    FGPU_HIP(hipGetLastError());
+                    continue;
+                }
                 hipLaunchKernelGGL(pr_prep_kernel, dim3(nb), dim3(256), 0, ctx->stream(), (const float*)tp,
                                    (const float*)d.p, (const unsigned char*)sink.p, (const u64*)act.p, n, w.p, part.p,
                                    (const int*)state.p);
                 hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part.p, nb,
                                    teleport0, damp_over_n, scal.p, state.p, 0, 0.0f);
                 if (timing) (void)hipEventRecord(ev[1], ctx->stream());
-                if (parts) {
-                    const u32 nblk = cdiv(n, PR_RB);
-                    hipLaunchKernelGGL(pr_part_spmv_kernel, dim3(nblk * PR_NPARTS), dim3(256), 0, ctx->stream(), (const u32*)parts->prp,
-                                       (const u32*)parts->pcol, n, (const float*)w.p, ppart.p, (const int*)state.p);
-                    if (timing) (void)hipEventRecord(ev[2], ctx->stream());
-                    hipLaunchKernelGGL(pr_part_combine_kernel, dim3(cgrid), dim3(256), 0, ctx->stream(), (const double*)ppart.p,
-                                       (const u64*)act.p, n, (const float*)scal.p, (const float*)tp, rp, part2.p, (const int*)state.p);
-                    if (timing) (void)hipEventRecord(ev[3], ctx->stream());
-                    hipLaunchKernelGGL(pr_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream(), (const double*)part2.p, cgrid,
-                                       0.0f, 1.0f, scal.p + 1, state.p, 1, tol);
-                    if (timing) (void)hipEventRecord(ev[4], ctx->stream());
-                    FGPU_HIP(hipGetLastError());
-                    continue;
-                }
                 hipLaunchKernelGGL(pr_spmv_kernel, dim3(grid), dim3(256), 0, ctx->stream(), vat, (const u64*)act.p, n,
                                    (const float*)w.p, (const float*)scal.p, (const float*)tp, rp, part2.p + 1,
                                    (const int*)state.p);
@@ -575,9 +613,13 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
                 FGPU_HIP(hipGetLastError());
             }
             int hstate[2] = {0, 0};
-            FGPU_HIP(hipMemcpyAsync(ctx->pinned(), state.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream()));
-            FGPU_HIP(hipStreamSynchronize(ctx->stream()));
-            memcpy(hstate, ctx->pinned(), sizeof(hstate));
+            if (timing) {   // (the events below must have completed)
+                FGPU_HIP(hipMemcpyAsync(ctx->pinned(), state.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream()));
+                FGPU_HIP(hipStreamSynchronize(ctx->stream()));
+                memcpy(hstate, ctx->pinned(), sizeof(hstate));
+            } else {        // one-thread publish kernel + a polled pinned line: 8 us instead of the runtime's 22 (ctx.hip read_words)
+                FGPU_TRY(read_words(ctx, (const u32*)state.p, 2, (u32*)hstate));
+            }
             stopped = hstate[0] != 0;
             it = hstate[1];
             if (timing) {
