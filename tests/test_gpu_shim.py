@@ -196,6 +196,21 @@ def test_algo_rs_call_sequences_through_the_lagraph_abi_match_the_oracle(replay_
     assert blocks[bi + 1][0] == ["allocator_blocks", "0"]      # nothing of the caller's allocator is left behind
 
 
+def test_replay_programs_link_against_the_three_libraries(tmp_path):
+    """Link completeness at LINK time, without a GPU: both replay programs — written against the transcribed bindgen
+    declarations only — link with `-z defs` semantics of an executable (every symbol they reference must be defined by
+    libgraphblas.so / liblagraph.so / liblagraphx.so), using the three library names build.rs:50-52 links."""
+    from falkordb_amd import build as fb
+    fb.build_shim()
+    for src, libs in (("replay_matrix_rs.c", ["-lgraphblas"]), ("replay_algo_rs.c", ["-llagraphx", "-llagraph", "-lgraphblas"])):
+        exe = str(tmp_path / src[:-2])
+        r = subprocess.run(["gcc", "-std=c11", "-O1", "-Wall", "-Werror=implicit-function-declaration",
+                            "-I" + os.path.join(ROOT, "tests", "shim"), os.path.join(ROOT, "tests", "shim", src), "-o", exe,
+                            "-L" + LIBDIR] + libs + ["-Wl,-rpath," + LIBDIR, "-Wl,--no-undefined"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert os.path.exists(exe)
+
+
 def test_shim_exports_every_symbol_the_wrapper_imports():
     """Link completeness, checked mechanically: tests/golden/shim_symbols.json is GENERATED (tests/golden/
     make_shim_symbols.py, run in the build container) from the `use super::{...}` import lists of the reference's
