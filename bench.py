@@ -701,6 +701,7 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
     # wider batches: half of a :P batch's sources have no out-edges and are compacted out of the bit state, so 2048 sources
     # fill the 128-byte rows the last hop gathers at the same rate as 64-byte ones (the reference's operator feeds <= 1024
     # rows, batch.rs:81 — a host layer that coalesces two child batches gets this; secondary figure, same sources)
+    wide = None
     if not args.no_lanes_sweep and nb_all >= 4:
         wide = [srcs[j * 2 * B:(j + 1) * 2 * B] for j in range(min(nb_all // 2, max(args.steps // 2, 2)))]
         engine.expand_count(ctx, wide[0], *clean)
@@ -727,6 +728,8 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
 
         def sweep():
             box["q"] = [run_lanes(timed, clean, k) for k in (2, 3, 4)]
+            if wide and len(wide) >= 4:                      # both at once: 2048-source batches from four query threads
+                box["wide4"] = run_lanes(wide, clean, 4)
         th = threading.Thread(target=sweep, daemon=True)
         th.start()
         th.join(120)
@@ -735,6 +738,8 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
             STALLED_THREADS.append("khop query threads")
         else:
             det["query_threads"] = box["q"]
+            if box.get("wide4"):
+                det["batch_2048"]["threads4"] = {k_: box["wide4"][k_] for k_ in ("ms_per_batch", "TEPS", "batches")}
             det["query_threads_checksum_matches_timed"] = all(q["checksum"] == f"{cs:016x}" for q in det["query_threads"])
     for b in ks[:2]:
         engine.expand_count(ctx, b, *dirty)
@@ -1197,6 +1202,8 @@ def main():
         if head.get("batch_2048"):
             sec["khop%d" % scale].update({"b2048_TEPS": head["batch_2048"]["TEPS"], "b2048_ms": head["batch_2048"]["ms_per_batch"],
                                           "b2048_ok": head["batch_2048"]["agrees_with_1024_row_batches"]})
+            if head["batch_2048"].get("threads4"):
+                sec["khop%d" % scale]["b2048_threads4_TEPS"] = head["batch_2048"]["threads4"]["TEPS"]
         if head.get("query_threads"):                 # the timed batches again from 4 query threads (4 lanes of the one context)
             q = head["query_threads"][-1]
             sec["khop%d" % scale].update({"threads%d_TEPS" % q["lanes"]: q["TEPS"], "threads%d_ms" % q["lanes"]: q["ms_per_batch"],
