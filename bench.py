@@ -44,6 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.m
 
 
 STALLED_THREADS = []          # legs whose helper threads never came back: main() must not wait for them at exit
+DIST_FAILED = []              # the RCCL leg raised on this rank: the other ranks may be stuck in its collectives
 
 
 def csrc_hash():
@@ -1045,6 +1046,33 @@ def bfs_dist_leg(ctx, engine, args, scale, rank, world, dev, td, torch, steps, w
     return out
 
 
+def bfs_dist_leg_guarded(ctx, engine, args, scale, rank, world, dev, td, torch, steps, warmup, deadline_s=300):
+    """bfs_dist_leg behind a deadline and a try: the RCCL exchange of this leg has never run on more than one real GPU
+    (DESIGN.md §6), and a collective that stalls — or a rank that fails while the others wait for it — must cost the line this
+    one secondary entry, not the headline.  Returns (result | None, error | None); after a stall the caller leaves through
+    os._exit once its line is out (the worker thread sits inside the library and cannot be cancelled)."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            if dev is not None and getattr(dev, "type", "") == "cuda":
+                torch.cuda.set_device(dev)               # torch's current device is per thread
+            box["d"] = bfs_dist_leg(ctx, engine, args, scale, rank, world, dev, td, torch, steps, warmup)
+        except BaseException as e:   # noqa: BLE001 — reported in the line
+            box["err"] = repr(e)[:300]
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(deadline_s)
+    if th.is_alive():
+        STALLED_THREADS.append("RCCL BFS leg")
+        return None, f"did not finish within {deadline_s} s"
+    if "err" in box:
+        DIST_FAILED.append(box["err"])
+        return None, box["err"]
+    return box["d"], None
+
+
 def emit(line, detail):
     """DETAIL line + sidecar first, the compact bench line LAST (the driver keeps the tail of stdout)."""
     try:
@@ -1166,7 +1194,12 @@ def main():
     if args.leg == "bfs":
         scale = args.scale or (26 if world > 1 else 22)
         if use_dist:
-            d = bfs_dist_leg(ctx, engine, args, scale, rank, world, dev, td, torch, args.steps, args.warmup)
+            d, derr = bfs_dist_leg_guarded(ctx, engine, args, scale, rank, world, dev, td, torch, args.steps, args.warmup)
+            if d is None:
+                if rank == 0:
+                    emit(dict(base, metric="traversed edges/sec (TEPS) on BFS (boolean vxm frontier loop), synthetic R-MAT", value=None,
+                              unit="TEPS", steps=args.steps, warmup=args.warmup, ms_per_step=None, error=derr), {"bfs": {"error": derr}})
+                os._exit(1)
         else:
             d, A, At, roots, _ = bfs_single_leg(ctx, engine, args, scale, steps=args.steps, warmup=args.warmup)
         if rank == 0:
@@ -1283,11 +1316,15 @@ def main():
     elif world > 1:
         # ---- N > 1: BASELINE config 4 as a secondary leg of the same line ---------------------------------------------
         if not args.no_bfs and not one_device:
-            d = bfs_dist_leg(ctx, engine, args, 26, rank, world, dev, td, torch, 32, 8)
-            detail["bfs26_dist"] = d
-            sec["bfs26_dist"] = {"TEPS": d["TEPS"], "ms": d["ms_per_step"], "ranks": world, "scaling": "strong",
-                                 "level_kernels_ms": d["per_search_ms"]["level_kernels"],
-                                 "frontier_exchange_ms": d["per_search_ms"]["frontier_exchange"]}
+            d, derr = bfs_dist_leg_guarded(ctx, engine, args, 26, rank, world, dev, td, torch, 32, 8)
+            if d is None:
+                detail["bfs26_dist"] = {"error": derr}
+                sec["bfs26_dist"] = {"error": derr[:160], "ranks": world}
+            else:
+                detail["bfs26_dist"] = d
+                sec["bfs26_dist"] = {"TEPS": d["TEPS"], "ms": d["ms_per_step"], "ranks": world, "scaling": "strong",
+                                     "level_kernels_ms": d["per_search_ms"]["level_kernels"],
+                                     "frontier_exchange_ms": d["per_search_ms"]["frontier_exchange"]}
     if rank == 0:
         if bfs22:
             r = bfs22.get("roofline") or {}
@@ -1335,6 +1372,9 @@ def main():
                    secondary=sec, detail="DETAIL line above / bench_detail.json")
         emit(out, detail)
     if use_dist:
+        if STALLED_THREADS or DIST_FAILED:     # other ranks may never reach the barrier (or this one left a thread behind)
+            sys.stdout.flush()
+            os._exit(0)
         td.barrier()
         td.destroy_process_group()
 
