@@ -1308,6 +1308,15 @@ def main():
                 roofline["traffic_source"] = ("live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --pmc-child` (same "
                                               "graph and kernels); FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes per launch"
                                               if "error" not in pmc else "live PMC passes failed: " + str(pmc["error"])[:120])
+            # the metric's other scale: the same passes over the RMAT-26 k-hop replay (no BFS part), hop 3's bytes per launch
+            if "khop26" in sec and "error" not in pmc:
+                import types
+                pmc26 = live_pmc(types.SimpleNamespace(scale=26, no_bfs=True), timeout_s=240)
+                detail["pmc_khop26"] = pmc26
+                e26 = pmc26.get("bp_pull_kernel<dense, count>") if isinstance(pmc26, dict) else None
+                if e26:
+                    sec["khop26"]["hop3_traffic"] = e26["hbm_bytes_per_dispatch"]
+                    sec["khop26"]["hop3_fetch_raw"] = e26["fetch_bytes_raw"]
             if bfs22 and bfs22.get("roofline"):
                 for d in bfs22["roofline"]["by_direction"]:
                     d["traffic"] = hbm(d["kernel"])
