@@ -3,6 +3,8 @@
 
 #include <atomic>
 
+#include <unordered_map>
+
 #include "host.hpp"
 
 namespace falkor {
@@ -69,8 +71,17 @@ struct Matrix::State {
     Type type;
     u64 nrows, ncols;
     std::shared_ptr<Snap> snap;
-    // pending tuples / zombies: coordinate -> value to store, or nullopt to delete (last write wins)
-    std::map<std::pair<u64, u64>, std::optional<u64>> pend;
+    // pending tuples / zombies: coordinate -> value to store, or nullopt to delete (last write wins).  Hashed, not ordered:
+    // wait() hands the tuples to fgpu_mat_from_coo, which sorts on the device, and a bulk load queues one entry per edge in
+    // three of these logs (67 M edges through ordered maps were most of a three-minute load)
+    struct CoordHash {
+        size_t operator()(const std::pair<u64, u64>& p) const noexcept {
+            u64 x = (p.first + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull ^ (p.second * 0x94D049BB133111EBull);
+            x ^= x >> 31;
+            return (size_t)(x * 0xD6E8FEB86659FD93ull);
+        }
+    };
+    std::unordered_map<std::pair<u64, u64>, std::optional<u64>, CoordHash> pend;
     // Matrix::wait's protocol (matrix.rs:781-796): `has_pending` is what concurrent READERS look at (acquire); only
     // the one that wins `lock` touches `pend` / `snap`, and it publishes the new snapshot with a release store of
     // the flag.  Writers (set / remove / build ...) hold the matrix exclusively, as `&mut self` makes them in Rust.

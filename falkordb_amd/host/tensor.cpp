@@ -2,6 +2,8 @@
 // (mirrors graph/src/graph/graphblas/tensor.rs; per-pair state diagram at tensor.rs:72-108).
 #include <algorithm>
 
+#include <unordered_map>
+
 #include "host.hpp"
 
 namespace falkor {
@@ -109,13 +111,14 @@ void Tensor::set_all_from_slices(const std::vector<u64>& srcs, const std::vector
     std::vector<u64> cur, m_vals;
     eff_get_batch(m_, dp_.layer(), dm_.layer(), srcs, dsts, present, cur, &masked, &in_dp, &in_m, &m_vals);
     constexpr size_t PROMOTED = ~(size_t)0;
-    std::map<std::pair<u64, u64>, size_t> batch;   // pair -> index of its pending inline slot, or PROMOTED
+    std::unordered_map<u64, size_t> batch;         // pair (compound key) -> index of its pending inline slot, or PROMOTED
+    batch.reserve(srcs.size());
     std::vector<u64> w_src, w_dst, w_id;
     std::vector<std::optional<u64>> w_masked;      // committed m value of pairs needing delta reconciliation
     for (size_t k = 0; k < srcs.size(); ++k) {
         const u64 s = srcs[k], d = dsts[k], id = ids[k];
         const u64 key = compound_key(s, d);
-        auto it = batch.find({s, d});
+        auto it = batch.find(key);
         if (it != batch.end()) {
             if (it->second != PROMOTED) {          // second edge of a pair new in this batch: promote in place
                 me_insert(me_, key, w_id[it->second]);
@@ -128,15 +131,15 @@ void Tensor::set_all_from_slices(const std::vector<u64>& srcs, const std::vector
         auto committed = [&]() -> std::optional<u64> { return in_m[k] ? std::optional<u64>(m_vals[k]) : std::nullopt; };
         if (present[k] && cur[k] == MULTI_EDGE) {  // already multi-edge: just add the id
             me_insert(me_, key, id);
-            batch[{s, d}] = PROMOTED;
+            batch[key] = PROMOTED;
         } else if (present[k]) {                   // present single edge: promote
             me_insert(me_, key, cur[k]);
             me_insert(me_, key, id);
-            batch[{s, d}] = PROMOTED;
+            batch[key] = PROMOTED;
             w_src.push_back(s); w_dst.push_back(d); w_id.push_back(MULTI_EDGE);
             w_masked.push_back(in_dp[k] ? committed() : std::nullopt);
         } else {                                   // first edge of the pair: inline
-            batch[{s, d}] = w_id.size();
+            batch[key] = w_id.size();
             w_src.push_back(s); w_dst.push_back(d); w_id.push_back(id);
             w_masked.push_back(masked[k] ? committed() : std::nullopt);
         }
