@@ -689,7 +689,7 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
             gate.wait()                              # one warm batch on EVERY worker thread: its lane's pools exist afterwards
             return engine.expand_count(ctx, b, *layers)
         with ThreadPoolExecutor(lanes) as ex:
-            list(ex.map(warm, bl[:lanes]))
+            list(ex.map(warm, [bl[i % len(bl)] for i in range(lanes)]))   # exactly `lanes` warm tasks: the gate waits for that many
             t = time.perf_counter()
             res = list(ex.map(lambda b: engine.expand_count(ctx, b, *layers), bl))
             d = time.perf_counter() - t
@@ -1046,6 +1046,110 @@ def bfs_dist_leg(ctx, engine, args, scale, rank, world, dev, td, torch, steps, w
     return out
 
 
+def bfs_gang_leg(engine, args, scale, ndev, torch, steps, warmup, ctx_opts, devices=None):
+    """BASELINE config 4 the other way in (dist.hip: "one process, several GPUs" — how a Redis-module process would drive a
+    node): rank 0's process opens a context on every device, each owns one column slab, and fgpu_bfs_dist_run drives the gang
+    from ONE thread with NO communicator: per level one kernel per device, then every rank's owned frontier words are stored
+    straight into every peer's bitmap over xGMI (dist_scatter_kernel, hipDeviceEnablePeerAccess) — no RCCL launch in the loop.
+    Strong scaling: the same graph as the one-rank base."""
+    t_build = time.time()
+    ctxs = [engine.Context(d) for d in (devices if devices is not None else range(ndev))]   # (tests: every rank on device 0)
+    try:
+        for c in ctxs:
+            for kv in ctx_opts:
+                k, v = kv.split("=")
+                c.set_option(k, int(v))
+        full0 = ctxs[0].mat_rmat(scale, args.edge_factor, 0x5EED1234 + scale)
+        n, nnz = full0.nrows, full0.nvals
+        roots = pick_roots(full0, 64)
+        splits = full0.balanced_splits(ndev)
+        plans, keep, slab_nnz = [], [], []
+        for r, c in enumerate(ctxs):
+            full = full0 if r == 0 else c.mat_rmat(scale, args.edge_factor, 0x5EED1234 + scale)
+            A = full.col_slab(int(splits[r]), int(min(splits[r + 1], n)))
+            full.free()
+            At = A.transpose()
+            keep += [A, At]
+            slab_nnz.append(int(A.nvals))
+            p = engine.BfsPlan(c, A, At, r, ndev, splits=splits)
+            p.tune(alpha=args.alpha, force_direction=args.force_dir)
+            plans.append(p)
+        for c in ctxs:
+            c.sync()
+        t_build = time.time() - t_build
+        edges = {}
+        for r in roots:
+            engine.bfs_dist_run(plans, r, -1, False)
+            edges[r] = sum(p.stats()["edges_traversed"] for p in plans)
+        for i in range(warmup):
+            engine.bfs_dist_run(plans, roots[i % len(roots)], -1, False)
+        for c in ctxs:
+            c.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            engine.bfs_dist_run(plans, roots[i % len(roots)], -1, False)
+        for c in ctxs:
+            c.sync()
+        dt = time.perf_counter() - t0
+        tot = sum(edges[roots[i % len(roots)]] for i in range(steps))
+        lm = cm = 0.0
+        nl = 0
+        for c in ctxs:
+            c.set_option("dist_timing", 1)
+        k = min(steps, 16)
+        per_rank = [[0.0, 0.0] for _ in plans]
+        for i in range(k):
+            engine.bfs_dist_run(plans, roots[i], -1, False)
+            for r, p in enumerate(plans):
+                a_, b_, c_ = p.dist_times()
+                per_rank[r][0] += a_; per_rank[r][1] += b_
+                if r == 0:
+                    lm += a_; cm += b_; nl += c_
+        for c in ctxs:
+            c.set_option("dist_timing", 0)
+        out = {"workload": f"RMAT scale-{scale} BFS, adjacency in {ndev} column slab(s) balanced by nnz, ONE process driving {ndev} "
+                           f"GPUs, frontier words stored into the peers' bitmaps over xGMI (no RCCL call in the level loop)",
+               "scale": scale, "vertices": int(n), "edges": int(nnz), "ranks": ndev, "TEPS": round(tot / dt, 1), "steps": steps,
+               "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "scaling": "strong", "build_seconds": round(t_build, 2),
+               "slab_nnz": slab_nnz, "levels_per_search": round(nl / max(k, 1), 2),
+               "per_search_ms": {"level_kernels": round(lm / max(k, 1), 4), "frontier_exchange": round(cm / max(k, 1), 4)},
+               "per_rank_ms_per_search": [{"rank": r, "level_kernels": round(x[0] / max(k, 1), 4),
+                                           "frontier_exchange": round(x[1] / max(k, 1), 4)} for r, x in enumerate(per_rank)]}
+        for p in plans:
+            p.free()
+        for m_ in keep:
+            m_.free()
+        return out
+    finally:
+        for c in ctxs:
+            try:
+                c.close()
+            except Exception:
+                pass
+
+
+def bfs_gang_leg_guarded(engine, args, scale, ndev, torch, steps, warmup, deadline_s=240):
+    """bfs_gang_leg behind a deadline and a try (never run on more than one real GPU: DESIGN.md §6) — it may cost the line
+    this one secondary entry, never the headline."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            box["d"] = bfs_gang_leg(engine, args, scale, ndev, torch, steps, warmup, args.opt)
+        except BaseException as e:   # noqa: BLE001 — reported in the line
+            box["err"] = repr(e)[:300]
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(deadline_s)
+    if th.is_alive():
+        STALLED_THREADS.append("peer-store BFS gang leg")
+        return None, f"did not finish within {deadline_s} s"
+    if "err" in box:
+        return None, box["err"]
+    return box["d"], None
+
+
 def bfs_dist_leg_guarded(ctx, engine, args, scale, rank, world, dev, td, torch, steps, warmup, deadline_s=300):
     """bfs_dist_leg behind a deadline and a try: the RCCL exchange of this leg has never run on more than one real GPU
     (DESIGN.md §6), and a collective that stalls — or a rank that fails while the others wait for it — must cost the line this
@@ -1139,8 +1243,18 @@ def main():
     if one_device:
         local_rank = 0
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            # `python bench.py --gpus N` from a plain shell: become the launcher — one rank per GPU under
+            # torch.distributed.run on this node, same arguments, same stdout (rank 0 prints the ONE line)
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            sys.stdout.flush()
+            os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                      "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                      "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]])
         args.gpus = world
 
     import torch
@@ -1331,9 +1445,40 @@ def main():
                 sec["bfs26_dist"] = {"error": derr[:160], "ranks": world}
             else:
                 detail["bfs26_dist"] = d
-                sec["bfs26_dist"] = {"TEPS": d["TEPS"], "ms": d["ms_per_step"], "ranks": world, "scaling": "strong",
+                sec["bfs26_dist"] = {"TEPS": d["TEPS"], "ms": d["ms_per_step"], "ranks": world, "rccl_ranks": ctx.comm_info()[1],
+                                     "scaling": "strong", "levels": d["levels_per_search"],
                                      "level_kernels_ms": d["per_search_ms"]["level_kernels"],
                                      "frontier_exchange_ms": d["per_search_ms"]["frontier_exchange"]}
+            # the same searches with ONE process driving all the GPUs and peer stores instead of RCCL calls (rank 0 only; the other
+            # ranks wait on the launcher's key-value store, not in a device-side barrier that would hold CUs of their GPUs)
+            store = None
+            try:
+                store = td.distributed_c10d._get_default_store()
+            except Exception:
+                pass
+            if rank == 0:
+                g, gerr = (None, "skipped: the RCCL leg left a stalled thread") if STALLED_THREADS else \
+                    bfs_gang_leg_guarded(engine, args, 26, world, torch, 32, 8)
+                if g is None:
+                    detail["bfs26_gang"] = {"error": gerr}
+                    sec["bfs26_gang"] = {"error": gerr[:160], "ranks": world}
+                else:
+                    detail["bfs26_gang"] = g
+                    sec["bfs26_gang"] = {"TEPS": g["TEPS"], "ms": g["ms_per_step"], "ranks": world, "scaling": "strong",
+                                         "exchange": "peer stores, one process", "levels": g["levels_per_search"],
+                                         "level_kernels_ms": g["per_search_ms"]["level_kernels"],
+                                         "frontier_exchange_ms": g["per_search_ms"]["frontier_exchange"]}
+                if store is not None:
+                    try:
+                        store.set("fgpu_gang_done", "1")
+                    except Exception:
+                        pass
+            elif store is not None:
+                try:
+                    import datetime
+                    store.wait(["fgpu_gang_done"], datetime.timedelta(seconds=300))
+                except Exception:
+                    pass
     if rank == 0:
         if bfs22:
             r = bfs22.get("roofline") or {}
@@ -1384,8 +1529,14 @@ def main():
         if STALLED_THREADS or DIST_FAILED:     # other ranks may never reach the barrier (or this one left a thread behind)
             sys.stdout.flush()
             os._exit(0)
-        td.barrier()
-        td.destroy_process_group()
+        try:
+            td.barrier()
+            td.destroy_process_group()
+        except Exception as e:   # noqa: BLE001 — a peer that left early (its own stall or failure) must not turn this rank's exit code
+            sys.stderr.write("bench.py: rank %d: closing barrier failed (%s); leaving\n" % (rank, repr(e)[:200]))
+            sys.stderr.flush()
+            sys.stdout.flush()
+            os._exit(0)
 
 
 BASELINE_METRIC = "traversed edges/sec (TEPS) on k-hop MATCH, RMAT scale-22/26; % HBM roofline"

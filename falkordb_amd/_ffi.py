@@ -43,6 +43,7 @@ SIGNATURES = {
     "fgpu_set_stream": (C.c_int32, [vp, vp]),
     "fgpu_sync": (C.c_int32, [vp]),
     "fgpu_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int64]),
+    "fgpu_get_option": (C.c_int32, [vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "fgpu_mat_build_tiles": (C.c_int32, [vp, vp, C.c_int, C.c_int, C.c_int]),
     "fgpu_mat_tiles_info": (C.c_int32, [vp, u64p]),
     "fgpu_device_info": (C.c_int32, [vp, C.c_char_p, i32p, i32p, i64p, i64p]),

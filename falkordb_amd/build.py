@@ -25,6 +25,31 @@ def _newer(a: str, b: str) -> bool:
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+def _digest(paths, extra=""):
+    """Content hash of a build step's inputs.  Staleness is decided by CONTENT, not by mtime: a snapshot copied to another box
+    (gpurun, the driver's fresh checkout) carries objects whose timestamps say nothing about the sources beside them."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(out: str, digest: str) -> bool:
+    stamp = out + ".sha"
+    if not os.path.exists(out) or not os.path.exists(stamp):
+        return True
+    with open(stamp) as f:
+        return f.read().strip() != digest
+
+
+def _stamp(out: str, digest: str) -> None:
+    with open(out + ".sha", "w") as f:
+        f.write(digest)
+
+
 def _deps() -> list[str]:
     inc = os.path.join(os.path.dirname(HERE), "include")
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [
@@ -36,12 +61,15 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     deps = _deps()
     jobs = []
+    dep_digest = _digest(deps, " ".join(FLAGS))
+    digests = {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+        digests[o] = _digest([s], dep_digest)
+        if force or _stale(o, digests[o]):
             jobs.append((s, o))
 
     def cc(job):
@@ -52,6 +80,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{r.stderr}")
+        _stamp(o, digests[o])
         return r.stderr
 
     if jobs:
@@ -61,13 +90,15 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                     print(err, file=sys.stderr)
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES
             if os.path.exists(os.path.join(CSRC, s))]
-    if force or jobs or not os.path.exists(LIB):
+    lib_digest = _digest([], "".join(digests[o] for o in sorted(digests)))
+    if force or jobs or _stale(LIB, lib_digest):
         # RCCL (the frontier exchange of the multi-GPU BFS, dist.hip) is bound with dlopen at first use, not linked:
         # a process that also hosts PyTorch must share PyTorch's copy of librccl.so.1 (see dist.hip)
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+        _stamp(LIB, lib_digest)
     return LIB
 
 
@@ -83,7 +114,8 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(HOST_DIR, f) for f in HOST_SOURCES]
     deps = srcs + [os.path.join(HOST_DIR, "host.hpp")] + [
         os.path.join(os.path.dirname(HERE), "include", f) for f in ("fgpu.h", "falkor_host.h")]
-    if not force and os.path.exists(HOST_LIB) and not any(_newer(d, HOST_LIB) for d in deps):
+    dg = _digest(deps, "host -O2")
+    if not force and not _stale(HOST_LIB, dg):
         return HOST_LIB
     cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, *srcs,
            "-L" + LIBDIR, "-lfgpu", "-Wl,-rpath,$ORIGIN"]
@@ -94,6 +126,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"host layer build failed:\n{r.stderr}")
     if verbose and r.stderr:
         print(r.stderr, file=sys.stderr)
+    _stamp(HOST_LIB, dg)
     return HOST_LIB
 
 
@@ -107,9 +140,10 @@ def build_shim(force: bool = False, verbose: bool = False) -> str:
     the reference's matrix.rs binds, for BOOL / UINT64 + ANY_PAIR, on this engine."""
     build_host(force=False, verbose=verbose)
     src = os.path.join(HERE, "shim", "graphblas_shim.cpp")
-    deps = [src, os.path.join(HOST_DIR, "host.hpp"), HOST_LIB]
+    deps = [src, os.path.join(HOST_DIR, "host.hpp"), HOST_LIB + ".sha"]
     deps.append(os.path.join(HERE, "shim", "shim_internal.hpp"))
-    if force or not os.path.exists(SHIM_LIB) or any(_newer(d, SHIM_LIB) for d in deps):
+    dg = _digest(deps, "shim -O2")
+    if force or _stale(SHIM_LIB, dg):
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", SHIM_LIB, src,
                "-L" + LIBDIR, "-lfalkor_host", "-lfgpu", "-Wl,-rpath,$ORIGIN"]
         if verbose:
@@ -117,10 +151,12 @@ def build_shim(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"graphblas shim build failed:\n{r.stderr}")
+        _stamp(SHIM_LIB, dg)
     # the LAGraph-named libraries over it (build.rs:50-52 links lagraphx, lagraph, graphblas): one source, two outputs
     lsrc = os.path.join(HERE, "shim", "lagraph_shim.cpp")
+    ldg = _digest(deps + [lsrc], "lagraph -O2 " + dg)
     for lib, defs in ((LAGRAPH_LIB, []), (LAGRAPHX_LIB, ["-DFG_LAGRAPHX"])):
-        if not force and os.path.exists(lib) and not any(_newer(d, lib) for d in deps + [lsrc, SHIM_LIB]):
+        if not force and not _stale(lib, ldg + "".join(defs)):
             continue
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", *defs, "-o", lib, lsrc,
                "-L" + LIBDIR, "-lgraphblas", "-lfalkor_host", "-lfgpu", "-Wl,-rpath,$ORIGIN"]
@@ -129,6 +165,7 @@ def build_shim(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"lagraph shim build failed:\n{r.stderr}")
+        _stamp(lib, ldg + "".join(defs))
     return SHIM_LIB
 
 

@@ -2175,7 +2175,7 @@ static fgpu_info dist_setup(fgpu_bfs_plan* const* P, int np) {
             p->slab_glob[0] = p->dist_glob;
             p->slab_glob[1] = p->dist_glob2;
         }
-    if (rccl) {
+    if (rccl || (np == 1 && P[0]->ctx->comm && P[0]->ctx->opt.dist_force_self)) {   // (second form: test-only, one rank on real RCCL)
         if (np > 1) FGPU_TRY(comm_group_begin());
         for (int k = 0; k < np; ++k) FGPU_TRY(comm_allreduce_sum_u32(P[k]->ctx, P[k]->dist_deg, P[k]->n));
         if (np > 1) FGPU_TRY(comm_group_end());

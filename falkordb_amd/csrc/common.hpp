@@ -83,6 +83,8 @@ struct fgpu_options {  // fgpu_set_option
     int dist_timing = 0;       // fgpu_bfs_dist_run records HIP events around every level kernel and exchange (fgpu_bfs_dist_times)
     int dist_collective = 0;   // frontier exchange of the in-library multi-GPU BFS: 0 grouped ncclSend/ncclRecv
                                // (all-gather-v, direct peer-to-peer over xGMI), 1 one ncclBroadcast per rank in a group
+    int dist_force_self = 0;   // TEST ONLY: a communicator of one rank still issues the grouped self send / recv, broadcast and
+                               // all-reduce of a multi-rank exchange (dist.hip) — the code path on the real librccl of a 1-GPU box
     int transpose_mode = 0;    // pattern transpose: 0 counting transpose (no sort), 1 COO rebuild through the sorter (A/B)
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
     int expand_compact = 1;    // fgpu_expand*: source rows that are empty after the CSR hops (sources without out-edges: half of an
@@ -156,6 +158,8 @@ struct fgpu_ctx {
     // multi-GPU: this context's rank in an RCCL communicator (dist.hip); nullptr = not part of one
     void* comm = nullptr;               // ncclComm_t
     int comm_rank = 0, comm_nranks = 1;
+    std::atomic<uint64_t> dist_self_calls{0};   // forced self collectives issued (dist_force_self)
+    std::atomic<uint64_t> expand_launches{0};   // kernels launched by fgpu_expand* (fgpu_get_option "expand_kernel_launches")
     // kernel profiler (measurement hook): off unless fgpu_prof_enable(ctx, 1)
     bool prof_on = false;
     std::mutex prof_mu;

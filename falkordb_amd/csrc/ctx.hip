@@ -780,6 +780,17 @@ fgpu_info fgpu_prof_read(fgpu_ctx* ctx, const char** names, double* ms, uint64_t
     return FGPU_OK;
 }
 
+fgpu_info fgpu_get_option(fgpu_ctx* ctx, const char* name, int64_t* value) {
+    FGPU_REQUIRE(ctx && name && value, FGPU_NULL_POINTER, "fgpu_get_option: NULL argument");
+    if (!strcmp(name, "dist_force_self")) *value = ctx->opt.dist_force_self;
+    else if (!strcmp(name, "dist_self_calls")) *value = (int64_t)ctx->dist_self_calls.load(std::memory_order_relaxed);
+    else if (!strcmp(name, "dist_collective")) *value = ctx->opt.dist_collective;
+    else if (!strcmp(name, "expand_kernel_launches")) *value = (int64_t)ctx->expand_launches.load(std::memory_order_relaxed);
+    else if (!strcmp(name, "expand_mode")) *value = ctx->opt.expand_mode;
+    else { set_error("fgpu_get_option: unknown name '%s'", name); return FGPU_INVALID; }
+    return FGPU_OK;
+}
+
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     FGPU_REQUIRE(ctx && name, FGPU_NULL_POINTER, "fgpu_set_option: NULL argument");
     ctx->opt_epoch.fetch_add(1, std::memory_order_relaxed);
@@ -838,6 +849,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "pinned_pool_mb")) {
         FGPU_REQUIRE(value >= 0 && value <= (1 << 20), FGPU_INVALID, "pinned_pool_mb out of range");
         ctx->opt.pinned_pool_mb = (int)value;
+    } else if (!strcmp(name, "dist_force_self")) {
+        ctx->opt.dist_force_self = value != 0;
     } else if (!strcmp(name, "dist_collective")) {
         FGPU_REQUIRE(value == 0 || value == 1, FGPU_INVALID, "dist_collective must be 0 (send/recv) or 1 (broadcasts)");
         ctx->opt.dist_collective = (int)value;

@@ -117,9 +117,33 @@ fgpu_info comm_allgatherv_u64(fgpu_ctx* ctx, const u64* send, u64* buf, const u6
         hipLaunchKernelGGL(own_words_kernel, dim3((u32)g), dim3(256), 0, st, send, buf + offs[me], counts[me]);
         FGPU_HIP(hipGetLastError());
     }
-    if (nr == 1 || !ctx->comm) return FGPU_OK;
+    // test-only (option dist_force_self): a communicator of ONE rank still issues the grouped calls of a multi-rank
+    // exchange, addressed to itself — a self ncclSend / ncclRecv pair inside ncclGroupStart / End, or (dist_collective 1)
+    // ncclBroadcast from root 0 — into a scratch buffer that then REPLACES the rank's own words: symbol binding, group
+    // nesting and stream ordering run on the real librccl of a 1-GPU box, and the search's result depends on the transfer
+    const bool self_test = nr == 1 && ctx->comm && ctx->opt.dist_force_self && counts[me];
+    if ((nr == 1 && !self_test) || !ctx->comm) return FGPU_OK;
     FGPU_RCCL_OR_FAIL(R);
     ncclComm_t comm = (ncclComm_t)ctx->comm;
+    if (self_test) {
+        DevBuf<u64> scratch;
+        FGPU_TRY(scratch.alloc(ctx, counts[me]));
+        FGPU_HIP(hipMemsetAsync(scratch.p, 0xA5, counts[me] * sizeof(u64), st));
+        FGPU_NCCL(R->GroupStart());
+        if (ctx->opt.dist_collective == 1) {
+            FGPU_NCCL(R->Broadcast((const void*)send, scratch.p, counts[me], ncclUint64, 0, comm, st));
+        } else {
+            FGPU_NCCL(R->Send(send, counts[me], ncclUint64, 0, comm, st));
+            FGPU_NCCL(R->Recv(scratch.p, counts[me], ncclUint64, 0, comm, st));
+        }
+        FGPU_NCCL(R->GroupEnd());
+        u64 g = (counts[me] + 1023) / 1024;
+        if (g > (u64)ctx->cus * 4) g = (u64)ctx->cus * 4;
+        hipLaunchKernelGGL(own_words_kernel, dim3((u32)g), dim3(256), 0, st, (const u64*)scratch.p, buf + offs[me], counts[me]);
+        FGPU_HIP(hipGetLastError());
+        ctx->dist_self_calls.fetch_add(1, std::memory_order_relaxed);
+        return FGPU_OK;
+    }
     FGPU_NCCL(R->GroupStart());
     if (ctx->opt.dist_collective == 1) {
         for (int r = 0; r < nr; ++r)
@@ -138,8 +162,9 @@ fgpu_info comm_allgatherv_u64(fgpu_ctx* ctx, const u64* send, u64* buf, const u6
 }
 
 fgpu_info comm_allreduce_sum_u32(fgpu_ctx* ctx, u32* buf, u64 n) {
-    if (ctx->comm_nranks == 1 || !ctx->comm) return FGPU_OK;
+    if ((ctx->comm_nranks == 1 && !ctx->opt.dist_force_self) || !ctx->comm) return FGPU_OK;
     FGPU_RCCL_OR_FAIL(R);
+    if (ctx->comm_nranks == 1) ctx->dist_self_calls.fetch_add(1, std::memory_order_relaxed);   // (test-only path: a sum over one rank)
     FGPU_NCCL(R->AllReduce(buf, buf, n, ncclUint32, ncclSum, (ncclComm_t)ctx->comm, ctx->stream()));
     return FGPU_OK;
 }

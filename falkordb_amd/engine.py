@@ -57,6 +57,11 @@ class Context:
     def set_option(self, name: str, value: int):
         check(self.lib.fgpu_set_option(self._h, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        v = C.c_int64(0)
+        check(self.lib.fgpu_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     # ---- multi-GPU communicator (RCCL inside libfgpu.so; dist.hip) ----
     def comm_unique_id(self) -> bytes:
         """ncclGetUniqueId: rank 0 calls it, the launcher's own channel carries the 128 bytes to the other ranks."""

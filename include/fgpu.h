@@ -107,6 +107,12 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * the push / pull twins of the level kernel so rocprofv3 can tell them apart by name), "bfs_hub_first" (1 = BFS plans
  * read the pull direction from a copy of At whose rows are reordered by descending out-degree class). */
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
+/* Read-back of measurement / test counters kept by the context (a subset of the option names plus counters that
+ * have no setter): "dist_force_self" (test-only, set through fgpu_set_option: a communicator of ONE rank still issues the
+ * grouped self ncclSend / ncclRecv, ncclBroadcast and ncclAllReduce of a multi-rank exchange — tests/test_gpu_dist.py),
+ * "dist_self_calls" (how many such calls ran), "expand_kernel_launches" (kernels launched by fgpu_expand* on this context so
+ * far: the launch count of a batch is a difference of two reads).  Unknown names return FGPU_INVALID. */
+fgpu_info fgpu_get_option(fgpu_ctx* ctx, const char* name, int64_t* value);
 /* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */
 fgpu_info fgpu_device_info(fgpu_ctx* ctx, char* name, int32_t* cus, int32_t* wave,
                            int64_t* lds_bytes, int64_t* hbm_bytes);

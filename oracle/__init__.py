@@ -34,13 +34,22 @@ _omp = None
 
 
 def build(force: bool = False) -> str:
-    stale = force
-    for src, lib_path in (("oracle.c", _LIB_PATH), ("oracle_omp.c", _OMP_PATH)):
-        s = os.path.join(_HERE, src)
-        if not os.path.exists(lib_path) or os.path.getmtime(s) > os.path.getmtime(lib_path):
-            stale = True
+    # staleness by CONTENT (a snapshot copied to another box carries libraries whose mtimes say nothing about the sources)
+    import hashlib
+    h = hashlib.sha256()
+    for src in ("oracle.c", "oracle_omp.c", "Makefile"):
+        with open(os.path.join(_HERE, src), "rb") as f:
+            h.update(f.read())
+    digest = h.hexdigest()
+    stamp = os.path.join(_HERE, "_build", "sources.sha")
+    stale = force or not (os.path.exists(_LIB_PATH) and os.path.exists(_OMP_PATH) and os.path.exists(stamp))
+    if not stale:
+        with open(stamp) as f:
+            stale = f.read().strip() != digest
     if stale:
-        subprocess.run(["make", "-C", _HERE, "all"] + (["-B"] if force else []), check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "-B", "all"], check=True, capture_output=True)
+        with open(stamp, "w") as f:
+            f.write(digest)
     return _LIB_PATH
 
 

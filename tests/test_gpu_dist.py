@@ -243,6 +243,78 @@ def test_in_library_loop_over_an_rccl_communicator_of_one(ctx):
         ctx2.close()
 
 
+def test_grouped_collectives_run_on_the_real_rccl_with_one_rank(ctx):
+    """on a 1-GPU box the real librccl had only ever seen ncclGetUniqueId / CommInitRank / CommDestroy —
+    the exchange and the degree all-reduce return early for one rank.  The test-only option `dist_force_self` keeps the calls:
+    per level a grouped self ncclSend / ncclRecv (dist_collective 0) or an ncclBroadcast from root 0 (1) into a scratch buffer
+    that REPLACES the rank's own frontier words, plus the ncclAllReduce of the degree vector at set-up — so symbol binding,
+    group nesting and stream ordering execute on real RCCL, and the levels only match the oracle if the bytes arrived."""
+    a = oracle.rmat_csr(13)
+    for coll in (0, 1):
+        ctx2 = engine.Context(0)
+        try:
+            ctx2.comm_init_rank(1, 0, ctx2.comm_unique_id())
+            ctx2.set_option("dist_force_self", 1)
+            ctx2.set_option("dist_collective", coll)
+            assert ctx2.get_option("dist_force_self") == 1 and ctx2.get_option("dist_self_calls") == 0
+            A = ctx2.mat_rmat(13)
+            plan = engine.BfsPlan(ctx2, A, A.transpose(), 0, 1, splits=A.balanced_splits(1))
+            levels = 0
+            for src in (3, int(np.argmax(np.diff(a.rowptr)))):
+                for force in (0, 1, 2):
+                    plan.tune(force_direction=force)
+                    engine.bfs_dist_run([plan], src)
+                    lv, _ = plan.fetch()
+                    ref = oracle.bfs(a, src, -1)[0]
+                    np.testing.assert_array_equal(lv[:a.nrows], ref)
+                    levels += int(ref.max())
+            calls = ctx2.get_option("dist_self_calls")
+            assert calls >= levels + 1, (calls, levels)     # one exchange per level that ran + the degree all-reduce
+            plan.free()
+            ctx2.comm_finalize()
+        finally:
+            ctx2.close()
+
+
+def test_bench_gang_leg_on_one_device():
+    """bench.py's second BFS-26 leg for N > 1 (one process driving every GPU, frontier words stored into the peers' bitmaps):
+    the leg's own code — contexts, slabs, plans, fgpu_bfs_dist_run in peer mode, the time split — on a small graph with both
+    "ranks" on the one GPU of a test box.  The BFS results of that mode are held to the oracle by
+    test_in_library_dist_loop_matches_the_oracle; here the leg must run and report consistent numbers."""
+    import types
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    args = types.SimpleNamespace(edge_factor=16, alpha=0.0, force_dir=0, opt=[])
+    g = bench.bfs_gang_leg(engine, args, 16, 2, None, 6, 2, [], devices=[0, 0])
+    assert g["ranks"] == 2 and g["TEPS"] > 0 and g["levels_per_search"] >= 2
+    assert sum(g["slab_nnz"]) == g["edges"] and len(g["per_rank_ms_per_search"]) == 2
+    a = oracle.rmat_csr(16)
+    assert g["edges"] == a.nnz and g["vertices"] == a.nrows
+
+
+def test_bench_spawns_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (it used to exit with an error):
+    bench.py re-executes itself under torch.distributed.run, one rank per GPU, and still prints ONE line.  Both ranks share
+    the one GPU of a test box (FGPU_BENCH_ONE_DEVICE, gloo for the launcher's collectives)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FGPU_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale", "18",
+           "--no-cpu-baseline", "--no-pmc", "--no-varlen"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["parity"]["ok"] is True and d["value"] > 0
+
+
 # ---- the multi-rank RCCL branch of the exchange, executed on one GPU through the loop-back library -------------------
 
 _STUB_SCRIPT = r"""
