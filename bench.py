@@ -72,6 +72,9 @@ PMC_GROUPS = (  # (reported name, regex over rocprofv3's Kernel_Name)
     ("bp_delta_kernel<dm>", r"bp_delta_kernel<true>"),
     ("bp_delta_kernel<dp>", r"bp_delta_kernel<false>"),
     ("bp_pull_groups_kernel", r"bp_pull_groups_kernel"),
+    ("xp_pull_kernel", r"xp_pull_kernel"),
+    ("xp_long_kernel", r"xp_long_kernel"),
+    ("xp_fold_kernel", r"xp_fold_kernel"),
     ("bp_rows_kernel<emit>", r"bp_rows_kernel<true>"),
     ("bp_rows_kernel<count>", r"bp_rows_kernel<false>"),
 )

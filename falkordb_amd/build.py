@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libfgpu.so")
-SOURCES = ["ctx.hip", "prims.hip", "mat.hip", "bfs.hip", "spgemm.hip", "tiled.hip", "blocked.hip", "bitexpand.hip", "merge.hip", "pagerank.hip", "transpose.hip", "dist.hip"]
+SOURCES = ["ctx.hip", "prims.hip", "mat.hip", "bfs.hip", "spgemm.hip", "tiled.hip", "blocked.hip", "bitexpand.hip", "bitpart.hip", "merge.hip", "pagerank.hip", "transpose.hip", "dist.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -17,7 +17,7 @@
 // line at W = 16) per entry: HBM-bound, independent of how many duplicates the product contains.
 // The result is converted back to the ascending (row_i, dest) CSR the operator emits
 // (cond_traverse.rs:644) by a 64×64 bit transposition per (64 vertices, word): ballot per source bit.
-#include "common.hpp"
+#include "bitexpand.hpp"
 
 namespace fgpu {
 
@@ -25,30 +25,6 @@ constexpr u32 BP_ITEM = 256;    // entries of A' per work item (the sparse pull 
 static_assert(BP_ITEM == 256, "bp_pull_kernel<.., SPARSE> unrolls an item into four 64-entry trips");
 constexpr u32 BP_VCHUNK = 4096; // vertices per emission chunk (64 blocks of 64)
 
-// Two 64-bit sums of a kernel (nnz + checksum, flops + rows) without same-address atomics: every wavefront adding into ONE
-// pair of words costs ~5.6 ns per atomic at the memory side — 65 K wavefronts ending together made a ~100 us
-// tail of the counting kernels.  A workgroup reduces its wavefronts through LDS and adds into one of BP_ACC_SLOTS pairs, a
-// 128-byte line apart (atomics to different words of one line serialise too); the host sums the slots after ONE copy.
-constexpr u32 BP_ACC_SLOTS = 256, BP_ACC_STRIDE = 16;   // stride in 64-bit words
-constexpr size_t BP_ACC_WORDS = (size_t)BP_ACC_SLOTS * BP_ACC_STRIDE;
-__device__ __forceinline__ void bp_block_add2(u64 a, u64 b, unsigned long long* __restrict__ acc) {
-    __shared__ u64 s_acc_red[32];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        a += __shfl_xor(a, d, 64);
-        b += __shfl_xor(b, d, 64);
-    }
-    const u32 wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if (lane_id() == 0) { s_acc_red[wv] = a; s_acc_red[16 + wv] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 sa = 0, sb = 0;
-        for (u32 i = 0; i < nw; ++i) { sa += s_acc_red[i]; sb += s_acc_red[16 + i]; }
-        unsigned long long* slot = acc + (size_t)(blockIdx.x % BP_ACC_SLOTS) * BP_ACC_STRIDE;
-        if (sa) atomicAdd(slot, (unsigned long long)sa);
-        if (sb) atomicAdd(slot + 1, (unsigned long long)sb);
-    }
-}
 static fgpu_info bp_acc_alloc(fgpu_ctx* ctx, DevBuf<u64>& acc) {
     FGPU_TRY(acc.alloc(ctx, BP_ACC_WORDS));
     FGPU_HIP(hipMemsetAsync(acc.p, 0, BP_ACC_WORDS * sizeof(u64), ctx->stream()));
@@ -341,16 +317,7 @@ struct BpProbe {
 // What happens to a finished row (MODE): 0 = it is stored into Y (split rows OR into it) and flagged — a hop in the
 // middle of a chain; 1 / 2 = the LAST hop of a count-only chain: the row is counted here (2: and its checksum terms
 // summed through the LDS nibble tables) and never written, except for "touched" rows — rows cut into several items or
-// named by a delta layer — which go to their slot of the side buffer `y` (slot = rank of v in the touched bitmap).
-struct BpFinal {
-    const u64* tbits;        // touched bitmap (n bits)
-    const u32* tpref;        // exclusive prefix of its word popcounts
-    const u64* label;        // destination-label bitmap (nullable)
-    const u64* tab;          // checksum tables, w x 256 (MODE 2)
-    unsigned long long* acc; // [0] nnz, [1] checksum
-    u32 w;
-};
-
+// named by a delta layer — which go to their slot of the side buffer `y` (BpFinal, bitexpand.hpp).
 template <int LN, bool SPARSE, int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView at, const u32* __restrict__ items, u32 nitems, u32 ws,
                                                      const u64* __restrict__ x, BpProbe pr,
@@ -1138,395 +1105,6 @@ static fgpu_info bp_flops(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* a, u
 
 // one delta_lmxm in bit form: s.x <- ((X·m) & ~(X·dm)) | (X·dp)
 // what the counting form of a hop needs beside the hop itself
-// ---------------------------------------------------------------------------------
-// XCD-partitioned hot rows (round 4; DESIGN.md §4.3, tools/micro/xcdgather.hip).
-//
-// The dense pull gathers one 128 B row of X per entry of A' and every XCD gathers from the whole of X, so the eight 4 MiB
-// L2s all cache the same hottest rows: measured hit rate 0.22, the hop runs on the L2-miss path (~62 G rows/s).  Workgroups
-// are dealt to the XCDs round-robin, and a gather whose rows are partitioned BY XCD is served by the L2s at ~95 G rows/s
-// (the micro): the 8 x P hottest rows of X (by out-degree of u = how often the row is gathered) are split into 8 partitions
-// (hot index mod 8) of P rows (2 MiB at 1024 source rows) and the entries (v, u) of A' with u hot are handed to workgroups
-// of partition(u)'s XCD.  A row v of A' then receives partial rows from up to 8 XCDs; that only pays when v holds MANY hot
-// entries (one 128 B partial written and read back per (v, partition) against one 128 B gather per entry), so only rows with
-// at least `expand_hot_min` hot entries join ("hot rows of A'": the in-hubs — at RMAT-22 the 128 K hottest u and the 512 K
-// rows with most in-edges share 69 % of the entries, tools/experiments/khop_hot_counts.py).  Plan, once per snapshot:
-//   col     A''s column ids with every hot row permuted to [cold entries | partition 0 | ... | partition 7];
-//   items   the item list of the plain pull over `col`: every row's cold part (all of a row that is not hot);
-//   pitems  per partition k the (hot row, segment chunk) items of the hot pass; a segment of more than BP_HOT_ITEM entries
-//           is cut into several (they OR into one partial row with atomics; single-item segments store it);
-//   tbits   split rows | hot rows: all hot rows are "touched" — their parts meet in the side buffer like a split row's.
-// Per hop: plain pull over `items`; hot pass (grid 8 x G, partition = blockIdx & 7) writing the partial rows P[h][k]; a
-// fold kernel ORs the partials of each hot row into its side-buffer slot; the delta fix-ups and the count follow as before.
-// ---------------------------------------------------------------------------------
-constexpr u32 BP_HOT_ITEM = 512;
-struct BpHotPlan {
-    int rows_per_part = 0, min_hot = 0;   // the options it was built with
-    bool usable = false;                  // false: nothing to gain here (small graph, no hot rows) — the plain pull runs
-    u32 n_hot_u = 0;                      // hot rows of X (all partitions)
-    u32 n_rows = 0;                       // hot rows of A'
-    u64 hot_entries = 0;                  // entries of A' the hot pass gathers
-    u32* col = nullptr;
-    u32* items = nullptr;
-    u32 n_items = 0;
-    uint4* pitems = nullptr;              // (hot row index, begin, end | multi << 31, partition)
-    u32 n_pitems = 0;
-    u32 pstart[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // first item of partition k (host copy: grid sizing)
-    u32* pstart_dev = nullptr;
-    u32* rows = nullptr;                  // vertex of hot row h
-    uint8_t* pmask = nullptr;             // bit k: hot row h has entries in partition k
-    u64* tbits = nullptr;
-};
-
-void bp_hot_release(fgpu_ctx* ctx, BpHotPlan* h) {
-    if (!h) return;
-    if (ctx) {
-        ctx->dev_free(h->col); ctx->dev_free(h->items); ctx->dev_free(h->pitems); ctx->dev_free(h->rows);
-        ctx->dev_free(h->pmask); ctx->dev_free(h->tbits); ctx->dev_free(h->pstart_dev);
-    }
-    delete h;
-}
-
-__global__ void hot_hist_kernel(const u32* __restrict__ col, u64 nnz, u32* __restrict__ deg) {
-    for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += (u64)gridDim.x * blockDim.x) atomicAdd(&deg[col[q]], 1u);
-}
-__global__ __launch_bounds__(256) void hot_count_ge_kernel(const u32* __restrict__ deg, u32 n, u32 d, u32* __restrict__ out) {
-    u32 c = 0;
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += deg[i] >= d;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s, 64);
-    if (lane_id() == 0 && c) atomicAdd(out, c);
-}
-__global__ void hot_flag_kernel(const u32* __restrict__ deg, u32 n, u32 d, u32* __restrict__ flag) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n) flag[i] = (i < n && deg[i] >= d) ? 1u : 0u;
-}
-// hotidx[u] = rank of u among the hot rows, ~0 for a cold one (in place over the flag array's scan)
-__global__ void hot_index_kernel(const u32* __restrict__ flag, const u32* __restrict__ rank, u32 n, u32* __restrict__ hotidx) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hotidx[i] = flag[i] ? rank[i] : 0xFFFFFFFFu;
-}
-__global__ void hot_cand_flag_kernel(const u32* __restrict__ rowptr, u32 nrows, u32 min_len, u32* __restrict__ flag) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r <= nrows) flag[r] = (r < nrows && rowptr[r + 1] - rowptr[r] >= min_len) ? 1u : 0u;
-}
-__global__ void hot_compact_kernel(const u32* __restrict__ flag, const u32* __restrict__ rank, u32 n, u32* __restrict__ list) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) list[rank[i]] = i;
-}
-// a wavefront per candidate row: entries per class (partition 0..7 of a hot u, 8 = cold u)
-__global__ __launch_bounds__(256) void hot_classify_kernel(CsrView at, const u32* __restrict__ cand, u32 ncand,
-                                                           const u32* __restrict__ hotidx, u32 min_hot, u32* __restrict__ cc,
-                                                           u32* __restrict__ is_hot) {
-    const u32 lane = lane_id();
-    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
-    for (u32 ci = wave; ci < ncand; ci += nwaves) {
-        const u32 v = cand[ci];
-        const u32 b = at.rowptr[v], e = at.rowptr[v + 1];
-        u32 cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (u32 q0 = b; q0 < e; q0 += 64) {
-            const u32 q = q0 + lane;
-            u32 cls = 9;
-            if (q < e) { const u32 h = hotidx[at.colidx[q]]; cls = h == 0xFFFFFFFFu ? 8u : (h & 7u); }
-#pragma unroll
-            for (u32 k = 0; k < 9; ++k) cnt[k] += (u32)__popcll(__ballot(cls == k));
-        }
-        if (lane < 9) cc[(size_t)ci * 9 + lane] = cnt[lane];
-        if (lane == 0) is_hot[ci] = (e - b - cnt[8]) >= min_hot ? 1u : 0u;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) is_hot[ncand] = 0;
-}
-// a wavefront per hot row: the permuted copy of its entries, its segment table, its bit in the hot bitmap
-__global__ __launch_bounds__(256) void hot_place_kernel(CsrView at, const u32* __restrict__ cand, u32 ncand, const u32* __restrict__ hotidx,
-                                                        const u32* __restrict__ cc, const u32* __restrict__ is_hot,
-                                                        const u32* __restrict__ hrank, u32* __restrict__ col, u32* __restrict__ rows,
-                                                        uint8_t* __restrict__ pmask, u32* __restrict__ seg, u32* __restrict__ coldend,
-                                                        unsigned long long* __restrict__ hotbits, unsigned long long* __restrict__ total) {
-    const u32 lane = lane_id();
-    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
-    for (u32 ci = wave; ci < ncand; ci += nwaves) {
-        if (!is_hot[ci]) continue;
-        const u32 v = cand[ci], h = hrank[ci];
-        const u32 b = at.rowptr[v], e = at.rowptr[v + 1];
-        u32 base[9];
-        base[8] = b;                                        // cold entries first: the plain pull's part of the row
-        u32 o = b + cc[(size_t)ci * 9 + 8];
-        u32 mask = 0;
-#pragma unroll
-        for (u32 k = 0; k < 8; ++k) { base[k] = o; const u32 c = cc[(size_t)ci * 9 + k]; o += c; mask |= c ? (1u << k) : 0u; }
-        if (lane < 9) seg[(size_t)h * 9 + lane] = lane < 8 ? base[lane] : e;
-        if (lane == 0) {
-            rows[h] = v; pmask[h] = (uint8_t)mask; coldend[v] = base[0];
-            atomicOr(&hotbits[v >> 6], 1ull << (v & 63));
-            atomicAdd(total, (unsigned long long)(e - base[0]));
-        }
-        const u64 below = (1ull << lane) - 1ull;
-        for (u32 q0 = b; q0 < e; q0 += 64) {
-            const u32 q = q0 + lane;
-            u32 cls = 9, u = 0;
-            if (q < e) { u = at.colidx[q]; const u32 hh = hotidx[u]; cls = hh == 0xFFFFFFFFu ? 8u : (hh & 7u); }
-#pragma unroll
-            for (u32 k = 0; k < 9; ++k) {
-                const u64 m = __ballot(cls == k);
-                if (cls == k) col[base[k] + (u32)__popcll(m & below)] = u;
-                base[k] += (u32)__popcll(m);
-            }
-        }
-    }
-}
-__global__ void hot_item_count_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ rowend, u32 nrows, u32* __restrict__ cnt) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > nrows) return;
-    cnt[r] = (r < nrows) ? (rowend[r] - rowptr[r] + BP_ITEM - 1) / BP_ITEM : 0u;
-}
-__global__ void hot_item_fill_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ rowend, u32 nrows, const u32* __restrict__ off,
-                                     u32* __restrict__ items) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    const u32 b = rowptr[r], e = rowend[r];
-    const u32 n = (e - b + BP_ITEM - 1) / BP_ITEM;
-    const u32 split = n > 1 ? 0x80000000u : 0u;
-    u32 o = off[r];
-    for (u32 k = 0; k < n; ++k, ++o) {
-        const u32 ib = b + k * BP_ITEM;
-        items[3 * o] = r; items[3 * o + 1] = ib; items[3 * o + 2] = (ib + BP_ITEM < e ? ib + BP_ITEM : e) | split;
-    }
-}
-// touched-by-construction bitmap: rows whose cold part is cut into several items | hot rows
-__global__ __launch_bounds__(256) void hot_tbits_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ rowend, u32 nrows,
-                                                        const u64* __restrict__ hotbits, u64* __restrict__ bits) {
-    const u32 lane = lane_id();
-    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
-    const u32 nwords = (nrows + 63) >> 6;
-    for (u32 w = wave; w < nwords; w += nwaves) {
-        const u32 r = (w << 6) + lane;
-        const u64 m = __ballot(r < nrows && rowend[r] - rowptr[r] > BP_ITEM);
-        if (lane == 0) bits[w] = m | hotbits[w];
-    }
-}
-// hot-pass items: entry t = k * nhot + h (partition-major, so that a partition's items are contiguous)
-__global__ void hot_pitem_count_kernel(const u32* __restrict__ seg, u32 nhot, u32* __restrict__ cnt) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > 8 * nhot) return;
-    u32 c = 0;
-    if (t < 8 * nhot) {
-        const u32 k = t / nhot, h = t % nhot;
-        c = (seg[(size_t)h * 9 + k + 1] - seg[(size_t)h * 9 + k] + BP_HOT_ITEM - 1) / BP_HOT_ITEM;
-    }
-    cnt[t] = c;
-}
-__global__ void hot_pitem_fill_kernel(const u32* __restrict__ seg, u32 nhot, const u32* __restrict__ off, uint4* __restrict__ pitems) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 8 * nhot) return;
-    const u32 k = t / nhot, h = t % nhot;
-    const u32 b = seg[(size_t)h * 9 + k], e = seg[(size_t)h * 9 + k + 1];
-    const u32 n = (e - b + BP_HOT_ITEM - 1) / BP_HOT_ITEM;
-    const u32 multi = n > 1 ? 0x80000000u : 0u;
-    u32 o = off[t];
-    for (u32 j = 0; j < n; ++j, ++o) {
-        const u32 ib = b + j * BP_HOT_ITEM;
-        pitems[o] = make_uint4(h, ib, (ib + BP_HOT_ITEM < e ? ib + BP_HOT_ITEM : e) | multi, k);
-    }
-}
-__global__ void hot_pstart_kernel(const u32* __restrict__ off, u32 nhot, u32* __restrict__ out) {
-    if (threadIdx.x < 9) out[threadIdx.x] = off[(size_t)threadIdx.x * nhot];
-}
-
-// ---- per hop -------------------------------------------------------------------------------------------------------------
-// partial rows of segments cut into several items start from zero (their items OR into them)
-__global__ __launch_bounds__(256) void bp_hot_zero_kernel(const uint4* __restrict__ pitems, u32 n, u32 ws, u64* __restrict__ part) {
-    const u32 per = 256 / ws;                                  // items per workgroup trip (ws <= 64 lanes per item)
-    for (u32 it = blockIdx.x * per + threadIdx.x / ws; it < n; it += gridDim.x * per) {
-        const uint4 p = pitems[it];
-        if ((p.z >> 31) && threadIdx.x / ws < per) part[((size_t)p.x * 8 + p.w) * ws + threadIdx.x % ws] = 0ull;
-    }
-}
-// the hot pass: workgroup b serves partition b & 7 — and is dealt to XCD b & 7 — so the rows of X it gathers are the rows
-// that XCD's L2 holds.  Same gather shape as the dense pull (LN lanes per row, 8 gathers in flight per lane).
-template <int LN>
-__global__ __launch_bounds__(256) void bp_hot_kernel(const u32* __restrict__ col, const uint4* __restrict__ pitems, const u32* __restrict__ pstart,
-                                                     u32 ws, const u64* __restrict__ x, u64* __restrict__ part) {
-    constexpr int SLOTS = 64 / LN;
-    constexpr int G = SLOTS <= 4 ? 8 : 4;
-    const u32 lane = lane_id();
-    const u32 wl = lane % LN, slot = lane / LN;
-    const u32 k = blockIdx.x & 7u;
-    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 3) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const u32 nwaves = (gridDim.x >> 3) * (blockDim.x >> 6);
-    const u32 i0 = pstart[k], i1 = pstart[k + 1];
-    for (u32 it = i0 + wave; it < i1; it += nwaves) {
-        const uint4 p = pitems[it];
-        const u32 h = (u32)__builtin_amdgcn_readfirstlane((int)p.x);
-        const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)p.y);
-        const u32 e3 = (u32)__builtin_amdgcn_readfirstlane((int)p.z);
-        const u32 e = e3 & 0x7FFFFFFFu;
-        u64 acc = 0ull;
-        for (u32 q0 = b; q0 < e; q0 += G * SLOTS) {
-            u32 u[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const u32 q = q0 + g * SLOTS + slot;
-                u[g] = (q < e) ? col[q] : 0xFFFFFFFFu;
-            }
-            u64 xv[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) xv[g] = (u[g] != 0xFFFFFFFFu) ? x[(size_t)u[g] * ws + wl] : 0ull;
-#pragma unroll
-            for (int g = 0; g < G; ++g) acc |= xv[g];
-        }
-#pragma unroll
-        for (int d = LN; d < 64; d <<= 1) acc |= __shfl_xor(acc, d, 64);
-        if (slot == 0) {
-            u64* dst = &part[((size_t)h * 8 + k) * ws + wl];
-            if (e3 >> 31) { if (acc) atomicOr((unsigned long long*)dst, (unsigned long long)acc); }
-            else *dst = acc;
-        }
-    }
-}
-// OR the partial rows of every hot row into its slot of the side buffer (after the plain pull and the hot pass, before the
-// delta fix-ups: the fix-ups act on the complete row of F x m)
-__global__ __launch_bounds__(256) void bp_hot_fold_kernel(const u64* __restrict__ part, const uint8_t* __restrict__ pmask,
-                                                          const u32* __restrict__ rows, u32 nhot, u32 ws, const u64* __restrict__ tbits,
-                                                          const u32* __restrict__ tpref, u64* __restrict__ side) {
-    const u32 per = 256 / ws;
-    const u32 wl = threadIdx.x % ws, sub = threadIdx.x / ws;
-    for (u32 h = blockIdx.x * per + sub; h < nhot; h += gridDim.x * per) {
-        if (sub >= per) break;
-        const u32 mask = pmask[h];
-        u64 acc = 0ull;
-#pragma unroll
-        for (u32 k = 0; k < 8; ++k)
-            if ((mask >> k) & 1u) acc |= part[((size_t)h * 8 + k) * ws + wl];
-        if (acc) {
-            const u32 v = rows[h];
-            const u64 tw = tbits[v >> 6];
-            const u32 sl = tpref[v >> 6] + (u32)__popcll(tw & ((1ull << (v & 63)) - 1ull));
-            side[(size_t)sl * ws + wl] |= acc;
-        }
-    }
-}
-
-// the plan of `t` (= the cached transpose of m), built under m's index mutex on the first dense count hop
-static fgpu_info hot_plan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const BpHotPlan** out) {
-    *out = nullptr;
-    if (!ctx->opt.expand_hot || !t || t->is_hyper()) return FGPU_OK;
-    std::lock_guard<std::mutex> idx_guard(m->idx_mu);
-    if (t->bp_hot && (t->bp_hot->rows_per_part != ctx->opt.expand_hot_rows || t->bp_hot->min_hot != ctx->opt.expand_hot_min)) {
-        FGPU_HIP(hipStreamSynchronize(ctx->stream()));       // (an option changed: a measurement context, one caller)
-        bp_hot_release(ctx, t->bp_hot);
-        t->bp_hot = nullptr;
-    }
-    if (t->bp_hot) { if (t->bp_hot->usable) *out = t->bp_hot; return FGPU_OK; }
-    BpHotPlan* hp = new (std::nothrow) BpHotPlan();
-    FGPU_REQUIRE(hp, FGPU_OOM, "out of host memory");
-    hp->rows_per_part = ctx->opt.expand_hot_rows;
-    hp->min_hot = ctx->opt.expand_hot_min;
-    t->bp_hot = hp;                                           // (published as "not usable" until the build below completes)
-    const u32 nrows = (u32)t->nrows, ncols = (u32)t->ncols;
-    const u32 HU = 8u * (u32)hp->rows_per_part;
-    // nothing to partition when X fits the L2s as it is (or the graph is tiny): 4 x the hot set is the bar
-    if ((u64)ncols < 4ull * HU || t->nnz < (1u << 20)) return FGPU_OK;
-    hipStream_t st = ctx->stream();
-    DevBuf<u32> deg, flag, rank, hotidx, cand, cc, is_hot, hrank, seg, coldend, cnt, off, small;
-    DevBuf<unsigned long long> hotbits, total;
-    FGPU_TRY(deg.alloc(ctx, (size_t)ncols + 1));
-    FGPU_HIP(hipMemsetAsync(deg.p, 0, ((size_t)ncols + 1) * sizeof(u32), st));
-    hipLaunchKernelGGL(hot_hist_kernel, dim3(ctx->cus * 16), dim3(256), 0, st, (const u32*)t->colidx, (u64)t->nnz, deg.p);
-    FGPU_HIP(hipGetLastError());
-    // the smallest degree bar that leaves at most HU rows above it (binary search, one counting pass per step)
-    FGPU_TRY(small.alloc(ctx, 16));
-    u32 lo = 1, hi = 0x7FFFFFFFu;
-    while (lo < hi) {
-        const u32 mid = lo + (hi - lo) / 2;
-        FGPU_HIP(hipMemsetAsync(small.p, 0, sizeof(u32), st));
-        hipLaunchKernelGGL(hot_count_ge_kernel, dim3(ctx->cus * 4), dim3(256), 0, st, (const u32*)deg.p, ncols, mid, small.p);
-        u32 c = 0;
-        FGPU_TRY(read_u32(ctx, small.p, &c));
-        if (c <= HU) hi = mid; else lo = mid + 1;
-    }
-    const u32 bar = lo;
-    FGPU_TRY(flag.alloc(ctx, (size_t)ncols + 1));
-    FGPU_TRY(rank.alloc(ctx, (size_t)ncols + 1));
-    FGPU_TRY(hotidx.alloc(ctx, (size_t)ncols + 1));
-    hipLaunchKernelGGL(hot_flag_kernel, dim3(cdiv((u64)ncols + 1, 256)), dim3(256), 0, st, (const u32*)deg.p, ncols, bar, flag.p);
-    FGPU_TRY(scan_u32(ctx, flag.p, rank.p, (u64)ncols + 1, nullptr));
-    FGPU_TRY(read_u32(ctx, rank.p + ncols, &hp->n_hot_u));
-    if (hp->n_hot_u < 64) return FGPU_OK;
-    hipLaunchKernelGGL(hot_index_kernel, dim3(cdiv(ncols, 256)), dim3(256), 0, st, (const u32*)flag.p, (const u32*)rank.p, ncols, hotidx.p);
-    // candidate rows of A' (long enough to hold min_hot hot entries at all), their class counts, the hot ones among them
-    DevBuf<u32> cflag, crank;
-    FGPU_TRY(cflag.alloc(ctx, (size_t)nrows + 1));
-    FGPU_TRY(crank.alloc(ctx, (size_t)nrows + 1));
-    hipLaunchKernelGGL(hot_cand_flag_kernel, dim3(cdiv((u64)nrows + 1, 256)), dim3(256), 0, st, (const u32*)t->rowptr, nrows,
-                       (u32)hp->min_hot, cflag.p);
-    FGPU_TRY(scan_u32(ctx, cflag.p, crank.p, (u64)nrows + 1, nullptr));
-    u32 ncand = 0;
-    FGPU_TRY(read_u32(ctx, crank.p + nrows, &ncand));
-    if (ncand == 0) return FGPU_OK;
-    FGPU_TRY(cand.alloc(ctx, ncand));
-    hipLaunchKernelGGL(hot_compact_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, st, (const u32*)cflag.p, (const u32*)crank.p, nrows, cand.p);
-    FGPU_TRY(cc.alloc(ctx, (size_t)ncand * 9));
-    FGPU_TRY(is_hot.alloc(ctx, (size_t)ncand + 1));
-    FGPU_TRY(hrank.alloc(ctx, (size_t)ncand + 1));
-    u32 wgrid = cdiv(ncand, 4);
-    if (wgrid > (u32)ctx->cus * 16) wgrid = ctx->cus * 16;
-    hipLaunchKernelGGL(hot_classify_kernel, dim3(wgrid), dim3(256), 0, st, view_of(t), (const u32*)cand.p, ncand, (const u32*)hotidx.p,
-                       (u32)hp->min_hot, cc.p, is_hot.p);
-    FGPU_HIP(hipGetLastError());
-    FGPU_TRY(scan_u32(ctx, is_hot.p, hrank.p, (u64)ncand + 1, nullptr));
-    FGPU_TRY(read_u32(ctx, hrank.p + ncand, &hp->n_rows));
-    if (hp->n_rows == 0) return FGPU_OK;
-    const u32 nhot = hp->n_rows;
-    // the permuted column ids (cold rows: a plain copy), the hot rows' vertices / masks / segment tables
-    FGPU_TRY(ctx->dev_alloc((void**)&hp->col, (size_t)(t->nnz ? t->nnz : 1) * sizeof(u32)));
-    FGPU_HIP(hipMemcpyAsync(hp->col, t->colidx, (size_t)t->nnz * sizeof(u32), hipMemcpyDeviceToDevice, st));
-    FGPU_TRY(ctx->dev_alloc((void**)&hp->rows, (size_t)nhot * sizeof(u32)));
-    FGPU_TRY(ctx->dev_alloc((void**)&hp->pmask, (size_t)nhot));
-    FGPU_TRY(seg.alloc(ctx, (size_t)nhot * 9));
-    FGPU_TRY(coldend.alloc(ctx, (size_t)nrows + 1));
-    FGPU_HIP(hipMemcpyAsync(coldend.p, t->rowptr + 1, (size_t)nrows * sizeof(u32), hipMemcpyDeviceToDevice, st));   // rowend = rowptr[r + 1]
-    const u32 nwords = (nrows + 63) / 64;
-    FGPU_TRY(hotbits.alloc(ctx, (size_t)nwords + 2));
-    FGPU_HIP(hipMemsetAsync(hotbits.p, 0, ((size_t)nwords + 2) * sizeof(u64), st));
-    FGPU_TRY(total.alloc(ctx, 1));
-    FGPU_HIP(hipMemsetAsync(total.p, 0, sizeof(u64), st));
-    hipLaunchKernelGGL(hot_place_kernel, dim3(wgrid), dim3(256), 0, st, view_of(t), (const u32*)cand.p, ncand, (const u32*)hotidx.p,
-                       (const u32*)cc.p, (const u32*)is_hot.p, (const u32*)hrank.p, hp->col, hp->rows, hp->pmask, seg.p, coldend.p,
-                       hotbits.p, total.p);
-    FGPU_HIP(hipGetLastError());
-    FGPU_TRY(read_u64(ctx, (const u64*)total.p, &hp->hot_entries));
-    // item list of the plain pull over the cold parts, and the touched-by-construction bitmap
-    FGPU_TRY(cnt.alloc(ctx, (size_t)(nrows > 8 * nhot ? nrows : 8 * nhot) + 2));
-    FGPU_TRY(off.alloc(ctx, (size_t)(nrows > 8 * nhot ? nrows : 8 * nhot) + 2));
-    hipLaunchKernelGGL(hot_item_count_kernel, dim3(cdiv((u64)nrows + 1, 256)), dim3(256), 0, st, (const u32*)t->rowptr, (const u32*)coldend.p,
-                       nrows, cnt.p);
-    FGPU_TRY(scan_u32(ctx, cnt.p, off.p, (u64)nrows + 1, nullptr));
-    FGPU_TRY(read_u32(ctx, off.p + nrows, &hp->n_items));
-    FGPU_TRY(ctx->dev_alloc((void**)&hp->items, (size_t)(hp->n_items ? hp->n_items : 1) * 3 * sizeof(u32)));
-    hipLaunchKernelGGL(hot_item_fill_kernel, dim3(cdiv(nrows, 256)), dim3(256), 0, st, (const u32*)t->rowptr, (const u32*)coldend.p, nrows,
-                       (const u32*)off.p, hp->items);
-    FGPU_TRY(ctx->dev_alloc((void**)&hp->tbits, ((size_t)nwords + 2) * sizeof(u64)));
-    hipLaunchKernelGGL(hot_tbits_kernel, dim3(ctx->cus * 4), dim3(256), 0, st, (const u32*)t->rowptr, (const u32*)coldend.p, nrows,
-                       (const u64*)hotbits.p, hp->tbits);
-    FGPU_HIP(hipGetLastError());
-    // hot-pass items, partition-major
-    hipLaunchKernelGGL(hot_pitem_count_kernel, dim3(cdiv((u64)8 * nhot + 1, 256)), dim3(256), 0, st, (const u32*)seg.p, nhot, cnt.p);
-    FGPU_TRY(scan_u32(ctx, cnt.p, off.p, (u64)8 * nhot + 1, nullptr));
-    FGPU_TRY(read_u32(ctx, off.p + (size_t)8 * nhot, &hp->n_pitems));
-    FGPU_TRY(ctx->dev_alloc((void**)&hp->pitems, (size_t)(hp->n_pitems ? hp->n_pitems : 1) * sizeof(uint4)));
-    hipLaunchKernelGGL(hot_pitem_fill_kernel, dim3(cdiv((u64)8 * nhot, 256)), dim3(256), 0, st, (const u32*)seg.p, nhot, (const u32*)off.p,
-                       hp->pitems);
-    FGPU_TRY(ctx->dev_alloc((void**)&hp->pstart_dev, 16 * sizeof(u32)));
-    hipLaunchKernelGGL(hot_pstart_kernel, dim3(1), dim3(64), 0, st, (const u32*)off.p, nhot, hp->pstart_dev);
-    FGPU_HIP(hipGetLastError());
-    FGPU_TRY(ctx->d2h(hp->pstart, hp->pstart_dev, 9 * sizeof(u32)));
-    FGPU_HIP(hipStreamSynchronize(st));
-    hp->pstart[8] = hp->n_pitems;
-    // worth it only when the hot pass takes a real share of the gathers
-    hp->usable = hp->hot_entries * 8 >= (u64)t->nnz;
-    if (hp->usable) *out = hp;
-    return FGPU_OK;
-}
-
 struct CountArgs {
     const u64* label;   // destination-label bitmap on the device (nullable)
     u64* nnz;
@@ -1557,17 +1135,18 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     u32 ntouched = 0;
     const int mode = !ca ? 0 : (ca->checksum ? 2 : 1);
     size_t lds = 0;
-    // the dense count hop may run with the XCD-partitioned hot rows (BpHotPlan above): the sparse form, rows wider than a
-    // wavefront and mid-chain hops keep the plain pull
+    // the dense count hop runs in its XCD-partitioned form (bitpart.hip) when the state is well past one L2: the sparse
+    // form, rows wider than 128 bytes, 8-byte rows and mid-chain hops keep the plain pull
     const bool will_sparse = m->nnz && s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n &&
                              bp_sparse_fits(ctx, mode == 2 ? (size_t)s.w * 256 * sizeof(u64) : 0);
-    const BpHotPlan* hot = nullptr;
-    if (ca && t && !will_sparse && !s.lazy && s.ws <= 64) FGPU_TRY(hot_plan(ctx, m, t, &hot));
+    const BpXPlan* xp = nullptr;
+    if (ca && t && !will_sparse && !s.lazy && s.ws >= 2 && s.ws <= 16 && (u64)s.n * s.ws * 8 >= (u64)ctx->opt.expand_xcd_min_mb << 20)
+        FGPU_TRY(bp_xplan(ctx, m, t, &xp));
     if (ca) {
         const u32 nwords = (n_out + 63) / 64;
         FGPU_TRY(tbits.alloc(ctx, (size_t)nwords + 2));
-        if (hot)
-            FGPU_HIP(hipMemcpyAsync(tbits.p, hot->tbits, (size_t)nwords * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream()));
+        if (xp)   // every row is completed by the fold: only the destinations of a delta layer are "touched"
+            FGPU_HIP(hipMemsetAsync(tbits.p, 0, (size_t)nwords * sizeof(u64), ctx->stream()));
         else if (t && t->bp_split_bits)
             FGPU_HIP(hipMemcpyAsync(tbits.p, t->bp_split_bits, (size_t)nwords * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream()));
         else
@@ -1607,7 +1186,10 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     u64* ydst = ca ? side.p : o.x.p;          // rows of Y, or the slots of the side buffer
     uint8_t* yflag = ca ? nullptr : o.flag.p;
     int pull_idx = -1;
-    if (m->nnz) {
+    if (m->nnz && xp) {
+        const u64 xrows = s.nz_rows < (u64)s.n ? s.nz_rows : (u64)s.n;
+        FGPU_TRY(bp_xpull_count(ctx, xp, t, (const u64*)s.x.p, s.ws, mode, fin, side.p, lds, xrows));
+    } else if (m->nnz) {
         // (the sparse form stages a <= 16 KiB coarse flag map in LDS next to the checksum tables of MODE 2)
         const bool sparse = s.flag.p != nullptr && s.nz_rows * 8 < (u64)s.n && bp_sparse_fits(ctx, lds);
         FGPU_REQUIRE(sparse || !s.lazy, FGPU_INVALID, "bit-parallel hop: a lazily zeroed state needs the sparse pull");
@@ -1616,11 +1198,9 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         // ... and it can sum the next hop's traversed-edge count and the flagged rows on its way (the next matrix must be
         // plain CSR over the same vertices); rows a delta fix-up changes after the pull are summed after it
         fuse_stats = groups && next_m && !next_m->is_hyper() && next_m->nrows == m->ncols;
-        FGPU_REQUIRE(!hot || !sparse, FGPU_INVALID, "bit-parallel hop: hot plan chosen for a sparse pull");
-        const u32 nitems = hot ? hot->n_items : groups ? t->n_bp_sitems : t->n_bp_items;
-        const u32* item_list = hot ? hot->items : groups ? t->bp_sitems : t->bp_items;
-        CsrView tv = view_of(t);
-        if (hot) tv.colidx = hot->col;                 // hot rows permuted: the plain pull walks their cold part only
+        const u32 nitems = groups ? t->n_bp_sitems : t->n_bp_items;
+        const u32* item_list = groups ? t->bp_sitems : t->bp_items;
+        const CsrView tv = view_of(t);
         u32 grid = cdiv(nitems ? nitems : 1, 4);
         if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
         const u32 threads = mode == 2 ? 1024 : 256;
@@ -1656,7 +1236,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         const u64 xrows = s.nz_rows < (u64)s.n ? s.nz_rows : (u64)s.n;
         const char* nm = ca ? (sparse ? "bp_pull_kernel<sparse, count>" : "bp_pull_kernel<dense, count>")
                             : (sparse ? "bp_pull_kernel<sparse>" : "bp_pull_kernel<dense>");
-        ProfScope ps(ctx, nm, 4 * ((u64)t->nnz - (hot ? hot->hot_entries : 0)) + 12 * (u64)nitems + xrows * 8 * s.w +
+        ProfScope ps(ctx, nm, 4 * (u64)t->nnz + 12 * (u64)nitems + xrows * 8 * s.w +
                                   (sparse ? (u64)s.n / 8 : 0));
         ps.idx_out = &pull_idx;
 #define BP_LAUNCH3(LN, SP, MD)                                                                                          \
@@ -1732,46 +1312,6 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
 #undef BP_LAUNCH
 #undef BP_LAUNCH3
         FGPU_HIP(hipGetLastError());
-    }
-    DevBuf<u64> hot_part;
-    if (hot) {
-        // ---- the hot pass: entries (v, u) of the hot rows whose u is hot, gathered by the XCD that owns u's partition ----
-        const u32 nhot = hot->n_rows;
-        FGPU_TRY(hot_part.alloc(ctx, (size_t)nhot * 8 * s.ws));
-        {
-            u32 zgrid = cdiv(hot->n_pitems, 256 / s.ws);
-            if (zgrid > (u32)ctx->cus * 8) zgrid = ctx->cus * 8;
-            hipLaunchKernelGGL(bp_hot_zero_kernel, dim3(zgrid ? zgrid : 1), dim3(256), 0, ctx->stream(), (const uint4*)hot->pitems,
-                               hot->n_pitems, s.ws, hot_part.p);
-        }
-        {
-            // bytes: the hot entries' column ids and the item list once, the hot rows of X once, every partial row written
-            ProfScope ps(ctx, "bp_hot_kernel", 4 * hot->hot_entries + 16 * (u64)hot->n_pitems + (u64)hot->n_hot_u * 8 * s.w +
-                                                   (u64)hot->n_pitems * 8 * s.w);
-            u32 most = 0;
-            for (int k = 0; k < 8; ++k) most = std::max(most, hot->pstart[k + 1] - hot->pstart[k]);
-            u32 per = cdiv(most ? most : 1, 4);            // workgroups per partition: a wavefront per item ...
-            if (per > (u32)ctx->cus * 4) per = ctx->cus * 4;   // ... up to 32 workgroups per CU over the 8 partitions
-            const u32 hgrid = per * 8;
-            switch (s.ws < 64 ? s.ws : 64) {
-                case 1: hipLaunchKernelGGL(bp_hot_kernel<1>, dim3(hgrid), dim3(256), 0, ctx->stream(), (const u32*)hot->col, (const uint4*)hot->pitems, (const u32*)hot->pstart_dev, s.ws, (const u64*)s.x.p, hot_part.p); break;
-                case 2: hipLaunchKernelGGL(bp_hot_kernel<2>, dim3(hgrid), dim3(256), 0, ctx->stream(), (const u32*)hot->col, (const uint4*)hot->pitems, (const u32*)hot->pstart_dev, s.ws, (const u64*)s.x.p, hot_part.p); break;
-                case 4: hipLaunchKernelGGL(bp_hot_kernel<4>, dim3(hgrid), dim3(256), 0, ctx->stream(), (const u32*)hot->col, (const uint4*)hot->pitems, (const u32*)hot->pstart_dev, s.ws, (const u64*)s.x.p, hot_part.p); break;
-                case 8: hipLaunchKernelGGL(bp_hot_kernel<8>, dim3(hgrid), dim3(256), 0, ctx->stream(), (const u32*)hot->col, (const uint4*)hot->pitems, (const u32*)hot->pstart_dev, s.ws, (const u64*)s.x.p, hot_part.p); break;
-                case 16: hipLaunchKernelGGL(bp_hot_kernel<16>, dim3(hgrid), dim3(256), 0, ctx->stream(), (const u32*)hot->col, (const uint4*)hot->pitems, (const u32*)hot->pstart_dev, s.ws, (const u64*)s.x.p, hot_part.p); break;
-                case 32: hipLaunchKernelGGL(bp_hot_kernel<32>, dim3(hgrid), dim3(256), 0, ctx->stream(), (const u32*)hot->col, (const uint4*)hot->pitems, (const u32*)hot->pstart_dev, s.ws, (const u64*)s.x.p, hot_part.p); break;
-                default: hipLaunchKernelGGL(bp_hot_kernel<64>, dim3(hgrid), dim3(256), 0, ctx->stream(), (const u32*)hot->col, (const uint4*)hot->pitems, (const u32*)hot->pstart_dev, s.ws, (const u64*)s.x.p, hot_part.p); break;
-            }
-            FGPU_HIP(hipGetLastError());
-        }
-        {
-            ProfScope ps(ctx, "bp_hot_fold_kernel", (u64)hot->n_pitems * 8 * s.w + (u64)nhot * (16 * s.w + 5));
-            u32 fgrid = cdiv(nhot, 256 / s.ws);
-            if (fgrid > (u32)ctx->cus * 16) fgrid = ctx->cus * 16;
-            hipLaunchKernelGGL(bp_hot_fold_kernel, dim3(fgrid ? fgrid : 1), dim3(256), 0, ctx->stream(), (const u64*)hot_part.p,
-                               (const uint8_t*)hot->pmask, (const u32*)hot->rows, nhot, s.ws, (const u64*)tbits.p, (const u32*)tpref.p, side.p);
-            FGPU_HIP(hipGetLastError());
-        }
     }
     {
         u32 ln = 1;                               // lanes per delta entry: a power of two covering the row words

@@ -92,11 +92,10 @@ struct fgpu_options {  // fgpu_set_option
     int pagerank_parts = 1;    // PageRank SpMV: 1 = A' in 8 column ranges, range k gathered by XCD k out of its own L2 (when the score
                                // vector exceeds one L2), 2 = always, 0 = the one-pass pull over the whole vector (A/B)
     int expand_first_hop = 1;  // fgpu_expand*: a clean first hop from one-entry rows copies the source rows (0 = the general product; A/B)
-    int expand_hot = 0;        // dense count hop of the bit-parallel chain: 1 = hot rows of X are gathered by the XCD that owns them
-                               // (bitexpand.hip BpHotPlan; measured slower than the plain pull at every setting, DESIGN.md §4.3 — kept
-                               // as the experiment), 0 = every workgroup gathers from the whole of X
-    int expand_hot_rows = 16384;   // hot rows of X per XCD partition (x 8 partitions; 128 B rows: 2 MiB of each 4 MiB L2)
-    int expand_hot_min = 32;   // a row of A' joins the hot pass when it holds at least this many hot entries
+    int expand_xcd = 1;        // dense count hop of the bit-parallel chain: 1 = the rows of X are gathered by the XCD that owns their
+                               // partition, partial rows folded per vertex (bitpart.hip), 0 = every workgroup gathers from all of X (A/B)
+    int expand_xcd_dbg = 0;    // EXPERIMENT switches of the partitioned pull (results are wrong with any of them set)
+    int expand_xcd_min_mb = 32; // ... when the bit state holds at least this many MiB (8 L2s of 4 MiB; below that the plain pull)
     int pinned_results = 1;    // result arrays >= 256 KiB come from the context's pinned-host pool and are filled by DMA (0 = the
                                // caller's allocator / malloc + staged copies, the round-3 path; A/B)
     int pinned_pool_mb = 4096; // pinned blocks kept for reuse after fgpu_free (beyond it they go back to the OS)
@@ -274,7 +273,7 @@ struct fgpu_tiles;  // tiled.hip: LDS-staged frontier-tile edge layout (accelera
 // below are built lazily on first use; every such build happens under `idx_mu`, is complete on the device
 // (stream synchronised) before its pointer is published, and is never replaced afterwards — concurrent readers
 // on other lanes either see no index (and take the lock) or a finished one.
-namespace fgpu { struct BpHotPlan; struct PrParts; }   // bitexpand.hip, pagerank.hip
+namespace fgpu { struct BpXPlan; struct PrParts; }   // bitexpand.hip, pagerank.hip
 struct fgpu_mat {
     fgpu_ctx* ctx = nullptr;
     mutable std::mutex idx_mu;
@@ -316,8 +315,8 @@ struct fgpu_mat {
     mutable uint32_t n_bp_sitems = 0;
     mutable uint64_t* bp_split_bits = nullptr;  // on the cached transpose: bit v set <=> row v is cut into several items
     mutable fgpu::PrParts* pr_parts = nullptr;  // pagerank.hip: this matrix split into 8 column ranges (one per XCD), lazily, owned
-    mutable fgpu::BpHotPlan* bp_hot = nullptr; // on the cached transpose: the XCD-partitioned hot-row plan of the dense count hop
-                                                // (bitexpand.hip, built on the first such hop; released by bp_hot_release)
+    mutable fgpu::BpXPlan* bp_xplan = nullptr; // on the cached transpose: the XCD-partitioned layout of the dense count hop
+                                               // (bitpart.hip, built on the first such hop; released by bp_xplan_release)
     bool is_hyper() const { return hrows != nullptr; }
 };
 
@@ -417,7 +416,7 @@ fgpu_info compact_segments(fgpu_ctx* ctx, const u32* data, const u64* off, const
 // ---- matrix helpers (mat.hip) ---------------------------------------------------
 // free a snapshot no other thread has seen (temporaries, failed builds); fgpu_mat_free adds the cross-lane fence
 void mat_release(fgpu_mat* m);
-void bp_hot_release(fgpu_ctx* ctx, BpHotPlan* h);   // bitexpand.hip
+void bp_xplan_release(fgpu_ctx* ctx, BpXPlan* p);   // bitpart.hip
 void pr_parts_release(fgpu_ctx* ctx, PrParts* p);   // pagerank.hip
 void mat_drop_bfs_plan(const fgpu_mat* a);   // caller holds bfs_link_mu() and a->bfs_mu
 // One process-wide mutex orders every change of the (adjacency <-> transpose) plan links (bfs_plan / bfs_plan_at /

@@ -818,14 +818,13 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.pagerank_parts = (int)value;
     } else if (!strcmp(name, "expand_first_hop")) {
         ctx->opt.expand_first_hop = value != 0;
-    } else if (!strcmp(name, "expand_hot")) {
-        ctx->opt.expand_hot = value != 0;
-    } else if (!strcmp(name, "expand_hot_rows")) {
-        FGPU_REQUIRE(value >= 64 && value <= (1 << 20), FGPU_INVALID, "expand_hot_rows out of range");
-        ctx->opt.expand_hot_rows = (int)value;
-    } else if (!strcmp(name, "expand_hot_min")) {
-        FGPU_REQUIRE(value >= 1 && value <= (1 << 20), FGPU_INVALID, "expand_hot_min out of range");
-        ctx->opt.expand_hot_min = (int)value;
+    } else if (!strcmp(name, "expand_xcd")) {
+        ctx->opt.expand_xcd = value != 0;
+    } else if (!strcmp(name, "expand_xcd_dbg")) {
+        ctx->opt.expand_xcd_dbg = (int)value;
+    } else if (!strcmp(name, "expand_xcd_min_mb")) {
+        FGPU_REQUIRE(value >= 0 && value <= (1 << 20), FGPU_INVALID, "expand_xcd_min_mb out of range");
+        ctx->opt.expand_xcd_min_mb = (int)value;
     } else if (!strcmp(name, "expand_bits_ratio")) {
         FGPU_REQUIRE(value >= 1 && value <= 1024, FGPU_INVALID, "expand_bits_ratio out of range");
         ctx->opt.expand_bits_ratio = (int)value;

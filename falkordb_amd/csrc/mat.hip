@@ -65,7 +65,7 @@ void mat_release(fgpu_mat* m) {
     if (c) c->dev_free(m->bp_items);
     if (c) c->dev_free(m->bp_sitems);
     if (c) c->dev_free(m->bp_split_bits);
-    if (m->bp_hot) bp_hot_release(c, m->bp_hot);
+    if (m->bp_xplan) bp_xplan_release(c, m->bp_xplan);
     if (m->pr_parts) pr_parts_release(c, m->pr_parts);
     if (m->tcache) mat_release(m->tcache);
     delete m;

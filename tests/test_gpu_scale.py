@@ -73,42 +73,55 @@ def test_khop_rmat20_dirty_layers_match_the_oracle(ctx, rmat20, mode):
 
 @pytest.fixture(scope="module")
 def rmat20_refs(rmat20):
+    """(nnz, checksum, flops) of the 3-hop chain at RMAT-20 for source sets of 100 / 200 / 400 / 640 rows — bit rows of 2 / 4 /
+    8 / 16 words, every width the partitioned count hop serves — clean and dirty; for 400 rows also under a destination label."""
     A, dp, dm, a, hdp, hdm = rmat20
-    src = p_sources(a.nrows, 1024)[:640]                      # 10 words per row -> ws = 16: the bench's row width
+    allsrc = p_sources(a.nrows, 1024)
+    label = oracle.mix64(np.arange(a.nrows, dtype=U64)) % U64(3) != 0
     refs = {}
-    for dirty in (False, True):
-        c, flops, _ = oracle.expand_omp(src, [(a, hdp, hdm) if dirty else (a, None, None)] * 3)
-        refs[dirty] = (c.nnz, oracle.checksum_omp(c), flops)
-        del c
-    return src, refs
+    for nsrc in (100, 200, 400, 640):
+        src = allsrc[:nsrc]
+        for dirty in (False, True):
+            c, flops, _ = oracle.expand_omp(src, [(a, hdp, hdm) if dirty else (a, None, None)] * 3)
+            refs[(nsrc, dirty, False)] = (c.nnz, oracle.checksum_omp(c), flops)
+            if nsrc == 400:
+                keep = label[c.colidx.astype(np.int64)]
+                rows = np.repeat(np.arange(c.nrows), np.diff(c.rowptr).astype(np.int64))[keep]
+                rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=c.nrows))]).astype(U64)
+                cl = oracle.CSR(c.nrows, c.ncols, rp, c.colidx[keep])
+                refs[(nsrc, dirty, True)] = (cl.nnz, oracle.checksum_omp(cl), flops)
+            del c
+    return allsrc, refs, oracle.bits_from_ids(a.nrows, np.nonzero(label)[0])
 
 
-@pytest.mark.parametrize("hot_rows,hot_min", [(0, 0), (64, 1), (64, 32), (1024, 8), (16384, 32)])
-def test_khop_rmat20_count_hop_with_xcd_partitioned_hot_rows(ctx, rmat20, rmat20_refs, hot_rows, hot_min):
-    """The dense count hop with the hot rows of X partitioned over the XCDs (bitexpand.hip BpHotPlan): whatever the hot
-    set (64 rows per partition ... the default 16384) and the bar a row of A' must pass to join the hot pass (1 hot entry:
-    almost every row is cut into partial rows; 32: the in-hubs), clean and dirty layers, count-only and checksum forms give
-    the oracle's (nnz, checksum, flops); hot_rows = 0 is the plain pull (expand_hot off — the default: the hot pass measured
-    slower than the plain pull at every setting; it stays in the library as the experiment it was)."""
+@pytest.mark.parametrize("xcd", [1, 0])
+@pytest.mark.parametrize("nsrc", [100, 200, 400, 640])
+def test_khop_rmat20_count_hop_partitioned_by_xcd(ctx, rmat20, rmat20_refs, xcd, nsrc):
+    """The dense count hop in its XCD-partitioned form (bitpart.hip: every entry of A' gathered by the XCD that owns its row of
+    X, partial rows folded per vertex) against the oracle's (nnz, checksum, flops): bit rows of 2 / 4 / 8 / 16 words, clean and
+    dirty layers (the delta fix-ups act on the folded rows of the side buffer), count-only and checksum forms, a destination
+    label; xcd = 0 is the plain pull on the same inputs (the A/B the bench quotes).  expand_xcd_min_mb = 0 forces the form on a
+    state that would otherwise be too small to bother."""
     A, dp, dm, a, hdp, hdm = rmat20
-    src, refs = rmat20_refs
+    allsrc, refs, label_bits = rmat20_refs
+    src = allsrc[:nsrc]
     try:
         ctx.set_option("expand_mode", 2)
-        ctx.set_option("expand_hot", 1 if hot_rows else 0)
-        if hot_rows:
-            ctx.set_option("expand_hot_rows", hot_rows)
-            ctx.set_option("expand_hot_min", hot_min)
+        ctx.set_option("expand_xcd", xcd)
+        ctx.set_option("expand_xcd_min_mb", 0)
         for dirty in (False, True):
             layers = ([A] * 3, [dp] * 3, [dm] * 3) if dirty else ([A] * 3,)
             for _ in range(2):                                 # the second call reuses the plan (and the recycled state)
-                assert engine.expand_count(ctx, src, *layers) == refs[dirty], (hot_rows, hot_min, dirty)
+                assert engine.expand_count(ctx, src, *layers) == refs[(nsrc, dirty, False)], (xcd, nsrc, dirty)
             nn, _, fl = engine.expand_count(ctx, src, *layers, want_checksum=False)
-            assert (nn, fl) == (refs[dirty][0], refs[dirty][2])
+            assert (nn, fl) == (refs[(nsrc, dirty, False)][0], refs[(nsrc, dirty, False)][2])
+            if nsrc == 400:
+                lay = layers if dirty else ([A] * 3, None, None)
+                assert engine.expand_count(ctx, src, *lay, dst_label_bitmap=label_bits) == refs[(nsrc, dirty, True)], (xcd, dirty, "label")
     finally:
         ctx.set_option("expand_mode", 0)
-        ctx.set_option("expand_hot", 0)
-        ctx.set_option("expand_hot_rows", 16384)
-        ctx.set_option("expand_hot_min", 32)
+        ctx.set_option("expand_xcd", 1)
+        ctx.set_option("expand_xcd_min_mb", 32)
 
 
 def test_khop_rmat20_full_rows_match_the_oracle(ctx, rmat20):
