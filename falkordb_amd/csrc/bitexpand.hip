@@ -608,8 +608,17 @@ __global__ __launch_bounds__(256) void bp_split_stats_kernel(const u64* __restri
     const u32 wl = lane & (ln - 1u), slot = lane >> lnsh;
     const u64 field = ln == 64 ? ~0ull : (((1ull << ln) - 1ull) << (slot * ln));
     u64 fl = 0, rows = 0;
-    for (u32 w = wave; w < nwords; w += nwaves) {
-        u64 m = bits[w];                         // wave-uniform
+    // 64 bitmap words per step, a lane each (one dependent load per 4096 vertices instead of one per 64: the ~10^5 split rows
+    // of a hop sit in a bitmap that is almost all zeros, and a wavefront walking it word by word spent 40 us on 32 round trips)
+    for (u32 w0 = wave * 64; w0 < nwords; w0 += nwaves * 64) {
+      const u64 mine = w0 + lane < nwords ? bits[w0 + lane] : 0ull;
+      u64 nzw = __ballot(mine != 0ull);
+      while (nzw) {
+        const u32 j = (u32)__builtin_ctzll(nzw);
+        nzw &= nzw - 1ull;
+        const u32 w = w0 + j;
+        u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine >> 32), (int)j) << 32) |
+                (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine, (int)j);   // wave-uniform
         while (m) {
             u32 v = 0xFFFFFFFFu;
             for (u32 sl = 0; sl < rpw; ++sl) {
@@ -626,6 +635,7 @@ __global__ __launch_bounds__(256) void bp_split_stats_kernel(const u64* __restri
             if (pc) fl += (u64)pc * (next_rowptr[v + 1] - next_rowptr[v]);
             if (wl == 0 && (nz & field)) rows += 1;
         }
+      }
     }
     bp_block_add2(fl, rows, stats);
 }
@@ -1142,7 +1152,10 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     const BpXPlan* xp = nullptr;
     if (ca && t && !will_sparse && !s.lazy && s.ws >= 2 && s.ws <= 16 && (u64)s.n * s.ws * 8 >= (u64)ctx->opt.expand_xcd_min_mb << 20)
         FGPU_TRY(bp_xplan(ctx, m, t, &xp));
-    if (ca) {
+    // clean layers in the partitioned form: the fold completes every row, nothing is "touched" — no bitmap, no prefix, no side
+    // buffer, no read-back (six launches and a host round trip per batch)
+    const bool no_touched = ca && xp && !has_dm && !has_dp;
+    if (ca && !no_touched) {
         const u32 nwords = (n_out + 63) / 64;
         FGPU_TRY(tbits.alloc(ctx, (size_t)nwords + 2));
         if (xp)   // every row is completed by the fold: only the destinations of a delta layer are "touched"
@@ -1167,6 +1180,8 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
         FGPU_TRY(read_u32(ctx, ttot.p, &ntouched));
         FGPU_TRY(side.alloc(ctx, (size_t)(ntouched ? ntouched : 1) * s.ws));
         FGPU_HIP(hipMemsetAsync(side.p, 0, (size_t)(ntouched ? ntouched : 1) * s.ws * sizeof(u64), ctx->stream()));
+    }
+    if (ca) {
         FGPU_TRY(bp_acc_alloc(ctx, acc));
         if (mode == 2) {
             lds = (size_t)s.w * 256 * sizeof(u64);

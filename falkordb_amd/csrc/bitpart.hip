@@ -51,6 +51,8 @@ struct BpXPlan {
     u32* cstart = nullptr;         // first entry of the chunk
     u32* crun0 = nullptr;          // run (= partial row) of the chunk's first entry
     uint8_t* cshared = nullptr;    // 1: that run began in an earlier chunk (its pieces meet through atomics)
+    u32* zrows = nullptr;          // the partial rows that receive pieces from several chunks (zeroed before every hop)
+    u32 nzrows = 0;
     u64* ne = nullptr;             // [8][ng] bit r: (partition, row 64 g + r) has entries
     u32* pbase = nullptr;          // [8][ng] partial row of the group's first non-empty row
 };
@@ -58,7 +60,7 @@ struct BpXPlan {
 void bp_xplan_release(fgpu_ctx* ctx, BpXPlan* p) {
     if (!p) return;
     if (ctx) {
-        ctx->dev_free(p->pcol); ctx->dev_free(p->pstart_dev); ctx->dev_free(p->cstart); ctx->dev_free(p->crun0); ctx->dev_free(p->cshared);
+        ctx->dev_free(p->pcol); ctx->dev_free(p->pstart_dev); ctx->dev_free(p->cstart); ctx->dev_free(p->crun0); ctx->dev_free(p->cshared); ctx->dev_free(p->zrows);
         ctx->dev_free(p->ne); ctx->dev_free(p->pbase);
     }
     delete p;
@@ -150,6 +152,12 @@ __global__ void xp_chunks_kernel(const u32* __restrict__ off, const u32* __restr
     }
 }
 
+__global__ void xp_shared_rows_kernel(const u32* __restrict__ crun0, const uint8_t* __restrict__ cshared, u32 nchunks,
+                                      u32* __restrict__ zrows, u32* __restrict__ count) {
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c < nchunks && cshared[c]) zrows[atomicAdd(count, 1u)] = crun0[c];   // (a run over several chunks is listed once per chunk: harmless)
+}
+
 fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const BpXPlan** out) {
     *out = nullptr;
     if (!ctx->opt.expand_xcd || !t || t->is_hyper()) return FGPU_OK;
@@ -210,6 +218,16 @@ fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const Bp
     hipLaunchKernelGGL(xp_chunks_kernel, dim3(ctx->cus * 16), dim3(256), 0, st, (const u32*)off.p, (const u32*)ridx.p, n,
                        (const u32*)xp->pstart_dev, xp->cstart, xp->crun0, xp->cshared);
     FGPU_HIP(hipGetLastError());
+    {   // the shared rows, compacted once (a few thousand among ~10^5 chunks)
+        DevBuf<u32> zc;
+        FGPU_TRY(zc.alloc(ctx, 1));
+        FGPU_HIP(hipMemsetAsync(zc.p, 0, sizeof(u32), st));
+        FGPU_TRY(ctx->dev_alloc((void**)&xp->zrows, ((size_t)xp->nchunks + 1) * sizeof(u32)));
+        hipLaunchKernelGGL(xp_shared_rows_kernel, dim3(cdiv(xp->nchunks ? xp->nchunks : 1, 256)), dim3(256), 0, st, (const u32*)xp->crun0,
+                           (const uint8_t*)xp->cshared, xp->nchunks, xp->zrows, zc.p);
+        FGPU_HIP(hipGetLastError());
+        FGPU_TRY(read_u32(ctx, zc.p, &xp->nzrows));
+    }
     FGPU_HIP(hipStreamSynchronize(st));
     xp->usable = true;
     *out = xp;
@@ -226,11 +244,10 @@ __device__ __forceinline__ void atomic_or4(uint4* dst, uint4 v) {
 }
 
 // partial rows that receive pieces from several chunks start from zero
-__global__ __launch_bounds__(256) void xp_zero_shared_kernel(const u32* __restrict__ crun0, const uint8_t* __restrict__ cshared, u32 nchunks,
-                                                             u32 ql, uint4* __restrict__ partial) {
+__global__ __launch_bounds__(256) void xp_zero_rows_kernel(const u32* __restrict__ rows, u32 nrows, u32 ql, uint4* __restrict__ partial) {
     const u32 per = 256 / ql;
-    for (u32 c = blockIdx.x * per + threadIdx.x / ql; c < nchunks; c += gridDim.x * per)
-        if (cshared[c]) partial[(size_t)crun0[c] * ql + threadIdx.x % ql] = make_uint4(0, 0, 0, 0);
+    for (u32 i = blockIdx.x * per + threadIdx.x / ql; i < nrows; i += gridDim.x * per)
+        partial[(size_t)rows[i] * ql + threadIdx.x % ql] = make_uint4(0, 0, 0, 0);
 }
 
 // the stream pull: QL lanes of 16 bytes per row of X (ws = 2 QL words), 64 / QL slots per wavefront, QL consecutive entries
@@ -240,9 +257,8 @@ template <int QL, bool WIDE>
 __global__ __launch_bounds__(256) void xp_stream_kernel(const u32* __restrict__ pcol, const u32* __restrict__ pstart,
                                                         const u32* __restrict__ cstart, const u32* __restrict__ crun0,
                                                         const uint8_t* __restrict__ cshared, const uint4* __restrict__ x,
-                                                        uint4* __restrict__ partial, u32 dbg) {
+                                                        uint4* __restrict__ partial) {
     constexpr int SLOTS = 64 / QL;
-    const u32 dbg_mask = (dbg & 2u) ? 0xFFu : (dbg & 4u) ? 0xFFFFu : 0x7FFFFFFFu;   // EXPERIMENT: gather from a hot subset of X
     extern __shared__ uint4 s_tile[];                        // per wavefront XP_RUNS rows (the runs of one chunk) x QL quads
     const u32 lane = lane_id(), wl = lane % QL, slot = lane / QL, wib = threadIdx.x >> 6;
     uint4* tile = s_tile + (size_t)wib * XP_RUNS * QL;
@@ -271,13 +287,6 @@ __global__ __launch_bounds__(256) void xp_stream_kernel(const u32* __restrict__ 
             const u32 fb = (u32)(mask >> (slot * QL));       // bit k: entry k of this slot starts a run
             u32 row = base + (u32)__popcll(mask & upto);     // tile row (= run of the chunk) of the slot's first entry
             uint4 acc = xv[0];
-            if (dbg & 1u) {                                  // EXPERIMENT: no LDS flushes
-#pragma unroll
-                for (int k = 1; k < QL; ++k) acc = or4(acc, xv[k]);
-                if (acc.x == 0x12345u) tile64[0] = acc.y;
-                base += (u32)__popcll(mask);
-                return;
-            }
 #pragma unroll
             for (int k = 1; k < QL; ++k) {
                 if ((fb >> k) & 1u) {
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(256) void xp_stream_kernel(const u32* __restrict__ 
 #define XP_COL(T) pcol[(T) + lane < E ? (T) + lane : E - 1]
 #define XP_GATHER(XV, CW)                                                                                   \
         _Pragma("unroll") for (int k = 0; k < QL; ++k) {                                                    \
-            const u32 uk = (u32)__shfl((int)(CW), (int)(slot * QL + k), 64) & dbg_mask;                     \
+            const u32 uk = (u32)__shfl((int)(CW), (int)(slot * QL + k), 64) & ~XP_FIRST;                    \
             if (WIDE) XV[k] = *reinterpret_cast<const uint4*>(xb + (size_t)uk * (QL * 16));                 \
             else XV[k] = *reinterpret_cast<const uint4*>(xb + (u32)(uk * (u32)(QL * 16)));                  \
         }
@@ -372,8 +381,8 @@ __global__ __launch_bounds__(256) void xp_fold_kernel(const u64* __restrict__ ne
             any |= nw[k];
         }
         if (!any) continue;
-        const u64 tw = fin.tbits[g];
-        const u32 tp = fin.tpref[g];
+        const u64 tw = fin.tbits ? fin.tbits[g] : 0ull;      // (clean layers: no touched rows, no bitmap)
+        const u32 tp = fin.tbits ? fin.tpref[g] : 0u;
         const u64 lb = fin.label ? fin.label[g] : ~0ull;
 #pragma unroll 1
         for (u32 r0 = 0; r0 < 64; r0 += SLOTS) {
@@ -391,28 +400,27 @@ __global__ __launch_bounds__(256) void xp_fold_kernel(const u64* __restrict__ ne
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if ((nw[k] >> r) & 1ull) a = or4(a, pv[k]);
-            if (!any4(a)) continue;
-            const u32 v = g * 64 + r;
-            if ((tw >> r) & 1ull) {
+            const bool touched = (tw >> r) & 1ull;
+            const bool counted = !touched && ((lb >> r) & 1ull);
+            if (touched && any4(a)) {
                 const u32 sl = tp + (u32)__popcll(tw & below);
                 side[(size_t)sl * QL + wl] = a;              // the only writer of this slot before the delta fix-ups
-            } else if ((lb >> r) & 1ull) {
-                f_cnt += (u64)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w));
-                if (MODE == 2) {
-                    const u64* t0 = s_tab + (size_t)(2 * wl) * 256;
-                    const u64* t1 = t0 + 256;
-                    const u64 w0 = ((u64)a.y << 32) | a.x, w1 = ((u64)a.w << 32) | a.z;
-                    u64 rs = 0;                             // (a non-zero word has an index below fin.w: the tables cover it)
-                    if (w0) {
+            }
+            const u32 pc = (u32)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w));
+            f_cnt += counted ? (u64)pc : 0ull;
+            if (MODE == 2) {
+                // (an all-zero word looks up entry 0 of its tables — zero — so nothing needs a test: words at or past fin.w are
+                // zero by construction and their tables, past the end of s_tab, are never multiplied in)
+                const u64 w0 = counted ? (((u64)a.y << 32) | a.x) : 0ull, w1 = counted ? (((u64)a.w << 32) | a.z) : 0ull;
+                const u32 k0 = 2 * wl < fin.w ? 2 * wl : 0u, k1 = 2 * wl + 1 < fin.w ? 2 * wl + 1 : 0u;
+                const u64* t0 = s_tab + (size_t)k0 * 256;
+                const u64* t1 = s_tab + (size_t)k1 * 256;
+                u64 rs = 0;
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) rs += t0[j * 16 + (u32)((w0 >> (4 * j)) & 15ull)];
-                    }
-                    if (w1) {
+                for (int j = 0; j < 16; ++j) rs += t0[j * 16 + (u32)((w0 >> (4 * j)) & 15ull)];
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) rs += t1[j * 16 + (u32)((w1 >> (4 * j)) & 15ull)];
-                    }
-                    f_sum += rs * cs_dest_hash(v);
-                }
+                for (int j = 0; j < 16; ++j) rs += t1[j * 16 + (u32)((w1 >> (4 * j)) & 15ull)];
+                f_sum += rs * cs_dest_hash(g * 64 + r);
             }
         }
     }
@@ -427,11 +435,10 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
     hipStream_t st = ctx->stream();
     DevBuf<uint4> partial;
     FGPU_TRY(partial.alloc(ctx, ((size_t)xp->nprows + 1) * ql));
-    {
-        u32 zg = cdiv(xp->nchunks, 256 / ql);
+    if (xp->nzrows) {
+        u32 zg = cdiv(xp->nzrows, 256 / ql);
         if (zg > (u32)ctx->cus * 4) zg = ctx->cus * 4;
-        hipLaunchKernelGGL(xp_zero_shared_kernel, dim3(zg ? zg : 1), dim3(256), 0, st, (const u32*)xp->crun0, (const uint8_t*)xp->cshared,
-                           xp->nchunks, ql, partial.p);
+        hipLaunchKernelGGL(xp_zero_rows_kernel, dim3(zg), dim3(256), 0, st, (const u32*)xp->zrows, xp->nzrows, ql, partial.p);
         FGPU_HIP(hipGetLastError());
     }
     const u64 prow_bytes = (u64)xp->nprows * ws * 8;
@@ -447,12 +454,11 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
         u32 grid = (u32)ctx->cus * per_cu;
         const u32 need = 8 * cdiv(most ? most : 1, 4);
         if (grid > need) grid = need;
-        if (ctx->opt.expand_xcd_dbg >> 8) { const u32 g2 = (u32)ctx->cus * (u32)(ctx->opt.expand_xcd_dbg >> 8); if (g2 < grid) grid = g2; }   // EXPERIMENT: workgroups per CU
         grid = (grid + 7) & ~7u;
         const bool wide = (u64)xp->n * ws * 8 > (1ull << 32) || (u64)t->ncols * ws * 8 > (1ull << 32);
 #define XP_PULL2(Q, W) hipLaunchKernelGGL((xp_stream_kernel<Q, W>), dim3(grid), dim3(256), lds, st, (const u32*)xp->pcol,        \
                                           (const u32*)xp->pstart_dev, (const u32*)xp->cstart, (const u32*)xp->crun0,           \
-                                          (const uint8_t*)xp->cshared, (const uint4*)x, partial.p, (u32)ctx->opt.expand_xcd_dbg)
+                                          (const uint8_t*)xp->cshared, (const uint4*)x, partial.p)
 #define XP_PULL(Q) do { if (wide) XP_PULL2(Q, true); else XP_PULL2(Q, false); } while (0)
         switch (ql) {
             case 1: XP_PULL(1); break;
@@ -474,7 +480,7 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
             if (lds > 48 * 1024)                                                                                                 \
                 FGPU_HIP(hipFuncSetAttribute((const void*)xp_fold_kernel<Q, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL((xp_fold_kernel<Q, M>), dim3(grid), dim3(256), lds, st, (const u64*)xp->ne, (const u32*)xp->pbase, xp->ng,  \
-                               (const uint4*)partial.p, fin, (uint4*)side);                                                      \
+                               (const uint4*)partial.p, fin, (uint4*)side);                                                                                     \
         } while (0)
 #define XP_FOLD(Q) do { if (mode == 2) XP_FOLD2(Q, 2); else XP_FOLD2(Q, 1); } while (0)
         switch (ql) {

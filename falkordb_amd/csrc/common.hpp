@@ -94,7 +94,6 @@ struct fgpu_options {  // fgpu_set_option
     int expand_first_hop = 1;  // fgpu_expand*: a clean first hop from one-entry rows copies the source rows (0 = the general product; A/B)
     int expand_xcd = 1;        // dense count hop of the bit-parallel chain: 1 = the rows of X are gathered by the XCD that owns their
                                // partition, partial rows folded per vertex (bitpart.hip), 0 = every workgroup gathers from all of X (A/B)
-    int expand_xcd_dbg = 0;    // EXPERIMENT switches of the partitioned pull (results are wrong with any of them set)
     int expand_xcd_min_mb = 32; // ... when the bit state holds at least this many MiB (8 L2s of 4 MiB; below that the plain pull)
     int pinned_results = 1;    // result arrays >= 256 KiB come from the context's pinned-host pool and are filled by DMA (0 = the
                                // caller's allocator / malloc + staged copies, the round-3 path; A/B)

@@ -73,13 +73,14 @@ def test_khop_rmat20_dirty_layers_match_the_oracle(ctx, rmat20, mode):
 
 @pytest.fixture(scope="module")
 def rmat20_refs(rmat20):
-    """(nnz, checksum, flops) of the 3-hop chain at RMAT-20 for source sets of 100 / 200 / 400 / 640 rows — bit rows of 2 / 4 /
-    8 / 16 words, every width the partitioned count hop serves — clean and dirty; for 400 rows also under a destination label."""
+    """(nnz, checksum, flops) of the 3-hop chain at RMAT-20 for source sets of 100 / 160 / 200 / 400 / 640 rows — bit rows of 2 /
+    4 (three in use) / 4 / 8 / 16 words, every width the partitioned count hop serves — clean and dirty; for 400 rows also under
+    a destination label."""
     A, dp, dm, a, hdp, hdm = rmat20
     allsrc = p_sources(a.nrows, 1024)
     label = oracle.mix64(np.arange(a.nrows, dtype=U64)) % U64(3) != 0
     refs = {}
-    for nsrc in (100, 200, 400, 640):
+    for nsrc in (100, 160, 200, 400, 640):
         src = allsrc[:nsrc]
         for dirty in (False, True):
             c, flops, _ = oracle.expand_omp(src, [(a, hdp, hdm) if dirty else (a, None, None)] * 3)
@@ -95,7 +96,7 @@ def rmat20_refs(rmat20):
 
 
 @pytest.mark.parametrize("xcd", [1, 0])
-@pytest.mark.parametrize("nsrc", [100, 200, 400, 640])
+@pytest.mark.parametrize("nsrc", [100, 160, 200, 400, 640])
 def test_khop_rmat20_count_hop_partitioned_by_xcd(ctx, rmat20, rmat20_refs, xcd, nsrc):
     """The dense count hop in its XCD-partitioned form (bitpart.hip: every entry of A' gathered by the XCD that owns its row of
     X, partial rows folded per vertex) against the oracle's (nnz, checksum, flops): bit rows of 2 / 4 / 8 / 16 words, clean and

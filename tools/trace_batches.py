@@ -17,10 +17,10 @@ for r in rows:
     cur.append((name[:44], (en - st) / 1000, gap))
     last = en
 batches.append(cur)
-big = [b for b in batches if any('bp_pull_kernel' in k[0] for k in b)]
+big = [b for b in batches if any('bp_pull_kernel' in k[0] or 'xp_stream' in k[0] for k in b)]
 print(len(batches), 'segments,', len(big), 'with a bit-parallel pull')
 for b in big[first:first + count]:
     busy = sum(d for _, d, _ in b); idle = sum(g for _, _, g in b[1:])
     print(f'--- batch: {len(b)} kernels, busy {busy:.0f} us, idle between kernels {idle:.0f} us, lead-in gap {b[0][2]:.0f} us')
     for k, d, g in b:
-        if d > 8 or g > 8: print(f'   {k:44s} {d:8.1f} us   (+{g:.1f} idle before)')
+        if d > 0 or g > 8: print(f'   {k:44s} {d:8.1f} us   (+{g:.1f} idle before)')
