@@ -158,6 +158,26 @@ def bfs_threads_child(args, scale, threads=3, steps=128, warmup=16, timeout_s=15
         return {"error": repr(e)}
 
 
+def operator_child(scale=20, timeout_s=200):
+    """CondTraverseOp::expand_batch (the drop-in unit: label probes, layer waits, the chain, the two result columns) beside
+    the bare fgpu_expand of the same 1024-source 2-hop batch — tools/bench_paths.py host, in a child process with a deadline
+    (the host layer loads its graph edge by edge: ~50 s at RMAT-20, which is why this leg is not run at RMAT-22 here;
+    profiles/ holds the RMAT-22 run)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_paths.py"), "host", str(scale)], capture_output=True,
+                           text=True, timeout=timeout_s, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"did not finish within {timeout_s} s"}
+    for l in r.stdout.splitlines()[::-1]:
+        if l.startswith("{") and "host_expand_batch" in l:
+            d = json.loads(l)
+            return {"scale": d["scale"], "rows_out": d["rows_out"], "ms_operator": d["ms_cpp_expand_batch"],
+                    "ms_bare_fgpu_expand": d["ms_bare_fgpu_expand"],
+                    "ratio": round(d["ms_cpp_expand_batch"] / max(d["ms_bare_fgpu_expand"], 1e-9), 3), "graph_load_s": d["graph_load_s"]}
+    return {"error": (r.stderr or r.stdout)[-200:]}
+
+
 def probe_reference_libs():
     """look for the reference's own CPU libraries on this box before falling back to the port.  They
     are not part of this image (no SuiteSparse:GraphBLAS, no LAGraph, no python-graphblas), so the expected answer is
@@ -1230,6 +1250,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle checks")
     ap.add_argument("--no-bfs", action="store_true", help="skip the BFS / SpMV secondary legs")
     ap.add_argument("--no-varlen", action="store_true", help="skip the config-5 stand-in leg")
+    ap.add_argument("--no-operator", action="store_true", help="skip the CondTraverseOp::expand_batch vs fgpu_expand leg (RMAT-20, ~1 min)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (traffic = committed / null)")
     ap.add_argument("--bfs-steps", type=int, default=64)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -1412,6 +1433,11 @@ def main():
                 "batches": int(nb_v), "TEPS": round(fl_v / dt_v, 1), "ms_per_batch": round(dt_v / max(nb_v, 1) * 1e3, 3),
                 "distinct_pairs": int(un_v)}
             sec["config5_varlen_TEPS"] = detail["config5_varlen"]["TEPS"]
+        # ---- the operator beside the bare device call ----------------------------------------------
+        if not args.no_operator:
+            op = operator_child(20)
+            detail["operator20"] = op
+            sec["operator20"] = {k_: op[k_] for k_ in ("rows_out", "ms_operator", "ms_bare_fgpu_expand", "ratio") if k_ in op} or op
         # ---- HBM traffic per launch, measured now: rocprofv3 --pmc passes over a reduced replay -----------------------
         if not args.no_pmc and not args.no_roofline:
             pmc = live_pmc(args)

@@ -736,6 +736,46 @@ __global__ __launch_bounds__(256) void trail2_count_kernel(CsrView f1, const u64
 
 using namespace fgpu;
 
+// ---- (active_row, dest) columns built on the device (include/fgpu.h fgpu_expand_pairs) ------------------------------------
+// rows the operator may keep: all of a free row, at most the one entry equal to the pinned destination of a pinned row
+__global__ void pairs_len_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ colidx, const u32* __restrict__ pin, u32 nsrc,
+                                 u32* __restrict__ len, u32* __restrict__ pos) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nsrc) return;
+    u32 l = 0, p = 0;
+    if (i < nsrc) {
+        const u32 b = rowptr[i], e = rowptr[i + 1];
+        const u32 want = pin[i];
+        if (want == 0xFFFFFFFFu) { l = e - b; p = b; }
+        else if (want != 0xFFFFFFFEu) {                      // (0xFFFFFFFE: a pinned id beyond 32 bits — no vertex has it)
+            u32 lo = b, hi = e;                              // destinations are ascending and unique per row
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (colidx[mid] < want) lo = mid + 1; else hi = mid;
+            }
+            if (lo < e && colidx[lo] == want) { l = 1; p = lo; }
+        }
+    }
+    len[i] = l;
+    pos[i] = p;
+}
+// a thread per OUTPUT entry: its row by a search of the (new) row pointers, its destination from the row's first kept entry
+template <typename RowT>
+__global__ __launch_bounds__(256) void pairs_fill_kernel(const u32* __restrict__ newptr, const u32* __restrict__ pos,
+                                                         const u32* __restrict__ colidx, u32 nsrc, u64 n,
+                                                         RowT* __restrict__ out_row, u64* __restrict__ out_dest) {
+    for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
+        u32 lo = 0, hi = nsrc - 1;                           // largest row with newptr[row] <= q
+        while (lo < hi) {
+            const u32 mid = (lo + hi + 1) >> 1;
+            if (newptr[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        out_row[q] = (RowT)lo;
+        out_dest[q] = (u64)colidx[pos[lo] + (u32)(q - newptr[lo])];
+    }
+}
+
+
 extern "C" {
 
 static fgpu_info mxm_impl(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* b) {
@@ -766,6 +806,86 @@ fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, con
     fgpu_info i = fgpu_mat_export_csr(ctx, r, out_rowptr, out_dest, &vals, out_nnz);
     mat_release(r);
     return i;
+}
+
+fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                            const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                            const uint64_t* pinned_dest, int row_bits, void** out_row, uint64_t** out_dest, uint64_t* out_n,
+                            uint64_t* flops) {
+    FGPU_REQUIRE(ctx && out_row && out_dest && out_n, FGPU_NULL_POINTER, "fgpu_expand_pairs: NULL argument");
+    FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_pairs: NULL src_ids");
+    FGPU_REQUIRE(row_bits == 16 || row_bits == 32, FGPU_INVALID, "fgpu_expand_pairs: row_bits must be 16 or 32");
+    FGPU_REQUIRE(row_bits == 32 || nsrc <= 65536, FGPU_INVALID, "fgpu_expand_pairs: %llu source rows do not fit 16-bit row indices",
+                 (unsigned long long)nsrc);
+    *out_row = nullptr; *out_dest = nullptr; *out_n = 0;
+    if (flops) *flops = 0;
+    fgpu_mat* r = nullptr;
+    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
+    struct Rel { fgpu_mat* r; ~Rel() { if (r) mat_release(r); } } rel{r};
+    if (nsrc == 0 || r->nnz == 0) return FGPU_OK;
+    hipStream_t st = ctx->stream();
+    const u32 k = (u32)nsrc;
+    DevBuf<u32> pin, len, pos, newptr, total;
+    FGPU_TRY(pin.alloc(ctx, k + 1));
+    FGPU_TRY(len.alloc(ctx, (size_t)k + 1));
+    FGPU_TRY(pos.alloc(ctx, (size_t)k + 1));
+    FGPU_TRY(newptr.alloc(ctx, (size_t)k + 1));
+    FGPU_TRY(total.alloc(ctx, 1));
+    u64 n = r->nnz;
+    const u32* rowptr = r->rowptr;                           // (no pinned row: the result's own row pointers and entries)
+    const u32* first = r->rowptr;
+    if (pinned_dest) {
+        std::vector<u32> hp(k);
+        bool any = false;
+        for (u32 i = 0; i < k; ++i) {
+            hp[i] = pinned_dest[i] == ~0ull ? 0xFFFFFFFFu : pinned_dest[i] >= 0xFFFFFFFEull ? 0xFFFFFFFEu : (u32)pinned_dest[i];
+            any = any || hp[i] != 0xFFFFFFFFu;
+        }
+        if (any) {
+            FGPU_TRY(ctx->h2d(pin.p, hp.data(), (size_t)k * sizeof(u32)));
+            hipLaunchKernelGGL(pairs_len_kernel, dim3(cdiv((u64)k + 1, 256)), dim3(256), 0, st, (const u32*)r->rowptr, (const u32*)r->colidx,
+                               (const u32*)pin.p, k, len.p, pos.p);
+            FGPU_HIP(hipGetLastError());
+            FGPU_TRY(scan_u32(ctx, len.p, newptr.p, (u64)k + 1, total.p));
+            u32 t = 0;
+            FGPU_TRY(read_u32(ctx, total.p, &t));
+            n = t;
+            rowptr = newptr.p;
+            first = pos.p;
+        }
+    }
+    if (n == 0) return FGPU_OK;
+    const size_t rb = row_bits / 8;
+    DevBuf<u64> ddest;
+    DevBuf<uint8_t> drow;
+    FGPU_TRY(ddest.alloc(ctx, n));
+    FGPU_TRY(drow.alloc(ctx, n * rb));
+    {
+        ProfScope ps(ctx, "pairs_fill_kernel", n * (4 + 8 + rb));
+        u32 grid = cdiv(n, 256 * 4);
+        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        if (row_bits == 16)
+            hipLaunchKernelGGL(pairs_fill_kernel<uint16_t>, dim3(grid ? grid : 1), dim3(256), 0, st, rowptr, first, (const u32*)r->colidx, k,
+                               n, (uint16_t*)drow.p, ddest.p);
+        else
+            hipLaunchKernelGGL(pairs_fill_kernel<u32>, dim3(grid ? grid : 1), dim3(256), 0, st, rowptr, first, (const u32*)r->colidx, k, n,
+                               (u32*)drow.p, ddest.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    void* hrow = ctx->result_alloc(n * rb);
+    u64* hdest = (u64*)ctx->result_alloc(n * sizeof(u64));
+    if (!hrow || !hdest) {
+        ctx->host_free(hrow); ctx->host_free(hdest);
+        set_error("fgpu_expand_pairs: host allocation failed");
+        return FGPU_OOM;
+    }
+    fgpu_info i = ctx->d2h(hdest, ddest.p, n * sizeof(u64));
+    if (i == FGPU_OK) i = ctx->d2h(hrow, drow.p, n * rb);
+    if (i != FGPU_OK) { ctx->host_free(hrow); ctx->host_free(hdest); return i; }
+    *out_row = hrow;
+    *out_dest = hdest;
+    *out_n = n;
+    return FGPU_OK;
 }
 
 // ---- streamed result (include/fgpu.h fgpu_expand_stream_*) ----------------------------------------------------------

@@ -22,59 +22,17 @@ from typing import Callable
 
 
 def _lib():
-    """libfgpu.so when it can be loaded (its partition functions are pure host code, but the library links the HIP
-    runtime); None on a box without ROCm — the CPU launcher / gloo tests then use the Python restatement below, which
-    tests/test_gpu_dist.py holds equal to the library's arithmetic."""
-    try:
-        from . import _ffi
-        return _ffi.load(), _ffi
-    except (OSError, ImportError, AttributeError, RuntimeError):
-        return None, None
-
-
-def _slab_layout_py(n: int, nranks: int, splits=None):
-    """fgpu_slab_layout (dist.hip) restated: equal slabs = ceil(n / nranks) rounded up to 4096 vertices per rank."""
-    if nranks < 1:
-        raise ValueError("slab_layout: nranks must be >= 1")
-    per = (n + nranks - 1) // nranks
-    slab = (per + 4095) & ~4095
-    lo = [int(splits[r]) if splits is not None else slab * r for r in range(nranks)]
-    hi = [int(splits[r + 1]) if splits is not None else slab * (r + 1) for r in range(nranks)]
-    for l, h in zip(lo, hi):
-        if h < l or l % 4096 or h % 4096:
-            raise ValueError("slab_layout: boundaries must ascend in multiples of 4096")
-    return lo, hi, [l // 64 for l in lo], [(h - l) // 64 for l, h in zip(lo, hi)]
-
-
-def _balanced_splits_py(block_counts, n: int, nparts: int, shift: int = 12):
-    """fgpu_balanced_splits_from_hist (dist.hip) restated: boundary k = the block edge whose entry prefix is nearest to
-    k * nnz / nparts (edges never move backwards), clamped to the padded vertex count."""
-    if nparts < 1 or not 12 <= shift < 40:
-        raise ValueError("balanced_splits: bad nparts / shift")
-    top = ((n + 4095) >> 12) << 12
-    pre = [0]
-    for c in block_counts:
-        pre.append(pre[-1] + int(c))
-    nb, nnz = len(pre) - 1, pre[-1]
-    out, j = [0], 0
-    for k in range(1, nparts):
-        t = float(nnz) * float(k) / float(nparts)
-        while j < nb and abs(float(pre[j + 1]) - t) <= abs(float(pre[j]) - t):
-            j += 1
-        out.append(min(j << shift, top))
-    out.append(top)
-    return out
+    """libfgpu.so: the ONE definition of the partition arithmetic (fgpu_slab_layout / fgpu_balanced_splits_from_hist /
+    fgpu_splits_shift, pure host functions of dist.hip).  The launchers, the bench and the CPU (gloo) tests all call it —
+    there is no Python restatement beside it; a box where the library cannot be loaded cannot run the product either."""
+    from . import _ffi
+    return _ffi.load(), _ffi
 
 
 def splits_shift(ncols: int) -> int:
     """fgpu_splits_shift: log2 of the column-block width of the balancing histogram (at most 8192 blocks)."""
     lib, _ = _lib()
-    if lib is not None:
-        return int(lib.fgpu_splits_shift(int(ncols)))
-    shift = 12
-    while ((ncols + (1 << shift) - 1) >> shift) > 8192:
-        shift += 1
-    return shift
+    return int(lib.fgpu_splits_shift(int(ncols)))
 
 
 def slab_layout(n: int, nranks: int, splits=None):
@@ -82,8 +40,6 @@ def slab_layout(n: int, nranks: int, splits=None):
     range [lo, hi) and its (word offset, word count) in the global frontier bitmap.  splits=None: the equal slabs of
     fgpu_bfs_plan_create."""
     lib, ffi = _lib()
-    if lib is None:
-        return _slab_layout_py(int(n), int(nranks), splits)
     import ctypes as C
 
     import numpy as np
@@ -105,8 +61,6 @@ def balanced_splits(block_counts, n: int, nparts: int, shift: int = 12):
     whose column lies in block b of 2**shift columns; boundary k is the block edge whose entry prefix is nearest to
     k * nnz / nparts; boundaries are multiples of 4096, start at 0 and end at n rounded up to 4096."""
     lib, ffi = _lib()
-    if lib is None:
-        return _balanced_splits_py(block_counts, int(n), int(nparts), int(shift))
     import ctypes as C
 
     import numpy as np

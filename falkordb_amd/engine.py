@@ -617,3 +617,27 @@ def bench_spmv(ctx: Context, A: Mat, which=0, iters=20):
     ab = C.c_uint64()
     check(ctx.lib.fgpu_bench_spmv(ctx._h, A._h, which, iters, C.byref(ms), C.byref(ab)))
     return ms.value, ab.value
+
+
+def expand_pairs(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None, pinned_dest=None, row_bits=16):
+    """fgpu_expand_pairs: the (active_row, dest) columns CondTraverseOp::expand_batch hands on, built on the device;
+    pinned_dest[i] = a pre-bound destination of source row i, or 2**64 - 1.  Returns (rows, dest, flops) as numpy arrays."""
+    src = _u64(src_ids)
+    am = _hop_arrays(m)
+    adp = _hop_arrays(dp) if dp is not None else None
+    adm = _hop_arrays(dm) if dm is not None else None
+    lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
+    pin = _u64(pinned_dest) if pinned_dest is not None else None
+    prow, pdest = C.c_void_p(), u64p()
+    n, flops = C.c_uint64(), C.c_uint64()
+    check(ctx.lib.fgpu_expand_pairs(ctx._h, _p(src), len(src), am, adp, adm, len(m), _p(lab), _p(pin), int(row_bits),
+                                    C.byref(prow), C.byref(pdest), C.byref(n), C.byref(flops)))
+    k = n.value
+    if k == 0:
+        return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64), flops.value
+    rt = np.uint16 if row_bits == 16 else np.uint32
+    rows = np.ctypeslib.as_array(C.cast(prow, C.POINTER(C.c_uint16 if row_bits == 16 else C.c_uint32)), shape=(k,)).astype(np.uint64)
+    dest = np.ctypeslib.as_array(pdest, shape=(k,)).copy()
+    ctx.lib.fgpu_free(ctx._h, prow)
+    ctx.lib.fgpu_free(ctx._h, pdest)
+    return rows, dest, flops.value

@@ -457,13 +457,25 @@ int fh_cond_traverse_batch(fh_graph* g, const char* spec, const int64_t* src, co
         bool ok = op.expand_batch(g->g, s, to_bound ? &tb : nullptr, rows, nulls, &fl);
         g_last_op_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         *batched = ok ? 1 : 0;
+        const size_t n_rows = rows.size();
         int64_t* e = (int64_t*)malloc((rows.size() ? rows.size() : 1) * sizeof(int64_t));
         if (rows.edge.empty()) memset(e, 0xFF, (rows.size() ? rows.size() : 1) * sizeof(int64_t));   // -1: none
         else memcpy(e, rows.edge.data(), rows.size() * sizeof(int64_t));
-        *out_row = hand(rows.active_row);
-        *out_dest = hand(rows.dest);
+        if (rows.pinned()) {                                 // the harness wants malloc'ed u64 arrays: copy out of the pinned columns
+            const size_t nn = rows.size();
+            u64* r_ = (u64*)malloc((nn ? nn : 1) * sizeof(u64));
+            u64* d_ = (u64*)malloc((nn ? nn : 1) * sizeof(u64));
+            for (size_t q = 0; q < nn; ++q) r_[q] = rows.row_pin[q];
+            if (nn) memcpy(d_, rows.dest_pin, nn * sizeof(u64));
+            *out_row = r_;
+            *out_dest = d_;
+            rows.release_pinned();                           // (not kept across calls: the context may be gone before this thread is)
+        } else {
+            *out_row = hand(rows.active_row);
+            *out_dest = hand(rows.dest);
+        }
         *out_edge = e;
-        *n = rows.size();
+        *n = n_rows;
         *null_rows = hand(nulls);
         *n_null = nulls.size();
         if (flops) *flops = fl;

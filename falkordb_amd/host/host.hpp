@@ -375,6 +375,10 @@ class Graph {
         int32_t* level_pin = nullptr;
         int64_t* parent_pin = nullptr;
         u64 pin_rows = 0;
+        // one search at a time runs on the cached plan AND reads its pinned result blocks: the reference's worker pool calls
+        // algo.BFS on a shared const Graph from several threads (threadpool.rs:89-128); a second caller that finds the plan
+        // busy takes the one-shot path with vectors of its own instead of waiting
+        std::mutex mu;
         BfsPlanCache(Matrix a, Matrix at) : adj(std::move(a)), adj_t(std::move(at)) {}
         ~BfsPlanCache() {
             if (plan) fgpu_bfs_plan_free(plan);
@@ -383,6 +387,7 @@ class Graph {
         }
     };
     mutable std::shared_ptr<BfsPlanCache> bfs_cache_;
+    mutable std::mutex bfs_cache_mu_;      // orders readers and replacers of bfs_cache_ (the entry itself has its own lock)
     // the same for a partitioned search over a gang of contexts: balanced splits, one column slab (+ transpose) and one
     // slab plan per device — building them costs far more than a search, so they live as long as the
     // adjacency snapshot, the relationship filter and the gang stay the same
@@ -431,8 +436,24 @@ struct ExpandedRows {
     std::vector<u64> active_row;   // index into the input batch
     std::vector<u64> dest;
     std::vector<u64> edge;         // empty unless bind_relationship
-    size_t size() const { return dest.size(); }
-    void clear() { active_row.clear(); dest.clear(); edge.clear(); }
+    // The batched path hands over the two columns as the DEVICE built them (fgpu_expand_pairs): pinned blocks of the context's
+    // pool filled by DMA, 16-bit row indices (a child batch holds at most 1024 rows, batch.rs:81).  They are owned until
+    // clear(); materialize() copies them into the vectors above for the rare consumers that edit the columns in place.
+    fgpu_ctx* pin_ctx = nullptr;
+    const uint16_t* row_pin = nullptr;
+    const u64* dest_pin = nullptr;
+    size_t n_pin = 0;
+    ExpandedRows() = default;
+    ExpandedRows(const ExpandedRows&) = delete;
+    ExpandedRows& operator=(const ExpandedRows&) = delete;
+    ~ExpandedRows() { release_pinned(); }
+    bool pinned() const { return dest_pin != nullptr; }
+    size_t size() const { return pinned() ? n_pin : dest.size(); }
+    u64 row_at(size_t i) const { return pinned() ? (u64)row_pin[i] : active_row[i]; }
+    u64 dest_at(size_t i) const { return pinned() ? dest_pin[i] : dest[i]; }
+    void release_pinned();
+    void materialize();
+    void clear() { active_row.clear(); dest.clear(); edge.clear(); release_pinned(); }
 };
 
 // CondTraverseOp (runtime/ops/cond_traverse.rs).  Only the matrix path and its eligibility rule are

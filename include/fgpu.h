@@ -251,6 +251,20 @@ fgpu_info fgpu_expand_mat(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
                           const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
                           fgpu_mat** out, uint64_t* flops);
 
+/* The same chain with the result as the two COLUMNS CondTraverseOp::expand_batch hands on (cond_traverse.rs:644-751: walk
+ * (row_i, dest) ascending; drop a destination that differs from a pre-bound `to`, :657-661; emit `gather(out_indices)` +
+ * NodeIds): out_row[q] = index of the source row of pair q (uint16_t or uint32_t per `row_bits`; a child batch holds at most
+ * 1024 rows, batch.rs:81), out_dest[q] = its destination, pairs ascending by (row, dest).  `pinned_dest` (nullable, nsrc
+ * entries): ~0 = the row keeps every destination, anything else = the row keeps only that destination if it is reached.  Both
+ * columns are built on the device (row indices expanded from the row pointers, the pinned rows cut down by a binary search)
+ * and arrive by DMA in pinned blocks of the context's pool — the host never walks the result.  Release both with fgpu_free;
+ * *out_n = 0 leaves both NULL. */
+fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                            const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                            const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                            const uint64_t* pinned_dest, int row_bits, void** out_row, uint64_t** out_dest,
+                            uint64_t* out_n, uint64_t* flops);
+
 /* The same chain with the result STREAMED to the host in chunks of whole source rows — the shape in which
  * CondTraverseOp::expand_batch consumes it (cond_traverse.rs:644-751: walk (row_i, dest) ascending, emit an output batch
  * every 1024 pairs): the chain runs once, F stays on the device, and chunks of at most `chunk_rows` consecutive source

@@ -1008,6 +1008,43 @@ def test_algo_bfs_matches_the_oracle_on_rmat(rnd_graph):     # algo_procedures.r
             assert d == v and level[s] + 1 == level[v]
 
 
+def test_algo_bfs_from_several_threads_on_one_graph(rnd_graph):
+    """the reference's worker pool runs algo.BFS on a shared const Graph from several threads
+    (threadpool.rs:89-128).  The cached plan and its pinned level / parent blocks belong to ONE search at a time: a caller
+    that finds them busy takes the one-shot path with arrays of its own.  Eight threads x different sources, every result
+    must equal the same call made alone."""
+    import threading
+    g, og, n, per_type = rnd_graph
+    deg = {}
+    for (s, d) in og.adjacency.extract():
+        deg[s] = deg.get(s, 0) + 1
+    srcs = sorted(deg, key=deg.get, reverse=True)[:8]
+    alone = {s: g.algo_bfs(s, -1, None, want_edges=False) for s in srcs}
+    for s in srcs:
+        want = model.algo_bfs(og, s, -1, None, want_edges=False)
+        assert alone[s][0] == want[0]
+    got, errs = {}, []
+    gate = threading.Barrier(len(srcs))
+
+    def work(s):
+        try:
+            gate.wait()
+            for _ in range(6):
+                r = g.algo_bfs(s, -1, None, want_edges=False)
+                if r != alone[s]:
+                    errs.append((s, "differs from the call made alone"))
+            got[s] = r
+        except Exception as e:   # noqa: BLE001
+            errs.append((s, repr(e)))
+    ts = [threading.Thread(target=work, args=(s,)) for s in srcs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs[:3]
+    assert got == alone
+
+
 def test_algo_bfs_partitioned_over_a_gang_of_contexts(rnd_graph, hctx):
     """libfalkor_host's algo.BFS over several contexts (here three contexts on the one device): nnz-balanced
     column slabs, level loop + frontier exchange inside libfgpu.so (fgpu_bfs_dist_run) — everything through

@@ -709,6 +709,55 @@ def test_expand_stream_chunks_concatenate_to_the_oracle_result(ctx, rmat18, chun
     st.close()
 
 
+@pytest.mark.parametrize("row_bits", [16, 32])
+def test_expand_pairs_columns_match_the_oracle_with_and_without_pinned_rows(ctx, rmat18, row_bits):
+    """fgpu_expand_pairs: the (active_row, dest) columns of CondTraverseOp::expand_batch (cond_traverse.rs:644-751) built on
+    the device — every pair of the oracle's chain in (row, dest) order; with pre-bound `to` values (:657-661) a pinned row
+    keeps exactly its pinned destination when the chain reaches it and nothing otherwise, free rows are untouched; a
+    destination label filters first; a batch with no result and a pinned id no vertex carries."""
+    A, a = rmat18
+    src = np.arange(5, a.nrows, 1531, dtype=U64)
+    k = len(src)
+    c, flops, _ = oracle.expand_omp(src, [(a, None, None)] * 2)
+    ref_rows = np.repeat(np.arange(k, dtype=U64), np.diff(c.rowptr).astype(np.int64))
+    rows, dest, fl = engine.expand_pairs(ctx, src, [A, A], row_bits=row_bits)
+    assert fl == flops
+    np.testing.assert_array_equal(rows, ref_rows)
+    np.testing.assert_array_equal(dest, c.colidx)
+    # pinned rows: every third row pinned to one of its own destinations, every fifth to a vertex it does not reach
+    rng = np.random.default_rng(7)
+    pin = np.full(k, 2 ** 64 - 1, dtype=U64)
+    want_r, want_d = [], []
+    for i in range(k):
+        row = c.colidx[int(c.rowptr[i]):int(c.rowptr[i + 1])]
+        if i % 3 == 0 and len(row):
+            pin[i] = row[rng.integers(0, len(row))]
+            want_r.append(i); want_d.append(int(pin[i]))
+        elif i % 5 == 0:
+            miss = int(rng.integers(0, a.nrows))
+            while miss in set(row.tolist()):
+                miss = int(rng.integers(0, a.nrows))
+            pin[i] = miss
+        elif i % 7 == 0:
+            pin[i] = 2 ** 40 + 3                             # no vertex carries this id
+        else:
+            want_r += [i] * len(row); want_d += row.tolist()
+    rows, dest, fl = engine.expand_pairs(ctx, src, [A, A], pinned_dest=pin, row_bits=row_bits)
+    assert fl == flops                                       # the chain ran whole: the pinning filters its result
+    np.testing.assert_array_equal(rows, np.asarray(want_r, dtype=U64))
+    np.testing.assert_array_equal(dest, np.asarray(want_d, dtype=U64))
+    # a destination label (applied by the chain) and pinned rows together
+    label = oracle.mix64(np.arange(a.nrows, dtype=U64)) % U64(2) == 0
+    bits = oracle.bits_from_ids(a.nrows, np.nonzero(label)[0])
+    rows, dest, _ = engine.expand_pairs(ctx, src, [A, A], dst_label_bitmap=bits, pinned_dest=pin, row_bits=row_bits)
+    keep = label[np.asarray(want_d, dtype=np.int64)]
+    np.testing.assert_array_equal(rows, np.asarray(want_r, dtype=U64)[keep])
+    np.testing.assert_array_equal(dest, np.asarray(want_d, dtype=U64)[keep])
+    e = ctx.mat_new(a.nrows, a.nrows)
+    rows, dest, _ = engine.expand_pairs(ctx, src[:5], [e], row_bits=row_bits)
+    assert len(rows) == 0 and len(dest) == 0
+
+
 def test_bfs_into_pinned_caller_arrays_matches_the_oracle(ctx, rmat18):
     """fgpu_bfs with level[] / parent[] in pinned memory from fgpu_host_alloc (DMA, the parent widened on the device)
     against the same call into pageable numpy arrays (staging ring) and the oracle's levels."""
