@@ -409,6 +409,17 @@ def khop_leg(ctx, engine, args, scale, nb_want, graph=None, parity_rows=1024):
         if not ok:
             raise SystemExit(f"bench.py: k-hop parity FAILED at scale {scale}: gpu {gpu} vs oracle clean {ref_clean[:3]} "
                              f"dirty {ref_dirty[:3]}")
+        # the WHOLE timed batch 0 against the committed oracle run of exactly these inputs (tests/golden/make_khop26_golden.py:
+        # two and a half minutes of CPU at RMAT-26, done once), when one exists for this scale
+        gpath = os.path.join(ROOT, "tests", "golden", "khop%d_batch0.json" % scale)
+        if parity_rows < B and os.path.exists(gpath) and args.edge_factor == 16:
+            gold = json.load(open(gpath))
+            full_ok = (gold.get("edges") == int(nnz) and gold.get("rows") == B and
+                       all(tuple(batch0[k_]) == (gold[k_]["nnz"], gold[k_]["checksum"], gold[k_]["flops"]) for k_ in ("clean", "dirty")))
+            out["parity"]["full_batch_vs_committed_oracle_run"] = {"ok": bool(full_ok), "rows": B, "golden": "tests/golden/khop%d_batch0.json" % scale}
+            if not full_ok:
+                raise SystemExit(f"bench.py: k-hop parity FAILED at scale {scale} against {gpath}: gpu {batch0}")
+            out["parity"]["rows"] = B
         out["cpu_baseline"] = {"value": round(ref_clean[2] / t_clean, 1), "unit": "TEPS", "cores": threads, "kind": "port",
                                "sample": f"{len(rows)} of batch 0's 1024 :P sources, 3 hops, clean layers, {t_clean:.1f} s "
                                          f"(dirty layers: {t_dirty:.1f} s = {ref_dirty[2] / t_dirty / 1e9:.2f} GTEPS), row-parallel "
@@ -765,6 +776,22 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
             if box.get("wide4"):
                 det["batch_2048"]["threads4"] = {k_: box["wide4"][k_] for k_ in ("ms_per_batch", "TEPS", "batches")}
             det["query_threads_checksum_matches_timed"] = all(q["checksum"] == f"{cs:016x}" for q in det["query_threads"])
+    # every row with a pre-bound destination (multi-hop ExpandInto / CondTraverse with `to` bound): the
+    # same batches through fgpu_expand_probe — hops 1-2 as usual, the last hop one bit per row — beside fgpu_expand_count
+    try:
+        rng_ = np.random.default_rng(5)
+        dsts_ = [rng_.integers(0, n, len(b)).astype(np.uint64) for b in ks[:8]]
+        engine.expand_probe(ctx, ks[0], dsts_[0], [A] * hops)
+        ctx.sync()
+        t_ = time.perf_counter()
+        hits_ = 0
+        for b, d_ in zip(ks[:8], dsts_):
+            pr_, _ = engine.expand_probe(ctx, b, d_, [A] * hops)
+            hits_ += int(pr_.sum())
+        det["pinned_probe"] = {"batches": len(dsts_), "ms_per_batch": round((time.perf_counter() - t_) / len(dsts_) * 1e3, 3),
+                               "rows_present": hits_, "what": "fgpu_expand_probe: 1024 (source, bound destination) rows, 3 hops, clean layers"}
+    except Exception as e:   # noqa: BLE001 — a secondary figure must not cost the line
+        det["pinned_probe"] = {"error": repr(e)[:200]}
     for b in ks[:2]:
         engine.expand_count(ctx, b, *dirty)
     det["dirty"] = run(ks, dirty)
@@ -1370,6 +1397,8 @@ def main():
         first, roofline = extra
         sec["khop%d" % scale] = {"count_only_TEPS": head["count_only"]["TEPS"], "count_only_ms": head["count_only"]["ms_per_batch"],
                                  "dirty_TEPS": head["dirty"]["TEPS"], "dirty_ms": head["dirty"]["ms_per_batch"]}
+        if (head.get("pinned_probe") or {}).get("ms_per_batch"):
+            sec["khop%d" % scale]["pinned_probe_ms"] = head["pinned_probe"]["ms_per_batch"]
         if head.get("batch_2048"):
             sec["khop%d" % scale].update({"b2048_TEPS": head["batch_2048"]["TEPS"], "b2048_ms": head["batch_2048"]["ms_per_batch"],
                                           "b2048_ok": head["batch_2048"]["agrees_with_1024_row_batches"]})

@@ -73,6 +73,7 @@ SIGNATURES = {
     "fgpu_expand": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, C.POINTER(u64p),
                                 C.POINTER(u64p), u64p, u64p]),
     "fgpu_expand_mat": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, vpp, u64p]),
+    "fgpu_expand_probe": (C.c_int32, [vp, u64p, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u8p, u64p]),
     "fgpu_expand_pairs": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u64p, C.c_int, vpp, C.POINTER(u64p), u64p, u64p]),
     "fgpu_expand_levels": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p]),
     "fgpu_expand_trail_counts": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, C.c_int, C.POINTER(u64p),

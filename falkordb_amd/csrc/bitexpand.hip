@@ -1419,6 +1419,91 @@ fgpu_info bp_hop_count(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu
     return bp_hop_impl(ctx, s, m, dp, dm, flops, &ca);
 }
 
+// ---------------------------------------------------------------------------------
+// the LAST hop of a chain whose every row has a pre-bound destination (CondTraverse with `to` bound on every row of the batch,
+// the multi-hop ExpandInto shape of tests/flow/test_expand_into.py:63-95; cond_traverse.rs:657-661): row i only asks whether
+// dst[i] is in (X·m)<not (X·dm)> U (X·dp) — ONE bit of one row of Y.  A wavefront per row walks the in-neighbours of dst[i]
+// in A' looking for bit[i]; the delta layers are walked entry by entry (a lane each), the rows whose destination an entry
+// names found by a search of the sorted (dst, row) list.  No Y, no emission, nothing to copy back but a byte per row.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bp_probe_rows_kernel(CsrView at, const u32* __restrict__ dst, const u32* __restrict__ bit, u32 k,
+                                                            const u64* __restrict__ x, u32 ws, uint8_t* __restrict__ hit) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    for (u32 i = wave; i < k; i += nwaves) {
+        const u32 v = dst[i], j = bit[i];
+        if (v == 0xFFFFFFFFu || j == 0xFFFFFFFFu) continue;   // (no such vertex / the source row is empty: hit stays 0)
+        u32 b, e;
+        row_range(at, v, b, e);
+        bool found = false;
+        for (u32 q0 = b; q0 < e && !found; q0 += 64) {
+            const u32 q = q0 + lane;
+            bool h = false;
+            if (q < e) h = (x[(size_t)at.colidx[q] * ws + (j >> 6)] >> (j & 63)) & 1ull;
+            found = __ballot(h) != 0ull;
+        }
+        if (found && lane == 0) hit[i] = 1;
+    }
+}
+// delta layer: a lane per entry (u, v); every row whose destination is v tests its bit of X[u]
+__global__ __launch_bounds__(256) void bp_probe_delta_kernel(CsrView d, u32 nnz, const u32* __restrict__ wordrow,
+                                                             const u32* __restrict__ sdst, const u32* __restrict__ srow, u32 k,
+                                                             const u32* __restrict__ bit, const u64* __restrict__ x, u32 ws,
+                                                             uint8_t* __restrict__ hit) {
+    for (u32 q = blockIdx.x * 256 + threadIdx.x; q < nnz; q += gridDim.x * 256) {
+        const u32 v = d.colidx[q];
+        u32 lo = 0, hi = k;                                  // first entry of the sorted list with sdst >= v
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (sdst[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= k || sdst[lo] != v) continue;
+        u32 rl = wordrow[q >> 6], rh = wordrow[(q >> 6) + 1];   // stored row of entry q (merge.hip mat_wordrow)
+        while (rl < rh) {
+            const u32 mid = (rl + rh + 1) >> 1;
+            if (d.rowptr[mid] <= q) rl = mid; else rh = mid - 1;
+        }
+        const u32 u = d.hrows ? d.hrows[rl] : rl;
+        for (u32 p = lo; p < k && sdst[p] == v; ++p) {
+            const u32 i = srow[p], j = bit[i];
+            if (j != 0xFFFFFFFFu && ((x[(size_t)u * ws + (j >> 6)] >> (j & 63)) & 1ull)) hit[i] = 1;
+        }
+    }
+}
+
+// hit_m / hit_dm / hit_dp (k bytes each, zeroed by the caller): does row i reach dst[i] through m / dm / dp from the state `s`
+fgpu_info bp_probe_rows(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
+                        const u32* dst_dev, const u32* bit_dev, const u32* sdst_dev, const u32* srow_dev, u32 k,
+                        uint8_t* hit_m, uint8_t* hit_dm, uint8_t* hit_dp) {
+    FGPU_REQUIRE(!s.lazy || s.flag.p, FGPU_INVALID, "bit-parallel probe: bad state");
+    FGPU_REQUIRE(m->nrows == s.n, FGPU_DIM_MISMATCH, "bit-parallel probe: matrix has %llu rows, frontier %u",
+                 (unsigned long long)m->nrows, s.n);
+    if (k == 0) return FGPU_OK;
+    if (m->nnz) {
+        FGPU_REQUIRE(!s.lazy, FGPU_INVALID, "bit-parallel probe: a lazily zeroed state cannot be probed row by row");
+        const fgpu_mat* t = nullptr;
+        FGPU_TRY(transposed_with_items(ctx, m, &t));
+        ProfScope ps(ctx, "bp_probe_rows_kernel", (u64)k * 16);
+        u32 grid = cdiv(k, 4);
+        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        hipLaunchKernelGGL(bp_probe_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(t), dst_dev, bit_dev, k,
+                           (const u64*)s.x.p, s.ws, hit_m);
+        FGPU_HIP(hipGetLastError());
+    }
+    struct { const fgpu_mat* d; uint8_t* hit; } layers[2] = {{dm, hit_dm}, {dp, hit_dp}};
+    for (auto& l : layers) {
+        if (!l.d || l.d->nnz == 0) continue;
+        const u32* wr = nullptr;
+        FGPU_TRY(mat_wordrow(ctx, l.d, &wr));
+        u32 grid = cdiv(l.d->nnz, 256);
+        if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
+        hipLaunchKernelGGL(bp_probe_delta_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(l.d), (u32)l.d->nnz, wr, sdst_dev,
+                           srow_dev, k, bit_dev, (const u64*)s.x.p, s.ws, l.hit);
+        FGPU_HIP(hipGetLastError());
+    }
+    return FGPU_OK;
+}
+
 // X -> CSR snapshot with nsrc rows (dest ascending per row); `label_dev` (nullable) = destination
 // label bitmap applied on the way out (cond_traverse.rs:647-651)
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out) {

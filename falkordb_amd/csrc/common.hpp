@@ -506,6 +506,10 @@ fgpu_info bp_push_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f, const 
 fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,
                  const fgpu_mat* next_m = nullptr);
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out);
+// the last hop of an all-pinned batch read off the state: one bit per row (bitexpand.hip)
+fgpu_info bp_probe_rows(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
+                        const u32* dst_dev, const u32* bit_dev, const u32* sdst_dev, const u32* srow_dev, u32 k,
+                        uint8_t* hit_m, uint8_t* hit_dm, uint8_t* hit_dp);
 // nnz + order-independent checksum of the result read straight from the bit state (fgpu_expand_count)
 fgpu_info bp_count(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, u64* nnz, u64* checksum);
 // the LAST hop of a count-only chain: the hop and the count in one pass — the result rows are counted where they are

@@ -11,6 +11,8 @@
 // ("flops"), (2) one wavefront per F-entry copies its B-row coalesced into the row's segment,
 // (3) segments with more than one source go through segsort_unique (prims.hip), single-source
 // segments (hop 1 of every traversal) are already sorted and unique, (4) compaction to CSR.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace fgpu {
@@ -526,7 +528,9 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                                const uint64_t* dst_label_bitmap, fgpu_mat** result, u64* flops,
                                u64* count_only = nullptr /* [0] nnz, [1] checksum: no CSR is built when the
                                                             chain ends in bit form */,
-                               bool want_checksum = true) {
+                               bool want_checksum = true,
+                               BitState* keep_bits = nullptr /* a chain that ends in bit form hands its state over
+                                                                 (*result = nullptr) instead of emitting it */) {
     FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
     fgpu_mat* f = nullptr;
     FGPU_TRY(upload_sources(ctx, &f, src_ids, nsrc, m[0]->nrows));
@@ -638,6 +642,11 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         mat_release(f);
         if (i != FGPU_OK) return i;
         f = c;
+    }
+    if (bits && keep_bits) {
+        *keep_bits = std::move(bs);
+        *result = nullptr;
+        return FGPU_OK;
     }
     if (bits) {
         DevBuf<u64> bm;
@@ -776,6 +785,42 @@ __global__ __launch_bounds__(256) void pairs_fill_kernel(const u32* __restrict__
 }
 
 
+// the last hop of an all-pinned batch from a SORTED-CSR frontier F: a wavefront per row i, a lane per entry u of F[i, :] — is
+// dst[i] in m[u, :] / dm[u, :] / dp[u, :]?  (rows are ascending: binary search)
+__global__ __launch_bounds__(256) void probe_csr_rows_kernel(CsrView f, CsrView m, CsrView dm, CsrView dp, const u32* __restrict__ dst,
+                                                             u32 k, uint8_t* __restrict__ hit_m, uint8_t* __restrict__ hit_dm,
+                                                             uint8_t* __restrict__ hit_dp) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    auto has = [](const CsrView& a, u32 u, u32 v) {
+        if (!a.rowptr) return false;
+        u32 b, e;
+        row_range(a, u, b, e);
+        while (b < e) {
+            const u32 mid = (b + e) >> 1;
+            if (a.colidx[mid] < v) b = mid + 1; else e = mid;
+        }
+        u32 b0, e0;
+        row_range(a, u, b0, e0);
+        return b < e0 && a.colidx[b] == v;
+    };
+    for (u32 i = wave; i < k; i += nwaves) {
+        const u32 v = dst[i];
+        if (v == 0xFFFFFFFFu) continue;
+        const u32 fb = f.rowptr[i], fe = f.rowptr[i + 1];
+        bool a = false, b = false, c = false;
+        for (u32 q = fb + lane; q < fe; q += 64) {
+            const u32 u = f.colidx[q];
+            a = a || has(m, u, v);
+            b = b || has(dm, u, v);
+            c = c || has(dp, u, v);
+        }
+        if (__ballot(a) && lane == 0) hit_m[i] = 1;
+        if (__ballot(b) && lane == 0) hit_dm[i] = 1;
+        if (__ballot(c) && lane == 0) hit_dp[i] = 1;
+    }
+}
+
 extern "C" {
 
 static fgpu_info mxm_impl(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* b) {
@@ -885,6 +930,74 @@ fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
     *out_row = hrow;
     *out_dest = hdest;
     *out_n = n;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_expand_probe(fgpu_ctx* ctx, const uint64_t* src_ids, const uint64_t* dst_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                            const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                            uint8_t* present, uint64_t* flops) {
+    FGPU_REQUIRE(ctx && present && (nsrc == 0 || (src_ids && dst_ids)), FGPU_NULL_POINTER, "fgpu_expand_probe: NULL argument");
+    if (flops) *flops = 0;
+    FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
+    if (nsrc == 0) return FGPU_OK;
+    const u32 k = (u32)nsrc;
+    memset(present, 0, k);
+    const fgpu_mat* ml = m[nhops - 1];
+    const fgpu_mat* dpl = dp ? dp[nhops - 1] : nullptr;
+    const fgpu_mat* dml = dm ? dm[nhops - 1] : nullptr;
+    // the chain up to the last hop: a sorted-CSR frontier, or the bit state it ended in
+    fgpu_mat* f = nullptr;
+    BitState bs;
+    if (nhops == 1) FGPU_TRY(upload_sources(ctx, &f, src_ids, nsrc, m[0]->nrows));
+    else FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops - 1, nullptr, &f, flops, nullptr, true, &bs));
+    struct Rel { fgpu_mat* f; ~Rel() { if (f) mat_release(f); } } rel{f};
+    // destinations (a vertex the last matrix does not have, or one the label filter drops: no match), the bit of every row
+    const u64 ncols = ml->ncols;
+    std::vector<u32> hdst(k), hbit(k), order(k), sdst(k), srow(k);
+    std::vector<u32> rank;
+    if (!f && bs.nsrc_full) {
+        rank.resize((size_t)bs.nsrc_full + 1);
+        FGPU_TRY(ctx->d2h(rank.data(), bs.rowrank.p, rank.size() * sizeof(u32)));
+    }
+    for (u32 i = 0; i < k; ++i) {
+        u64 v = dst_ids[i];
+        if (v >= ncols || src_ids[i] == UINT64_MAX) v = ~0ull;
+        else if (dst_label_bitmap && !((dst_label_bitmap[v >> 6] >> (v & 63)) & 1ull)) v = ~0ull;
+        hdst[i] = v == ~0ull ? 0xFFFFFFFFu : (u32)v;
+        if (rank.empty()) hbit[i] = i;
+        else hbit[i] = rank[i + 1] > rank[i] ? rank[i] : 0xFFFFFFFFu;   // (a source row dropped before the chain went to bits is empty)
+        order[i] = i;
+    }
+    std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return hdst[a] < hdst[b] || (hdst[a] == hdst[b] && a < b); });
+    for (u32 p = 0; p < k; ++p) { sdst[p] = hdst[order[p]]; srow[p] = order[p]; }
+    DevBuf<u32> d_dst, d_bit, d_sdst, d_srow;
+    DevBuf<uint8_t> hits;
+    FGPU_TRY(d_dst.alloc(ctx, k)); FGPU_TRY(d_bit.alloc(ctx, k)); FGPU_TRY(d_sdst.alloc(ctx, k)); FGPU_TRY(d_srow.alloc(ctx, k));
+    FGPU_TRY(hits.alloc(ctx, (size_t)3 * k));
+    FGPU_TRY(ctx->h2d(d_dst.p, hdst.data(), (size_t)k * 4));
+    FGPU_TRY(ctx->h2d(d_bit.p, hbit.data(), (size_t)k * 4));
+    FGPU_TRY(ctx->h2d(d_sdst.p, sdst.data(), (size_t)k * 4));
+    FGPU_TRY(ctx->h2d(d_srow.p, srow.data(), (size_t)k * 4));
+    FGPU_HIP(hipMemsetAsync(hits.p, 0, (size_t)3 * k, ctx->stream()));
+    if (f) {
+        if (f->nnz) {
+            CsrView none;
+            none.rowptr = nullptr; none.colidx = nullptr; none.hrows = nullptr; none.nvec = 0; none.nrows = 0;
+            u32 grid = cdiv(k, 4);
+            if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+            hipLaunchKernelGGL(probe_csr_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(f), view_of(ml),
+                               (dml && dml->nnz) ? view_of(dml) : none, (dpl && dpl->nnz) ? view_of(dpl) : none, (const u32*)d_dst.p, k,
+                               hits.p, hits.p + k, hits.p + 2 * (size_t)k);
+            FGPU_HIP(hipGetLastError());
+        }
+    } else {
+        FGPU_TRY(bp_probe_rows(ctx, bs, ml, dpl, dml, d_dst.p, d_bit.p, d_sdst.p, d_srow.p, k, hits.p, hits.p + k, hits.p + 2 * (size_t)k));
+    }
+    std::vector<uint8_t> h((size_t)3 * k);
+    FGPU_TRY(ctx->d2h(h.data(), hits.p, (size_t)3 * k));
+    if (!f) bp_finish(ctx, bs);
+    // (F·m)<not (F·dm)> U (F·dp), one entry of it: the row-level mask of Matrix::delta_lmxm (matrix.rs:1343-1361)
+    for (u32 i = 0; i < k; ++i) present[i] = ((h[i] && !h[k + i]) || h[2 * (size_t)k + i]) ? 1 : 0;
     return FGPU_OK;
 }
 

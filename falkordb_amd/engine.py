@@ -641,3 +641,19 @@ def expand_pairs(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=No
     ctx.lib.fgpu_free(ctx._h, prow)
     ctx.lib.fgpu_free(ctx._h, pdest)
     return rows, dest, flops.value
+
+
+def expand_probe(ctx: Context, src_ids, dst_ids, m, dp=None, dm=None, dst_label_bitmap=None):
+    """fgpu_expand_probe: present[i] = dst_ids[i] is reached from src_ids[i] by the chain (every row of the batch has a
+    pre-bound destination); returns (present as a bool array, flops of the hops that ran)."""
+    src, dst = _u64(src_ids), _u64(dst_ids)
+    assert len(src) == len(dst)
+    am = _hop_arrays(m)
+    adp = _hop_arrays(dp) if dp is not None else None
+    adm = _hop_arrays(dm) if dm is not None else None
+    lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
+    out = np.zeros(max(len(src), 1), dtype=np.uint8)
+    flops = C.c_uint64()
+    check(ctx.lib.fgpu_expand_probe(ctx._h, _p(src), _p(dst), len(src), am, adp, adm, len(m), _p(lab),
+                                    out.ctypes.data_as(u8p), C.byref(flops)))
+    return out[:len(src)].astype(bool), flops.value

@@ -280,6 +280,21 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
     }
     const bool want_edge = bind_relationship && hops.size() == 1;
     if (k > 65536) throw GrbError(FGPU_INVALID, "CondTraverse::expand_batch: more than 65536 rows in one batch");
+    bool all_pinned = !pinned_to.empty();
+    for (u64 i = 0; i < k && all_pinned; ++i)
+        if (src_ids[i] != ~0ull && pinned_to[i] == ~0ull) all_pinned = false;
+    if (all_pinned) {
+        // every row of the batch has its destination bound (the multi-hop ExpandInto shape, test_expand_into.py:63-95): the
+        // last hop is one probe per row of the chain's state (fgpu_expand_probe) — nothing is expanded, emitted or copied
+        std::vector<uint8_t> present(k, 0);
+        check(fgpu_expand_probe(ctx, src_ids.data(), pinned_to.data(), k, hl.m.data(), hl.dp.data(), hl.dm.data(), (int)hops.size(),
+                                bitmap.empty() ? nullptr : bitmap.data(), present.data(), &fl),
+              "CondTraverse::expand_batch (pinned)");
+        for (u64 i = 0; i < k; ++i)
+            if (present[i] && src_ids[i] != ~0ull) { rows.active_row.push_back(i); rows.dest.push_back(pinned_to[i]); }
+        if (flops) *flops = fl;
+        lap("fgpu_expand_probe");
+    } else {
     void* prow = nullptr;
     u64* pdest = nullptr;
     check(fgpu_expand_pairs(ctx, src_ids.data(), k, hl.m.data(), hl.dp.data(), hl.dm.data(), (int)hops.size(),
@@ -292,6 +307,7 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
     rows.n_pin = np;
     if (flops) *flops = fl;
     lap("fgpu_expand_pairs");
+    }
     std::vector<uint8_t> matched(k, 0);
     if (want_edge) {
         // representative edge: first id found scanning the types in order (:663-695), batched per type

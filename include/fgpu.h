@@ -265,6 +265,18 @@ fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
                             const uint64_t* pinned_dest, int row_bits, void** out_row, uint64_t** out_dest,
                             uint64_t* out_n, uint64_t* flops);
 
+/* The same chain when EVERY row has a pre-bound destination — CondTraverse with `to` bound on the whole batch, the multi-hop
+ * ExpandInto shape `MATCH (a)-[*]->(b) ... MATCH (a)-->()-->(b)` (tests/flow/test_expand_into.py:63-95; the reference runs
+ * the whole chain and drops every destination but the bound one, cond_traverse.rs:657-661): present[i] = 1 iff dst_ids[i]
+ * is reached from src_ids[i] by the chain (and passes the destination label).  The hops before the last run as in
+ * fgpu_expand; the last one is ONE entry of (F·m)<not (F·dm)> U (F·dp) per row — in bit form one bit of one row of the
+ * state, found by walking the in-neighbours of dst_ids[i]; in sorted-CSR form a binary search per frontier entry — so no
+ * result is materialised, emitted or copied back.  present[nsrc] is a HOST array; *flops (nullable) counts the traversed
+ * edges of the hops that ran (the last hop is not expanded). */
+fgpu_info fgpu_expand_probe(fgpu_ctx* ctx, const uint64_t* src_ids, const uint64_t* dst_ids, uint64_t nsrc,
+                            const fgpu_mat* const* m, const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                            const uint64_t* dst_label_bitmap, uint8_t* present, uint64_t* flops);
+
 /* The same chain with the result STREAMED to the host in chunks of whole source rows — the shape in which
  * CondTraverseOp::expand_batch consumes it (cond_traverse.rs:644-751: walk (row_i, dest) ascending, emit an output batch
  * every 1024 pairs): the chain runs once, F stays on the device, and chunks of at most `chunk_rows` consecutive source

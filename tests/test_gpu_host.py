@@ -867,6 +867,17 @@ def test_expand_batch_to_bound_and_null_sources(rnd_graph):  # cond_traverse.rs:
     tb = [None, full[0][1] if full else 0, None, 1]
     rows, _, _ = g.cond_traverse_batch(spec, [5, 9, 300, 17], to_bound=tb)
     assert rows == model.expand_batch(og, [5, 9, 300, 17], ["A"], to_bound=tb)[0]
+    # every row bound (the multi-hop ExpandInto shape): the operator probes the chain's state instead of expanding the last hop
+    spec2 = host.cond_spec(hops=[(["A"], []), ([], [])])
+    srcs = [5, 9, 300, 17, 40, 41, 42, 77]
+    free, _, _ = g.cond_traverse_batch(spec2, srcs)
+    by_row = {}
+    for row in free:
+        by_row.setdefault(row[0], []).append(row[1])
+    tb2 = [by_row[i][len(by_row[i]) // 2] if i in by_row and i % 2 == 0 else (i * 37) % n for i in range(len(srcs))]
+    rows, _, _ = g.cond_traverse_batch(spec2, srcs, to_bound=tb2)
+    assert rows == model.expand_batch(og, srcs, ["A"], chain=[([], [])], to_bound=tb2)[0]
+    assert any(row[0] % 2 == 0 for row in rows)
 
 
 def test_expand_row_fallback_matches_brute_force(rnd_graph):   # cond_traverse.rs:758-1117

@@ -125,6 +125,65 @@ def test_khop_rmat20_count_hop_partitioned_by_xcd(ctx, rmat20, rmat20_refs, xcd,
         ctx.set_option("expand_xcd_min_mb", 32)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("hops", [1, 2, 3])
+def test_expand_probe_all_rows_pinned_matches_the_oracle(ctx, rmat20, mode, hops):
+    """fgpu_expand_probe — every row of the batch has a pre-bound destination (CondTraverse with `to` bound, the multi-hop
+    ExpandInto shape of tests/flow/test_expand_into.py:63-95; cond_traverse.rs:657-661): present[i] must say whether dst[i] is
+    in row i of the oracle's delta_lmxm chain — for 1 / 2 / 3 hops, clean and dirty layers (the row-level tombstone mask of
+    matrix.rs:1343-1361 decides single entries here), with the chain kept in sorted-CSR form (mode 1: the last hop is a binary
+    search per frontier entry), in bit form from the first hop (mode 2: one bit of one row of the state) and left to choose;
+    destinations drawn from the row itself, from the vertices the tombstones removed, at random, beyond the matrix, and under
+    a destination label; an unbound source."""
+    A, dp, dm, a, hdp, hdm = rmat20
+    k = 300
+    src = p_sources(a.nrows, k, first=7000)
+    rng = np.random.default_rng(100 * hops + mode)
+    label = oracle.mix64(np.arange(a.nrows, dtype=U64)) % U64(4) != 0
+    bits = oracle.bits_from_ids(a.nrows, np.nonzero(label)[0])
+    for dirty in (False, True):
+        layers = [(a, hdp, hdm) if dirty else (a, None, None)] * hops
+        c, flops, _ = oracle.expand_omp(src, layers)
+        clean_c = c if not dirty else oracle.expand_omp(src, [(a, None, None)] * hops)[0]
+        dst = np.zeros(k, dtype=U64)
+        for i in range(k):
+            row = c.colidx[int(c.rowptr[i]):int(c.rowptr[i + 1])]
+            crow = clean_c.colidx[int(clean_c.rowptr[i]):int(clean_c.rowptr[i + 1])]
+            r = i % 4
+            if r == 0 and len(row):
+                dst[i] = row[rng.integers(0, len(row))]                 # reached
+            elif r == 1 and len(crow):
+                dst[i] = crow[rng.integers(0, len(crow))]               # reached over clean layers: maybe tombstoned now
+            elif r == 2:
+                dst[i] = rng.integers(0, a.nrows)
+            else:
+                dst[i] = a.nrows + 5 if i % 8 == 3 else rng.integers(0, a.nrows)
+        want = np.zeros(k, dtype=bool)
+        for i in range(k):
+            row = c.colidx[int(c.rowptr[i]):int(c.rowptr[i + 1])]
+            j = np.searchsorted(row, dst[i])
+            want[i] = j < len(row) and row[j] == dst[i]
+        assert want.sum() > k // 5 and (~want).sum() > k // 5
+        gm = [A] * hops
+        gl = ([dp] * hops, [dm] * hops) if dirty else (None, None)
+        try:
+            ctx.set_option("expand_mode", mode)
+            got, _ = engine.expand_probe(ctx, src, dst, gm, *gl)
+            np.testing.assert_array_equal(got, want)
+            got, _ = engine.expand_probe(ctx, src, dst, gm, *gl, dst_label_bitmap=bits)
+            inb = dst < a.nrows
+            lw = want.copy()
+            lw[inb] &= label[dst[inb].astype(np.int64)]
+            np.testing.assert_array_equal(got, lw)
+            s2 = src.copy()
+            s2[5] = 2 ** 64 - 1                                          # an unbound source: its row is empty
+            got, _ = engine.expand_probe(ctx, s2, dst, gm, *gl)
+            w2 = want.copy(); w2[5] = False
+            np.testing.assert_array_equal(got, w2)
+        finally:
+            ctx.set_option("expand_mode", 0)
+
+
 def test_khop_rmat20_full_rows_match_the_oracle(ctx, rmat20):
     """The same chain with the whole (row, dest) result compared entry by entry (fgpu_expand, what the operator emits),
     clean and dirty layers, with a destination-label bitmap on the dirty run."""
@@ -252,6 +311,33 @@ def test_khop_rmat26_batch_rows_match_the_oracle(ctx, rmat26_bench, dirty):
         assert got == ref[:3], (mode, dirty, got, ref)
         assert list(lv["hop_nnz"]) == ref[3] and lv["flops"] == ref[2]
     assert ref[0] > 100_000_000
+
+
+@pytest.mark.parametrize("dirty", [False, True])
+def test_khop_rmat26_full_batch_matches_the_committed_oracle_run(ctx, bench_graphs, dirty):
+    """RMAT-26 at the size it is quoted: ALL 1024 rows of batch 0, 3 hops, clean and dirty — (nnz, checksum, flops) and the
+    per-hop sizes against tests/golden/khop26_batch0.json, the CPU oracle's chain over exactly these inputs run once by
+    tests/golden/make_khop26_golden.py (45 + 103 s of CPU: not repeated per session).  The inputs are re-derived here and
+    pinned by hashes, so a change of the generator or of the layers cannot pass silently."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "khop26_batch0.json")))
+    A, _, a = bench_graphs(26)
+    dp, dm, hdp, hdm = bench_graphs.khop_layers(26)
+    src = p_sources(A.nrows, 1024)
+    assert gold["rows"] == 1024 and gold["edges"] == a.nnz and gold["nnz_dp"] == hdp.nnz and gold["nnz_dm"] == hdm.nnz
+    assert gold["sources_sha256"] == hashlib.sha256(np.ascontiguousarray(src).tobytes()).hexdigest()
+    assert gold["colidx_sha256"] == hashlib.sha256(np.ascontiguousarray(a.colidx).tobytes()).hexdigest()
+    ref = gold["dirty" if dirty else "clean"]
+    layers = ([A] * 3, [dp] * 3, [dm] * 3) if dirty else ([A] * 3,)
+    got = engine.expand_count(ctx, src, *layers)
+    assert got == (ref["nnz"], ref["checksum"], ref["flops"]), (dirty, got, ref)
+    nn, _, fl = engine.expand_count(ctx, src, *layers, want_checksum=False)
+    assert (nn, fl) == (ref["nnz"], ref["flops"])
+    lv = engine.expand_levels(ctx, src, *layers)
+    assert list(lv["hop_nnz"]) == ref["hop_nnz"] and lv["flops"] == ref["flops"]
+    assert ref["nnz"] > 4_000_000_000
 
 
 def test_khop_rmat24_two_hop_host_arrays_match_the_oracle(ctx, rmat24_bench):
