@@ -321,7 +321,8 @@ struct BpProbe {
 template <int LN, bool SPARSE, int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView at, const u32* __restrict__ items, u32 nitems, u32 ws,
                                                      const u64* __restrict__ x, BpProbe pr,
-                                                     u64* __restrict__ y, uint8_t* __restrict__ yflag, BpFinal fin) {
+                                                     u64* __restrict__ y, uint8_t* __restrict__ yflag, BpFinal fin,
+                                                     const u32* __restrict__ yperm /* MODE 0, nullable: row v of Y is stored at slot yperm[v] */) {
     // MODE 2 runs 1024-thread workgroups: the 2 KiB-per-word tables are shared by 16 wavefronts, so the LDS they take
     // does not cost resident wavefronts (the gathers are latency-bound: 20 instead of 32 waves per CU made the dense
     // hop 1.6 x slower when every 256-thread workgroup carried its own copy)
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
             for (int d = LN; d < 64; d <<= 1) acc |= __shfl_xor(acc, d, 64);
             if (MODE == 0) {
                 if (slot == 0 && acc) {
-                    u64* dst = &y[(size_t)v * ws + wo];
+                    u64* dst = &y[(size_t)(yperm ? yperm[v] : v) * ws + wo];
                     if (split) atomicOr((unsigned long long*)dst, (unsigned long long)acc);
                     else *dst = acc;
                 }
@@ -474,7 +475,8 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
                                                                              uint8_t* __restrict__ yflag,
                                                                              const u32* __restrict__ next_rowptr,
                                                                              unsigned long long* __restrict__ stats,
-                                                                             const u64* __restrict__ later_bits) {
+                                                                             const u64* __restrict__ later_bits,
+                                                                             const u32* __restrict__ yperm /* nullable: row v of Y at slot yperm[v] */) {
     // stats (nullable, with next_rowptr): [0] += popcount(Y[v]) * out-degree of v in the next hop's matrix, [1] += rows
     // written — what bp_flops / bp_count_flags would find in a pass of their own.  Rows flagged in `later_bits`
     // (nullable: destinations of a delta layer, whose rows change after this kernel) are left to bp_split_stats_kernel.
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
             const u32 row = r0 + slot;
             const u64 a = row < R ? acc[row * LN + wl] : 0ull;   // (LN == 1: 64 slots, 32 rows)
             if (a) {
-                y[(size_t)(v0 + row) * LN + wl] = a;
+                y[(size_t)(yperm ? yperm[v0 + row] : v0 + row) * LN + wl] = a;
                 acc[row * LN + wl] = 0ull;
             }
             const u64 nzm = __ballot(a != 0ull);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
 // the ~10^5 split rows of RMAT-24: 48 of 64 lanes idle on 16-word rows, one dependent load per row).
 __global__ __launch_bounds__(256) void bp_split_stats_kernel(const u64* __restrict__ bits, u32 n, u32 ws, u32 lnsh,
                                                             const u64* __restrict__ y, const u32* __restrict__ next_rowptr,
-                                                            unsigned long long* __restrict__ stats) {
+                                                            unsigned long long* __restrict__ stats, const u32* __restrict__ yperm) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(256) void bp_split_stats_kernel(const u64* __restri
             }
             u32 pc = 0;
             if (v != 0xFFFFFFFFu)
-                for (u32 k = wl; k < ws; k += ln) pc += (u32)__popcll(y[(size_t)v * ws + k]);
+                for (u32 k = wl; k < ws; k += ln) pc += (u32)__popcll(y[(size_t)(yperm ? yperm[v] : v) * ws + k]);
             const u64 nz = __ballot(pc != 0);
             if (pc) fl += (u64)pc * (next_rowptr[v + 1] - next_rowptr[v]);
             if (wl == 0 && (nz & field)) rows += 1;
@@ -672,7 +674,9 @@ __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w
                                                       uint8_t* __restrict__ yflag, const u64* __restrict__ tbits,
                                                       const u32* __restrict__ tpref,
                                                       const uint8_t* __restrict__ xflag /* lazy X: rows without a flag are undefined (= empty) */,
-                                                      const u32* __restrict__ wordrow /* stored row of every 64th entry */) {
+                                                      const u32* __restrict__ wordrow /* stored row of every 64th entry */,
+                                                      const u32* __restrict__ xperm /* nullable: row u of X at slot xperm[u] */,
+                                                      const u32* __restrict__ yperm /* nullable (no side buffer): row v of Y at slot yperm[v] */) {
     const u32 t = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     const u32 per = nth / ln;             // entries in flight per sweep
     const u32 sub = t % ln;
@@ -688,13 +692,13 @@ __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w
         if (xflag && !xflag[u]) continue;
         const u32 v = d.colidx[q];
         // the row of v: in Y, or (counting hop) in its slot of the side buffer — every delta destination is "touched"
-        size_t yrow = (size_t)v * ws;
+        size_t yrow = (size_t)(yperm ? yperm[v] : v) * ws;
         if (tbits) {
             const u64 tw = tbits[v >> 6];
             yrow = (size_t)(tpref[v >> 6] + (u32)__popcll(tw & ((1ull << (v & 63)) - 1ull))) * ws;
         }
         for (u32 k = sub; k < w; k += ln) {
-            const u64 xv = x[(size_t)u * ws + k];
+            const u64 xv = x[(size_t)(xperm ? xperm[u] : u) * ws + k];
             if (xv == 0ull) continue;
             if (IS_DM) atomicAnd((unsigned long long*)&y[yrow + k], (unsigned long long)~xv);
             else {
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(256) void bp_delta_kernel(CsrView d, u32 nnz, u32 w
 // traversed-edge count of a hop: sum_v popcount(X[v]) * deg(v)
 __global__ __launch_bounds__(256) void bp_flops_kernel(CsrView a, u32 w, u32 ws, const u64* __restrict__ x,
                                                       const uint8_t* __restrict__ xflag,
-                                                      unsigned long long* __restrict__ out) {
+                                                      unsigned long long* __restrict__ out, const u32* __restrict__ xperm) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(256) void bp_flops_kernel(CsrView a, u32 w, u32 ws,
         const u32 v = a.hrows ? a.hrows[r] : r;
         if (xflag && !xflag[v]) continue;   // a byte instead of the 8 W-byte row: most rows of a sparse state are empty
         u32 pc = 0;
-        for (u32 k = 0; k < w; ++k) pc += (u32)__popcll(x[(size_t)v * ws + k]);
+        for (u32 k = 0; k < w; ++k) pc += (u32)__popcll(x[(size_t)(xperm ? xperm[v] : v) * ws + k]);
         sum += (u64)pc * deg;
     }
 #pragma unroll
@@ -867,7 +871,7 @@ static fgpu_info bp_alloc_zero(fgpu_ctx* ctx, DevBuf<u64>& buf, const BitState& 
 
 // zero the rows the flags name (every non-zero row of a non-lazy state is flagged), LN lanes per row
 __global__ __launch_bounds__(256) void bp_rezero_rows_kernel(const uint8_t* __restrict__ flag, u32 n, u32 ws2, u32 lsh,
-                                                            uint4* __restrict__ x) {
+                                                            uint4* __restrict__ x, const u32* __restrict__ xperm) {
     // A block compacts the flagged rows of a 2048-row tile into LDS, then clears them with (1 << lsh) lanes of 16 B per row.
     __shared__ u32 s_list[2048];
     __shared__ u32 s_cnt;
@@ -891,11 +895,67 @@ __global__ __launch_bounds__(256) void bp_rezero_rows_kernel(const uint8_t* __re
         __syncthreads();
         const u32 cnt = s_cnt;
         for (u32 i = tid >> lsh; i < cnt; i += 256u >> lsh) {
-            uint4* row = x + (size_t)s_list[i] * ws2;
+            uint4* row = x + (size_t)(xperm ? xperm[s_list[i]] : s_list[i]) * ws2;
             for (u32 k = tid & (L - 1u); k < ws2; k += L) row[k] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
     }
+}
+
+// Move the flagged rows of a (non-lazy) state from one layout to another — row v from slot src[v] to slot dst[v] (nullptr =
+// vertex order) of a zeroed block — and leave zeros behind, so the old block goes back to the pool as a zeroed one.  Used
+// when the hop that produced a state could not write it in the layout its reader wants (a state scattered from a CSR
+// frontier feeding a partitioned count hop; a permuted state meeting the plain or sparse pull after all).
+__global__ __launch_bounds__(256) void bp_move_rows_kernel(const uint8_t* __restrict__ flag, u32 n, u32 ws2, u32 lsh,
+                                                          uint4* __restrict__ from, uint4* __restrict__ to,
+                                                          const u32* __restrict__ src, const u32* __restrict__ dst) {
+    __shared__ u32 s_list[2048];
+    __shared__ u32 s_cnt;
+    const u32 tid = threadIdx.x, L = 1u << lsh;
+    const u32 tiles = (n + 2047u) >> 11;
+    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        const u32 base = (tile << 11) + tid * 8u;
+        for (u32 j = 0; j < 8u; ++j)
+            if (base + j < n && flag[base + j]) s_list[atomicAdd(&s_cnt, 1u)] = base + j;
+        __syncthreads();
+        const u32 cnt = s_cnt;
+        for (u32 i = tid >> lsh; i < cnt; i += 256u >> lsh) {
+            const u32 v = s_list[i];
+            uint4* a = from + (size_t)(src ? src[v] : v) * ws2;
+            uint4* b = to + (size_t)(dst ? dst[v] : v) * ws2;
+            for (u32 k = tid & (L - 1u); k < ws2; k += L) {
+                b[k] = a[k];
+                a[k] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+static fgpu_info bp_relayout(fgpu_ctx* ctx, BitState& s, const u32* want) {
+    if (s.perm == want) return FGPU_OK;
+    FGPU_REQUIRE(!s.lazy && s.flag.p && (s.ws & 1u) == 0, FGPU_INVALID, "bit state: cannot change the layout of a lazy / odd-width state");
+    const size_t words = (size_t)s.n * s.ws;
+    void* q = nullptr;
+    bool was_zero = false;
+    FGPU_TRY(ctx->dev_alloc_zeroed(&q, (words ? words : 1) * sizeof(u64), &was_zero));
+    if (!was_zero) FGPU_HIP(hipMemsetAsync(q, 0, words * sizeof(u64), ctx->stream()));
+    const u32 ws2 = s.ws / 2;
+    u32 lsh = 0;
+    while ((2u << lsh) <= ws2 && lsh < 4) ++lsh;
+    const u32 tiles = (s.n + 2047u) >> 11;
+    const u32 grid = tiles < (u32)ctx->cus * 8u ? tiles : (u32)ctx->cus * 8u;
+    {
+        ProfScope ps(ctx, "bp_move_rows_kernel", (u64)s.n + 2 * s.nz_rows * s.ws * 8);
+        hipLaunchKernelGGL(bp_move_rows_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream(), (const uint8_t*)s.flag.p, s.n, ws2, lsh,
+                           (uint4*)s.x.p, (uint4*)q, s.perm, want);
+        FGPU_HIP(hipGetLastError());
+    }
+    ctx->dev_free_zeroed(s.x.take(), words * sizeof(u64));   // every row that held bits was cleared on the way
+    s.x.ctx = ctx; s.x.p = (u64*)q; s.x.n = words;
+    s.perm = want;
+    return FGPU_OK;
 }
 
 // The chain is done with state `s` (the input of its last hop).  When few of its rows hold bits, clearing those rows and
@@ -910,7 +970,7 @@ static void bp_recycle_state(fgpu_ctx* ctx, BitState& s) {
         const u32 grid = tiles < (u32)ctx->cus * 8u ? tiles : (u32)ctx->cus * 8u;
         ProfScope ps(ctx, "bp_rezero_rows_kernel", (u64)s.n + s.nz_rows * s.ws * 8);
         hipLaunchKernelGGL(bp_rezero_rows_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream(), (const uint8_t*)s.flag.p, s.n,
-                           ws2, lsh, (uint4*)s.x.p);
+                           ws2, lsh, (uint4*)s.x.p, s.perm);
         if (hipGetLastError() == hipSuccess) {
             ctx->dev_free_zeroed(s.x.take(), words * sizeof(u64));
             s.flag.release();
@@ -1105,7 +1165,7 @@ static fgpu_info bp_flops(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* a, u
     u32 grid = cdiv(a->nvec ? a->nvec : 1, 256);
     if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
     hipLaunchKernelGGL(bp_flops_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(a), s.w, s.ws,
-                       (const u64*)s.x.p, (const uint8_t*)s.flag.p, (unsigned long long*)acc.p);
+                       (const u64*)s.x.p, (const uint8_t*)s.flag.p, (unsigned long long*)acc.p, s.perm);
     FGPU_HIP(hipGetLastError());
     u64 v = 0;
     FGPU_TRY(read_u64(ctx, acc.p, &v));
@@ -1122,10 +1182,11 @@ struct CountArgs {
 };
 
 static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
-                             u64* flops, const CountArgs* ca, const fgpu_mat* next_m = nullptr) {
+                             u64* flops, const CountArgs* ca, const fgpu_mat* next_m = nullptr, const fgpu_mat* count_next = nullptr) {
     FGPU_REQUIRE(m->nrows == s.n, FGPU_DIM_MISMATCH, "bit-parallel hop: matrix has %llu rows, frontier %u",
                  (unsigned long long)m->nrows, s.n);
     FGPU_REQUIRE(m->nnz < 0x7FFFFFFFull, FGPU_INVALID, "bit-parallel hop: nnz must be < 2^31");
+    FGPU_REQUIRE(ca || !s.perm, FGPU_INVALID, "bit-parallel hop: a mid-chain hop met a state laid out for a count hop");
     if (flops) {
         if (s.pre_for == m) *flops += s.pre_flops;     // summed by the hop that produced X
         else FGPU_TRY(bp_flops(ctx, s, m, flops));
@@ -1152,6 +1213,18 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     const BpXPlan* xp = nullptr;
     if (ca && t && !will_sparse && !s.lazy && s.ws >= 2 && s.ws <= 16 && (u64)s.n * s.ws * 8 >= (u64)ctx->opt.expand_xcd_min_mb << 20)
         FGPU_TRY(bp_xplan(ctx, m, t, &xp));
+    // the layout of the state: the count hop reads what its plan gathers from (hot-first per partition when the partitioned
+    // form runs, vertex order otherwise); a mid-chain hop about to feed such a count hop WRITES its rows in that layout
+    if (ca) FGPU_TRY(bp_relayout(ctx, s, xp ? bp_xplan_perm(xp) : nullptr));
+    const u32* operm = nullptr;
+    if (!ca && count_next && count_next->nnz && !count_next->is_hyper() && count_next->nrows == m->ncols && o.ws >= 2 && o.ws <= 16 &&
+        (u64)o.n * o.ws * 8 >= (u64)ctx->opt.expand_xcd_min_mb << 20) {
+        const fgpu_mat* tn = nullptr;
+        const BpXPlan* nxp = nullptr;
+        FGPU_TRY(transposed_with_items(ctx, count_next, &tn));
+        FGPU_TRY(bp_xplan(ctx, count_next, tn, &nxp));
+        operm = bp_xplan_perm(nxp);
+    }
     // clean layers in the partitioned form: the fold completes every row, nothing is "touched" — no bitmap, no prefix, no side
     // buffer, no read-back (six launches and a host round trip per batch)
     const bool no_touched = ca && xp && !has_dm && !has_dp;
@@ -1261,7 +1334,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             FGPU_HIP(hipFuncSetAttribute((const void*)bp_pull_kernel<LN, SP, MD>,                                       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all));                    \
         hipLaunchKernelGGL((bp_pull_kernel<LN, SP, MD>), dim3(grid), dim3(threads), lds_all, ctx->stream(),             \
-                           tv, item_list, nitems, s.ws, (const u64*)s.x.p, pr, ydst, yflag, fin);                       \
+                           tv, item_list, nitems, s.ws, (const u64*)s.x.p, pr, ydst, yflag, fin, MD == 0 ? operm : (const u32*)nullptr); \
     } while (0)
 #define BP_LAUNCH(LN)                                                                                                   \
     do {                                                                                                                \
@@ -1303,7 +1376,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
                            view_of(t), (u32)t->nrows, (const u64*)s.x.p, pr, ydst, yflag,                               \
                            fuse_stats ? (const u32*)next_m->rowptr : (const u32*)nullptr,                               \
                            fuse_stats ? (unsigned long long*)gstats.p : (unsigned long long*)nullptr,                   \
-                           (const u64*)later.p);                                                                        \
+                           (const u64*)later.p, operm);                                                                 \
     } while (0)
             switch (s.ws) {
                 case 1: BP_GROUPS(1); break;
@@ -1340,7 +1413,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
             hipLaunchKernelGGL(bp_delta_kernel<true>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dm), (u32)dm->nnz,
                                s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref,
-                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr, wr_dm);
+                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr, wr_dm, s.perm, ca ? (const u32*)nullptr : operm);
             FGPU_HIP(hipGetLastError());
         }
         if (has_dp) {
@@ -1349,7 +1422,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
             hipLaunchKernelGGL(bp_delta_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream(), view_of(dp), (u32)dp->nnz,
                                s.w, s.ws, ln, (const u64*)s.x.p, ydst, yflag, fin.tbits, fin.tpref,
-                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr, wr_dp);
+                               s.lazy ? (const uint8_t*)s.flag.p : (const uint8_t*)nullptr, wr_dp, s.perm, ca ? (const u32*)nullptr : operm);
             FGPU_HIP(hipGetLastError());
         }
     }
@@ -1386,7 +1459,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             while ((2u << lnsh) <= s.ws && lnsh < 6) ++lnsh;
             hipLaunchKernelGGL(bp_split_stats_kernel, dim3(ctx->cus * 2), dim3(256), 0, ctx->stream(),
                                later.p ? (const u64*)later.p : (const u64*)t->bp_split_bits,
-                               n_out, s.ws, lnsh, (const u64*)o.x.p, (const u32*)next_m->rowptr, (unsigned long long*)gstats.p);
+                               n_out, s.ws, lnsh, (const u64*)o.x.p, (const u32*)next_m->rowptr, (unsigned long long*)gstats.p, operm);
             FGPU_HIP(hipGetLastError());
         }
         u64 st[2] = {0, 0};
@@ -1400,6 +1473,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
     prof_add_bytes(ctx, pull_idx, o.nz_rows * 8 * s.w);
     s.x = std::move(o.x);
     s.flag = std::move(o.flag);
+    s.perm = operm;
     s.nz_rows = o.nz_rows;
     s.lazy = false;            // o.x was zeroed as a whole
     s.pre_for = o.pre_for;
@@ -1409,8 +1483,8 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
 }
 
 fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,
-                 const fgpu_mat* next_m) {
-    return bp_hop_impl(ctx, s, m, dp, dm, flops, nullptr, next_m);
+                 const fgpu_mat* next_m, const fgpu_mat* count_next) {
+    return bp_hop_impl(ctx, s, m, dp, dm, flops, nullptr, next_m, count_next);
 }
 
 fgpu_info bp_hop_count(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,

@@ -49,6 +49,7 @@ struct BpXPlan;
 // *out = nullptr when the partitioned form does not apply (option off, matrix too small / too wide, ids beyond 2^26)
 fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const BpXPlan** out);
 void bp_xplan_release(fgpu_ctx* ctx, BpXPlan* p);
+const u32* bp_xplan_perm(const BpXPlan* p);   // slot of row u of X in the state the plan gathers from (nullptr: slot = u)
 // rows of Y = OR of the gathered rows of X, per vertex, counted / check-summed (mode 1 / 2) or — touched rows — stored into
 // their side-buffer slot; `side` is zeroed by the caller, the delta fix-ups and the side-row count follow in bp_hop_impl
 fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, const u64* x, u32 ws, int mode, const BpFinal& fin,

@@ -55,13 +55,20 @@ struct BpXPlan {
     u32 nzrows = 0;
     u64* ne = nullptr;             // [8][ng] bit r: (partition, row 64 g + r) has entries
     u32* pbase = nullptr;          // [8][ng] partial row of the group's first non-empty row
+    // slot of X's row u in the state this plan gathers from (nullptr: slot = u).  Rows are ranked by how often they are gathered
+    // (out-degree of u in m, descending) and dealt to the partitions in turn — slot = (rank % 8) x range + rank / 8 — so every
+    // partition holds an eighth of the hot rows, packed hot-first: a 128-byte line then carries two rows (64-byte rows) of about
+    // the same heat, where vertex order puts a hot row next to a random one — the L2's capacity for hot rows doubles
+    // (simulated: hit rate 0.75 -> 0.85 at RMAT-22).  The hop that PRODUCES the state writes row v at slot perm[v] (bitexpand.hip).
+    u32* perm = nullptr;
 };
+const u32* bp_xplan_perm(const BpXPlan* p) { return p ? p->perm : nullptr; }
 
 void bp_xplan_release(fgpu_ctx* ctx, BpXPlan* p) {
     if (!p) return;
     if (ctx) {
         ctx->dev_free(p->pcol); ctx->dev_free(p->pstart_dev); ctx->dev_free(p->cstart); ctx->dev_free(p->crun0); ctx->dev_free(p->cshared); ctx->dev_free(p->zrows);
-        ctx->dev_free(p->ne); ctx->dev_free(p->pbase);
+        ctx->dev_free(p->ne); ctx->dev_free(p->pbase); ctx->dev_free(p->perm);
     }
     delete p;
 }
@@ -72,8 +79,8 @@ void bp_xplan_release(fgpu_ctx* ctx, BpXPlan* p) {
 // (cnt counts down: the order inside a run does not matter to an OR; whichever entry lands first carries the flag).
 template <bool FILL>
 __global__ __launch_bounds__(256) void xp_walk_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ colidx, u32 n, u32 ng,
-                                                      u32 prange, u32* __restrict__ cnt, const u32* __restrict__ off,
-                                                      u32* __restrict__ pcol) {
+                                                      u32 prange, const u32* __restrict__ perm, u32* __restrict__ cnt,
+                                                      const u32* __restrict__ off, u32* __restrict__ pcol) {
     __shared__ u32 s_off[4][65];
     const u32 lane = lane_id(), wib = threadIdx.x >> 6;
     const u32 wave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void xp_walk_kernel(const u32* __restrict__ ro
 #pragma unroll
             for (u32 step = 32; step >= 1; step >>= 1)
                 if (so[lo + step] <= q) lo += step;
-            const u32 u = colidx[q];
+            const u32 u = perm ? perm[colidx[q]] : colidx[q];     // the row's SLOT in the state
             const size_t i = (size_t)(u / prange) * n + v0 + lo;
             if (!FILL) {
                 atomicAdd(&cnt[i], 1u);
@@ -158,6 +165,21 @@ __global__ void xp_shared_rows_kernel(const u32* __restrict__ crun0, const uint8
     if (c < nchunks && cshared[c]) zrows[atomicAdd(count, 1u)] = crun0[c];   // (a run over several chunks is listed once per chunk: harmless)
 }
 
+__global__ void xp_deg_hist_kernel(const u32* __restrict__ rowptr, u32 n, u32* __restrict__ hist) {
+    for (u32 u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+        const u32 d = rowptr[u + 1] - rowptr[u];
+        atomicAdd(&hist[65535u - (d < 65535u ? d : 65535u)], 1u);
+    }
+}
+__global__ void xp_rank_kernel(const u32* __restrict__ rowptr, u32 n, u32 prange, u32* __restrict__ cursor /* bucket bases, counted up */,
+                               u32* __restrict__ perm) {
+    for (u32 u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
+        const u32 d = rowptr[u + 1] - rowptr[u];
+        const u32 rank = atomicAdd(&cursor[65535u - (d < 65535u ? d : 65535u)], 1u);
+        perm[u] = (rank & 7u) * prange + (rank >> 3);
+    }
+}
+
 fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const BpXPlan** out) {
     *out = nullptr;
     if (!ctx->opt.expand_xcd || !t || t->is_hyper()) return FGPU_OK;
@@ -179,8 +201,21 @@ fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const Bp
     u32 wgrid = cdiv(ng, 4);
     if (wgrid > (u32)ctx->cus * 16) wgrid = ctx->cus * 16;
     const u32 prange = (u32)((((t->ncols + 7) / 8) + 15) & ~15ull);
+    if (ctx->opt.expand_xcd_relabel && !m->is_hyper() && m->nrows == t->ncols && t->ncols % 128 == 0 && (u64)prange * 8 == t->ncols) {
+        // rank the rows of X by out-degree (65536 buckets, descending; ties in any order) and deal the ranks to the partitions
+        const u32 nu = (u32)t->ncols;
+        DevBuf<u32> hist, base;
+        FGPU_TRY(hist.alloc(ctx, 65536 + 1));
+        FGPU_TRY(base.alloc(ctx, 65536 + 1));
+        FGPU_HIP(hipMemsetAsync(hist.p, 0, (65536 + 1) * sizeof(u32), st));
+        FGPU_TRY(ctx->dev_alloc((void**)&xp->perm, (size_t)nu * sizeof(u32)));
+        hipLaunchKernelGGL(xp_deg_hist_kernel, dim3(ctx->cus * 8), dim3(256), 0, st, (const u32*)m->rowptr, nu, hist.p);
+        FGPU_TRY(scan_u32(ctx, hist.p, base.p, 65536 + 1, nullptr));
+        hipLaunchKernelGGL(xp_rank_kernel, dim3(ctx->cus * 8), dim3(256), 0, st, (const u32*)m->rowptr, nu, prange, base.p, xp->perm);
+        FGPU_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(xp_walk_kernel<false>, dim3(wgrid), dim3(256), 0, st, (const u32*)t->rowptr, (const u32*)t->colidx, n, ng, prange,
-                       cnt.p, (const u32*)nullptr, (u32*)nullptr);
+                       (const u32*)xp->perm, cnt.p, (const u32*)nullptr, (u32*)nullptr);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY(scan_u32(ctx, cnt.p, off.p, total + 1, nullptr));
     hipLaunchKernelGGL(xp_nonempty_kernel, dim3(ctx->cus * 16), dim3(256), 0, st, (const u32*)cnt.p, total, ridx.p);
@@ -203,7 +238,7 @@ fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const Bp
     FGPU_TRY(ctx->h2d(xp->pstart_dev, hp, 27 * sizeof(u32)));
     FGPU_TRY(ctx->dev_alloc((void**)&xp->pcol, ((size_t)t->nnz + 64) * sizeof(u32)));
     hipLaunchKernelGGL(xp_walk_kernel<true>, dim3(wgrid), dim3(256), 0, st, (const u32*)t->rowptr, (const u32*)t->colidx, n, ng, prange,
-                       cnt.p, (const u32*)off.p, xp->pcol);
+                       (const u32*)xp->perm, cnt.p, (const u32*)off.p, xp->pcol);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY(ctx->dev_alloc((void**)&xp->ne, (size_t)8 * ng * sizeof(u64)));
     FGPU_TRY(ctx->dev_alloc((void**)&xp->pbase, ((size_t)8 * ng + 1) * sizeof(u32)));

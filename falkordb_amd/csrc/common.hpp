@@ -94,6 +94,7 @@ struct fgpu_options {  // fgpu_set_option
     int expand_first_hop = 1;  // fgpu_expand*: a clean first hop from one-entry rows copies the source rows (0 = the general product; A/B)
     int expand_xcd = 1;        // dense count hop of the bit-parallel chain: 1 = the rows of X are gathered by the XCD that owns their
                                // partition, partial rows folded per vertex (bitpart.hip), 0 = every workgroup gathers from all of X (A/B)
+    int expand_xcd_relabel = 1; // ... and the state it reads is laid out hot-first per partition by the hop that produces it (0 = vertex order; A/B)
     int expand_xcd_min_mb = 32; // ... when the bit state holds at least this many MiB (8 L2s of 4 MiB; below that the plain pull)
     int pinned_results = 1;    // result arrays >= 256 KiB come from the context's pinned-host pool and are filled by DMA (0 = the
                                // caller's allocator / malloc + staged copies, the round-3 path; A/B)
@@ -494,6 +495,9 @@ struct BitState {
     bool lazy = false;
     // a chain whose EMPTY source rows were dropped before it went to bits (spgemm.hip compact_source_rows): bit i stands for
     // source row rowmap[i] — the checksum's row hashes and the emitted row pointers need to know (nullptr: bit i = row i)
+    // row v of the state lives at slot perm[v] (nullptr: at v): the layout the XCD-partitioned count hop gathers from
+    // (bitpart.hip BpXPlan::perm, owned by the next hop's matrix); only the state that FEEDS a count hop is ever permuted
+    const u32* perm = nullptr;
     DevBuf<u32> rowmap;
     DevBuf<u32> rowrank;   // nsrc_full + 1 entries: live rows before source row i (the way back for chains that emit rows)
     u32 nsrc_full = 0;     // source rows before the compaction (0: not compacted)
@@ -503,8 +507,10 @@ fgpu_info bp_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f);
 fgpu_info bp_push_from_csr(fgpu_ctx* ctx, BitState& s, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* dp,
                            const fgpu_mat* dm);
 // `next_m` (nullable): the base matrix of the hop after this one, if it will run in bit form too
+// `count_next` (nullable): the base matrix of the NEXT hop when that hop is the counting end of the chain (bp_hop_count) — the
+// state is then written in the layout its partitioned form gathers from
 fgpu_info bp_hop(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm, u64* flops,
-                 const fgpu_mat* next_m = nullptr);
+                 const fgpu_mat* next_m = nullptr, const fgpu_mat* count_next = nullptr);
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out);
 // the last hop of an all-pinned batch read off the state: one bit per row (bitexpand.hip)
 fgpu_info bp_probe_rows(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,

@@ -820,6 +820,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.expand_first_hop = value != 0;
     } else if (!strcmp(name, "expand_xcd")) {
         ctx->opt.expand_xcd = value != 0;
+    } else if (!strcmp(name, "expand_xcd_relabel")) {
+        ctx->opt.expand_xcd_relabel = value != 0;
     } else if (!strcmp(name, "expand_xcd_min_mb")) {
         FGPU_REQUIRE(value >= 0 && value <= (1 << 20), FGPU_INVALID, "expand_xcd_min_mb out of range");
         ctx->opt.expand_xcd_min_mb = (int)value;

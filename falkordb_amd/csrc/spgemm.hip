@@ -337,9 +337,11 @@ static fgpu_info check_hops(const fgpu_mat* const* m, const fgpu_mat* const* dp,
 // scans the <= 4096 source degrees, one read-back of the size, and one copy kernel that also sums the NEXT hop's traversed
 // edges (sum over the copied entries of deg_next(col): what mxm_flops would compute for the form decision of hop 2).
 constexpr u32 FH_MAX_ROWS = 4096;
-__global__ __launch_bounds__(1024) void first_hop_scan_kernel(CsrView f, CsrView m, u32 k, u32* __restrict__ rp, u32* __restrict__ total) {
+__global__ __launch_bounds__(1024) void first_hop_scan_kernel(CsrView f, CsrView m, u32 k, u32* __restrict__ rp, u32* __restrict__ total,
+                                                              unsigned long long* __restrict__ tnext_slots) {
     __shared__ u32 s_wave[16];
     __shared__ u32 s_base;
+    tnext_slots[threadIdx.x] = 0ull;              // the 64 x 16 words first_hop_copy_kernel sums into (one launch less than a memset)
     u32 d[4], sum = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                 // thread t owns rows 4 t .. 4 t + 3 (consecutive: the scan stays in order)
@@ -373,28 +375,38 @@ __global__ __launch_bounds__(1024) void first_hop_scan_kernel(CsrView f, CsrView
     }
     if (threadIdx.x == 0) total[0] = s_base;
 }
-// a wavefront per source row: copy the row of m, sum deg_next over its column ids (nxt.rowptr nullable)
-__global__ __launch_bounds__(256) void first_hop_copy_kernel(CsrView f, CsrView m, u32 k, const u32* __restrict__ rp, u32* __restrict__ col,
+// a lane per RESULT entry (the row of an entry by a search of the <= 4097 row pointers in LDS): a hub source — one :P vertex in
+// a thousand has 10^5 out-edges — was copied by ONE wavefront in the first version, 27 us of a 1.45 ms batch.  Sums deg_next
+// over the copied column ids (next_rowptr nullable); workgroup 0 also writes the result's row pointers.
+__global__ __launch_bounds__(256) void first_hop_copy_kernel(CsrView f, CsrView m, u32 k, const u32* __restrict__ rp, u32 nnz,
+                                                             u32* __restrict__ out_rowptr, u32* __restrict__ col,
                                                              const u32* __restrict__ next_rowptr, u32 next_rows,
                                                              unsigned long long* __restrict__ tnext) {
-    const u32 lane = lane_id();
-    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    __shared__ u32 s_rp[FH_MAX_ROWS + 1];
+    for (u32 i = threadIdx.x; i <= k; i += 256) {
+        const u32 v = rp[i];
+        s_rp[i] = v;
+        if (blockIdx.x == 0) out_rowptr[i] = v;
+    }
+    __syncthreads();
     u64 t = 0;
-    for (u32 i = wave; i < k; i += nwaves) {
-        if (f.rowptr[i + 1] == f.rowptr[i]) continue;
-        u32 b, e;
-        row_range(m, f.colidx[f.rowptr[i]], b, e);
-        const u32 o = rp[i];
-        for (u32 q = b + lane; q < e; q += 64) {
-            const u32 c = m.colidx[q];
-            col[o + (q - b)] = c;
-            if (next_rowptr && c < next_rows) t += next_rowptr[c + 1] - next_rowptr[c];
+    for (u32 q = blockIdx.x * 256 + threadIdx.x; q < nnz; q += gridDim.x * 256) {
+        u32 lo = 0, hi = k - 1;                              // largest row with s_rp[row] <= q
+        while (lo < hi) {
+            const u32 mid = (lo + hi + 1) >> 1;
+            if (s_rp[mid] <= q) lo = mid; else hi = mid - 1;
         }
+        u32 b, e;
+        row_range(m, f.colidx[f.rowptr[lo]], b, e);
+        const u32 c = m.colidx[b + (q - s_rp[lo])];
+        col[q] = c;
+        if (next_rowptr && c < next_rows) t += next_rowptr[c + 1] - next_rowptr[c];
     }
     if (tnext) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
-        if (lane == 0 && t) atomicAdd(&tnext[(wave & 63u) * 16u], (unsigned long long)t);   // 64 slots, a 128-byte line apart
+        const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+        if (lane_id() == 0 && t) atomicAdd(&tnext[(wave & 63u) * 16u], (unsigned long long)t);   // 64 slots, a 128-byte line apart
     }
 }
 // the 64 slots summed; lane 0 publishes the sum into the lane's mapped line itself when there is one (ctx.hip pub_begin)
@@ -421,9 +433,12 @@ static fgpu_info first_hop_rows(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat
     const u32 k = (u32)f->nrows;
     if (k == 0 || k > FH_MAX_ROWS || f->is_hyper() || f->nnz > f->nrows || m->nnz == 0 || f->nnz == 0) return FGPU_NO_VALUE;
     DevBuf<u32> rp, tot;
+    DevBuf<u64> tn;
     FGPU_TRY(rp.alloc(ctx, (size_t)k + 1));
     FGPU_TRY(tot.alloc(ctx, 1));
-    hipLaunchKernelGGL(first_hop_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream(), view_of(f), view_of(m), k, rp.p, tot.p);
+    FGPU_TRY(tn.alloc(ctx, 64 * 16));
+    hipLaunchKernelGGL(first_hop_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream(), view_of(f), view_of(m), k, rp.p, tot.p,
+                       (unsigned long long*)tn.p);
     FGPU_HIP(hipGetLastError());
     u32 nnz = 0;
     FGPU_TRY(read_u32(ctx, tot.p, &nnz));
@@ -431,19 +446,13 @@ static fgpu_info first_hop_rows(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat
     fgpu_mat* c = nullptr;
     FGPU_TRY(mat_alloc(ctx, &c, k, m->ncols, nnz, false, 0, false));
     const bool sum_next = next && !next->is_hyper() && next->nnz && nnz;
-    DevBuf<u64> tn;
     fgpu_info i = FGPU_OK;
-    if (sum_next) {
-        i = tn.alloc(ctx, 64 * 16);
-        if (i == FGPU_OK && hipMemsetAsync(tn.p, 0, 64 * 16 * sizeof(u64), ctx->stream()) != hipSuccess) i = FGPU_DEVICE;
-    }
-    if (i == FGPU_OK && hipMemcpyAsync(c->rowptr, rp.p, ((size_t)k + 1) * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()) != hipSuccess)
-        i = FGPU_DEVICE;
-    if (i == FGPU_OK && nnz) {
-        u32 grid = cdiv(k, 4);
-        hipLaunchKernelGGL(first_hop_copy_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(f), view_of(m), k, (const u32*)rp.p,
-                           c->colidx, sum_next ? (const u32*)next->rowptr : (const u32*)nullptr, sum_next ? (u32)next->nrows : 0u,
-                           sum_next ? (unsigned long long*)tn.p : (unsigned long long*)nullptr);
+    {
+        u32 grid = cdiv(nnz ? nnz : 1, 256 * 4);
+        if (grid > (u32)ctx->cus * 4) grid = ctx->cus * 4;
+        hipLaunchKernelGGL(first_hop_copy_kernel, dim3(grid ? grid : 1), dim3(256), 0, ctx->stream(), view_of(f), view_of(m), k,
+                           (const u32*)rp.p, nnz, c->rowptr, c->colidx, sum_next ? (const u32*)next->rowptr : (const u32*)nullptr,
+                           sum_next ? (u32)next->nrows : 0u, sum_next ? (unsigned long long*)tn.p : (unsigned long long*)nullptr);
         if (hipGetLastError() != hipSuccess) i = FGPU_DEVICE;
     }
     if (i == FGPU_OK && sum_next) {
@@ -476,11 +485,46 @@ __global__ void cr_flag_kernel(const u32* __restrict__ rowptr, u32 k, u32* __res
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= k) flag[i] = (i < k && rowptr[i + 1] > rowptr[i]) ? 1u : 0u;
 }
-__global__ void cr_build_kernel(const u32* __restrict__ rowptr, u32 k, const u32* __restrict__ flag, const u32* __restrict__ rank,
-                                u32* __restrict__ new_rowptr, u32* __restrict__ map, u32 nlive) {
+// k <= 4096 rows (a child batch holds 1024): flags, their exclusive scan and the read-back of the live count in ONE
+// single-workgroup launch (was: flag kernel, scan, a one-thread publish kernel)
+__global__ __launch_bounds__(1024) void cr_rank_kernel(const u32* __restrict__ rowptr, u32 k, u32* __restrict__ rank, u32* __restrict__ pub,
+                                                       u32 seq) {
+    __shared__ u32 s_wave[16];
+    u32 d[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = threadIdx.x * 4 + j;
+        d[j] = (i < k && rowptr[i + 1] > rowptr[i]) ? 1u : 0u;
+        sum += d[j];
+    }
+    u32 inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = (u32)__shfl_up((int)inc, o, 64); if ((int)lane_id() >= o) inc += v; }
+    if (lane_id() == 63) s_wave[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int w = 0; w < 16; ++w) { const u32 v = s_wave[w]; s_wave[w] = run; run += v; }
+    }
+    __syncthreads();
+    u32 off = s_wave[threadIdx.x >> 6] + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = threadIdx.x * 4 + j;
+        if (i <= k) rank[i] = off;
+        if (i == k && pub) {
+            __hip_atomic_store(pub + 0, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pub + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        off += d[j];
+    }
+}
+__global__ void cr_build_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ colidx, u32 k, u32 nnz, const u32* __restrict__ rank,
+                                u32* __restrict__ new_rowptr, u32* __restrict__ new_colidx, u32* __restrict__ map, u32 nlive) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < k && flag[i]) { new_rowptr[rank[i]] = rowptr[i]; map[rank[i]] = i; }
+    if (i < k && rowptr[i + 1] > rowptr[i]) { new_rowptr[rank[i]] = rowptr[i]; map[rank[i]] = i; }
     if (i == k) new_rowptr[nlive] = rowptr[k];
+    for (u32 q = i; q < nnz; q += gridDim.x * blockDim.x) new_colidx[q] = colidx[q];   // (the entries stay where they are)
 }
 static u32 bits_stride(u32 rows) {                         // = bp_layout's row stride for `rows` source rows
     u32 w = (rows + 63) / 64;
@@ -496,22 +540,34 @@ static fgpu_info compact_source_rows(fgpu_ctx* ctx, const fgpu_mat* f, fgpu_mat*
     const u32 k = (u32)f->nrows;
     if (f->is_hyper() || k < 128 || f->nnz == 0) return FGPU_OK;
     DevBuf<u32> flag, rank;
-    FGPU_TRY(flag.alloc(ctx, (size_t)k + 1));
     FGPU_TRY(rank.alloc(ctx, (size_t)k + 1));
-    hipLaunchKernelGGL(cr_flag_kernel, dim3(cdiv((u64)k + 1, 256)), dim3(256), 0, ctx->stream(), (const u32*)f->rowptr, k, flag.p);
-    FGPU_HIP(hipGetLastError());
-    FGPU_TRY(scan_u32(ctx, flag.p, rank.p, (u64)k + 1, nullptr));
     u32 nlive = 0;
-    FGPU_TRY(read_u32(ctx, rank.p + k, &nlive));
+    u32* pub = nullptr;
+    u32 seq = 0;
+    if (k <= 4095 && pub_begin(ctx, &pub, &seq)) {
+        hipLaunchKernelGGL(cr_rank_kernel, dim3(1), dim3(1024), 0, ctx->stream(), (const u32*)f->rowptr, k, rank.p, pub, seq);
+        FGPU_HIP(hipGetLastError());
+        u32 w[1] = {0};
+        FGPU_TRY(pub_wait(ctx, seq, 1, w));
+        nlive = w[0];
+    } else {
+        FGPU_TRY(flag.alloc(ctx, (size_t)k + 1));
+        hipLaunchKernelGGL(cr_flag_kernel, dim3(cdiv((u64)k + 1, 256)), dim3(256), 0, ctx->stream(), (const u32*)f->rowptr, k, flag.p);
+        FGPU_HIP(hipGetLastError());
+        FGPU_TRY(scan_u32(ctx, flag.p, rank.p, (u64)k + 1, nullptr));
+        FGPU_TRY(read_u32(ctx, rank.p + k, &nlive));
+    }
     if (nlive == 0 || bits_stride(nlive) >= bits_stride(k)) return FGPU_OK;
     fgpu_mat* c = nullptr;
     FGPU_TRY(mat_alloc(ctx, &c, nlive, f->ncols, f->nnz, false, 0, false));
     fgpu_info i = map.alloc(ctx, nlive);
     if (i == FGPU_OK) {
-        hipLaunchKernelGGL(cr_build_kernel, dim3(cdiv((u64)k + 1, 256)), dim3(256), 0, ctx->stream(), (const u32*)f->rowptr, k,
-                           (const u32*)flag.p, (const u32*)rank.p, c->rowptr, map.p, nlive);
-        if (hipGetLastError() != hipSuccess ||
-            hipMemcpyAsync(c->colidx, f->colidx, (size_t)f->nnz * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream()) != hipSuccess) {
+        u32 grid = cdiv((u64)k + 1, 256);
+        const u32 want = cdiv(f->nnz, 256 * 8);
+        if (grid < want) grid = want < (u32)ctx->cus * 4 ? want : (u32)ctx->cus * 4;
+        hipLaunchKernelGGL(cr_build_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const u32*)f->rowptr, (const u32*)f->colidx, k,
+                           (u32)f->nnz, (const u32*)rank.p, c->rowptr, c->colidx, map.p, nlive);
+        if (hipGetLastError() != hipSuccess) {
             set_error("compact_source_rows: device call failed");
             i = FGPU_DEVICE;
         }
@@ -634,7 +690,9 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 return bp_hop_count(ctx, bs, mh, dph, dmh, flops, dst_label_bitmap ? bm.p : nullptr, &count_only[0],
                                     want_checksum ? &count_only[1] : nullptr);
             }
-            FGPU_TRY(bp_hop(ctx, bs, mh, dph, dmh, flops, (flops && h + 1 < nhops) ? m[h + 1] : nullptr));
+            // (the hop right before a counting end of the chain writes its state in the layout that end gathers from)
+            FGPU_TRY(bp_hop(ctx, bs, mh, dph, dmh, flops, (flops && h + 1 < nhops) ? m[h + 1] : nullptr,
+                            (count_only && ctx->opt.expand_fuse_count && !keep_bits && h + 2 == nhops) ? m[h + 1] : nullptr));
             continue;
         }
         fgpu_mat* c = nullptr;

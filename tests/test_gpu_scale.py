@@ -73,14 +73,14 @@ def test_khop_rmat20_dirty_layers_match_the_oracle(ctx, rmat20, mode):
 
 @pytest.fixture(scope="module")
 def rmat20_refs(rmat20):
-    """(nnz, checksum, flops) of the 3-hop chain at RMAT-20 for source sets of 100 / 160 / 200 / 400 / 640 rows — bit rows of 2 /
-    4 (three in use) / 4 / 8 / 16 words, every width the partitioned count hop serves — clean and dirty; for 400 rows also under
+    """(nnz, checksum, flops) of the 3-hop chain at RMAT-20 for source sets of 100 / 160 / 400 / 640 rows — bit rows of 2 /
+    4 (three in use) / 8 / 16 words, every width the partitioned count hop serves — clean and dirty; for 400 rows also under
     a destination label."""
     A, dp, dm, a, hdp, hdm = rmat20
     allsrc = p_sources(a.nrows, 1024)
     label = oracle.mix64(np.arange(a.nrows, dtype=U64)) % U64(3) != 0
     refs = {}
-    for nsrc in (100, 160, 200, 400, 640):
+    for nsrc in (100, 160, 400, 640):
         src = allsrc[:nsrc]
         for dirty in (False, True):
             c, flops, _ = oracle.expand_omp(src, [(a, hdp, hdm) if dirty else (a, None, None)] * 3)
@@ -95,8 +95,7 @@ def rmat20_refs(rmat20):
     return allsrc, refs, oracle.bits_from_ids(a.nrows, np.nonzero(label)[0])
 
 
-@pytest.mark.parametrize("xcd", [1, 0])
-@pytest.mark.parametrize("nsrc", [100, 160, 200, 400, 640])
+@pytest.mark.parametrize("xcd,nsrc", [(1, 100), (1, 160), (1, 400), (1, 640), (0, 400)])
 def test_khop_rmat20_count_hop_partitioned_by_xcd(ctx, rmat20, rmat20_refs, xcd, nsrc):
     """The dense count hop in its XCD-partitioned form (bitpart.hip: every entry of A' gathered by the XCD that owns its row of
     X, partial rows folded per vertex) against the oracle's (nnz, checksum, flops): bit rows of 2 / 4 / 8 / 16 words, clean and
@@ -125,45 +124,56 @@ def test_khop_rmat20_count_hop_partitioned_by_xcd(ctx, rmat20, rmat20_refs, xcd,
         ctx.set_option("expand_xcd_min_mb", 32)
 
 
+@pytest.fixture(scope="module")
+def probe_cases(rmat20):
+    """Per (hops, dirty): 200 :P sources, a bound destination for each — drawn from the row itself, from the vertices the
+    tombstones removed, at random, beyond the matrix — and whether the oracle's delta_lmxm chain reaches it."""
+    A, dp, dm, a, hdp, hdm = rmat20
+    k = 200
+    src = p_sources(a.nrows, k, first=7000)
+    cases = {}
+    for hops in (1, 2, 3):
+        clean_c = oracle.expand_omp(src, [(a, None, None)] * hops)[0]
+        for dirty in (False, True):
+            c = oracle.expand_omp(src, [(a, hdp, hdm)] * hops)[0] if dirty else clean_c
+            rng = np.random.default_rng(100 * hops + dirty)
+            dst = np.zeros(k, dtype=U64)
+            want = np.zeros(k, dtype=bool)
+            for i in range(k):
+                row = c.colidx[int(c.rowptr[i]):int(c.rowptr[i + 1])]
+                crow = clean_c.colidx[int(clean_c.rowptr[i]):int(clean_c.rowptr[i + 1])]
+                r = i % 4
+                if r == 0 and len(row):
+                    dst[i] = row[rng.integers(0, len(row))]                 # reached
+                elif r == 1 and len(crow):
+                    dst[i] = crow[rng.integers(0, len(crow))]               # reached over clean layers: maybe tombstoned now
+                elif r == 2:
+                    dst[i] = rng.integers(0, a.nrows)
+                else:
+                    dst[i] = a.nrows + 5 if i % 8 == 3 else rng.integers(0, a.nrows)
+                j = np.searchsorted(row, dst[i])
+                want[i] = j < len(row) and row[j] == dst[i]
+            assert want.sum() > k // 5 and (~want).sum() > k // 5
+            cases[(hops, dirty)] = (dst, want)
+    return src, cases
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("hops", [1, 2, 3])
-def test_expand_probe_all_rows_pinned_matches_the_oracle(ctx, rmat20, mode, hops):
+def test_expand_probe_all_rows_pinned_matches_the_oracle(ctx, rmat20, probe_cases, mode, hops):
     """fgpu_expand_probe — every row of the batch has a pre-bound destination (CondTraverse with `to` bound, the multi-hop
     ExpandInto shape of tests/flow/test_expand_into.py:63-95; cond_traverse.rs:657-661): present[i] must say whether dst[i] is
     in row i of the oracle's delta_lmxm chain — for 1 / 2 / 3 hops, clean and dirty layers (the row-level tombstone mask of
     matrix.rs:1343-1361 decides single entries here), with the chain kept in sorted-CSR form (mode 1: the last hop is a binary
     search per frontier entry), in bit form from the first hop (mode 2: one bit of one row of the state) and left to choose;
-    destinations drawn from the row itself, from the vertices the tombstones removed, at random, beyond the matrix, and under
-    a destination label; an unbound source."""
+    under a destination label; with an unbound source."""
     A, dp, dm, a, hdp, hdm = rmat20
-    k = 300
-    src = p_sources(a.nrows, k, first=7000)
-    rng = np.random.default_rng(100 * hops + mode)
+    src, cases = probe_cases
+    k = len(src)
     label = oracle.mix64(np.arange(a.nrows, dtype=U64)) % U64(4) != 0
     bits = oracle.bits_from_ids(a.nrows, np.nonzero(label)[0])
     for dirty in (False, True):
-        layers = [(a, hdp, hdm) if dirty else (a, None, None)] * hops
-        c, flops, _ = oracle.expand_omp(src, layers)
-        clean_c = c if not dirty else oracle.expand_omp(src, [(a, None, None)] * hops)[0]
-        dst = np.zeros(k, dtype=U64)
-        for i in range(k):
-            row = c.colidx[int(c.rowptr[i]):int(c.rowptr[i + 1])]
-            crow = clean_c.colidx[int(clean_c.rowptr[i]):int(clean_c.rowptr[i + 1])]
-            r = i % 4
-            if r == 0 and len(row):
-                dst[i] = row[rng.integers(0, len(row))]                 # reached
-            elif r == 1 and len(crow):
-                dst[i] = crow[rng.integers(0, len(crow))]               # reached over clean layers: maybe tombstoned now
-            elif r == 2:
-                dst[i] = rng.integers(0, a.nrows)
-            else:
-                dst[i] = a.nrows + 5 if i % 8 == 3 else rng.integers(0, a.nrows)
-        want = np.zeros(k, dtype=bool)
-        for i in range(k):
-            row = c.colidx[int(c.rowptr[i]):int(c.rowptr[i + 1])]
-            j = np.searchsorted(row, dst[i])
-            want[i] = j < len(row) and row[j] == dst[i]
-        assert want.sum() > k // 5 and (~want).sum() > k // 5
+        dst, want = cases[(hops, dirty)]
         gm = [A] * hops
         gl = ([dp] * hops, [dm] * hops) if dirty else (None, None)
         try:
@@ -328,7 +338,8 @@ def test_khop_rmat26_full_batch_matches_the_committed_oracle_run(ctx, bench_grap
     src = p_sources(A.nrows, 1024)
     assert gold["rows"] == 1024 and gold["edges"] == a.nnz and gold["nnz_dp"] == hdp.nnz and gold["nnz_dm"] == hdm.nnz
     assert gold["sources_sha256"] == hashlib.sha256(np.ascontiguousarray(src).tobytes()).hexdigest()
-    assert gold["colidx_sha256"] == hashlib.sha256(np.ascontiguousarray(a.colidx).tobytes()).hexdigest()
+    if not dirty:                                            # (4.3 GB: hashed once)
+        assert gold["colidx_sha256"] == hashlib.sha256(np.ascontiguousarray(a.colidx).tobytes()).hexdigest()
     ref = gold["dirty" if dirty else "clean"]
     layers = ([A] * 3, [dp] * 3, [dm] * 3) if dirty else ([A] * 3,)
     got = engine.expand_count(ctx, src, *layers)
