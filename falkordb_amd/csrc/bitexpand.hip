@@ -611,30 +611,33 @@ __global__ __launch_bounds__(256) void bp_split_stats_kernel(const u64* __restri
     const u64 field = ln == 64 ? ~0ull : (((1ull << ln) - 1ull) << (slot * ln));
     u64 fl = 0, rows = 0;
     // 64 bitmap words per step, a lane each (one dependent load per 4096 vertices instead of one per 64: the ~10^5 split rows
-    // of a hop sit in a bitmap that is almost all zeros, and a wavefront walking it word by word spent 40 us on 32 round trips)
+    // of a hop sit in a bitmap that is almost all zeros, and a wavefront walking it word by word spent 40 us on 32 round trips).
+    // The set bits of the 64 words are packed into an LDS list first, so that every step reads 64 / LN rows whatever words
+    // they came from (a dirty layer names ~2 vertices in every word: a step per word read 2 rows with 8 slots, 93 us).
+    __shared__ u32 s_list[4][256];
+    u32* list = s_list[threadIdx.x >> 6];
     for (u32 w0 = wave * 64; w0 < nwords; w0 += nwaves * 64) {
-      const u64 mine = w0 + lane < nwords ? bits[w0 + lane] : 0ull;
-      u64 nzw = __ballot(mine != 0ull);
-      while (nzw) {
-        const u32 j = (u32)__builtin_ctzll(nzw);
-        nzw &= nzw - 1ull;
-        const u32 w = w0 + j;
-        u64 m = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(mine >> 32), (int)j) << 32) |
-                (u64)(u32)__builtin_amdgcn_readlane((int)(u32)mine, (int)j);   // wave-uniform
-        while (m) {
-            u32 v = 0xFFFFFFFFu;
-            for (u32 sl = 0; sl < rpw; ++sl) {
-                if (m) {
-                    const u32 idx = (u32)__builtin_ctzll(m);
-                    m &= m - 1ull;
-                    if (slot == sl) v = (w << 6) + idx;
-                }
-            }
-            u32 pc = 0;
+      u64 mine = w0 + lane < nwords ? bits[w0 + lane] : 0ull;
+      while (__ballot(mine != 0ull)) {
+        // up to 256 vertices into the list: lane order, bit order (lanes whose bits do not fit keep them for the next round)
+        const u32 pc = (u32)__popcll(mine);
+        u32 inc = pc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)inc, o, 64); if ((int)lane >= o) inc += t; }
+        u32 at = inc - pc;
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        while (mine && at < 256u) {
+            list[at++] = ((w0 + lane) << 6) + (u32)__builtin_ctzll(mine);
+            mine &= mine - 1ull;
+        }
+        const u32 cnt = total < 256u ? total : 256u;
+        for (u32 b0 = 0; b0 < cnt; b0 += rpw) {
+            const u32 v = b0 + slot < cnt ? list[b0 + slot] : 0xFFFFFFFFu;
+            u32 pcr = 0;
             if (v != 0xFFFFFFFFu)
-                for (u32 k = wl; k < ws; k += ln) pc += (u32)__popcll(y[(size_t)(yperm ? yperm[v] : v) * ws + k]);
-            const u64 nz = __ballot(pc != 0);
-            if (pc) fl += (u64)pc * (next_rowptr[v + 1] - next_rowptr[v]);
+                for (u32 k = wl; k < ws; k += ln) pcr += (u32)__popcll(y[(size_t)(yperm ? yperm[v] : v) * ws + k]);
+            const u64 nz = __ballot(pcr != 0);
+            if (pcr) fl += (u64)pcr * (next_rowptr[v + 1] - next_rowptr[v]);
             if (wl == 0 && (nz & field)) rows += 1;
         }
       }

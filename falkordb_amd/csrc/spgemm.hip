@@ -474,6 +474,241 @@ static fgpu_info first_hop_rows(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat
     return FGPU_OK;
 }
 
+// ---- the first hop from one-entry rows over DIRTY layers -----------------------------------------------------------------
+// Row i of F holds one source u: (F·m)<not (F·dm)> U (F·dp) is then (m[u] \ dm[u]) U dp[u] row by row (the row-level mask of
+// Matrix::delta_lmxm, matrix.rs:1343-1361, is the row's own tombstones).  The general product does this in ~75 launches of a
+// few microseconds (three gathers, three sorts, the merge machinery); here: candidate offsets (one single-workgroup scan), keep
+// flags a lane per candidate (binary searches in the sorted rows), two scans of the flags, row lengths, and a fill that places
+// every kept candidate by its rank among the kept entries of both lists — the result row stays ascending and unique whatever
+// the layers hold (no Delta invariant is assumed: a dp entry that m already has is dropped, a tombstone outside m does nothing).
+__global__ __launch_bounds__(1024) void fhd_scan_kernel(CsrView f, CsrView m, CsrView dp, u32 k, u32* __restrict__ cm, u32* __restrict__ cp,
+                                                        u32* __restrict__ totals, unsigned long long* __restrict__ tnext_slots) {
+    __shared__ u32 s_wave[2][16];
+    tnext_slots[threadIdx.x] = 0ull;
+    u32 a[4], b[4], sa = 0, sb = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = threadIdx.x * 4 + j;
+        u32 da = 0, db = 0;
+        if (i < k && f.rowptr[i + 1] > f.rowptr[i]) {
+            const u32 u = f.colidx[f.rowptr[i]];
+            u32 x, y;
+            row_range(m, u, x, y); da = y - x;
+            row_range(dp, u, x, y); db = y - x;
+        }
+        a[j] = da; b[j] = db; sa += da; sb += db;
+    }
+    u32 ia = sa, ib = sb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 va = (u32)__shfl_up((int)ia, o, 64), vb = (u32)__shfl_up((int)ib, o, 64);
+        if ((int)lane_id() >= o) { ia += va; ib += vb; }
+    }
+    if (lane_id() == 63) { s_wave[0][threadIdx.x >> 6] = ia; s_wave[1][threadIdx.x >> 6] = ib; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        u32 run = 0;
+        for (int w = 0; w < 16; ++w) { const u32 v = s_wave[threadIdx.x][w]; s_wave[threadIdx.x][w] = run; run += v; }
+        totals[threadIdx.x] = run;
+    }
+    __syncthreads();
+    u32 oa = s_wave[0][threadIdx.x >> 6] + ia - sa, ob = s_wave[1][threadIdx.x >> 6] + ib - sb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = threadIdx.x * 4 + j;
+        if (i <= k) { cm[i] = oa; cp[i] = ob; }
+        oa += a[j]; ob += b[j];
+    }
+}
+__device__ __forceinline__ u32 fhd_lower_bound(const u32* __restrict__ col, u32 b, u32 e, u32 x) {
+    while (b < e) {
+        const u32 mid = (b + e) >> 1;
+        if (col[mid] < x) b = mid + 1; else e = mid;
+    }
+    return b;
+}
+// the row of candidate q: largest i with ptr[i] <= q (k + 1 offsets in LDS)
+__device__ __forceinline__ u32 fhd_row_of(const u32* s_ptr, u32 k, u32 q) {
+    u32 lo = 0, hi = k - 1;
+    while (lo < hi) {
+        const u32 mid = (lo + hi + 1) >> 1;
+        if (s_ptr[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// FILL = false: keep flags.  FILL = true: every kept candidate to its place (rank among the kept entries of both lists).
+template <bool FILL>
+__global__ __launch_bounds__(256) void fhd_cand_kernel(CsrView f, CsrView m, CsrView dp, CsrView dm, u32 k, const u32* __restrict__ cm,
+                                                       const u32* __restrict__ cp, u32 ncm, u32 ncp, u32* __restrict__ keepm,
+                                                       u32* __restrict__ keepp, const u32* __restrict__ pm, const u32* __restrict__ pp,
+                                                       const u32* __restrict__ rowptr, u32* __restrict__ col,
+                                                       const u32* __restrict__ next_rowptr, u32 next_rows,
+                                                       unsigned long long* __restrict__ tnext) {
+    __shared__ u32 s_cm[FH_MAX_ROWS + 1], s_cp[FH_MAX_ROWS + 1];
+    for (u32 i = threadIdx.x; i <= k; i += 256) { s_cm[i] = cm[i]; s_cp[i] = cp[i]; }
+    __syncthreads();
+    u64 t = 0;
+    for (u32 q = blockIdx.x * 256 + threadIdx.x; q < ncm + ncp; q += gridDim.x * 256) {
+        const bool from_m = q < ncm;
+        const u32 c = from_m ? q : q - ncm;
+        const u32 i = fhd_row_of(from_m ? s_cm : s_cp, k, c);
+        const u32 u = f.colidx[f.rowptr[i]];
+        u32 mb, me, pb, pe, db, de;
+        row_range(m, u, mb, me);
+        row_range(dp, u, pb, pe);
+        row_range(dm, u, db, de);
+        const u32 j = c - (from_m ? s_cm[i] : s_cp[i]);
+        const u32 x = from_m ? m.colidx[mb + j] : dp.colidx[pb + j];
+        const u32 dl = fhd_lower_bound(dm.colidx, db, de, x);
+        const bool tomb = dl < de && dm.colidx[dl] == x;
+        bool keep;
+        u32 other = 0;                                       // index of x's lower bound in the OTHER list
+        if (from_m) {
+            keep = !tomb;
+            if (FILL) other = fhd_lower_bound(dp.colidx, pb, pe, x) - pb;
+        } else {
+            const u32 ml = fhd_lower_bound(m.colidx, mb, me, x);
+            keep = !(ml < me && m.colidx[ml] == x && !tomb);  // (m keeps x itself: the dp copy is a duplicate)
+            other = ml - mb;
+        }
+        if (!FILL) {
+            (from_m ? keepm : keepp)[c] = keep ? 1u : 0u;
+        } else if (keep) {
+            const u32 pos = from_m ? (pm[c] - pm[s_cm[i]]) + (pp[s_cp[i] + other] - pp[s_cp[i]])
+                                   : (pp[c] - pp[s_cp[i]]) + (pm[s_cm[i] + other] - pm[s_cm[i]]);
+            col[rowptr[i] + pos] = x;
+            if (next_rowptr && x < next_rows) t += next_rowptr[x + 1] - next_rowptr[x];
+        }
+    }
+    if (FILL && tnext) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+        if (lane_id() == 0 && t) atomicAdd(&tnext[(wave & 63u) * 16u], (unsigned long long)t);
+    }
+}
+// row lengths from the two flag scans, their exclusive scan, the total published (k <= 4095)
+__global__ __launch_bounds__(1024) void fhd_rowptr_kernel(const u32* __restrict__ cm, const u32* __restrict__ cp, const u32* __restrict__ pm,
+                                                          const u32* __restrict__ pp, u32 k, u32* __restrict__ rowptr, u32* __restrict__ pub,
+                                                          u32 seq, u32* __restrict__ total) {
+    __shared__ u32 s_wave[16];
+    u32 d[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = threadIdx.x * 4 + j;
+        d[j] = i < k ? (pm[cm[i + 1]] - pm[cm[i]]) + (pp[cp[i + 1]] - pp[cp[i]]) : 0u;
+        sum += d[j];
+    }
+    u32 inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = (u32)__shfl_up((int)inc, o, 64); if ((int)lane_id() >= o) inc += v; }
+    if (lane_id() == 63) s_wave[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int w = 0; w < 16; ++w) { const u32 v = s_wave[w]; s_wave[w] = run; run += v; }
+    }
+    __syncthreads();
+    u32 off = s_wave[threadIdx.x >> 6] + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = threadIdx.x * 4 + j;
+        if (i <= k) rowptr[i] = off;
+        if (i == k) {
+            total[0] = off;
+            if (pub) {
+                __hip_atomic_store(pub + 0, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(pub + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        off += d[j];
+    }
+}
+
+static fgpu_info first_hop_rows_dirty(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat* m, const fgpu_mat* dp, const fgpu_mat* dm,
+                                      const fgpu_mat* next, fgpu_mat** out, u64* T0, u64* Tnext, bool* have_next) {
+    *have_next = false;
+    const u32 k = (u32)f->nrows;
+    if (k == 0 || k >= FH_MAX_ROWS || f->is_hyper() || f->nnz > f->nrows || f->nnz == 0 || m->is_hyper()) return FGPU_NO_VALUE;
+    hipStream_t st = ctx->stream();
+    DevBuf<u32> cm, cp, tot, empty;
+    DevBuf<u64> tn;
+    FGPU_TRY(cm.alloc(ctx, (size_t)k + 1));
+    FGPU_TRY(cp.alloc(ctx, (size_t)k + 1));
+    FGPU_TRY(tot.alloc(ctx, 4));
+    FGPU_TRY(tn.alloc(ctx, 64 * 16));
+    FGPU_TRY(empty.alloc(ctx, 4));
+    FGPU_HIP(hipMemsetAsync(empty.p, 0, 4 * sizeof(u32), st));
+    auto view_or_empty = [&](const fgpu_mat* a) {
+        if (a && a->nnz) return view_of(a);
+        CsrView v;                                           // hypersparse with no stored row: every row_range is empty
+        v.rowptr = empty.p; v.colidx = empty.p; v.hrows = empty.p; v.nvec = 0; v.nrows = (u32)m->nrows;
+        return v;
+    };
+    const CsrView vm = view_of(m), vdp = view_or_empty(dp), vdm = view_or_empty(dm), vf = view_of(f);
+    hipLaunchKernelGGL(fhd_scan_kernel, dim3(1), dim3(1024), 0, st, vf, vm, vdp, k, cm.p, cp.p, tot.p, (unsigned long long*)tn.p);
+    FGPU_HIP(hipGetLastError());
+    u32 w2[2] = {0, 0};
+    FGPU_TRY(read_words(ctx, tot.p, 2, w2));
+    const u32 ncm = w2[0], ncp = w2[1];
+    *T0 = (u64)ncm + ncp;                                    // traversed edges of the hop: deg over m and over dp
+    DevBuf<u32> keepm, keepp, pm, pp;
+    FGPU_TRY(keepm.alloc(ctx, (size_t)ncm + 1)); FGPU_TRY(keepp.alloc(ctx, (size_t)ncp + 1));
+    FGPU_TRY(pm.alloc(ctx, (size_t)ncm + 1)); FGPU_TRY(pp.alloc(ctx, (size_t)ncp + 1));
+    u32 grid = cdiv((u64)ncm + ncp ? (u64)ncm + ncp : 1, 256 * 2);
+    if (grid > (u32)ctx->cus * 4) grid = ctx->cus * 4;
+    FGPU_HIP(hipMemsetAsync(keepm.p + ncm, 0, sizeof(u32), st));
+    FGPU_HIP(hipMemsetAsync(keepp.p + ncp, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(fhd_cand_kernel<false>, dim3(grid ? grid : 1), dim3(256), 0, st, vf, vm, vdp, vdm, k, (const u32*)cm.p, (const u32*)cp.p,
+                       ncm, ncp, keepm.p, keepp.p, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr, (u32*)nullptr,
+                       (const u32*)nullptr, 0u, (unsigned long long*)nullptr);
+    FGPU_HIP(hipGetLastError());
+    FGPU_TRY(scan_u32(ctx, keepm.p, pm.p, (u64)ncm + 1, nullptr));
+    FGPU_TRY(scan_u32(ctx, keepp.p, pp.p, (u64)ncp + 1, nullptr));
+    DevBuf<u32> rp;
+    FGPU_TRY(rp.alloc(ctx, (size_t)k + 1));
+    u32 nnz = 0;
+    {
+        u32* pub = nullptr;
+        u32 seq = 0;
+        const bool mapped = pub_begin(ctx, &pub, &seq);
+        hipLaunchKernelGGL(fhd_rowptr_kernel, dim3(1), dim3(1024), 0, st, (const u32*)cm.p, (const u32*)cp.p, (const u32*)pm.p,
+                           (const u32*)pp.p, k, rp.p, mapped ? pub : (u32*)nullptr, seq, tot.p + 2);
+        FGPU_HIP(hipGetLastError());
+        if (mapped) { u32 w[1] = {0}; FGPU_TRY(pub_wait(ctx, seq, 1, w)); nnz = w[0]; }
+        else FGPU_TRY(read_u32(ctx, tot.p + 2, &nnz));
+    }
+    fgpu_mat* c = nullptr;
+    FGPU_TRY(mat_alloc(ctx, &c, k, m->ncols, nnz, false, 0, false));
+    const bool sum_next = next && !next->is_hyper() && next->nnz && nnz;
+    fgpu_info i = FGPU_OK;
+    if (hipMemcpyAsync(c->rowptr, rp.p, ((size_t)k + 1) * sizeof(u32), hipMemcpyDeviceToDevice, st) != hipSuccess) i = FGPU_DEVICE;
+    if (i == FGPU_OK && nnz) {
+        hipLaunchKernelGGL(fhd_cand_kernel<true>, dim3(grid ? grid : 1), dim3(256), 0, st, vf, vm, vdp, vdm, k, (const u32*)cm.p,
+                           (const u32*)cp.p, ncm, ncp, (u32*)nullptr, (u32*)nullptr, (const u32*)pm.p, (const u32*)pp.p, (const u32*)rp.p,
+                           c->colidx, sum_next ? (const u32*)next->rowptr : (const u32*)nullptr, sum_next ? (u32)next->nrows : 0u,
+                           sum_next ? (unsigned long long*)tn.p : (unsigned long long*)nullptr);
+        if (hipGetLastError() != hipSuccess) i = FGPU_DEVICE;
+    }
+    if (i == FGPU_OK && sum_next) {
+        u32* pub = nullptr;
+        u32 seq = 0;
+        const bool mapped = pub_begin(ctx, &pub, &seq);
+        hipLaunchKernelGGL(first_hop_fold_kernel, dim3(1), dim3(64), 0, st, (unsigned long long*)tn.p, mapped ? pub : (u32*)nullptr, seq);
+        if (mapped) {
+            u32 w[2] = {0, 0};
+            i = hipGetLastError() == hipSuccess ? pub_wait(ctx, seq, 2, w) : FGPU_DEVICE;
+            *Tnext = (u64)w[0] | ((u64)w[1] << 32);
+        } else {
+            i = read_u64(ctx, tn.p + 1, Tnext);
+        }
+        *have_next = i == FGPU_OK;
+    }
+    if (i != FGPU_OK) { mat_release(c); if (i == FGPU_DEVICE) set_error("dirty first hop: device call failed"); return i; }
+    *out = c;
+    return FGPU_OK;
+}
+
 // ---- dropping the empty source rows of a count-only chain before it goes to bits ------------------------------------------
 // A source without out-edges (half of the vertices of an R-MAT graph, half of a `:P` batch) leaves an empty row after the
 // first hop and can never contribute again, but keeps its bit in every 128-byte row of the bit state.  When the live rows
@@ -614,6 +849,21 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 if (flops) *flops += T0;
                 mat_release(f);
                 f = c;
+                if (have) { T_known = Tn; T_for = m[1]; T_f = f; }
+                continue;
+            }
+            if (fi != FGPU_NO_VALUE) { mat_release(f); return fi; }
+        } else if (h == 0 && mode != 2 && ctx->opt.expand_first_hop) {
+            // dirty first hop from one-entry rows: (m[u] \ dm[u]) U dp[u] row by row (first_hop_rows_dirty above)
+            fgpu_mat* c = nullptr;
+            u64 T0 = 0, Tn = 0;
+            bool have = false;
+            const fgpu_info fi = first_hop_rows_dirty(ctx, f, mh, dph, dmh, nhops > 1 ? m[1] : nullptr, &c, &T0, &Tn, &have);
+            if (fi == FGPU_OK) {
+                if (flops) *flops += T0;
+                mat_release(f);
+                f = c;
+                // (the next hop's traversed edges over its BASE matrix only: with a dirty next layer its dp part is summed there)
                 if (have) { T_known = Tn; T_for = m[1]; T_f = f; }
                 continue;
             }
