@@ -36,6 +36,7 @@ namespace fgpu {
 constexpr u32 XP_FIRST = 0x80000000u;   // bit 31 of a packed entry: first entry of its (partition, row) run
 constexpr u32 XP_SPAN = 768;       // a chunk spans < XP_SPAN of the key (entry index + XP_RUNW x run index) inside its partition:
 constexpr u32 XP_RUNW = 8;         //   <= XP_SPAN entries and <= XP_RUNS runs (the rows of its LDS tile)
+constexpr int XP_FOLD_THREADS = 256;
 constexpr u32 XP_RUNS = XP_SPAN / XP_RUNW;
 
 struct BpXPlan {
@@ -392,8 +393,11 @@ __global__ __launch_bounds__(256) void xp_stream_kernel(const u32* __restrict__ 
 // a touched row (a delta layer names it) goes to its slot of the side buffer, any other is counted (MODE 2: and its checksum
 // terms summed through the nibble tables in LDS) and never written.  A wavefront per 64-row group, 64 / QL rows per step,
 // the (up to) 8 partial rows of a vertex in flight together.
+__device__ __forceinline__ u64 xp_uniform64(u64 v) {
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
 template <int QL, int MODE>
-__global__ __launch_bounds__(256) void xp_fold_kernel(const u64* __restrict__ ne, const u32* __restrict__ pbase, u32 ng,
+__global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_kernel(const u64* __restrict__ ne, const u32* __restrict__ pbase, u32 ng,
                                                       const uint4* __restrict__ partial, BpFinal fin, uint4* __restrict__ side) {
     constexpr int SLOTS = 64 / QL;
     extern __shared__ u64 s_tab[];
@@ -411,14 +415,14 @@ __global__ __launch_bounds__(256) void xp_fold_kernel(const u64* __restrict__ ne
         u64 any = 0ull;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            nw[k] = ne[(size_t)k * ng + g];                 // (wave-uniform: scalar loads)
-            pb[k] = pbase[(size_t)k * ng + g];
+            nw[k] = xp_uniform64(ne[(size_t)k * ng + g]);   // (wave-uniform: kept in scalar registers whatever the loads were)
+            pb[k] = (u32)__builtin_amdgcn_readfirstlane((int)pbase[(size_t)k * ng + g]);
             any |= nw[k];
         }
         if (!any) continue;
-        const u64 tw = fin.tbits ? fin.tbits[g] : 0ull;      // (clean layers: no touched rows, no bitmap)
-        const u32 tp = fin.tbits ? fin.tpref[g] : 0u;
-        const u64 lb = fin.label ? fin.label[g] : ~0ull;
+        const u64 tw = fin.tbits ? xp_uniform64(fin.tbits[g]) : 0ull;      // (clean layers: no touched rows, no bitmap)
+        const u32 tp = fin.tbits ? (u32)__builtin_amdgcn_readfirstlane((int)fin.tpref[g]) : 0u;
+        const u64 lb = fin.label ? xp_uniform64(fin.label[g]) : ~0ull;
 #pragma unroll 1
         for (u32 r0 = 0; r0 < 64; r0 += SLOTS) {
             if (((any >> r0) & (SLOTS == 64 ? ~0ull : ((1ull << SLOTS) - 1ull))) == 0ull) continue;   // (wave-uniform)
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(256) void xp_fold_kernel(const u64* __restrict__ ne
                 const u64* t0 = s_tab + (size_t)k0 * 256;
                 const u64* t1 = s_tab + (size_t)k1 * 256;
                 u64 rs = 0;
+                // (all 32 look-ups in flight: batches of 8 + 8 free 30 registers and cost 35 us of exposed LDS latency at RMAT-22)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) rs += t0[j * 16 + (u32)((w0 >> (4 * j)) & 15ull)];
 #pragma unroll
@@ -507,14 +512,17 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
     }
     {
         ProfScope ps(ctx, "xp_fold_kernel", prow_bytes + (u64)8 * xp->ng * 12 + (u64)xp->ng * 20);
-        u32 grid = cdiv(xp->ng, 4);
-        if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
+        // (4 or 8 wavefronts sharing one copy of the checksum tables, 16 or 32 resident per CU: the same 214 / 148 us with and
+        // without the checksum at RMAT-22 — the kernel is not short of wavefronts)
+        const u32 fthreads = XP_FOLD_THREADS;
+        u32 grid = cdiv(xp->ng, fthreads / 64);
+        if (grid > (u32)ctx->cus * (2048u / fthreads)) grid = ctx->cus * (2048u / fthreads);
         const size_t lds = mode == 2 ? lds_tables : 0;
 #define XP_FOLD2(Q, M)                                                                                                           \
         do {                                                                                                                     \
             if (lds > 48 * 1024)                                                                                                 \
                 FGPU_HIP(hipFuncSetAttribute((const void*)xp_fold_kernel<Q, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((xp_fold_kernel<Q, M>), dim3(grid), dim3(256), lds, st, (const u64*)xp->ne, (const u32*)xp->pbase, xp->ng,  \
+            hipLaunchKernelGGL((xp_fold_kernel<Q, M>), dim3(grid), dim3(fthreads), lds, st, (const u64*)xp->ne, (const u32*)xp->pbase, xp->ng,  \
                                (const uint4*)partial.p, fin, (uint4*)side);                                                                                     \
         } while (0)
 #define XP_FOLD(Q) do { if (mode == 2) XP_FOLD2(Q, 2); else XP_FOLD2(Q, 1); } while (0)

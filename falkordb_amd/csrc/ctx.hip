@@ -854,7 +854,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         FGPU_REQUIRE(value == 0 || value == 1, FGPU_INVALID, "dist_collective must be 0 (send/recv) or 1 (broadcasts)");
         ctx->opt.dist_collective = (int)value;
     } else if (!strcmp(name, "transpose_mode")) {
-        FGPU_REQUIRE(value == 0 || value == 1, FGPU_INVALID, "transpose_mode must be 0 (counting) or 1 (COO rebuild)");
+        FGPU_REQUIRE(value >= 0 && value <= 3, FGPU_INVALID,
+                     "transpose_mode must be 0 (counting sort, form picked), 1 (COO rebuild), 2 (LDS-staged levels) or 3 (two levels)");
         ctx->opt.transpose_mode = (int)value;
     } else if (!strcmp(name, "merge_items")) {
         ctx->opt.merge_items = value != 0;

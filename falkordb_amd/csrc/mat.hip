@@ -198,7 +198,7 @@ __global__ void coo_scatter_kernel(const u32* __restrict__ rows, const u32* __re
 
 fgpu_info mat_from_device_coo(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows, const u32* cols,
                               u64 n) {
-    if (ctx->opt.transpose_mode == 0) {   // two stable counting sorts, no atomics, no per-row sort (transpose.hip)
+    if (ctx->opt.transpose_mode != 1) {   // two stable counting sorts, no atomics, no per-row sort (transpose.hip)
         fgpu_info ci = mat_from_device_coo_counting(ctx, out, nrows, ncols, rows, cols, n);
         if (ci != FGPU_NO_VALUE) return ci;
     }
@@ -578,7 +578,7 @@ fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a
         *out = o;
         return FGPU_OK;
     }
-    if (ctx->opt.transpose_mode == 0) {   // stable partition by column: rows of the result come out ascending, no sort
+    if (ctx->opt.transpose_mode != 1) {   // stable partition by column: rows of the result come out ascending, no sort
         fgpu_info ci = mat_transpose_counting(ctx, out, a);
         if (ci != FGPU_NO_VALUE) return ci;
     }

@@ -322,6 +322,410 @@ fgpu_info sort_pairs_by_key(fgpu_ctx* ctx, const u32* key, const u32* val, const
     return FGPU_OK;
 }
 
+// ---- the same stable sort with every scattered store staged through LDS (transpose_mode 2) -------------------------------
+// What held the two-level form at 2.5 ms for RMAT-22 (67 M entries; 0.55 GB algorithmic) is the shape of its stores, not
+// their bytes: a wavefront's 64 pairs go to ~60 different 128-byte lines, and a line that leaves L2 before its other
+// entries arrive costs one trip of the L2 miss path per STORE — the same ~57 G lines/s that bounds the row gather of the
+// k-hop (67 M stores / 57 G/s = 1.2 ms, measured 1.0 + 1.2 ms for the two scatters).  Runs of whole lines
+// need  entries per block >= run length x buckets,  and a block has to fit LDS: 4096 entries and <= 512 buckets give
+// runs of 8-32 pairs.  So the key is cut into THREE digits (8 + 7 + 7 bits at 2^22 keys) and every level is the same
+// most-significant-digit partition:
+//
+//   segments   the buckets of the digits already sorted (level 1: the whole input), contiguous in the level's input
+//   blocks     <= KP_EB consecutive entries of ONE segment; block table = prefix of ceil(len / KP_EB) over the segments
+//   count      one workgroup per block: LDS histogram of the level's digit -> cnt[(segment, digit, block)] laid out
+//              segment-major, digit-major inside a segment: ONE flat exclusive scan gives every (block, digit) run its
+//              place, and the place of (segment, digit, block 0) is the start of the next level's segment
+//   scatter    the workgroup re-reads its block into registers (16 entries per thread, wavefront q owns the q-th quarter
+//              so that order = stability), ranks every entry inside the block (per-wavefront cursors, ballot match as
+//              above), writes it to its slot of an LDS copy of the block sorted by digit, and then copies that out:
+//              consecutive threads -> consecutive slots -> consecutive addresses of a run
+//
+// The last level writes the values alone, and the key pointers are the starts of the "segments" one level further down.
+constexpr u32 KP_EB = 2048;
+constexpr u32 KP_MAX_D = 512;
+constexpr bool KP_AUTO = true;    // transpose_mode 0 picks the staged levels from 2^17 keys
+struct KpLevel {
+    u32 shift;   // digit = (key >> shift) & (D - 1)
+    u32 dbits, D;
+    u32 S;       // segments of this level = 2^(bits above the digit); segment of a key = key >> (shift + dbits)
+};
+
+// start of every segment of the NEXT level (q = segment * D + digit of this level; S * D + 1 entries wanted) out of this
+// level's positions, and how many blocks each takes.  `limit`: entries written (the key pointers stop at nkeys).
+__global__ __launch_bounds__(256) void kp_seg_kernel(const u32* __restrict__ pos, const u32* __restrict__ blkstart, KpLevel lv, u64 limit,
+                                                     u32* __restrict__ segstart, u32* __restrict__ nblk) {
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (q > limit) return;
+    const u32 NB = blkstart[lv.S];
+    auto start_of = [&](u64 x) -> u32 {
+        if (x >= (u64)lv.S * lv.D) return pos[(size_t)lv.D * NB];
+        const u32 sg = (u32)(x >> lv.dbits), d = (u32)x & (lv.D - 1u);
+        const u32 b0 = blkstart[sg], nbs = blkstart[sg + 1] - b0;
+        return pos[(size_t)lv.D * b0 + (size_t)d * nbs];
+    };
+    const u32 a = start_of(q);
+    segstart[q] = a;
+    if (nblk) nblk[q] = q < limit ? (start_of(q + 1) - a + KP_EB - 1) / KP_EB : 0u;
+}
+__global__ void kp_first_kernel(u32 n, u32* __restrict__ segstart, u32* __restrict__ blkstart) {
+    segstart[0] = 0; segstart[1] = n;
+    blkstart[0] = 0; blkstart[1] = (n + KP_EB - 1) / KP_EB;
+}
+// exclusive scan of a short array (the blocks per segment) in ONE launch: 1024 threads, a contiguous piece each
+constexpr u64 KP_SMALL_SCAN = 1u << 18;
+__global__ __launch_bounds__(1024) void kp_small_scan_kernel(const u32* __restrict__ in, u32 n, u32* __restrict__ out) {
+    __shared__ u32 s_w[16];
+    const u32 per = (n + 1023u) / 1024u;
+    const u32 b = threadIdx.x * per, e = b + per < n ? b + per : n;
+    u32 sum = 0;
+    for (u32 i = b; i < e; ++i) sum += in[i];
+    u32 inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = (u32)__shfl_up((int)inc, o, 64); if ((int)lane_id() >= o) inc += v; }
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u32 run = inc - sum;
+    for (u32 w = 0; w < (threadIdx.x >> 6); ++w) run += s_w[w];
+    for (u32 i = b; i < e; ++i) { const u32 v = in[i]; out[i] = run; run += v; }
+}
+
+// every block of a level: its entries [e0, e1) and where its counters are (digit d at cbase + d * cstride); cstride = ~0 marks
+// the unused tail of the table (the grid is sized by the bound n / KP_EB + S, the blocks that exist are only known here)
+struct KpBlock { u32 e0, e1, cbase, cstride; };
+__global__ __launch_bounds__(256) void kp_blk_table_kernel(const u32* __restrict__ segstart, const u32* __restrict__ blkstart, KpLevel lv,
+                                                           u32 nb_max, uint4* __restrict__ desc, const u32* __restrict__ rowptr, u32 nrows,
+                                                           uint2* __restrict__ brows, u32* __restrict__ cnt) {
+    const u32 b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb_max) return;
+    if (b == 0) cnt[(size_t)lv.D * nb_max] = 0u;  // the scan runs over the bound: its last entry is the total
+    if (b >= blkstart[lv.S]) { desc[b] = make_uint4(0u, 0u, 0u, 0xFFFFFFFFu); return; }
+    u32 lo = 0, hi = lv.S - 1;                    // the last segment whose first block is <= b
+    while (lo < hi) {
+        const u32 mid = (lo + hi + 1) >> 1;
+        if (blkstart[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const u32 b0 = blkstart[lo], nbs = blkstart[lo + 1] - b0, j = b - b0;
+    const u32 e0 = segstart[lo] + j * KP_EB, end = segstart[lo + 1];
+    const u32 e1 = e0 + KP_EB < end ? e0 + KP_EB : end;
+    desc[b] = make_uint4(e0, e1, lv.D * b0 + j, nbs);
+    // implicit values (level 1 of a transpose): the rows of the block's first and last entry, searched here for all blocks at
+    // once (in the scatter kernel the two searches were ~4 us of dependent loads at the head of every block)
+    if (rowptr) brows[b] = make_uint2(row_of_entry(rowptr, 0, nrows - 1, e0), row_of_entry(rowptr, 0, nrows - 1, e1 - 1u));
+}
+// Workgroups are dealt to the 8 XCDs round-robin: hardware workgroup h takes logical block (h % 8) * (grid / 8) + h / 8, so
+// that ONE XCD walks a contiguous range of blocks in order — neighbouring blocks write neighbouring pieces of every digit's
+// run, and the line two pieces share is completed in that XCD's L2 instead of leaving two L2s half written.  (grid % 8 == 0)
+__device__ __forceinline__ bool kp_block(const uint4* __restrict__ desc, u32 h, u32 grid, KpBlock& k) {
+    const u32 b = (h & 7u) * (grid >> 3) + (h >> 3);
+    const uint4 d = desc[b];
+    k.e0 = d.x; k.e1 = d.y; k.cbase = d.z; k.cstride = d.w;
+    return d.w != 0xFFFFFFFFu;
+}
+
+// FIRST: keys / values in two arrays (values nullable = implicit rows, never dropped); otherwise packed pairs
+template <bool FIRST>
+__global__ __launch_bounds__(256) void kp_count_kernel(const u32* __restrict__ key1, const u32* __restrict__ val1, const uint2* __restrict__ in,
+                                                      KpLevel lv, const uint4* __restrict__ desc, u32* __restrict__ cnt) {
+    __shared__ u32 s_hist[KP_MAX_D];
+    KpBlock k;
+    if (!kp_block(desc, blockIdx.x, gridDim.x, k)) {
+        // counters of the blocks that exist fill [0, D * NB); the rest of the bound is zeroed by the blocks that do not
+        const u32 b = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        for (u32 d = threadIdx.x; d < lv.D; d += 256) cnt[(size_t)lv.D * b + d] = 0u;
+        return;
+    }
+    for (u32 d = threadIdx.x; d < lv.D; d += 256) s_hist[d] = 0;
+    __syncthreads();
+    for (u32 i = k.e0 + threadIdx.x; i < k.e1; i += 256) {
+        u32 key;
+        if (FIRST) {
+            if (val1 && val1[i] == KS_INVALID) continue;
+            key = key1[i];
+        } else {
+            key = in[i].x;
+        }
+        atomicAdd(&s_hist[(key >> lv.shift) & (lv.D - 1u)], 1u);
+    }
+    __syncthreads();
+    for (u32 d = threadIdx.x; d < lv.D; d += 256) cnt[(size_t)k.cbase + (size_t)d * k.cstride] = s_hist[d];
+}
+
+template <bool FIRST, bool IMPLICIT, bool LAST>
+__global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__ key1, const u32* __restrict__ val1,
+                                                        const u32* __restrict__ rowptr, u32 nrows, const uint2* __restrict__ in,
+                                                        KpLevel lv, const uint4* __restrict__ desc, const uint2* __restrict__ brows,
+                                                        const u32* __restrict__ pos, uint2* __restrict__ out_pairs, u32* __restrict__ out_val) {
+    extern __shared__ u32 s_kp[];
+    __shared__ u32 s_wave[4], s_total;
+    const u32 D = lv.D;
+    uint2* stage = (uint2*)s_kp;                  // KP_EB pairs
+    u32* cur = s_kp + 2 * KP_EB;                  // [4][D]: per-wavefront counters, then cursors
+    u32* lstart = cur + 4 * D;                    // [D]: first slot of a digit in the staged block
+    u32* gpos = lstart + D;                       // [D]: where that run goes
+    KpBlock k;
+    if (!kp_block(desc, blockIdx.x, gridDim.x, k)) return;   // (uniform over the workgroup)
+    const u32 lane = lane_id(), q = threadIdx.x >> 6;
+    for (u32 i = threadIdx.x; i < 4 * D; i += 256) cur[i] = 0;
+    // where this block's run of every digit goes: asked for now, used after the counting sweep (thread c owns digits c * per ..)
+    const u32 per = D >= 256 ? D / 256 : 1u;
+    const u32 c0 = threadIdx.x * per;
+    u32 gp[KP_MAX_D / 256];
+#pragma unroll
+    for (u32 c = 0; c < KP_MAX_D / 256; ++c) gp[c] = (c < per && c0 + c < D) ? pos[(size_t)k.cbase + (size_t)(c0 + c) * k.cstride] : 0u;
+    __syncthreads();
+    constexpr int T = KP_EB / 256;                // trips of a wavefront
+    const u32 qs = k.e0 + q * (KP_EB / 4);
+    u32 key[T], val[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const u32 i = qs + t * 64 + lane;
+        const bool on = i < k.e1;
+        if (FIRST) {
+            key[t] = on ? key1[i] : 0u;
+            val[t] = (!IMPLICIT && on) ? val1[i] : 0u;
+        } else {
+            const uint2 p = on ? in[i] : make_uint2(0u, 0u);
+            key[t] = p.x;
+            val[t] = p.y;
+        }
+    }
+    if (FIRST && IMPLICIT) {
+        // rows of the block's entries, the other way round: every row that STARTS inside the block marks its first entry in
+        // an LDS copy of the block (the last of several empty rows wins: it owns the entry), a running maximum then gives
+        // every entry its row.  (Entry -> row by a window search per trip, rows_of_trip above, is a chain of 16 dependent
+        // loads per wavefront: ~24 us of the 31 us a block took.)
+        u32* mark = s_kp;                         // KP_EB words of the staging area, free until the ranks are known
+        __shared__ u32 s_wmax[4];
+        const uint2 ends = brows[(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)];
+        for (u32 i = threadIdx.x; i < KP_EB; i += 256) mark[i] = 0;
+        __syncthreads();
+        const u32 rlo = ends.x, rhi = ends.y;
+        for (u32 r = rlo + 1u + threadIdx.x; r <= rhi; r += 256) atomicMax(&mark[rowptr[r] - k.e0], r);   // (e0 < rowptr[r] < e1)
+        __syncthreads();
+        u32 carry = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            u32 x = mark[q * (KP_EB / 4) + t * 64 + lane];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u32 y = (u32)__shfl_up((int)x, d, 64);
+                if (lane >= (u32)d && y > x) x = y;
+            }
+            if (carry > x) x = carry;
+            carry = (u32)__builtin_amdgcn_readlane((int)x, 63);
+            val[t] = x;
+        }
+        if (lane == 0) s_wmax[q] = carry;
+        __syncthreads();
+        u32 before = rlo;
+        for (u32 w = 0; w < q; ++w) before = s_wmax[w] > before ? s_wmax[w] : before;
+#pragma unroll
+        for (int t = 0; t < T; ++t) val[t] = val[t] > before ? val[t] : before;
+        __syncthreads();                          // the marks are read: the area is the staging buffer again
+    }
+    // count AND rank in one sweep: the wavefront walks its quarter in order, lanes with the same digit find each other by
+    // ballots, the lowest bumps the wavefront's counter of that digit by the size of the group — what it gets back is the
+    // group's place among the entries of (wavefront, digit), which is all the second sweep needs on top of the counter scan
+    // (ranking again there, as the two-level form does, made the kernel instruction-bound: ~100 VALU per trip, twice)
+    u32 live = 0;                                  // bit t: this lane's entry of trip t takes part
+    u32 loc[T / 2];                                // place inside (wavefront, digit), two 16-bit fields a word
+#pragma unroll
+    for (int t = 0; t < T / 2; ++t) loc[t] = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (qs + t * 64 >= k.e1) break;           // wave-uniform
+        const u32 i = qs + t * 64 + lane;
+        const bool on = i < k.e1 && !(FIRST && !IMPLICIT && val[t] == KS_INVALID);
+        const u32 d = (key[t] >> lv.shift) & (D - 1u);
+        const u64 peers = match_digit(d, lv.dbits, on);
+        if (on) {
+            live |= 1u << t;
+            const u32 rank = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+            const u32 leader = (u32)__builtin_ctzll(peers);
+            u32 base = 0;
+            if (lane == leader) base = atomicAdd(&cur[q * D + d], (u32)__popcll(peers));
+            base = (u32)__shfl((int)base, (int)leader, 64);
+            loc[t >> 1] |= (base + rank) << ((t & 1) * 16);
+        }
+    }
+    __syncthreads();
+    {   // slots: digits ascending, wavefronts ascending inside a digit; thread c owns digits c * per .. (per = D / 256, at least 1)
+        u32 mine = 0;
+        if (c0 < D)
+            for (u32 c = c0; c < c0 + per; ++c) mine += cur[c] + cur[D + c] + cur[2 * D + c] + cur[3 * D + c];
+        u32 inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 y = (u32)__shfl_up((int)inc, d, 64);
+            if (lane >= (u32)d) inc += y;
+        }
+        if (lane == 63) s_wave[q] = inc;
+        __syncthreads();
+        u32 run = inc - mine;
+        for (u32 w = 0; w < q; ++w) run += s_wave[w];
+#pragma unroll
+        for (u32 ci = 0; ci < KP_MAX_D / 256; ++ci) {
+            const u32 c = c0 + ci;
+            if (ci < per && c < D) {
+                const u32 t0 = cur[c], t1 = cur[D + c], t2 = cur[2 * D + c], t3 = cur[3 * D + c];
+                lstart[c] = run;
+                gpos[c] = gp[ci];
+                cur[c] = run;
+                cur[D + c] = run + t0;
+                cur[2 * D + c] = run + t0 + t1;
+                cur[3 * D + c] = run + t0 + t1 + t2;
+                run += t0 + t1 + t2 + t3;
+            }
+        }
+        if (threadIdx.x == 255) s_total = run;     // (threads past the last digit carry the total along)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (qs + t * 64 >= k.e1) break;           // wave-uniform
+        if ((live >> t) & 1u) {
+            const u32 d = (key[t] >> lv.shift) & (D - 1u);
+            stage[cur[q * D + d] + ((loc[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu)] = make_uint2(key[t], val[t]);
+        }
+    }
+    __syncthreads();
+    const u32 total = s_total;
+    for (u32 slot = threadIdx.x; slot < total; slot += 256) {
+        const uint2 p = stage[slot];
+        const u32 d = (p.x >> lv.shift) & (D - 1u);
+        const u32 dst = gpos[d] + (slot - lstart[d]);
+        if (LAST) out_val[dst] = p.y;
+        else out_pairs[dst] = p;
+    }
+}
+
+// digit widths, most significant first: as few levels as 9 bits a level allow, at least ... balanced
+static int kp_widths(u64 nkeys, u32* w) {
+    u32 kb = 1;
+    while (kb < 32 && (1ull << kb) < nkeys) ++kb;
+    int L = (int)((kb + 8) / 9);
+    if (L < 1) L = 1;
+    if (kb >= 17 && L < 3) L = 3;                 // (runs of whole lines need <= 512 buckets a level; 3 levels from 2^17 keys)
+    if ((u32)L > kb) L = (int)kb;
+    // the wider digits last: a level's runs are KP_EB / D entries long, and the last level moves 4-byte values in segments
+    // that mostly fit one block (written as one contiguous piece whatever D is)
+    for (int l = 0; l < L; ++l) w[l] = kb / L + ((u32)(L - 1 - l) < kb % L ? 1u : 0u);
+    return L;
+}
+
+fgpu_info sort_pairs_by_key_staged(fgpu_ctx* ctx, const u32* key, const u32* val, const u32* rowptr, u32 nrows, u64 n,
+                                   u64 nkeys, u32* out_val, u32* keyptr, u32* n_valid_out) {
+    if (n == 0 || n >= 0xFFFFFFFFull - KP_EB || nkeys == 0 || nkeys > (1ull << 31)) return FGPU_NO_VALUE;
+    const bool implicit = val == nullptr;
+    u32 w[8];
+    const int L = kp_widths(nkeys, w);
+    u32 kb = 0;
+    for (int l = 0; l < L; ++l) kb += w[l];
+    hipStream_t st = ctx->stream();
+    DevBuf<uint2> bufA, bufB;
+    if (L >= 2) FGPU_TRY(bufA.alloc(ctx, n));
+    if (L >= 3) FGPU_TRY(bufB.alloc(ctx, n));
+    DevBuf<u32> segstart, nblk, blkstart, cnt, pos, segnext, tot;
+    DevBuf<uint4> desc;
+    DevBuf<uint2> brows;
+    FGPU_TRY(tot.alloc(ctx, 1));
+    // upper bounds: a level with S segments has at most n / KP_EB + S blocks
+    u64 S_max = 1;
+    {
+        u32 done = 0;
+        for (int l = 0; l + 1 < L; ++l) { done += w[l]; S_max = 1ull << done; }
+    }
+    const u64 S_keys = 1ull << kb;                              // "segments" below the last level = keys
+    const u64 nb_top = n / KP_EB + 9 + S_max;
+    u32 dmax = 0;
+    for (int l = 0; l < L; ++l) dmax = std::max(dmax, 1u << w[l]);
+    FGPU_TRY(segstart.alloc(ctx, S_max + 2));
+    FGPU_TRY(segnext.alloc(ctx, S_max + 2));
+    FGPU_TRY(nblk.alloc(ctx, S_max + 2));
+    FGPU_TRY(blkstart.alloc(ctx, S_max + 2));
+    FGPU_TRY(desc.alloc(ctx, nb_top + 1));
+    if (implicit) FGPU_TRY(brows.alloc(ctx, n / KP_EB + 16));
+    FGPU_TRY(cnt.alloc(ctx, (size_t)dmax * nb_top + 2));
+    FGPU_TRY(pos.alloc(ctx, (size_t)dmax * nb_top + 2));
+    (void)S_keys;
+    hipLaunchKernelGGL(kp_first_kernel, dim3(1), dim3(1), 0, st, (u32)n, segstart.p, blkstart.p);
+    FGPU_HIP(hipGetLastError());
+    u32 done = 0;
+    const uint2* in = nullptr;
+    for (int l = 0; l < L; ++l) {
+        KpLevel lv;
+        lv.dbits = w[l];
+        lv.D = 1u << w[l];
+        lv.shift = kb - done - w[l];
+        lv.S = 1u << done;
+        const bool first = l == 0, last = l == L - 1;
+        const u64 nb_max = (n / KP_EB + 1 + lv.S + 7) & ~7ull;
+        const size_t ncnt = (size_t)lv.D * nb_max + 1;
+        hipLaunchKernelGGL(kp_blk_table_kernel, dim3(cdiv(nb_max, 256)), dim3(256), 0, st, (const u32*)segstart.p, (const u32*)blkstart.p, lv,
+                           (u32)nb_max, desc.p, first && implicit ? rowptr : (const u32*)nullptr, nrows, brows.p, cnt.p);
+        FGPU_HIP(hipGetLastError());
+        {
+            static const char* const names[] = {"kp_count_kernel L1", "kp_count_kernel L2", "kp_count_kernel L3", "kp_count_kernel L4"};
+            ProfScope ps(ctx, names[l < 4 ? l : 3], (first ? 4 : 8) * n + 4 * ncnt);
+            if (first)
+                hipLaunchKernelGGL(kp_count_kernel<true>, dim3((u32)nb_max), dim3(256), 0, st, key, val, (const uint2*)nullptr, lv,
+                                   (const uint4*)desc.p, cnt.p);
+            else
+                hipLaunchKernelGGL(kp_count_kernel<false>, dim3((u32)nb_max), dim3(256), 0, st, (const u32*)nullptr, (const u32*)nullptr, in, lv,
+                                   (const uint4*)desc.p, cnt.p);
+            FGPU_HIP(hipGetLastError());
+        }
+        FGPU_TRY(scan_u32(ctx, cnt.p, pos.p, ncnt, nullptr));
+        uint2* outp = last ? nullptr : (l == 0 ? bufA.p : (in == bufA.p ? bufB.p : bufA.p));
+        const size_t lds = ((size_t)2 * KP_EB + (size_t)6 * lv.D) * sizeof(u32);
+        {
+            static const char* const names[] = {"kp_scatter_kernel L1", "kp_scatter_kernel L2", "kp_scatter_kernel L3", "kp_scatter_kernel L4"};
+            ProfScope ps(ctx, names[l < 4 ? l : 3], (first ? (implicit ? 4 : 8) : 8) * n + (last ? 4 : 8) * n + 4 * ncnt);
+#define KP_SCATTER(F, I, LA)                                                                                                              \
+            do {                                                                                                                          \
+                if (lds > 48 * 1024)                                                                                                      \
+                    FGPU_HIP(hipFuncSetAttribute((const void*)kp_scatter_kernel<F, I, LA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL((kp_scatter_kernel<F, I, LA>), dim3((u32)nb_max), dim3(256), lds, st, key, val, rowptr, nrows, in, lv,  \
+                                   (const uint4*)desc.p, (const uint2*)brows.p, (const u32*)pos.p, outp, out_val);                         \
+            } while (0)
+            if (first) {
+                if (implicit) { if (last) KP_SCATTER(true, true, true); else KP_SCATTER(true, true, false); }
+                else { if (last) KP_SCATTER(true, false, true); else KP_SCATTER(true, false, false); }
+            } else {
+                if (last) KP_SCATTER(false, false, true); else KP_SCATTER(false, false, false);
+            }
+#undef KP_SCATTER
+            FGPU_HIP(hipGetLastError());
+        }
+        // the next level's segments (or, after the last level, the key pointers)
+        const u64 nseg_next = (u64)lv.S * lv.D;
+        if (last) {
+            hipLaunchKernelGGL(kp_seg_kernel, dim3(cdiv(nkeys + 1, 256)), dim3(256), 0, st, (const u32*)pos.p, (const u32*)blkstart.p, lv, nkeys,
+                               keyptr, (u32*)nullptr);
+            FGPU_HIP(hipGetLastError());
+            if (n_valid_out) {
+                if (implicit) *n_valid_out = (u32)n;
+                else FGPU_TRY(read_u32(ctx, keyptr + nkeys, n_valid_out));
+            }
+        } else {
+            hipLaunchKernelGGL(kp_seg_kernel, dim3(cdiv(nseg_next + 1, 256)), dim3(256), 0, st, (const u32*)pos.p, (const u32*)blkstart.p, lv,
+                               nseg_next, segnext.p, nblk.p);
+            FGPU_HIP(hipGetLastError());
+            std::swap(segstart, segnext);
+            if (nseg_next + 1 <= KP_SMALL_SCAN) {
+                hipLaunchKernelGGL(kp_small_scan_kernel, dim3(1), dim3(1024), 0, st, (const u32*)nblk.p, (u32)(nseg_next + 1), blkstart.p);
+                FGPU_HIP(hipGetLastError());
+            } else {
+                FGPU_TRY(scan_u32(ctx, nblk.p, blkstart.p, nseg_next + 1, nullptr));
+            }
+            in = outp;
+        }
+        done += w[l];
+    }
+    return FGPU_OK;
+}
+
 // ---- duplicate collapse of a sorted CSR (rows ascending, duplicates adjacent) --------------------------------------
 __global__ __launch_bounds__(256) void dedup_flag_kernel(const u32* __restrict__ rowptr, u32 nrows,
                                                         const u32* __restrict__ col, u32 n, u32* __restrict__ keep) {
@@ -352,14 +756,32 @@ __global__ __launch_bounds__(256) void dedup_scatter_kernel(const u32* __restric
 }
 
 // pattern transpose of a non-hypersparse snapshot without a sort; FGPU_NO_VALUE = not applicable (caller falls back)
+// which form sorts (n pairs, nkeys keys): transpose_mode 2 = the LDS-staged levels always, 3 = the two-level form always,
+// 0 = the staged levels where the key space is wide enough for the store shape to matter; false = neither applies
+static bool ks_applicable(fgpu_ctx* ctx, u64 n, u64 nkeys, bool* staged) {
+    const int mode = ctx->opt.transpose_mode;
+    const bool can = nkeys >= 2 && nkeys <= (1ull << 31) && n < 0xFFFFFFFFull - KP_EB;
+    *staged = can && (mode == 2 || (mode == 0 && KP_AUTO && nkeys >= (1ull << 17)));
+    if (*staged) return true;
+    KsGeom g;
+    return ks_geometry(n, nkeys, g);
+}
+static fgpu_info sort_pairs(fgpu_ctx* ctx, const u32* key, const u32* val, const u32* rowptr, u32 nrows, u64 n, u64 nkeys,
+                            u32* out_val, u32* keyptr, u32* n_valid_out) {
+    bool staged = false;
+    if (!ks_applicable(ctx, n, nkeys, &staged)) return FGPU_NO_VALUE;
+    return staged ? sort_pairs_by_key_staged(ctx, key, val, rowptr, nrows, n, nkeys, out_val, keyptr, n_valid_out)
+                  : sort_pairs_by_key(ctx, key, val, rowptr, nrows, n, nkeys, out_val, keyptr, n_valid_out);
+}
+
 fgpu_info mat_transpose_counting(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
     if (a->is_hyper() || a->nnz < 4096 || a->nrows == 0) return FGPU_NO_VALUE;
-    KsGeom g;
-    if (!ks_geometry(a->nnz, a->ncols, g)) return FGPU_NO_VALUE;
+    bool staged = false;
+    if (!ks_applicable(ctx, a->nnz, a->ncols, &staged)) return FGPU_NO_VALUE;
     fgpu_mat* t = nullptr;
     FGPU_TRY(mat_alloc(ctx, &t, a->ncols, a->nrows, a->nnz, false, 0, false));
-    fgpu_info i = sort_pairs_by_key(ctx, a->colidx, nullptr, a->rowptr, (u32)a->nrows, a->nnz, a->ncols, t->colidx,
-                                    t->rowptr, nullptr);
+    fgpu_info i = sort_pairs(ctx, a->colidx, nullptr, a->rowptr, (u32)a->nrows, a->nnz, a->ncols, t->colidx,
+                             t->rowptr, nullptr);
     // hub lists / max degree are built when a BFS plan, vxm or PageRank first asks (mat_ensure_finalized)
     if (i != FGPU_OK) { mat_release(t); return i; }
     *out = t;
@@ -372,18 +794,18 @@ fgpu_info mat_transpose_counting(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* 
 fgpu_info mat_from_device_coo_counting(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
                                        const u32* cols, u64 n) {
     if (n < 4096 || n >= 0xFFFFFFFFull || nrows == 0 || ncols == 0) return FGPU_NO_VALUE;
-    KsGeom g;
-    if (!ks_geometry(n, ncols, g) || !ks_geometry(n, nrows, g)) return FGPU_NO_VALUE;
+    bool staged = false;
+    if (!ks_applicable(ctx, n, ncols, &staged) || !ks_applicable(ctx, n, nrows, &staged)) return FGPU_NO_VALUE;
     DevBuf<u32> byc_row, colptr, byr_col, rowptr;
     FGPU_TRY(byc_row.alloc(ctx, n));
     FGPU_TRY(colptr.alloc(ctx, ncols + 1));
     u32 nv = 0;
-    FGPU_TRY(sort_pairs_by_key(ctx, cols, rows, nullptr, 0, n, ncols, byc_row.p, colptr.p, &nv));
+    FGPU_TRY(sort_pairs(ctx, cols, rows, nullptr, 0, n, ncols, byc_row.p, colptr.p, &nv));
     if (nv == 0) return FGPU_NO_VALUE;   // nothing survived: let the generic path build the empty matrix
     FGPU_TRY(byr_col.alloc(ctx, nv));
     FGPU_TRY(rowptr.alloc(ctx, nrows + 1));
     // the column-major form is a CSR over `ncols` rows whose "column ids" are the original rows
-    fgpu_info i = sort_pairs_by_key(ctx, byc_row.p, nullptr, colptr.p, (u32)ncols, nv, nrows, byr_col.p, rowptr.p, nullptr);
+    fgpu_info i = sort_pairs(ctx, byc_row.p, nullptr, colptr.p, (u32)ncols, nv, nrows, byr_col.p, rowptr.p, nullptr);
     if (i != FGPU_OK) return i;
     byc_row.release();
     DevBuf<u32> keep, newpos, tot;

@@ -316,13 +316,13 @@ class VersionedMatrix:
 
 
 def cond_spec(src_labels=(), hops=((), ()), optional=False, bind=False, emit=False, bidir=False, siblings=False,
-              attrs=False):
+              attrs=False, transposed=False):
     """hops: sequence of (types, dst_labels); hop 0 is the operator's own pattern, the rest the fused chain."""
     parts = ["src=" + ",".join(src_labels)]
     for types, labels in hops:
         parts.append("hop=" + ",".join(types) + "|" + ",".join(labels))
     for k, v in (("optional", optional), ("bind", bind), ("emit", emit), ("bidir", bidir), ("siblings", siblings),
-                 ("attrs", attrs)):
+                 ("attrs", attrs), ("transposed", transposed)):
         parts.append(f"{k}={1 if v else 0}")
     return ";".join(parts).encode()
 

@@ -67,6 +67,7 @@ static CondTraverseOp parse_spec(const char* spec) {
         else if (k == "bidir") op.bidirectional = v == "1";
         else if (k == "siblings") op.has_sibling_edges = v == "1";
         else if (k == "attrs") op.has_inline_attrs = v == "1";
+        else if (k == "transposed") op.transposed = v == "1";
     }
     if (op.hops.empty()) op.hops.push_back(Hop{});
     return op;

@@ -173,11 +173,37 @@ bool resolve_hop_types(const Graph& g, const std::vector<std::string>& types, st
 // Matrix choice per hop (cond_traverse.rs:478-505): no type -> adjacency; one type -> that tensor's forward
 // layers; an alternation -> materialized union of its known types with clean deltas (also when only one of them
 // is known: the reference branches on the number of NAMES).  Returns false for no_match.
-bool hop_layers(const Graph& g, const std::vector<Hop>& hops, HopLayers& hl, std::vector<std::vector<u64>>& type_ids) {
+bool hop_layers(const Graph& g, const std::vector<Hop>& hops, HopLayers& hl, std::vector<std::vector<u64>>& type_ids,
+                bool transposed = false) {
+    hl.owned.reserve(3 * hops.size());
     for (auto& h : hops) {
         std::vector<u64> ids;
         if (!resolve_hop_types(g, h.types, ids)) return false;
         type_ids.push_back(ids);
+        if (transposed) {
+            // the structures build_transposed_iter walks (cond_traverse.rs:221-235), as device layers: the tensor's own `mt`
+            // (kept by every insert / delete, Tensor::matrix_t), the transposes of the adjacency layers (cached on their
+            // snapshots: paid once per matrix version), the transpose of a materialized alternation
+            auto keep = [&](Matrix m) { hl.owned.push_back(std::move(m)); return hl.owned.back().snapshot(); };
+            if (h.types.size() == 1) {
+                const VersionedMatrix& mt = g.relationship_tensors()[ids[0]].matrix_t();
+                mt.wait();
+                hl.m.push_back(mt.m().snapshot());
+                hl.dp.push_back(mt.dp().nvals() ? mt.dp().snapshot() : nullptr);
+                hl.dm.push_back(mt.dm().nvals() ? mt.dm().snapshot() : nullptr);
+            } else if (h.types.empty()) {
+                const VersionedMatrix& a = g.adjacency_matrix();
+                a.wait();
+                hl.m.push_back(keep(a.m().transpose()));
+                hl.dp.push_back(a.dp().nvals() ? keep(a.dp().transpose()) : nullptr);
+                hl.dm.push_back(a.dm().nvals() ? keep(a.dm().transpose()) : nullptr);
+            } else {
+                hl.m.push_back(keep(g.build_relationship_matrix_unrestricted(ids).transpose()));
+                hl.dp.push_back(nullptr);
+                hl.dm.push_back(nullptr);
+            }
+            continue;
+        }
         if (h.types.empty()) {
             const VersionedMatrix& a = g.adjacency_matrix();
             a.wait();
@@ -223,7 +249,14 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
     };
     HopLayers hl;
     std::vector<std::vector<u64>> type_ids;
-    if (!hop_layers(g, hops, hl, type_ids)) return no_match();          // unknown type (:485-490)
+    // A `transposed` operator has the matrix DESTINATION bound (select_scan_node swaps from / to): the reference declines
+    // the batch there (:556-568) and walks row d of the transposed structure per row (:221-235, 840-870).  The device holds
+    // those structures as matrices, so the same batch machinery runs over them — F[i, bound_i] = 1, one product with the
+    // transposed layers, `src_labels` on the bound node, the hop's labels on the node it reaches, the representative edge
+    // looked up as (reached, bound) — and gives what the per-row path gives row by row.  One hop only (a transposed operator
+    // is never fused, fuse_anonymous_traverse.rs:118-122).
+    if (transposed && hops.size() != 1) return false;
+    if (!hop_layers(g, hops, hl, type_ids, transposed)) return no_match();          // unknown type (:485-490)
     lap("hop_layers");
     auto last_dst = g.resolve_label_ids(hops.back().dst_labels);
     auto src_lids = g.resolve_label_ids(src_labels);
@@ -321,7 +354,8 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
         std::vector<std::optional<u64>> rep(n);
         for (u64 t : tids) {
             std::vector<std::vector<u64>> ids;
-            g.relationship_tensors()[t].get_batch(es, rows.dest, ids);
+            if (transposed) g.relationship_tensors()[t].get_batch(rows.dest, es, ids);   // the stored pair is (reached, bound)
+            else g.relationship_tensors()[t].get_batch(es, rows.dest, ids);
             for (size_t r = 0; r < n; ++r)
                 if (!rep[r] && !ids[r].empty()) rep[r] = ids[r][0];
         }

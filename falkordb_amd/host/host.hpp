@@ -464,6 +464,9 @@ struct CondTraverseOp {
     bool optional = false;
     bool bind_relationship = false;      // representative edge wanted (cond_traverse.rs:663-695)
     bool emit_relationship = false, bidirectional = false, has_sibling_edges = false, has_inline_attrs = false;
+    // the pattern runs against the storage direction: the bound alias is the matrix DESTINATION (cond_traverse.rs:221-235).
+    // The reference serves these per row only; expand_batch takes them over the transposed layers (an extension, row-equal)
+    bool transposed = false;
 
     // cond_traverse.rs:308-316: the batched matrix path may run at all
     bool batched_eligible() const;

@@ -853,6 +853,62 @@ def test_expand_batch_matches_the_oracle(rnd_graph, case):   # cond_traverse.rs:
     assert nulls == want[1]
 
 
+T_CASES = [
+    dict(types=["B"], from_labels=[], to_labels=[]),
+    dict(types=["A"], from_labels=["Q"], to_labels=["P"]),
+    dict(types=[], from_labels=[], to_labels=["P"]),                  # adjacency: its layers transposed on the device
+    dict(types=[], from_labels=["P"], to_labels=[]),
+    dict(types=["A", "B"], from_labels=[], to_labels=["Q"]),          # alternation: the materialized union, transposed
+    dict(types=["A", "Nope"], from_labels=[], to_labels=[]),
+    dict(types=["Nope"], from_labels=[], to_labels=[]),               # unknown type: no rows
+]
+
+
+@pytest.mark.parametrize("case", T_CASES, ids=lambda c: json.dumps(c, separators=(",", ":"))[:60])
+def test_expand_batch_over_the_transposed_layers_matches_the_per_row_path(rnd_graph, case):
+    """A `transposed` CondTraverse (the bound alias is the matrix destination; the reference serves it row by row over
+    build_transposed_iter, cond_traverse.rs:221-235, 840-870) through expand_batch over the transposed device layers — the
+    batch against the per-row path of the same library and against oracle/model.py expand_row, emission order and
+    representative edge included; then with a pre-bound far end on some rows."""
+    g, og, n, per_type = rnd_graph
+    rng = np.random.default_rng(23)
+    bound = rng.integers(0, n, 150).tolist() + [d for _, d in list(per_type[0])[:50]]
+    kw = dict(src_labels=case["from_labels"], hops=[(case["types"], case["to_labels"])])
+    spec_rows = host.cond_spec(emit=False, **kw)
+    want = []
+    for i, b in enumerate(bound):
+        want += [(i,) + x for x in model.expand_row(og, b, None, case["types"], from_labels=case["from_labels"],
+                                                    to_labels=case["to_labels"], transposed=True, emit_relationship=False)]
+    per_row = g.cond_traverse_rows(spec_rows, bound, [None] * len(bound), transposed=True)
+    assert per_row == want
+    got = g.cond_traverse_batch(host.cond_spec(bind=True, transposed=True, **kw), bound)
+    assert got is not None
+    rows, nulls, _ = got
+    assert [(r, bound[r], d, e) for r, d, e in rows] == want
+    assert nulls == []
+    # no edge alias: the pairs alone
+    rows2, _, _ = g.cond_traverse_batch(host.cond_spec(transposed=True, **kw), bound)
+    assert rows2 == [(w[0], w[2]) for w in want]
+    if want:
+        assert len({w[0] for w in want}) > 20
+        # a pre-bound far end on every other row (the reached node must be that one)
+        tb = [None] * len(bound)
+        first = {}
+        for w in want:
+            first.setdefault(w[0], w[2])
+        for r, d in first.items():
+            if r % 2 == 0:
+                tb[r] = d
+        rows3, _, _ = g.cond_traverse_batch(host.cond_spec(transposed=True, **kw), bound, to_bound=tb)
+        assert rows3 == [(w[0], w[2]) for w in want if tb[w[0]] is None or tb[w[0]] == w[2]]
+    # OPTIONAL: rows that reach nothing are null-padded
+    rows4, nulls4, _ = g.cond_traverse_batch(host.cond_spec(transposed=True, optional=True, **kw), bound)
+    assert rows4 == [(w[0], w[2]) for w in want]
+    assert nulls4 == sorted(set(range(len(bound))) - {w[0] for w in want})
+    # a fused chain is never transposed: the batch declines
+    assert g.cond_traverse_batch(host.cond_spec(src_labels=[], hops=[(["A"], []), (["B"], [])], transposed=True), bound[:4]) is None
+
+
 def test_expand_batch_to_bound_and_null_sources(rnd_graph):  # cond_traverse.rs:566-575, 657-661
     g, og, n, _ = rnd_graph
     src = [5, None, 9, 300, 17]

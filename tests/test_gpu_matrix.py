@@ -85,11 +85,13 @@ def test_transpose(ctx, seed):
 
 @pytest.mark.parametrize("nrows,ncols,n", [(3000, 2000, 40000), (257, 70000, 100000), (70000, 255, 90000),
                                            (1 << 17, 1 << 17, 1 << 21), (5000, 1 << 20, 300000), (40, 40, 9000)])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_counting_builders_match_the_oracle(ctx, nrows, ncols, n, mode):
-    """transpose.hip: the sort-free builders (two stable counting-sort passes) against the oracle and against the
-    round-1 sorter path (transpose_mode 1) — rectangular shapes, key spaces that are not a multiple of the bucket
-    width, one bucket only, heavy duplication (40 x 40 with 9000 tuples), a hub column and a hub row."""
+    """transpose.hip: the sort-free builders (stable counting sorts: the two-level form, transpose_mode 3, and the
+    LDS-staged levels, transpose_mode 2 — one, two and three digits over these key spaces) against the oracle and
+    against the round-1 sorter path (transpose_mode 1) — rectangular shapes, key spaces that are not a multiple of the
+    bucket width or a power of two, one bucket only, heavy duplication (40 x 40 with 9000 tuples), a hub column and a
+    hub row."""
     rng = np.random.default_rng(nrows + 3 * ncols + n)
     r, c = rand_coo(rng, nrows, ncols, n)
     r[: n // 8] = nrows // 3                      # hub row

@@ -229,6 +229,55 @@ def test_sparse_pull_row_groups_match_the_item_form_and_the_oracle(ctx, k, dirty
         ctx.set_option("expand_row_groups", 1)
 
 
+@pytest.mark.parametrize("layers", ["both", "dp", "dm"])
+@pytest.mark.parametrize("k", [1, 7, 700, 4000])
+def test_dirty_first_hop_from_one_entry_rows_matches_the_general_delta_product(ctx, layers, k):
+    """The first hop of a batch over DIRTY layers (first_hop_rows_dirty: (m[u] \\ dm[u]) U dp[u] per row, candidates placed
+    by rank) against the oracle's delta_lmxm (matrix.rs:1323-1361 restated) and against the general three-product path
+    (expand_first_hop = 0), on deltas that also BREAK the Delta invariants the engine must not rely on: pending additions m
+    already holds, tombstones of entries m never had, an entry named by both layers; hub rows, repeated sources."""
+    a = oracle.rmat_csr(12)
+    n = a.nrows
+    rng = np.random.default_rng(500 + k)
+    rows, cols = a.pairs()
+    pick = rng.choice(len(rows), 3000, replace=False)
+    dm_r = np.concatenate([rows[pick], rng.integers(0, n, 500, dtype=np.uint64)])          # + tombstones outside m
+    dm_c = np.concatenate([cols[pick], rng.integers(0, n, 500, dtype=np.uint64)])
+    dup = rng.choice(len(rows), 400, replace=False)
+    dp_r = np.concatenate([rng.integers(0, n, 3000, dtype=np.uint64), rows[dup], rows[pick[:300]]])   # + held by m, + in dm too
+    dp_c = np.concatenate([rng.integers(0, n, 3000, dtype=np.uint64), cols[dup], cols[pick[:300]]])
+    dm = oracle.build_csr(n, n, dm_r, dm_c) if layers != "dp" else None
+    dp = oracle.build_csr(n, n, dp_r, dp_c) if layers != "dm" else None
+    deg = np.diff(a.rowptr).astype(np.int64)
+    hubs = np.argsort(-deg)[:4].astype(U64)
+    src = rng.integers(0, n, k).astype(U64)
+    src[: min(k, 4)] = hubs[: min(k, 4)]
+    if k > 10:
+        src[5] = src[6]                                                                      # the same source in two rows
+    f = oracle.build_csr(k, n, np.arange(k, dtype=U64), src)
+    A = up(ctx, a)
+    DP = up(ctx, dp) if dp is not None else None
+    DM = up(ctx, dm) if dm is not None else None
+    try:
+        for hops in (1, 2, 3):
+            c, flops_ref = f, 0
+            for _ in range(hops):
+                c, fl = oracle.delta_lmxm(c, a, dp, dm)
+                flops_ref += fl
+            got = {}
+            for fh in (1, 0):
+                ctx.set_option("expand_first_hop", fh)
+                rp, dest, flops = engine.expand(ctx, src, [A] * hops, [DP] * hops, [DM] * hops)
+                np.testing.assert_array_equal(rp, c.rowptr)
+                np.testing.assert_array_equal(dest, c.colidx)
+                assert flops == flops_ref
+                got[fh] = engine.expand_count(ctx, src, [A] * hops, [DP] * hops, [DM] * hops)
+                assert got[fh] == (c.nnz, oracle.checksum(c), flops_ref)
+            assert got[0] == got[1]
+    finally:
+        ctx.set_option("expand_first_hop", 1)
+
+
 @pytest.mark.parametrize("k,with_delta,with_label", [(1, False, False), (70, True, False), (300, True, True),
                                                      (1100, False, True)])
 def test_expand_levels_per_hop_sets_and_distinct_union(ctx, k, with_delta, with_label):

@@ -1,4 +1,4 @@
-"""Wall time + per-kernel HIP-event times of fgpu_mat_transpose / the R-MAT COO build (transpose.hip), both modes.
+"""Wall time + per-kernel HIP-event times of fgpu_mat_transpose / the R-MAT COO build (transpose.hip), every mode.
 usage: python tools/time_transpose.py [scales...]"""
 import sys
 import time
@@ -8,7 +8,7 @@ from falkordb_amd import engine
 
 ctx = engine.Context(0)
 for scale in [int(x) for x in sys.argv[1:]] or [22, 24]:
-    for mode in (0, 1):
+    for mode in (3, 2, 1):
         ctx.set_option("transpose_mode", mode)
         ts = []
         for _ in range(3):
@@ -21,10 +21,10 @@ for scale in [int(x) for x in sys.argv[1:]] or [22, 24]:
             t0 = time.perf_counter(); T = A.transpose(); ctx.sync(); ts.append(time.perf_counter() - t0); T.free()
         n, nnz = A.nrows, A.nvals
         alg = 8 * nnz + 8 * (n + 1)     # read colidx + rowptr, write colidx' + rowptr'
-        print({"scale": scale, "mode": ["counting", "coo+sort"][mode], "rmat_build_ms": round(tb * 1e3, 2),
+        print({"scale": scale, "mode": {3: "counting, two levels", 2: "counting, LDS-staged levels", 1: "coo+sort"}[mode], "rmat_build_ms": round(tb * 1e3, 2),
                "transpose_ms": [round(t * 1e3, 2) for t in ts], "nnz": nnz,
                "transpose_GBps": round(alg / min(ts) / 1e9, 1), "frac_hbm": round(alg / min(ts) / 8e12, 4)}, flush=True)
-        if mode == 0:
+        if mode != 1:
             ctx.prof_enable(True)
             T = A.transpose()
             for k in ctx.prof_read():
