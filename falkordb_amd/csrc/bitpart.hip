@@ -75,44 +75,57 @@ void bp_xplan_release(fgpu_ctx* ctx, BpXPlan* p) {
 }
 
 // ---- plan build (once per snapshot) ----------------------------------------------------------------------------------------
-// a wavefront per 64-row group of A': its entries are one contiguous range, a lane per entry, the row of an entry by a
-// search of the group's 65 offsets in LDS.  FILL = false: cnt[part * n + v] += 1.  FILL = true: the entry goes to its place
-// (cnt counts down: the order inside a run does not matter to an OR; whichever entry lands first carries the flag).
-template <bool FILL>
-__global__ __launch_bounds__(256) void xp_walk_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ colidx, u32 n, u32 ng,
-                                                      u32 prange, const u32* __restrict__ perm, u32* __restrict__ cnt,
-                                                      const u32* __restrict__ off, u32* __restrict__ pcol) {
-    __shared__ u32 s_off[4][65];
-    const u32 lane = lane_id(), wib = threadIdx.x >> 6;
-    const u32 wave = blockIdx.x * 4 + wib, nwaves = gridDim.x * 4;
-    u32* so = s_off[wib];
-    for (u32 g = wave; g < ng; g += nwaves) {
-        const u32 v0 = g * 64;
-        so[lane] = rowptr[v0 + lane < n ? v0 + lane : n];
-        if (lane == 0) so[64] = rowptr[v0 + 64 < n ? v0 + 64 : n];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const u32 b = so[0], e = so[64];
-        for (u32 q = b + lane; q < e; q += 64) {
-            u32 lo = 0;                                    // largest row with so[row] <= q
+// The entries of A' arrive partitioned by the slot range of their column (partition_csr_entries, transpose.hip: one
+// LDS-staged stable partition pass, (slot, row) pairs — the walk that did this with one atomic and one scattered 4-byte store
+// per entry took 3.5 + 4.1 ms at RMAT-22, three times the transpose itself).  What is left: the flag on the first entry of
+// every (partition, row) run, and where every run starts — off[x * n + v] for ALL rows v, those without entries included,
+// which a position that opens a run fills for the rows since the previous run.
+__global__ __launch_bounds__(256) void xp_runs_kernel(const uint2* __restrict__ pairs, const u32* __restrict__ pstart, u32 n, u32 nnz,
+                                                      u32* __restrict__ pcol, u32* __restrict__ off) {
+    __shared__ u32 s_ps[9];
+    if (threadIdx.x < 9) s_ps[threadIdx.x] = pstart[threadIdx.x];
+    __syncthreads();
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    for (u32 p0 = wave * 64; p0 < nnz; p0 += nwaves * 64) {
+        const u32 p = p0 + lane;
+        u32 g0 = 0, g1 = 0;                       // rows (g0 .. g1] of partition x start at p
+        size_t base = 0;
+        if (p < nnz) {
+            u32 x = 0;
 #pragma unroll
-            for (u32 step = 32; step >= 1; step >>= 1)
-                if (so[lo + step] <= q) lo += step;
-            const u32 u = perm ? perm[colidx[q]] : colidx[q];     // the row's SLOT in the state
-            const size_t i = (size_t)(u / prange) * n + v0 + lo;
-            if (!FILL) {
-                atomicAdd(&cnt[i], 1u);
-            } else {
-                const u32 k = atomicSub(&cnt[i], 1u) - 1u;
-                pcol[off[i] + k] = (k == 0 ? XP_FIRST : 0u) | u;
-            }
+            for (u32 k = 1; k < 8; ++k) x += p >= s_ps[k] ? 1u : 0u;
+            const uint2 e = pairs[p];
+            const bool head = p == s_ps[x];
+            const u32 prev = head ? 0xFFFFFFFFu : pairs[p - 1].y;
+            const bool first = head || e.y != prev;
+            pcol[p] = e.x | (first ? XP_FIRST : 0u);
+            if (first) { g0 = prev + 1u; g1 = e.y + 1u; base = (size_t)x * n; }   // (prev + 1 wraps to 0 at the head)
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < 2 && g0 < g1; ++j, ++g0) off[base + g0] = p;          // the usual case: the row itself, one empty row
+        u64 more = __ballot(g0 < g1);
+        while (more) {                            // a long stretch of rows without entries: the whole wavefront fills it
+            const int l = (int)__builtin_ctzll(more);
+            more &= more - 1ull;
+            const u32 a = (u32)__builtin_amdgcn_readlane((int)g0, l), b = (u32)__builtin_amdgcn_readlane((int)g1, l);
+            const u32 at = (u32)__builtin_amdgcn_readlane((int)p, l);
+            const u64 bs = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)base >> 32), l) << 32) |
+                           (u64)(u32)__builtin_amdgcn_readlane((int)(u32)base, l);
+            for (u32 r = a + lane; r < b; r += 64) off[bs + r] = at;
+        }
     }
 }
-__global__ void xp_nonempty_kernel(const u32* __restrict__ cnt, u64 total, u32* __restrict__ nz) {
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i <= total; i += (u64)gridDim.x * 256) nz[i] = (i < total && cnt[i]) ? 1u : 0u;
+// the rows after a partition's last run (all of them when it has none) start where the partition ends
+__global__ __launch_bounds__(256) void xp_run_tails_kernel(const uint2* __restrict__ pairs, const u32* __restrict__ pstart, u32 n,
+                                                           u32* __restrict__ off) {
+    const u32 x = blockIdx.y;
+    const u32 b = pstart[x], e = pstart[x + 1];
+    const u32 from = e > b ? pairs[e - 1].y + 1u : 0u;
+    for (u32 r = from + blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) off[(size_t)x * n + r] = e;
+    if (x == 7 && blockIdx.x == 0 && threadIdx.x == 0) off[(size_t)8 * n] = pstart[8];
+}
+__global__ void xp_nonempty_kernel(const u32* __restrict__ off, u64 total, u32* __restrict__ nz) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i <= total; i += (u64)gridDim.x * 256) nz[i] = (i < total && off[i + 1] != off[i]) ? 1u : 0u;
 }
 // a wavefront per (partition, group): the non-empty bitmap and the partial row of the group's first non-empty row
 __global__ __launch_bounds__(256) void xp_groups_kernel(const u32* __restrict__ off, const u32* __restrict__ ridx, u32 n, u32 ng,
@@ -166,19 +179,20 @@ __global__ void xp_shared_rows_kernel(const u32* __restrict__ crun0, const uint8
     if (c < nchunks && cshared[c]) zrows[atomicAdd(count, 1u)] = crun0[c];   // (a run over several chunks is listed once per chunk: harmless)
 }
 
-__global__ void xp_deg_hist_kernel(const u32* __restrict__ rowptr, u32 n, u32* __restrict__ hist) {
+// rows of X ranked by out-degree, descending (ties by id): key = 65535 - min(degree, 65535), value = the row; the stable
+// counting sort of transpose.hip orders them, and rank r goes to slot (r % 8) * prange + r / 8 — the ranks dealt to the 8
+// partitions.  (One atomic per row on a histogram of degrees, then one on its cursor, was what this used to be: the two or
+// three buckets of the small degrees take millions of same-address atomics at ~5.6 ns each — 60 ms of the 63 ms a new
+// snapshot of RMAT-22 cost before its first batch.)
+__global__ void xp_deg_key_kernel(const u32* __restrict__ rowptr, u32 n, u32* __restrict__ key, u32* __restrict__ val) {
     for (u32 u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
         const u32 d = rowptr[u + 1] - rowptr[u];
-        atomicAdd(&hist[65535u - (d < 65535u ? d : 65535u)], 1u);
+        key[u] = 65535u - (d < 65535u ? d : 65535u);
+        val[u] = u;
     }
 }
-__global__ void xp_rank_kernel(const u32* __restrict__ rowptr, u32 n, u32 prange, u32* __restrict__ cursor /* bucket bases, counted up */,
-                               u32* __restrict__ perm) {
-    for (u32 u = blockIdx.x * 256 + threadIdx.x; u < n; u += gridDim.x * 256) {
-        const u32 d = rowptr[u + 1] - rowptr[u];
-        const u32 rank = atomicAdd(&cursor[65535u - (d < 65535u ? d : 65535u)], 1u);
-        perm[u] = (rank & 7u) * prange + (rank >> 3);
-    }
+__global__ void xp_rank_kernel(const u32* __restrict__ by_rank, u32 n, u32 prange, u32* __restrict__ perm) {
+    for (u32 r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) perm[by_rank[r]] = (r & 7u) * prange + (r >> 3);
 }
 
 fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const BpXPlan** out) {
@@ -194,40 +208,45 @@ fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const Bp
     xp->n = n; xp->ng = ng; xp->nentries = t->nnz;
     hipStream_t st = ctx->stream();
     const u64 total = 8ull * n;
-    DevBuf<u32> cnt, off, ridx;
-    FGPU_TRY(cnt.alloc(ctx, total + 1));
+    DevBuf<u32> off, ridx;
     FGPU_TRY(off.alloc(ctx, total + 1));
     FGPU_TRY(ridx.alloc(ctx, total + 1));
-    FGPU_HIP(hipMemsetAsync(cnt.p, 0, (total + 1) * sizeof(u32), st));
-    u32 wgrid = cdiv(ng, 4);
-    if (wgrid > (u32)ctx->cus * 16) wgrid = ctx->cus * 16;
     const u32 prange = (u32)((((t->ncols + 7) / 8) + 15) & ~15ull);
     if (ctx->opt.expand_xcd_relabel && !m->is_hyper() && m->nrows == t->ncols && t->ncols % 128 == 0 && (u64)prange * 8 == t->ncols) {
-        // rank the rows of X by out-degree (65536 buckets, descending; ties in any order) and deal the ranks to the partitions
+        // rank the rows of X by out-degree (descending, ties by id) and deal the ranks to the partitions
         const u32 nu = (u32)t->ncols;
-        DevBuf<u32> hist, base;
-        FGPU_TRY(hist.alloc(ctx, 65536 + 1));
-        FGPU_TRY(base.alloc(ctx, 65536 + 1));
-        FGPU_HIP(hipMemsetAsync(hist.p, 0, (65536 + 1) * sizeof(u32), st));
+        DevBuf<u32> dkey, dval, by_rank, kptr;
+        FGPU_TRY(dkey.alloc(ctx, nu));
+        FGPU_TRY(dval.alloc(ctx, nu));
+        FGPU_TRY(by_rank.alloc(ctx, nu));
+        FGPU_TRY(kptr.alloc(ctx, 65536 + 1));
         FGPU_TRY(ctx->dev_alloc((void**)&xp->perm, (size_t)nu * sizeof(u32)));
-        hipLaunchKernelGGL(xp_deg_hist_kernel, dim3(ctx->cus * 8), dim3(256), 0, st, (const u32*)m->rowptr, nu, hist.p);
-        FGPU_TRY(scan_u32(ctx, hist.p, base.p, 65536 + 1, nullptr));
-        hipLaunchKernelGGL(xp_rank_kernel, dim3(ctx->cus * 8), dim3(256), 0, st, (const u32*)m->rowptr, nu, prange, base.p, xp->perm);
+        hipLaunchKernelGGL(xp_deg_key_kernel, dim3(ctx->cus * 8), dim3(256), 0, st, (const u32*)m->rowptr, nu, dkey.p, dval.p);
+        FGPU_HIP(hipGetLastError());
+        FGPU_TRY(sort_u32_pairs_by_key(ctx, dkey.p, dval.p, nu, 65536, by_rank.p, kptr.p));
+        hipLaunchKernelGGL(xp_rank_kernel, dim3(ctx->cus * 8), dim3(256), 0, st, (const u32*)by_rank.p, nu, prange, xp->perm);
         FGPU_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(xp_walk_kernel<false>, dim3(wgrid), dim3(256), 0, st, (const u32*)t->rowptr, (const u32*)t->colidx, n, ng, prange,
-                       (const u32*)xp->perm, cnt.p, (const u32*)nullptr, (u32*)nullptr);
-    FGPU_HIP(hipGetLastError());
-    FGPU_TRY(scan_u32(ctx, cnt.p, off.p, total + 1, nullptr));
-    hipLaunchKernelGGL(xp_nonempty_kernel, dim3(ctx->cus * 16), dim3(256), 0, st, (const u32*)cnt.p, total, ridx.p);
+    FGPU_TRY(ctx->dev_alloc((void**)&xp->pstart_dev, 27 * sizeof(u32)));
+    FGPU_TRY(ctx->dev_alloc((void**)&xp->pcol, ((size_t)t->nnz + 64) * sizeof(u32)));
+    {
+        DevBuf<uint2> pairs;
+        FGPU_TRY(pairs.alloc(ctx, t->nnz));
+        FGPU_TRY(partition_csr_entries(ctx, t->colidx, t->rowptr, n, t->nnz, xp->perm, prange, 8, pairs.p, xp->pstart_dev));
+        u32 rgrid = cdiv(t->nnz, 256 * 4);
+        if (rgrid > (u32)ctx->cus * 16) rgrid = ctx->cus * 16;
+        hipLaunchKernelGGL(xp_runs_kernel, dim3(rgrid), dim3(256), 0, st, (const uint2*)pairs.p, (const u32*)xp->pstart_dev, n, (u32)t->nnz,
+                           xp->pcol, off.p);
+        hipLaunchKernelGGL(xp_run_tails_kernel, dim3(64, 8), dim3(256), 0, st, (const uint2*)pairs.p, (const u32*)xp->pstart_dev, n, off.p);
+        FGPU_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(xp_nonempty_kernel, dim3(ctx->cus * 16), dim3(256), 0, st, (const u32*)off.p, total, ridx.p);
     FGPU_HIP(hipGetLastError());
     FGPU_TRY(scan_u32(ctx, ridx.p, ridx.p, total + 1, nullptr));
     FGPU_TRY(read_u32(ctx, ridx.p + total, &xp->nprows));
     u32 hp[27];                                              // pstart[9] | cbase[9] | first run of partition k [9]
-    for (int k = 0; k <= 8; ++k) {
-        FGPU_TRY(read_u32(ctx, off.p + (size_t)k * n, &hp[k]));
-        FGPU_TRY(read_u32(ctx, ridx.p + (size_t)k * n, &hp[18 + k]));
-    }
+    FGPU_TRY(read_words(ctx, xp->pstart_dev, 9, hp));
+    for (int k = 0; k <= 8; ++k) FGPU_TRY(read_u32(ctx, ridx.p + (size_t)k * n, &hp[18 + k]));
     hp[9] = 0;
     for (int k = 0; k < 8; ++k) {
         const u64 len = hp[k + 1] - hp[k], runs = hp[19 + k] - hp[18 + k];
@@ -235,12 +254,7 @@ fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const Bp
     }
     for (int k = 0; k <= 8; ++k) { xp->pstart[k] = hp[k]; xp->cbase[k] = hp[9 + k]; }
     xp->nchunks = xp->cbase[8];
-    FGPU_TRY(ctx->dev_alloc((void**)&xp->pstart_dev, 27 * sizeof(u32)));
     FGPU_TRY(ctx->h2d(xp->pstart_dev, hp, 27 * sizeof(u32)));
-    FGPU_TRY(ctx->dev_alloc((void**)&xp->pcol, ((size_t)t->nnz + 64) * sizeof(u32)));
-    hipLaunchKernelGGL(xp_walk_kernel<true>, dim3(wgrid), dim3(256), 0, st, (const u32*)t->rowptr, (const u32*)t->colidx, n, ng, prange,
-                       (const u32*)xp->perm, cnt.p, (const u32*)off.p, xp->pcol);
-    FGPU_HIP(hipGetLastError());
     FGPU_TRY(ctx->dev_alloc((void**)&xp->ne, (size_t)8 * ng * sizeof(u64)));
     FGPU_TRY(ctx->dev_alloc((void**)&xp->pbase, ((size_t)8 * ng + 1) * sizeof(u32)));
     u32 ggrid = cdiv((u64)8 * ng, 4);

@@ -443,6 +443,11 @@ fgpu_info mat_transpose_pattern(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a
 fgpu_info mat_wordrow(fgpu_ctx* ctx, const fgpu_mat* a, const uint32_t** out);
 void ks_set_wb_override(int wb);   // experiment knob: low-digit bits of the counting sort (0 = pick)
 fgpu_info mat_transpose_counting(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a);
+// stable sort of n (key, value) pairs by key < nkeys: out_val = the values in key order, keyptr[nkeys + 1] = start of every key's run
+fgpu_info sort_u32_pairs_by_key(fgpu_ctx* ctx, const u32* key, const u32* val, u64 n, u64 nkeys, u32* out_val, u32* keyptr);
+// stable partition of the entries of a CSR by slot / div (slot = slot_of[column], or the column): (slot, row) pairs, part by part
+fgpu_info partition_csr_entries(fgpu_ctx* ctx, const u32* colidx, const u32* rowptr, u32 nrows, u64 nnz, const u32* slot_of, u32 div,
+                                u32 nparts, uint2* out_pairs, u32* pstart_dev);
 fgpu_info mat_from_device_coo_counting(fgpu_ctx* ctx, fgpu_mat** out, u64 nrows, u64 ncols, const u32* rows,
                                        const u32* cols, u64 n);
 fgpu_info mat_finalize(const fgpu_mat* m);  // hub list, max degree (after rowptr/colidx are filled; private or under idx_mu)

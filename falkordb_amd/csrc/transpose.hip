@@ -349,7 +349,11 @@ struct KpLevel {
     u32 shift;   // digit = (key >> shift) & (D - 1)
     u32 dbits, D;
     u32 S;       // segments of this level = 2^(bits above the digit); segment of a key = key >> (shift + dbits)
+    u32 div;     // != 0 (single-level partitions): digit = key / div instead
 };
+__device__ __forceinline__ u32 kp_digit(const KpLevel& lv, u32 key) {
+    return lv.div ? key / lv.div : (key >> lv.shift) & (lv.D - 1u);
+}
 
 // start of every segment of the NEXT level (q = segment * D + digit of this level; S * D + 1 entries wanted) out of this
 // level's positions, and how many blocks each takes.  `limit`: entries written (the key pointers stop at nkeys).
@@ -426,7 +430,9 @@ __device__ __forceinline__ bool kp_block(const uint4* __restrict__ desc, u32 h, 
 // FIRST: keys / values in two arrays (values nullable = implicit rows, never dropped); otherwise packed pairs
 template <bool FIRST>
 __global__ __launch_bounds__(256) void kp_count_kernel(const u32* __restrict__ key1, const u32* __restrict__ val1, const uint2* __restrict__ in,
-                                                      KpLevel lv, const uint4* __restrict__ desc, u32* __restrict__ cnt) {
+                                                      KpLevel lv, const uint4* __restrict__ desc, u32* __restrict__ cnt,
+                                                      const u32* __restrict__ keymap /* FIRST, nullable: the key is keymap[key1[i]] */,
+                                                      u32* __restrict__ mapped /* nullable: the mapped keys, kept for the scatter */) {
     __shared__ u32 s_hist[KP_MAX_D];
     KpBlock k;
     if (!kp_block(desc, blockIdx.x, gridDim.x, k)) {
@@ -437,15 +443,48 @@ __global__ __launch_bounds__(256) void kp_count_kernel(const u32* __restrict__ k
     }
     for (u32 d = threadIdx.x; d < lv.D; d += 256) s_hist[d] = 0;
     __syncthreads();
-    for (u32 i = k.e0 + threadIdx.x; i < k.e1; i += 256) {
-        u32 key;
+    constexpr int T = KP_EB / 256;                // all of a thread's loads in flight before the first is used
+    u32 key[T];
+    bool on[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const u32 i = k.e0 + t * 256 + threadIdx.x;
+        on[t] = i < k.e1;
         if (FIRST) {
-            if (val1 && val1[i] == KS_INVALID) continue;
-            key = key1[i];
+            key[t] = on[t] ? key1[i] : 0u;
+            if (val1 && on[t] && val1[i] == KS_INVALID) on[t] = false;
         } else {
-            key = in[i].x;
+            key[t] = on[t] ? in[i].x : 0u;
         }
-        atomicAdd(&s_hist[(key >> lv.shift) & (lv.D - 1u)], 1u);
+    }
+    if (FIRST && keymap) {
+        // (a gather over a table wider than one L2 rides the miss path, ~57 G lines/s: it is done once, the scatter reads `mapped`)
+#pragma unroll
+        for (int t = 0; t < T; ++t) key[t] = on[t] ? keymap[key[t]] : 0u;
+        if (mapped) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (on[t]) mapped[k.e0 + t * 256 + threadIdx.x] = key[t];
+        }
+    }
+    if (lv.D <= 16) {
+        // a handful of counters: 64 lanes on <= 16 LDS addresses serialise (the 8-way partition of the k-hop plan counted at
+        // 0.58 ms for 67 M entries, 5x a 128-way level) — count by ballots, lane d keeps digit d's sum, one atomic a wavefront
+        const u32 lane = lane_id();
+        u32 acc = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const u32 dg = kp_digit(lv, key[t]);
+            for (u32 d = 0; d < lv.D; ++d) {
+                const u32 c = (u32)__popcll(__ballot(on[t] && dg == d));
+                if (lane == d) acc += c;
+            }
+        }
+        if (lane < lv.D && acc) atomicAdd(&s_hist[lane], acc);
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            if (on[t]) atomicAdd(&s_hist[kp_digit(lv, key[t])], 1u);
     }
     __syncthreads();
     for (u32 d = threadIdx.x; d < lv.D; d += 256) cnt[(size_t)k.cbase + (size_t)d * k.cstride] = s_hist[d];
@@ -455,7 +494,8 @@ template <bool FIRST, bool IMPLICIT, bool LAST>
 __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__ key1, const u32* __restrict__ val1,
                                                         const u32* __restrict__ rowptr, u32 nrows, const uint2* __restrict__ in,
                                                         KpLevel lv, const uint4* __restrict__ desc, const uint2* __restrict__ brows,
-                                                        const u32* __restrict__ pos, uint2* __restrict__ out_pairs, u32* __restrict__ out_val) {
+                                                        const u32* __restrict__ pos, uint2* __restrict__ out_pairs, u32* __restrict__ out_val,
+                                                        const u32* __restrict__ keymap /* FIRST, nullable */) {
     extern __shared__ u32 s_kp[];
     __shared__ u32 s_wave[4], s_total;
     const u32 D = lv.D;
@@ -489,6 +529,11 @@ __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__
             key[t] = p.x;
             val[t] = p.y;
         }
+    }
+    if (FIRST && keymap) {                        // (after all the key loads are out: T gathers in flight, not one at a time)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            if (qs + t * 64 + lane < k.e1) key[t] = keymap[key[t]];
     }
     if (FIRST && IMPLICIT) {
         // rows of the block's entries, the other way round: every row that STARTS inside the block marks its first entry in
@@ -537,7 +582,7 @@ __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__
         if (qs + t * 64 >= k.e1) break;           // wave-uniform
         const u32 i = qs + t * 64 + lane;
         const bool on = i < k.e1 && !(FIRST && !IMPLICIT && val[t] == KS_INVALID);
-        const u32 d = (key[t] >> lv.shift) & (D - 1u);
+        const u32 d = kp_digit(lv, key[t]);
         const u64 peers = match_digit(d, lv.dbits, on);
         if (on) {
             live |= 1u << t;
@@ -585,7 +630,7 @@ __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__
     for (int t = 0; t < T; ++t) {
         if (qs + t * 64 >= k.e1) break;           // wave-uniform
         if ((live >> t) & 1u) {
-            const u32 d = (key[t] >> lv.shift) & (D - 1u);
+            const u32 d = kp_digit(lv, key[t]);
             stage[cur[q * D + d] + ((loc[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu)] = make_uint2(key[t], val[t]);
         }
     }
@@ -593,7 +638,7 @@ __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__
     const u32 total = s_total;
     for (u32 slot = threadIdx.x; slot < total; slot += 256) {
         const uint2 p = stage[slot];
-        const u32 d = (p.x >> lv.shift) & (D - 1u);
+        const u32 d = kp_digit(lv, p.x);
         const u32 dst = gpos[d] + (slot - lstart[d]);
         if (LAST) out_val[dst] = p.y;
         else out_pairs[dst] = p;
@@ -659,6 +704,7 @@ fgpu_info sort_pairs_by_key_staged(fgpu_ctx* ctx, const u32* key, const u32* val
         lv.D = 1u << w[l];
         lv.shift = kb - done - w[l];
         lv.S = 1u << done;
+        lv.div = 0;
         const bool first = l == 0, last = l == L - 1;
         const u64 nb_max = (n / KP_EB + 1 + lv.S + 7) & ~7ull;
         const size_t ncnt = (size_t)lv.D * nb_max + 1;
@@ -670,10 +716,10 @@ fgpu_info sort_pairs_by_key_staged(fgpu_ctx* ctx, const u32* key, const u32* val
             ProfScope ps(ctx, names[l < 4 ? l : 3], (first ? 4 : 8) * n + 4 * ncnt);
             if (first)
                 hipLaunchKernelGGL(kp_count_kernel<true>, dim3((u32)nb_max), dim3(256), 0, st, key, val, (const uint2*)nullptr, lv,
-                                   (const uint4*)desc.p, cnt.p);
+                                   (const uint4*)desc.p, cnt.p, (const u32*)nullptr, (u32*)nullptr);
             else
                 hipLaunchKernelGGL(kp_count_kernel<false>, dim3((u32)nb_max), dim3(256), 0, st, (const u32*)nullptr, (const u32*)nullptr, in, lv,
-                                   (const uint4*)desc.p, cnt.p);
+                                   (const uint4*)desc.p, cnt.p, (const u32*)nullptr, (u32*)nullptr);
             FGPU_HIP(hipGetLastError());
         }
         FGPU_TRY(scan_u32(ctx, cnt.p, pos.p, ncnt, nullptr));
@@ -687,7 +733,7 @@ fgpu_info sort_pairs_by_key_staged(fgpu_ctx* ctx, const u32* key, const u32* val
                 if (lds > 48 * 1024)                                                                                                      \
                     FGPU_HIP(hipFuncSetAttribute((const void*)kp_scatter_kernel<F, I, LA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 hipLaunchKernelGGL((kp_scatter_kernel<F, I, LA>), dim3((u32)nb_max), dim3(256), lds, st, key, val, rowptr, nrows, in, lv,  \
-                                   (const uint4*)desc.p, (const uint2*)brows.p, (const u32*)pos.p, outp, out_val);                         \
+                                   (const uint4*)desc.p, (const uint2*)brows.p, (const u32*)pos.p, outp, out_val, (const u32*)nullptr);    \
             } while (0)
             if (first) {
                 if (implicit) { if (last) KP_SCATTER(true, true, true); else KP_SCATTER(true, true, false); }
@@ -772,6 +818,65 @@ static fgpu_info sort_pairs(fgpu_ctx* ctx, const u32* key, const u32* val, const
     if (!ks_applicable(ctx, n, nkeys, &staged)) return FGPU_NO_VALUE;
     return staged ? sort_pairs_by_key_staged(ctx, key, val, rowptr, nrows, n, nkeys, out_val, keyptr, n_valid_out)
                   : sort_pairs_by_key(ctx, key, val, rowptr, nrows, n, nkeys, out_val, keyptr, n_valid_out);
+}
+
+// Stable partition of the entries of a CSR into `nparts` streams by slot / div, slot = slot_of[column] (or the column): the
+// (slot, row) pairs of part 0 in entry order, then part 1, ...; pstart[nparts + 1] = where every part begins.  One level of
+// the partition above with the digit slot / div and implicit rows (the partitioned k-hop plan, bitpart.hip).
+fgpu_info partition_csr_entries(fgpu_ctx* ctx, const u32* colidx, const u32* rowptr, u32 nrows, u64 nnz, const u32* slot_of, u32 div,
+                                u32 nparts, uint2* out_pairs, u32* pstart_dev) {
+    FGPU_REQUIRE(nnz > 0 && nnz < 0xFFFFFFFFull - KP_EB && div > 0 && nparts >= 1 && nparts <= KP_MAX_D, FGPU_INVALID,
+                 "partition_csr_entries: size out of range");
+    KpLevel lv;
+    lv.dbits = 0;
+    while ((1u << lv.dbits) < nparts) ++lv.dbits;
+    lv.D = 1u << lv.dbits;
+    lv.shift = 0;
+    lv.S = 1;
+    lv.div = div;
+    hipStream_t st = ctx->stream();
+    const u64 nb_max = (nnz / KP_EB + 2 + 7) & ~7ull;
+    const size_t ncnt = (size_t)lv.D * nb_max + 1;
+    DevBuf<u32> segstart, blkstart, cnt, pos, slots;
+    DevBuf<uint4> desc;
+    DevBuf<uint2> brows;
+    if (slot_of) FGPU_TRY(slots.alloc(ctx, nnz));
+    FGPU_TRY(segstart.alloc(ctx, 4));
+    FGPU_TRY(blkstart.alloc(ctx, 4));
+    FGPU_TRY(desc.alloc(ctx, nb_max + 1));
+    FGPU_TRY(brows.alloc(ctx, nb_max + 1));
+    FGPU_TRY(cnt.alloc(ctx, ncnt + 1));
+    FGPU_TRY(pos.alloc(ctx, ncnt + 1));
+    hipLaunchKernelGGL(kp_first_kernel, dim3(1), dim3(1), 0, st, (u32)nnz, segstart.p, blkstart.p);
+    hipLaunchKernelGGL(kp_blk_table_kernel, dim3(cdiv(nb_max, 256)), dim3(256), 0, st, (const u32*)segstart.p, (const u32*)blkstart.p, lv,
+                       (u32)nb_max, desc.p, rowptr, nrows, brows.p, cnt.p);
+    FGPU_HIP(hipGetLastError());
+    {
+        ProfScope ps(ctx, "kp_count_kernel part", 4 * nnz + 4 * ncnt);
+        hipLaunchKernelGGL(kp_count_kernel<true>, dim3((u32)nb_max), dim3(256), 0, st, colidx, (const u32*)nullptr, (const uint2*)nullptr, lv,
+                           (const uint4*)desc.p, cnt.p, slot_of, slot_of ? slots.p : (u32*)nullptr);
+        FGPU_HIP(hipGetLastError());
+    }
+    FGPU_TRY(scan_u32(ctx, cnt.p, pos.p, ncnt, nullptr));
+    {
+        ProfScope ps(ctx, "kp_scatter_kernel part", 4 * nnz + 8 * nnz + 4 * ncnt);
+        const size_t lds = ((size_t)2 * KP_EB + (size_t)6 * lv.D) * sizeof(u32);
+        hipLaunchKernelGGL((kp_scatter_kernel<true, true, false>), dim3((u32)nb_max), dim3(256), lds, st,
+                           slot_of ? (const u32*)slots.p : colidx, (const u32*)nullptr, rowptr, nrows, (const uint2*)nullptr, lv,
+                           (const uint4*)desc.p, (const uint2*)brows.p, (const u32*)pos.p, out_pairs, (u32*)nullptr, (const u32*)nullptr);
+        FGPU_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(kp_seg_kernel, dim3(cdiv((u64)nparts + 1, 256)), dim3(256), 0, st, (const u32*)pos.p, (const u32*)blkstart.p, lv,
+                       (u64)nparts, pstart_dev, (u32*)nullptr);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+
+// the stable sort by itself (ranking rows by degree for the partitioned k-hop plan, bitpart.hip): explicit values, any key space
+fgpu_info sort_u32_pairs_by_key(fgpu_ctx* ctx, const u32* key, const u32* val, u64 n, u64 nkeys, u32* out_val, u32* keyptr) {
+    fgpu_info i = sort_pairs_by_key_staged(ctx, key, val, nullptr, 0, n, nkeys, out_val, keyptr, nullptr);
+    FGPU_REQUIRE(i != FGPU_NO_VALUE, FGPU_INVALID, "sort_u32_pairs_by_key: size out of range");
+    return i;
 }
 
 fgpu_info mat_transpose_counting(fgpu_ctx* ctx, fgpu_mat** out, const fgpu_mat* a) {
