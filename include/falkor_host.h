@@ -134,8 +134,11 @@ int fh_graph_layer_iter(fh_graph* g, int64_t type_id, int which, uint64_t** rows
 
 /* ---- operators ---------------------------------------------------------------------------------------
  * `spec` is "key=value;..." with keys: src=<labels,>  hop=<types,>|<dst labels,> (repeatable: hop 0 then the
- * fused chain)  optional= bind= emit= bidir= siblings= attrs= (0/1).
- * src[i] / to_bound[i]: node id, -1 = unbound, -2 = bound to NULL / a non-node. */
+ * fused chain)  optional= bind= emit= bidir= siblings= attrs= transposed= (0/1).
+ * src[i] / to_bound[i]: node id, -1 = unbound, -2 = bound to NULL / a non-node.
+ * transposed=1: src[i] is the matrix DESTINATION (cond_traverse.rs:221-235); the batch runs over the transposed layers and
+ * out_dest holds the matrix sources reached — row-equal to fh_cond_traverse_rows(..., transposed = 1) (an extension: the
+ * reference takes these per row). */
 int fh_cond_traverse_batch(fh_graph* g, const char* spec, const int64_t* src, const int64_t* to_bound,
                            uint64_t k, int* batched, uint64_t** out_row, uint64_t** out_dest,
                            int64_t** out_edge, uint64_t* n, uint64_t** null_rows, uint64_t* n_null,
