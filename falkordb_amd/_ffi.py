@@ -82,6 +82,7 @@ SIGNATURES = {
     "fgpu_vxm": (C.c_int32, [vp, u64p, u64p, u64p, vp, vp, C.c_int]),
     "fgpu_bfs": (C.c_int32, [vp, vp, vp, C.c_uint64, C.c_int64, i32p, i64p, u64p]),
     "fgpu_pagerank": (C.c_int32, [vp, vp, vp, u64p, C.c_float, C.c_float, C.c_int32, C.POINTER(C.c_float), i32p]),
+    "fgpu_pagerank_status": (C.c_int32, [vp, vp, vp, u64p, C.c_float, C.c_float, C.c_int32, C.POINTER(C.c_float), i32p, i32p]),
     "fgpu_bfs_plan_create": (C.c_int32, [vp, vpp, vp, vp, C.c_int, C.c_int]),
     "fgpu_bfs_plan_free": (C.c_int32, [vp]),
     "fgpu_bfs_plan_tune": (C.c_int32, [vp, C.c_double, C.c_double, C.c_int]),

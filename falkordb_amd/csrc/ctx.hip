@@ -416,15 +416,24 @@ fgpu_info xfer_wait(fgpu_lane* l, int k) {
 }
 
 // u32 ids of the device -> the u64 ids of the caller (GrB_Index), 4 per thread: one 16-byte load, two 16-byte stores
+// `in` is a window of a column array at an arbitrary entry (4-byte aligned only): up to three leading elements go one by one
+// so that the 16-byte loads of the body are aligned; the 8-byte stores are aligned wherever the window starts.
 __global__ __launch_bounds__(256) void widen_u32_u64_kernel(const u32* __restrict__ in, u64* __restrict__ out, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t n4 = n / 4;
+    size_t head = ((16u - (u32)(reinterpret_cast<uintptr_t>(in) & 15u)) & 15u) / 4u;
+    if (head > n) head = n;
+    const size_t n4 = (n - head) / 4;
+    const uint4* body = reinterpret_cast<const uint4*>(in + head);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const uint4 v = reinterpret_cast<const uint4*>(in)[i];
-        reinterpret_cast<ulonglong2*>(out)[2 * i] = make_ulonglong2(v.x, v.y);
-        reinterpret_cast<ulonglong2*>(out)[2 * i + 1] = make_ulonglong2(v.z, v.w);
+        const uint4 v = body[i];
+        u64* o = out + head + 4 * i;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = in[n4 * 4 + threadIdx.x];
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) out[threadIdx.x] = in[threadIdx.x];
+        const size_t done = head + 4 * n4;
+        if (threadIdx.x < n - done) out[done + threadIdx.x] = in[done + threadIdx.x];
+    }
 }
 }  // namespace
 

@@ -447,7 +447,14 @@ using namespace fgpu;
 
 extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, const uint64_t* active_bitmap,
                                    float damping, float tol, int32_t itermax, float* centrality, int32_t* iters) {
+    return fgpu_pagerank_status(ctx, A, At, active_bitmap, damping, tol, itermax, centrality, iters, nullptr);
+}
+
+extern "C" fgpu_info fgpu_pagerank_status(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, const uint64_t* active_bitmap,
+                                          float damping, float tol, int32_t itermax, float* centrality, int32_t* iters,
+                                          int32_t* converged) {
     FGPU_REQUIRE(ctx && A && centrality, FGPU_NULL_POINTER, "fgpu_pagerank: NULL argument");
+    if (converged) *converged = 1;                // (the paths that run no iteration: nothing left to converge)
     FGPU_REQUIRE(A->nrows == A->ncols, FGPU_DIM_MISMATCH, "fgpu_pagerank: adjacency must be square");
     FGPU_REQUIRE(!At || (At->nrows == A->nrows && At->ncols == A->ncols), FGPU_DIM_MISMATCH,
                  "fgpu_pagerank: transpose has different dimensions");
@@ -468,6 +475,7 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
             centrality[v] = (on && n_act) ? 1.0f / (float)n_act : 0.0f;
         }
         if (iters) *iters = (n_act && itermax > 0 && tol < 1.0f) ? 1 : 0;
+        if (converged) *converged = (itermax > 0 || !(tol < 1.0f)) ? 1 : 0;
         return FGPU_OK;
     }
     // dense row pointers are indexed directly below: hypersparse inputs are densified, a missing transpose is built
@@ -639,6 +647,7 @@ extern "C" fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_
             for (auto& e : ev) (void)hipEventDestroy(e);
         }
         if (iters) *iters = it;
+        if (converged) *converged = stopped ? 1 : 0;   // the last executed iteration moved the scores by no more than tol
         FGPU_TRY(ctx->d2h(centrality, rp, (size_t)n * sizeof(float)));
         FGPU_HIP(hipStreamSynchronize(ctx->stream()));
         return FGPU_OK;

@@ -222,20 +222,13 @@ int LAGr_PageRank(GrB_Vector* centrality, int* iters, LAGraph_Graph G, float dam
         float* score = nullptr;
         check(fgpu_host_alloc(c->raw(), (n ? n : 1) * sizeof(float), (void**)&score), "LAGr_PageRank");
         GrB_Vector out = fgshim::vector_over_pinned(fgshim::type_fp32(), n, score, 0);
-        int32_t it = 0;
-        fgpu_info r = fgpu_pagerank(c->raw(), G->A->m.snapshot(), AT->m.snapshot(), nullptr, damping, tol, itermax, score, &it);
-        if (r == FGPU_OK && itermax > 0 && it >= itermax) {
-            // the engine reports iterations, not the last residual: one more allowed iteration tells a run that converged
-            // on its last iteration (stops at itermax again) from one that did not (goes on)
-            int32_t it2 = 0;
-            r = fgpu_pagerank(c->raw(), G->A->m.snapshot(), AT->m.snapshot(), nullptr, damping, tol, itermax + 1, score, &it2);
-            if (r == FGPU_OK && it2 > itermax) {
-                r = fgpu_pagerank(c->raw(), G->A->m.snapshot(), AT->m.snapshot(), nullptr, damping, tol, itermax, score, &it);
-                *iters = it;
-                GrB_Vector_free(&out);
-                if (r != FGPU_OK) check(r, "LAGr_PageRank");
-                return fail(msg, LAGRAPH_CONVERGENCE_FAILURE, "pagerank failed to converge");
-            }
+        int32_t it = 0, converged = 1;
+        fgpu_info r = fgpu_pagerank_status(c->raw(), G->A->m.snapshot(), AT->m.snapshot(), nullptr, damping, tol, itermax, score, &it,
+                                           &converged);
+        if (r == FGPU_OK && itermax > 0 && !converged) {   // itermax iterations did not reach tol (one run: the engine reports it)
+            *iters = it;
+            GrB_Vector_free(&out);
+            return fail(msg, LAGRAPH_CONVERGENCE_FAILURE, "pagerank failed to converge");
         }
         if (r != FGPU_OK) { GrB_Vector_free(&out); check(r, "LAGr_PageRank"); }
         *iters = it;

@@ -357,6 +357,11 @@ fgpu_info fgpu_vxm(fgpu_ctx* ctx, uint64_t* w, const uint64_t* f, const uint64_t
  * leaves 0 in the other slots.  centrality[nrows] is a HOST array; *iters (nullable) the iterations taken. */
 fgpu_info fgpu_pagerank(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, const uint64_t* active_bitmap,
                         float damping, float tol, int32_t itermax, float* centrality, int32_t* iters);
+/* The same run; *converged (nullable) = 1 when the last iteration changed the scores by no more than tol, 0 when itermax
+ * ended it first — what LAGr_PageRank turns into LAGRAPH_CONVERGENCE_FAILURE (lagraph_bindings.rs:549-558). */
+fgpu_info fgpu_pagerank_status(fgpu_ctx* ctx, const fgpu_mat* A, const fgpu_mat* At, const uint64_t* active_bitmap,
+                               float damping, float tol, int32_t itermax, float* centrality, int32_t* iters,
+                               int32_t* converged);
 
 /* Level-synchronous BFS: replaces LAGr_BreadthFirstSearch_Extended(level, parent, G,
  * src, max_level, -1, false) as called by algo.BFS (algo_procedures.rs:1079-1088;

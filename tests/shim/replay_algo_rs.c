@@ -106,6 +106,11 @@ static void run_errors(GrB_Matrix adj, GrB_Index n) {
     printf("errors not_cached %d %d\n", r, v == NULL);
     r = LAGr_BreadthFirstSearch_Extended(&v, &w, g, n + 5, -1, -1, false, msg);
     printf("errors bad_source %d %d\n", r, v == NULL && w == NULL);
+    OK(LAGraph_Cached_AT(g, msg));
+    OK(LAGraph_Cached_OutDegree(g, msg));
+    iters = -1;
+    r = LAGr_PageRank(&v, &iters, g, 0.85f, 1e-7f, 2, msg);                       /* two iterations cannot reach 1e-7 */
+    printf("errors no_convergence %d %d %d\n", r, v == NULL, iters);
     r = LAGr_ConnectedComponents(&v, g, msg);
     printf("errors off_path %d %d %s\n", r, v == NULL, strlen(msg) ? "message" : "silent");
     r = LAGr_BreadthFirstSearch_Extended(&v, NULL, NULL, 0, -1, -1, false, msg);

@@ -190,6 +190,7 @@ def test_algo_rs_call_sequences_through_the_lagraph_abi_match_the_oracle(replay_
                 bi += 1
             assert errs["not_cached"] == ["-1003", "1"]                    # LAGRAPH_NOT_CACHED (lagraph_bindings.rs:26)
             assert errs["bad_source"] == ["-4", "1"]                       # GrB_INVALID_INDEX
+            assert errs["no_convergence"] == ["-1005", "1", "2"]           # LAGRAPH_CONVERGENCE_FAILURE after itermax = 2, from ONE run
             assert errs["off_path"] == ["-8", "1", "message"]              # GrB_NOT_IMPLEMENTED, loudly
             assert errs["null_graph"] == ["-2"] and errs["no_matrix"] == ["-1000"]
     assert blocks[bi][0] == ["adjacency", str(a.nnz)]
