@@ -72,8 +72,7 @@ PMC_GROUPS = (  # (reported name, regex over rocprofv3's Kernel_Name)
     ("bp_delta_kernel<dm>", r"bp_delta_kernel<true>"),
     ("bp_delta_kernel<dp>", r"bp_delta_kernel<false>"),
     ("bp_pull_groups_kernel", r"bp_pull_groups_kernel"),
-    ("xp_pull_kernel", r"xp_pull_kernel"),
-    ("xp_long_kernel", r"xp_long_kernel"),
+    ("xp_stream_kernel", r"xp_stream_kernel"),
     ("xp_fold_kernel", r"xp_fold_kernel"),
     ("bp_rows_kernel<emit>", r"bp_rows_kernel<true>"),
     ("bp_rows_kernel<count>", r"bp_rows_kernel<false>"),
@@ -1510,7 +1509,7 @@ def main():
                 import types
                 pmc26 = live_pmc(types.SimpleNamespace(scale=26, no_bfs=True), timeout_s=240)
                 detail["pmc_khop26"] = pmc26
-                e26 = pmc26.get("bp_pull_kernel<dense, count>") if isinstance(pmc26, dict) else None
+                e26 = (pmc26.get("xp_stream_kernel") or pmc26.get("bp_pull_kernel<dense, count>")) if isinstance(pmc26, dict) else None
                 if e26:
                     sec["khop26"]["hop3_traffic"] = e26["hbm_bytes_per_dispatch"]
                     sec["khop26"]["hop3_fetch_raw"] = e26["fetch_bytes_raw"]
