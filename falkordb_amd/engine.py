@@ -31,6 +31,8 @@ class Context:
     def __init__(self, device: int = 0):
         self.lib = _ffi.load()
         self._h = C.c_void_p()
+        self._live_views = 0          # result arrays handed out as views of library memory (_take) and not yet dropped
+        self._close_pending = False
         check(self.lib.fgpu_init(C.byref(self._h), device, None, None))
 
     @property
@@ -38,9 +40,16 @@ class Context:
         return self._h
 
     def close(self):
-        if self._h:
-            self.lib.fgpu_finalize(self._h)
-            self._h = C.c_void_p()
+        """fgpu_finalize.  Result arrays are zero-copy views of pinned blocks the context owns: while any of them is alive
+        the finalize is put off until the last one is dropped (an array that outlived its context would dangle)."""
+        if not self._h:
+            return
+        if self._live_views > 0:
+            self._close_pending = True
+            return
+        self.lib.fgpu_finalize(self._h)
+        self._h = C.c_void_p()
+        self._close_pending = False
 
     def __del__(self):
         try:
@@ -120,12 +129,15 @@ class Context:
         addr = C.cast(ptr, C.c_void_p).value
         buf = (C.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(addr)
         arr = np.frombuffer(buf, dtype=dtype, count=int(n))
-        me = weakref.ref(self)
+        ctx = self                               # (a strong reference: the context outlives its views)
+        ctx._live_views += 1
 
         def release():
-            c = me()
-            if c is not None and c._h:          # (a closed context has already released its pinned blocks)
-                c.lib.fgpu_free(c._h, C.c_void_p(addr))
+            ctx._live_views -= 1
+            if ctx._h:
+                ctx.lib.fgpu_free(ctx._h, C.c_void_p(addr))
+                if ctx._close_pending and ctx._live_views == 0:
+                    ctx.close()
         weakref.finalize(buf, release)
         return arr
 

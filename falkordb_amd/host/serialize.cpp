@@ -376,13 +376,9 @@ Tensor Tensor::decode(Context& ctx, ByteReader& r, const BlobCodec& codec) {
     t.m_.wait();                                             // the committed base is never pending (:1190-1192)
     // The u64 before the groups is `total_tensor_count` in the reference and only its being > 0 is tested
     // (tensor.rs:1169-1170): writers differ in what they count there (edges, tensors), so nothing is derived from its
-    // value, nor from the count the MSB-flagged inline value carries.  What cannot be served is a pair flagged multi-edge
-    // with NO id list anywhere — Tensor::get would have nothing to return for it.
-    for (auto& kv : inl) {
-        if (kv.second != MULTI_EDGE) continue;
-        if (t.me_.find(compound_key(kv.first.first, kv.first.second)) == t.me_.end())
-            throw GrbError(FGPU_INVALID, "Tensor decode: a multi-edge pair has no id list in the tensor section");
-    }
+    // value, nor from the count the MSB-flagged inline value carries.  A pair flagged multi-edge with NO id list anywhere is
+    // accepted as the reference accepts it (tensor.rs:1169-1186 never cross-checks the two sections): Tensor::get finds no
+    // row under its compound key and returns no ids, exactly what the reference's `me` row iterator yields.
     return t;
 }
 

@@ -506,6 +506,14 @@ def test_tensor_v19_payload_with_multi_edges(hctx):
     # stores the number of TENSORS there (3) instead of the number of edges decodes to the same tensor
     alt, _ = host.Tensor.decode(hctx, payload[:off] + _frame_u(3) + payload[off + 8:])
     assert alt.state()["edge_count"] == sb["edge_count"] and alt.get(5, 6) == [5, 500, 501] and alt.get(0, 1) == [0]
+    # a pair flagged multi-edge whose id list is missing from the tensor section (the first of the three triples dropped,
+    # the group count lowered): the reference's decoder never cross-checks the two sections (tensor.rs:1169-1186) — the
+    # payload decodes, the pair keeps its MULTI_EDGE inline value and yields no ids, everything else is intact
+    first_len = rd(off + 32)
+    holed, used_h = host.Tensor.decode(hctx, payload[:off + 8] + _frame_u(2) + payload[off + 40 + first_len:])
+    assert used_h == len(payload) - (24 + first_len)
+    assert holed.eff_get(5, 6) == host.Tensor.MULTI_EDGE and holed.get(5, 6) == []
+    assert holed.get(9, 10) == t.get(9, 10) and holed.get(200, 201) == [900, 901] and holed.get(0, 1) == [0]
     # an empty tensor: three empty containers and a zero count, nothing else
     e = host.Tensor(hctx, 10, 10)
     pe = e.encode()

@@ -378,3 +378,23 @@ def test_merge_random_configurations(ctx):
             assert got.nvals == ref.nnz, (case, masks_dp)
             np.testing.assert_array_equal(rp, ref.rowptr, err_msg=f"case {case} masks_dp {masks_dp}")
             np.testing.assert_array_equal(ci, ref.colidx, err_msg=f"case {case} masks_dp {masks_dp}")
+
+
+def test_result_arrays_keep_their_context_alive_until_they_are_dropped():
+    """Result arrays are zero-copy views of pinned blocks the context owns (Context._take): closing the context while one
+    is alive must not leave it dangling — the finalize waits for the last view."""
+    import gc
+    c = engine.Context(0)
+    rng = np.random.default_rng(5)
+    r, cc = rand_coo(rng, 300, 300, 4000)
+    a = oracle.build_csr(300, 300, r, cc)
+    m = c.mat_from_coo(300, 300, r, cc)
+    rp, ci, _ = m.export_csr()
+    m.free()
+    c.close()                                    # put off: rp / ci are alive
+    assert c.handle and c._close_pending and c._live_views >= 2
+    np.testing.assert_array_equal(rp, a.rowptr)  # still the library's memory, still valid
+    np.testing.assert_array_equal(ci, a.colidx)
+    del rp, ci
+    gc.collect()
+    assert not c.handle and c._live_views == 0   # the last view finalised the context
