@@ -351,8 +351,9 @@ struct KpLevel {
     u32 S;       // segments of this level = 2^(bits above the digit); segment of a key = key >> (shift + dbits)
     u32 div;     // != 0 (single-level partitions): digit = key / div instead
 };
+template <bool DIV>
 __device__ __forceinline__ u32 kp_digit(const KpLevel& lv, u32 key) {
-    return lv.div ? key / lv.div : (key >> lv.shift) & (lv.D - 1u);
+    return DIV ? key / lv.div : (key >> lv.shift) & (lv.D - 1u);
 }
 
 // start of every segment of the NEXT level (q = segment * D + digit of this level; S * D + 1 entries wanted) out of this
@@ -428,7 +429,7 @@ __device__ __forceinline__ bool kp_block(const uint4* __restrict__ desc, u32 h, 
 }
 
 // FIRST: keys / values in two arrays (values nullable = implicit rows, never dropped); otherwise packed pairs
-template <bool FIRST>
+template <bool FIRST, bool DIV>
 __global__ __launch_bounds__(256) void kp_count_kernel(const u32* __restrict__ key1, const u32* __restrict__ val1, const uint2* __restrict__ in,
                                                       KpLevel lv, const uint4* __restrict__ desc, u32* __restrict__ cnt,
                                                       const u32* __restrict__ keymap /* FIRST, nullable: the key is keymap[key1[i]] */,
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256) void kp_count_kernel(const u32* __restrict__ k
         u32 acc = 0;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const u32 dg = kp_digit(lv, key[t]);
+            const u32 dg = kp_digit<DIV>(lv, key[t]);
             for (u32 d = 0; d < lv.D; ++d) {
                 const u32 c = (u32)__popcll(__ballot(on[t] && dg == d));
                 if (lane == d) acc += c;
@@ -484,19 +485,19 @@ __global__ __launch_bounds__(256) void kp_count_kernel(const u32* __restrict__ k
     } else {
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            if (on[t]) atomicAdd(&s_hist[kp_digit(lv, key[t])], 1u);
+            if (on[t]) atomicAdd(&s_hist[kp_digit<DIV>(lv, key[t])], 1u);
     }
     __syncthreads();
     for (u32 d = threadIdx.x; d < lv.D; d += 256) cnt[(size_t)k.cbase + (size_t)d * k.cstride] = s_hist[d];
 }
 
-template <bool FIRST, bool IMPLICIT, bool LAST>
+template <bool FIRST, bool IMPLICIT, bool LAST, bool DIV>
 __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__ key1, const u32* __restrict__ val1,
                                                         const u32* __restrict__ rowptr, u32 nrows, const uint2* __restrict__ in,
                                                         KpLevel lv, const uint4* __restrict__ desc, const uint2* __restrict__ brows,
                                                         const u32* __restrict__ pos, uint2* __restrict__ out_pairs, u32* __restrict__ out_val,
                                                         const u32* __restrict__ keymap /* FIRST, nullable */) {
-    extern __shared__ u32 s_kp[];
+    extern __shared__ __attribute__((aligned(16))) u32 s_kp[];   // (64-bit LDS atomics below: the base must not sit at 4 mod 8)
     __shared__ u32 s_wave[4], s_total;
     const u32 D = lv.D;
     uint2* stage = (uint2*)s_kp;                  // KP_EB pairs
@@ -569,30 +570,42 @@ __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__
         for (int t = 0; t < T; ++t) val[t] = val[t] > before ? val[t] : before;
         __syncthreads();                          // the marks are read: the area is the staging buffer again
     }
-    // count AND rank in one sweep: the wavefront walks its quarter in order, lanes with the same digit find each other by
-    // ballots, the lowest bumps the wavefront's counter of that digit by the size of the group — what it gets back is the
-    // group's place among the entries of (wavefront, digit), which is all the second sweep needs on top of the counter scan
-    // (ranking again there, as the two-level form does, made the kernel instruction-bound: ~100 VALU per trip, twice)
+    // count AND rank in one sweep: the wavefront walks its quarter in order; the lanes of a trip that hold the same digit find
+    // each other through LDS — every lane ORs its bit into the wavefront's 64-bit word of that digit and reads the word back
+    // (a wavefront's LDS instructions execute in order: the read sees the whole trip) — its rank is the popcount below it, the
+    // group's place among the entries of (wavefront, digit) is the counter before the lowest lane adds the group's size.  (The
+    // ballot match of the two-level form costs ~12 VALU per key BIT per trip, ~85 of the ~125 instructions a trip took: with 28
+    // wavefronts a CU the kernel was bound by instruction issue, not by memory.)
+    u64* seen = reinterpret_cast<u64*>(s_kp) + (size_t)q * D;      // [4][D] words in the staging area, free until the ranks are known
+    for (u32 i = threadIdx.x; i < 4 * D; i += 256) reinterpret_cast<u64*>(s_kp)[i] = 0ull;
+    __syncthreads();
     u32 live = 0;                                  // bit t: this lane's entry of trip t takes part
     u32 loc[T / 2];                                // place inside (wavefront, digit), two 16-bit fields a word
 #pragma unroll
     for (int t = 0; t < T / 2; ++t) loc[t] = 0;
+    const u64 mybit = 1ull << lane;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         if (qs + t * 64 >= k.e1) break;           // wave-uniform
         const u32 i = qs + t * 64 + lane;
         const bool on = i < k.e1 && !(FIRST && !IMPLICIT && val[t] == KS_INVALID);
-        const u32 d = kp_digit(lv, key[t]);
-        const u64 peers = match_digit(d, lv.dbits, on);
+        const u32 d = kp_digit<DIV>(lv, key[t]);
+        if (on) atomicOr((unsigned long long*)&seen[d], (unsigned long long)mybit);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (on) {
+            const u64 peers = seen[d];
+            const u32 base = cur[q * D + d];
             live |= 1u << t;
-            const u32 rank = (u32)__popcll(peers & ((1ull << lane) - 1ull));
-            const u32 leader = (u32)__builtin_ctzll(peers);
-            u32 base = 0;
-            if (lane == leader) base = atomicAdd(&cur[q * D + d], (u32)__popcll(peers));
-            base = (u32)__shfl((int)base, (int)leader, 64);
+            const u32 rank = (u32)__popcll(peers & (mybit - 1ull));
             loc[t >> 1] |= (base + rank) << ((t & 1) * 16);
+            if ((peers & (mybit - 1ull)) == 0ull) {          // the lowest lane of the group tidies up for the next trip
+                seen[d] = 0ull;
+                cur[q * D + d] = base + (u32)__popcll(peers);
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     {   // slots: digits ascending, wavefronts ascending inside a digit; thread c owns digits c * per .. (per = D / 256, at least 1)
@@ -630,7 +643,7 @@ __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__
     for (int t = 0; t < T; ++t) {
         if (qs + t * 64 >= k.e1) break;           // wave-uniform
         if ((live >> t) & 1u) {
-            const u32 d = kp_digit(lv, key[t]);
+            const u32 d = kp_digit<DIV>(lv, key[t]);
             stage[cur[q * D + d] + ((loc[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu)] = make_uint2(key[t], val[t]);
         }
     }
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(256) void kp_scatter_kernel(const u32* __restrict__
     const u32 total = s_total;
     for (u32 slot = threadIdx.x; slot < total; slot += 256) {
         const uint2 p = stage[slot];
-        const u32 d = kp_digit(lv, p.x);
+        const u32 d = kp_digit<DIV>(lv, p.x);
         const u32 dst = gpos[d] + (slot - lstart[d]);
         if (LAST) out_val[dst] = p.y;
         else out_pairs[dst] = p;
@@ -715,10 +728,10 @@ fgpu_info sort_pairs_by_key_staged(fgpu_ctx* ctx, const u32* key, const u32* val
             static const char* const names[] = {"kp_count_kernel L1", "kp_count_kernel L2", "kp_count_kernel L3", "kp_count_kernel L4"};
             ProfScope ps(ctx, names[l < 4 ? l : 3], (first ? 4 : 8) * n + 4 * ncnt);
             if (first)
-                hipLaunchKernelGGL(kp_count_kernel<true>, dim3((u32)nb_max), dim3(256), 0, st, key, val, (const uint2*)nullptr, lv,
+                hipLaunchKernelGGL((kp_count_kernel<true, false>), dim3((u32)nb_max), dim3(256), 0, st, key, val, (const uint2*)nullptr, lv,
                                    (const uint4*)desc.p, cnt.p, (const u32*)nullptr, (u32*)nullptr);
             else
-                hipLaunchKernelGGL(kp_count_kernel<false>, dim3((u32)nb_max), dim3(256), 0, st, (const u32*)nullptr, (const u32*)nullptr, in, lv,
+                hipLaunchKernelGGL((kp_count_kernel<false, false>), dim3((u32)nb_max), dim3(256), 0, st, (const u32*)nullptr, (const u32*)nullptr, in, lv,
                                    (const uint4*)desc.p, cnt.p, (const u32*)nullptr, (u32*)nullptr);
             FGPU_HIP(hipGetLastError());
         }
@@ -731,8 +744,8 @@ fgpu_info sort_pairs_by_key_staged(fgpu_ctx* ctx, const u32* key, const u32* val
 #define KP_SCATTER(F, I, LA)                                                                                                              \
             do {                                                                                                                          \
                 if (lds > 48 * 1024)                                                                                                      \
-                    FGPU_HIP(hipFuncSetAttribute((const void*)kp_scatter_kernel<F, I, LA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                hipLaunchKernelGGL((kp_scatter_kernel<F, I, LA>), dim3((u32)nb_max), dim3(256), lds, st, key, val, rowptr, nrows, in, lv,  \
+                    FGPU_HIP(hipFuncSetAttribute((const void*)kp_scatter_kernel<F, I, LA, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                hipLaunchKernelGGL((kp_scatter_kernel<F, I, LA, false>), dim3((u32)nb_max), dim3(256), lds, st, key, val, rowptr, nrows, in, lv,  \
                                    (const uint4*)desc.p, (const uint2*)brows.p, (const u32*)pos.p, outp, out_val, (const u32*)nullptr);    \
             } while (0)
             if (first) {
@@ -853,7 +866,7 @@ fgpu_info partition_csr_entries(fgpu_ctx* ctx, const u32* colidx, const u32* row
     FGPU_HIP(hipGetLastError());
     {
         ProfScope ps(ctx, "kp_count_kernel part", 4 * nnz + 4 * ncnt);
-        hipLaunchKernelGGL(kp_count_kernel<true>, dim3((u32)nb_max), dim3(256), 0, st, colidx, (const u32*)nullptr, (const uint2*)nullptr, lv,
+        hipLaunchKernelGGL((kp_count_kernel<true, true>), dim3((u32)nb_max), dim3(256), 0, st, colidx, (const u32*)nullptr, (const uint2*)nullptr, lv,
                            (const uint4*)desc.p, cnt.p, slot_of, slot_of ? slots.p : (u32*)nullptr);
         FGPU_HIP(hipGetLastError());
     }
@@ -861,7 +874,7 @@ fgpu_info partition_csr_entries(fgpu_ctx* ctx, const u32* colidx, const u32* row
     {
         ProfScope ps(ctx, "kp_scatter_kernel part", 4 * nnz + 8 * nnz + 4 * ncnt);
         const size_t lds = ((size_t)2 * KP_EB + (size_t)6 * lv.D) * sizeof(u32);
-        hipLaunchKernelGGL((kp_scatter_kernel<true, true, false>), dim3((u32)nb_max), dim3(256), lds, st,
+        hipLaunchKernelGGL((kp_scatter_kernel<true, true, false, true>), dim3((u32)nb_max), dim3(256), lds, st,
                            slot_of ? (const u32*)slots.p : colidx, (const u32*)nullptr, rowptr, nrows, (const uint2*)nullptr, lv,
                            (const uint4*)desc.p, (const uint2*)brows.p, (const u32*)pos.p, out_pairs, (u32*)nullptr, (const u32*)nullptr);
         FGPU_HIP(hipGetLastError());
