@@ -473,8 +473,8 @@ __global__ __launch_bounds__(256) void kp_count_kernel(const u32* __restrict__ k
         }
     }
     if (lv.D <= 16) {
-        // a handful of counters: 64 lanes on <= 16 LDS addresses serialise (the 8-way partition of the k-hop plan counted at
-        // 0.58 ms for 67 M entries, 5x a 128-way level) — count by ballots, lane d keeps digit d's sum, one atomic a wavefront
+        // a handful of counters (the 8-way partition of the k-hop plan): 64 lanes on <= 16 LDS addresses serialise — count by
+        // ballots, lane d keeps digit d's sum, one atomic a wavefront.  (That pass is bound by its slot gather all the same.)
         const u32 lane = lane_id();
         u32 acc = 0;
 #pragma unroll
