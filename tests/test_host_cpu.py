@@ -101,6 +101,11 @@ def test_cond_traverse_eligibility_rule():               # cond_traverse.rs:308-
     assert L.fh_cond_traverse_eligible(host.cond_spec(hops=[(["R"], [])], attrs=True)) == 0
     # a fused chain makes inline attrs irrelevant (they can only sit on the fused-away intermediates)
     assert L.fh_cond_traverse_eligible(host.cond_spec(hops=[(["R"], []), ([], [])], attrs=True)) == 1
+    # `transposed` does not enter the rule (:308-316 test the pattern's shape): what makes the reference serve those per row is
+    # the unbound matrix source at run time (:556-568); this engine's expand_batch takes them over the transposed layers
+    assert L.fh_cond_traverse_eligible(host.cond_spec(hops=[(["R"], [])], transposed=True)) == 1
+    assert b"transposed=1" in host.cond_spec(hops=[(["R"], [])], transposed=True)
+    assert b"transposed=0" in host.cond_spec(hops=[(["R"], [])])
 
 
 def test_no_cpu_fallback_host_init_fails_without_a_device():
