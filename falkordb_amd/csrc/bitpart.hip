@@ -495,10 +495,11 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
         hipLaunchKernelGGL(xp_zero_rows_kernel, dim3(zg), dim3(256), 0, st, (const u32*)xp->zrows, xp->nzrows, ql, partial.p);
         FGPU_HIP(hipGetLastError());
     }
-    const u64 prow_bytes = (u64)xp->nprows * ws * 8;
     {
-        // algorithmic bytes: the entries and the chunk table once, every non-zero row of X once, the partial rows written
-        ProfScope ps(ctx, "xp_stream_kernel", 4 * xp->nentries + 9 * (u64)xp->nchunks + xrows * 8 * ws + prow_bytes);
+        // algorithmic bytes = what the HOP needs (SURVEY.md §8d's pull row): the entries of A' and its row pointers once, every
+        // non-zero row of X once.  The partial rows are NOT in it — they exist only because of the partition, are written here and
+        // read straight back by the fold (counting them made the kernel look 2.5 x closer to the roofline than the hop is)
+        ProfScope ps(ctx, "xp_stream_kernel", 4 * xp->nentries + 4 * ((u64)xp->n + 1) + xrows * 8 * ws);
         const size_t lds = (size_t)4 * XP_RUNS * ql * sizeof(uint4);
         u32 per_cu = (u32)((size_t)ctx->opt.lds_limit / lds);
         if (per_cu > 8) per_cu = 8;
@@ -525,7 +526,9 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
         FGPU_HIP(hipGetLastError());
     }
     {
-        ProfScope ps(ctx, "xp_fold_kernel", prow_bytes + (u64)8 * xp->ng * 12 + (u64)xp->ng * 20);
+        // (no algorithmic bytes of its own: everything it reads is the stream kernel's intermediate — bench.py quotes the hop,
+        // stream + fold, against the stream kernel's bytes)
+        ProfScope ps(ctx, "xp_fold_kernel", 0);
         // (4 or 8 wavefronts sharing one copy of the checksum tables, 16 or 32 resident per CU: the same 214 / 148 us with and
         // without the checksum at RMAT-22 — the kernel is not short of wavefronts)
         const u32 fthreads = XP_FOLD_THREADS;

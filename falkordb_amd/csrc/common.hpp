@@ -96,6 +96,10 @@ struct fgpu_options {  // fgpu_set_option
                                // partition, partial rows folded per vertex (bitpart.hip), 0 = every workgroup gathers from all of X (A/B)
     int expand_xcd_relabel = 1; // ... and the state it reads is laid out hot-first per partition by the hop that produces it (0 = vertex order; A/B)
     int expand_xcd_min_mb = 32; // ... when the bit state holds at least this many MiB (8 L2s of 4 MiB; below that the plain pull)
+    int expand_scan_min = 2048; // fgpu_expand_count: a call with more source rows than this is a WHOLE-FRONTIER call (spgemm.hip
+                               // expand_count_scan): live rows filtered and compacted on the device, cut into passes (0 = never)
+    int expand_scan_rows = 1024; // ... live rows per pass: 1024 = 16 words = one 128-byte line per vertex of the bit state
+    int expand_scan_lanes = 3;  // ... lanes (calling thread + workers, a stream and pool each) the passes are dealt to
     int pinned_results = 1;    // result arrays >= 256 KiB come from the context's pinned-host pool and are filled by DMA (0 = the
                                // caller's allocator / malloc + staged copies, the round-3 path; A/B)
     int pinned_pool_mb = 4096; // pinned blocks kept for reuse after fgpu_free (beyond it they go back to the OS)
@@ -158,6 +162,8 @@ struct fgpu_ctx {
     void* comm = nullptr;               // ncclComm_t
     int comm_rank = 0, comm_nranks = 1;
     std::atomic<uint64_t> dist_self_calls{0};   // forced self collectives issued (dist_force_self)
+    std::atomic<int> scan_active{0};            // lanes of whole-frontier calls running now (expand_count_scan)
+    std::atomic<uint32_t> scan_last_live{0}, scan_last_passes{0};   // the last such call: live source rows, passes ("expand_scan_*")
     std::atomic<uint64_t> expand_launches{0};   // kernels launched by fgpu_expand* (fgpu_get_option "expand_kernel_launches")
     // kernel profiler (measurement hook): off unless fgpu_prof_enable(ctx, 1)
     bool prof_on = false;

@@ -796,6 +796,11 @@ fgpu_info fgpu_get_option(fgpu_ctx* ctx, const char* name, int64_t* value) {
     else if (!strcmp(name, "dist_collective")) *value = ctx->opt.dist_collective;
     else if (!strcmp(name, "expand_kernel_launches")) *value = (int64_t)ctx->expand_launches.load(std::memory_order_relaxed);
     else if (!strcmp(name, "expand_mode")) *value = ctx->opt.expand_mode;
+    else if (!strcmp(name, "expand_scan_min")) *value = ctx->opt.expand_scan_min;
+    else if (!strcmp(name, "expand_scan_rows")) *value = ctx->opt.expand_scan_rows;
+    else if (!strcmp(name, "expand_scan_lanes")) *value = ctx->opt.expand_scan_lanes;
+    else if (!strcmp(name, "expand_scan_last_live")) *value = ctx->scan_last_live.load(std::memory_order_relaxed);
+    else if (!strcmp(name, "expand_scan_last_passes")) *value = ctx->scan_last_passes.load(std::memory_order_relaxed);
     else { set_error("fgpu_get_option: unknown name '%s'", name); return FGPU_INVALID; }
     return FGPU_OK;
 }
@@ -834,6 +839,16 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "expand_xcd_min_mb")) {
         FGPU_REQUIRE(value >= 0 && value <= (1 << 20), FGPU_INVALID, "expand_xcd_min_mb out of range");
         ctx->opt.expand_xcd_min_mb = (int)value;
+    } else if (!strcmp(name, "expand_scan_min")) {
+        FGPU_REQUIRE(value >= 0 && value <= (1ll << 31), FGPU_INVALID, "expand_scan_min out of range");
+        ctx->opt.expand_scan_min = (int)value;
+    } else if (!strcmp(name, "expand_scan_rows")) {
+        FGPU_REQUIRE(value >= 64 && value <= 4096 && (value & (value - 1)) == 0, FGPU_INVALID,
+                     "expand_scan_rows must be a power of two in 64 .. 4096");
+        ctx->opt.expand_scan_rows = (int)value;
+    } else if (!strcmp(name, "expand_scan_lanes")) {
+        FGPU_REQUIRE(value >= 1 && value <= 16, FGPU_INVALID, "expand_scan_lanes must be 1 .. 16");
+        ctx->opt.expand_scan_lanes = (int)value;
     } else if (!strcmp(name, "expand_bits_ratio")) {
         FGPU_REQUIRE(value >= 1 && value <= 1024, FGPU_INVALID, "expand_bits_ratio out of range");
         ctx->opt.expand_bits_ratio = (int)value;

@@ -12,6 +12,8 @@
 // (3) segments with more than one source go through segsort_unique (prims.hip), single-source
 // segments (hop 1 of every traversal) are already sorted and unique, (4) compaction to CSR.
 #include <algorithm>
+#include <string>
+#include <thread>
 
 #include "common.hpp"
 
@@ -105,14 +107,16 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const u32* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void checksum_kernel(CsrView c, u32 nrows, unsigned long long* __restrict__ acc) {
+// (rowmap, nullable: row r of c stands for row rowmap[r] of the call — a pass of a whole-frontier call)
+__global__ __launch_bounds__(256) void checksum_kernel(CsrView c, u32 nrows, unsigned long long* __restrict__ acc,
+                                                       const u32* __restrict__ rowmap) {
     const u32 lane = lane_id();
     const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const u32 nwaves = (gridDim.x * 256) >> 6;
     u64 sum = 0;
     for (u32 r = wave; r < nrows; r += nwaves) {
         const u32 rb = c.rowptr[r], re = c.rowptr[r + 1];
-        const u64 hr = cs_row_hash(r);
+        const u64 hr = cs_row_hash(rowmap ? rowmap[r] : r);
         for (u32 i = rb + lane; i < re; i += 64) sum += hr * cs_dest_hash(c.colidx[i]);
     }
 #pragma unroll
@@ -140,7 +144,7 @@ static fgpu_info mxm_flops(fgpu_ctx* ctx, const fgpu_mat* F, const fgpu_mat* B, 
 // entry-parallel form for results with few, very long rows (dense k-hop results: ~10^6 entries per row):
 // each lane takes one entry and finds its row in the short row-pointer array
 __global__ __launch_bounds__(256) void checksum_entries_kernel(CsrView c, u32 nrows, u32 nnz,
-                                                              unsigned long long* __restrict__ acc) {
+                                                              unsigned long long* __restrict__ acc, const u32* __restrict__ rowmap) {
     u64 sum = 0;
     for (u32 q = blockIdx.x * 256 + threadIdx.x; q < nnz; q += gridDim.x * 256) {
         u32 lo = 0, hi = nrows - 1;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void checksum_entries_kernel(CsrView c, u32 nr
             u32 mid = (lo + hi + 1) >> 1;
             if (c.rowptr[mid] <= q) lo = mid; else hi = mid - 1;
         }
-        sum += cs_row_hash(lo) * cs_dest_hash(c.colidx[q]);
+        sum += cs_row_hash(rowmap ? rowmap[lo] : lo) * cs_dest_hash(c.colidx[q]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
@@ -431,7 +435,8 @@ static fgpu_info first_hop_rows(fgpu_ctx* ctx, const fgpu_mat* f, const fgpu_mat
                                 u64* T0, u64* Tnext, bool* have_next) {
     *have_next = false;
     const u32 k = (u32)f->nrows;
-    if (k == 0 || k > FH_MAX_ROWS || f->is_hyper() || f->nnz > f->nrows || m->nnz == 0 || f->nnz == 0) return FGPU_NO_VALUE;
+    // (k == FH_MAX_ROWS is out: the scan kernel's 1024 threads x 4 rows write rp[0 .. 4095], never rp[4096])
+    if (k == 0 || k >= FH_MAX_ROWS || f->is_hyper() || f->nnz > f->nrows || m->nnz == 0 || f->nnz == 0) return FGPU_NO_VALUE;
     DevBuf<u32> rp, tot;
     DevBuf<u64> tn;
     FGPU_TRY(rp.alloc(ctx, (size_t)k + 1));
@@ -813,6 +818,13 @@ static fgpu_info compact_source_rows(fgpu_ctx* ctx, const fgpu_mat* f, fgpu_mat*
     return FGPU_OK;
 }
 
+// One pass of a whole-frontier call (expand_count_scan below): F is already on the device — one entry per row, no empty
+// rows — and row i of it is row rowmap[i] of the CALL (what the checksum's row hashes need).
+struct ChainSources {
+    fgpu_mat* f = nullptr;           // taken over by the chain
+    DevBuf<u32>* rowmap = nullptr;   // moved into the bit state while the chain runs, handed back when it ends in CSR form
+};
+
 // shared front half of fgpu_expand / fgpu_expand_count: result stays on device
 static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
                                const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
@@ -821,16 +833,23 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                                                             chain ends in bit form */,
                                bool want_checksum = true,
                                BitState* keep_bits = nullptr /* a chain that ends in bit form hands its state over
-                                                                 (*result = nullptr) instead of emitting it */) {
-    FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
+                                                                 (*result = nullptr) instead of emitting it */,
+                               ChainSources* pre = nullptr /* the sources are on the device already (src_ids unused) */) {
     fgpu_mat* f = nullptr;
-    FGPU_TRY(upload_sources(ctx, &f, src_ids, nsrc, m[0]->nrows));
+    if (pre) {
+        f = pre->f;
+        pre->f = nullptr;
+    } else {
+        FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
+        FGPU_TRY(upload_sources(ctx, &f, src_ids, nsrc, m[0]->nrows));
+    }
     // Hops run on the sorted-CSR products until a hop's gather volume T makes the bit-parallel form
     // cheaper (bitexpand.hip): it costs one pass over A' gathering max(64, 8 W) bytes per entry,
     // whatever T is; the CSR product moves ~T entries several times.  Once dense, stay dense.
     const int mode = ctx->opt.expand_mode;
     bool bits = false;
     BitState bs;
+    if (pre && pre->rowmap) bs.rowmap = std::move(*pre->rowmap);
     u64 T_known = 0;                      // traversed edges of f over T_for, when an earlier step already summed them
     const fgpu_mat *T_for = nullptr, *T_f = nullptr;
     for (int h = 0; h < nhops; ++h) {
@@ -886,7 +905,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
                 // 41 ps-per-entry pull and kept RMAT-26 batches in an 8.7 ms sort.)
                 if (mode == 0) go = T * ctx->opt.expand_bits_ratio > mh->nnz;
             }
-            if (go && ctx->opt.expand_compact) {
+            if (go && ctx->opt.expand_compact && !pre) {
                 // the empty source rows stay behind (compact_source_rows above); bp_to_csr finds the way back
                 fgpu_mat* fc = nullptr;
                 const u32 k_full = (u32)f->nrows;
@@ -987,6 +1006,7 @@ static fgpu_info expand_device(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t 
         if (i != FGPU_OK) return i;
         f = c;
     }
+    if (pre && pre->rowmap) *pre->rowmap = std::move(bs.rowmap);
     *result = f;
     return FGPU_OK;
 }
@@ -1129,6 +1149,189 @@ __global__ __launch_bounds__(256) void probe_csr_rows_kernel(CsrView f, CsrView 
     }
 }
 
+// nnz (+ checksum) of a chain that ended in CSR form; rowmap (nullable) = the call's row of every row of r
+static fgpu_info count_csr_result(fgpu_ctx* ctx, const fgpu_mat* r, const u32* rowmap, u64* out_nnz, u64* checksum) {
+    *out_nnz = r->nnz;
+    if (!checksum) return FGPU_OK;
+    *checksum = 0;
+    if (!r->nnz) return FGPU_OK;
+    DevBuf<u64> acc;
+    FGPU_TRY(acc.alloc(ctx, 1));
+    FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream()));
+    if (r->nnz / r->nrows >= 1024 && r->nnz < 0xFFFFFFFFull) {
+        u32 grid = cdiv(r->nnz, 256);
+        if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
+        hipLaunchKernelGGL(checksum_entries_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(r),
+                           (u32)r->nrows, (u32)r->nnz, (unsigned long long*)acc.p, rowmap);
+    } else {
+        u32 grid = cdiv(r->nrows, 4);
+        if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
+        hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(r),
+                           (u32)r->nrows, (unsigned long long*)acc.p, rowmap);
+    }
+    FGPU_HIP(hipGetLastError());
+    return read_u64(ctx, acc.p, checksum);
+}
+
+// ---- whole-frontier calls (SURVEY.md §7 "hard part 1", §8d) ---------------------------------------------------------------
+// The reference hands CondTraverse at most 1024 rows per mxm (BATCH_SIZE, graph/src/runtime/batch.rs:81; the loop of
+// cond_traverse.rs:452-751) — at that size a launch of this chip is latency, and half of a label scan's sources have no
+// out-edge at all (an R-MAT graph: 525 of the first 1024 :P sources), so a 1024-source batch fills 64 of the 128 bytes of
+// the row the count hop gathers per entry of A' and a missed gather costs a whole 128-byte line either way.
+// fgpu_expand_count therefore takes ALL sources of a scan (10^5 - 10^6 rows) in one call:
+//   1. the sources are filtered on the device: a row takes part when its source has an entry in m[0] or dp[0] (every other
+//      row's result is empty whatever follows), and the live rows are compacted — (source id, row of the call) pairs;
+//   2. the live rows are cut into PASSES of `expand_scan_rows` rows (1024: 16 words = one 128-byte line per vertex) — the
+//      width is picked from the LIVE rows, not from the caller's batch size;
+//   3. the passes are dealt to `expand_scan_lanes` lanes of the context (the calling thread + worker threads, each on its own
+//      stream and pool: a chain makes ~10 host-side decisions per pass — product sizes, the CSR -> bit-form switch, the
+//      counts — during which ITS stream idles), so one pass's launch-bound head and tail run under another's count hop;
+//   4. rows keep their identity: bit i of a pass stands for row rowmap[i] of the call, which is what the checksum hashes.
+// The sums are order-independent (64-bit wrap-around adds), so the result equals the 1024-row calls' sums bit for bit.
+__global__ void scan_live_kernel(const u32* __restrict__ ids, u32 n, CsrView m0, CsrView dp0, u32 has_dp, u32* __restrict__ flag) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    u32 live = 0;
+    if (i < n && ids[i] != 0xFFFFFFFFu) {
+        u32 b, e;
+        row_range(m0, ids[i], b, e);
+        live = e > b;
+        if (!live && has_dp) { row_range(dp0, ids[i], b, e); live = e > b; }
+    }
+    flag[i] = live;
+}
+__global__ void scan_compact_kernel(const u32* __restrict__ ids, const u32* __restrict__ flag, const u32* __restrict__ pos, u32 n,
+                                    u32* __restrict__ lid, u32* __restrict__ lrow) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) { lid[pos[i]] = ids[i]; lrow[pos[i]] = i; }
+}
+__global__ void scan_pass_kernel(const u32* __restrict__ lid, const u32* __restrict__ lrow, u32 first, u32 k, u32* __restrict__ rowptr,
+                                 u32* __restrict__ colidx, u32* __restrict__ rowmap) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= k) rowptr[i] = i;
+    if (i < k) { colidx[i] = lid[first + i]; rowmap[i] = lrow[first + i]; }
+}
+
+struct ScanJob {
+    fgpu_ctx* ctx;
+    const u32 *lid, *lrow;
+    u32 nlive, pass_rows, npasses;
+    const fgpu_mat* const* m; const fgpu_mat* const* dp; const fgpu_mat* const* dm;
+    int nhops;
+    const uint64_t* label;
+    bool want_cs, want_flops;
+    std::atomic<u32> next{0};
+    std::atomic<bool> failed{false};
+    std::mutex mu;                       // the sums and the first error
+    u64 nnz = 0, cs = 0, flops = 0;
+    fgpu_info err = FGPU_OK;
+    std::string msg;
+};
+
+static fgpu_info scan_one_pass(ScanJob& j, u32 p, u64* nnz, u64* cs, u64* fl) {
+    fgpu_ctx* ctx = j.ctx;
+    const u32 first = p * j.pass_rows;
+    const u32 k = std::min(j.pass_rows, j.nlive - first);
+    fgpu_mat* f = nullptr;
+    DevBuf<u32> rm;
+    FGPU_TRY(rm.alloc(ctx, k));
+    FGPU_TRY(mat_alloc(ctx, &f, k, j.m[0]->nrows, k, false, 0, false));
+    hipLaunchKernelGGL(scan_pass_kernel, dim3(cdiv((u64)k + 1, 256)), dim3(256), 0, ctx->stream(), j.lid, j.lrow, first, k, f->rowptr,
+                       f->colidx, rm.p);
+    if (hipGetLastError() != hipSuccess) { mat_release(f); set_error("expand scan: device call failed"); return FGPU_DEVICE; }
+    ChainSources pre;
+    pre.f = f;
+    pre.rowmap = &rm;
+    fgpu_mat* r = nullptr;
+    u64 cnt[2] = {0, 0};
+    *fl = 0;
+    FGPU_TRY(expand_device(ctx, nullptr, k, j.m, j.dp, j.dm, j.nhops, j.label, &r, j.want_flops ? fl : nullptr, cnt, j.want_cs, nullptr, &pre));
+    if (!r) { *nnz = cnt[0]; *cs = cnt[1]; return FGPU_OK; }
+    const fgpu_info i = count_csr_result(ctx, r, rm.p, nnz, j.want_cs ? cs : nullptr);
+    mat_release(r);
+    return i;
+}
+
+static void scan_worker(ScanJob* j) {
+    u64 nnz = 0, cs = 0, flops = 0;
+    fgpu_info err = FGPU_OK;
+    for (;;) {
+        if (j->failed.load(std::memory_order_relaxed)) break;
+        const u32 p = j->next.fetch_add(1, std::memory_order_relaxed);
+        if (p >= j->npasses) break;
+        u64 a = 0, b = 0, c = 0;
+        err = scan_one_pass(*j, p, &a, &b, &c);
+        if (err != FGPU_OK) { j->failed.store(true); break; }
+        nnz += a; cs += b; flops += c;
+    }
+    // (a worker thread's stream has nothing pending here: every pass ends with the read-back of its sums)
+    std::lock_guard<std::mutex> g(j->mu);
+    j->nnz += nnz; j->cs += cs; j->flops += flops;
+    if (err != FGPU_OK && j->err == FGPU_OK) { j->err = err; j->msg = get_error(); }
+}
+
+static fgpu_info expand_count_scan(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                                   const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                                   const uint64_t* dst_label_bitmap, uint64_t* out_nnz, uint64_t* checksum, uint64_t* flops) {
+    FGPU_TRY(check_hops(m, dp, dm, nhops, nsrc));
+    const u64 ncols0 = m[0]->nrows;
+    const u32 n = (u32)nsrc;
+    std::vector<u32> ids(n);
+    for (u32 i = 0; i < n; ++i) {
+        if (src_ids[i] == UINT64_MAX) { ids[i] = 0xFFFFFFFFu; continue; }
+        FGPU_REQUIRE(src_ids[i] < ncols0, FGPU_OUT_OF_BOUNDS, "expand: source %u = %llu >= %llu", i,
+                     (unsigned long long)src_ids[i], (unsigned long long)ncols0);
+        ids[i] = (u32)src_ids[i];
+    }
+    DevBuf<u32> dids, flag, pos, lid, lrow;
+    FGPU_TRY(dids.alloc(ctx, n));
+    FGPU_TRY(flag.alloc(ctx, (size_t)n + 1));
+    FGPU_TRY(pos.alloc(ctx, (size_t)n + 1));
+    FGPU_TRY(ctx->h2d(dids.p, ids.data(), (size_t)n * sizeof(u32)));
+    const fgpu_mat* dp0 = dp && dp[0] && dp[0]->nnz ? dp[0] : nullptr;
+    hipLaunchKernelGGL(scan_live_kernel, dim3(cdiv((u64)n + 1, 256)), dim3(256), 0, ctx->stream(), (const u32*)dids.p, n, view_of(m[0]),
+                       dp0 ? view_of(dp0) : view_of(m[0]), dp0 ? 1u : 0u, flag.p);
+    FGPU_HIP(hipGetLastError());
+    FGPU_TRY(scan_u32(ctx, flag.p, pos.p, (u64)n + 1, nullptr));
+    u32 nlive = 0;
+    FGPU_TRY(read_u32(ctx, pos.p + n, &nlive));
+    *out_nnz = 0;
+    if (checksum) *checksum = 0;
+    ctx->scan_last_live.store(nlive, std::memory_order_relaxed);
+    ctx->scan_last_passes.store(0, std::memory_order_relaxed);
+    if (nlive == 0) return FGPU_OK;
+    FGPU_TRY(lid.alloc(ctx, nlive));
+    FGPU_TRY(lrow.alloc(ctx, nlive));
+    hipLaunchKernelGGL(scan_compact_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream(), (const u32*)dids.p, (const u32*)flag.p,
+                       (const u32*)pos.p, n, lid.p, lrow.p);
+    FGPU_HIP(hipGetLastError());
+    FGPU_HIP(hipStreamSynchronize(ctx->stream()));           // the other lanes read the live list
+    ScanJob j;
+    j.ctx = ctx; j.lid = lid.p; j.lrow = lrow.p; j.nlive = nlive;
+    j.pass_rows = (u32)ctx->opt.expand_scan_rows;
+    j.npasses = cdiv(nlive, j.pass_rows);
+    j.m = m; j.dp = dp; j.dm = dm; j.nhops = nhops; j.label = dst_label_bitmap;
+    j.want_cs = checksum != nullptr; j.want_flops = flops != nullptr;
+    ctx->scan_last_passes.store(j.npasses, std::memory_order_relaxed);
+    u32 lanes = (u32)ctx->opt.expand_scan_lanes;
+    if (lanes > j.npasses) lanes = j.npasses;
+    if (lanes < 1) lanes = 1;
+    std::vector<std::thread> th;
+    th.reserve(lanes);
+    ctx->scan_active.fetch_add((int)lanes, std::memory_order_relaxed);
+    for (u32 t = 1; t < lanes; ++t) {
+        try { th.emplace_back(scan_worker, &j); } catch (...) { break; }   // (fewer lanes: the passes are pulled, not assigned)
+    }
+    scan_worker(&j);
+    for (auto& t : th) t.join();
+    ctx->scan_active.fetch_sub((int)lanes, std::memory_order_relaxed);
+    if (j.err != FGPU_OK) { set_error("%s", j.msg.c_str()); return j.err; }
+    *out_nnz = j.nnz;
+    if (checksum) *checksum = j.cs;
+    if (flops) *flops = j.flops;
+    return FGPU_OK;
+}
+
 extern "C" {
 
 static fgpu_info mxm_impl(fgpu_ctx* ctx, fgpu_mat** c, const fgpu_mat* f, const fgpu_mat* b) {
@@ -1176,6 +1379,9 @@ fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
     FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
     struct Rel { fgpu_mat* r; ~Rel() { if (r) mat_release(r); } } rel{r};
     if (nsrc == 0 || r->nnz == 0) return FGPU_OK;
+    // (the kernels below index the result's row pointers densely, nsrc + 1 of them)
+    FGPU_REQUIRE(!r->is_hyper() && r->nrows == nsrc, FGPU_INVALID, "fgpu_expand_pairs: the chain's result is not a dense-row CSR of %llu rows",
+                 (unsigned long long)nsrc);
     hipStream_t st = ctx->stream();
     const u32 k = (u32)nsrc;
     DevBuf<u32> pin, len, pos, newptr, total;
@@ -1465,6 +1671,8 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
     FGPU_REQUIRE(ctx && out_nnz, FGPU_NULL_POINTER, "fgpu_expand_count: NULL argument");
     FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_count: NULL src_ids");
     if (flops) *flops = 0;
+    if (ctx->opt.expand_scan_min > 0 && nsrc > (u64)ctx->opt.expand_scan_min && ctx->opt.expand_mode != 1)
+        return expand_count_scan(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, out_nnz, checksum, flops);
     fgpu_mat* r = nullptr;
     u64 cnt[2] = {0, 0};
     FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops, cnt, checksum != nullptr));
@@ -1473,30 +1681,7 @@ fgpu_info fgpu_expand_count(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
         if (checksum) *checksum = cnt[1];
         return FGPU_OK;
     }
-    *out_nnz = r->nnz;
-    fgpu_info i = FGPU_OK;
-    if (checksum) {
-        *checksum = 0;
-        if (r->nnz) {
-            DevBuf<u64> acc;
-            i = acc.alloc(ctx, 1);
-            if (i == FGPU_OK) {
-                (void)hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream());
-                if (r->nnz / r->nrows >= 1024 && r->nnz < 0xFFFFFFFFull) {
-                    u32 grid = cdiv(r->nnz, 256);
-                    if (grid > (u32)ctx->cus * 32) grid = ctx->cus * 32;
-                    hipLaunchKernelGGL(checksum_entries_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(r),
-                                       (u32)r->nrows, (u32)r->nnz, (unsigned long long*)acc.p);
-                } else {
-                    u32 grid = cdiv(r->nrows, 4);
-                    if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-                    hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, ctx->stream(), view_of(r),
-                                       (u32)r->nrows, (unsigned long long*)acc.p);
-                }
-                i = read_u64(ctx, acc.p, checksum);
-            }
-        }
-    }
+    const fgpu_info i = count_csr_result(ctx, r, nullptr, out_nnz, checksum);
     mat_release(r);
     return i;
 }
