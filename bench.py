@@ -4,26 +4,39 @@ fraction of the HBM roofline of the dominant kernel.
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE 1024-source batch of `MATCH (a:P)-->()-->()-->(c)` through the device core of
-CondTraverseOp::expand_batch (cond_traverse.rs:452-751: F = build(sources); F = delta_lmxm(F; hop) for each of the three
-hops, matrix.rs:1317-1402) = one fgpu_expand_count call (count + order-independent checksum of the (row, dest) result,
-H2D of the sources and D2H of the result included, adjacency and its cached transpose resident in HBM).  The graph is
-R-MAT scale 22 (edge factor 16, directed, deduplicated; `--scale` changes it), sources = the synthetic label :P
-(hash(id) % 16 == 0) in ascending id order, clean layers.  W untimed batches, then exactly K timed ones between two
-fences (barrier + torch.cuda.synchronize()); `value` = sum over the K steps (and over the ranks) of the traversed edges
-(sum over hops of flops) / max-over-ranks wall time.
+A "step" is ONE label scan of `MATCH (a:L)-->()-->()-->(c)` through the device core of CondTraverseOp::expand_batch
+(cond_traverse.rs:452-751: F = build(sources); F = delta_lmxm(F; hop) for each of the three hops, matrix.rs:1317-1402) as
+ONE WHOLE-FRONTIER call: every source of the label (~N/16 vertices: 261 6xx rows at scale 22) goes into a single
+fgpu_expand_count (count + order-independent checksum of the (row, dest) result; H2D of the sources and D2H of the sums
+included, adjacency and its cached transpose resident in HBM).  SURVEY.md §7 "hard part 1" / §8d define the k-hop measurement
+this way — "all active sources of a scan" — and name the reference's 1024-row child batch (batch.rs:81) as the thing NOT to
+inherit; rounds 1-5 still drove the engine one 1024-row call at a time (kept as `secondary.khop22.batch1024_*`).  Inside the
+call the library drops the rows whose source has no out-edge (half of an R-MAT label), cuts the live rows into passes of 1024
+(one 128-byte line of the bit state per vertex) and deals the passes to 3 lanes (streams) of the context (spgemm.hip
+expand_count_scan; `config` states sources per call, live rows, pass width, passes and lanes).  The graph is R-MAT scale 22
+(edge factor 16, directed, deduplicated; `--scale` changes it); the labels are the 16 residue classes of hash(id) % 16 —
+step i scans class i mod 16, class 0 = the label :P of SURVEY.md §8d first — clean layers.  W untimed steps, then exactly K
+timed ones between two fences (barrier + torch.cuda.synchronize()); `value` = sum over the K steps (and over the ranks) of
+the traversed edges (sum over hops of flops) / max-over-ranks wall time.
 
-N > 1: the source batches are sharded round-robin over the ranks (rank r takes batches r, r + N, ...), the adjacency is
+READ `value` WITH `roofline.hop.frac`.  "TEPS" here is ALGEBRAIC: the edges the reference's GrB_mxm chain would traverse
+(sum over hops of flops, verified against the oracle), not edges this engine touches one by one — a bit-parallel pull over A'
+serves ~100 counted edges per physical row gather, so TEPS x 4 bytes exceeds the HBM peak by construction.  How well the
+hardware is used is what `roofline` says: the dominant kernel's (and its hop's) compulsory bytes over its measured time.
+
+N > 1: the label scans are dealt round-robin over the ranks (rank r scans classes r, r + N, ...), the adjacency is
 replicated, no collective on the data path (k-hop MATCH shards its source rows) — weak scaling.  The
 RMAT-26 BFS over column slabs with one RCCL frontier all-gather-v per level (BASELINE config 4) runs as a secondary leg
 of the same line (`secondary.bfs26_dist`; its single-GPU base point is `secondary.bfs26` of the N = 1 line).
 
 Rank 0 prints TWO lines: `DETAIL {...}` (every leg in full; also written to bench_detail.json) and then, LAST, the
 compact bench line (< 4 KB, asserted): metric / value / config of the headline, `roofline` of its dominant kernel
-(bp_pull_kernel<dense, count>: HIP-event average over the timed batches replayed, algorithmic bytes per launch, live PMC
-traffic), `cpu_baseline` (the oracle's OpenMP Gustavson chain on this box's host cores, bounded sample, quartiles),
-in-run `parity` against the oracle, and `secondary`: numbers only for BFS 22 / 26, boolean SpMV 22 / 24 / 26, k-hop
-24 / 26, dirty layers, the materialised form, the host-array entries and the config-5 stand-in.
+(xp_stream_kernel: HIP-event average over one scan replayed, compulsory bytes per launch, live PMC traffic; `hop` = the
+count hop, stream + fold, against the same bytes), `cpu_baseline` (the oracle's OpenMP Gustavson chain on this box's host
+cores, bounded sample, quartiles; `probe` = what was looked for of the reference's own CPU library; `scipy` = a second point),
+in-run `parity` against the oracle (first 1024 rows live, the whole :P scan against a committed oracle run), and
+`secondary`: numbers only for BFS 22 / 26, boolean SpMV 22 / 24 / 26, k-hop 24 / 26, dirty layers, the materialised form,
+the host-array entries and the config-5 stand-in.
 """
 from __future__ import annotations
 
@@ -237,10 +250,11 @@ def mix64_np(z):
     return z ^ (z >> np.uint64(31))
 
 
-def p_label_sources(n):
-    """The synthetic label :P of SURVEY.md §8d: ids with hash(id) % 16 == 0 (hash = splitmix64 finaliser), ascending."""
+def p_label_sources(n, cls=0):
+    """The synthetic label :P of SURVEY.md §8d: ids with hash(id) % 16 == 0 (hash = splitmix64 finaliser), ascending.
+    `cls` = the residue: 16 disjoint labels of the same size (the timed steps of the headline walk them, :P first)."""
     ids = np.arange(n, dtype=np.uint64)
-    return ids[mix64_np(ids) % np.uint64(16) == 0]
+    return ids[mix64_np(ids) % np.uint64(16) == np.uint64(cls)]
 
 
 def khop_inputs(ctx, scale, edge_factor, want_host=False):
@@ -292,7 +306,7 @@ def cpu_threads():
     return max(1, min(ncpu, int(quota))) if quota else ncpu, ncpu, quota
 
 
-def khop_leg(ctx, engine, args, scale, nb_want, graph=None, parity_rows=1024):
+def khop_leg(ctx, engine, args, scale, nb_want, graph=None, parity_rows=1024, scan_sources=8192):
     """BASELINE config 3's shape at one scale: RMAT-<scale> 3-hop MATCH (a:P)-->()-->()-->(c) as a masked GrB_mxm chain =
     the device core of CondTraverseOp::expand_batch (cond_traverse.rs:452-751: F = build(sources); F = delta_lmxm(F; hop)
     per hop, matrix.rs:1317-1402), batches of 1024 :P sources, result = count + order-independent checksum on the device
@@ -339,11 +353,12 @@ def khop_leg(ctx, engine, args, scale, nb_want, graph=None, parity_rows=1024):
         for b in batches:
             engine.expand_count(ctx, b, *layers, want_checksum=False)
         dt_count = time.perf_counter() - t1
-        # kernel table: the same calls again with HIP events around every modelled launch
+        # kernel table: ONE whole-frontier call over `scan_sources` rows (the form the line quotes: 1024 live rows per pass,
+        # 128-byte rows of the bit state) with HIP events around every modelled launch
+        engine.expand_count(ctx, srcs[:max(min(len(srcs), scan_sources), B)], *layers)
         ctx.prof_enable(True)
         t1 = time.perf_counter()
-        for b in batches:
-            engine.expand_count(ctx, b, *layers)
+        engine.expand_count(ctx, srcs[:max(min(len(srcs), scan_sources), B)], *layers)
         dt_prof = time.perf_counter() - t1
         prof = ctx.prof_read()
         ctx.prof_enable(False)
@@ -362,7 +377,34 @@ def khop_leg(ctx, engine, args, scale, nb_want, graph=None, parity_rows=1024):
                      "hop_nnz_per_batch": [h // nlv for h in hop_tot],
                      "spgemm_form_alg_bytes_per_batch": int(alg // nlv),
                      "count_only": {"ms_per_batch": round(dt_count / nb * 1e3, 3), "TEPS": round(tot_f / dt_count, 1)},
-                     "ms_per_batch_with_kernel_events": round(dt_prof / nb * 1e3, 3)}
+                     "ms_scan_call_with_kernel_events": round(dt_prof * 1e3, 3)}
+    # ---- the same label as ONE whole-frontier call (the headline's form): `scan_sources` sources, clean and dirty -------
+    S = min(len(srcs), scan_sources)
+    if S > B:
+        sc = {"sources": int(S)}
+        for name, layers in (("clean", ([A] * hops, None, None)), ("dirty", ([A] * hops, [dp] * hops, [dm] * hops))):
+            engine.expand_count(ctx, srcs[:S], *layers)                 # warm: the worker lanes' pools
+            ctx.sync()
+            t1 = time.perf_counter()
+            r = engine.expand_count(ctx, srcs[:S], *layers)
+            d = time.perf_counter() - t1
+            sc[name] = {"ms_per_call": round(d * 1e3, 3), "TEPS": round(r[2] / d, 1), "flops": int(r[2]), "out_nnz": int(r[0]),
+                        "ms_per_1024_sources": round(d * 1e3 / (S / 1024), 4)}
+            if name == "clean":
+                sc["live_sources"] = ctx.get_option("expand_scan_last_live")
+                sc["passes"] = ctx.get_option("expand_scan_last_passes")
+            # the whole-frontier path on batch 0 alone (forced: the call is below the switch-over size) must give the
+            # oracle-checked triple of the 1024-row call, checksum included (row i of the call = row i of the batch)
+            smin = ctx.get_option("expand_scan_min")
+            try:
+                ctx.set_option("expand_scan_min", 1)
+                forced = engine.expand_count(ctx, batches[0], *layers)
+            finally:
+                ctx.set_option("expand_scan_min", smin)
+            sc[name]["batch0_through_the_scan_path_ok"] = bool(tuple(forced) == tuple(batch0[name]))
+            if tuple(forced) != tuple(batch0[name]):
+                raise SystemExit(f"bench.py: scale {scale} {name}: batch 0 through the whole-frontier path {forced} != {batch0[name]}")
+        out["scan"] = sc
     out["note"] = ("spgemm_form_alg_bytes follows SURVEY.md §8d's SpGEMM row (4 B per traversed edge + F / C / row-pointer "
                    "terms): what a gather-and-sort product of the same chain would move.  Dense hops run in bit form (one "
                    "pass over A' per hop whatever the traversed-edge count), so no fraction of peak is quoted against that "
@@ -381,7 +423,12 @@ def khop_leg(ctx, engine, args, scale, nb_want, graph=None, parity_rows=1024):
                            "alg_bytes_per_launch": int(d["alg_bytes"] / d["launches"]),
                            "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches": d["launches"],
                            "share_of_kernel_time": round(d["ms"] / max(sum(k["ms"] for k in kern), 1e-9), 3),
-                           "timing": "HIP events around each launch (fgpu_prof_*), clean layers, the timed batches replayed"}
+                           "timing": "HIP events around each launch (fgpu_prof_*), clean layers, one whole-frontier call replayed"}
+        byname = {k["kernel"]: k for k in kern}
+        if d["kernel"] == "xp_stream_kernel" and "xp_fold_kernel" in byname:
+            hop_ms = d["ms"] + byname["xp_fold_kernel"]["ms"]
+            out["roofline"]["hop_frac"] = round(d["alg_bytes"] / max(hop_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)
+            out["roofline"]["hop_us"] = round(hop_ms / d["launches"] * 1e3, 2)
     # ---- parity of what was just timed, and the CPU baseline from the same oracle run -------------------------
     if not args.no_parity and host is not None:
         import oracle
@@ -613,13 +660,15 @@ def pmc_child(args):
     scale = args.scale or 22
     A, dp, dm, _ = khop_inputs(ctx, scale, args.edge_factor)
     srcs = p_label_sources(A.nrows)
-    for i in range(3):
+    # the k-hop kernels in the form the line quotes: whole-frontier calls (passes of 1024 live rows, 128-byte rows of the state)
+    S = 6144 if scale <= 24 else 4096
+    ctx.set_option("expand_scan_lanes", 1)                     # (one stream: the counters are read per dispatch)
+    engine.expand_count(ctx, srcs[:S], [A] * 3)
+    engine.expand_count(ctx, srcs[:S], [A] * 3, [dp] * 3, [dm] * 3)
+    for i in range(1, 3):
         b = srcs[i * 1024:(i + 1) * 1024]
-        engine.expand_count(ctx, b, [A] * 3)
-        if i:
-            engine.expand_count(ctx, b, [A] * 3, [dp] * 3, [dm] * 3)
-            m_, _ = engine.expand_mat(ctx, b, [A] * 2)          # the emitting path (bp_rows_kernel count / emit)
-            m_.free()
+        m_, _ = engine.expand_mat(ctx, b, [A] * 2)              # the emitting path (bp_rows_kernel count / emit)
+        m_.free()
     if not args.no_bfs:
         At = A.transpose()
         roots = pick_roots(A, 8)
@@ -648,8 +697,9 @@ def _kernel_rows(prof, top=10):
 
 
 def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, reduce_sum):
-    """THE timed region of the bench line (module docstring): K 1024-source batches of the 3-hop MATCH, clean layers,
-    fgpu_expand_count with the checksum, W untimed batches before.  Returns (line fields, detail, graph tuple)."""
+    """THE timed region of the bench line (module docstring): K WHOLE-FRONTIER calls of the 3-hop MATCH — one
+    fgpu_expand_count per label scan, all ~N/16 sources of the label in the call, clean layers, count + checksum — W untimed
+    calls before.  Returns (line fields, detail, graph tuple)."""
     hops, B = 3, 1024
     t0 = time.time()
     want_host = rank == 0 and not args.no_parity
@@ -657,32 +707,36 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
     ctx.sync()
     t_build = time.time() - t0
     n, nnz = A.nrows, A.nvals
-    srcs = p_label_sources(n)
+    srcs = p_label_sources(n)                       # label :P (class 0)
     nb_all = len(srcs) // B
+    labels = {0: srcs}
 
-    def batch(i):                                   # this rank's i-th batch: round-robin over the ranks, cycling the :P set
-        j = (rank + i * world) % nb_all
-        return srcs[j * B:(j + 1) * B]
+    def scan(i):                                    # this rank's i-th label scan: classes round-robin over the ranks, :P first
+        c = (rank + i * world) % 16
+        if c not in labels:
+            labels[c] = p_label_sources(n, c)
+        return labels[c]
     clean = ([A] * hops, None, None)
     dirty = ([A] * hops, [dp] * hops, [dm] * hops)
     # snapshot preparation (untimed, once per matrix version like the upload itself): the cached transpose of A, the pull
     # item lists and the device pools are built by the first call that needs them
     t_prep = time.perf_counter()
-    engine.expand_count(ctx, batch(0), *clean)
+    batch0 = srcs[:B]
+    first = engine.expand_count(ctx, batch0, *clean)      # (also the reference's own unit: one 1024-row child batch)
     ctx.sync()
     t_prep = time.perf_counter() - t_prep                # transpose of A, pull item lists, the partitioned layout of the count hop, pools
-    for i in range(args.warmup):
-        engine.expand_count(ctx, batch(i), *clean)
-    timed = [batch(i) for i in range(args.steps)]
+    for i in range(max(args.warmup, 1)):                 # (>= 1: the worker lanes' pools are grown by the first whole-frontier call)
+        engine.expand_count(ctx, scan(i), *clean)
+    timed = [scan(i) for i in range(args.steps)]
     fence()
     t1 = time.perf_counter()
     tot_f = tot_n = 0
     cs = 0
-    first = None
+    scan0 = None
     for b in timed:
         nn, c, f = engine.expand_count(ctx, b, *clean)
-        if first is None:
-            first = (nn, c, f)
+        if scan0 is None:
+            scan0 = (nn, c, f)
         tot_n += nn
         tot_f += f
         cs = (cs + c) & 0xFFFFFFFFFFFFFFFF
@@ -691,112 +745,86 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
     flops_all = reduce_sum(tot_f)
     nnz_all = reduce_sum(tot_n)
     line = {"value": round(flops_all / dt, 1), "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4)}
+    scan_cfg = {"sources_per_call": int(len(timed[0])) if timed else int(len(srcs)),
+                "live_sources_last_call": ctx.get_option("expand_scan_last_live"), "passes_last_call": ctx.get_option("expand_scan_last_passes"),
+                "pass_rows": ctx.get_option("expand_scan_rows"), "lanes": ctx.get_option("expand_scan_lanes")}
     # what a NEW matrix version costs once the pools are warm (t_prep above also grew them): a second snapshot of the same
     # matrix (transposed twice on the device: no cache is shared with A), its first batch against a steady one
     snap_prep = None
     if rank == 0 and scale <= 24:
         try:
+            t_ = time.perf_counter()
+            engine.expand_count(ctx, batch0, *clean)
+            ctx.sync()
+            steady = time.perf_counter() - t_
             At = A.transpose()
             A2 = At.transpose()
             At.free()
             ctx.sync()
             t_ = time.perf_counter()
-            r2 = engine.expand_count(ctx, timed[0], [A2] * hops, None, None)
+            r2 = engine.expand_count(ctx, batch0, [A2] * hops, None, None)
             ctx.sync()
             t_ = time.perf_counter() - t_
             if r2 == first:
-                snap_prep = round(max(t_ - dt / max(args.steps, 1), 0.0) * 1e3, 2)
+                snap_prep = round(max(t_ - steady, 0.0) * 1e3, 2)
             A2.free()
         except Exception as e:                        # a report field, never the reason the bench fails
             snap_prep = None
     det = {"workload": f"RMAT scale-{scale} {hops}-hop MATCH (a:P)-->()-->()-->(c), CondTraverse expand_batch core (masked "
-                       f"GrB_mxm ANY_PAIR chain), sources = label :P (hash(id) % 16 == 0) in batches of {B}, clean layers",
-           "scale": scale, "vertices": int(n), "edges": int(nnz), "hops": hops, "batch_rows": B,
-           "label_P_sources": int(len(srcs)), "batches_in_P": nb_all, "build_seconds": round(t_build, 2),
+                       f"GrB_mxm ANY_PAIR chain): ONE fgpu_expand_count call per label scan — every source of the label "
+                       f"(hash(id) % 16 == class; :P = class 0 first), live rows filtered on the device, passes of "
+                       f"{scan_cfg['pass_rows']} live rows on {scan_cfg['lanes']} lanes; clean layers",
+           "scale": scale, "vertices": int(n), "edges": int(nnz), "hops": hops, "scan": scan_cfg,
+           "label_P_sources": int(len(srcs)), "build_seconds": round(t_build, 2),
            "prep_ms": round(t_prep * 1e3, 2), "snapshot_prep_ms": snap_prep,
            "nnz_dp": int(dp.nvals), "nnz_dm": int(dm.nvals),
            "timed": {"steps": args.steps, "warmup": args.warmup, "seconds": round(dt, 5), "flops": int(flops_all),
-                     "out_nnz": int(nnz_all), "rank0_checksum": f"{cs:016x}", "TEPS": line["value"]}}
+                     "out_nnz": int(nnz_all), "rank0_checksum": f"{cs:016x}", "TEPS": line["value"],
+                     "step0": {"nnz": int(scan0[0]), "checksum": f"{scan0[1]:016x}", "flops": int(scan0[2])} if scan0 else None}}
     if rank != 0:
-        return line, det, (A, dp, dm, host, timed, None)
-    # ---- the same batches again, untimed legs: count only, dirty layers, kernel table ------------------------------
-    ks = timed[:min(len(timed), 32)] or [batch(0)]
+        return line, det, (A, dp, dm, host, batch0, None)
+    # ---- untimed legs over the same label: the calls it replaces, count only, dirty layers, lanes, kernel table -------
+    P = srcs
 
-    def run(bl, layers, cs_=True):
+    def run(src, layers, cs_=True, reps=1):
+        engine.expand_count(ctx, src[:4096], *layers, want_checksum=cs_)
         ctx.sync()
-        t = time.perf_counter()
-        fl = 0
-        for b in bl:
-            fl += engine.expand_count(ctx, b, *layers, want_checksum=cs_)[2]
-        d = time.perf_counter() - t
-        return {"ms_per_batch": round(d / len(bl) * 1e3, 3), "TEPS": round(fl / d, 1), "batches": len(bl)}
-    det["count_only"] = run(ks, clean, False)
-
-    def run_lanes(bl, layers, lanes):
-        """The same batches from `lanes` query threads at once — the reference's worker pool (threadpool.rs:89-128) calling
-        into one context, every thread on its own lane (stream + scratch): one batch's small launches and read-backs run
-        under the other's pulls."""
-        import threading
-        from concurrent.futures import ThreadPoolExecutor
-        gate = threading.Barrier(lanes)
-
-        def warm(b):
-            gate.wait()                              # one warm batch on EVERY worker thread: its lane's pools exist afterwards
-            return engine.expand_count(ctx, b, *layers)
-        with ThreadPoolExecutor(lanes) as ex:
-            list(ex.map(warm, [bl[i % len(bl)] for i in range(lanes)]))   # exactly `lanes` warm tasks: the gate waits for that many
+        best = None
+        for _ in range(reps):
             t = time.perf_counter()
-            res = list(ex.map(lambda b: engine.expand_count(ctx, b, *layers), bl))
+            r = engine.expand_count(ctx, src, *layers, want_checksum=cs_)
             d = time.perf_counter() - t
-        fl = sum(r[2] for r in res)
-        cs2 = 0
-        for r in res:
-            cs2 = (cs2 + r[1]) & 0xFFFFFFFFFFFFFFFF
-        return {"lanes": lanes, "ms_per_batch": round(d / len(bl) * 1e3, 3), "TEPS": round(fl / d, 1), "batches": len(bl),
-                "checksum": f"{cs2:016x}"}
-    # wider batches: half of a :P batch's sources have no out-edges and are compacted out of the bit state, so 2048 sources
-    # fill the 128-byte rows the last hop gathers at the same rate as 64-byte ones (the reference's operator feeds <= 1024
-    # rows, batch.rs:81 — a host layer that coalesces two child batches gets this; secondary figure, same sources)
-    wide = None
-    if not args.no_lanes_sweep and nb_all >= 4:
-        wide = [srcs[j * 2 * B:(j + 1) * 2 * B] for j in range(min(nb_all // 2, max(args.steps // 2, 2)))]
-        engine.expand_count(ctx, wide[0], *clean)
-        ctx.sync()
-        t = time.perf_counter()
-        wn = wf = 0
-        for b in wide:
-            nn, _, f = engine.expand_count(ctx, b, *clean)
-            wn += nn
-            wf += f
-        d = time.perf_counter() - t
-        ref_n = ref_f = 0                                # the same sources as 1024-row batches: rows are independent
-        for j in range(2 * len(wide)):
-            nn, _, f = engine.expand_count(ctx, srcs[j * B:(j + 1) * B], *clean)
-            ref_n += nn
-            ref_f += f
-        det["batch_2048"] = {"batches": len(wide), "ms_per_batch": round(d / len(wide) * 1e3, 3), "TEPS": round(wf / d, 1),
-                             "agrees_with_1024_row_batches": bool(wn == ref_n and wf == ref_f)}
+            best = d if best is None or d < best else best
+        return {"ms_per_call": round(best * 1e3, 3), "TEPS": round(r[2] / best, 1), "sources": int(len(src)),
+                "ms_per_1024_sources": round(best * 1e3 / (len(src) / 1024), 4)}, r
+    # the reference's own batch shape: one call per 1024-row child batch (batch.rs:81), one thread — what rounds 1-5 timed
+    ks = [P[j * B:(j + 1) * B] for j in range(min(nb_all, 32))]
+    ctx.sync()
+    t = time.perf_counter()
+    bn = bf = 0
+    for b in ks:
+        nn, _, f = engine.expand_count(ctx, b, *clean)
+        bn += nn
+        bf += f
+    d = time.perf_counter() - t
+    det["batch_1024"] = {"batches": len(ks), "ms_per_batch": round(d / len(ks) * 1e3, 3), "TEPS": round(bf / d, 1)}
+    # ... and the same rows as ONE whole-frontier call: the sums must agree (rows are independent)
+    sl, r_sl = run(P[:len(ks) * B], clean)
+    det["batch_1024"]["same_rows_one_call"] = dict(sl, agrees=bool((r_sl[0], r_sl[2]) == (bn, bf)))
+    if (r_sl[0], r_sl[2]) != (bn, bf):
+        raise SystemExit(f"bench.py: whole-frontier call over {len(ks) * B} rows gives (nnz, flops) {(r_sl[0], r_sl[2])}, the "
+                         f"1024-row calls over the same rows {(bn, bf)}")
+    det["count_only"], _ = run(P, clean, False)
+    det["dirty"], _ = run(P, dirty)
     if not args.no_lanes_sweep:
-        # (behind a deadline: host threads spinning on device flags cannot be cancelled — if the sweep stalls, the line is still
-        # printed and main() leaves through os._exit)
-        import threading
-        box = {}
-
-        def sweep():
-            box["q"] = [run_lanes(timed, clean, k) for k in (2, 3, 4)]
-            if wide and len(wide) >= 4:                      # both at once: 2048-source batches from four query threads
-                box["wide4"] = run_lanes(wide, clean, 4)
-        th = threading.Thread(target=sweep, daemon=True)
-        th.start()
-        th.join(120)
-        if th.is_alive():
-            det["query_threads_error"] = "the query-thread sweep did not finish within 120 s"
-            STALLED_THREADS.append("khop query threads")
-        else:
-            det["query_threads"] = box["q"]
-            if box.get("wide4"):
-                det["batch_2048"]["threads4"] = {k_: box["wide4"][k_] for k_ in ("ms_per_batch", "TEPS", "batches")}
-            det["query_threads_checksum_matches_timed"] = all(q["checksum"] == f"{cs:016x}" for q in det["query_threads"])
+        base_lanes = ctx.get_option("expand_scan_lanes")
+        sw = []
+        for k in (1, 2, 3, 4):
+            ctx.set_option("expand_scan_lanes", k)
+            q, r_q = run(P[:32 * B], clean)
+            sw.append(dict(q, lanes=k, agrees=bool(len(ks) != 32 or (r_q[0], r_q[2]) == (bn, bf))))
+        ctx.set_option("expand_scan_lanes", base_lanes)
+        det["lanes_sweep"] = sw
     # every row with a pre-bound destination (multi-hop ExpandInto / CondTraverse with `to` bound, VERDICT r04 item 3): the
     # same batches through fgpu_expand_probe — hops 1-2 as usual, the last hop one bit per row — beside fgpu_expand_count
     try:
@@ -813,15 +841,14 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
                                "rows_present": hits_, "what": "fgpu_expand_probe: 1024 (source, bound destination) rows, 3 hops, clean layers"}
     except Exception as e:   # noqa: BLE001 — a secondary figure must not cost the line
         det["pinned_probe"] = {"error": repr(e)[:200]}
-    for b in ks[:2]:
-        engine.expand_count(ctx, b, *dirty)
-    det["dirty"] = run(ks, dirty)
-    det["dirty_count_only"] = run(ks, dirty, False)
+    # kernel table of ONE whole-frontier call (HIP events on each lane's stream around every modelled launch)
+    l0 = ctx.get_option("expand_kernel_launches")
     ctx.prof_enable(True)
-    for b in timed:
-        engine.expand_count(ctx, b, *clean)
+    engine.expand_count(ctx, P, *clean)
     prof = ctx.prof_read()
     ctx.prof_enable(False)
+    passes = max(ctx.get_option("expand_scan_last_passes"), 1)
+    det["kernel_launches_per_pass"] = round((ctx.get_option("expand_kernel_launches") - l0) / passes, 1)
     det["kernels"] = _kernel_rows(prof)
     roofline = None
     kern = sorted(prof, key=lambda k: -k["ms"])
@@ -833,15 +860,26 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
                     "alg_bytes_per_launch": int(d["alg_bytes"] / d["launches"]),
                     "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches": int(d["launches"]),
                     "share_of_kernel_time": round(d["ms"] / max(sum(k["ms"] for k in kern), 1e-9), 3),
-                    "timing": "HIP events on the launching stream around each launch (fgpu_prof_*), the K timed batches replayed"}
-    lv = engine.expand_levels(ctx, timed[0], *clean)
+                    "timing": "HIP events on the launching stream around each launch (fgpu_prof_*), one whole-frontier call over :P replayed"}
+        # the HOP the kernel belongs to: the partitioned count hop is stream + fold, and only the stream kernel's bytes are
+        # bytes the problem needs (the partial rows between the two are an artefact of the partition)
+        byname = {k["kernel"]: k for k in prof}
+        if d["kernel"] == "xp_stream_kernel" and "xp_fold_kernel" in byname:
+            fo = byname["xp_fold_kernel"]
+            hop_ms = d["ms"] + fo["ms"]
+            roofline["hop"] = {"kernels": "xp_stream_kernel + xp_fold_kernel", "us_per_pass": round(hop_ms / d["launches"] * 1e3, 2),
+                               "achieved": round(d["alg_bytes"] / max(hop_ms, 1e-9) / 1e6, 2),
+                               "frac": round(d["alg_bytes"] / max(hop_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+    lv = engine.expand_levels(ctx, batch0, *clean)
     det["batch0_hop_nnz"] = [int(x) for x in lv["hop_nnz"]]
-    return line, det, (A, dp, dm, host, timed, (first, roofline))
+    return line, det, (A, dp, dm, host, batch0, (first, roofline, scan0))
 
 
 def khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, batch0, gpu_first, scale):
-    """In-run parity of batch 0 (clean: the timed call's own result; dirty: one more call) against the oracle's delta_lmxm
-    chain, and the CPU baseline from that same oracle run: per 64-row chunk rates give the quartiles."""
+    """In-run parity of the first 1024 :P rows (one child batch of the reference, batch.rs:81; clean and dirty) against the
+    oracle's delta_lmxm chain, and the CPU baseline from that same oracle run: per 64-row chunk rates give the quartiles.
+    BASELINE.md §3 step 1: the box is probed for the reference's own CPU library first (`probe`), and scipy.sparse's CSR
+    product of the first 64 rows is timed as the second point it promises."""
     import oracle
     hops = 3
     a, hdp, hdm = host
@@ -857,7 +895,7 @@ def khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, batch0, gpu_first, s
     gpu_dirty = engine.expand_count(ctx, rows, [A] * hops, [dp] * hops, [dm] * hops)
     ok = tuple(gpu_first) == tuple(ref_clean[:3]) and tuple(gpu_dirty) == tuple(ref_dirty[:3])
     parity = {"checked": True, "ok": bool(ok), "rows": int(len(rows)),
-              "what": "(nnz, checksum, flops) of timed batch 0, clean and dirty layers, fgpu_expand_count vs the oracle's "
+              "what": "(nnz, checksum, flops) of the first 1024 :P rows, clean and dirty layers, fgpu_expand_count vs the oracle's "
                       "delta_lmxm chain (oracle.expand_summary_omp; matrix.rs:1317-1402)",
               "clean": {"nnz": int(ref_clean[0]), "checksum": f"{ref_clean[1]:016x}", "flops": int(ref_clean[2])},
               "dirty": {"nnz": int(ref_dirty[0]), "checksum": f"{ref_dirty[1]:016x}", "flops": int(ref_dirty[2])}}
@@ -868,11 +906,31 @@ def khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, batch0, gpu_first, s
     q = [rates[len(rates) // 4], rates[len(rates) // 2], rates[(3 * len(rates)) // 4]] if rates else [0, 0, 0]
     cpu = {"value": round(ref_clean[2] / t_clean, 1), "unit": "TEPS", "cores": threads, "kind": "port",
            "quartiles": [round(x, 1) for x in q],
-           "sample": f"timed batch 0 (1024 :P sources, 3 hops, clean layers, count + checksum): {t_clean:.1f} s of row-parallel "
+           "sample": f"the first 1024 :P sources (3 hops, clean layers, count + checksum): {t_clean:.1f} s of row-parallel "
                      f"OpenMP Gustavson ANY_PAIR products (oracle/oracle_omp.c) on {threads} threads = the job's CPU quota "
                      f"({ncpu} hardware threads visible); quartiles over its sixteen 64-row chunks; stand-in for "
                      f"SuiteSparse:GraphBLAS GrB_mxm, absent from this image",
            "dirty_TEPS": round(ref_dirty[2] / t_dirty, 1)}
+    # what was looked for before settling for the port (graphblas.sh:71-72 builds SuiteSparse:GraphBLAS v10.5.0 from a clone)
+    found = probe_reference_libs()
+    cpu["probe"] = {"looked_for": "libgraphblas / liblagraph(x) (ldconfig, linker path, /usr/lib*, /usr/local/lib, /opt), GraphBLAS.h, "
+                                  "python-graphblas",
+                    "found": {k_: v_ for k_, v_ in found.items() if v_} or None}
+    try:                                             # second point: scipy.sparse CSR x CSR (SMMP, one thread), pattern re-binarised per hop
+        import scipy.sparse as sp
+        k_ = 64
+        a_sp = sp.csr_matrix((np.ones(a.nnz, dtype=np.int32), a.colidx.astype(np.int64), a.rowptr.astype(np.int64)), shape=(a.nrows, a.ncols))
+        f_sp = sp.csr_matrix((np.ones(k_, dtype=np.int32), (np.arange(k_), rows[:k_].astype(np.int64))), shape=(k_, a.nrows))
+        t1 = time.perf_counter()
+        for _ in range(hops):
+            f_sp = f_sp @ a_sp
+            f_sp.data[:] = 1
+        t_sp = time.perf_counter() - t1
+        fl_sp = chunks[0][0] if chunks else 0
+        cpu["scipy"] = {"value": round(fl_sp / t_sp, 1), "unit": "TEPS", "cores": 1, "rows": k_, "seconds": round(t_sp, 2),
+                        "nnz_matches_oracle_chunk": None}
+    except Exception as e:   # noqa: BLE001 — a report field
+        cpu["scipy"] = {"error": repr(e)[:120]}
     return parity, cpu
 
 
@@ -1277,8 +1335,8 @@ def emit(line, detail):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64, help="timed 1024-source batches of the k-hop MATCH (per rank)")
-    ap.add_argument("--warmup", type=int, default=8, help="untimed batches before them")
+    ap.add_argument("--steps", type=int, default=16, help="timed whole-frontier label scans of the k-hop MATCH (per rank)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed scans before them")
     ap.add_argument("--scale", type=int, default=0, help="R-MAT scale of the headline leg (default 22)")
     ap.add_argument("--leg", default="khop", choices=("khop", "bfs"),
                     help="khop (default): the bench line.  bfs: only the BFS leg at --scale, its TEPS as `value` (tools; with "
@@ -1409,31 +1467,41 @@ def main():
 
     # ================= the bench line: k-hop MATCH =====================================================================
     scale = args.scale or 22
-    line, head, (A, dp, dm, host, timed, extra) = khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max,
-                                                                reduce_sum)
+    line, head, (A, dp, dm, host, batch0, extra) = khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max,
+                                                                 reduce_sum)
     detail = {"headline": head, "device": info}
     sec = {}
     roofline = parity = cpu = None
     if rank == 0:
-        first, roofline = extra
-        sec["khop%d" % scale] = {"count_only_TEPS": head["count_only"]["TEPS"], "count_only_ms": head["count_only"]["ms_per_batch"],
-                                 "dirty_TEPS": head["dirty"]["TEPS"], "dirty_ms": head["dirty"]["ms_per_batch"]}
+        first, roofline, scan0 = extra
+        key = "khop%d" % scale
+        sec[key] = {"count_only_TEPS": head["count_only"]["TEPS"], "count_only_ms": head["count_only"]["ms_per_call"],
+                    "dirty_TEPS": head["dirty"]["TEPS"], "dirty_ms": head["dirty"]["ms_per_call"],
+                    "batch1024_TEPS": head["batch_1024"]["TEPS"], "batch1024_ms": head["batch_1024"]["ms_per_batch"],
+                    "launches_per_pass": head.get("kernel_launches_per_pass")}
         if head.get("prep_ms") is not None:
-            sec["khop%d" % scale]["prep_ms"] = head["prep_ms"]     # first call of the process: pools + transpose, item lists, layout
-            sec["khop%d" % scale]["snapshot_prep_ms"] = head.get("snapshot_prep_ms")   # a new matrix version, pools warm
+            sec[key]["prep_ms"] = head["prep_ms"]     # first call of the process: pools + transpose, item lists, layout
+            sec[key]["snapshot_prep_ms"] = head.get("snapshot_prep_ms")   # a new matrix version, pools warm
         if (head.get("pinned_probe") or {}).get("ms_per_batch"):
-            sec["khop%d" % scale]["pinned_probe_ms"] = head["pinned_probe"]["ms_per_batch"]
-        if head.get("batch_2048"):
-            sec["khop%d" % scale].update({"b2048_TEPS": head["batch_2048"]["TEPS"], "b2048_ms": head["batch_2048"]["ms_per_batch"],
-                                          "b2048_ok": head["batch_2048"]["agrees_with_1024_row_batches"]})
-            if head["batch_2048"].get("threads4"):
-                sec["khop%d" % scale]["b2048_threads4_TEPS"] = head["batch_2048"]["threads4"]["TEPS"]
-        if head.get("query_threads"):                 # the timed batches again from 4 query threads (4 lanes of the one context)
-            q = head["query_threads"][-1]
-            sec["khop%d" % scale].update({"threads%d_TEPS" % q["lanes"]: q["TEPS"], "threads%d_ms" % q["lanes"]: q["ms_per_batch"],
-                                          "threads_checksum_ok": head["query_threads_checksum_matches_timed"]})
+            sec[key]["pinned_probe_ms"] = head["pinned_probe"]["ms_per_batch"]
+        if head.get("lanes_sweep"):                   # the same 32 K sources in one call on 1 .. 4 lanes
+            sec[key]["lanes_TEPS"] = {str(q["lanes"]): q["TEPS"] for q in head["lanes_sweep"]}
         if not args.no_parity and host is not None:
-            parity, cpu = khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, timed[0], first, scale)
+            parity, cpu = khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, batch0, first, scale)
+            # the WHOLE :P scan — timed step 0 — against the committed oracle run of exactly these inputs
+            # (tests/golden/make_khop22_scan_golden.py: a quarter of an hour of 16-thread CPU, done once)
+            gpath = os.path.join(ROOT, "tests", "golden", "khop%d_scan.json" % scale)
+            if os.path.exists(gpath) and args.edge_factor == 16 and scan0 is not None:
+                gold = json.load(open(gpath))
+                ok = (gold.get("edges") == head["edges"] and gold.get("rows") == head["label_P_sources"] and
+                      tuple(scan0) == (gold["nnz"], gold["checksum"], gold["flops"]))
+                parity["whole_scan_vs_committed_oracle_run"] = {"ok": bool(ok), "rows": int(gold.get("rows", 0)),
+                                                                "golden": "tests/golden/khop%d_scan.json" % scale}
+                if not ok:
+                    raise SystemExit(f"bench.py: whole-scan parity FAILED at scale {scale} against {gpath}: gpu {scan0} vs "
+                                     f"({gold['nnz']}, {gold['checksum']}, {gold['flops']})")
+                parity["ok"] = bool(parity["ok"] and ok)
+                parity["rows"] = int(gold["rows"])
             detail["parity"] = parity
             if args.no_cpu_baseline:
                 cpu = None
@@ -1454,7 +1522,7 @@ def main():
         # ---- k-hop at the other scales (BASELINE config 3 = RMAT-24; the metric's RMAT-26) ---------------------------
         for sc in [int(x) for x in args.khop_extra_scales.split(",") if x.strip() and int(x) != scale]:
             leg, (KA, Kdp, Kdm, Khost, kb) = khop_leg(ctx, engine, args, sc, 16 if sc <= 24 else 4,
-                                                      parity_rows=1024 if sc <= 24 else 128)
+                                                      parity_rows=1024 if sc <= 24 else 128, scan_sources=16384 if sc <= 24 else 8192)
             if sc == 24:
                 if not args.no_roofline:
                     KAt = KA.transpose()
@@ -1465,10 +1533,13 @@ def main():
             del Khost
             detail["khop%d" % sc] = leg
             r_ = leg.get("roofline") or {}
-            sec["khop%d" % sc] = {"TEPS": leg["clean"]["TEPS"], "ms": leg["clean"]["ms_per_batch"],
-                                  "count_only_TEPS": leg["clean"]["count_only"]["TEPS"],
-                                  "dirty_TEPS": leg["dirty"]["TEPS"], "dirty_ms": leg["dirty"]["ms_per_batch"],
-                                  "batches": leg["batches_timed"], "hop3_frac": r_.get("frac"), "hop3_us": r_.get("avg_launch_us"),
+            scn = leg.get("scan") or {}
+            sec["khop%d" % sc] = {"TEPS": (scn.get("clean") or leg["clean"])["TEPS"], "sources_per_call": scn.get("sources"),
+                                  "ms_per_1024_sources": (scn.get("clean") or {}).get("ms_per_1024_sources"),
+                                  "dirty_TEPS": (scn.get("dirty") or leg["dirty"])["TEPS"],
+                                  "batch1024_TEPS": leg["clean"]["TEPS"], "batch1024_ms": leg["clean"]["ms_per_batch"],
+                                  "batch1024_dirty_ms": leg["dirty"]["ms_per_batch"],
+                                  "batches": leg["batches_timed"], "hop3_frac": r_.get("frac"), "hop3_us": r_.get("avg_launch_us"), "hop3_hop_frac": r_.get("hop_frac"),
                                   "parity_ok": leg["parity"].get("ok"), "parity_rows": leg["parity"].get("rows"),
                                   "cpu_TEPS": (leg.get("cpu_baseline") or {}).get("value")}
         # ---- RMAT-26 BFS on this one GPU: base point of the multi-GPU curve (BASELINE config 4) ----------------------
@@ -1596,15 +1667,20 @@ def main():
                                      for k, v in em.items()}
         out = dict(base, metric=BASELINE_METRIC, value=line["value"], unit="TEPS", steps=args.steps, warmup=args.warmup,
                    ms_per_step=line["ms_per_step"], scaling="weak",
-                   config={"workload": f"RMAT scale-{scale} 3-hop MATCH (a:P)-->()-->()-->(c), 1024-source batches, clean layers, "
-                                       f"count + checksum on device (fgpu_expand_count)",
-                           "scale": scale, "vertices": head["vertices"], "edges": head["edges"], "hops": 3, "batch_rows": 1024,
+                   config={"workload": f"RMAT scale-{scale} 3-hop MATCH (a:P)-->()-->()-->(c): one whole-frontier fgpu_expand_count call "
+                                       f"per label scan (all ~N/16 sources of the label), clean layers, count + checksum on device",
+                           "scale": scale, "vertices": head["vertices"], "edges": head["edges"], "hops": 3,
+                           "sources_per_call": head["scan"]["sources_per_call"], "live_sources": head["scan"]["live_sources_last_call"],
+                           "pass_rows": head["scan"]["pass_rows"], "passes_per_call": head["scan"]["passes_last_call"],
+                           "lanes": head["scan"]["lanes"],
                            "edge_factor": args.edge_factor, "device": info["name"],
-                           "parallelism": ("1 GPU" if world == 1 else f"{world} GPUs: source batches round-robin over the ranks, "
+                           "parallelism": ("1 GPU" if world == 1 else f"{world} GPUs: label scans round-robin over the ranks, "
                                                                       f"adjacency replicated, no collective")},
                    roofline=roofline, cpu_baseline=cpu,
-                   parity=({"ok": parity["ok"], "rows": parity["rows"], "what": "timed batch 0 (nnz, checksum, flops), clean + dirty, "
-                            "vs oracle delta_lmxm chain"} if parity else {"checked": False}),
+                   parity=({"ok": parity["ok"], "rows": parity["rows"],
+                            "what": "(nnz, checksum, flops): the first 1024 :P rows clean + dirty vs the oracle's delta_lmxm chain run here"
+                                    + ("; timed step 0 (the whole :P scan) vs the committed oracle run tests/golden/khop%d_scan.json" % scale
+                                       if parity.get("whole_scan_vs_committed_oracle_run") else "")} if parity else {"checked": False}),
                    secondary=sec, detail="DETAIL line above / bench_detail.json")
         emit(out, detail)
     if use_dist:

@@ -458,6 +458,61 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
 }
 
 // ---------------------------------------------------------------------------------
+// compact records of a sparse bit state, for the pull that reads it
+// ---------------------------------------------------------------------------------
+// The state a chain holds right after it left the CSR form is the union of ~10^3 out-neighbourhoods: 10^4 - 10^5 non-zero
+// rows whose rows hold ONE or two bits each (bit i of X[u] <=> source i has an edge to u; a vertex needs an in-degree of
+// ~N / 256 from the sources of the pass to collect more than four).  The next pull gathers such a row once per LIVE entry of
+// A' — half of the entries at 1024 live sources, the hubs being in every frontier — and with 128-byte rows that is 16 lanes,
+// a 128-byte line through the vector cache and a 16-word OR per entry to convey one bit (hop 2 of a 1024-live-row pass:
+// 635 us at RMAT-22 against 354 us for the same hop at half the row width).  rec[u] = the bits of X[u] as up to four 16-bit
+// source indices (0xFFFF = none), or BP_REC_ESC when the row holds more: a lane per live entry then loads 8 bytes and sets
+// the bits in the group's LDS accumulator itself; only the entries that meet an ESC row go through the row gathers.
+constexpr u64 BP_REC_ESC = 0xFFFFFFFFFFFFFFFEull;
+__global__ __launch_bounds__(256) void bp_records_kernel(const uint8_t* __restrict__ flag, u32 n, u32 ws, const u64* __restrict__ x,
+                                                        u64* __restrict__ rec) {
+    __shared__ u32 s_list[2048];
+    __shared__ u32 s_cnt;
+    const u32 tid = threadIdx.x;
+    const u32 tiles = (n + 2047u) >> 11;
+    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        const u32 base = (tile << 11) + tid * 8u;
+        u64 f = 0;
+        if (base + 8u <= n) {
+            f = *reinterpret_cast<const u64*>(flag + base);
+        } else {
+            for (u32 j = 0; j < 8u; ++j)
+                if (base + j < n && flag[base + j]) f |= 0xffull << (8u * j);
+        }
+        if (f) {
+            for (u32 j = 0; j < 8u; ++j)
+                if ((f >> (8u * j)) & 0xffull) s_list[atomicAdd(&s_cnt, 1u)] = base + j;
+        }
+        __syncthreads();
+        const u32 cnt = s_cnt;
+        for (u32 i = tid; i < cnt; i += 256u) {
+            const u32 u = s_list[i];
+            const u64* row = x + (size_t)u * ws;
+            u64 r = ~0ull;
+            u32 c = 0;
+            for (u32 k = 0; k < ws && c <= 4u; ++k) {
+                u64 w = row[k];
+                while (w && c <= 4u) {
+                    const u32 b = (u32)__builtin_ctzll(w);
+                    w &= w - 1ull;
+                    if (c < 4u) r = (r & ~(0xFFFFull << (16u * c))) | ((u64)(k * 64u + b) << (16u * c));
+                    ++c;
+                }
+            }
+            rec[u] = c > 4u ? BP_REC_ESC : r;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // sparse pull, row-group form (a mid-chain hop whose X has few non-zero rows)
 // ---------------------------------------------------------------------------------
 // The item form gives a wavefront one row at a time: at RMAT-24 that is 8.5 M items of ~30 entries, each a chain of five
@@ -476,7 +531,8 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
                                                                              const u32* __restrict__ next_rowptr,
                                                                              unsigned long long* __restrict__ stats,
                                                                              const u64* __restrict__ later_bits,
-                                                                             const u32* __restrict__ yperm /* nullable: row v of Y at slot yperm[v] */) {
+                                                                             const u32* __restrict__ yperm /* nullable: row v of Y at slot yperm[v] */,
+                                                                             const u64* __restrict__ rec /* nullable: bp_records_kernel's form of X */) {
     // stats (nullable, with next_rowptr): [0] += popcount(Y[v]) * out-degree of v in the next hop's matrix, [1] += rows
     // written — what bp_flops / bp_count_flags would find in a pass of their own.  Rows flagged in `later_bits`
     // (nullable: destinations of a delta layer, whose rows change after this kernel) are left to bp_split_stats_kernel.
@@ -555,6 +611,40 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (rec) {
+                // a lane per live entry (<= 256 of them: four per lane, their records in flight together): the record's source
+                // indices are set in the row's accumulator; entries whose neighbour holds more than four bits are compacted to
+                // the front of the list and take the row gathers below
+                u64 pe[4], rc[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 i = 64u * k + lane;
+                    pe[k] = (i < n_live) ? list[i] : ~0ull;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rc[k] = (pe[k] != ~0ull) ? rec[(u32)pe[k]] : ~0ull;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (every lane has read its list entries before any is rewritten)
+                __builtin_amdgcn_wave_barrier();
+                u32 n_esc = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool esc = pe[k] != ~0ull && rc[k] == BP_REC_ESC;
+                    const u64 em = __ballot(esc);
+                    if (esc) list[n_esc + (u32)__popcll(em & below)] = pe[k];
+                    n_esc += (u32)__popcll(em);
+                    if (!esc) {
+                        u64* arow = acc + (size_t)(u32)(pe[k] >> 32) * LN;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const u32 sid = (u32)(rc[k] >> (16 * j)) & 0xFFFFu;
+                            if (sid < 0xFFFEu) atomicOr((unsigned long long*)&arow[sid >> 6], 1ull << (sid & 63u));
+                        }
+                    }
+                }
+                n_live = n_esc;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             for (u32 i0 = 0; i0 < n_live; i0 += 4 * SLOTS) {
                 u64 pu[4];
 #pragma unroll
@@ -1363,6 +1453,18 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
                 FGPU_HIP(hipGetLastError());
             }
         }
+        DevBuf<u64> recs;
+        if (groups && ctx->opt.expand_records && s.nsrc < 0xFFFEu && s.nz_rows * 8 < (u64)s.n) {
+            // the state's non-zero rows as records of <= 4 source indices (bp_records_kernel): what the row-group pull reads per
+            // live entry instead of the whole row
+            FGPU_TRY(recs.alloc(ctx, (size_t)s.n + 1));
+            ProfScope psr(ctx, "bp_records_kernel", (u64)s.n + s.nz_rows * (s.ws * 8 + 8));
+            const u32 tiles = (s.n + 2047u) >> 11;
+            const u32 rgrid = tiles < (u32)ctx->cus * 8u ? tiles : (u32)ctx->cus * 8u;
+            hipLaunchKernelGGL(bp_records_kernel, dim3(rgrid ? rgrid : 1), dim3(256), 0, ctx->stream(), (const uint8_t*)s.flag.p, s.n, s.ws,
+                               (const u64*)s.x.p, recs.p);
+            FGPU_HIP(hipGetLastError());
+        }
         if (groups) {
             const size_t per_wave = ((size_t)BP_GROUP * s.ws + 256 + 32) * sizeof(u64);
             const size_t lds_g = lds_co + BP_GROUP_WAVES * per_wave;
@@ -1379,7 +1481,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
                            view_of(t), (u32)t->nrows, (const u64*)s.x.p, pr, ydst, yflag,                               \
                            fuse_stats ? (const u32*)next_m->rowptr : (const u32*)nullptr,                               \
                            fuse_stats ? (unsigned long long*)gstats.p : (unsigned long long*)nullptr,                   \
-                           (const u64*)later.p, operm);                                                                 \
+                           (const u64*)later.p, operm, (const u64*)recs.p);                                             \
     } while (0)
             switch (s.ws) {
                 case 1: BP_GROUPS(1); break;

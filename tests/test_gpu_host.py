@@ -917,6 +917,34 @@ def test_expand_batch_over_the_transposed_layers_matches_the_per_row_path(rnd_gr
     assert g.cond_traverse_batch(host.cond_spec(src_labels=[], hops=[(["A"], []), (["B"], [])], transposed=True), bound[:4]) is None
 
 
+def test_expand_batch_over_two_coalesced_child_batches(rnd_graph):
+    """A host layer that hands the engine TWO child batches at once (2 x 1024 rows; the reference's operator calls down once
+    per 1024-row batch, batch.rs:81, cond_traverse.rs:452) must emit, row for row and in the reference's order
+    (cond_traverse.rs:644: ascending (row_i, dest)), exactly the two separate calls' rows — the second batch's row indices
+    shifted by 1024 — and the oracle's expand_batch over all 2048 rows; 3 x 1024 + 500 rows likewise (the call is then a
+    whole frontier for the count form and a plain wide batch for the emitting form)."""
+    g, og, n, _ = rnd_graph
+    rng = np.random.default_rng(41)
+    for hops, kw in (([([], []), (["A"], ["P"])], dict(types=[], chain=[(["A"], ["P"])])),
+                     ([(["A"], [])], dict(types=["A"], chain=[])),
+                     ([(["B"], []), ([], []), (["A"], [])], dict(types=["B"], chain=[([], []), (["A"], [])]))):
+        for total in (2048, 3 * 1024 + 500):
+            src = rng.integers(0, n, total).tolist()
+            spec = host.cond_spec(src_labels=["P"] if len(hops) == 2 else [], hops=hops)
+            both, nulls, flops = g.cond_traverse_batch(spec, src)
+            want = []
+            fl = 0
+            for j in range(0, total, 1024):
+                part, _, f = g.cond_traverse_batch(spec, src[j:j + 1024])
+                want += [(r + j, d) for r, d in part]
+                fl += f
+            assert both == want and flops == fl
+            ref = model.expand_batch(og, src, kw["types"], src_labels=["P"] if len(hops) == 2 else [], dst_labels=hops[0][1] if not kw["chain"] else [],
+                                     chain=kw["chain"])
+            assert both == ref[0] and nulls == ref[1]
+            assert len(both) > total
+
+
 def test_expand_batch_to_bound_and_null_sources(rnd_graph):  # cond_traverse.rs:566-575, 657-661
     g, og, n, _ = rnd_graph
     src = [5, None, 9, 300, 17]

@@ -351,6 +351,144 @@ def test_khop_rmat26_full_batch_matches_the_committed_oracle_run(ctx, bench_grap
     assert ref["nnz"] > 4_000_000_000
 
 
+def _scan_opts(ctx, **kw):
+    """set whole-frontier options, return the old values (restored by the caller's finally)"""
+    old = {k: ctx.get_option(k) for k in kw}
+    for k, v in kw.items():
+        ctx.set_option(k, v)
+    return old
+
+
+@pytest.mark.parametrize("dirty", [False, True])
+def test_whole_frontier_call_matches_the_oracle(ctx, rmat20, dirty):
+    """fgpu_expand_count over a whole frontier (spgemm.hip expand_count_scan; SURVEY.md §7 hard part 1, §8d: all sources of a
+    scan in one call): 6000 source rows of RMAT-20 — NULL rows, a repeated source and sources without out-edges among them —
+    3 hops, clean and dirty, with and without a destination label: (nnz, checksum, flops) against the oracle's delta_lmxm
+    chain over the SAME rows (every row hashed by its index in the call), for every pass width / lane count the option
+    allows here, in the auto and the bit-parallel mode, count-only included."""
+    A, dp, dm, a, hdp, hdm = rmat20
+    src = p_sources(a.nrows, 6000).copy()
+    src[17] = np.iinfo(np.uint64).max                      # a NULL source row (cond_traverse.rs:566-575, OPTIONAL)
+    src[4000] = np.iinfo(np.uint64).max
+    src[123] = src[122]                                    # the same node bound on two rows
+    lay = [(a, hdp, hdm) if dirty else (a, None, None)] * 3
+    keep = np.nonzero(src != np.iinfo(np.uint64).max)[0]
+    # the oracle's F holds one row per call row: NULL rows stay empty (their index still counts)
+    ref = None
+    nnz = cs = flops = 0
+    for c0 in range(0, len(keep), 64):
+        rows = keep[c0:c0 + 64]
+        f = oracle.build_csr(len(src), a.nrows, rows.astype(U64), src[rows])
+        for (m_, dp_, dm_) in lay:
+            f, fl = oracle.delta_lmxm_omp(f, m_, dp_, dm_, 8)
+            flops += fl
+        nnz += f.nnz
+        cs = (cs + oracle.checksum_omp(f, 8)) & 0xFFFFFFFFFFFFFFFF
+    ref = (nnz, cs, flops)
+    layers = ([A] * 3, [dp] * 3, [dm] * 3) if dirty else ([A] * 3,)
+    seen = set()
+    for rows_, lanes, mode in ((1024, 3, 0), (1024, 1, 0), (256, 4, 0), (512, 2, 2), (64, 3, 0)):
+        old = _scan_opts(ctx, expand_scan_rows=rows_, expand_scan_lanes=lanes, expand_mode=mode)
+        try:
+            got = engine.expand_count(ctx, src, *layers)
+            nn, _, fl = engine.expand_count(ctx, src, *layers, want_checksum=False)
+            passes, live = ctx.get_option("expand_scan_last_passes"), ctx.get_option("expand_scan_last_live")
+        finally:
+            _scan_opts(ctx, **old)
+        assert got == ref, (rows_, lanes, mode, got, ref)
+        assert (nn, fl) == (ref[0], ref[2])
+        assert passes == -(-live // rows_) and 2000 < live < len(keep)
+        seen.add(passes)
+    assert len(seen) >= 3 and ref[0] > 500_000_000
+    # ... and against the calls it replaces: 1024 rows per call (nnz and flops add up; the checksum hashes call rows)
+    bn = bf = 0
+    for j in range(0, len(src), 1024):
+        r = engine.expand_count(ctx, src[j:j + 1024], *layers)
+        bn += r[0]
+        bf += r[2]
+    assert (bn, bf) == (ref[0], ref[2])
+    # a destination label (the dst filter of the LAST hop, cond_traverse.rs:647-651)
+    if not dirty:
+        label = oracle.mix64(np.arange(a.nrows, dtype=U64)) % U64(3) != 0
+        bits = oracle.bits_from_ids(a.nrows, np.nonzero(label)[0])
+        small = src[:2500]
+        got = engine.expand_count(ctx, small, [A] * 3, dst_label_bitmap=bits)
+        want = [0, 0]
+        for c0 in range(0, len(small), 1024):
+            r = engine.expand_count(ctx, small[c0:c0 + 1024], [A] * 3, dst_label_bitmap=bits)
+            want = [want[0] + r[0], want[1] + r[2]]
+        assert [got[0], got[2]] == want and 0 < got[0]
+
+
+def test_whole_frontier_call_on_a_graph_that_stays_in_csr_form(ctx):
+    """The same call where the chain never leaves the sorted-CSR products (a small graph: every pass ends in CSR form and is
+    check-summed with the call's row indices), and in expand_mode 1 where the whole-frontier path is not taken at all."""
+    a = oracle.rmat_csr(12)
+    A = ctx.mat_from_csr(a.nrows, a.ncols, a.rowptr, a.colidx)
+    src = np.arange(0, a.nrows, dtype=U64)[:3000]
+    ref = oracle.expand_summary_omp(src, [(a, None, None)] * 2, chunk=256, threads=8)
+    for mode in (0, 1):
+        old = _scan_opts(ctx, expand_mode=mode, expand_scan_rows=256)
+        try:
+            got = engine.expand_count(ctx, src, [A] * 2)
+        finally:
+            _scan_opts(ctx, **old)
+        assert got == ref[:3], (mode, got, ref[:3])
+    A.free()
+
+
+def test_clean_first_hop_over_exactly_4096_rows(ctx, rmat20):
+    """a clean first hop over exactly FH_MAX_ROWS = 4096 one-entry rows published an unwritten row pointer (the scan
+    kernel's 1024 threads x 4 rows write rp[0..4095]); 4095, 4096 and 4097 rows through the single-call chain (the
+    whole-frontier path switched off) against the oracle."""
+    A, dp, dm, a, hdp, hdm = rmat20
+    allsrc = p_sources(a.nrows, 4097)
+    old = _scan_opts(ctx, expand_scan_min=0)
+    try:
+        for k in (4095, 4096, 4097):
+            src = allsrc[:k]
+            ref = oracle.expand_summary_omp(src, [(a, None, None)] * 2, chunk=512, threads=8)
+            got = engine.expand_count(ctx, src, [A] * 2)
+            assert got == ref[:3], (k, got, ref[:3])
+    finally:
+        _scan_opts(ctx, **old)
+
+
+def test_khop_rmat22_whole_scan_matches_the_committed_oracle_run(ctx, bench_graphs):
+    """The bench line's step at the size it is quoted: ALL :P sources of RMAT-22 (261 6xx rows) in ONE fgpu_expand_count call,
+    3 hops, clean — (nnz, checksum, flops) against tests/golden/khop22_scan.json, the CPU oracle's chain over exactly these
+    inputs run once by tests/golden/make_khop22_scan_golden.py (a quarter of an hour of 16-thread CPU: not repeated per
+    session); then the first 32 slabs of 1024 rows as separate whole-frontier calls against the golden's per-slab sums (nnz,
+    flops: the checksum of a slab hashes rows of the WHOLE call).  Inputs re-derived here and pinned by hashes."""
+    import hashlib
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "khop22_scan.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/khop22_scan.json not generated yet")
+    gold = json.load(open(path))
+    A, _, a = bench_graphs(22)
+    ids = np.arange(a.nrows, dtype=U64)
+    src = ids[oracle.mix64(ids) % U64(16) == 0]
+    assert gold["rows"] == len(src) and gold["edges"] == a.nnz
+    assert gold["sources_sha256"] == hashlib.sha256(np.ascontiguousarray(src).tobytes()).hexdigest()
+    assert gold["colidx_sha256"] == hashlib.sha256(np.ascontiguousarray(a.colidx).tobytes()).hexdigest()
+    got = engine.expand_count(ctx, src, [A] * 3)
+    assert got == (gold["nnz"], gold["checksum"], gold["flops"]), (got, gold["nnz"], gold["checksum"], gold["flops"])
+    assert ctx.get_option("expand_scan_last_passes") > 100
+    nn, _, fl = engine.expand_count(ctx, src, [A] * 3, want_checksum=False)
+    assert (nn, fl) == (gold["nnz"], gold["flops"])
+    S = gold["slab_rows"]
+    assert sum(x[0] for x in gold["slabs"]) == gold["nnz"] and sum(x[2] for x in gold["slabs"]) == gold["flops"]
+    for j in (0, 1, 7, 31):
+        r = engine.expand_count(ctx, src[j * S:(j + 1) * S], [A] * 3)
+        assert (r[0], r[2]) == (gold["slabs"][j][0], gold["slabs"][j][2]), j
+    r = engine.expand_count(ctx, src[:8 * S], [A] * 3)            # 8 slabs, one call: the prefix sums, checksum included
+    assert r == (sum(x[0] for x in gold["slabs"][:8]), sum(x[1] for x in gold["slabs"][:8]) & 0xFFFFFFFFFFFFFFFF,
+                 sum(x[2] for x in gold["slabs"][:8]))
+    assert gold["nnz"] > 100_000_000_000
+
+
 def test_khop_rmat24_two_hop_host_arrays_match_the_oracle(ctx, rmat24_bench):
     """What the operator consumes (cond_traverse.rs:608, 644-751): the (row_i, dest) arrays of fgpu_expand in HOST memory
     for the 1024-row 2-hop batch bench.py's materialised leg times (30.8 M entries at RMAT-24), entry for entry against
