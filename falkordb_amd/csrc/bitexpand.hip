@@ -1472,6 +1472,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             if (wgs < 1) wgs = 1;
             if (wgs > 4) wgs = 4;
             const u32 ggrid = (u32)ctx->cus * wgs;
+            ProfScope psg(ctx, "bp_pull_groups_kernel", 0);      // (inside the hop's record above: the row groups' share of it)
 #define BP_GROUPS(LN)                                                                                                   \
     do {                                                                                                                \
         if (lds_g > 48 * 1024)                                                                                          \
@@ -1685,7 +1686,164 @@ fgpu_info bp_probe_rows(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* m, con
 
 // X -> CSR snapshot with nsrc rows (dest ascending per row); `label_dev` (nullable) = destination
 // label bitmap applied on the way out (cond_traverse.rs:647-651)
+// ---------------------------------------------------------------------------------
+// emission as a stable sort (round 6): bit state -> (row, vertex) pairs in vertex order -> the LDS-staged counting sort
+// ---------------------------------------------------------------------------------
+// bp_rows_kernel turns bit columns into rows with one ballot per (64-vertex block, word, bit column that occurs): after two
+// hops a block holds ~7 set bits per word, so almost every ballot serves ONE bit — eight wave-wide instructions per emitted
+// entry, twice (count, then emit), and every entry leaves as a lone 4-byte store into its row's segment (0.04 of the HBM
+// roofline; 55 % of the device time of the operator's 2-hop batch at RMAT-24).  Turning vertex-major bit rows into row-major
+// id lists is a stable sort of (row, vertex) pairs by row with the vertices already ascending — what the LDS-staged counting
+// sort of transpose.hip does in whole-line runs.  So: a lane per WORD of a non-zero row writes that word's bits as pairs (a
+// few instructions per entry, on one lane), the pairs of a 2048-vertex tile landing in one contiguous piece whose start comes
+// from a scan of the tiles' popcounts; sort_u32_pairs_by_key then delivers the column ids in row order and the row pointers.
+constexpr u32 BP_PT = 2048;   // vertices per tile
+// rows are handled LN = 2^lsh lanes a row (a lane per word, words strided by LN); pc = the lane's popcount over its words
+template <bool FILL>
+__global__ __launch_bounds__(256) void bp_pairs_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws, u32 lsh, const uint8_t* __restrict__ flag,
+                                                      const u64* __restrict__ label, const u32* __restrict__ perm,
+                                                      u32* __restrict__ tile_cnt, const u64* __restrict__ tile_off,
+                                                      u32* __restrict__ key, u32* __restrict__ val) {
+    __shared__ u32 s_row[BP_PT + 1];          // FILL: exclusive prefix of the rows' popcounts
+    __shared__ u32 s_wave[4];
+    const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const u32 LN = 1u << lsh, wl = tid & (LN - 1u), RPS = 256u >> lsh;      // rows per step of the workgroup
+    const u32 v0 = blockIdx.x * BP_PT;
+    const u32 rows = n - v0 < BP_PT ? n - v0 : BP_PT;
+    u32 total = 0;
+    // pass A: popcount of every row (0 for unflagged / unlabelled rows)
+    for (u32 r0 = 0; r0 < rows; r0 += RPS) {
+        const u32 r = r0 + (tid >> lsh);
+        u32 pc = 0;
+        if (r < rows) {
+            const u32 v = v0 + r;
+            bool on = !flag || flag[v];
+            if (on && label) on = (label[v >> 6] >> (v & 63)) & 1ull;
+            if (on) {
+                const u64* row = y + (size_t)(perm ? perm[v] : v) * ws;
+                for (u32 k = wl; k < w; k += LN) pc += (u32)__popcll(row[k]);
+            }
+        }
+        for (u32 d = 1; d < LN; d <<= 1) pc += (u32)__shfl_xor((int)pc, (int)d, 64);
+        if (FILL) { if (r < rows && wl == 0) s_row[r] = pc; }
+        else if (wl == 0) total += pc;
+    }
+    if (!FILL) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) total += (u32)__shfl_xor((int)total, d, 64);
+        if (lane == 0) s_wave[wv] = total;
+        __syncthreads();
+        if (tid == 0) tile_cnt[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        return;
+    }
+    __syncthreads();
+    // exclusive scan of s_row[0 .. rows): 8 rows a thread, then the wavefront / workgroup prefix
+    {
+        u32 loc[8], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const u32 i = tid * 8 + j; loc[j] = i < rows ? s_row[i] : 0u; sum += loc[j]; }
+        u32 inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)inc, o, 64); if ((int)lane >= o) inc += t; }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        u32 base = 0;
+        for (u32 q = 0; q < wv; ++q) base += s_wave[q];
+        u32 run = base + inc - sum;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const u32 i = tid * 8 + j; if (i < rows) s_row[i] = run; run += loc[j]; }
+    }
+    __syncthreads();
+    // pass B: a lane per word writes the word's bits (rows re-read: the tile's non-zero rows are still in the L2)
+    const u32 out0 = (u32)tile_off[blockIdx.x];
+    for (u32 r0 = 0; r0 < rows; r0 += RPS) {
+        const u32 r = r0 + (tid >> lsh);
+        const u32 v = v0 + (r < rows ? r : 0u);
+        bool on = r < rows && (!flag || flag[v]);
+        if (on && label) on = (label[v >> 6] >> (v & 63)) & 1ull;
+        const u64* row = y + (size_t)(perm ? perm[v] : v) * ws;
+        // words in ROW order per lane group: lane wl takes words wl, wl + LN, ...; the pairs of a row may leave in any order of
+        // their keys (the sort is by key; only the order of the VERTICES inside one key matters, and a row is one vertex)
+        u32 at = on ? out0 + s_row[r] : 0u;
+        for (u32 k0 = 0; k0 < w; k0 += LN) {
+            const u32 k = k0 + wl;
+            u64 word = (on && k < w) ? row[k] : 0ull;
+            const u32 pc = (u32)__popcll(word);
+            u32 inc = pc;                                  // prefix over the LN lanes of the row
+            for (u32 d = 1; d < LN; d <<= 1) { const u32 t = (u32)__shfl_up((int)inc, (int)d, 64); if (wl >= d) inc += t; }
+            u32 o = at + inc - pc;
+            while (word) {
+                const u32 b = (u32)__builtin_ctzll(word);
+                word &= word - 1ull;
+                key[o] = k * 64u + b;
+                val[o] = v;
+                ++o;
+            }
+            at += (u32)__shfl((int)inc, (int)((lane | (LN - 1u))), 64);   // the row's total over this round of words
+        }
+    }
+}
+
+static fgpu_info bp_to_csr_sorted(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out) {
+    const u32 ntiles = cdiv(s.n ? s.n : 1, BP_PT);
+    u32 lsh = 0;
+    while ((2u << lsh) <= s.w && lsh < 4) ++lsh;          // lanes per row: the largest power of two <= min(w, 16)
+    DevBuf<u32> tcnt, key, val, rp_live;
+    FGPU_TRY(tcnt.alloc(ctx, (size_t)ntiles + 1));
+    FGPU_HIP(hipMemsetAsync(tcnt.p + ntiles, 0, sizeof(u32), ctx->stream()));
+    const u64 nzr = (s.flag.p && s.nz_rows < (u64)s.n) ? s.nz_rows : (u64)s.n;
+    {
+        ProfScope ps(ctx, "bp_pairs_kernel<count>", nzr * s.w * 8 + (u64)s.n);
+        hipLaunchKernelGGL(bp_pairs_kernel<false>, dim3(ntiles), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n, s.w, s.ws, lsh,
+                           (const uint8_t*)s.flag.p, label_dev, s.perm, tcnt.p, (const u64*)nullptr, (u32*)nullptr, (u32*)nullptr);
+        FGPU_HIP(hipGetLastError());
+    }
+    DevBuf<u64> toff;
+    FGPU_TRY(toff.alloc(ctx, (size_t)ntiles + 1));
+    FGPU_TRY(scan_u32_to_u64(ctx, tcnt.p, toff.p, (u64)ntiles + 1, nullptr));
+    u64 nnz = 0;
+    FGPU_TRY(read_u64(ctx, toff.p + ntiles, &nnz));
+    FGPU_REQUIRE(nnz < 0xFFFFFFFFull - 4096, FGPU_OOM,
+                 "expand: %llu result entries exceed the 32-bit row-pointer space; batch the source rows", (unsigned long long)nnz);
+    fgpu_mat* o = nullptr;
+    const u32 out_rows = s.nsrc_full ? s.nsrc_full : s.nsrc;
+    FGPU_TRY(mat_alloc(ctx, &o, out_rows, s.n, nnz, false, 0, false));
+    fgpu_info i = FGPU_OK;
+    u32* rp = o->rowptr;
+    if (s.nsrc_full) { i = rp_live.alloc(ctx, (size_t)s.nsrc + 2); rp = rp_live.p; }
+    if (i == FGPU_OK && nnz) {
+        i = key.alloc(ctx, nnz);
+        if (i == FGPU_OK) i = val.alloc(ctx, nnz);
+        if (i == FGPU_OK) {
+            ProfScope ps(ctx, "bp_pairs_kernel<fill>", nzr * s.w * 8 + (u64)s.n + 8 * nnz);
+            hipLaunchKernelGGL(bp_pairs_kernel<true>, dim3(ntiles), dim3(256), 0, ctx->stream(), (const u64*)s.x.p, s.n, s.w, s.ws, lsh,
+                               (const uint8_t*)s.flag.p, label_dev, s.perm, (u32*)nullptr, (const u64*)toff.p, key.p, val.p);
+            if (hipGetLastError() != hipSuccess) { set_error("bit-parallel emission failed"); i = FGPU_DEVICE; }
+        }
+        if (i == FGPU_OK) {
+            ProfScope ps(ctx, "emission sort (pairs by row)", 16 * nnz + 4 * nnz);
+            i = sort_u32_pairs_by_key(ctx, key.p, val.p, nnz, s.nsrc, o->colidx, rp);
+        }
+    } else if (i == FGPU_OK) {
+        if (hipMemsetAsync(rp, 0, ((size_t)s.nsrc + 1) * sizeof(u32), ctx->stream()) != hipSuccess) i = FGPU_DEVICE;
+    }
+    if (i == FGPU_OK && s.nsrc_full) {
+        // compacted source rows: row i of the result is live row rowrank[i] (an empty source row starts and ends where the next
+        // live one starts)
+        hipLaunchKernelGGL(bp_rowptr_full_kernel, dim3(cdiv((u64)out_rows + 1, 256)), dim3(256), 0, ctx->stream(),
+                           (const u32*)rp_live.p, (const u32*)s.rowrank.p, out_rows, o->rowptr);
+        if (hipGetLastError() != hipSuccess) i = FGPU_DEVICE;
+    }
+    if (i == FGPU_OK && hipStreamSynchronize(ctx->stream()) != hipSuccess) { set_error("bit-parallel emission failed"); i = FGPU_DEVICE; }
+    if (i != FGPU_OK) { mat_release(o); return i; }
+    *out = o;
+    return FGPU_OK;
+}
+
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out) {
+    // (the sort's key space needs >= 2 rows; a result of a few entries is not worth its launches)
+    if (ctx->opt.expand_emit_sort && s.nsrc >= 2 && s.n >= 4096) return bp_to_csr_sorted(ctx, s, label_dev, out);
     const u32 nchunks = cdiv(s.n ? s.n : 1, BP_VCHUNK);
     const u32 krows = s.w * 64;  // counted rows (>= nsrc; the tail rows are empty)
     const size_t ncnt = (size_t)krows * nchunks;

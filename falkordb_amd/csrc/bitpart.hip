@@ -277,6 +277,9 @@ fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const Bp
                            (const uint8_t*)xp->cshared, xp->nchunks, xp->zrows, zc.p);
         FGPU_HIP(hipGetLastError());
         FGPU_TRY(read_u32(ctx, zc.p, &xp->nzrows));
+        // ... and the spare row after the last run: the all-zero partial row the fold reads for (row, partition) pairs without one
+        FGPU_TRY(ctx->h2d(xp->zrows + xp->nzrows, &xp->nprows, sizeof(u32)));
+        xp->nzrows += 1;
     }
     FGPU_HIP(hipStreamSynchronize(st));
     xp->usable = true;
@@ -412,7 +415,8 @@ __device__ __forceinline__ u64 xp_uniform64(u64 v) {
 }
 template <int QL, int MODE>
 __global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_kernel(const u64* __restrict__ ne, const u32* __restrict__ pbase, u32 ng,
-                                                      const uint4* __restrict__ partial, BpFinal fin, uint4* __restrict__ side) {
+                                                      const uint4* __restrict__ partial, BpFinal fin, uint4* __restrict__ side,
+                                                      u32 zrow /* an all-zero partial row */) {
     constexpr int SLOTS = 64 / QL;
     extern __shared__ u64 s_tab[];
     if (MODE == 2) {
@@ -437,126 +441,31 @@ __global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_kernel(const u64* __r
         const u64 tw = fin.tbits ? xp_uniform64(fin.tbits[g]) : 0ull;      // (clean layers: no touched rows, no bitmap)
         const u32 tp = fin.tbits ? (u32)__builtin_amdgcn_readfirstlane((int)fin.tpref[g]) : 0u;
         const u64 lb = fin.label ? xp_uniform64(fin.label[g]) : ~0ull;
-        // Two steps in flight (ping-pong registers): the partial rows of the NEXT non-empty step are requested before the current
-        // one is OR-ed, counted and check-summed — the loop used to be load -> wait -> 32 table look-ups -> load, one exposed
-        // round trip per 64 / QL rows, and ran at 2.2 TB/s of partial rows where a read stream reaches 5 (1024-live-row passes:
-        // 466 us of a 2.05 ms pass at RMAT-22).  No branch sits between an issue and its use: a step past the group's last one
-        // re-requests the current rows and is consumed with `valid` off.
-        constexpr u64 SMASK = SLOTS == 64 ? ~0ull : ((1ull << (SLOTS % 64)) - 1ull);
-        auto next_step = [&](u32 r0) -> u32 {                 // (wave-uniform)
-            while (r0 < 64u && ((any >> r0) & SMASK) == 0ull) r0 += SLOTS;
-            return r0;
-        };
-        auto issue = [&](u32 r0, uint4 (&pv)[8]) {
-            const u32 r = r0 + slot;
-            const u64 below = (1ull << r) - 1ull;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool has = (nw[k] >> r) & 1ull;
-                const u32 idx = has ? pb[k] + (u32)__popcll(nw[k] & below) : 0u;     // (row 0: a valid line, masked below)
-                pv[k] = partial[(size_t)idx * QL + wl];
-            }
-        };
-        auto consume = [&](u32 r0, const uint4 (&pv)[8], bool valid) {
-            const u32 r = r0 + slot;
-            const u64 below = (1ull << r) - 1ull;
-            uint4 a = make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if ((nw[k] >> r) & 1ull) a = or4(a, pv[k]);
-            const bool touched = valid && ((tw >> r) & 1ull);
-            const bool counted = valid && !((tw >> r) & 1ull) && ((lb >> r) & 1ull);
-            if (touched && any4(a)) {
-                const u32 sl = tp + (u32)__popcll(tw & below);
-                side[(size_t)sl * QL + wl] = a;              // the only writer of this slot before the delta fix-ups
-            }
-            const u32 pc = (u32)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w));
-            f_cnt += counted ? (u64)pc : 0ull;
-            if (MODE == 2) {
-                // (an all-zero word looks up entry 0 of its tables — zero — so nothing needs a test: words at or past fin.w are
-                // zero by construction and their tables, past the end of s_tab, are never multiplied in)
-                const u64 w0 = counted ? (((u64)a.y << 32) | a.x) : 0ull, w1 = counted ? (((u64)a.w << 32) | a.z) : 0ull;
-                const u32 k0 = 2 * wl < fin.w ? 2 * wl : 0u, k1 = 2 * wl + 1 < fin.w ? 2 * wl + 1 : 0u;
-                const u64* t0 = s_tab + (size_t)k0 * 256;
-                const u64* t1 = s_tab + (size_t)k1 * 256;
-                // (the look-ups of one word in flight together, the two words one after the other: all 32 at once cost 64 registers,
-                // and with two steps of partial rows held as well the kernel fell to 3 wavefronts per SIMD; the LDS latency this
-                // exposes sits under the next step's loads)
-                u64 rs = 0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) rs += t0[j * 16 + (u32)((w0 >> (4 * j)) & 15ull)];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) rs += t1[j * 16 + (u32)((w1 >> (4 * j)) & 15ull)];
-                f_sum += rs * cs_dest_hash(g * 64 + r);
-            }
-        };
-        // (sched_barrier: hipcc otherwise hoists the first ORs of a consume above the issue before it, and with them a vmcnt(0))
-        uint4 pvA[8], pvB[8];
-        u32 ra = next_step(0);                                   // (any != 0: ra < 64)
-        issue(ra, pvA);
-#pragma unroll 1
-        while (ra < 64u) {
-            const u32 rb = next_step(ra + SLOTS);
-            issue(rb < 64u ? rb : ra, pvB);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(ra, pvA, true);
-            const u32 rn = rb < 64u ? next_step(rb + SLOTS) : 64u;
-            __builtin_amdgcn_sched_barrier(0);
-            issue(rn < 64u ? rn : ra, pvA);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(rb < 64u ? rb : ra, pvB, rb < 64u);
-            __builtin_amdgcn_sched_barrier(0);
-            ra = rn;
-        }
-    }
-    bp_block_add2(f_cnt, MODE == 2 ? f_sum : 0ull, fin.acc);
-}
-
-// (A/B: the unpipelined loop of round 5, option expand_fold_pipe = 0)
-template <int QL, int MODE>
-__global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_plain_kernel(const u64* __restrict__ ne, const u32* __restrict__ pbase, u32 ng,
-                                                      const uint4* __restrict__ partial, BpFinal fin, uint4* __restrict__ side) {
-    constexpr int SLOTS = 64 / QL;
-    extern __shared__ u64 s_tab[];
-    if (MODE == 2) {
-        for (u32 i = threadIdx.x; i < fin.w * 256; i += blockDim.x) s_tab[i] = fin.tab[i];
-        __syncthreads();
-    }
-    const u32 lane = lane_id(), wl = lane % QL, slot = lane / QL;
-    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
-    u64 f_cnt = 0, f_sum = 0;
-    for (u32 g = wave; g < ng; g += nwaves) {
-        u64 nw[8];
-        u32 pb[8];
-        u64 any = 0ull;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            nw[k] = xp_uniform64(ne[(size_t)k * ng + g]);   // (wave-uniform: kept in scalar registers whatever the loads were)
-            pb[k] = (u32)__builtin_amdgcn_readfirstlane((int)pbase[(size_t)k * ng + g]);
-            any |= nw[k];
-        }
-        if (!any) continue;
-        const u64 tw = fin.tbits ? xp_uniform64(fin.tbits[g]) : 0ull;      // (clean layers: no touched rows, no bitmap)
-        const u32 tp = fin.tbits ? (u32)__builtin_amdgcn_readfirstlane((int)fin.tpref[g]) : 0u;
-        const u64 lb = fin.label ? xp_uniform64(fin.label[g]) : ~0ull;
+        // The kernel is VALU-bound, not memory-bound (round 6: two steps of loads in flight changed nothing; ~330 VALU
+        // instructions per step at 64 / QL rows a step): the part of a partial row's index that is the same for the whole step —
+        // pb[k] + the set bits of nw[k] below the step — is scalar work, a lane adds the popcount of the step's own (<= 32-bit)
+        // field below its slot; a row that has no piece in partition k loads the plan's all-zero partial row (zrow) instead of
+        // being masked out afterwards, so the OR is unconditional.
 #pragma unroll 1
         for (u32 r0 = 0; r0 < 64; r0 += SLOTS) {
-            if (((any >> r0) & (SLOTS == 64 ? ~0ull : ((1ull << SLOTS) - 1ull))) == 0ull) continue;   // (wave-uniform)
+            if (((any >> r0) & (SLOTS == 64 ? ~0ull : ((1ull << (SLOTS % 64)) - 1ull))) == 0ull) continue;   // (wave-uniform)
             const u32 r = r0 + slot;
             const u64 below = (1ull << r) - 1ull;
+            const u64 before = (1ull << r0) - 1ull;          // (wave-uniform)
             uint4 pv[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const bool has = (nw[k] >> r) & 1ull;
-                const u32 idx = has ? pb[k] + (u32)__popcll(nw[k] & below) : 0u;     // (row 0: a valid line, masked below)
+                u32 idx;
+                if (SLOTS <= 32) {
+                    const u32 fld = (u32)(nw[k] >> r0) & (SLOTS >= 32 ? 0xFFFFFFFFu : ((1u << (SLOTS % 32)) - 1u));   // scalar
+                    const u32 first = pb[k] + (u32)__popcll(nw[k] & before);                                         // scalar
+                    idx = ((fld >> slot) & 1u) ? first + (u32)__popc(fld & ((1u << slot) - 1u)) : zrow;
+                } else {
+                    idx = ((nw[k] >> r) & 1ull) ? pb[k] + (u32)__popcll(nw[k] & below) : zrow;
+                }
                 pv[k] = partial[(size_t)idx * QL + wl];
             }
-            uint4 a = make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if ((nw[k] >> r) & 1ull) a = or4(a, pv[k]);
+            uint4 a = or4(or4(or4(pv[0], pv[1]), or4(pv[2], pv[3])), or4(or4(pv[4], pv[5]), or4(pv[6], pv[7])));
             const bool touched = (tw >> r) & 1ull;
             const bool counted = !touched && ((lb >> r) & 1ull);
             if (touched && any4(a)) {
@@ -641,17 +550,10 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
         const size_t lds = mode == 2 ? lds_tables : 0;
 #define XP_FOLD2(Q, M)                                                                                                           \
         do {                                                                                                                     \
-            if (ctx->opt.expand_fold_pipe) {                                                                                     \
-                if (lds > 48 * 1024)                                                                                             \
-                    FGPU_HIP(hipFuncSetAttribute((const void*)xp_fold_kernel<Q, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                hipLaunchKernelGGL((xp_fold_kernel<Q, M>), dim3(grid), dim3(fthreads), lds, st, (const u64*)xp->ne, (const u32*)xp->pbase, xp->ng,  \
-                                   (const uint4*)partial.p, fin, (uint4*)side);                                                  \
-            } else {                                                                                                             \
-                if (lds > 48 * 1024)                                                                                             \
-                    FGPU_HIP(hipFuncSetAttribute((const void*)xp_fold_plain_kernel<Q, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                hipLaunchKernelGGL((xp_fold_plain_kernel<Q, M>), dim3(grid), dim3(fthreads), lds, st, (const u64*)xp->ne, (const u32*)xp->pbase, xp->ng,  \
-                                   (const uint4*)partial.p, fin, (uint4*)side);                                                  \
-            }                                                                                                                    \
+            if (lds > 48 * 1024)                                                                                                 \
+                FGPU_HIP(hipFuncSetAttribute((const void*)xp_fold_kernel<Q, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((xp_fold_kernel<Q, M>), dim3(grid), dim3(fthreads), lds, st, (const u64*)xp->ne, (const u32*)xp->pbase, xp->ng,  \
+                               (const uint4*)partial.p, fin, (uint4*)side, xp->nprows);                                                                         \
         } while (0)
 #define XP_FOLD(Q) do { if (mode == 2) XP_FOLD2(Q, 2); else XP_FOLD2(Q, 1); } while (0)
         switch (ql) {

@@ -102,7 +102,8 @@ struct fgpu_options {  // fgpu_set_option
     int expand_scan_lanes = 3;  // ... lanes (calling thread + workers, a stream and pool each) the passes are dealt to
     int expand_records = 1;     // sparse mid-chain pull: rows of X with <= 4 bits are read as 8-byte records of source indices, a lane
                                // per live entry (bitexpand.hip bp_records_kernel; 0 = every live entry gathers the whole row; A/B)
-    int expand_fold_pipe = 1;   // xp_fold_kernel: two steps of partial rows in flight (0 = the round-5 loop; A/B)
+    int expand_emit_sort = 1;   // bit state -> CSR: (row, vertex) pairs in vertex order + the LDS-staged stable sort by row (0 = the
+                               // ballot transpose of rounds 3-5, bp_rows_kernel; A/B)
     int pinned_results = 1;    // result arrays >= 256 KiB come from the context's pinned-host pool and are filled by DMA (0 = the
                                // caller's allocator / malloc + staged copies, the round-3 path; A/B)
     int pinned_pool_mb = 4096; // pinned blocks kept for reuse after fgpu_free (beyond it they go back to the OS)

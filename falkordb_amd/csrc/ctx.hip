@@ -849,8 +849,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "expand_scan_lanes")) {
         FGPU_REQUIRE(value >= 1 && value <= 16, FGPU_INVALID, "expand_scan_lanes must be 1 .. 16");
         ctx->opt.expand_scan_lanes = (int)value;
-    } else if (!strcmp(name, "expand_fold_pipe")) {
-        ctx->opt.expand_fold_pipe = value != 0;
+    } else if (!strcmp(name, "expand_emit_sort")) {
+        ctx->opt.expand_emit_sort = value != 0;
     } else if (!strcmp(name, "expand_records")) {
         ctx->opt.expand_records = value != 0;
     } else if (!strcmp(name, "expand_bits_ratio")) {
