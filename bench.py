@@ -511,17 +511,25 @@ def khop_emit_leg(ctx, engine, args, A, host, batches):
         ctx.prof_enable(False)
         # the host-array entry (fgpu_expand: pinned result blocks filled by DMA, ids widened on the device): the first call pays
         # the pinning of its result blocks, later ones reuse them (fgpu_free returns them to the context's pool)
-        t_first_host, t_host = None, []
+        t_first_host, t_host, t_host64 = None, [], []
         for rep in range(2):                       # pass 0 sizes the pool (results of a batch differ by tens of per cent), pass 1 is timed
             for b in bl[:5]:
                 t1 = time.perf_counter()
-                r_ = engine.expand(ctx, b, [A] * hops)
+                r_ = engine.expand32(ctx, b, [A] * hops)       # the device's own 32-bit arrays, two DMAs (what the operator takes)
                 d1 = time.perf_counter() - t1
                 if rep == 0 and b is bl[0]:
                     t_first_host = d1
-                    rp, dest = r_[0].copy(), r_[1].copy()
+                    rp, dest = r_[0].astype(np.uint64), r_[1].astype(np.uint64)
                 if rep == 1:
                     t_host.append(d1)
+                del r_
+                t1 = time.perf_counter()
+                r_ = engine.expand(ctx, b, [A] * hops)         # GrB_Index-wide arrays: ids widened on the device, twice the PCIe bytes
+                d1 = time.perf_counter() - t1
+                if rep == 0 and b is bl[0] and not (np.array_equal(r_[0], rp) and np.array_equal(r_[1], dest)):
+                    raise SystemExit(f"bench.py: fgpu_expand and fgpu_expand32 disagree ({name})")
+                if rep == 1:
+                    t_host64.append(d1)
                 del r_
         # the streamed form (fgpu_expand_stream_*): 64-row chunks, the caller walking each chunk (here: touching its ends)
         t1 = time.perf_counter()
@@ -539,6 +547,7 @@ def khop_emit_leg(ctx, engine, args, A, host, batches):
                "TEPS": round(tot_f / dt, 1), "out_nnz_per_batch": int(tot_n // nb),
                "host_arrays_ms_first_batch": round(t_first_host * 1e3, 3),
                "host_arrays_ms": round(sorted(t_host)[len(t_host) // 2] * 1e3, 3),
+               "host_arrays_u64_ms": round(sorted(t_host64)[len(t_host64) // 2] * 1e3, 3),
                "stream_ms": {"first_chunk": round(t_first * 1e3, 3), "all_chunks": round(t_stream * 1e3, 3), "chunk_rows": 64},
                "kernels": [{"kernel": k["kernel"], "ms_total": round(k["ms"], 3), "launches": k["launches"],
                             "avg_launch_us": round(k["ms"] / max(k["launches"], 1) * 1e3, 2),
@@ -872,6 +881,33 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
                                "frac": round(d["alg_bytes"] / max(hop_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
     lv = engine.expand_levels(ctx, batch0, *clean)
     det["batch0_hop_nnz"] = [int(x) for x in lv["hop_nnz"]]
+    # the NON-pushdown form of the headline's own unit: the first 1024 :P rows, 3 hops, every (row_i, dest) pair
+    # EMITTED as cond_traverse.rs:644-751 emits them — the CSR left on the device (fgpu_expand_mat) and brought to host arrays
+    # (fgpu_expand32); its entry count must equal the count form's
+    try:
+        m_, _ = engine.expand_mat(ctx, batch0, *clean)
+        n_emit = int(m_.nvals)
+        m_.free()
+        ctx.sync()
+        t_ = time.perf_counter()
+        for _ in range(3):
+            m_, f_ = engine.expand_mat(ctx, batch0, *clean)
+            m_.free()
+        ctx.sync()
+        d_dev = (time.perf_counter() - t_) / 3
+        r_ = engine.expand32(ctx, batch0, *clean)
+        del r_
+        t_ = time.perf_counter()
+        r_ = engine.expand32(ctx, batch0, *clean)
+        d_host = time.perf_counter() - t_
+        ok_ = n_emit == first[0] and len(r_[1]) == first[0]
+        del r_
+        det["emitting_three_hop_1024_rows"] = {"entries": n_emit, "ms_device": round(d_dev * 1e3, 3), "ms_host_arrays": round(d_host * 1e3, 3),
+                                               "TEPS_device": round(first[2] / d_dev, 1), "entries_match_count_form": bool(ok_)}
+        if not ok_:
+            raise SystemExit(f"bench.py: the emitting 3-hop batch holds {n_emit} entries, the count form {first[0]}")
+    except MemoryError as e:
+        det["emitting_three_hop_1024_rows"] = {"error": repr(e)[:160]}
     return line, det, (A, dp, dm, host, batch0, (first, roofline, scan0))
 
 
@@ -1484,6 +1520,9 @@ def main():
             sec[key]["snapshot_prep_ms"] = head.get("snapshot_prep_ms")   # a new matrix version, pools warm
         if (head.get("pinned_probe") or {}).get("ms_per_batch"):
             sec[key]["pinned_probe_ms"] = head["pinned_probe"]["ms_per_batch"]
+        em3 = head.get("emitting_three_hop_1024_rows") or {}
+        if em3.get("ms_device"):
+            sec[key].update({"emit3hop_ms_device": em3["ms_device"], "emit3hop_ms_host": em3["ms_host_arrays"], "emit3hop_entries": em3["entries"]})
         if head.get("lanes_sweep"):                   # the same 32 K sources in one call on 1 .. 4 lanes
             sec[key]["lanes_TEPS"] = {str(q["lanes"]): q["TEPS"] for q in head["lanes_sweep"]}
         if not args.no_parity and host is not None:
@@ -1661,6 +1700,7 @@ def main():
         em = detail.get("khop_materialised")
         if em:
             sec["materialised24"] = {k: {"ms_device": v["ms_per_batch"], "ms_host_arrays": v["host_arrays_ms"],
+                                         "ms_host_arrays_u64": v.get("host_arrays_u64_ms"),
                                          "ms_host_arrays_first": v["host_arrays_ms_first_batch"],
                                          "ms_stream_first_chunk": v["stream_ms"]["first_chunk"], "ms_stream_all": v["stream_ms"]["all_chunks"],
                                          "entries": v["out_nnz_per_batch"], "parity_ok": (v.get("parity") or {}).get("ok")}

@@ -23,6 +23,7 @@ FGPU_DEVICE = -7002
 
 u64p = C.POINTER(C.c_uint64)
 u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
 i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
 vp = C.c_void_p
@@ -72,9 +73,12 @@ SIGNATURES = {
     "fgpu_delta_lmxm": (C.c_int32, [vp, vpp, vp, vp, vp, vp]),
     "fgpu_expand": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, C.POINTER(u64p),
                                 C.POINTER(u64p), u64p, u64p]),
+    "fgpu_expand32": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, C.POINTER(u32p),
+                                  C.POINTER(u32p), u64p, u64p]),
     "fgpu_expand_mat": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, vpp, u64p]),
     "fgpu_expand_probe": (C.c_int32, [vp, u64p, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u8p, u64p]),
     "fgpu_expand_pairs": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u64p, C.c_int, vpp, C.POINTER(u64p), u64p, u64p]),
+    "fgpu_expand_pairs32": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u64p, C.c_int, vpp, C.POINTER(u32p), u64p, u64p]),
     "fgpu_expand_levels": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p]),
     "fgpu_expand_trail_counts": (C.c_int32, [vp, u64p, C.c_uint64, vpp, vpp, vpp, C.c_int, C.c_int, C.POINTER(u64p),
                                              C.POINTER(u64p), C.POINTER(u64p), u64p]),

@@ -208,12 +208,27 @@ __global__ __launch_bounds__(256) void bp_zero_rows_kernel(const u32* __restrict
     }
 }
 
-__global__ void bp_flag_count_kernel(const uint8_t* __restrict__ flag, u32 n, unsigned long long* __restrict__ out) {
+// (eight flags a load; one atomic per WORKGROUP: a byte per lane and an atomic per wavefront on the one counter took 105 us
+// for the 4 M flags of RMAT-22 — 8192 same-address atomics at ~5.6 ns each behind a 64-byte-per-instruction read)
+__global__ __launch_bounds__(256) void bp_flag_count_kernel(const uint8_t* __restrict__ flag, u32 n, unsigned long long* __restrict__ out) {
+    __shared__ u32 s_c[4];
     u32 c = 0;
-    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += flag[i] != 0;
+    const u32 n8 = n >> 3;
+    const u64* f8 = reinterpret_cast<const u64*>(flag);     // (device blocks are 256-byte aligned)
+    for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n8; i += gridDim.x * 256) {
+        u64 v = f8[i];
+        v |= v >> 4; v |= v >> 2; v |= v >> 1;               // bit 0 of every byte = the byte is non-zero
+        c += (u32)__popcll(v & 0x0101010101010101ull);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7u)) c += flag[(n8 << 3) + threadIdx.x] != 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if (lane_id() == 0 && c) atomicAdd(out, (unsigned long long)c);
+    if (lane_id() == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        if (t) atomicAdd(out, (unsigned long long)t);
+    }
 }
 
 // nnz and the order-independent checksum of the result (sum of row_hash(row) * dest_hash(dest), common.hpp) straight
@@ -1093,8 +1108,8 @@ static fgpu_info bp_count_flags(fgpu_ctx* ctx, BitState& s) {
     FGPU_HIP(hipMemsetAsync(acc.p, 0, sizeof(u64), ctx->stream()));
     if (s.n) {
         ProfScope ps(ctx, "bp_flag_count_kernel", (u64)s.n);
-        u32 grid = cdiv(s.n, 256);
-        if (grid > (u32)ctx->cus * 8) grid = ctx->cus * 8;
+        u32 grid = cdiv(s.n, 256 * 8);
+        if (grid > (u32)ctx->cus * 2) grid = ctx->cus * 2;
         hipLaunchKernelGGL(bp_flag_count_kernel, dim3(grid), dim3(256), 0, ctx->stream(), (const uint8_t*)s.flag.p, s.n,
                            (unsigned long long*)acc.p);
         FGPU_HIP(hipGetLastError());
@@ -1698,50 +1713,87 @@ fgpu_info bp_probe_rows(fgpu_ctx* ctx, const BitState& s, const fgpu_mat* m, con
 // few instructions per entry, on one lane), the pairs of a 2048-vertex tile landing in one contiguous piece whose start comes
 // from a scan of the tiles' popcounts; sort_u32_pairs_by_key then delivers the column ids in row order and the row pointers.
 constexpr u32 BP_PT = 2048;   // vertices per tile
-// rows are handled LN = 2^lsh lanes a row (a lane per word, words strided by LN); pc = the lane's popcount over its words
+// The rows that count (flagged, labelled) are compacted IN ORDER into a list first: one round of flag loads for the whole tile
+// instead of a flag -> row dependency per 16 rows (four rows in five are empty after a hop from a light frontier: the first
+// version walked all 2048 rows, 128 dependent steps a tile, 280 us for the count pass at RMAT-24), and the passes below run
+// four list rows per lane group in flight.  Rows are handled LN = 2^lsh lanes a row (a lane per word, words strided by LN).
 template <bool FILL>
 __global__ __launch_bounds__(256) void bp_pairs_kernel(const u64* __restrict__ y, u32 n, u32 w, u32 ws, u32 lsh, const uint8_t* __restrict__ flag,
                                                       const u64* __restrict__ label, const u32* __restrict__ perm,
                                                       u32* __restrict__ tile_cnt, const u64* __restrict__ tile_off,
                                                       u32* __restrict__ key, u32* __restrict__ val) {
-    __shared__ u32 s_row[BP_PT + 1];          // FILL: exclusive prefix of the rows' popcounts
+    __shared__ u32 s_list[BP_PT];             // the tile's rows that count, ascending
+    __shared__ u32 s_row[BP_PT + 1];          // FILL: exclusive prefix of their popcounts
     __shared__ u32 s_wave[4];
     const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const u32 LN = 1u << lsh, wl = tid & (LN - 1u), RPS = 256u >> lsh;      // rows per step of the workgroup
+    const u32 LN = 1u << lsh, wl = tid & (LN - 1u), grp = tid >> lsh, RPS = 256u >> lsh;      // rows per step of the workgroup
     const u32 v0 = blockIdx.x * BP_PT;
-    const u32 rows = n - v0 < BP_PT ? n - v0 : BP_PT;
+    // ---- the list: thread t owns vertices v0 + 8 t .. + 7
+    u32 onbits = 0;
+    {
+        const u32 base = v0 + tid * 8u;
+        u64 f = 0;
+        if (!flag) f = ~0ull;
+        else if (base + 8u <= n) f = *reinterpret_cast<const u64*>(flag + base);
+        else
+            for (u32 j = 0; j < 8u; ++j)
+                if (base + j < n && flag[base + j]) f |= 0xffull << (8u * j);
+        for (u32 j = 0; j < 8u; ++j)
+            if (base + j < n && ((f >> (8u * j)) & 0xffull)) onbits |= 1u << j;
+        if (label && onbits) onbits &= (u32)(label[base >> 6] >> (base & 63u)) & 0xffu;     // (8 | 64: the byte never straddles a word)
+    }
+    u32 nlist;
+    {
+        const u32 c = (u32)__popc(onbits);
+        u32 inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)inc, o, 64); if ((int)lane >= o) inc += t; }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        u32 base = 0;
+        for (u32 q = 0; q < wv; ++q) base += s_wave[q];
+        nlist = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        u32 at = base + inc - c;
+        for (u32 j = 0; j < 8u; ++j)
+            if ((onbits >> j) & 1u) s_list[at++] = v0 + tid * 8u + j;
+        __syncthreads();
+    }
+    // ---- pass A: popcount of every listed row, four rows per lane group in flight
     u32 total = 0;
-    // pass A: popcount of every row (0 for unflagged / unlabelled rows)
-    for (u32 r0 = 0; r0 < rows; r0 += RPS) {
-        const u32 r = r0 + (tid >> lsh);
-        u32 pc = 0;
-        if (r < rows) {
-            const u32 v = v0 + r;
-            bool on = !flag || flag[v];
-            if (on && label) on = (label[v >> 6] >> (v & 63)) & 1ull;
-            if (on) {
+    for (u32 i0 = 0; i0 < nlist; i0 += 4u * RPS) {
+        u32 pc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 i = i0 + q * RPS + grp;
+            if (i < nlist) {
+                const u32 v = s_list[i];
                 const u64* row = y + (size_t)(perm ? perm[v] : v) * ws;
-                for (u32 k = wl; k < w; k += LN) pc += (u32)__popcll(row[k]);
+                for (u32 k = wl; k < w; k += LN) pc[q] += (u32)__popcll(row[k]);
             }
         }
-        for (u32 d = 1; d < LN; d <<= 1) pc += (u32)__shfl_xor((int)pc, (int)d, 64);
-        if (FILL) { if (r < rows && wl == 0) s_row[r] = pc; }
-        else if (wl == 0) total += pc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            for (u32 d = 1; d < LN; d <<= 1) pc[q] += (u32)__shfl_xor((int)pc[q], (int)d, 64);
+            const u32 i = i0 + q * RPS + grp;
+            if (FILL) { if (i < nlist && wl == 0) s_row[i] = pc[q]; }
+            else if (wl == 0) total += pc[q];
+        }
     }
     if (!FILL) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) total += (u32)__shfl_xor((int)total, d, 64);
+        __syncthreads();
         if (lane == 0) s_wave[wv] = total;
         __syncthreads();
         if (tid == 0) tile_cnt[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         return;
     }
     __syncthreads();
-    // exclusive scan of s_row[0 .. rows): 8 rows a thread, then the wavefront / workgroup prefix
+    // exclusive scan of s_row[0 .. nlist): 8 rows a thread, then the wavefront / workgroup prefix
     {
         u32 loc[8], sum = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const u32 i = tid * 8 + j; loc[j] = i < rows ? s_row[i] : 0u; sum += loc[j]; }
+        for (int j = 0; j < 8; ++j) { const u32 i = tid * 8 + j; loc[j] = i < nlist ? s_row[i] : 0u; sum += loc[j]; }
         u32 inc = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)inc, o, 64); if ((int)lane >= o) inc += t; }
@@ -1750,37 +1802,47 @@ __global__ __launch_bounds__(256) void bp_pairs_kernel(const u64* __restrict__ y
         u32 base = 0;
         for (u32 q = 0; q < wv; ++q) base += s_wave[q];
         u32 run = base + inc - sum;
-        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const u32 i = tid * 8 + j; if (i < rows) s_row[i] = run; run += loc[j]; }
+        for (int j = 0; j < 8; ++j) { const u32 i = tid * 8 + j; if (i < nlist) s_row[i] = run; run += loc[j]; }
     }
     __syncthreads();
-    // pass B: a lane per word writes the word's bits (rows re-read: the tile's non-zero rows are still in the L2)
+    // ---- pass B: a lane per word writes the word's bits (rows re-read: the tile's non-zero rows are still in the L2).  The
+    // pairs of ONE row may leave in any order of their keys — the sort is by key, and only the order of the VERTICES inside a
+    // key matters; a row is one vertex.
     const u32 out0 = (u32)tile_off[blockIdx.x];
-    for (u32 r0 = 0; r0 < rows; r0 += RPS) {
-        const u32 r = r0 + (tid >> lsh);
-        const u32 v = v0 + (r < rows ? r : 0u);
-        bool on = r < rows && (!flag || flag[v]);
-        if (on && label) on = (label[v >> 6] >> (v & 63)) & 1ull;
-        const u64* row = y + (size_t)(perm ? perm[v] : v) * ws;
-        // words in ROW order per lane group: lane wl takes words wl, wl + LN, ...; the pairs of a row may leave in any order of
-        // their keys (the sort is by key; only the order of the VERTICES inside one key matters, and a row is one vertex)
-        u32 at = on ? out0 + s_row[r] : 0u;
+    for (u32 i0 = 0; i0 < nlist; i0 += 2u * RPS) {
         for (u32 k0 = 0; k0 < w; k0 += LN) {
             const u32 k = k0 + wl;
-            u64 word = (on && k < w) ? row[k] : 0ull;
-            const u32 pc = (u32)__popcll(word);
-            u32 inc = pc;                                  // prefix over the LN lanes of the row
-            for (u32 d = 1; d < LN; d <<= 1) { const u32 t = (u32)__shfl_up((int)inc, (int)d, 64); if (wl >= d) inc += t; }
-            u32 o = at + inc - pc;
-            while (word) {
-                const u32 b = (u32)__builtin_ctzll(word);
-                word &= word - 1ull;
-                key[o] = k * 64u + b;
-                val[o] = v;
-                ++o;
+            u64 word[2];
+            u32 vv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32 i = i0 + q * RPS + grp;
+                vv[q] = i < nlist ? s_list[i] : 0xFFFFFFFFu;
+                word[q] = (vv[q] != 0xFFFFFFFFu && k < w) ? y[(size_t)(perm ? perm[vv[q]] : vv[q]) * ws + k] : 0ull;
             }
-            at += (u32)__shfl((int)inc, (int)((lane | (LN - 1u))), 64);   // the row's total over this round of words
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32 i = i0 + q * RPS + grp;
+                const u32 pc = (u32)__popcll(word[q]);
+                u32 inc = pc;                                  // prefix over the LN lanes of the row
+                for (u32 d = 1; d < LN; d <<= 1) { const u32 t = (u32)__shfl_up((int)inc, (int)d, 64); if (wl >= d) inc += t; }
+                const u32 rowtot = (u32)__shfl((int)inc, (int)(lane | (LN - 1u)), 64);
+                u32 at = 0;
+                if (i < nlist) {
+                    at = s_row[i];
+                    if (wl == 0 && k0 + LN < w) s_row[i] = at + rowtot;      // (the row's next round of words goes on from here)
+                }
+                u32 o = out0 + at + inc - pc;
+                u64 wd = word[q];
+                while (wd) {
+                    const u32 b = (u32)__builtin_ctzll(wd);
+                    wd &= wd - 1ull;
+                    key[o] = k * 64u + b;
+                    val[o] = vv[q];
+                    ++o;
+                }
+            }
         }
     }
 }

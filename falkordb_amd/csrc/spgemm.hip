@@ -1097,10 +1097,11 @@ __global__ void pairs_len_kernel(const u32* __restrict__ rowptr, const u32* __re
     pos[i] = p;
 }
 // a thread per OUTPUT entry: its row by a search of the (new) row pointers, its destination from the row's first kept entry
-template <typename RowT>
+// (out_dest nullable: the 32-bit form of an unpinned batch ships the result's own column ids and only needs the row column)
+template <typename RowT, typename DestT>
 __global__ __launch_bounds__(256) void pairs_fill_kernel(const u32* __restrict__ newptr, const u32* __restrict__ pos,
                                                          const u32* __restrict__ colidx, u32 nsrc, u64 n,
-                                                         RowT* __restrict__ out_row, u64* __restrict__ out_dest) {
+                                                         RowT* __restrict__ out_row, DestT* __restrict__ out_dest) {
     for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
         u32 lo = 0, hi = nsrc - 1;                           // largest row with newptr[row] <= q
         while (lo < hi) {
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(256) void pairs_fill_kernel(const u32* __restrict__
             if (newptr[mid] <= q) lo = mid; else hi = mid - 1;
         }
         out_row[q] = (RowT)lo;
-        out_dest[q] = (u64)colidx[pos[lo] + (u32)(q - newptr[lo])];
+        if (out_dest) out_dest[q] = (DestT)colidx[pos[lo] + (u32)(q - newptr[lo])];
     }
 }
 
@@ -1364,10 +1365,10 @@ fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, con
     return i;
 }
 
-fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
-                            const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
-                            const uint64_t* pinned_dest, int row_bits, void** out_row, uint64_t** out_dest, uint64_t* out_n,
-                            uint64_t* flops) {
+static fgpu_info expand_pairs_impl(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                                   const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                                   const uint64_t* pinned_dest, int row_bits, int dest_bits, void** out_row, void** out_dest, uint64_t* out_n,
+                                   uint64_t* flops) {
     FGPU_REQUIRE(ctx && out_row && out_dest && out_n, FGPU_NULL_POINTER, "fgpu_expand_pairs: NULL argument");
     FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand_pairs: NULL src_ids");
     FGPU_REQUIRE(row_bits == 16 || row_bits == 32, FGPU_INVALID, "fgpu_expand_pairs: row_bits must be 16 or 32");
@@ -1414,37 +1415,55 @@ fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
         }
     }
     if (n == 0) return FGPU_OK;
-    const size_t rb = row_bits / 8;
-    DevBuf<u64> ddest;
-    DevBuf<uint8_t> drow;
-    FGPU_TRY(ddest.alloc(ctx, n));
+    const size_t rb = row_bits / 8, db = dest_bits / 8;
+    // the 32-bit form of a batch without pinned rows: the destination column IS the result's column-id array
+    const bool dest_is_colidx = dest_bits == 32 && rowptr == r->rowptr;
+    DevBuf<uint8_t> ddest, drow;
+    if (!dest_is_colidx) FGPU_TRY(ddest.alloc(ctx, n * db));
     FGPU_TRY(drow.alloc(ctx, n * rb));
     {
-        ProfScope ps(ctx, "pairs_fill_kernel", n * (4 + 8 + rb));
+        ProfScope ps(ctx, "pairs_fill_kernel", n * (4 + (dest_is_colidx ? 0 : db) + rb));
         u32 grid = cdiv(n, 256 * 4);
         if (grid > (u32)ctx->cus * 16) grid = ctx->cus * 16;
-        if (row_bits == 16)
-            hipLaunchKernelGGL(pairs_fill_kernel<uint16_t>, dim3(grid ? grid : 1), dim3(256), 0, st, rowptr, first, (const u32*)r->colidx, k,
-                               n, (uint16_t*)drow.p, ddest.p);
-        else
-            hipLaunchKernelGGL(pairs_fill_kernel<u32>, dim3(grid ? grid : 1), dim3(256), 0, st, rowptr, first, (const u32*)r->colidx, k, n,
-                               (u32*)drow.p, ddest.p);
+        if (!grid) grid = 1;
+#define PAIRS_FILL(RT, DT)                                                                                                     \
+        hipLaunchKernelGGL((pairs_fill_kernel<RT, DT>), dim3(grid), dim3(256), 0, st, rowptr, first, (const u32*)r->colidx, k, n, \
+                           (RT*)drow.p, (DT*)ddest.p)
+        if (row_bits == 16) { if (dest_bits == 64) PAIRS_FILL(uint16_t, u64); else PAIRS_FILL(uint16_t, u32); }
+        else { if (dest_bits == 64) PAIRS_FILL(u32, u64); else PAIRS_FILL(u32, u32); }
+#undef PAIRS_FILL
         FGPU_HIP(hipGetLastError());
     }
     void* hrow = ctx->result_alloc(n * rb);
-    u64* hdest = (u64*)ctx->result_alloc(n * sizeof(u64));
+    void* hdest = ctx->result_alloc(n * db);
     if (!hrow || !hdest) {
         ctx->host_free(hrow); ctx->host_free(hdest);
         set_error("fgpu_expand_pairs: host allocation failed");
         return FGPU_OOM;
     }
-    fgpu_info i = ctx->d2h(hdest, ddest.p, n * sizeof(u64));
+    fgpu_info i = ctx->d2h(hdest, dest_is_colidx ? (const void*)r->colidx : (const void*)ddest.p, n * db);
     if (i == FGPU_OK) i = ctx->d2h(hrow, drow.p, n * rb);
     if (i != FGPU_OK) { ctx->host_free(hrow); ctx->host_free(hdest); return i; }
     *out_row = hrow;
     *out_dest = hdest;
     *out_n = n;
     return FGPU_OK;
+}
+
+fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                            const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                            const uint64_t* pinned_dest, int row_bits, void** out_row, uint64_t** out_dest, uint64_t* out_n,
+                            uint64_t* flops) {
+    return expand_pairs_impl(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, pinned_dest, row_bits, 64, out_row, (void**)out_dest,
+                             out_n, flops);
+}
+
+fgpu_info fgpu_expand_pairs32(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                              const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                              const uint64_t* pinned_dest, int row_bits, void** out_row, uint32_t** out_dest, uint64_t* out_n,
+                              uint64_t* flops) {
+    return expand_pairs_impl(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, pinned_dest, row_bits, 32, out_row, (void**)out_dest,
+                             out_n, flops);
 }
 
 fgpu_info fgpu_expand_probe(fgpu_ctx* ctx, const uint64_t* src_ids, const uint64_t* dst_ids, uint64_t nsrc, const fgpu_mat* const* m,
@@ -1647,6 +1666,33 @@ fgpu_info fgpu_expand_stream_next(fgpu_expand_stream* s, uint64_t* first_row, ui
     s->head = (s->head + 1) % NS;
     --s->inflight;
     s->held = true;
+    return FGPU_OK;
+}
+
+fgpu_info fgpu_expand32(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc, const fgpu_mat* const* m,
+                        const fgpu_mat* const* dp, const fgpu_mat* const* dm, int nhops,
+                        const uint64_t* dst_label_bitmap, uint32_t** out_rowptr, uint32_t** out_dest,
+                        uint64_t* out_nnz, uint64_t* flops) {
+    FGPU_REQUIRE(ctx && out_rowptr && out_dest && out_nnz, FGPU_NULL_POINTER, "fgpu_expand32: NULL argument");
+    FGPU_REQUIRE(nsrc == 0 || src_ids, FGPU_NULL_POINTER, "fgpu_expand32: NULL src_ids");
+    *out_rowptr = nullptr; *out_dest = nullptr; *out_nnz = 0;
+    if (flops) *flops = 0;
+    fgpu_mat* r = nullptr;
+    FGPU_TRY(expand_device(ctx, src_ids, nsrc, m, dp, dm, nhops, dst_label_bitmap, &r, flops));
+    struct Rel { fgpu_mat* r; ~Rel() { if (r) mat_release(r); } } rel{r};
+    FGPU_REQUIRE(!r->is_hyper() && r->nrows == nsrc, FGPU_INVALID, "fgpu_expand32: the chain's result is not a dense-row CSR");
+    // the device arrays as they are: two DMAs into pinned result blocks, nothing widened anywhere
+    u32* hrp = (u32*)ctx->result_alloc((nsrc + 1) * sizeof(u32));
+    u32* hci = (u32*)ctx->result_alloc((r->nnz ? r->nnz : 1) * sizeof(u32));
+    fgpu_info i = (hrp && hci) ? FGPU_OK : FGPU_OOM;
+    if (i == FGPU_OK) i = ctx->d2h(hrp, r->rowptr, (nsrc + 1) * sizeof(u32));
+    if (i == FGPU_OK && r->nnz) i = ctx->d2h(hci, r->colidx, r->nnz * sizeof(u32));
+    if (i != FGPU_OK) {
+        ctx->host_free(hrp); ctx->host_free(hci);
+        if (i == FGPU_OOM) set_error("fgpu_expand32: host allocation failed");
+        return i;
+    }
+    *out_rowptr = hrp; *out_dest = hci; *out_nnz = r->nnz;
     return FGPU_OK;
 }
 

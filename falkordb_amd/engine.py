@@ -352,6 +352,25 @@ def expand(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
     return rowptr, dest, flops.value
 
 
+def expand32(ctx: Context, src_ids, m, dp=None, dm=None, dst_label_bitmap=None):
+    """fgpu_expand32: the same result in the device's own 32-bit form — (rowptr uint32[nsrc + 1], dest uint32[nnz], flops):
+    two DMAs of the arrays as they lie, half the PCIe bytes of fgpu_expand."""
+    src = _u64(src_ids)
+    nh = len(m)
+    am = _hop_arrays(m)
+    adp = _hop_arrays(dp) if dp is not None else None
+    adm = _hop_arrays(dm) if dm is not None else None
+    lab = _u64(dst_label_bitmap) if dst_label_bitmap is not None else None
+    u32p = C.POINTER(C.c_uint32)
+    rp, ci = u32p(), u32p()
+    nnz, flops = C.c_uint64(), C.c_uint64()
+    check(ctx.lib.fgpu_expand32(ctx._h, _p(src), len(src), am, adp, adm, nh, _p(lab), C.byref(rp), C.byref(ci),
+                                C.byref(nnz), C.byref(flops)))
+    rowptr = ctx._take(rp, len(src) + 1, dtype=np.uint32)
+    dest = ctx._take(ci, max(nnz.value, 1), dtype=np.uint32)[: nnz.value]
+    return rowptr, dest, flops.value
+
+
 class ExpandStream:
     """fgpu_expand_stream_*: the chain's result handed over in chunks of whole source rows while later chunks are still
     on the link.  Iterating yields (first_row, rowptr, dest) — views valid until the next step."""

@@ -466,8 +466,7 @@ int fh_cond_traverse_batch(fh_graph* g, const char* spec, const int64_t* src, co
             const size_t nn = rows.size();
             u64* r_ = (u64*)malloc((nn ? nn : 1) * sizeof(u64));
             u64* d_ = (u64*)malloc((nn ? nn : 1) * sizeof(u64));
-            for (size_t q = 0; q < nn; ++q) r_[q] = rows.row_pin[q];
-            if (nn) memcpy(d_, rows.dest_pin, nn * sizeof(u64));
+            for (size_t q = 0; q < nn; ++q) { r_[q] = rows.row_at(q); d_[q] = rows.dest_at(q); }
             *out_row = r_;
             *out_dest = d_;
             rows.release_pinned();                           // (not kept across calls: the context may be gone before this thread is)

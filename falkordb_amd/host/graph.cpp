@@ -312,7 +312,6 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
         if (!any_pinned) pinned_to.clear();
     }
     const bool want_edge = bind_relationship && hops.size() == 1;
-    if (k > 65536) throw GrbError(FGPU_INVALID, "CondTraverse::expand_batch: more than 65536 rows in one batch");
     bool all_pinned = !pinned_to.empty();
     for (u64 i = 0; i < k && all_pinned; ++i)
         if (src_ids[i] != ~0ull && pinned_to[i] == ~0ull) all_pinned = false;
@@ -329,13 +328,15 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
         lap("fgpu_expand_probe");
     } else {
     void* prow = nullptr;
-    u64* pdest = nullptr;
-    check(fgpu_expand_pairs(ctx, src_ids.data(), k, hl.m.data(), hl.dp.data(), hl.dm.data(), (int)hops.size(),
-                            bitmap.empty() ? nullptr : bitmap.data(), pinned_to.empty() ? nullptr : pinned_to.data(), 16, &prow,
-                            &pdest, &np, &fl),
+    uint32_t* pdest = nullptr;
+    const int row_bits = k > 65536 ? 32 : 16;                // (more than 64 child batches coalesced into one call)
+    check(fgpu_expand_pairs32(ctx, src_ids.data(), k, hl.m.data(), hl.dp.data(), hl.dm.data(), (int)hops.size(),
+                              bitmap.empty() ? nullptr : bitmap.data(), pinned_to.empty() ? nullptr : pinned_to.data(), row_bits, &prow,
+                              &pdest, &np, &fl),
           "CondTraverse::expand_batch");
     rows.pin_ctx = ctx;
-    rows.row_pin = (const uint16_t*)prow;
+    rows.row_pin = row_bits == 16 ? (const uint16_t*)prow : nullptr;
+    rows.row_pin32 = row_bits == 32 ? (const uint32_t*)prow : nullptr;
     rows.dest_pin = pdest;
     rows.n_pin = np;
     if (flops) *flops = fl;
@@ -383,16 +384,17 @@ bool CondTraverseOp::expand_batch(const Graph& g, const std::vector<Value>& src,
 void ExpandedRows::release_pinned() {
     if (pin_ctx) {
         if (row_pin) fgpu_free(pin_ctx, (void*)row_pin);
+        if (row_pin32) fgpu_free(pin_ctx, (void*)row_pin32);
         if (dest_pin) fgpu_free(pin_ctx, (void*)dest_pin);
     }
-    pin_ctx = nullptr; row_pin = nullptr; dest_pin = nullptr; n_pin = 0;
+    pin_ctx = nullptr; row_pin = nullptr; row_pin32 = nullptr; dest_pin = nullptr; n_pin = 0;
 }
 
 void ExpandedRows::materialize() {
     if (!pinned()) return;
     active_row.resize(n_pin);
-    dest.assign(dest_pin, dest_pin + n_pin);
-    for (size_t i = 0; i < n_pin; ++i) active_row[i] = row_pin[i];
+    dest.resize(n_pin);
+    for (size_t i = 0; i < n_pin; ++i) { active_row[i] = row_pin ? (u64)row_pin[i] : (u64)row_pin32[i]; dest[i] = dest_pin[i]; }
     release_pinned();
 }
 

@@ -436,12 +436,16 @@ struct ExpandedRows {
     std::vector<u64> active_row;   // index into the input batch
     std::vector<u64> dest;
     std::vector<u64> edge;         // empty unless bind_relationship
-    // The batched path hands over the two columns as the DEVICE built them (fgpu_expand_pairs): pinned blocks of the context's
-    // pool filled by DMA, 16-bit row indices (a child batch holds at most 1024 rows, batch.rs:81).  They are owned until
-    // clear(); materialize() copies them into the vectors above for the rare consumers that edit the columns in place.
+    // The batched path hands over the two columns as the DEVICE built them (fgpu_expand_pairs32): pinned blocks of the context's
+    // pool filled by DMA — 16-bit row indices (a child batch holds at most 1024 rows, batch.rs:81; 32-bit ones when a host layer
+    // coalesces more than 65536 rows into one call) and the destinations as the 32-bit node ids the device works in (every node
+    // id of a traversed graph fits 32 bits: tensor.rs:154-163 demands it of the multi-edge keys); row_at / dest_at widen on
+    // access, which is where the reference's NodeId(u64) is needed.  They are owned until clear(); materialize() copies them into
+    // the vectors above for the rare consumers that edit the columns in place.
     fgpu_ctx* pin_ctx = nullptr;
     const uint16_t* row_pin = nullptr;
-    const u64* dest_pin = nullptr;
+    const uint32_t* row_pin32 = nullptr;
+    const uint32_t* dest_pin = nullptr;
     size_t n_pin = 0;
     ExpandedRows() = default;
     ExpandedRows(const ExpandedRows&) = delete;
@@ -449,8 +453,8 @@ struct ExpandedRows {
     ~ExpandedRows() { release_pinned(); }
     bool pinned() const { return dest_pin != nullptr; }
     size_t size() const { return pinned() ? n_pin : dest.size(); }
-    u64 row_at(size_t i) const { return pinned() ? (u64)row_pin[i] : active_row[i]; }
-    u64 dest_at(size_t i) const { return pinned() ? dest_pin[i] : dest[i]; }
+    u64 row_at(size_t i) const { return pinned() ? (row_pin ? (u64)row_pin[i] : (u64)row_pin32[i]) : active_row[i]; }
+    u64 dest_at(size_t i) const { return pinned() ? (u64)dest_pin[i] : dest[i]; }
     void release_pinned();
     void materialize();
     void clear() { active_row.clear(); dest.clear(); edge.clear(); release_pinned(); }

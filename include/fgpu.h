@@ -241,6 +241,16 @@ fgpu_info fgpu_expand(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
                       uint64_t** out_rowptr, uint64_t** out_dest, uint64_t* out_nnz,
                       uint64_t* flops);
 
+/* fgpu_expand with the result in the device's own 32-bit form: out_rowptr[nsrc + 1] and out_dest[nnz] are uint32_t (the
+ * engine's row pointers and node ids are 32-bit throughout; a result of 2^32 entries or more is refused by every emitting
+ * entry) — two DMAs of the arrays as they lie, nothing widened on the device or the host, half the PCIe bytes of fgpu_expand.
+ * Release both with fgpu_free. */
+fgpu_info fgpu_expand32(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                      const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                      const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                      uint32_t** out_rowptr, uint32_t** out_dest, uint64_t* out_nnz,
+                      uint64_t* flops);
+
 /* Same chain, the result F left on the device as a matrix handle — what the reference holds between
  * `F = delta_lmxm(...)` and `F.iter(...)` (cond_traverse.rs:602-608: F IS a Matrix<bool>; its rows are then walked
  * with the row iterator, :644).  *out is a BOOL snapshot with nsrc rows (row i = source i), dest ascending and unique
@@ -263,6 +273,17 @@ fgpu_info fgpu_expand_pairs(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsr
                             const fgpu_mat* const* m, const fgpu_mat* const* dp,
                             const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
                             const uint64_t* pinned_dest, int row_bits, void** out_row, uint64_t** out_dest,
+                            uint64_t* out_n, uint64_t* flops);
+
+/* The same two columns with the destinations as the 32-bit node ids the device holds (node ids of a traversed graph fit 32
+ * bits: Tensor's multi-edge keys demand it, tensor.rs:154-163): half the bytes over PCIe for the column that IS the result —
+ * without pinned rows it is the chain's own column-id array, copied out as it lies — and what CondTraverseOp's C++ twin takes
+ * (falkordb_amd/host/graph.cpp: ExpandedRows widens on access, where the reference's NodeId(u64) is needed).  Otherwise
+ * identical to fgpu_expand_pairs. */
+fgpu_info fgpu_expand_pairs32(fgpu_ctx* ctx, const uint64_t* src_ids, uint64_t nsrc,
+                            const fgpu_mat* const* m, const fgpu_mat* const* dp,
+                            const fgpu_mat* const* dm, int nhops, const uint64_t* dst_label_bitmap,
+                            const uint64_t* pinned_dest, int row_bits, void** out_row, uint32_t** out_dest,
                             uint64_t* out_n, uint64_t* flops);
 
 /* The same chain when EVERY row has a pre-bound destination — CondTraverse with `to` bound on the whole batch, the multi-hop

@@ -726,6 +726,44 @@ def test_expand_host_arrays_pinned_and_staged_paths_agree_with_the_oracle(ctx, r
         ctx.set_option("pinned_results", 1)
 
 
+@pytest.mark.parametrize("emit_sort", [1, 0])
+def test_expand32_and_both_emission_forms_agree_with_the_oracle(ctx, rmat18, emit_sort):
+    """fgpu_expand32 — the result in the device's own 32-bit form, two DMAs, nothing widened — entry for entry against the
+    oracle's chain, with the bit state turned into rows by pairs + the stable sort (expand_emit_sort = 1, round 6) and by the
+    ballot transpose of rounds 3-5 (0); 2 and 3 hops (CSR and bit-form chains), dirty layers, NULL rows and a label."""
+    A, a = rmat18
+    rng = np.random.default_rng(7)
+    dm = oracle.sample(a, 0x18D, 500)
+    DM = up(ctx, dm)
+    src = np.arange(11, a.nrows, 499, dtype=U64)
+    src[5] = np.iinfo(np.uint64).max
+    label = oracle.mix64(np.arange(a.nrows, dtype=U64)) % U64(5) != 0
+    bits = oracle.bits_from_ids(a.nrows, np.nonzero(label)[0])
+    try:
+        ctx.set_option("expand_emit_sort", emit_sort)
+        for hops, layers, dev in ((2, [(a, None, None)] * 2, ([A, A],)), (3, [(a, None, dm)] * 3, ([A] * 3, None, [DM] * 3))):
+            keep = src != np.iinfo(np.uint64).max
+            f = oracle.build_csr(len(src), a.nrows, np.nonzero(keep)[0].astype(U64), src[keep])
+            fl = 0
+            for (m_, dp_, dm_) in layers:
+                f, x = oracle.delta_lmxm_omp(f, m_, dp_, dm_, 8)
+                fl += x
+            rowptr, dest, flops = engine.expand32(ctx, src, *dev)
+            assert rowptr.dtype == np.uint32 and dest.dtype == np.uint32 and flops == fl
+            np.testing.assert_array_equal(rowptr, f.rowptr.astype(np.uint32))
+            np.testing.assert_array_equal(dest, f.colidx.astype(np.uint32))
+            assert f.nnz > 1_000_000
+            if hops == 2:
+                rowptr, dest, _ = engine.expand32(ctx, src, *dev, dst_label_bitmap=bits)
+                sel = label[f.colidx.astype(np.int64)]
+                np.testing.assert_array_equal(dest, f.colidx[sel].astype(np.uint32))
+                rows = np.repeat(np.arange(f.nrows), np.diff(f.rowptr).astype(np.int64))[sel]
+                np.testing.assert_array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=f.nrows))]).astype(np.uint32))
+    finally:
+        ctx.set_option("expand_emit_sort", 1)
+        DM.free()
+
+
 @pytest.mark.parametrize("chunk_rows,dest_bits", [(1, 64), (7, 32), (64, 64), (4096, 32)])
 def test_expand_stream_chunks_concatenate_to_the_oracle_result(ctx, rmat18, chunk_rows, dest_bits):
     """fgpu_expand_stream_*: what CondTraverseOp::expand_batch walks (cond_traverse.rs:644-751), chunk by chunk — the

@@ -34,9 +34,10 @@ def test_host_layer_reaches_the_engine_only_through_the_c_abi():
                                                                         "libfalkor_host.so")],
                          capture_output=True, text=True, check=True).stdout
     used = set(re.findall(r" U (fgpu_[a-z0-9_]+)", out))
-    # (expand_batch takes the chain's result as device-built columns since round 5 — fgpu_expand_pairs, or fgpu_expand_probe when
-    # every row has a bound destination; algo_bfs fetches into pinned blocks)
-    assert {"fgpu_init", "fgpu_expand_pairs", "fgpu_expand_probe", "fgpu_host_alloc",
+    # (expand_batch takes the chain's result as device-built columns since round 5 — fgpu_expand_pairs32 since round 6: the
+    # destinations as the device's 32-bit node ids — or fgpu_expand_probe when every row has a bound destination; algo_bfs
+    # fetches into pinned blocks)
+    assert {"fgpu_init", "fgpu_expand_pairs32", "fgpu_expand_probe", "fgpu_host_alloc",
             "fgpu_bfs", "fgpu_mat_merge", "fgpu_mat_probe", "fgpu_delta_lmxm"} <= used
     assert not re.search(r" U hip[A-Z]", out), "host layer must not call HIP directly"
 
