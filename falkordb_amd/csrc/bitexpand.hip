@@ -1487,7 +1487,6 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             if (wgs < 1) wgs = 1;
             if (wgs > 4) wgs = 4;
             const u32 ggrid = (u32)ctx->cus * wgs;
-            ProfScope psg(ctx, "bp_pull_groups_kernel", 0);      // (inside the hop's record above: the row groups' share of it)
 #define BP_GROUPS(LN)                                                                                                   \
     do {                                                                                                                \
         if (lds_g > 48 * 1024)                                                                                          \
