@@ -36,7 +36,7 @@ namespace fgpu {
 constexpr u32 XP_FIRST = 0x80000000u;   // bit 31 of a packed entry: first entry of its (partition, row) run
 constexpr u32 XP_SPAN = 768;       // a chunk spans < XP_SPAN of the key (entry index + XP_RUNW x run index) inside its partition:
 constexpr u32 XP_RUNW = 8;         //   <= XP_SPAN entries and <= XP_RUNS runs (the rows of its LDS tile)
-constexpr int XP_FOLD_THREADS = 256;
+constexpr int XP_FOLD_THREADS = 512;   // 8 wavefronts share one copy of the checksum tables
 constexpr u32 XP_RUNS = XP_SPAN / XP_RUNW;
 
 struct BpXPlan {
@@ -426,6 +426,8 @@ __global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_kernel(const u64* __r
     const u32 lane = lane_id(), wl = lane % QL, slot = lane / QL;
     const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const u32 nwaves = (gridDim.x * blockDim.x) >> 6;
+    constexpr u32 STR = 2 * QL + 1;                          // stage row stride in words (odd: the transposed reads spread over the banks)
+    u64* stg = s_tab + (MODE == 2 ? (size_t)fin.w * 256 : 0) + (size_t)(threadIdx.x >> 6) * (32 * STR);   // MODE 2: 32 staged rows a wavefront
     u64 f_cnt = 0, f_sum = 0;
     for (u32 g = wave; g < ng; g += nwaves) {
         u64 nw[8];
@@ -441,13 +443,17 @@ __global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_kernel(const u64* __r
         const u64 tw = fin.tbits ? xp_uniform64(fin.tbits[g]) : 0ull;      // (clean layers: no touched rows, no bitmap)
         const u32 tp = fin.tbits ? (u32)__builtin_amdgcn_readfirstlane((int)fin.tpref[g]) : 0u;
         const u64 lb = fin.label ? xp_uniform64(fin.label[g]) : ~0ull;
-        // The kernel is VALU-bound, not memory-bound (round 6: two steps of loads in flight changed nothing; ~330 VALU
-        // instructions per step at 64 / QL rows a step): the part of a partial row's index that is the same for the whole step —
-        // pb[k] + the set bits of nw[k] below the step — is scalar work, a lane adds the popcount of the step's own (<= 32-bit)
-        // field below its slot; a row that has no piece in partition k loads the plan's all-zero partial row (zrow) instead of
-        // being masked out afterwards, so the OR is unconditional.
+        // Where the time goes (PMC, round 6, checksum on): not the partial rows — two steps of loads in flight changed nothing —
+        // but LDS: 83 % of the LDS-active cycles were bank conflicts.  With a row's words spread over QL lanes, one look-up
+        // instruction reads 2 QL different tables, and entry e of EVERY table sits in the same bank pair: 64 random 8-byte reads
+        // over 16 bank pairs.  The look-ups now run after a half group (32 rows) is staged in LDS with a lane per ROW: an
+        // instruction then reads ONE table per half wavefront (16 addresses, broadcast, no conflict).  The index arithmetic of a
+        // step is scalar where it is the same for the step; a row without a piece in partition k loads the plan's zero row.
 #pragma unroll 1
-        for (u32 r0 = 0; r0 < 64; r0 += SLOTS) {
+        for (u32 hf0 = 0; hf0 < 64; hf0 += (SLOTS >= 64 ? 64 : 32)) {        // (SLOTS = 64: one step is the whole group)
+        u32 staged = 0;                                       // (wave-uniform) rows of this half staged for the look-ups
+#pragma unroll 1
+        for (u32 r0 = hf0; r0 < hf0 + 32 && r0 < 64; r0 += SLOTS) {
             if (((any >> r0) & (SLOTS == 64 ? ~0ull : ((1ull << (SLOTS % 64)) - 1ull))) == 0ull) continue;   // (wave-uniform)
             const u32 r = r0 + slot;
             const u64 below = (1ull << r) - 1ull;
@@ -478,17 +484,45 @@ __global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_kernel(const u64* __r
                 // (an all-zero word looks up entry 0 of its tables — zero — so nothing needs a test: words at or past fin.w are
                 // zero by construction and their tables, past the end of s_tab, are never multiplied in)
                 const u64 w0 = counted ? (((u64)a.y << 32) | a.x) : 0ull, w1 = counted ? (((u64)a.w << 32) | a.z) : 0ull;
-                const u32 k0 = 2 * wl < fin.w ? 2 * wl : 0u, k1 = 2 * wl + 1 < fin.w ? 2 * wl + 1 : 0u;
-                const u64* t0 = s_tab + (size_t)k0 * 256;
-                const u64* t1 = s_tab + (size_t)k1 * 256;
-                u64 rs = 0;
-                // (all 32 look-ups in flight: batches of 8 + 8 free 30 registers and cost 35 us of exposed LDS latency at RMAT-22)
+                if (QL >= 2) {
+                    u64* srow = stg + (size_t)(r & 31u) * STR + 2 * wl;
+                    srow[0] = w0;
+                    srow[1] = w1;
+                    staged |= (u32)((SLOTS >= 32 ? 0xFFFFFFFFull : ((1ull << (SLOTS % 32)) - 1ull)) << (r0 & 31u));
+                } else {
+                    const u32 k0 = 2 * wl < fin.w ? 2 * wl : 0u, k1 = 2 * wl + 1 < fin.w ? 2 * wl + 1 : 0u;
+                    const u64* t0 = s_tab + (size_t)k0 * 256;
+                    const u64* t1 = s_tab + (size_t)k1 * 256;
+                    u64 rs = 0;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) rs += t0[j * 16 + (u32)((w0 >> (4 * j)) & 15ull)];
+                    for (int j = 0; j < 16; ++j) rs += t0[j * 16 + (u32)((w0 >> (4 * j)) & 15ull)];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) rs += t1[j * 16 + (u32)((w1 >> (4 * j)) & 15ull)];
-                f_sum += rs * cs_dest_hash(g * 64 + r);
+                    for (int j = 0; j < 16; ++j) rs += t1[j * 16 + (u32)((w1 >> (4 * j)) & 15ull)];
+                    f_sum += rs * cs_dest_hash(g * 64 + r);
+                }
             }
+        }
+        if (MODE == 2 && QL >= 2 && staged) {
+            // the half group's look-ups, a lane per row: lanes 0-31 take the first QL words of rows hf0 .. hf0 + 31, lanes 32-63
+            // the other QL — every instruction reads one table per half wavefront
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const u32 row = lane & 31u, hw = lane >> 5;
+            const bool on = (staged >> row) & 1u;
+            u64 rs = 0;
+#pragma unroll 2
+            for (u32 kk = 0; kk < (u32)QL; ++kk) {
+                const u32 k = hw * QL + kk;
+                const u64 w = on ? stg[(size_t)row * STR + k] : 0ull;
+                const u64* tk = s_tab + (size_t)(k < fin.w ? k : 0u) * 256;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) rs += tk[j * 16 + (u32)((w >> (4 * j)) & 15ull)];
+            }
+            rs += (u64)__shfl_xor((long long)rs, 32, 64);                 // the two halves of a row
+            if (hw == 0 && on) f_sum += rs * cs_dest_hash(g * 64 + hf0 + row);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (read before the next half overwrites the stage)
+            __builtin_amdgcn_wave_barrier();
+        }
         }
     }
     bp_block_add2(f_cnt, MODE == 2 ? f_sum : 0ull, fin.acc);
@@ -547,7 +581,9 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
         const u32 fthreads = XP_FOLD_THREADS;
         u32 grid = cdiv(xp->ng, fthreads / 64);
         if (grid > (u32)ctx->cus * (2048u / fthreads)) grid = ctx->cus * (2048u / fthreads);
-        const size_t lds = mode == 2 ? lds_tables : 0;
+        // MODE 2: the checksum tables + a stage of 32 rows per wavefront (xp_fold_kernel)
+        const size_t lds = mode == 2 ? lds_tables + (size_t)(fthreads / 64) * 32 * (2 * ql + 1) * sizeof(u64) : 0;
+        FGPU_REQUIRE(lds <= (size_t)ctx->opt.lds_limit, FGPU_INVALID, "partitioned pull: the fold needs %zu B of LDS", lds);
 #define XP_FOLD2(Q, M)                                                                                                           \
         do {                                                                                                                     \
             if (lds > 48 * 1024)                                                                                                 \
