@@ -727,7 +727,7 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
         c = (rank + i * world) % 16
         if c not in labels:
             labels[c] = p_label_sources(n, c)
-        return labels[c]
+        return labels[c][:args.sources_per_call] if args.sources_per_call > 0 else labels[c]
     clean = ([A] * hops, None, None)
     dirty = ([A] * hops, [dp] * hops, [dm] * hops)
     # snapshot preparation (untimed, once per matrix version like the upload itself): the cached transpose of A, the pull
@@ -796,7 +796,7 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
     if rank != 0:
         return line, det, (A, dp, dm, host, batch0, None)
     # ---- untimed legs over the same label: the calls it replaces, count only, dirty layers, lanes, kernel table -------
-    P = srcs
+    P = srcs[:args.sources_per_call] if args.sources_per_call > 0 else srcs
 
     def run(src, layers, cs_=True, reps=1):
         engine.expand_count(ctx, src[:4096], *layers, want_checksum=cs_)
@@ -892,6 +892,8 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
     # EMITTED as cond_traverse.rs:644-751 emits them — the CSR left on the device (fgpu_expand_mat) and brought to host arrays
     # (fgpu_expand32); its entry count must equal the count form's
     try:
+        if scale > 22:
+            raise MemoryError("skipped above scale 22: the result of 1024 rows passes 2^32 entries")
         m_, _ = engine.expand_mat(ctx, batch0, *clean)
         n_emit = int(m_.nvals)
         m_.free()
@@ -1408,6 +1410,9 @@ def main():
     ap.add_argument("--steps", type=int, default=16, help="timed whole-frontier label scans of the k-hop MATCH (per rank)")
     ap.add_argument("--warmup", type=int, default=2, help="untimed scans before them")
     ap.add_argument("--scale", type=int, default=0, help="R-MAT scale of the headline leg (default 22)")
+    ap.add_argument("--sources-per-call", type=int, default=0,
+                    help="cap on the sources of one whole-frontier call (0 = the whole label, ~N/16; tools use it at scales 24 / 26, "
+                         "where a whole label is 3.6 / 57 s per step)")
     ap.add_argument("--leg", default="khop", choices=("khop", "bfs"),
                     help="khop (default): the bench line.  bfs: only the BFS leg at --scale, its TEPS as `value` (tools; with "
                          "--force-dist the multi-rank slab path on one rank)")
@@ -1563,7 +1568,7 @@ def main():
             # the WHOLE :P scan — timed step 0 — against the committed oracle run of exactly these inputs
             # (tests/golden/make_khop22_scan_golden.py: a quarter of an hour of 16-thread CPU, done once)
             gpath = os.path.join(ROOT, "tests", "golden", "khop%d_scan.json" % scale)
-            if os.path.exists(gpath) and args.edge_factor == 16 and scan0 is not None:
+            if os.path.exists(gpath) and args.edge_factor == 16 and scan0 is not None and args.sources_per_call <= 0:
                 gold = json.load(open(gpath))
                 ok = (gold.get("edges") == head["edges"] and gold.get("rows") == head["label_P_sources"] and
                       tuple(scan0) == (gold["nnz"], gold["checksum"], gold["flops"]))

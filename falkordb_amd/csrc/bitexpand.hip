@@ -1070,7 +1070,7 @@ static fgpu_info bp_relayout(fgpu_ctx* ctx, BitState& s, const u32* want) {
 // handing the block back marked "zero" is cheaper than the memset the next batch would pay for a state of the same size.
 static void bp_recycle_state(fgpu_ctx* ctx, BitState& s) {
     const size_t words = (size_t)s.n * s.ws;
-    if (s.x.p && s.flag.p && !s.lazy && (s.ws & 1u) == 0 && words >= (1u << 20) && s.nz_rows * 3 < (u64)s.n) {
+    if (s.x.p && s.flag.p && !s.lazy && (s.ws & 1u) == 0 && words >= (1u << 20) && s.nz_rows * 8 < (u64)s.n * 7) {   // (a pass of 1024 live sources leaves a third of the rows non-zero: still cheaper than the memset)
         const u32 ws2 = s.ws / 2;
         u32 lsh = 0;
         while ((2u << lsh) <= ws2 && lsh < 4) ++lsh;

@@ -15,10 +15,11 @@ run() {  # name, bench args...
   tail -1 $out/$name.out | cut -c1-400
   head -6 $out/${name}_kernel_stats.csv | cut -c1-160
 }
-run khop22 --quick --scale 22 --steps 20 --warmup 5
-python tools/trace_batches.py $(ls $out/khop22/*/t_kernel_trace.csv $out/khop22/t_kernel_trace.csv 2>/dev/null | head -1) 10 1
-run khop24 --quick --scale 24 --steps 16 --warmup 4
-run khop26 --quick --scale 26 --steps 4 --warmup 1
+run khop22 --quick --scale 22 --steps 8 --warmup 2
+# the same leg on ONE lane: kernels run alone, the averages are what bench.py's roofline (a one-lane replay) quotes
+run khop22_1lane --quick --scale 22 --steps 4 --warmup 1 --opt expand_scan_lanes=1
+run khop24 --quick --scale 24 --steps 8 --warmup 2 --sources-per-call 16384
+run khop26 --quick --scale 26 --steps 4 --warmup 1 --sources-per-call 8192
 run bfs22 --leg bfs --scale 22 --steps 64 --warmup 8
 run bfs26 --leg bfs --scale 26 --steps 32 --warmup 8
 find $out -name '*.csv' -size +6M -delete
