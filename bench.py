@@ -619,6 +619,11 @@ def spmv_pass(ctx, engine, At, scale, iters=50):
             "csr_pull_us": round(ms0 * 1e3, 2), "csr_pull_GBps": round(gb(ms0), 2)}
 
 
+def types_ns(**kw):
+    import types
+    return types.SimpleNamespace(**kw)
+
+
 def strong_scaling_base(ctx, engine, args, scale=26, steps=32, warmup=8):
     """The N = 1 point of the curve `--gpus N` (N > 1) measures: the same RMAT-26 BFS on this one device, same 64-root
     rule, same two-plan pipelined loop as the headline.  Reported inside the N = 1 line so that the driver's N = 1, 2, 4,
@@ -1667,7 +1672,28 @@ def main():
             if bfs22 and bfs22.get("spmv_full_pass"):
                 bfs22["spmv_full_pass"]["traffic"] = hbm(bfs22["spmv_full_pass"]["kernel"])
     elif world > 1:
-        # ---- N > 1: BASELINE config 4 as a secondary leg of the same line ---------------------------------------------
+        # ---- N > 1: the k-hop metric at its OTHER scale, RMAT-26 (north_star names it), the same way: every rank scans its own
+        # slice of a label over a replicated adjacency (4.3 GB), no collective; the sums meet in one all-reduce afterwards -------
+        if not args.quick and not one_device:
+            try:
+                A26 = ctx.mat_rmat(26, args.edge_factor, 0x5EED1234 + 26)
+                S26 = 8192
+                lab = p_label_sources(A26.nrows, rank % 16)[:S26]
+                engine.expand_count(ctx, lab[:2048], [A26] * 3)
+                engine.expand_count(ctx, lab, [A26] * 3)
+                fence()
+                t_ = time.perf_counter()
+                r26 = engine.expand_count(ctx, lab, [A26] * 3)
+                fence()
+                d26 = reduce_max(time.perf_counter() - t_)
+                f26 = reduce_sum(int(r26[2]))
+                A26.free()
+                sec["khop26_weak"] = {"TEPS": round(f26 / d26, 1), "ms": round(d26 * 1e3, 3), "sources_per_rank": S26, "ranks": world,
+                                      "scaling": "weak"}
+            except Exception as e:   # noqa: BLE001 — a secondary figure
+                sec["khop26_weak"] = {"error": repr(e)[:160]}
+                fence()
+        # ---- BASELINE config 4 as a secondary leg of the same line -----------------------------------------------------
         if not args.no_bfs and not one_device:
             d, derr = bfs_dist_leg_guarded(ctx, engine, args, 26, rank, world, dev, td, torch, 32, 8)
             if d is None:
@@ -1698,6 +1724,19 @@ def main():
                                          "exchange": "peer stores, one process", "levels": g["levels_per_search"],
                                          "level_kernels_ms": g["per_search_ms"]["level_kernels"],
                                          "frontier_exchange_ms": g["per_search_ms"]["frontier_exchange"]}
+                # the 1-GPU base point of BOTH BFS-26 legs, on rank 0's device, in the same line: the >= 6 x of north_star can be read
+                # off one SCALE record (bfs26_gang.TEPS / bfs26_base.TEPS, bfs26_dist.TEPS / bfs26_base.TEPS)
+                if not STALLED_THREADS:
+                    try:
+                        nr = types_ns(no_roofline=True, edge_factor=args.edge_factor, alpha=args.alpha, force_dir=args.force_dir)
+                        b_ = strong_scaling_base(ctx, engine, nr, 26, steps=16, warmup=4)
+                        detail["bfs26_base"] = b_
+                        sec["bfs26_base"] = {"TEPS": b_["value"], "ms": b_["ms_per_step"], "ranks": 1}
+                        for k_ in ("bfs26_dist", "bfs26_gang"):
+                            if isinstance(sec.get(k_), dict) and sec[k_].get("TEPS"):
+                                sec[k_]["x_base"] = round(sec[k_]["TEPS"] / max(b_["value"], 1.0), 3)
+                    except Exception as e:   # noqa: BLE001
+                        sec["bfs26_base"] = {"error": repr(e)[:160]}
                 if store is not None:
                     try:
                         store.set("fgpu_gang_done", "1")
@@ -1706,7 +1745,7 @@ def main():
             elif store is not None:
                 try:
                     import datetime
-                    store.wait(["fgpu_gang_done"], datetime.timedelta(seconds=300))
+                    store.wait(["fgpu_gang_done"], datetime.timedelta(seconds=600))
                 except Exception:
                     pass
     if rank == 0:

@@ -2239,6 +2239,13 @@ static fgpu_info dist_event(fgpu_bfs_plan* p, size_t idx) {
     return FGPU_OK;
 }
 
+// TEST ONLY (option dist_test_delay_us): a rank that finishes its level late — one lane spinning on the constant 100 MHz clock
+// behind the level kernel.  The peers' next levels must wait for its words (the `copied` events), however late they come.
+__global__ void dist_test_delay_kernel(u32 us) {
+    const u64 t0 = wall_clock64();
+    while (wall_clock64() - t0 < (u64)us * 100ull) __builtin_amdgcn_s_sleep(16);
+}
+
 fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t src, int64_t max_level, int want_parent) {
     FGPU_REQUIRE(plans && nplans >= 1 && plans[0], FGPU_NULL_POINTER, "fgpu_bfs_dist_run: NULL plans");
     fgpu_bfs_plan* p0 = plans[0];
@@ -2280,6 +2287,10 @@ fgpu_info fgpu_bfs_dist_run(fgpu_bfs_plan* const* plans, int nplans, uint64_t sr
         for (int k = 0; k < nplans; ++k) {
             if (timed) FGPU_TRY(dist_event(plans[k], 3 * nlev));
             FGPU_TRY(fgpu_bfs_slab_level(plans[k], &idx[k]));
+            if (plans[k]->ctx->opt.dist_test_delay_us > 0) {
+                hipLaunchKernelGGL(dist_test_delay_kernel, dim3(1), dim3(1), 0, plans[k]->ctx->stream(), (u32)plans[k]->ctx->opt.dist_test_delay_us);
+                FGPU_HIP(hipGetLastError());
+            }
             if (timed) FGPU_TRY(dist_event(plans[k], 3 * nlev + 1));
         }
         if (!peer) {

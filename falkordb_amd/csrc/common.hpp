@@ -85,6 +85,8 @@ struct fgpu_options {  // fgpu_set_option
                                // (all-gather-v, direct peer-to-peer over xGMI), 1 one ncclBroadcast per rank in a group
     int dist_force_self = 0;   // TEST ONLY: a communicator of one rank still issues the grouped self send / recv, broadcast and
                                // all-reduce of a multi-rank exchange (dist.hip) — the code path on the real librccl of a 1-GPU box
+    int dist_test_delay_us = 0; // TEST ONLY: fgpu_bfs_dist_run puts a kernel spinning this many microseconds behind every level kernel of
+                               // THIS context's rank (a peer that finishes its levels late; tests/test_gpu_dist.py)
     int transpose_mode = 0;    // pattern transpose / COO build: 0 counting sort (form picked by key space), 1 COO rebuild through the sorter (A/B), 2 LDS-staged levels, 3 two levels
     int lds_limit = 0;         // usable LDS bytes per workgroup (filled by fgpu_init)
     int expand_compact = 1;    // fgpu_expand*: source rows that are empty after the CSR hops (sources without out-edges: half of an

@@ -876,6 +876,9 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "pinned_pool_mb")) {
         FGPU_REQUIRE(value >= 0 && value <= (1 << 20), FGPU_INVALID, "pinned_pool_mb out of range");
         ctx->opt.pinned_pool_mb = (int)value;
+    } else if (!strcmp(name, "dist_test_delay_us")) {
+        FGPU_REQUIRE(value >= 0 && value <= 100000, FGPU_INVALID, "dist_test_delay_us out of range");
+        ctx->opt.dist_test_delay_us = (int)value;
     } else if (!strcmp(name, "dist_force_self")) {
         ctx->opt.dist_force_self = value != 0;
     } else if (!strcmp(name, "dist_collective")) {

@@ -295,6 +295,51 @@ def test_bench_gang_leg_on_one_device():
     assert g["edges"] == a.nnz and g["vertices"] == a.nrows
 
 
+@pytest.mark.parametrize("late", [0, 2, 3])
+def test_gang_survives_a_peer_that_finishes_its_levels_late(late):
+    """The single-process gang (fgpu_bfs_dist_run in peer mode: one context and one stream per rank, every rank's frontier
+    words stored into every peer's bitmap, the next level ordered behind every source's `copied` event) with ONE rank
+    finishing each of its levels 400 microseconds late (option dist_test_delay_us: a kernel spinning behind its level
+    kernel): the peers' next levels must wait for the late rank's words, whichever rank it is — levels against the oracle for
+    several roots, and the blind level budget must still end every search.  Four "ranks" share the one GPU of a test box."""
+    scale, nranks = 15, 4
+    a = oracle.rmat_csr(scale)
+    n = a.nrows
+    ctxs = [engine.Context(0) for _ in range(nranks)]
+    plans, keep = [], []
+    try:
+        full0 = ctxs[0].mat_rmat(scale)
+        splits = full0.balanced_splits(nranks)
+        for r, c in enumerate(ctxs):
+            full = full0 if r == 0 else c.mat_rmat(scale)
+            A = full.col_slab(int(splits[r]), int(min(splits[r + 1], n)))
+            full.free()
+            At = A.transpose()
+            keep += [A, At]
+            plans.append(engine.BfsPlan(c, A, At, r, nranks, splits=splits))
+        ctxs[late].set_option("dist_test_delay_us", 400)
+        for c in ctxs:
+            c.sync()
+        deg = np.diff(a.rowptr)
+        for src in [int(np.argmax(deg)), 7, int(np.nonzero(deg > 0)[0][-1]), 1234]:
+            engine.bfs_dist_run(plans, src, -1, False)
+            ref, _, ref_edges = oracle.bfs(a, src, -1)
+            level = np.full(n, -1, dtype=np.int32)
+            for r, p in enumerate(plans):
+                lv, _ = p.fetch(want_parent=False)
+                lo, hi = int(splits[r]), int(min(splits[r + 1], n))
+                level[lo:hi] = lv[lo:hi]
+            np.testing.assert_array_equal(level, ref)
+            assert sum(p.stats()["edges_traversed"] for p in plans) == ref_edges
+    finally:
+        for p in plans:
+            p.free()
+        for m_ in keep:
+            m_.free()
+        for c in ctxs:
+            c.close()
+
+
 def test_bench_spawns_its_own_ranks_from_a_plain_shell():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (it used to exit with an error):
     bench.py re-executes itself under torch.distributed.run, one rank per GPU, and still prints ONE line.  Both ranks share
