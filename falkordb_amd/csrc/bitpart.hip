@@ -195,7 +195,27 @@ __global__ void xp_rank_kernel(const u32* __restrict__ by_rank, u32 n, u32 prang
     for (u32 r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) perm[by_rank[r]] = (r & 7u) * prange + (r >> 3);
 }
 
+static fgpu_info bp_xplan_build(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const BpXPlan** out);
+// The plan is an optional accelerator: when its build fails (its temporaries are large — 64 bytes per vertex and 8 per entry) the
+// half-built plan's buffers are freed, it stays attached as "not usable" (no second attempt per snapshot), the error is dropped
+// and the hop falls back to the plain pull.
 fgpu_info bp_xplan(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const BpXPlan** out) {
+    const fgpu_info i = bp_xplan_build(ctx, m, t, out);
+    if (i == FGPU_OK) return FGPU_OK;
+    *out = nullptr;
+    if (t && t->bp_xplan && !t->bp_xplan->usable) {
+        BpXPlan* p = t->bp_xplan;
+        ctx->dev_free(p->pcol); ctx->dev_free(p->pstart_dev); ctx->dev_free(p->cstart); ctx->dev_free(p->crun0); ctx->dev_free(p->cshared);
+        ctx->dev_free(p->zrows); ctx->dev_free(p->ne); ctx->dev_free(p->pbase); ctx->dev_free(p->perm);
+        p->pcol = nullptr; p->pstart_dev = nullptr; p->cstart = nullptr; p->crun0 = nullptr; p->cshared = nullptr; p->zrows = nullptr;
+        p->ne = nullptr; p->pbase = nullptr; p->perm = nullptr;
+        (void)hipGetLastError();
+        set_error("%s", "");
+        return FGPU_OK;
+    }
+    return i;                                                // (failed before a plan was attached: an argument / state error)
+}
+static fgpu_info bp_xplan_build(fgpu_ctx* ctx, const fgpu_mat* m, const fgpu_mat* t, const BpXPlan** out) {
     *out = nullptr;
     if (!ctx->opt.expand_xcd || !t || t->is_hyper()) return FGPU_OK;
     if (t->ncols >= (1ull << 31) || t->nrows >= 0xFFFFFFC0ull || t->nnz < 4096 || t->nnz >= 0x7FFFFFFFull) return FGPU_OK;
