@@ -880,8 +880,7 @@ def khop_headline(ctx, engine, args, scale, rank, world, fence, reduce_max, redu
                     "alg_bytes_per_launch": int(d["alg_bytes"] / d["launches"]),
                     "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2), "launches": int(d["launches"]),
                     "share_of_kernel_time": round(d["ms"] / max(sum(k["ms"] for k in kern), 1e-9), 3),
-                    "timing": "HIP events on the launching stream around each launch (fgpu_prof_*), one whole-frontier call over 32 K "
-                              ":P sources replayed on one lane"}
+                    "timing": "HIP events per launch, one 32 K-source call replayed on one lane"}
         # the HOP the kernel belongs to: the partitioned count hop is stream + fold, and only the stream kernel's bytes are
         # bytes the problem needs (the partial rows between the two are an artefact of the partition)
         byname = {k["kernel"]: k for k in prof}
@@ -956,15 +955,12 @@ def khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, batch0, gpu_first, s
     q = [rates[len(rates) // 4], rates[len(rates) // 2], rates[(3 * len(rates)) // 4]] if rates else [0, 0, 0]
     cpu = {"value": round(ref_clean[2] / t_clean, 1), "unit": "TEPS", "cores": threads, "kind": "port",
            "quartiles": [round(x, 1) for x in q],
-           "sample": f"the first 1024 :P sources (3 hops, clean layers, count + checksum): {t_clean:.1f} s of row-parallel "
-                     f"OpenMP Gustavson ANY_PAIR products (oracle/oracle_omp.c) on {threads} threads = the job's CPU quota "
-                     f"({ncpu} hardware threads visible); quartiles over its sixteen 64-row chunks; stand-in for "
-                     f"SuiteSparse:GraphBLAS GrB_mxm, absent from this image",
+           "sample": f"first 1024 :P sources, 3 hops, clean: {t_clean:.1f} s of OpenMP Gustavson ANY_PAIR products (oracle/oracle_omp.c) on "
+                     f"{threads} threads (the job's CPU quota); stand-in for SuiteSparse:GraphBLAS, absent here",
            "dirty_TEPS": round(ref_dirty[2] / t_dirty, 1)}
     # what was looked for before settling for the port (graphblas.sh:71-72 builds SuiteSparse:GraphBLAS v10.5.0 from a clone)
     found = probe_reference_libs()
-    cpu["probe"] = {"looked_for": "libgraphblas / liblagraph(x) (ldconfig, linker path, /usr/lib*, /usr/local/lib, /opt), GraphBLAS.h, "
-                                  "python-graphblas",
+    cpu["probe"] = {"looked_for": "libgraphblas, liblagraph(x), GraphBLAS.h, python-graphblas",
                     "found": {k_: v_ for k_, v_ in found.items() if v_} or None}
     try:                                             # second point: scipy.sparse CSR x CSR (SMMP, one thread), pattern re-binarised per hop
         import scipy.sparse as sp
@@ -977,8 +973,7 @@ def khop_parity_and_cpu(ctx, engine, args, A, dp, dm, host, batch0, gpu_first, s
             f_sp.data[:] = 1
         t_sp = time.perf_counter() - t1
         fl_sp = chunks[0][0] if chunks else 0
-        cpu["scipy"] = {"value": round(fl_sp / t_sp, 1), "unit": "TEPS", "cores": 1, "rows": k_, "seconds": round(t_sp, 2),
-                        "nnz_matches_oracle_chunk": None}
+        cpu["scipy"] = {"value": round(fl_sp / t_sp, 1), "unit": "TEPS", "cores": 1, "rows": k_}
     except Exception as e:   # noqa: BLE001 — a report field
         cpu["scipy"] = {"error": repr(e)[:120]}
     return parity, cpu
@@ -1385,10 +1380,12 @@ def emit(line, detail):
     txt = json.dumps(line, separators=(",", ":"))
     # the driver keeps the tail of stdout: the line must stay under 4 KB.  Secondary figures leave in this order until it does
     # (all of them are in the DETAIL line / bench_detail.json); what was dropped is named in the line.
-    drop = [("materialised24", "three_hop_64_rows"), ("khop22", "pinned_probe_ms"), ("khop22", "snapshot_prep_ms"), ("khop22", "prep_ms"),
-            ("bfs22", "cpu_quartiles"), ("bfs22", "push_traffic"), ("khop24", "batch1024_dirty_ms"), ("khop26", "batch1024_dirty_ms"),
-            ("khop26", "hop3_fetch_raw"), ("khop24", "cpu_TEPS"), ("khop26", "cpu_TEPS"), ("config5_varlen_TEPS",), ("operator20",),
-            ("spmv_full_pass", "24"), ("spmv_full_pass", "26"), ("materialised24",), ("bfs26",), ("khop24",)]
+    drop = [("khop22", "pinned_probe_ms"), ("khop22", "snapshot_prep_ms"), ("khop22", "prep_ms"), ("bfs22", "cpu_quartiles"),
+            ("bfs22", "push_traffic"), ("khop24", "batch1024_dirty_ms"), ("khop26", "batch1024_dirty_ms"), ("khop26", "hop3_fetch_raw"),
+            ("khop24", "cpu_TEPS"), ("khop26", "cpu_TEPS"), ("khop24", "batches"), ("khop26", "batches"), ("khop24", "parity_rows"),
+            ("materialised24", "three_hop_64_rows"), ("bfs22", "host_arrays_ms"), ("bfs22", "push_frac"), ("bfs22", "pull_frac"),
+            ("spmv_full_pass", "24"), ("spmv_full_pass", "26"), ("config5_varlen_TEPS",), ("operator20",), ("khop22", "emit3hop_entries"),
+            ("bfs26",), ("materialised24",), ("khop24",)]
     dropped = []
     sec = line.get("secondary") if isinstance(line.get("secondary"), dict) else None
     while len(txt) >= 4000 and sec is not None and drop:
@@ -1654,8 +1651,7 @@ def main():
                 return e["hbm_bytes_per_dispatch"] if e else None
             if roofline:
                 roofline["traffic"] = hbm(roofline["kernel"])
-                roofline["traffic_source"] = ("live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --pmc-child` (same "
-                                              "graph and kernels); FETCH_SIZE x2 (gfx950) + WRITE_SIZE, bytes per launch"
+                roofline["traffic_source"] = ("live rocprofv3 --pmc passes over `bench.py --pmc-child`: FETCH_SIZE x2 + WRITE_SIZE per launch"
                                               if "error" not in pmc else "live PMC passes failed: " + str(pmc["error"])[:120])
             # the metric's other scale: the same passes over the RMAT-26 k-hop replay (no BFS part), hop 3's bytes per launch
             if "khop26" in sec and "error" not in pmc:
@@ -1778,14 +1774,13 @@ def main():
         if em:
             sec["materialised24"] = {k: {"ms_device": v["ms_per_batch"], "ms_host_arrays": v["host_arrays_ms"],
                                          "ms_host_arrays_u64": v.get("host_arrays_u64_ms"),
-                                         "ms_host_arrays_first": v["host_arrays_ms_first_batch"],
-                                         "ms_stream_first_chunk": v["stream_ms"]["first_chunk"], "ms_stream_all": v["stream_ms"]["all_chunks"],
+                                         "ms_stream_all": v["stream_ms"]["all_chunks"],
                                          "entries": v["out_nnz_per_batch"], "parity_ok": (v.get("parity") or {}).get("ok")}
                                      for k, v in em.items()}
         out = dict(base, metric=BASELINE_METRIC, value=line["value"], unit="TEPS", steps=args.steps, warmup=args.warmup,
                    ms_per_step=line["ms_per_step"], scaling="weak",
                    config={"workload": f"RMAT scale-{scale} 3-hop MATCH (a:P)-->()-->()-->(c): one whole-frontier fgpu_expand_count call "
-                                       f"per label scan (all ~N/16 sources of the label), clean layers, count + checksum on device",
+                                       f"per label scan, clean layers, count + checksum",
                            "scale": scale, "vertices": head["vertices"], "edges": head["edges"], "hops": 3,
                            "sources_per_call": head["scan"]["sources_per_call"], "live_sources": head["scan"]["live_sources_last_call"],
                            "pass_rows": head["scan"]["pass_rows"], "passes_per_call": head["scan"]["passes_last_call"],
@@ -1795,10 +1790,10 @@ def main():
                                                                       f"adjacency replicated, no collective")},
                    roofline=roofline, cpu_baseline=cpu,
                    parity=({"ok": parity["ok"], "rows": parity["rows"],
-                            "what": "(nnz, checksum, flops): the first 1024 :P rows clean + dirty vs the oracle's delta_lmxm chain run here"
-                                    + ("; timed step 0 (the whole :P scan) vs the committed oracle run tests/golden/khop%d_scan.json" % scale
+                            "what": "(nnz, checksum, flops): first 1024 :P rows clean + dirty vs the oracle run here"
+                                    + ("; timed step 0 (whole :P scan) vs tests/golden/khop%d_scan.json" % scale
                                        if parity.get("whole_scan_vs_committed_oracle_run") else "")} if parity else {"checked": False}),
-                   secondary=sec, detail="DETAIL line above / bench_detail.json")
+                   secondary=sec)
         emit(out, detail)
     if use_dist:
         if STALLED_THREADS or DIST_FAILED:     # other ranks may never reach the barrier (or this one left a thread behind)
