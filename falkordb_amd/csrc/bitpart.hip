@@ -316,6 +316,19 @@ __device__ __forceinline__ void atomic_or4(uint4* dst, uint4 v) {
     if (v.z | v.w) atomicOr(d + 1, ((unsigned long long)v.w << 32) | v.z);
 }
 
+// streaming hints (option expand_nt; A/B): a partial row is written once and read once by the fold, an entry of the column-id stream is
+// read once per hop — neither should displace the partition's hot rows of X from its XCD's L2
+typedef unsigned int xp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 xp_load_nt(const uint4* p) {
+    const xp_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const xp_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void xp_store_nt(uint4* p, uint4 v) {
+    xp_u32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<xp_u32x4*>(p));
+}
+
 // partial rows that receive pieces from several chunks start from zero
 __global__ __launch_bounds__(256) void xp_zero_rows_kernel(const u32* __restrict__ rows, u32 nrows, u32 ql, uint4* __restrict__ partial) {
     const u32 per = 256 / ql;
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void xp_zero_rows_kernel(const u32* __restrict
 // the stream pull: QL lanes of 16 bytes per row of X (ws = 2 QL words), 64 / QL slots per wavefront, QL consecutive entries
 // per slot and trip.  WIDE = false: the state is at most 4 GiB, a row's byte offset fits 32 bits (one multiply-add per gather
 // address instead of 64-bit arithmetic: the kernel issues ~100 instructions per 64 entries and is not far from VALU-bound).
-template <int QL, bool WIDE>
+template <int QL, bool WIDE, int NT>
 __global__ __launch_bounds__(256) void xp_stream_kernel(const u32* __restrict__ pcol, const u32* __restrict__ pstart,
                                                         const u32* __restrict__ cstart, const u32* __restrict__ crun0,
                                                         const uint8_t* __restrict__ cshared, const uint4* __restrict__ x,
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(256) void xp_stream_kernel(const u32* __restrict__ 
         // loads OLDER than the ones that should stay in flight (vmcnt counts in issue order: a column word loaded after the
         // previous trip's gathers would drain them).  Loads past the chunk's end repeat its last entry (no branch around a
         // load); the extra round of gathers per chunk hits the row it has just gathered.
-#define XP_COL(T) pcol[(T) + lane < E ? (T) + lane : E - 1]
+#define XP_COL(T) ((NT & 2) ? __builtin_nontemporal_load(&pcol[(T) + lane < E ? (T) + lane : E - 1]) : pcol[(T) + lane < E ? (T) + lane : E - 1])
 #define XP_GATHER(XV, CW)                                                                                   \
         _Pragma("unroll") for (int k = 0; k < QL; ++k) {                                                    \
             const u32 uk = (u32)__shfl((int)(CW), (int)(slot * QL + k), 64) & ~XP_FIRST;                    \
@@ -417,6 +430,7 @@ __global__ __launch_bounds__(256) void xp_stream_kernel(const u32* __restrict__ 
                 const uint4 v4 = tile[r * QL + wl];
                 uint4* dst = partial + (size_t)(R0 + r) * QL + wl;
                 if ((r == 0 && first_atomic) || (r + 1 == nr && last_atomic)) atomic_or4(dst, v4);
+                else if (NT & 1) xp_store_nt(dst, v4);
                 else *dst = v4;
                 tile[r * QL + wl] = make_uint4(0, 0, 0, 0);
             }
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(256) void xp_stream_kernel(const u32* __restrict__ 
 __device__ __forceinline__ u64 xp_uniform64(u64 v) {
     return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
 }
-template <int QL, int MODE>
+template <int QL, int MODE, bool NT>
 __global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_kernel(const u64* __restrict__ ne, const u32* __restrict__ pbase, u32 ng,
                                                       const uint4* __restrict__ partial, BpFinal fin, uint4* __restrict__ side,
                                                       u32 zrow /* an all-zero partial row */) {
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(XP_FOLD_THREADS) void xp_fold_kernel(const u64* __r
                 } else {
                     idx = ((nw[k] >> r) & 1ull) ? pb[k] + (u32)__popcll(nw[k] & below) : zrow;
                 }
-                pv[k] = partial[(size_t)idx * QL + wl];
+                pv[k] = NT ? xp_load_nt(&partial[(size_t)idx * QL + wl]) : partial[(size_t)idx * QL + wl];
             }
             uint4 a = or4(or4(or4(pv[0], pv[1]), or4(pv[2], pv[3])), or4(or4(pv[4], pv[5]), or4(pv[6], pv[7])));
             const bool touched = (tw >> r) & 1ull;
@@ -578,9 +592,11 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
         if (grid > need) grid = need;
         grid = (grid + 7) & ~7u;
         const bool wide = (u64)xp->n * ws * 8 > (1ull << 32) || (u64)t->ncols * ws * 8 > (1ull << 32);
-#define XP_PULL2(Q, W) hipLaunchKernelGGL((xp_stream_kernel<Q, W>), dim3(grid), dim3(256), lds, st, (const u32*)xp->pcol,        \
+#define XP_PULL3(Q, W, N) hipLaunchKernelGGL((xp_stream_kernel<Q, W, N>), dim3(grid), dim3(256), lds, st, (const u32*)xp->pcol,  \
                                           (const u32*)xp->pstart_dev, (const u32*)xp->cstart, (const u32*)xp->crun0,           \
                                           (const uint8_t*)xp->cshared, (const uint4*)x, partial.p)
+#define XP_PULL2(Q, W) do { switch (ctx->opt.expand_nt & 3) { case 1: XP_PULL3(Q, W, 1); break; case 2: XP_PULL3(Q, W, 2); break;  \
+                                                              case 3: XP_PULL3(Q, W, 3); break; default: XP_PULL3(Q, W, 0); break; } } while (0)
 #define XP_PULL(Q) do { if (wide) XP_PULL2(Q, true); else XP_PULL2(Q, false); } while (0)
         switch (ql) {
             case 1: XP_PULL(1); break;
@@ -588,6 +604,7 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
             case 4: XP_PULL(4); break;
             default: XP_PULL(8); break;
         }
+#undef XP_PULL3
 #undef XP_PULL2
 #undef XP_PULL
         FGPU_HIP(hipGetLastError());
@@ -604,13 +621,14 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
         // MODE 2: the checksum tables + a stage of 32 rows per wavefront (xp_fold_kernel)
         const size_t lds = mode == 2 ? lds_tables + (size_t)(fthreads / 64) * 32 * (2 * ql + 1) * sizeof(u64) : 0;
         FGPU_REQUIRE(lds <= (size_t)ctx->opt.lds_limit, FGPU_INVALID, "partitioned pull: the fold needs %zu B of LDS", lds);
-#define XP_FOLD2(Q, M)                                                                                                           \
+#define XP_FOLD3(Q, M, N)                                                                                                        \
         do {                                                                                                                     \
             if (lds > 48 * 1024)                                                                                                 \
-                FGPU_HIP(hipFuncSetAttribute((const void*)xp_fold_kernel<Q, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((xp_fold_kernel<Q, M>), dim3(grid), dim3(fthreads), lds, st, (const u64*)xp->ne, (const u32*)xp->pbase, xp->ng,  \
+                FGPU_HIP(hipFuncSetAttribute((const void*)xp_fold_kernel<Q, M, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((xp_fold_kernel<Q, M, N>), dim3(grid), dim3(fthreads), lds, st, (const u64*)xp->ne, (const u32*)xp->pbase, xp->ng,  \
                                (const uint4*)partial.p, fin, (uint4*)side, xp->nprows);                                                                         \
         } while (0)
+#define XP_FOLD2(Q, M) do { if (ctx->opt.expand_nt & 4) XP_FOLD3(Q, M, true); else XP_FOLD3(Q, M, false); } while (0)
 #define XP_FOLD(Q) do { if (mode == 2) XP_FOLD2(Q, 2); else XP_FOLD2(Q, 1); } while (0)
         switch (ql) {
             case 1: XP_FOLD(1); break;
@@ -620,6 +638,7 @@ fgpu_info bp_xpull_count(fgpu_ctx* ctx, const BpXPlan* xp, const fgpu_mat* t, co
         }
 #undef XP_FOLD
 #undef XP_FOLD2
+#undef XP_FOLD3
         FGPU_HIP(hipGetLastError());
     }
     (void)t;

@@ -104,6 +104,10 @@ struct fgpu_options {  // fgpu_set_option
     int expand_scan_lanes = 3;  // ... lanes (calling thread + workers, a stream and pool each) the passes are dealt to
     int expand_records = 1;     // sparse mid-chain pull: rows of X with <= 4 bits are read as 8-byte records of source indices, a lane
                                // per live entry (bitexpand.hip bp_records_kernel; 0 = every live entry gathers the whole row; A/B)
+    int expand_nt = 1;          // XCD-partitioned count hop, streaming hints (bit mask): 1 = the partial rows leave the stream kernel with
+                               // non-temporal stores (1 GB per pass that would otherwise displace the partition's hot rows of X from its L2:
+                               // stream kernel 824 -> 771 us at RMAT-22, no change at RMAT-26), 2 = its column-id stream is read non-temporal,
+                               // 4 = the fold reads the partial rows non-temporal (2, 4: no effect, off; profiles/NOTES_r06.md section 7)
     int expand_emit_sort = 1;   // bit state -> CSR: (row, vertex) pairs in vertex order + the LDS-staged stable sort by row (0 = the
                                // ballot transpose of rounds 3-5, bp_rows_kernel; A/B)
     int pinned_results = 1;    // result arrays >= 256 KiB come from the context's pinned-host pool and are filled by DMA (0 = the

@@ -799,6 +799,7 @@ fgpu_info fgpu_get_option(fgpu_ctx* ctx, const char* name, int64_t* value) {
     else if (!strcmp(name, "expand_scan_min")) *value = ctx->opt.expand_scan_min;
     else if (!strcmp(name, "expand_scan_rows")) *value = ctx->opt.expand_scan_rows;
     else if (!strcmp(name, "expand_scan_lanes")) *value = ctx->opt.expand_scan_lanes;
+    else if (!strcmp(name, "expand_nt")) *value = ctx->opt.expand_nt;
     else if (!strcmp(name, "expand_scan_last_live")) *value = ctx->scan_last_live.load(std::memory_order_relaxed);
     else if (!strcmp(name, "expand_scan_last_passes")) *value = ctx->scan_last_passes.load(std::memory_order_relaxed);
     else { set_error("fgpu_get_option: unknown name '%s'", name); return FGPU_INVALID; }
@@ -853,6 +854,9 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->opt.expand_emit_sort = value != 0;
     } else if (!strcmp(name, "expand_records")) {
         ctx->opt.expand_records = value != 0;
+    } else if (!strcmp(name, "expand_nt")) {
+        FGPU_REQUIRE(value >= 0 && value <= 7, FGPU_INVALID, "expand_nt is a mask of 1 | 2 | 4");
+        ctx->opt.expand_nt = (int)value;
     } else if (!strcmp(name, "expand_bits_ratio")) {
         FGPU_REQUIRE(value >= 1 && value <= 1024, FGPU_INVALID, "expand_bits_ratio out of range");
         ctx->opt.expand_bits_ratio = (int)value;
