@@ -1481,6 +1481,7 @@ static fgpu_info bp_hop_impl(fgpu_ctx* ctx, BitState& s, const fgpu_mat* m, cons
             FGPU_HIP(hipGetLastError());
         }
         if (groups) {
+            ProfScope pg(ctx, "sparse pull: row groups", 0);   // (nested in the hop's record: the split between the two launches)
             const size_t per_wave = ((size_t)BP_GROUP * s.ws + 256 + 32) * sizeof(u64);
             const size_t lds_g = lds_co + BP_GROUP_WAVES * per_wave;
             u32 wgs = (u32)((size_t)ctx->opt.lds_limit / lds_g);

@@ -6,6 +6,7 @@ arrays to the plain pointers the ABI takes, and raise FgpuError on any non-zero 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import weakref
 
@@ -34,6 +35,11 @@ class Context:
         self._live_views = 0          # result arrays handed out as views of library memory (_take) and not yet dropped
         self._close_pending = False
         check(self.lib.fgpu_init(C.byref(self._h), device, None, None))
+        # A/B plumbing for the tools and the test-suite: FGPU_OPTS="name=value,name=value" sets library options on every context this
+        # process opens (e.g. the whole parity suite under an experiment switch) — the library itself reads no environment for them
+        for kv in filter(None, os.environ.get("FGPU_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), int(v))
 
     @property
     def handle(self):
