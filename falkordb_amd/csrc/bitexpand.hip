@@ -369,6 +369,7 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
         const u32 e3 = (u32)__builtin_amdgcn_readfirstlane((int)items[3 * it + 2]);
         const u32 e = e3 & 0x7FFFFFFFu;
         const bool split = (e3 >> 31) != 0;
+        const u32 yv = (MODE == 0 && yperm) ? yperm[v] : v;   // (requested here, with the column ids — not under the `if` that stores the row)
         bool any = false;
         u32 n_live = 0;
         if (SPARSE) {
@@ -380,18 +381,19 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const u32 q = b + 64 * k + lane;
-                un[k] = (q < e) ? at.colidx[q] : 0xFFFFFFFFu;
+                const u32 c = at.colidx[q < e ? q : e - 1u];     // (clamped, not conditional: see bp_pull_groups_kernel)
+                un[k] = (q < e) ? c : 0xFFFFFFFFu;
             }
+            u64 fw[4];
+            bool sv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                bool hit = un[k] != 0xFFFFFFFFu;
-                if (hit) {
-                    const u32 cb = un[k] >> pr.cshift;
-                    hit = (s_co[cb >> 5] >> (cb & 31)) & 1u;
-                }
-                if (hit) hit = (xbits[un[k] >> 6] >> (un[k] & 63)) & 1ull;
-                live[k] = __ballot(hit);
+                const u32 cb = (un[k] != 0xFFFFFFFFu ? un[k] : 0u) >> pr.cshift;
+                sv[k] = un[k] != 0xFFFFFFFFu && ((s_co[cb >> 5] >> (cb & 31)) & 1u);
+                fw[k] = xbits[sv[k] ? (un[k] >> 6) : 0u];
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) live[k] = __ballot(sv[k] && ((fw[k] >> (un[k] & 63)) & 1ull));
             const u64 below = (1ull << lane) - 1ull;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -417,7 +419,10 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
                     }
                     u64 xv[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) xv[k] = (u[k] != 0xFFFFFFFFu) ? x[(size_t)u[k] * ws + wo] : 0ull;
+                    for (int k = 0; k < 4; ++k) {
+                        const u64 r = x[(size_t)(u[k] != 0xFFFFFFFFu ? u[k] : 0u) * ws + wo];
+                        xv[k] = (u[k] != 0xFFFFFFFFu) ? r : 0ull;
+                    }
                     acc |= (xv[0] | xv[1]) | (xv[2] | xv[3]);
                 }
             } else {
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(MODE == 2 ? 1024 : 256) void bp_pull_kernel(CsrView
             for (int d = LN; d < 64; d <<= 1) acc |= __shfl_xor(acc, d, 64);
             if (MODE == 0) {
                 if (slot == 0 && acc) {
-                    u64* dst = &y[(size_t)(yperm ? yperm[v] : v) * ws + wo];
+                    u64* dst = &y[(size_t)yv * ws + wo];
                     if (split) atomicOr((unsigned long long*)dst, (unsigned long long)acc);
                     else *dst = acc;
                 }
@@ -576,6 +581,9 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
         const u32 ri = v0 + lane < nrows ? v0 + lane : nrows;
         const u32 rp = at.rowptr[ri];
         const u32 nrp = stats ? next_rowptr[ri] : 0u;   // next hop's out-degrees of the group's rows, loaded with the rest
+        // ... and the slots of the group's rows in Y: one coalesced load here instead of a gather under `if (a)` in each of the
+        // flush's steps (hipcc sinks a conditional load into its branch and waits for it there: eight dependent round trips a group)
+        const u32 yp = yperm ? yperm[ri < nrows ? ri : nrows - 1u] : ri;
         const u32 later = later_bits ? (u32)(later_bits[v0 >> 6] >> (v0 & 63)) : 0u;   // (R = 32 rows: half a word)
         const u32 rp1 = (u32)__shfl_down((int)rp, 1, 64);
         const u32 ndeg = (u32)__shfl_down((int)nrp, 1, 64) - nrp;
@@ -605,19 +613,23 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
                 for (u32 step = R / 2; step >= 1; step >>= 1)
                     if (pref[lo + step] <= t) lo += step;
                 rw[k] = lo;
-                un[k] = (t < total) ? at.colidx[t + base[lo]] : 0xFFFFFFFFu;
+                // (loads go to a clamped address, never under a branch: hipcc sinks a conditional load into its branch and waits
+                // for it there — the four flag probes below were four dependent round trips in the ISA, not one)
+                const u32 tc = t < total ? t : total - 1u;
+                const u32 c = at.colidx[tc + base[t < total ? lo : R - 1u]];
+                un[k] = (t < total) ? c : 0xFFFFFFFFu;
             }
             u64 live[4];
+            u64 fw[4];
+            bool sv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                bool hit = un[k] != 0xFFFFFFFFu;
-                if (hit) {
-                    const u32 cb = un[k] >> pr.cshift;
-                    hit = (s_co[cb >> 5] >> (cb & 31)) & 1u;
-                }
-                if (hit) hit = (pr.bits[un[k] >> 6] >> (un[k] & 63)) & 1ull;
-                live[k] = __ballot(hit);
+                const u32 cb = (un[k] != 0xFFFFFFFFu ? un[k] : 0u) >> pr.cshift;
+                sv[k] = un[k] != 0xFFFFFFFFu && ((s_co[cb >> 5] >> (cb & 31)) & 1u);
+                fw[k] = pr.bits[sv[k] ? (un[k] >> 6) : 0u];
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) live[k] = __ballot(sv[k] && ((fw[k] >> (un[k] & 63)) & 1ull));
             u32 n_live = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -637,7 +649,10 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
                     pe[k] = (i < n_live) ? list[i] : ~0ull;
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) rc[k] = (pe[k] != ~0ull) ? rec[(u32)pe[k]] : ~0ull;
+                for (int k = 0; k < 4; ++k) {
+                    const u64 r = rec[pe[k] != ~0ull ? (u32)pe[k] : 0u];
+                    rc[k] = (pe[k] != ~0ull) ? r : ~0ull;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (every lane has read its list entries before any is rewritten)
                 __builtin_amdgcn_wave_barrier();
                 u32 n_esc = 0;
@@ -669,7 +684,10 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
                 }
                 u64 xv[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) xv[k] = (pu[k] != ~0ull) ? x[(size_t)(u32)pu[k] * LN + wl] : 0ull;
+                for (int k = 0; k < 4; ++k) {
+                    const u64 r = x[(size_t)(pu[k] != ~0ull ? (u32)pu[k] : 0u) * LN + wl];
+                    xv[k] = (pu[k] != ~0ull) ? r : 0ull;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (xv[k]) atomicOr((unsigned long long*)&acc[(u32)(pu[k] >> 32) * LN + wl], (unsigned long long)xv[k]);
@@ -681,8 +699,9 @@ __global__ __launch_bounds__(BP_GROUP_WAVES * 64) void bp_pull_groups_kernel(Csr
         for (u32 r0 = 0; r0 < R; r0 += SLOTS) {
             const u32 row = r0 + slot;
             const u64 a = row < R ? acc[row * LN + wl] : 0ull;   // (LN == 1: 64 slots, 32 rows)
+            const u32 yrow = (u32)__shfl((int)yp, (int)(row < R ? row : 0u), 64);
             if (a) {
-                y[(size_t)(yperm ? yperm[v0 + row] : v0 + row) * LN + wl] = a;
+                y[(size_t)yrow * LN + wl] = a;
                 acc[row * LN + wl] = 0ull;
             }
             const u64 nzm = __ballot(a != 0ull);
