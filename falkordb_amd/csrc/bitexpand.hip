@@ -1742,6 +1742,8 @@ __global__ __launch_bounds__(256) void bp_pairs_kernel(const u64* __restrict__ y
                                                       u32* __restrict__ tile_cnt, const u64* __restrict__ tile_off,
                                                       u32* __restrict__ key, u32* __restrict__ val) {
     __shared__ u32 s_list[BP_PT];             // the tile's rows that count, ascending
+    __shared__ u32 s_slot[BP_PT];             // ... and where each lies in the state (perm[v]): gathered ONCE per tile, in one round
+                                              // trip — under `if (i < nlist)` in the passes it was a dependent load per row and step
     __shared__ u32 s_row[BP_PT + 1];          // FILL: exclusive prefix of their popcounts
     __shared__ u32 s_wave[4];
     const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
@@ -1776,19 +1778,26 @@ __global__ __launch_bounds__(256) void bp_pairs_kernel(const u64* __restrict__ y
         for (u32 j = 0; j < 8u; ++j)
             if ((onbits >> j) & 1u) s_list[at++] = v0 + tid * 8u + j;
         __syncthreads();
+        for (u32 i = tid; i < nlist; i += 256u) s_slot[i] = perm ? perm[s_list[i]] : s_list[i];
+        __syncthreads();
     }
     // ---- pass A: popcount of every listed row, four rows per lane group in flight
     u32 total = 0;
     for (u32 i0 = 0; i0 < nlist; i0 += 4u * RPS) {
         u32 pc[4] = {0, 0, 0, 0};
+        const u64* row[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32 i = i0 + q * RPS + grp;
-            if (i < nlist) {
-                const u32 v = s_list[i];
-                const u64* row = y + (size_t)(perm ? perm[v] : v) * ws;
-                for (u32 k = wl; k < w; k += LN) pc[q] += (u32)__popcll(row[k]);
-            }
+            row[q] = y + (size_t)s_slot[i < nlist ? i : 0u] * ws;             // (clamped: the loads of the four rows go out together)
+        }
+        for (u32 k0 = 0; k0 < w; k0 += LN) {
+            const u32 k = k0 + wl < w ? k0 + wl : 0u;
+            u64 wd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wd[q] = row[q][k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pc[q] += (k0 + wl < w && i0 + q * RPS + grp < nlist) ? (u32)__popcll(wd[q]) : 0u;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1834,12 +1843,18 @@ __global__ __launch_bounds__(256) void bp_pairs_kernel(const u64* __restrict__ y
             const u32 k = k0 + wl;
             u64 word[2];
             u32 vv[2];
+            u32 sl[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const u32 i = i0 + q * RPS + grp;
                 vv[q] = i < nlist ? s_list[i] : 0xFFFFFFFFu;
-                word[q] = (vv[q] != 0xFFFFFFFFu && k < w) ? y[(size_t)(perm ? perm[vv[q]] : vv[q]) * ws + k] : 0ull;
+                sl[q] = s_slot[i < nlist ? i : 0u];
             }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) word[q] = y[(size_t)sl[q] * ws + (k < w ? k : 0u)];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (vv[q] == 0xFFFFFFFFu || k >= w) word[q] = 0ull;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const u32 i = i0 + q * RPS + grp;
