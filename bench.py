@@ -387,12 +387,18 @@ def khop_leg(ctx, engine, args, scale, nb_want, graph=None, parity_rows=1024, sc
         sc = {"sources": int(S)}
         for name, layers in (("clean", ([A] * hops, None, None)), ("dirty", ([A] * hops, [dp] * hops, [dm] * hops))):
             engine.expand_count(ctx, srcs[:S], *layers)                 # warm: the worker lanes' pools
-            ctx.sync()
-            t1 = time.perf_counter()
-            r = engine.expand_count(ctx, srcs[:S], *layers)
-            d = time.perf_counter() - t1
+            # (a call of a few passes deals them to its lanes as they come free: a lane that got one pass in the warm call and two
+            # in the timed one grows its pool — a hipMalloc of 10+ GB at RMAT-26 — inside the timed call; two timed calls, the faster
+            # one quoted, both recorded)
+            ds = []
+            for _ in range(2):
+                ctx.sync()
+                t1 = time.perf_counter()
+                r = engine.expand_count(ctx, srcs[:S], *layers)
+                ds.append(time.perf_counter() - t1)
+            d = min(ds)
             sc[name] = {"ms_per_call": round(d * 1e3, 3), "TEPS": round(r[2] / d, 1), "flops": int(r[2]), "out_nnz": int(r[0]),
-                        "ms_per_1024_sources": round(d * 1e3 / (S / 1024), 4)}
+                        "ms_per_1024_sources": round(d * 1e3 / (S / 1024), 4), "ms_calls": [round(x * 1e3, 3) for x in ds]}
             if name == "clean":
                 sc["live_sources"] = ctx.get_option("expand_scan_last_live")
                 sc["passes"] = ctx.get_option("expand_scan_last_passes")

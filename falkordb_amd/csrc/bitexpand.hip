@@ -1881,7 +1881,13 @@ __global__ __launch_bounds__(256) void bp_pairs_kernel(const u64* __restrict__ y
     }
 }
 
-static fgpu_info bp_to_csr_sorted(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out) {
+// `dense` (nullable): the count pass found more than BP_DENSE_OUT entries per vertex — a result that dense is cheaper through
+// the ballot transpose (one ballot serves many bits there, and it writes each row's ids as runs instead of sorting 28 B per
+// entry); the caller takes that path, nothing but the 50-80 us count pass is spent.  Crossover from the two forms' measured
+// costs (ballot ~99 us per M vertices + 4.9 us per M entries, pairs + sort ~7 + 17: equal at 7.6 entries per vertex; 2-hop
+// batches of 1024 rows sit at 1.8 - 3.8, the 3-hop batch of the headline at 115: 11.8 -> 2.8 ms; profiles/NOTES_r06.md section 12).
+constexpr u64 BP_DENSE_OUT = 8;
+static fgpu_info bp_to_csr_sorted(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out, bool* dense) {
     const u32 ntiles = cdiv(s.n ? s.n : 1, BP_PT);
     u32 lsh = 0;
     while ((2u << lsh) <= s.w && lsh < 4) ++lsh;          // lanes per row: the largest power of two <= min(w, 16)
@@ -1900,6 +1906,7 @@ static fgpu_info bp_to_csr_sorted(fgpu_ctx* ctx, const BitState& s, const u64* l
     FGPU_TRY(scan_u32_to_u64(ctx, tcnt.p, toff.p, (u64)ntiles + 1, nullptr));
     u64 nnz = 0;
     FGPU_TRY(read_u64(ctx, toff.p + ntiles, &nnz));
+    if (dense && nnz > BP_DENSE_OUT * (u64)s.n) { *dense = true; return FGPU_OK; }
     FGPU_REQUIRE(nnz < 0xFFFFFFFFull - 4096, FGPU_OOM,
                  "expand: %llu result entries exceed the 32-bit row-pointer space; batch the source rows", (unsigned long long)nnz);
     fgpu_mat* o = nullptr;
@@ -1939,7 +1946,12 @@ static fgpu_info bp_to_csr_sorted(fgpu_ctx* ctx, const BitState& s, const u64* l
 
 fgpu_info bp_to_csr(fgpu_ctx* ctx, const BitState& s, const u64* label_dev, fgpu_mat** out) {
     // (the sort's key space needs >= 2 rows; a result of a few entries is not worth its launches)
-    if (ctx->opt.expand_emit_sort && s.nsrc >= 2 && s.n >= 4096) return bp_to_csr_sorted(ctx, s, label_dev, out);
+    // expand_emit_sort: 1 = by the density the count pass finds, 2 = always pairs + sort, 0 = always the ballot transpose
+    if (ctx->opt.expand_emit_sort && s.nsrc >= 2 && s.n >= 4096) {
+        bool dense = false;
+        FGPU_TRY(bp_to_csr_sorted(ctx, s, label_dev, out, ctx->opt.expand_emit_sort == 1 ? &dense : nullptr));
+        if (!dense) return FGPU_OK;
+    }
     const u32 nchunks = cdiv(s.n ? s.n : 1, BP_VCHUNK);
     const u32 krows = s.w * 64;  // counted rows (>= nsrc; the tail rows are empty)
     const size_t ncnt = (size_t)krows * nchunks;

@@ -108,8 +108,9 @@ struct fgpu_options {  // fgpu_set_option
                                // non-temporal stores (1 GB per pass that would otherwise displace the partition's hot rows of X from its L2:
                                // stream kernel 824 -> 771 us at RMAT-22, no change at RMAT-26), 2 = its column-id stream is read non-temporal,
                                // 4 = the fold reads the partial rows non-temporal (2, 4: no effect, off; profiles/NOTES_r06.md section 7)
-    int expand_emit_sort = 1;   // bit state -> CSR: (row, vertex) pairs in vertex order + the LDS-staged stable sort by row (0 = the
-                               // ballot transpose of rounds 3-5, bp_rows_kernel; A/B)
+    int expand_emit_sort = 1;   // bit state -> CSR: 2 = (row, vertex) pairs in vertex order + the LDS-staged stable sort by row, 0 = the
+                               // ballot transpose of rounds 3-5 (bp_rows_kernel), 1 = pairs + sort unless the count pass finds more
+                               // than 8 entries per vertex (a dense result: the ballot transpose is 4 x cheaper there)
     int pinned_results = 1;    // result arrays >= 256 KiB come from the context's pinned-host pool and are filled by DMA (0 = the
                                // caller's allocator / malloc + staged copies, the round-3 path; A/B)
     int pinned_pool_mb = 4096; // pinned blocks kept for reuse after fgpu_free (beyond it they go back to the OS)

@@ -625,8 +625,10 @@ void* fgpu_ctx::pinned_alloc(size_t bytes) {
 }
 
 void* fgpu_ctx::result_alloc(size_t bytes) {
-    // (arrays beyond 1 GiB — an exported RMAT-26 adjacency — stay pageable: pinning them costs more than staging saves)
-    if (opt.pinned_results && bytes >= PIN_MIN && bytes <= ((size_t)1 << 30)) {
+    // (arrays the pool could not keep for the next call — beyond pinned_pool_mb, 4 GiB by default: an exported RMAT-26 adjacency
+    // — stay pageable.  Up to round 5 the bound was 1 GiB "because pinning costs what staging saves"; measured in round 6 on the
+    // 2 GB result of an emitting 3-hop batch: staged copy into pageable memory 317 ms, pinned ~40 us per MiB once, DMA after)
+    if (opt.pinned_results && bytes >= PIN_MIN && bytes <= ((size_t)opt.pinned_pool_mb << 20)) {
         void* p = pinned_alloc(bytes);
         if (p) return p;
     }
@@ -851,7 +853,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
         FGPU_REQUIRE(value >= 1 && value <= 16, FGPU_INVALID, "expand_scan_lanes must be 1 .. 16");
         ctx->opt.expand_scan_lanes = (int)value;
     } else if (!strcmp(name, "expand_emit_sort")) {
-        ctx->opt.expand_emit_sort = value != 0;
+        FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "expand_emit_sort is 0 (ballot transpose), 1 (by density) or 2 (pairs + sort)");
+        ctx->opt.expand_emit_sort = (int)value;
     } else if (!strcmp(name, "expand_records")) {
         ctx->opt.expand_records = value != 0;
     } else if (!strcmp(name, "expand_nt")) {

@@ -726,11 +726,13 @@ def test_expand_host_arrays_pinned_and_staged_paths_agree_with_the_oracle(ctx, r
         ctx.set_option("pinned_results", 1)
 
 
-@pytest.mark.parametrize("emit_sort", [1, 0])
+@pytest.mark.parametrize("emit_sort", [1, 2, 0])
 def test_expand32_and_both_emission_forms_agree_with_the_oracle(ctx, rmat18, emit_sort):
     """fgpu_expand32 — the result in the device's own 32-bit form, two DMAs, nothing widened — entry for entry against the
-    oracle's chain, with the bit state turned into rows by pairs + the stable sort (expand_emit_sort = 1, round 6) and by the
-    ballot transpose of rounds 3-5 (0); 2 and 3 hops (CSR and bit-form chains), dirty layers, NULL rows and a label."""
+    oracle's chain, with the bit state turned into rows by pairs + the stable sort (expand_emit_sort = 2, round 6), by the
+    ballot transpose of rounds 3-5 (0) and by whichever the density of the result picks (1, the default: the labelled 2-hop
+    result here is sparse, the others hold > 8 entries per vertex and take the ballot transpose after the pairs' count pass);
+    2 and 3 hops (CSR and bit-form chains), dirty layers, NULL rows and a label."""
     A, a = rmat18
     rng = np.random.default_rng(7)
     dm = oracle.sample(a, 0x18D, 500)
@@ -753,9 +755,11 @@ def test_expand32_and_both_emission_forms_agree_with_the_oracle(ctx, rmat18, emi
             np.testing.assert_array_equal(rowptr, f.rowptr.astype(np.uint32))
             np.testing.assert_array_equal(dest, f.colidx.astype(np.uint32))
             assert f.nnz > 1_000_000
+            assert f.nnz > 8 * a.nrows                            # (the dense side of the density rule, bitexpand.hip BP_DENSE_OUT)
             if hops == 2:
                 rowptr, dest, _ = engine.expand32(ctx, src, *dev, dst_label_bitmap=bits)
                 sel = label[f.colidx.astype(np.int64)]
+                assert 1_000_000 < int(sel.sum()) < 8 * a.nrows       # (... and its sparse side: pairs + sort)
                 np.testing.assert_array_equal(dest, f.colidx[sel].astype(np.uint32))
                 rows = np.repeat(np.arange(f.nrows), np.diff(f.rowptr).astype(np.int64))[sel]
                 np.testing.assert_array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=f.nrows))]).astype(np.uint32))

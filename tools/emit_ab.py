@@ -1,5 +1,6 @@
 """The emitting form of the chain (fgpu_expand_mat / fgpu_expand: what CondTraverse walks, cond_traverse.rs:644-751) with the
-bit state turned into rows by the ballot transpose (expand_emit_sort = 0, rounds 3-5) and by pairs + the stable sort (1):
+bit state turned into rows by the ballot transpose (expand_emit_sort = 0, rounds 3-5), by pairs + the stable sort (2) and by
+the density rule (1, the default):
 ms per batch on the device, into host arrays, the kernel table, and the two results compared array for array.
 usage: python tools/emit_ab.py [scale=24] [hops=2] [rows=1024] [batches=6]"""
 import json
@@ -23,7 +24,7 @@ A = ctx.mat_rmat(scale, 16, 0x5EED1234 + scale)
 srcs = bench.p_label_sources(A.nrows)
 bl = [srcs[j * 1024:j * 1024 + rows] for j in range(nb)]
 ref = None
-for mode in (0, 1, 0, 1):
+for mode in (0, 2, 1):
     ctx.set_option("expand_emit_sort", mode)
     for b in bl[:2]:
         m_, _ = engine.expand_mat(ctx, b, [A] * hops)
