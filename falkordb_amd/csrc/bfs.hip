@@ -80,6 +80,11 @@ struct BfsCtrl {
                                   // fused levels between two tiny-kernel launches next time
     u64 nnz_at;
     u64 n_total;     // != 0 selects the fused path's m_u estimate (vertex count)
+    u64 pb_min;      // propagation blocking (bfs_pb_* below): a push level with at least this many edges goes that way; 0 = never
+    u32 pb_mask;     // bit k: the host enqueued the four bfs_pb_* launches in front of fused launch k of this search
+    u32 pb_levels;   // levels of this search run that way
+    u32 pb_at;       // bit k: fused launch k of this search was such a level (the host arms the next search's launches with it)
+    u32 pb_pad;
     // per-launch accumulators, spread over slots to keep same-address atomics off the critical path; one slot per
     // 128 B: atomics to different words of ONE line serialise at the memory side just like same-address ones
     // (tools/micro/levelfloor.hip: 1792 workgroups' arrivals on 64 packed counters cost 8.6 us per launch, 0.6 us
@@ -101,6 +106,20 @@ struct BfsCtrl {
     u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
     u32 tick_pad[28];
     u32 tick[64 * TICK_PAD];   // (round-2 ticket counters; the slot words carry the tickets now — kept for the layout)
+};
+
+// propagation blocking of heavy push levels (the bfs_pb_* kernels further down)
+constexpr u32 PB_BINS = 256;
+constexpr u32 PB_C = 8192;          // edges per chunk: 8 per thread of a 1024-thread workgroup
+constexpr u32 PB_T = 1024;
+struct PbPart { u64 count, mf; u32 hub; u32 pad[11]; };   // a window's share of the level statistics (one 64-byte line)
+struct BfsPb {
+    u32 nlist, nchunks, total, shift;   // rows of the compacted frontier, chunks, edges of the level; log2(vertices per window)
+    u32 pad[28];
+    unsigned long long agg[64];         // bfs_pb_prefix_kernel's look-back words (zero between levels)
+    u32 count[PB_BINS * 32];            // entries per bin, a counter per 128 bytes (same-line atomics serialise)
+    u32 cursor[PB_BINS * 32];
+    PbPart part[PB_BINS];
 };
 
 struct BfsArgs {
@@ -128,6 +147,7 @@ struct BfsArgs {
     u64* slab_nxt;    // this level's send buffer (slabw words), indexed with the GLOBAL word index minus lo / 64
     u64* slab_zero;   // the other send buffer: zeroed for the next level
     const u32* gdeg;  // nullable: global out-degree of every vertex (a column slab only knows its own share)
+    const BfsPb* pb;   // nullable: the plan's propagation-blocking block (direction 3 levels, bfs_pb_* below)
 };
 
 __device__ __forceinline__ bool test_bit(const u64* bm, u32 v) {
@@ -957,6 +977,8 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
     const u32 pl0 = c->push_levels, pll0 = c->pull_levels;
     const u32 q_open0 = c->q_open, force_dir = c->force_dir, has_at = c->has_at;
     const u64 n_total = c->n_total, nnz_at = c->nnz_at;
+    const u64 pb_min = c->pb_min;
+    const u32 pb_mask = c->pb_mask, pb_at0 = c->pb_at;
     const float alpha = c->alpha;
     u64 v0 = __hip_atomic_load(&c->slot[t].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v1 = __hip_atomic_load(&c->slot[t].mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -999,7 +1021,7 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
     }
     if (t != 0) return;
     // ---- lane 0: register arithmetic, then stores only -----------------------------------------------------------------
-    if (dir0 == 1) { c->scanned_push = sp0 + v3; c->push_levels = pl0 + 1; }
+    if (dir0 != 2) { c->scanned_push = sp0 + v3; c->push_levels = pl0 + 1; }   // (3 = a push by propagation blocking)
     else { c->scanned_pull = spl0 + v3; c->pull_levels = pll0 + 1; }
     const i32 level = level0 + 1;
     c->level = level;
@@ -1057,8 +1079,10 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
     c->hubs[rot & 1] = 0;
     const bool done = (v0 == 0) || (max_level >= 0 && level >= max_level);
     c->done = done ? 1 : 0;
-    if (done && host_done)  // the host polls this word instead of paying a D2H copy + stream sync
+    if (done && host_done) {  // the host polls this word instead of paying a D2H copy + stream sync
+        __hip_atomic_store(host_done + 1, pb_at0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (read after the flag; a hint)
         __hip_atomic_store(host_done, done_word_of(hb, he, level), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     int nd = 1;
     if (force_dir == 1 || !has_at) nd = 1;
     else if (force_dir == 2) nd = 2;
@@ -1067,21 +1091,24 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
         const u64 m_u = (u64)((double)nnz_at * un / (double)n_total);
         nd = ((double)v1 * (double)alpha > (double)m_u) ? 2 : 1;
     }
+    // (the tiny kernel's control steps — nwg == 0 — are not fused launches: the count stays)
+    const unsigned long long seq = (__hip_atomic_load(&c->nact_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + (nwg ? 1ull : 0ull);
+    // a heavy push of a queue-listed frontier goes by propagation blocking (bfs_pb_* below) when the host put its four
+    // launches in front of the next fused launch (= launch `seq` of the search)
+    const bool pb = nd == 1 && use_queue && !done && nwg && pb_min && v1 >= pb_min && seq < 32ull && ((pb_mask >> (u32)seq) & 1u);
+    if (pb) { nd = 3; c->pb_at = pb_at0 | (1u << (u32)seq); }
     c->direction = nd;
     // the next level may append its discoveries only if it is light: a push examines m_frontier
     // edges, a pull can discover at most the unvisited vertices
     const u64 unv = n_total > reached ? n_total - reached : 0;
-    c->q_open = ((nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u;
+    c->q_open = (!pb && (nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u;
     // workgroups the next launch needs: twice its work items (queue chunks + one per 1024 hub-row edges), at least 64
     u32 na = 0;
     if (nd == 1 && use_queue && !done) {
         const u64 items = (u64)QSHARDS * ((qmx + qchunk - 1) / qchunk) + v1 / PUSH_HUB_CHUNK + 1;
         na = items * 2 < 64 ? 64u : (items * 2 > 60000ull ? 0u : (u32)(items * 2));
     }
-    {   // (the tiny kernel's control steps — nwg == 0 — are not fused launches: the count stays)
-        const unsigned long long seq = (__hip_atomic_load(&c->nact_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + (nwg ? 1ull : 0ull);
-        __hip_atomic_store(&c->nact_seq, (seq << 32) | (unsigned long long)na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __hip_atomic_store(&c->nact_seq, (seq << 32) | (unsigned long long)na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     c->tiny = (!done && nd == 1 && use_queue && v1 <= TINY_EDGES && v0 <= TINY_VERTS) ? 1u : 0u;
     c->zr_dirty = 1;   // bfs_tiny_kernel resets it after its own levels
 }
@@ -1147,7 +1174,18 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
         g_bfs_dbg[blockIdx.x * 8 + 7] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
     }
 #endif
-    if (dir == 1)
+    if (dir == 3) {
+        // the level was run by the bfs_pb_* launches in front of this one: the windows' statistics go through this launch's
+        // ticket like any level's
+        if (threadIdx.x == 0) {
+            for (u32 b = blockIdx.x; b < PB_BINS; b += nwg) {
+                acc.count += a.pb->part[b].count;
+                acc.mf += a.pb->part[b].mf;
+                acc.hub |= a.pb->part[b].hub;
+            }
+            if (blockIdx.x == 0) acc.scanned += a.pb->total;
+        }
+    } else if (dir == 1)
         push_fused<PARENT>(a, cur, use_q ? a.queue[rot & 1] : nullptr, &c->qlen[rot & 1][0], qmax, qchunk, hubs_present,
                            a.visited, nxt, newlevel, qc, acc, nwg);
     else
@@ -1289,6 +1327,443 @@ __global__ __launch_bounds__(256) void bfs_tiny_kernel(BfsArgs a) {
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Heavy push levels by propagation blocking (round 6; direction 3 of the fused single-rank path)
+// ---------------------------------------------------------------------------------
+// What a push discovery costs is its memory-side operations: a returning device-scope atomicOr on `visited`, an atomicOr on the
+// next frontier, a scattered level store, a degree read — ~12 G discoveries/s chip-wide (tools/micro/atomicbw.hip), whatever the
+// scope of the atomics and whichever XCD owns the words (tools/micro/atomscope.hip, round 6: workgroup-scope atomics on words
+// only one XCD touches run at the same 10-16 G/s).  At RMAT-22 the heaviest push level examines ~1 M edges (26 us); at RMAT-26
+// the level that expands ~10^4 near-hub vertices examines 40-50 M edges and discovers 8-9 M vertices in 1.2-1.4 ms — two
+// thirds of a 2.2 ms search (tools/level_stats.py 26), and a pull of the same level is no cheaper (alpha sweep, plan_create).
+// Propagation blocking (Beamer et al., "Reducing PageRank communication via propagation blocking", here for BFS) takes the
+// atomics out: the destinations of the frontier's edges are first BINNED by 2^shift-vertex window (256 windows; LDS-staged
+// counting sort per 8192-edge chunk, whole runs written), then ONE workgroup per window marks its bin's destinations in a copy
+// of the window's `visited` words in LDS — discoveries are LDS atomics, visited / next leave as whole words, plain stores.
+//   bfs_pb_prefix_kernel   one workgroup: the frontier queue -> compacted list of its rows with edges, the exclusive prefix of
+//                          their degrees, every chunk's first row; zeroes the bin counters
+//   bfs_pb_count_kernel    per chunk: histogram of the destinations' windows -> bin totals (one global add per bin and chunk)
+//   bfs_pb_scatter_kernel  per chunk: the destinations (and their sources, when parents are wanted) sorted by window in LDS,
+//                          written into the bins in runs
+//   bfs_pb_apply_kernel    per window: visited / next / level / parent / the level's statistics
+// and the fused level kernel that follows only zeroes its bitmap, sums the windows' statistics through its ticket and runs
+// the control step.  All four return at once unless the control step of the previous level chose direction 3 — which it only
+// does for a queue-listed frontier (<= 65536 vertices) with at least `bfs_pb_min_edges` edges, in front of a fused launch the
+// host enqueued them for (BfsCtrl::pb_mask).
+struct PbArgs {
+    BfsCtrl* ctrl;
+    BfsPb* pb;
+    const u32* queue[2];
+    const u32* deg;          // out-degree per vertex
+    CsrView A;
+    u32 *tmpv, *tmpd;        // QCAP each: the queue flattened, its degrees
+    u32 *list, *P, *S;       // compacted frontier rows, exclusive prefix of their degrees (nlist + 1), first entry of each in colidx
+    u32* crow;               // chunk -> index of the row holding its first edge
+    u32 *dst, *src;          // the bins
+    u32* wgh;                // [workgroups of the count / scatter launches][PB_BINS]: a workgroup's histogram over its chunks
+    u64* bm[3];
+    u64* visited;
+    i32* level;
+    u32* parent;             // nullable
+    u32 nw;
+};
+
+__device__ __forceinline__ bool pb_level(const BfsCtrl* c) { return !c->done && c->direction == 3; }
+
+// block-wide exclusive scan of one u32 per thread (PB_T threads); returns the exclusive prefix, *total = the sum
+__device__ __forceinline__ u32 pb_block_scan(u32 v, u32* s_w /* >= 17 words */, u32* total) {
+    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = (u32)__shfl_up((int)inc, o, 64); if ((int)lane >= o) inc += t; }
+    __syncthreads();                                         // (s_w may still be read from a previous scan)
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+    const u32 nwv = blockDim.x >> 6;
+    for (u32 q = 0; q < nwv; ++q) { const u32 x = s_w[q]; if (q < wv) base += x; tot += x; }
+    *total = tot;
+    return base + inc - v;
+}
+
+// QCAP / PB_T = 64 workgroups, a queue position per thread: ONE workgroup doing the ~3 x 10^4 random reads of a frontier's degrees
+// and row pointers took 75-90 us at RMAT-26 (a single CU sustains ~0.5 G random lines/s), whatever the number of dependent
+// round trips.  The prefix across workgroups is a one-wavefront look-back: a workgroup publishes (rows with edges, edges) of its
+// 1024 positions in one 64-bit word of BfsPb::agg (bit 63 = published), its first wavefront reads the words of ALL the
+// workgroups before it in one load and spins until they are there — 64 workgroups are always resident together.  The apply
+// kernel, last of the level's launches, zeroes the words again.
+__global__ __launch_bounds__(PB_T) void bfs_pb_prefix_kernel(PbArgs g) {
+    BfsCtrl* c = g.ctrl;
+    if (!pb_level(c)) return;
+    __shared__ u32 s_ql[QSHARDS + 1];
+    __shared__ u32 s_w[20];
+    __shared__ u32 s_basec, s_bases;
+    const u32 t = threadIdx.x, blk = blockIdx.x;
+    const u32 rot = c->rot;
+    const u32* __restrict__ q = g.queue[rot & 1];
+    if (t < QSHARDS) {                                       // the eight segment lengths in one round of loads
+        const u32 l = c->qlen[rot & 1][t * 16];
+        const u32 len = l < QSEG ? l : QSEG;
+        u32 inc = len;
+#pragma unroll
+        for (int o = 1; o < (int)QSHARDS; o <<= 1) { const u32 x = (u32)__shfl_up((int)inc, o, 64); if ((int)t >= o) inc += x; }
+        s_ql[t] = inc - len;
+        if (t == QSHARDS - 1) s_ql[QSHARDS] = inc;
+    }
+    if (blk == 0)
+        for (u32 i = t; i < PB_BINS; i += PB_T) { g.pb->count[i * 32] = 0; g.pb->cursor[i * 32] = 0; }
+    __syncthreads();
+    const u32 nq = s_ql[QSHARDS];
+    const u32 pos = blk * PB_T + t;
+    const u32 pc = pos < nq ? pos : (nq ? nq - 1u : 0u);     // (every load from a clamped address)
+    u32 sc = 0;
+#pragma unroll
+    for (u32 k = 1; k < QSHARDS; ++k) sc += (s_ql[k] <= pc) ? 1u : 0u;
+    const u32 v = q[sc * QSEG + (pc - s_ql[sc])];
+    u32 d = g.deg[v];
+    const u32 rs = g.A.rowptr[v];
+    if (pos >= nq) d = 0;
+    u32 bc, bs;
+    const u32 lc = pb_block_scan(d ? 1u : 0u, s_w, &bc);
+    const u32 ls = pb_block_scan(d, s_w, &bs);
+    unsigned long long* agg = const_cast<unsigned long long*>(g.pb->agg);
+    if (t == 0)
+        __hip_atomic_store(&agg[blk], (1ull << 63) | ((unsigned long long)bc << 32) | (unsigned long long)bs, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 64) {
+        unsigned long long w = 0ull;
+        if (t < blk) {
+            do { w = __hip_atomic_load(&agg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(w >> 63));
+        }
+        u32 pcn = (u32)(w >> 32) & 0x7FFFFFFFu, psm = (u32)w;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { pcn += (u32)__shfl_xor((int)pcn, o, 64); psm += (u32)__shfl_xor((int)psm, o, 64); }
+        if (t == 0) { s_basec = pcn; s_bases = psm; }
+    }
+    __syncthreads();
+    const u32 ci = s_basec + lc, run = s_bases + ls;
+    if (d) {
+        g.list[ci] = v;
+        g.P[ci] = run;
+        g.S[ci] = rs;
+        // the chunks that begin inside this row's edges [run, run + d)
+        for (u32 kk = (run + PB_C - 1) / PB_C; (u64)kk * PB_C < (u64)run + d; ++kk) g.crow[kk] = ci;
+    }
+    if (blk == gridDim.x - 1 && t == 0) {                    // the last workgroup knows the totals
+        const u32 nlist = s_basec + bc, total = s_bases + bs;
+        g.P[nlist] = total;
+        const u32 nch = (total + PB_C - 1) / PB_C;
+        g.crow[nch] = nlist ? nlist - 1 : 0;
+        g.pb->nlist = nlist;
+        g.pb->total = total;
+        g.pb->nchunks = nch;
+        c->pb_levels += 1;
+    }
+}
+
+// the rows of a chunk: sP / sS = prefix and first colidx entry of rows r0 .. r0 + nwin (inclusive: the sentinel closes the last)
+__device__ __forceinline__ u32 pb_window(const PbArgs& g, u32 r0, u32 r1, u32 nlist, u32* sP, u32* sS) {
+    const u32 nwin = r1 - r0 + 1;
+    for (u32 i = threadIdx.x; i <= nwin; i += PB_T) {
+        const u32 r = r0 + i <= nlist ? r0 + i : nlist;
+        sP[i] = g.P[r];
+        sS[i] = g.S[r < nlist ? r : (nlist ? nlist - 1u : 0u)];
+    }
+    return nwin;
+}
+// the rows (indices into the window) of a thread's eight edges: the last i with sP[i] <= e — eight searches step by step
+// together (one after the other they were 8 x 14 dependent LDS reads per chunk)
+__device__ __forceinline__ void pb_rows_of(const u32* sP, u32 nwin, const u32 (&e)[8], u32 (&row)[8]) {
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { lo[k] = 0; hi[k] = nwin; }
+    for (u32 span = nwin; span > 1; span = (span + 1) >> 1) {            // (wave-uniform trip count: ceil(log2(nwin)))
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u32 mid = (lo[k] + hi[k]) >> 1;
+            const bool go = hi[k] - lo[k] > 1 && sP[mid] <= e[k];
+            const bool stay = hi[k] - lo[k] > 1 && !go;
+            lo[k] = go ? mid : lo[k];
+            hi[k] = stay ? mid : hi[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) row[k] = lo[k];
+}
+
+// One histogram add per RUN of equal bins among a wavefront's 64 consecutive edges, not per lane: a row's neighbours are sorted
+// by id, so the 64 consecutive edges of a hub row (10^5 - 10^6 entries over 2^26 ids) fall into ONE window and 64 lanes adding
+// to one LDS word are served one after the other — measured at RMAT-26 (52 M edges): count pass 189 us with a lane per add,
+// 53 us with pseudo-random bins (tools/experiments/pb_dbg.sh).  Returns the entry's rank inside its bin (valid lanes).
+__device__ __forceinline__ u32 pb_hist_add(u32* s_hist, u32 b, bool valid, u32 lane) {
+    const u32 key = valid ? b : 0xFFFFFFFFu - lane;          // (an invalid lane never continues a run)
+    const u32 pk = (u32)__shfl_up((int)key, 1, 64);
+    const bool head = lane == 0 || pk != key;
+    const u64 heads = __ballot(head);
+    const u64 at_or_below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const u32 hl = 63u - (u32)__builtin_clzll(at_or_below);
+    const u64 above = (heads >> 1) >> lane;
+    const u32 len = above ? 1u + (u32)__builtin_ctzll(above) : 64u - lane;
+    u32 base = 0;
+    if (head && valid) base = atomicAdd(&s_hist[b], len);
+    base = (u32)__shfl((int)base, (int)hl, 64);
+    return base + (lane - hl);
+}
+
+// Both passes give workgroup w the SAME contiguous range of chunks, [w x kper, (w + 1) x kper): the count pass keeps one
+// histogram per workgroup over all its chunks (one global add per bin and WORKGROUP — per chunk it was 1.6 M same-address
+// atomics a pass at RMAT-26 — and the histogram itself in wgh[w][bin]); the scatter pass reserves the workgroup's share of
+// every bin with one returning add and then only adds chunk histograms to its own running offsets.
+__global__ __launch_bounds__(PB_T) void bfs_pb_count_kernel(PbArgs g) {
+    if (!pb_level(g.ctrl)) return;
+    extern __shared__ u32 s_dyn[];
+    u32* sP = s_dyn;                      // PB_C + 2
+    u32* sS = sP + PB_C + 2;              // PB_C + 2
+    u32* s_hist = sS + PB_C + 2;          // PB_BINS
+    const u32 nch = g.pb->nchunks, nlist = g.pb->nlist, total = g.pb->total, shift = g.pb->shift;
+    const u32 t = threadIdx.x;
+    const u32 kper = (nch + gridDim.x - 1) / gridDim.x;
+    const u32 c0 = blockIdx.x * kper, c1 = c0 + kper < nch ? c0 + kper : nch;
+    for (u32 i = t; i < PB_BINS; i += PB_T) s_hist[i] = 0;
+    u32 rnext = c0 < c1 ? g.crow[c0] : 0u;
+    for (u32 c = c0; c < c1; ++c) {
+        const u32 r0 = rnext, r1 = g.crow[c + 1];
+        rnext = r1;
+        __syncthreads();                                     // (the previous chunk's searches are done with sP)
+        const u32 nwin = pb_window(g, r0, r1, nlist, sP, sS);
+        __syncthreads();
+        const u32 e0 = c * PB_C;
+        u32 e[8], row[8], v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const u32 x = e0 + t + k * PB_T; e[k] = x < total ? x : total - 1; }
+        pb_rows_of(sP, nwin, e, row);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = g.A.colidx[sS[row[k]] + (e[k] - sP[row[k]])];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) (void)pb_hist_add(s_hist, v[k] >> shift, e0 + t + k * PB_T < total, t & 63u);
+    }
+    __syncthreads();
+    for (u32 b = t; b < PB_BINS; b += PB_T) {
+        const u32 h = s_hist[b];
+        g.wgh[(size_t)blockIdx.x * PB_BINS + b] = h;
+        if (h) atomicAdd(&g.pb->count[b * 32], h);
+    }
+}
+
+// exclusive scan of the bin totals into s_base[PB_BINS] (every workgroup computes its own copy)
+__device__ __forceinline__ void pb_bin_bases(const BfsPb* pb, u32* s_base, u32* s_w) {
+    const u32 t = threadIdx.x;
+    const u32 h = t < PB_BINS ? pb->count[t * 32] : 0u;
+    u32 tot;
+    const u32 ex = pb_block_scan(h, s_w, &tot);
+    if (t < PB_BINS) s_base[t] = ex;
+    __syncthreads();
+}
+
+template <bool PARENT>
+__global__ __launch_bounds__(PB_T) void bfs_pb_scatter_kernel(PbArgs g) {
+    if (!pb_level(g.ctrl)) return;
+    extern __shared__ u32 s_dyn[];
+    u32* sP = s_dyn;                      // PB_C + 2; the sorted destinations once the edges are in registers
+    u32* sS = sP + PB_C + 2;              // PB_C + 2; ... their sources
+    u32* s_hist = sS + PB_C + 2;          // PB_BINS
+    u32* s_loc = s_hist + PB_BINS;        // PB_BINS: first staged position of a bin
+    u32* s_gb = s_loc + PB_BINS;          // PB_BINS: where the workgroup's next run of a bin goes
+    __shared__ u32 s_w[20];
+    const u32 nch = g.pb->nchunks, nlist = g.pb->nlist, total = g.pb->total, shift = g.pb->shift;
+    const u32 t = threadIdx.x;
+    const u32 kper = (nch + gridDim.x - 1) / gridDim.x;
+    const u32 c0 = blockIdx.x * kper, c1 = c0 + kper < nch ? c0 + kper : nch;
+    if (c0 >= c1) return;                                    // (block-uniform)
+    pb_bin_bases(g.pb, s_gb, s_w);
+    if (t < PB_BINS) {                                       // this workgroup's share of every bin, reserved once
+        const u32 h = g.wgh[(size_t)blockIdx.x * PB_BINS + t];
+        s_gb[t] += h ? atomicAdd(&g.pb->cursor[t * 32], h) : 0u;
+    }
+    u32 rnext = g.crow[c0];
+    for (u32 c = c0; c < c1; ++c) {
+        const u32 r0 = rnext, r1 = g.crow[c + 1];
+        rnext = r1;
+        __syncthreads();                                     // (the previous chunk's runs have left sP / sS; s_gb is set)
+        for (u32 i = t; i < PB_BINS; i += PB_T) s_hist[i] = 0;
+        const u32 nwin = pb_window(g, r0, r1, nlist, sP, sS);
+        __syncthreads();
+        const u32 e0 = c * PB_C;
+        const u32 ne = total - e0 < PB_C ? total - e0 : PB_C;
+        u32 e[8], row[8], v[8], u[8], rk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const u32 x = e0 + t + k * PB_T; e[k] = x < total ? x : total - 1; }
+        pb_rows_of(sP, nwin, e, row);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = g.A.colidx[sS[row[k]] + (e[k] - sP[row[k]])];
+            u[k] = PARENT ? g.list[r0 + row[k]] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rk[k] = pb_hist_add(s_hist, v[k] >> shift, t + k * PB_T < ne, t & 63u);
+        __syncthreads();                                     // sP / sS are free from here
+        u32 h = 0, tot;
+        if (t < PB_BINS) h = s_hist[t];
+        const u32 ex = pb_block_scan(h, s_w, &tot);
+        if (t < PB_BINS) s_loc[t] = ex;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (t + k * PB_T < ne) {
+                const u32 at = s_loc[v[k] >> shift] + rk[k];
+                sP[at] = v[k];
+                if (PARENT) sS[at] = u[k];
+            }
+        __syncthreads();
+        for (u32 i = t; i < ne; i += PB_T) {
+            const u32 vv = sP[i];
+            const u32 b = vv >> shift;
+            const u32 at = s_gb[b] + (i - s_loc[b]);
+            g.dst[at] = vv;
+            if (PARENT) g.src[at] = sS[i];
+        }
+        __syncthreads();
+        if (t < PB_BINS) s_gb[t] += h;                       // the workgroup's next run of the bin follows this one
+    }
+}
+
+// A window's bin: (1) every destination ORs its bit into the LDS copy of the window's `visited` words — nothing else in that loop
+// (on gfx9 a pending global store makes every later wait a vmcnt(0): with the level store and the degree read of a discovery in
+// the loop the kernel took 460 us for 52 M entries at RMAT-26, 56 us without them; only the parent of a discovery, when parents
+// are wanted, is stored there); (2) new bits = LDS word ^ visited word: visited and the next frontier leave as whole words;
+// (3) the window's degrees are read in vertex order, coalesced, and summed over the new bits; (4) the levels of the new bits
+// are stored — a loop of stores only.
+template <bool PARENT>
+__global__ __launch_bounds__(PB_T) void bfs_pb_apply_kernel(PbArgs g) {
+    BfsCtrl* c = g.ctrl;
+    if (!pb_level(c)) return;
+    extern __shared__ u32 s_dyn[];
+    u32* s_vis = s_dyn;                                      // 2^shift bits
+    __shared__ u32 s_base[PB_BINS];
+    __shared__ u32 s_w[20];
+    __shared__ unsigned long long s_acc[2];
+    __shared__ u32 s_hub;
+    const u32 t = threadIdx.x;
+    if (blockIdx.x == 0 && t < 64) g.pb->agg[t] = 0ull;      // (the prefix kernel's look-back words, for the next such level)
+    const u32 shift = g.pb->shift;
+    const u32 rot = c->rot;
+    const i32 newlevel = c->level + 1;
+    const u32 nv_all = g.A.nrows ? (u32)g.A.nrows : 1u;      // degrees exist for vertices below this
+    u64* __restrict__ nxt = g.bm[(rot + 1) % 3];
+    pb_bin_bases(g.pb, s_base, s_w);
+    const u32 ww = 1u << (shift - 6);                        // 64-bit words per window
+    for (u32 b = blockIdx.x; b < PB_BINS; b += gridDim.x) {
+        const u32 cnt = g.pb->count[b * 32];
+        const u32 w0 = b * ww;
+        if (t < 2) s_acc[t] = 0ull;
+        if (t == 0) s_hub = 0;
+        if (cnt == 0 || w0 >= g.nw) {                        // (block-uniform)
+            __syncthreads();
+            if (t == 0) { g.pb->part[b].count = 0; g.pb->part[b].mf = 0; g.pb->part[b].hub = 0; }
+            __syncthreads();
+            continue;
+        }
+        const u32 nwd = g.nw - w0 < ww ? g.nw - w0 : ww;
+        for (u32 i = t; i < nwd; i += PB_T) reinterpret_cast<u64*>(s_vis)[i] = g.visited[w0 + i];
+        __syncthreads();
+        const u32 off = s_base[b], vbase = b << shift;
+        // (1) eight entries per thread and round, the next round's requested before this round's are looked at
+        constexpr int R = 8;
+        u32 v[R], u[R], vn[R], un[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const u32 i = t + k * PB_T;
+            vn[k] = g.dst[off + (i < cnt ? i : cnt - 1)];
+            un[k] = PARENT ? g.src[off + (i < cnt ? i : cnt - 1)] : 0u;
+        }
+        for (u32 i0 = 0; i0 < cnt; i0 += PB_T * R) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) { v[k] = vn[k]; u[k] = un[k]; }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const u32 i = i0 + PB_T * R + t + k * PB_T;
+                vn[k] = g.dst[off + (i < cnt ? i : cnt - 1)];
+                un[k] = PARENT ? g.src[off + (i < cnt ? i : cnt - 1)] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const u32 lv = v[k] - vbase, bit = 1u << (lv & 31u);
+                if (i0 + t + k * PB_T < cnt) {
+                    if (PARENT) {
+                        const u32 old = atomicOr(&s_vis[lv >> 5], bit);
+                        if (!(old & bit)) g.parent[v[k]] = u[k];
+                    } else {
+                        atomicOr(&s_vis[lv >> 5], bit);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // (2) whole words out; the LDS copy keeps the NEW bits only
+        for (u32 i = t; i < nwd; i += PB_T) {
+            const u64 nv = reinterpret_cast<const u64*>(s_vis)[i], ov = g.visited[w0 + i];
+            const u64 nb = nv ^ ov;
+            if (nb) { g.visited[w0 + i] = nv; nxt[w0 + i] = nb; }
+            reinterpret_cast<u64*>(s_vis)[i] = nb;
+        }
+        __syncthreads();
+        // (3) + (4) side by side: wavefronts 0-7 read the window's degrees (vertex order, four consecutive vertices per load, eight
+        // loads in flight) and sum them over the new bits — loads only; wavefronts 8-15 store the levels of the new bits — stores
+        // only (a wavefront's own counter is what a store would hold up; measured apart: 67 us and 96 us of a 211 us kernel)
+        u64 n_new = 0, mf = 0;
+        u32 hub = 0;
+        const u32 nvert = nwd * 64u;
+        constexpr u32 HT = PB_T / 2;
+        if (t < HT) {
+            const bool vec_ok = vbase + nvert <= nv_all;       // (the window lies inside the degree array: whole quads)
+            for (u32 j0 = 0; j0 < nvert; j0 += HT * 4 * R) {
+                uint4 dq[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const u32 lv = j0 + (t + k * HT) * 4u;
+                    if (vec_ok) dq[k] = *reinterpret_cast<const uint4*>(g.deg + vbase + (lv < nvert ? lv : 0u));
+                    else {
+                        const u32 a0 = vbase + lv;
+                        dq[k].x = g.deg[a0 < nv_all ? a0 : nv_all - 1u];
+                        dq[k].y = g.deg[a0 + 1 < nv_all ? a0 + 1 : nv_all - 1u];
+                        dq[k].z = g.deg[a0 + 2 < nv_all ? a0 + 2 : nv_all - 1u];
+                        dq[k].w = g.deg[a0 + 3 < nv_all ? a0 + 3 : nv_all - 1u];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const u32 lv = j0 + (t + k * HT) * 4u;
+                    const u32 nib = lv < nvert ? (s_vis[lv >> 5] >> (lv & 31u)) & 15u : 0u;
+                    const u32 dd[4] = {dq[k].x, dq[k].y, dq[k].z, dq[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool on = (nib >> q) & 1u;
+                        n_new += on ? 1u : 0u;
+                        mf += on ? dd[q] : 0u;
+                        hub |= (on && dd[q] >= PUSH_HUB_DEG) ? 1u : 0u;
+                    }
+                }
+            }
+        } else {
+            for (u32 lv = t - HT; lv < nvert; lv += HT)
+                if ((s_vis[lv >> 5] >> (lv & 31u)) & 1u) g.level[vbase + lv] = newlevel;
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            n_new += __shfl_xor(n_new, dd, 64);
+            mf += __shfl_xor(mf, dd, 64);
+        }
+        if (__ballot(hub != 0) != 0ull && lane_id() == 0) s_hub = 1;
+        if (lane_id() == 0 && n_new) {
+            atomicAdd(&s_acc[0], (unsigned long long)n_new);
+            atomicAdd(&s_acc[1], (unsigned long long)mf);
+        }
+        __syncthreads();
+        if (t == 0) { g.pb->part[b].count = s_acc[0]; g.pb->part[b].mf = s_acc[1]; g.pb->part[b].hub = s_hub; }
         __syncthreads();
     }
 }
@@ -1474,7 +1949,7 @@ __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u
 // memsets + bfs_init_kernel).  Every word is written by exactly one thread, which also applies the
 // seed value if the source falls into its word; workgroup 0 owns the control block.
 __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at,
-                                                             u32 force_dir, float alpha, u64 nnz_at) {
+                                                             u32 force_dir, float alpha, u64 nnz_at, u64 pb_min, u32 pb_mask) {
     const u32 tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     // level[] is NOT cleared: level[v] is meaningful exactly where the visited bitmap has v set (the on-device
     // result is the pair); fgpu_bfs_fetch masks the rest to -1 on its way out (bfs_mask_levels_kernel).
@@ -1503,6 +1978,8 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     c->alpha = alpha;
     c->nnz_at = nnz_at;
     c->n_total = a.n;
+    c->pb_min = a.pb ? pb_min : 0ull;
+    c->pb_mask = pb_mask;
     a.queue[0][0] = src;
     c->qlen[0][0] = 1;
     c->qmax = 1;
@@ -1748,6 +2225,14 @@ struct fgpu_bfs_plan {
     u32* dist_deg = nullptr;
     u32 fused_idx = 0;                       // fused launches enqueued since fused_begin: launch k runs the instantiation of parity k & 1
     u32* own_deg = nullptr;                  // single-rank plans: out-degree of every vertex (one 4-byte read per discovery)
+    // propagation blocking of heavy push levels (bfs_pb_*): the control / statistics block, one allocation for the small arrays
+    // (tmpv | tmpd | list | P | S | crow) and the bins; pb_mask = the fused launches of the search in flight that have the four
+    // launches in front of them
+    BfsPb* pb = nullptr;
+    u32* pb_small = nullptr;
+    u32 *pb_dst = nullptr, *pb_src = nullptr;
+    u32 pb_maxchunks = 0, pb_mask = 0;
+    u32 pb_seen = 0, pb_searches = 0;        // fused launches that were such levels in this plan's searches so far; searches run
     bool dist_ready = false;
     std::vector<hipEvent_t> dist_ev;    // 3 per level: before the level kernel, after it, after the collective
     hipEvent_t dist_copied = nullptr;   // peer exchange: "this rank has delivered its words of the level" (kept across searches)
@@ -1774,6 +2259,7 @@ static BfsArgs make_args(fgpu_bfs_plan* p, bool fused = false) {
     a.ctrl = p->ctrl;
     a.nw = p->nw;
     a.slab_mode = 0; a.slabw = p->slabw; a.slab_nxt = nullptr; a.slab_zero = nullptr; a.gdeg = p->own_deg;
+    a.pb = fused ? p->pb : nullptr;
     if (p->bm_block && fused) {
         a.bm[0] = p->bm_block;
         a.bm[1] = p->bm_block + p->nw;
@@ -1825,6 +2311,10 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->slab_ring[2]);
     c->dev_free(p->dist_deg);
     c->dev_free(p->own_deg);
+    c->dev_free(p->pb);
+    c->dev_free(p->pb_small);
+    c->dev_free(p->pb_dst);
+    c->dev_free(p->pb_src);
     for (hipEvent_t e : p->dist_ev) (void)hipEventDestroy(e);
     if (p->dist_copied) (void)hipEventDestroy(p->dist_copied);
     c->flag_release(p->h_ctrl);   // (pooled: a plan never calls hipHostFree, see fgpu_ctx::flag_alloc)
@@ -1936,6 +2426,36 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
     if (i == FGPU_OK && nranks == 1) {
         i = ctx->dev_alloc((void**)&p->own_deg, ((size_t)p->n + 1) * sizeof(u32));
         if (i == FGPU_OK) i = fgpu_mat_row_degrees(ctx, A, p->own_deg);
+    }
+    // propagation blocking of heavy push levels: plans of >= 2^25 vertices (option bfs_pb; 2 = any; at RMAT-24 no push level is
+    // heavy enough and the armed launches cost 2-3 %: 0.513 -> 0.528 ms), windows of at most 2^19
+    // vertices (64 KiB of LDS), the bins sized for every edge of A.  An optional accelerator: without its memory the plan
+    // simply pushes as before.
+    if (i == FGPU_OK && nranks == 1 && !splits && ctx->opt.bfs_pb &&
+        (ctx->opt.bfs_pb == 2 || p->n >= (1u << 25)) && (u64)p->nw * 64 <= ((u64)PB_BINS << 19) && A->nnz + PB_C < 0xFFFFFFFFull) {
+        u32 shift = 6;
+        while (((u64)PB_BINS << shift) < (u64)p->nw * 64) ++shift;
+        p->pb_maxchunks = (u32)(A->nnz / PB_C) + 2;
+        const size_t small = (size_t)5 * QCAP + 8 + (size_t)p->pb_maxchunks + 2 + (size_t)ctx->cus * 2 * PB_BINS + 64;
+        fgpu_info pi = ctx->dev_alloc((void**)&p->pb, sizeof(BfsPb));
+        if (pi == FGPU_OK) pi = ctx->dev_alloc((void**)&p->pb_small, small * sizeof(u32));
+        if (pi == FGPU_OK) pi = ctx->dev_alloc((void**)&p->pb_dst, ((size_t)A->nnz + PB_C) * sizeof(u32));
+        if (pi == FGPU_OK) pi = ctx->dev_alloc((void**)&p->pb_src, ((size_t)A->nnz + PB_C) * sizeof(u32));
+        if (pi == FGPU_OK) {
+            BfsPb h;
+            memset(&h, 0, sizeof(u32) * 32);
+            h.shift = shift;
+            if (hipMemsetAsync(p->pb, 0, sizeof(BfsPb), ctx->stream()) != hipSuccess ||
+                hipMemcpyAsync(p->pb, &h, sizeof(u32) * 32, hipMemcpyHostToDevice, ctx->stream()) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream()) != hipSuccess)
+                pi = FGPU_DEVICE;
+        }
+        if (pi != FGPU_OK) {
+            ctx->dev_free(p->pb); ctx->dev_free(p->pb_small); ctx->dev_free(p->pb_dst); ctx->dev_free(p->pb_src);
+            p->pb = nullptr; p->pb_small = nullptr; p->pb_dst = nullptr; p->pb_src = nullptr;
+            (void)hipGetLastError();
+            set_error("%s", "");
+        }
     }
     if (i != FGPU_OK) { fgpu_bfs_plan_free(p); return i; }
     memset(p->h_ctrl, 0, sizeof(BfsCtrl));
@@ -2418,7 +2938,62 @@ static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) 
     p->levels_masked = false;
     p->mask_visited = p->bm_block + 3 * (size_t)p->nw;
     hipLaunchKernelGGL(bfs_fused_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), a, (u32)src, ml,
-                       p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull);
+                       p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull,
+                       (u64)(ctx->opt.bfs_pb_min_edges > 0 ? ctx->opt.bfs_pb_min_edges : 1), p->pb ? p->pb_mask : 0u);
+    FGPU_HIP(hipGetLastError());
+    return FGPU_OK;
+}
+
+// the four launches of a propagation-blocking level (each returns at once unless the control block says direction 3)
+static fgpu_info pb_launches(fgpu_bfs_plan* p) {
+    fgpu_ctx* ctx = p->ctx;
+    PbArgs g;
+    g.ctrl = p->ctrl;
+    g.pb = p->pb;
+    g.queue[0] = p->queue_block;
+    g.queue[1] = p->queue_block + QCAP;
+    g.deg = p->own_deg;
+    g.A = view_of(p->A);
+    g.tmpv = p->pb_small;
+    g.tmpd = g.tmpv + QCAP;
+    g.list = g.tmpd + QCAP;
+    g.P = g.list + QCAP;
+    g.S = g.P + QCAP + 4;
+    g.crow = g.S + QCAP + 4;
+    g.wgh = g.crow + p->pb_maxchunks + 2;
+    g.dst = p->pb_dst;
+    g.src = p->pb_src;
+    g.bm[0] = p->bm_block;
+    g.bm[1] = p->bm_block + p->nw;
+    g.bm[2] = p->bm_block + 2 * (size_t)p->nw;
+    g.visited = p->bm_block + 3 * (size_t)p->nw;
+    g.level = p->level;
+    g.parent = p->want_parent ? p->parent : nullptr;
+    g.nw = p->nw;
+    hipStream_t st = ctx->stream();
+    const size_t lds_count = ((size_t)2 * (PB_C + 2) + PB_BINS) * sizeof(u32);
+    const size_t lds_scat = ((size_t)2 * (PB_C + 2) + 4 * PB_BINS) * sizeof(u32);
+    u32 shift = 6;
+    while (((u64)PB_BINS << shift) < (u64)p->nw * 64) ++shift;
+    const size_t lds_apply = ((size_t)1 << shift) / 8;
+    static std::once_flag once;
+    std::call_once(once, [&]() {
+        (void)hipFuncSetAttribute((const void*)bfs_pb_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
+        (void)hipFuncSetAttribute((const void*)bfs_pb_scatter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scat);
+        (void)hipFuncSetAttribute((const void*)bfs_pb_scatter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scat);
+        (void)hipFuncSetAttribute((const void*)bfs_pb_apply_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)bfs_pb_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    });
+    const u32 cgrid = (u32)ctx->cus * 2;
+    hipLaunchKernelGGL(bfs_pb_prefix_kernel, dim3(QCAP / PB_T), dim3(PB_T), 0, st, g);
+    hipLaunchKernelGGL(bfs_pb_count_kernel, dim3(cgrid), dim3(PB_T), lds_count, st, g);
+    if (p->want_parent) {
+        hipLaunchKernelGGL(bfs_pb_scatter_kernel<true>, dim3(cgrid), dim3(PB_T), lds_scat, st, g);
+        hipLaunchKernelGGL(bfs_pb_apply_kernel<true>, dim3(PB_BINS), dim3(PB_T), lds_apply, st, g);
+    } else {
+        hipLaunchKernelGGL(bfs_pb_scatter_kernel<false>, dim3(cgrid), dim3(PB_T), lds_scat, st, g);
+        hipLaunchKernelGGL(bfs_pb_apply_kernel<false>, dim3(PB_BINS), dim3(PB_T), lds_apply, st, g);
+    }
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
@@ -2435,6 +3010,7 @@ static fgpu_info tiny_levels(fgpu_bfs_plan* p) {
 
 static fgpu_info fused_level(fgpu_bfs_plan* p) {
     BfsArgs a = make_args(p, true);
+    if (p->pb && p->fused_idx < 32 && ((p->pb_mask >> p->fused_idx) & 1u)) FGPU_TRY(pb_launches(p));
     const u32 grid = p->fgrid | (p->fused_idx++ & 1u);   // launch k carries its parity in the grid size (see the head of bfs_fused_kernel)
     if (p->want_parent)
         hipLaunchKernelGGL((bfs_fused_kernel<true, 0>), dim3(grid), dim3(256), 0, p->ctx->stream(), a);
@@ -2498,8 +3074,9 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     const u64 nf = p->h_ctrl->n_frontier, reached0 = p->h_ctrl->reached;
     float ms = 0;
     BfsArgs a = make_args(p, true);
-    const u32 pgrid = p->fgrid | (p->fused_idx++ & 1u);
     FGPU_HIP(hipEventRecord(p->ev0, ctx->stream()));
+    if (dir == 3) FGPU_TRY(pb_launches(p));              // (the profiled pass knows the direction: pb_mask is all ones there)
+    const u32 pgrid = p->fgrid | (p->fused_idx++ & 1u);
     // The events bracket the SAME instantiation the blind (timed) level loop launches, <.., 0>; only under
     // "bfs_prof_split" (rocprofv3 PMC passes, which can tell launches apart by kernel name alone) does the pass
     // launch the <.., 1> / <.., 2> twins that name a launch push / pull.
@@ -2516,16 +3093,16 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     FGPU_HIP(hipEventRecord(p->ev1, ctx->stream()));
     FGPU_HIP(hipEventSynchronize(p->ev1));
     FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
-    ProfSlot& s = p->prof[dir == 1 ? 0 : 1];
+    ProfSlot& s = p->prof[dir != 2 ? 0 : 1];
     s.ms += ms; s.launches += 1;
     FGPU_TRY(fetch_ctrl(p));
     // algorithmic bytes of the level (bitmap form): colidx actually examined,
     // rowptr pairs of the rows touched, the bitmaps streamed, level (+ out-degree) of new vertices
-    const u64 scanned = dir == 1 ? (p->h_ctrl->scanned_push - sp0) : (p->h_ctrl->scanned_pull - sl0);
+    const u64 scanned = dir != 2 ? (p->h_ctrl->scanned_push - sp0) : (p->h_ctrl->scanned_pull - sl0);
     const u64 newf = p->h_ctrl->n_frontier;
     const u64 unvisited = p->n > reached0 ? p->n - reached0 : 0;
     u64 bytes;
-    if (dir == 1) bytes = 4 * scanned + 8 * nf + (u64)p->nw * 8 * 2 + 12 * newf;
+    if (dir != 2) bytes = 4 * scanned + 8 * nf + (u64)p->nw * 8 * 2 + 12 * newf;
     else bytes = 4 * scanned + 8 * unvisited + (u64)p->nw * 8 * 2 + 12 * newf;
     s.alg_bytes += bytes;
     return FGPU_OK;
@@ -2537,6 +3114,16 @@ fgpu_info fgpu_bfs_run_async(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, 
                  "fgpu_bfs_run drives single-rank plans; multi-rank plans are stepped by the host loop");
     FGPU_REQUIRE(!p->profile, FGPU_INVALID, "a profiled plan runs synchronously (fgpu_bfs_run)");
     p->want_parent = want_parent != 0;
+    {   // propagation blocking: its four launches go in front of fused launches 1 .. 3 (levels 2 .. 4: where an R-MAT search has
+        // its heavy push) — 4.8 us each when they have nothing to do; not on deep searches (the tiny kernel's sequence)
+        const int tm = p->ctx->opt.bfs_tiny;
+        const bool deep = tm == 1 || (tm == 2 && p->last_levels > 12);
+        // (an armed launch costs 4 x 4.8 us: once the plan's searches have shown where their heavy push sits — level 3 of an
+        // R-MAT-26 search — only those launches are armed, and every eighth search looks at all three again)
+        u32 m = (p->pb_seen && (p->pb_searches & 7u) != 7u) ? (p->pb_seen & 0xEu) : 0xEu;
+        p->pb_mask = (p->pb && !deep) ? m : 0u;
+        p->pb_searches++;
+    }
     FGPU_TRY(fused_begin(p, src, max_level));
     // levels are enqueued blind; the kernels no-op once ctrl->done is raised (a no-op level still costs
     // ~4.6 us), so the default is one more than the plan's previous search needed: R-MAT searches from
@@ -2594,6 +3181,7 @@ fgpu_info fgpu_bfs_wait(fgpu_bfs_plan* p) {
             }
         }
         if (*flag & 0x80000000u) {
+            p->pb_seen |= ((volatile u32*)p->h_done)[1];
             p->last_levels = (int)(*flag & 0xFFFFFFu);
             p->last_heavy = (int)((*flag >> 24) & 0x7Fu);
             p->last_wait_us = waited_us();
@@ -2621,6 +3209,7 @@ fgpu_info fgpu_bfs_run(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, int wa
                  "fgpu_bfs_run drives single-rank plans; multi-rank plans are stepped by the host loop");
     if (p->profile) {
         p->want_parent = want_parent != 0;
+        p->pb_mask = p->pb ? 0xFFFFFFFFu : 0u;
         FGPU_TRY(fused_begin(p, src, max_level));
         for (;;) {
             FGPU_TRY(profiled_level(p));
@@ -2671,6 +3260,7 @@ fgpu_info fgpu_bfs_stats(fgpu_bfs_plan* p, uint64_t stats[8]) {
     stats[5] = c->scanned_push;
     stats[6] = c->scanned_pull;
     stats[7] = c->n_frontier;
+    p->ctx->bfs_pb_last.store(c->pb_levels, std::memory_order_relaxed);   // ("bfs_pb_last_levels": levels of that search run by propagation blocking)
     return FGPU_OK;
 }
 

@@ -76,6 +76,11 @@ struct fgpu_options {  // fgpu_set_option
     int bfs_tiny = 2;          // consecutive tiny BFS levels in one single-workgroup launch (bfs_tiny_kernel): 0 off, 1 on,
                                // 2 = when the plan's previous search took more than 12 levels
     int bfs_hub_first = 1;     // pull levels read A' rows reordered hub-first (bfs.hip ensure_pull_order)
+    int bfs_pb = 1;            // heavy push levels by propagation blocking (bfs.hip bfs_pb_*): the frontier's edges are binned by
+                               // destination window, a workgroup per window marks its discoveries in LDS — no global atomic per
+                               // edge.  0 off, 1 for plans of at least 2^25 vertices (a heavy push level of a smaller graph is a
+                               // few tens of microseconds: the four extra launches cost more), 2 for every single-rank plan
+    long long bfs_pb_min_edges = 4ll << 20;   // ... a push level with at least this many edges to examine goes that way
     int bfs_prof_split = 0;    // profiled BFS pass launches the <.., 1|2> twins that name a level push / pull (PMC passes)
     int merge_items = 1;       // Delta merge scatter: 1 = shifted copy by 2048-entry items with the dp insertion positions as events
                                // (merge.hip), 0 = the per-word / per-entry scatter (A/B)
@@ -174,6 +179,7 @@ struct fgpu_ctx {
     int comm_rank = 0, comm_nranks = 1;
     std::atomic<uint64_t> dist_self_calls{0};   // forced self collectives issued (dist_force_self)
     std::atomic<int> scan_active{0};            // lanes of whole-frontier calls running now (expand_count_scan)
+    std::atomic<uint32_t> bfs_pb_last{0};   // levels the search fgpu_bfs_stats last read ran by propagation blocking ("bfs_pb_last_levels")
     std::atomic<uint32_t> scan_last_live{0}, scan_last_passes{0};   // the last such call: live source rows, passes ("expand_scan_*")
     std::atomic<uint64_t> expand_launches{0};   // kernels launched by fgpu_expand* (fgpu_get_option "expand_kernel_launches")
     // kernel profiler (measurement hook): off unless fgpu_prof_enable(ctx, 1)

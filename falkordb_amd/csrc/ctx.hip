@@ -802,6 +802,9 @@ fgpu_info fgpu_get_option(fgpu_ctx* ctx, const char* name, int64_t* value) {
     else if (!strcmp(name, "expand_scan_rows")) *value = ctx->opt.expand_scan_rows;
     else if (!strcmp(name, "expand_scan_lanes")) *value = ctx->opt.expand_scan_lanes;
     else if (!strcmp(name, "expand_nt")) *value = ctx->opt.expand_nt;
+    else if (!strcmp(name, "bfs_pb")) *value = ctx->opt.bfs_pb;
+    else if (!strcmp(name, "bfs_pb_min_edges")) *value = ctx->opt.bfs_pb_min_edges;
+    else if (!strcmp(name, "bfs_pb_last_levels")) *value = ctx->bfs_pb_last.load(std::memory_order_relaxed);
     else if (!strcmp(name, "expand_scan_last_live")) *value = ctx->scan_last_live.load(std::memory_order_relaxed);
     else if (!strcmp(name, "expand_scan_last_passes")) *value = ctx->scan_last_passes.load(std::memory_order_relaxed);
     else { set_error("fgpu_get_option: unknown name '%s'", name); return FGPU_INVALID; }
@@ -872,6 +875,12 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "bfs_tiny")) {
         FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "bfs_tiny must be 0, 1 or 2");
         ctx->opt.bfs_tiny = (int)value;
+    } else if (!strcmp(name, "bfs_pb")) {
+        FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "bfs_pb must be 0, 1 or 2");
+        ctx->opt.bfs_pb = (int)value;
+    } else if (!strcmp(name, "bfs_pb_min_edges")) {
+        FGPU_REQUIRE(value >= 1, FGPU_INVALID, "bfs_pb_min_edges must be positive");
+        ctx->opt.bfs_pb_min_edges = (long long)value;
     } else if (!strcmp(name, "bfs_prof_split")) {
         ctx->opt.bfs_prof_split = value != 0;
     } else if (!strcmp(name, "bfs_hub_first")) {

@@ -439,6 +439,55 @@ def test_bfs_levels_and_parents(ctx, scale, force):
         assert st["reached"] == int(np.count_nonzero(ref_level >= 0))
 
 
+@pytest.mark.parametrize("force", [0, 1])
+@pytest.mark.parametrize("scale,min_edges", [(9, 1), (13, 64), (16, 2000), (18, 20000)])
+def test_bfs_heavy_push_levels_by_propagation_blocking(ctx, scale, min_edges, force):
+    """Direction 3 of the fused level loop (bfs.hip bfs_pb_*: the frontier's edges binned by destination window, a workgroup
+    per window marks its discoveries in LDS): forced on for small graphs (bfs_pb = 2) with a low edge threshold so that
+    the levels that qualify — a queue-listed frontier, a push — go that way; levels, parents, traversed edges and reached
+    count against the oracle's BFS, with and without parents, auto and push-only direction; max_level truncation; and the
+    option off gives the same vectors.  `bfs_pb_last_levels` says the path ran."""
+    a = oracle.rmat_csr(scale)
+    A = up(ctx, a)
+    At = A.transpose()
+    deg = np.diff(a.rowptr)
+    roots = [int(np.nonzero(deg > 0)[0][0]), int(np.argmax(deg)), int(np.nonzero(deg > 0)[0][-1])]
+    try:
+        ctx.set_option("bfs_pb", 2)
+        ctx.set_option("bfs_pb_min_edges", min_edges)
+        plan = engine.BfsPlan(ctx, A, At)
+        plan.tune(force_direction=force)
+        ran = 0
+        for src in roots:
+            ref_level, _, ref_edges = oracle.bfs(a, src, -1)
+            for want_parent in (True, False):
+                plan.run(src, -1, want_parent=want_parent)
+                level, parent = plan.fetch(want_parent=want_parent)
+                check_bfs(a, level, parent, src, ref_level)
+                st = plan.stats()
+                assert st["edges_traversed"] == ref_edges
+                assert st["reached"] == int(np.count_nonzero(ref_level >= 0))
+                ran += ctx.get_option("bfs_pb_last_levels")
+            plan.run(src, 2)
+            np.testing.assert_array_equal(plan.fetch()[0], np.where((ref_level >= 0) & (ref_level <= 2), ref_level, -1))
+            plan.run_async(src, -1, False, 3)                # too few levels enqueued: the top-up launches carry no bfs_pb_* kernels
+            plan.wait()
+            np.testing.assert_array_equal(plan.fetch()[0], ref_level)
+        assert ran > 0, "no level went by propagation blocking"
+        plan.free()
+        ctx.set_option("bfs_pb", 0)
+        plan = engine.BfsPlan(ctx, A, At)
+        plan.run(roots[1], -1, want_parent=True)
+        level, parent = plan.fetch(want_parent=True)
+        check_bfs(a, level, parent, roots[1], oracle.bfs(a, roots[1], -1)[0])
+        plan.stats()
+        assert ctx.get_option("bfs_pb_last_levels") == 0
+        plan.free()
+    finally:
+        ctx.set_option("bfs_pb", 1)
+        ctx.set_option("bfs_pb_min_edges", 4 << 20)
+
+
 @pytest.mark.parametrize("max_level", [0, 1, 2, 3])
 def test_bfs_max_level(ctx, max_level):
     a = oracle.rmat_csr(12)
