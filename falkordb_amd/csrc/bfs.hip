@@ -89,7 +89,8 @@ struct BfsCtrl {
     // 128 B: atomics to different words of ONE line serialise at the memory side just like same-address ones
     // (tools/micro/levelfloor.hip: 1792 workgroups' arrivals on 64 packed counters cost 8.6 us per launch, 0.6 us
     // with a line per counter)
-    StatSlot slot[STAT_SLOTS];
+    alignas(128) StatSlot slot[STAT_SLOTS];   // (on a line of its own each: the pb_* words above moved the array off its 128-byte
+                                              // alignment once — slots straddling lines cost the fused level 0.35 us, 1.4 % of an RMAT-22 search)
     // fused single-rank path: next-frontier queue, hub census and the end-of-level ticket
     u32 hubs[2];       // hub vertices (out-degree >= PUSH_HUB_DEG) in the current / next frontier
     u32 use_queue;     // the current frontier is completely listed in queue[rot & 1]
@@ -103,7 +104,7 @@ struct BfsCtrl {
     // run their control step.  ONE 64-bit word, stored once per control step and loaded once per workgroup: a workgroup that
     // starts after its launch's control step (see the head of bfs_fused_kernel) must see both halves of the same step
     unsigned long long nact_seq;
-    u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
+    alignas(64) u32 qlen[2][QSHARDS * 16];  // per-shard lengths of queue[0] / queue[1], one counter per 64 B line
     u32 tick_pad[28];
     u32 tick[64 * TICK_PAD];   // (round-2 ticket counters; the slot words carry the tickets now — kept for the layout)
 };
@@ -1080,7 +1081,7 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
     const bool done = (v0 == 0) || (max_level >= 0 && level >= max_level);
     c->done = done ? 1 : 0;
     if (done && host_done) {  // the host polls this word instead of paying a D2H copy + stream sync
-        __hip_atomic_store(host_done + 1, pb_at0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (read after the flag; a hint)
+        if (pb_at0) __hip_atomic_store(host_done + 1, pb_at0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (read after the flag; a hint)
         __hip_atomic_store(host_done, done_word_of(hb, he, level), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     int nd = 1;

@@ -105,13 +105,21 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * records HIP events around every level kernel and exchange for fgpu_bfs_dist_times; off by default, the events cost
  * ~20 us of stream idle time per level), "bfs_prof_split" (1 = a profiled plan launches
  * the push / pull twins of the level kernel so rocprofv3 can tell them apart by name), "bfs_hub_first" (1 = BFS plans
- * read the pull direction from a copy of At whose rows are reordered by descending out-degree class). */
+ * read the pull direction from a copy of At whose rows are reordered by descending out-degree class), "bfs_pb" (heavy push
+ * levels of a BFS by propagation blocking — the frontier's edges binned by destination window, a workgroup per window marking
+ * its discoveries in LDS: 0 off, 1 = plans of at least 2^25 vertices, 2 = every single-rank plan) with "bfs_pb_min_edges" (a
+ * push level with at least this many edges goes that way; default 4 Mi), "expand_emit_sort" (bit state -> rows of
+ * fgpu_expand*: 2 = (row, vertex) pairs + a stable sort by row, 0 = ballot transpose, 1 = pairs + sort unless the result
+ * holds more than 8 entries per vertex; the default), "pinned_results" / "pinned_pool_mb" (result arrays from 256 KiB up to
+ * the pool's size come from the context's pinned pool and are filled by DMA; blocks kept for reuse up to that many MiB). */
 fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
 /* Read-back of measurement / test counters kept by the context (a subset of the option names plus counters that
  * have no setter): "dist_force_self" (test-only, set through fgpu_set_option: a communicator of ONE rank still issues the
  * grouped self ncclSend / ncclRecv, ncclBroadcast and ncclAllReduce of a multi-rank exchange — tests/test_gpu_dist.py),
  * "dist_self_calls" (how many such calls ran), "expand_kernel_launches" (kernels launched by fgpu_expand* on this context so
- * far: the launch count of a batch is a difference of two reads).  Unknown names return FGPU_INVALID. */
+ * far: the launch count of a batch is a difference of two reads), "bfs_pb_last_levels" (levels the search fgpu_bfs_stats last
+ * read ran by propagation blocking), "expand_scan_last_live" / "expand_scan_last_passes" (live source rows and passes of the
+ * last whole-frontier fgpu_expand_count).  Unknown names return FGPU_INVALID. */
 fgpu_info fgpu_get_option(fgpu_ctx* ctx, const char* name, int64_t* value);
 /* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */
 fgpu_info fgpu_device_info(fgpu_ctx* ctx, char* name, int32_t* cus, int32_t* wave,
