@@ -35,7 +35,14 @@ constexpr int STAT_SLOTS = 64;
 constexpr unsigned QSHARDS = 8;          // the frontier queue is appended in 8 independent segments
 constexpr unsigned QCAP = 1u << 16;      // capacity of a frontier queue (vertex ids), all segments
 constexpr unsigned QSEG = QCAP / QSHARDS;
-constexpr unsigned long long QGATE = 1ull << 17;  // a level appends only when it can discover at most this many
+// A level appends its discoveries only when it can discover at most this many: a push examines m_frontier edges, a pull can
+// discover at most the unvisited vertices.  (Round 6 tried a 2^20-entry queue with the bound of a pull tightened to the unvisited
+// vertices that HAVE an in-edge, so that the push after the last pull of an R-MAT-26 search — 4 x 10^5 frontier vertices walked
+// through the whole bitmap, 162 us — runs from the queue: it did, in 34 us, but the pull level that then appends 4 x 10^5
+// discoveries through eight shard counters went 217 -> 965 us — same-address atomics, 5.6 ns each — and RMAT-22 0.198 -> 0.267
+// ms.  Appending is for light levels only.)
+constexpr unsigned long long QGATE = 1ull << 17;
+constexpr unsigned PB_QMAX = 1u << 16;   // propagation blocking: frontiers of at most this many queue entries (bfs_pb_prefix_kernel's grid)
 
 struct StatSlot { u64 count, mf, indeg, scan; u64 pad[12]; };
 // Fused levels: every slot word carries, above bit 52, the number of workgroups that have added to it this level.  The
@@ -967,7 +974,7 @@ __device__ __forceinline__ u32 done_word_of(u32 heavy_begin, u32 heavy_end, i32 
 // chain of dependent load -> store -> load round trips (the stores may alias the loads as far as the compiler knows) and
 // took 5.4 us of every level, after the last workgroup's ticket (tools/experiments/bfs_stamps.py); one round of loads,
 // register arithmetic and one round of stores is ~1.5 us.
-__device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
+__device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n_hubP) {
     const u32 t = threadIdx.x;  // 0..63
     // ---- loads (header snapshot: uniform; slots / queue lengths: per lane) ------------------------------------------
     const u32 rot = c->rot;
@@ -1096,17 +1103,21 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg) {
     const unsigned long long seq = (__hip_atomic_load(&c->nact_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + (nwg ? 1ull : 0ull);
     // a heavy push of a queue-listed frontier goes by propagation blocking (bfs_pb_* below) when the host put its four
     // launches in front of the next fused launch (= launch `seq` of the search)
-    const bool pb = nd == 1 && use_queue && !done && nwg && pb_min && v1 >= pb_min && seq < 32ull && ((pb_mask >> (u32)seq) & 1u);
+    const bool pb = nd == 1 && use_queue && !done && nwg && pb_min && v1 >= pb_min && v0 <= (u64)PB_QMAX && seq < 32ull &&
+                    ((pb_mask >> (u32)seq) & 1u);
     if (pb) { nd = 3; c->pb_at = pb_at0 | (1u << (u32)seq); }
     c->direction = nd;
     // the next level may append its discoveries only if it is light: a push examines m_frontier
     // edges, a pull can discover at most the unvisited vertices
     const u64 unv = n_total > reached ? n_total - reached : 0;
     c->q_open = (!pb && (nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u;
-    // workgroups the next launch needs: twice its work items (queue chunks + one per 1024 hub-row edges), at least 64
+    // workgroups the next launch needs: twice its work items (queue chunks + one per 1024 hub-row edges), at least 64 — and, when
+    // the frontier may hold a hub row (>= PUSH_HUB_DEG edges to examine), enough to screen the static hub chunk list in two
+    // rounds of 256 items a workgroup (3 x 10^5 items at RMAT-26: 64 workgroups took 18 rounds, 53 us for a level of 11 K edges)
     u32 na = 0;
     if (nd == 1 && use_queue && !done) {
-        const u64 items = (u64)QSHARDS * ((qmx + qchunk - 1) / qchunk) + v1 / PUSH_HUB_CHUNK + 1;
+        u64 items = (u64)QSHARDS * ((qmx + qchunk - 1) / qchunk) + v1 / PUSH_HUB_CHUNK + 1;
+        if (v1 >= PUSH_HUB_DEG && (u64)n_hubP / 1024 > items) items = (u64)n_hubP / 1024;
         na = items * 2 < 64 ? 64u : (items * 2 > 60000ull ? 0u : (u32)(items * 2));
     }
     __hip_atomic_store(&c->nact_seq, (seq << 32) | (unsigned long long)na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1234,7 +1245,7 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
     }
     __syncthreads();
     DBG_STAMP(4);
-    if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done, slab, nwg);
+    if (s_last && threadIdx.x < 64) fused_ctrl(c, a.host_done, slab, nwg, a.n_hubP);
     DBG_STAMP(5);
 }
 
@@ -1319,7 +1330,7 @@ __global__ __launch_bounds__(256) void bfs_tiny_kernel(BfsArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (t < 64) {
-            fused_ctrl(c, a.host_done, false, 0u);   // slot 0 holds this workgroup's plain sums: no arrival fields
+            fused_ctrl(c, a.host_done, false, 0u, a.n_hubP);   // slot 0 holds this workgroup's plain sums: no arrival fields
             if (t == 0) {
                 c->zr_dirty = 0;
                 c->tiny_levels += 1;
@@ -1361,7 +1372,6 @@ struct PbArgs {
     const u32* queue[2];
     const u32* deg;          // out-degree per vertex
     CsrView A;
-    u32 *tmpv, *tmpd;        // QCAP each: the queue flattened, its degrees
     u32 *list, *P, *S;       // compacted frontier rows, exclusive prefix of their degrees (nlist + 1), first entry of each in colidx
     u32* crow;               // chunk -> index of the row holding its first edge
     u32 *dst, *src;          // the bins
@@ -1391,7 +1401,7 @@ __device__ __forceinline__ u32 pb_block_scan(u32 v, u32* s_w /* >= 17 words */, 
     return base + inc - v;
 }
 
-// QCAP / PB_T = 64 workgroups, a queue position per thread: ONE workgroup doing the ~3 x 10^4 random reads of a frontier's degrees
+// PB_QMAX / PB_T = 64 workgroups, a queue position per thread: ONE workgroup doing the ~3 x 10^4 random reads of a frontier's degrees
 // and row pointers took 75-90 us at RMAT-26 (a single CU sustains ~0.5 G random lines/s), whatever the number of dependent
 // round trips.  The prefix across workgroups is a one-wavefront look-back: a workgroup publishes (rows with edges, edges) of its
 // 1024 positions in one 64-bit word of BfsPb::agg (bit 63 = published), its first wavefront reads the words of ALL the
@@ -2227,7 +2237,7 @@ struct fgpu_bfs_plan {
     u32 fused_idx = 0;                       // fused launches enqueued since fused_begin: launch k runs the instantiation of parity k & 1
     u32* own_deg = nullptr;                  // single-rank plans: out-degree of every vertex (one 4-byte read per discovery)
     // propagation blocking of heavy push levels (bfs_pb_*): the control / statistics block, one allocation for the small arrays
-    // (tmpv | tmpd | list | P | S | crow) and the bins; pb_mask = the fused launches of the search in flight that have the four
+    // (list | P | S | crow | per-workgroup histograms) and the bins; pb_mask = the fused launches of the search in flight that have the four
     // launches in front of them
     BfsPb* pb = nullptr;
     u32* pb_small = nullptr;
@@ -2437,7 +2447,7 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         u32 shift = 6;
         while (((u64)PB_BINS << shift) < (u64)p->nw * 64) ++shift;
         p->pb_maxchunks = (u32)(A->nnz / PB_C) + 2;
-        const size_t small = (size_t)5 * QCAP + 8 + (size_t)p->pb_maxchunks + 2 + (size_t)ctx->cus * 2 * PB_BINS + 64;
+        const size_t small = (size_t)3 * PB_QMAX + 8 + (size_t)p->pb_maxchunks + 2 + (size_t)ctx->cus * 2 * PB_BINS + 64;
         fgpu_info pi = ctx->dev_alloc((void**)&p->pb, sizeof(BfsPb));
         if (pi == FGPU_OK) pi = ctx->dev_alloc((void**)&p->pb_small, small * sizeof(u32));
         if (pi == FGPU_OK) pi = ctx->dev_alloc((void**)&p->pb_dst, ((size_t)A->nnz + PB_C) * sizeof(u32));
@@ -2955,12 +2965,10 @@ static fgpu_info pb_launches(fgpu_bfs_plan* p) {
     g.queue[1] = p->queue_block + QCAP;
     g.deg = p->own_deg;
     g.A = view_of(p->A);
-    g.tmpv = p->pb_small;
-    g.tmpd = g.tmpv + QCAP;
-    g.list = g.tmpd + QCAP;
-    g.P = g.list + QCAP;
-    g.S = g.P + QCAP + 4;
-    g.crow = g.S + QCAP + 4;
+    g.list = p->pb_small;
+    g.P = g.list + PB_QMAX;
+    g.S = g.P + PB_QMAX + 4;
+    g.crow = g.S + PB_QMAX + 4;
     g.wgh = g.crow + p->pb_maxchunks + 2;
     g.dst = p->pb_dst;
     g.src = p->pb_src;
@@ -2986,7 +2994,7 @@ static fgpu_info pb_launches(fgpu_bfs_plan* p) {
         (void)hipFuncSetAttribute((const void*)bfs_pb_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     });
     const u32 cgrid = (u32)ctx->cus * 2;
-    hipLaunchKernelGGL(bfs_pb_prefix_kernel, dim3(QCAP / PB_T), dim3(PB_T), 0, st, g);
+    hipLaunchKernelGGL(bfs_pb_prefix_kernel, dim3(PB_QMAX / PB_T), dim3(PB_T), 0, st, g);
     hipLaunchKernelGGL(bfs_pb_count_kernel, dim3(cgrid), dim3(PB_T), lds_count, st, g);
     if (p->want_parent) {
         hipLaunchKernelGGL(bfs_pb_scatter_kernel<true>, dim3(cgrid), dim3(PB_T), lds_scat, st, g);
