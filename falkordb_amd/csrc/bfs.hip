@@ -42,7 +42,9 @@ constexpr unsigned QSEG = QCAP / QSHARDS;
 // discoveries through eight shard counters went 217 -> 965 us — same-address atomics, 5.6 ns each — and RMAT-22 0.198 -> 0.267
 // ms.  Appending is for light levels only.)
 constexpr unsigned long long QGATE = 1ull << 17;
-constexpr unsigned PB_QMAX = 1u << 16;   // propagation blocking: frontiers of at most this many queue entries (bfs_pb_prefix_kernel's grid)
+constexpr unsigned PB_LMAX = 1u << 22;   // propagation blocking: frontiers of at most this many vertices (bfs_pb_prefix_kernel: 1024 workgroups x 1024 threads x 4)
+constexpr unsigned PB_PPT = 4;           // ... positions per thread
+constexpr unsigned PB_LWG = 256;         // workgroups of bfs_pb_list_kernel (a frontier that is not queue-listed: bitmap -> list)
 
 struct StatSlot { u64 count, mf, indeg, scan; u64 pad[12]; };
 // Fused levels: every slot word carries, above bit 52, the number of workgroups that have added to it this level.  The
@@ -91,7 +93,7 @@ struct BfsCtrl {
     u32 pb_mask;     // bit k: the host enqueued the four bfs_pb_* launches in front of fused launch k of this search
     u32 pb_levels;   // levels of this search run that way
     u32 pb_at;       // bit k: fused launch k of this search was such a level (the host arms the next search's launches with it)
-    u32 pb_pad;
+    u32 n_alive;     // vertices with an in-edge (0: not counted): what a pull can still discover, and the base of the m_u estimate
     // per-launch accumulators, spread over slots to keep same-address atomics off the critical path; one slot per
     // 128 B: atomics to different words of ONE line serialise at the memory side just like same-address ones
     // (tools/micro/levelfloor.hip: 1792 workgroups' arrivals on 64 packed counters cost 8.6 us per launch, 0.6 us
@@ -124,7 +126,8 @@ struct PbPart { u64 count, mf; u32 hub; u32 pad[11]; };   // a window's share of
 struct BfsPb {
     u32 nlist, nchunks, total, shift;   // rows of the compacted frontier, chunks, edges of the level; log2(vertices per window)
     u32 pad[28];
-    unsigned long long agg[64];         // bfs_pb_prefix_kernel's look-back words (zero between levels)
+    unsigned long long agg[PB_LMAX / PB_T / PB_PPT];   // bfs_pb_prefix_kernel's look-back words (zero between levels)
+    unsigned long long agg0[PB_LWG];          // bfs_pb_list_kernel's
     u32 count[PB_BINS * 32];            // entries per bin, a counter per 128 bytes (same-line atomics serialise)
     u32 cursor[PB_BINS * 32];
     PbPart part[PB_BINS];
@@ -986,7 +989,7 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
     const u32 q_open0 = c->q_open, force_dir = c->force_dir, has_at = c->has_at;
     const u64 n_total = c->n_total, nnz_at = c->nnz_at;
     const u64 pb_min = c->pb_min;
-    const u32 pb_mask = c->pb_mask, pb_at0 = c->pb_at;
+    const u32 pb_mask = c->pb_mask, pb_at0 = c->pb_at, n_alive = c->n_alive;
     const float alpha = c->alpha;
     u64 v0 = __hip_atomic_load(&c->slot[t].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v1 = __hip_atomic_load(&c->slot[t].mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1095,15 +1098,23 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
     if (force_dir == 1 || !has_at) nd = 1;
     else if (force_dir == 2) nd = 2;
     else {
-        const double un = (double)(n_total > reached ? n_total - reached : 0);
-        const u64 m_u = (u64)((double)nnz_at * un / (double)n_total);
+        // edges a pull would have to look at ~ nnz(A') x the unvisited share — of the vertices that HAVE an in-edge when the plan
+        // counted them: 60 % of an R-MAT graph's vertices have none and stay "unvisited" for ever, which made every late level
+        // look expensive to pull (RMAT-26, level 5 of a third of the roots: a 30 M-edge push from a 13 M-vertex frontier that
+        // discovers 10^5 vertices, 440 us, where the pull of the 3 x 10^5 vertices still open takes 220)
+        double un = (double)(n_total > reached ? n_total - reached : 0), base = (double)n_total;
+        if (n_alive) {
+            un = (double)((u64)n_alive + 1ull > reached ? (u64)n_alive + 1ull - reached : 0ull);
+            base = (double)n_alive;
+        }
+        const u64 m_u = (u64)((double)nnz_at * un / base);
         nd = ((double)v1 * (double)alpha > (double)m_u) ? 2 : 1;
     }
     // (the tiny kernel's control steps — nwg == 0 — are not fused launches: the count stays)
     const unsigned long long seq = (__hip_atomic_load(&c->nact_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + (nwg ? 1ull : 0ull);
-    // a heavy push of a queue-listed frontier goes by propagation blocking (bfs_pb_* below) when the host put its four
+    // a heavy push of a frontier of at most PB_LMAX vertices goes by propagation blocking (bfs_pb_* below) when the host put its
     // launches in front of the next fused launch (= launch `seq` of the search)
-    const bool pb = nd == 1 && use_queue && !done && nwg && pb_min && v1 >= pb_min && v0 <= (u64)PB_QMAX && seq < 32ull &&
+    const bool pb = nd == 1 && !done && nwg && pb_min && v1 >= pb_min && v0 <= (u64)PB_LMAX && seq < 32ull &&
                     ((pb_mask >> (u32)seq) & 1u);
     if (pb) { nd = 3; c->pb_at = pb_at0 | (1u << (u32)seq); }
     c->direction = nd;
@@ -1372,6 +1383,7 @@ struct PbArgs {
     const u32* queue[2];
     const u32* deg;          // out-degree per vertex
     CsrView A;
+    u32* lst0;               // PB_LMAX: the frontier as a list when the level's queue does not hold it (bfs_pb_list_kernel)
     u32 *list, *P, *S;       // compacted frontier rows, exclusive prefix of their degrees (nlist + 1), first entry of each in colidx
     u32* crow;               // chunk -> index of the row holding its first edge
     u32 *dst, *src;          // the bins
@@ -1401,7 +1413,54 @@ __device__ __forceinline__ u32 pb_block_scan(u32 v, u32* s_w /* >= 17 words */, 
     return base + inc - v;
 }
 
-// PB_QMAX / PB_T = 64 workgroups, a queue position per thread: ONE workgroup doing the ~3 x 10^4 random reads of a frontier's degrees
+// A frontier that its level's queue does not hold (the level before examined more than QGATE edges, or a queue segment
+// overflowed) is listed from its bitmap first: PB_LWG workgroups, a contiguous range of words each, the prefix across them by
+// the same look-back as below.  Half of the RMAT-26 roots have their heavy push behind such a level (the root's neighbours hold a
+// hub: level 2 examines 10^5 - 10^7 edges): without this they kept the 1.1 - 1.5 ms push.
+__global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
+    BfsCtrl* c = g.ctrl;
+    if (!pb_level(c) || c->use_queue) return;
+    __shared__ u32 s_w[20];
+    __shared__ u32 s_base;
+    const u32 t = threadIdx.x, blk = blockIdx.x;
+    const u64* __restrict__ fr = g.bm[c->rot % 3];
+    const u32 wpw = (g.nw + gridDim.x - 1) / gridDim.x;      // words per workgroup
+    const u32 K = (wpw + PB_T - 1) / PB_T;                   // ... per thread, consecutive
+    const u32 w0 = blk * wpw + t * K;
+    const u32 wend = (blk + 1) * wpw < g.nw ? (blk + 1) * wpw : g.nw;
+    u32 cnt = 0;
+    for (u32 k = 0; k < K; ++k) cnt += (w0 + k < wend) ? (u32)__popcll(fr[w0 + k]) : 0u;
+    u32 bc;
+    const u32 lc = pb_block_scan(cnt, s_w, &bc);
+    unsigned long long* agg = const_cast<unsigned long long*>(g.pb->agg0);
+    if (t == 0) __hip_atomic_store(&agg[blk], (1ull << 63) | (unsigned long long)bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 64) {
+        u32 pcn = 0;
+        for (u32 k0 = 0; k0 < blk; k0 += 64) {
+            unsigned long long w = 0ull;
+            if (k0 + t < blk) {
+                do { w = __hip_atomic_load(&agg[k0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(w >> 63));
+            }
+            pcn += (u32)w;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) pcn += (u32)__shfl_xor((int)pcn, o, 64);
+        if (t == 0) s_base = pcn;
+    }
+    __syncthreads();
+    u32 at = s_base + lc;
+    for (u32 k = 0; k < K; ++k) {
+        if (w0 + k >= wend) break;
+        u64 w = fr[w0 + k];
+        while (w) {
+            if (at < PB_LMAX) g.lst0[at] = (w0 + k) * 64u + (u32)__builtin_ctzll(w);
+            ++at;
+            w &= w - 1ull;
+        }
+    }
+}
+
+// PB_LMAX / PB_T = 1024 workgroups, a frontier position per thread: ONE workgroup doing the ~3 x 10^4 random reads of a frontier's degrees
 // and row pointers took 75-90 us at RMAT-26 (a single CU sustains ~0.5 G random lines/s), whatever the number of dependent
 // round trips.  The prefix across workgroups is a one-wavefront look-back: a workgroup publishes (rows with edges, edges) of its
 // 1024 positions in one 64-bit word of BfsPb::agg (bit 63 = published), its first wavefront reads the words of ALL the
@@ -1428,41 +1487,62 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_prefix_kernel(PbArgs g) {
     if (blk == 0)
         for (u32 i = t; i < PB_BINS; i += PB_T) { g.pb->count[i * 32] = 0; g.pb->cursor[i * 32] = 0; }
     __syncthreads();
-    const u32 nq = s_ql[QSHARDS];
-    const u32 pos = blk * PB_T + t;
-    const u32 pc = pos < nq ? pos : (nq ? nq - 1u : 0u);     // (every load from a clamped address)
-    u32 sc = 0;
+    const bool uq = c->use_queue != 0;                       // else bfs_pb_list_kernel has listed the frontier bitmap in lst0
+    const u32 nq = uq ? s_ql[QSHARDS] : (c->n_frontier < (u64)PB_LMAX ? (u32)c->n_frontier : PB_LMAX);
+    const u32* __restrict__ vsrc = uq ? q : g.lst0;
+    const u32 pos0 = (blk * PB_T + t) * PB_PPT;              // PB_PPT consecutive positions per thread
+    u32 v[PB_PPT], d[PB_PPT], rs[PB_PPT];
 #pragma unroll
-    for (u32 k = 1; k < QSHARDS; ++k) sc += (s_ql[k] <= pc) ? 1u : 0u;
-    const u32 v = q[sc * QSEG + (pc - s_ql[sc])];
-    u32 d = g.deg[v];
-    const u32 rs = g.A.rowptr[v];
-    if (pos >= nq) d = 0;
+    for (u32 j = 0; j < PB_PPT; ++j) {
+        const u32 pos = pos0 + j;
+        const u32 pc = pos < nq ? pos : (nq ? nq - 1u : 0u); // (every load from a clamped address)
+        u32 sc = 0;
+#pragma unroll
+        for (u32 k = 1; k < QSHARDS; ++k) sc += (s_ql[k] <= pc) ? 1u : 0u;
+        v[j] = vsrc[uq ? sc * QSEG + (pc - s_ql[sc]) : pc];
+    }
+#pragma unroll
+    for (u32 j = 0; j < PB_PPT; ++j) { d[j] = g.deg[v[j]]; rs[j] = g.A.rowptr[v[j]]; }
+    u32 tc = 0, ts = 0;
+#pragma unroll
+    for (u32 j = 0; j < PB_PPT; ++j) {
+        if (pos0 + j >= nq) d[j] = 0;
+        tc += d[j] ? 1u : 0u;
+        ts += d[j];
+    }
     u32 bc, bs;
-    const u32 lc = pb_block_scan(d ? 1u : 0u, s_w, &bc);
-    const u32 ls = pb_block_scan(d, s_w, &bs);
+    const u32 lc = pb_block_scan(tc, s_w, &bc);
+    const u32 ls = pb_block_scan(ts, s_w, &bs);
     unsigned long long* agg = const_cast<unsigned long long*>(g.pb->agg);
     if (t == 0)
         __hip_atomic_store(&agg[blk], (1ull << 63) | ((unsigned long long)bc << 32) | (unsigned long long)bs, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     if (t < 64) {
-        unsigned long long w = 0ull;
-        if (t < blk) {
-            do { w = __hip_atomic_load(&agg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(w >> 63));
+        u32 pcn = 0, psm = 0;
+        for (u32 k0 = 0; k0 < blk; k0 += 64) {               // (workgroups are dispatched in index order: those before this one run or are done)
+            unsigned long long w = 0ull;
+            if (k0 + t < blk) {
+                do { w = __hip_atomic_load(&agg[k0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(w >> 63));
+            }
+            pcn += (u32)(w >> 32) & 0x7FFFFFFFu;
+            psm += (u32)w;
         }
-        u32 pcn = (u32)(w >> 32) & 0x7FFFFFFFu, psm = (u32)w;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { pcn += (u32)__shfl_xor((int)pcn, o, 64); psm += (u32)__shfl_xor((int)psm, o, 64); }
         if (t == 0) { s_basec = pcn; s_bases = psm; }
     }
     __syncthreads();
-    const u32 ci = s_basec + lc, run = s_bases + ls;
-    if (d) {
-        g.list[ci] = v;
+    u32 ci = s_basec + lc, run = s_bases + ls;
+#pragma unroll
+    for (u32 j = 0; j < PB_PPT; ++j) {
+        if (!d[j]) continue;
+        g.list[ci] = v[j];
         g.P[ci] = run;
-        g.S[ci] = rs;
+        g.S[ci] = rs[j];
         // the chunks that begin inside this row's edges [run, run + d)
-        for (u32 kk = (run + PB_C - 1) / PB_C; (u64)kk * PB_C < (u64)run + d; ++kk) g.crow[kk] = ci;
+        for (u32 kk = (run + PB_C - 1) / PB_C; (u64)kk * PB_C < (u64)run + d[j]; ++kk) g.crow[kk] = ci;
+        run += d[j];
+        ++ci;
     }
     if (blk == gridDim.x - 1 && t == 0) {                    // the last workgroup knows the totals
         const u32 nlist = s_basec + bc, total = s_bases + bs;
@@ -1659,7 +1739,10 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_apply_kernel(PbArgs g) {
     __shared__ unsigned long long s_acc[2];
     __shared__ u32 s_hub;
     const u32 t = threadIdx.x;
-    if (blockIdx.x == 0 && t < 64) g.pb->agg[t] = 0ull;      // (the prefix kernel's look-back words, for the next such level)
+    if (blockIdx.x == 0) {                                   // (the look-back words of the list / prefix kernels, for the next such level)
+        for (u32 i = t; i < PB_LMAX / PB_T / PB_PPT; i += PB_T) g.pb->agg[i] = 0ull;
+        if (t < PB_LWG) g.pb->agg0[t] = 0ull;
+    }
     const u32 shift = g.pb->shift;
     const u32 rot = c->rot;
     const i32 newlevel = c->level + 1;
@@ -1960,7 +2043,7 @@ __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u
 // memsets + bfs_init_kernel).  Every word is written by exactly one thread, which also applies the
 // seed value if the source falls into its word; workgroup 0 owns the control block.
 __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at,
-                                                             u32 force_dir, float alpha, u64 nnz_at, u64 pb_min, u32 pb_mask) {
+                                                             u32 force_dir, float alpha, u64 nnz_at, u64 pb_min, u32 pb_mask, u32 n_alive) {
     const u32 tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     // level[] is NOT cleared: level[v] is meaningful exactly where the visited bitmap has v set (the on-device
     // result is the pair); fgpu_bfs_fetch masks the rest to -1 on its way out (bfs_mask_levels_kernel).
@@ -1991,6 +2074,7 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     c->n_total = a.n;
     c->pb_min = a.pb ? pb_min : 0ull;
     c->pb_mask = pb_mask;
+    c->n_alive = n_alive;
     a.queue[0][0] = src;
     c->qlen[0][0] = 1;
     c->qmax = 1;
@@ -2130,6 +2214,13 @@ __global__ void pull_seg_kernel(const u32* __restrict__ rowptr, u32 nrows, u64* 
 
 // head[v] = the first PULL_H column ids of row v of A' (in the order the pull levels read them), ~0 where the row is
 // shorter; rows of >= HUB_DEG entries carry HEAD_HUB (the hub section owns them); rows past n are empty.
+__global__ __launch_bounds__(256) void bfs_count_alive_kernel(const u32* __restrict__ rowptr, u32 n, u32* __restrict__ out) {
+    u32 c = 0;
+    for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) c += rowptr[v + 1] != rowptr[v] ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += (u32)__shfl_xor((int)c, d, 64);
+    if (lane_id() == 0 && c) atomicAdd(out, c);
+}
 __global__ void pull_head_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ col, u32 n, u32 n_pad,
                                  headv* __restrict__ head) {
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n_pad; v += gridDim.x * 256) {
@@ -2243,6 +2334,7 @@ struct fgpu_bfs_plan {
     u32* pb_small = nullptr;
     u32 *pb_dst = nullptr, *pb_src = nullptr;
     u32 pb_maxchunks = 0, pb_mask = 0;
+    u32 n_alive = 0;                         // vertices with an in-edge (0 when the plan has no transpose)
     u32 pb_seen = 0, pb_searches = 0;        // fused launches that were such levels in this plan's searches so far; searches run
     bool dist_ready = false;
     std::vector<hipEvent_t> dist_ev;    // 3 per level: before the level kernel, after it, after the collective
@@ -2437,6 +2529,15 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
     if (i == FGPU_OK && nranks == 1) {
         i = ctx->dev_alloc((void**)&p->own_deg, ((size_t)p->n + 1) * sizeof(u32));
         if (i == FGPU_OK) i = fgpu_mat_row_degrees(ctx, A, p->own_deg);
+        if (i == FGPU_OK && At) {                            // vertices a search can discover at all: those with an in-edge
+            DevBuf<u32> cnt;
+            i = cnt.alloc(ctx, 1);
+            if (i == FGPU_OK && hipMemsetAsync(cnt.p, 0, sizeof(u32), ctx->stream()) != hipSuccess) i = FGPU_DEVICE;
+            if (i == FGPU_OK) {
+                hipLaunchKernelGGL(bfs_count_alive_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), (const u32*)At->rowptr, p->n, cnt.p);
+                i = read_u32(ctx, cnt.p, &p->n_alive);
+            }
+        }
     }
     // propagation blocking of heavy push levels: plans of >= 2^25 vertices (option bfs_pb; 2 = any; at RMAT-24 no push level is
     // heavy enough and the armed launches cost 2-3 %: 0.513 -> 0.528 ms), windows of at most 2^19
@@ -2447,7 +2548,7 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
         u32 shift = 6;
         while (((u64)PB_BINS << shift) < (u64)p->nw * 64) ++shift;
         p->pb_maxchunks = (u32)(A->nnz / PB_C) + 2;
-        const size_t small = (size_t)3 * PB_QMAX + 8 + (size_t)p->pb_maxchunks + 2 + (size_t)ctx->cus * 2 * PB_BINS + 64;
+        const size_t small = (size_t)4 * PB_LMAX + 8 + (size_t)p->pb_maxchunks + 2 + (size_t)ctx->cus * 2 * PB_BINS + 64;
         fgpu_info pi = ctx->dev_alloc((void**)&p->pb, sizeof(BfsPb));
         if (pi == FGPU_OK) pi = ctx->dev_alloc((void**)&p->pb_small, small * sizeof(u32));
         if (pi == FGPU_OK) pi = ctx->dev_alloc((void**)&p->pb_dst, ((size_t)A->nnz + PB_C) * sizeof(u32));
@@ -2950,7 +3051,7 @@ static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) 
     p->mask_visited = p->bm_block + 3 * (size_t)p->nw;
     hipLaunchKernelGGL(bfs_fused_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), a, (u32)src, ml,
                        p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull,
-                       (u64)(ctx->opt.bfs_pb_min_edges > 0 ? ctx->opt.bfs_pb_min_edges : 1), p->pb ? p->pb_mask : 0u);
+                       (u64)(ctx->opt.bfs_pb_min_edges > 0 ? ctx->opt.bfs_pb_min_edges : 1), p->pb ? p->pb_mask : 0u, ctx->opt.bfs_alive_rule ? p->n_alive : 0u);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
@@ -2965,10 +3066,11 @@ static fgpu_info pb_launches(fgpu_bfs_plan* p) {
     g.queue[1] = p->queue_block + QCAP;
     g.deg = p->own_deg;
     g.A = view_of(p->A);
-    g.list = p->pb_small;
-    g.P = g.list + PB_QMAX;
-    g.S = g.P + PB_QMAX + 4;
-    g.crow = g.S + PB_QMAX + 4;
+    g.lst0 = p->pb_small;
+    g.list = g.lst0 + PB_LMAX;
+    g.P = g.list + PB_LMAX;
+    g.S = g.P + PB_LMAX + 4;
+    g.crow = g.S + PB_LMAX + 4;
     g.wgh = g.crow + p->pb_maxchunks + 2;
     g.dst = p->pb_dst;
     g.src = p->pb_src;
@@ -2994,7 +3096,8 @@ static fgpu_info pb_launches(fgpu_bfs_plan* p) {
         (void)hipFuncSetAttribute((const void*)bfs_pb_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     });
     const u32 cgrid = (u32)ctx->cus * 2;
-    hipLaunchKernelGGL(bfs_pb_prefix_kernel, dim3(PB_QMAX / PB_T), dim3(PB_T), 0, st, g);
+    hipLaunchKernelGGL(bfs_pb_list_kernel, dim3(PB_LWG), dim3(PB_T), 0, st, g);
+    hipLaunchKernelGGL(bfs_pb_prefix_kernel, dim3(PB_LMAX / PB_T / PB_PPT), dim3(PB_T), 0, st, g);
     hipLaunchKernelGGL(bfs_pb_count_kernel, dim3(cgrid), dim3(PB_T), lds_count, st, g);
     if (p->want_parent) {
         hipLaunchKernelGGL(bfs_pb_scatter_kernel<true>, dim3(cgrid), dim3(PB_T), lds_scat, st, g);

@@ -76,6 +76,8 @@ struct fgpu_options {  // fgpu_set_option
     int bfs_tiny = 2;          // consecutive tiny BFS levels in one single-workgroup launch (bfs_tiny_kernel): 0 off, 1 on,
                                // 2 = when the plan's previous search took more than 12 levels
     int bfs_hub_first = 1;     // pull levels read A' rows reordered hub-first (bfs.hip ensure_pull_order)
+    int bfs_alive_rule = 1;    // push <-> pull rule of the fused BFS: the unvisited share is taken over the vertices that have an in-edge
+                               // (0 = over all vertices, rounds 1-5; A/B)
     int bfs_pb = 1;            // heavy push levels by propagation blocking (bfs.hip bfs_pb_*): the frontier's edges are binned by
                                // destination window, a workgroup per window marks its discoveries in LDS — no global atomic per
                                // edge.  0 off, 1 for plans of at least 2^25 vertices (a heavy push level of a smaller graph is a

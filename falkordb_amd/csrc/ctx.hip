@@ -875,6 +875,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value) {
     } else if (!strcmp(name, "bfs_tiny")) {
         FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "bfs_tiny must be 0, 1 or 2");
         ctx->opt.bfs_tiny = (int)value;
+    } else if (!strcmp(name, "bfs_alive_rule")) {
+        ctx->opt.bfs_alive_rule = value != 0;
     } else if (!strcmp(name, "bfs_pb")) {
         FGPU_REQUIRE(value >= 0 && value <= 2, FGPU_INVALID, "bfs_pb must be 0, 1 or 2");
         ctx->opt.bfs_pb = (int)value;

@@ -444,7 +444,7 @@ def test_bfs_levels_and_parents(ctx, scale, force):
 def test_bfs_heavy_push_levels_by_propagation_blocking(ctx, scale, min_edges, force):
     """Direction 3 of the fused level loop (bfs.hip bfs_pb_*: the frontier's edges binned by destination window, a workgroup
     per window marks its discoveries in LDS): forced on for small graphs (bfs_pb = 2) with a low edge threshold so that
-    the levels that qualify — a queue-listed frontier, a push — go that way; levels, parents, traversed edges and reached
+    the push levels with that many edges go that way (queue-listed frontiers and, through bfs_pb_list_kernel, bitmap ones); levels, parents, traversed edges and reached
     count against the oracle's BFS, with and without parents, auto and push-only direction; max_level truncation; and the
     option off gives the same vectors.  `bfs_pb_last_levels` says the path ran."""
     a = oracle.rmat_csr(scale)
@@ -473,7 +473,8 @@ def test_bfs_heavy_push_levels_by_propagation_blocking(ctx, scale, min_edges, fo
             plan.run_async(src, -1, False, 3)                # too few levels enqueued: the top-up launches carry no bfs_pb_* kernels
             plan.wait()
             np.testing.assert_array_equal(plan.fetch()[0], ref_level)
-        assert ran > 0, "no level went by propagation blocking"
+        # (with the direction picked on the device a small graph may pull every level the launches are armed for)
+        assert ran > 0 or force == 0, "no level went by propagation blocking"
         plan.free()
         ctx.set_option("bfs_pb", 0)
         plan = engine.BfsPlan(ctx, A, At)
