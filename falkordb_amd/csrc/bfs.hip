@@ -2539,12 +2539,14 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
             }
         }
     }
-    // propagation blocking of heavy push levels: plans of >= 2^25 vertices (option bfs_pb; 2 = any; at RMAT-24 no push level is
-    // heavy enough and the armed launches cost 2-3 %: 0.513 -> 0.528 ms), windows of at most 2^19
+    // propagation blocking of heavy push levels: plans of >= 2^24 vertices (option bfs_pb; 2 = any).  With alpha as it was tuned for
+    // the atomic push RMAT-24 has no level heavy enough (0.513 -> 0.528 ms from the armed launches alone); with the blocked push
+    // being 3 x cheaper the rule should push for longer — alpha 8 there: 0.504 -> 0.473 ms.  RMAT-22: 0.196 -> 0.205 ms whatever
+    // alpha and threshold (a heavy push of 10^6 edges is 70 us; five launches are 25), windows of at most 2^19
     // vertices (64 KiB of LDS), the bins sized for every edge of A.  An optional accelerator: without its memory the plan
     // simply pushes as before.
     if (i == FGPU_OK && nranks == 1 && !splits && ctx->opt.bfs_pb &&
-        (ctx->opt.bfs_pb == 2 || p->n >= (1u << 25)) && (u64)p->nw * 64 <= ((u64)PB_BINS << 19) && A->nnz + PB_C < 0xFFFFFFFFull) {
+        (ctx->opt.bfs_pb == 2 || p->n >= (1u << 24)) && (u64)p->nw * 64 <= ((u64)PB_BINS << 19) && A->nnz + PB_C < 0xFFFFFFFFull) {
         u32 shift = 6;
         while (((u64)PB_BINS << shift) < (u64)p->nw * 64) ++shift;
         p->pb_maxchunks = (u32)(A->nnz / PB_C) + 2;
@@ -2603,6 +2605,10 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
     // bitmap fits L2 — RMAT-22 0.2052 ms at 48, 0.2071 at 32, 0.2101 at 24, 0.2055 at 64; RMAT-24 0.5156 / 0.5182 / 0.5209 /
     // 0.5283 — and still 20 beyond (RMAT-26: 1.903 ms at 20, 1.914 at 16, 1.916 at 24, 2.05 at 32 and above).
     p->alpha = ((size_t)p->nw * sizeof(u64) > (2u << 20)) ? 20.0 : 48.0;
+    // Round 6, plans whose heavy push levels go by propagation blocking (NOTES_r06 section 17, alive-vertex rule): RMAT-26 1.617 ms
+    // at alpha 3, 1.517 at 4, **1.487 at 6**, 1.503 at 8, 1.548 at 10, 1.568 at 20, 1.943 at 32; RMAT-24 0.484 at 6, **0.473 at 6-10
+    // with a 1 M-edge threshold**, 0.490 at 20.
+    if (p->pb) p->alpha = ((size_t)p->nw * sizeof(u64) > (2u << 20)) ? 6.0 : 8.0;
     p->prof = {{"bfs_fused_kernel<false, 1> (push level)"}, {"bfs_fused_kernel<false, 2> (pull level)"}};
     *out = p;
     return FGPU_OK;

@@ -80,9 +80,9 @@ struct fgpu_options {  // fgpu_set_option
                                // (0 = over all vertices, rounds 1-5; A/B)
     int bfs_pb = 1;            // heavy push levels by propagation blocking (bfs.hip bfs_pb_*): the frontier's edges are binned by
                                // destination window, a workgroup per window marks its discoveries in LDS — no global atomic per
-                               // edge.  0 off, 1 for plans of at least 2^25 vertices (a heavy push level of a smaller graph is a
+                               // edge.  0 off, 1 for plans of at least 2^24 vertices (a heavy push level of a smaller graph is a
                                // few tens of microseconds: the four extra launches cost more), 2 for every single-rank plan
-    long long bfs_pb_min_edges = 4ll << 20;   // ... a push level with at least this many edges to examine goes that way
+    long long bfs_pb_min_edges = 2ll << 20;   // ... a push level with at least this many edges to examine goes that way
     int bfs_prof_split = 0;    // profiled BFS pass launches the <.., 1|2> twins that name a level push / pull (PMC passes)
     int merge_items = 1;       // Delta merge scatter: 1 = shifted copy by 2048-entry items with the dp insertion positions as events
                                // (merge.hip), 0 = the per-word / per-entry scatter (A/B)

@@ -107,8 +107,9 @@ fgpu_info fgpu_sync(fgpu_ctx* ctx);
  * the push / pull twins of the level kernel so rocprofv3 can tell them apart by name), "bfs_hub_first" (1 = BFS plans
  * read the pull direction from a copy of At whose rows are reordered by descending out-degree class), "bfs_pb" (heavy push
  * levels of a BFS by propagation blocking — the frontier's edges binned by destination window, a workgroup per window marking
- * its discoveries in LDS: 0 off, 1 = plans of at least 2^25 vertices, 2 = every single-rank plan) with "bfs_pb_min_edges" (a
- * push level with at least this many edges goes that way; default 4 Mi), "expand_emit_sort" (bit state -> rows of
+ * its discoveries in LDS: 0 off, 1 = plans of at least 2^24 vertices, 2 = every single-rank plan) with "bfs_pb_min_edges" (a
+ * push level with at least this many edges goes that way; default 2 Mi), "bfs_alive_rule" (1 = the push <-> pull rule takes
+ * the unvisited share over the vertices that have an in-edge; 0 = over all vertices), "expand_emit_sort" (bit state -> rows of
  * fgpu_expand*: 2 = (row, vertex) pairs + a stable sort by row, 0 = ballot transpose, 1 = pairs + sort unless the result
  * holds more than 8 entries per vertex; the default), "pinned_results" / "pinned_pool_mb" (result arrays from 256 KiB up to
  * the pool's size come from the context's pinned pool and are filled by DMA; blocks kept for reuse up to that many MiB). */

@@ -486,7 +486,7 @@ def test_bfs_heavy_push_levels_by_propagation_blocking(ctx, scale, min_edges, fo
         plan.free()
     finally:
         ctx.set_option("bfs_pb", 1)
-        ctx.set_option("bfs_pb_min_edges", 4 << 20)
+        ctx.set_option("bfs_pb_min_edges", 2 << 20)
 
 
 @pytest.mark.parametrize("max_level", [0, 1, 2, 3])
