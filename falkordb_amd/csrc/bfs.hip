@@ -42,8 +42,8 @@ constexpr unsigned QSEG = QCAP / QSHARDS;
 // discoveries through eight shard counters went 217 -> 965 us — same-address atomics, 5.6 ns each — and RMAT-22 0.198 -> 0.267
 // ms.  Appending is for light levels only.)
 constexpr unsigned long long QGATE = 1ull << 17;
-constexpr unsigned PB_LMAX = 1u << 22;   // propagation blocking: frontiers of at most this many vertices (bfs_pb_prefix_kernel: 1024 workgroups x 1024 threads x 4)
-constexpr unsigned PB_PPT = 4;           // ... positions per thread
+constexpr unsigned PB_LMAX = 1u << 22;   // propagation blocking: frontiers of at most this many vertices (bfs_pb_prefix_kernel: 256 workgroups x 1024 threads x 16)
+constexpr unsigned PB_PPT = 16;          // ... positions per thread, strided by the grid (a small frontier spreads over the workgroups)
 constexpr unsigned PB_LWG = 256;         // workgroups of bfs_pb_list_kernel (a frontier that is not queue-listed: bitmap -> list)
 
 struct StatSlot { u64 count, mf, indeg, scan; u64 pad[12]; };
@@ -1460,7 +1460,7 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
     }
 }
 
-// PB_LMAX / PB_T = 1024 workgroups, a frontier position per thread: ONE workgroup doing the ~3 x 10^4 random reads of a frontier's degrees
+// PB_LMAX / PB_T / PB_PPT = 256 workgroups, PB_PPT frontier positions per thread: ONE workgroup doing the ~3 x 10^4 random reads of a frontier's degrees
 // and row pointers took 75-90 us at RMAT-26 (a single CU sustains ~0.5 G random lines/s), whatever the number of dependent
 // round trips.  The prefix across workgroups is a one-wavefront look-back: a workgroup publishes (rows with edges, edges) of its
 // 1024 positions in one 64-bit word of BfsPb::agg (bit 63 = published), its first wavefront reads the words of ALL the
@@ -1490,11 +1490,14 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_prefix_kernel(PbArgs g) {
     const bool uq = c->use_queue != 0;                       // else bfs_pb_list_kernel has listed the frontier bitmap in lst0
     const u32 nq = uq ? s_ql[QSHARDS] : (c->n_frontier < (u64)PB_LMAX ? (u32)c->n_frontier : PB_LMAX);
     const u32* __restrict__ vsrc = uq ? q : g.lst0;
-    const u32 pos0 = (blk * PB_T + t) * PB_PPT;              // PB_PPT consecutive positions per thread
+    // position j of a thread = j x (grid x PB_T) + blk x PB_T + t: a frontier of 10^4 vertices is one position per thread of the
+    // first ten workgroups (one CU sustains ~0.5 G random lines/s), a frontier of 4 M fills all sixteen.  The compacted list is in
+    // (workgroup, thread, j) order — any order of the frontier's rows will do as long as P is the prefix over it.
+    const u32 pos0 = blk * PB_T + t, pstride = gridDim.x * PB_T;
     u32 v[PB_PPT], d[PB_PPT], rs[PB_PPT];
 #pragma unroll
     for (u32 j = 0; j < PB_PPT; ++j) {
-        const u32 pos = pos0 + j;
+        const u32 pos = pos0 + j * pstride;
         const u32 pc = pos < nq ? pos : (nq ? nq - 1u : 0u); // (every load from a clamped address)
         u32 sc = 0;
 #pragma unroll
@@ -1506,7 +1509,7 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_prefix_kernel(PbArgs g) {
     u32 tc = 0, ts = 0;
 #pragma unroll
     for (u32 j = 0; j < PB_PPT; ++j) {
-        if (pos0 + j >= nq) d[j] = 0;
+        if (pos0 + j * pstride >= nq) d[j] = 0;
         tc += d[j] ? 1u : 0u;
         ts += d[j];
     }
@@ -1714,7 +1717,7 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_scatter_kernel(PbArgs g) {
             const u32 vv = sP[i];
             const u32 b = vv >> shift;
             const u32 at = s_gb[b] + (i - s_loc[b]);
-            g.dst[at] = vv;
+            g.dst[at] = vv;                                   // (non-temporal stores: no difference, 174 vs 176 us)
             if (PARENT) g.src[at] = sS[i];
         }
         __syncthreads();
