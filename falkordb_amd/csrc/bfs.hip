@@ -33,7 +33,9 @@ constexpr int PULL_H = 1;  // fused pull levels: leading in-neighbours kept in t
 typedef u32 headv __attribute__((ext_vector_type(PULL_H)));
 constexpr int STAT_SLOTS = 64;
 constexpr unsigned QSHARDS = 8;          // the frontier queue is appended in 8 independent segments
-constexpr unsigned QCAP = 1u << 16;      // capacity of a frontier queue (vertex ids), all segments
+constexpr unsigned QCAP = 1u << 20;      // capacity of a frontier queue (vertex ids), all segments.  Levels APPEND at most QGATE entries
+                                         // (below); the rest of the room is for bfs_pb_list_kernel, which lists a sparse bitmap
+                                         // frontier of up to QCAP / 2 vertices into the queue in front of a push level
 constexpr unsigned QSEG = QCAP / QSHARDS;
 // A level appends its discoveries only when it can discover at most this many: a push examines m_frontier edges, a pull can
 // discover at most the unvisited vertices.  (Round 6 tried a 2^20-entry queue with the bound of a pull tightened to the unvisited
@@ -94,6 +96,10 @@ struct BfsCtrl {
     u32 pb_levels;   // levels of this search run that way
     u32 pb_at;       // bit k: fused launch k of this search was such a level (the host arms the next search's launches with it)
     u32 n_alive;     // vertices with an in-edge (0: not counted): what a pull can still discover, and the base of the m_u estimate
+    u32 compact;     // the next level is a push whose frontier bfs_pb_list_kernel lists into the queue first (bit k of cp_mask: the
+    u32 cp_mask;     // host put that launch in front of fused launch k); cp_at: the launches of this search where it did
+    u32 cp_at;
+    u32 pull_floor;  // what a pull level costs whatever it finds, in scanned-edge units (0: not modelled)
     // per-launch accumulators, spread over slots to keep same-address atomics off the critical path; one slot per
     // 128 B: atomics to different words of ONE line serialise at the memory side just like same-address ones
     // (tools/micro/levelfloor.hip: 1792 workgroups' arrivals on 64 packed counters cost 8.6 us per launch, 0.6 us
@@ -989,7 +995,7 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
     const u32 q_open0 = c->q_open, force_dir = c->force_dir, has_at = c->has_at;
     const u64 n_total = c->n_total, nnz_at = c->nnz_at;
     const u64 pb_min = c->pb_min;
-    const u32 pb_mask = c->pb_mask, pb_at0 = c->pb_at, n_alive = c->n_alive;
+    const u32 pb_mask = c->pb_mask, pb_at0 = c->pb_at, n_alive = c->n_alive, cp_mask = c->cp_mask, cp_at0 = c->cp_at, pull_floor = c->pull_floor;
     const float alpha = c->alpha;
     u64 v0 = __hip_atomic_load(&c->slot[t].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     u64 v1 = __hip_atomic_load(&c->slot[t].mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1092,6 +1098,7 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
     c->done = done ? 1 : 0;
     if (done && host_done) {  // the host polls this word instead of paying a D2H copy + stream sync
         if (pb_at0) __hip_atomic_store(host_done + 1, pb_at0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (read after the flag; a hint)
+        if (cp_at0) __hip_atomic_store(host_done + 2, cp_at0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_done, done_word_of(hb, he, level), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     int nd = 1;
@@ -1108,7 +1115,10 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
             base = (double)n_alive;
         }
         const u64 m_u = (u64)((double)nnz_at * un / base);
-        nd = ((double)v1 * (double)alpha > (double)m_u) ? 2 : 1;
+        // ... plus what a pull costs whatever it finds (every word of the bitmaps, every unvisited row's head: ~150 us at RMAT-26,
+        // a push of ~2 x 10^6 edges) — counted where a push from a sparse frontier is cheap, i.e. where the list kernel can put it
+        // into the queue (plans with the propagation-blocking launches): the level after the last pull is then pushed, 35 us
+        nd = ((double)v1 * (double)alpha > (double)m_u + (double)pull_floor) ? 2 : 1;
     }
     // (the tiny kernel's control steps — nwg == 0 — are not fused launches: the count stays)
     const unsigned long long seq = (__hip_atomic_load(&c->nact_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + (nwg ? 1ull : 0ull);
@@ -1118,6 +1128,13 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
                     ((pb_mask >> (u32)seq) & 1u);
     if (pb) { nd = 3; c->pb_at = pb_at0 | (1u << (u32)seq); }
     c->direction = nd;
+    // a push from a sparse bitmap frontier (the level after the last pull: 10^5 vertices over 2^26) walks every 1024-vertex item
+    // that holds a frontier vertex — a chain of ~5 round trips and barriers each, 43 a workgroup, 150 us for 2 x 10^5 edges; listed
+    // into the queue first (bfs_pb_list_kernel, armed like the launches above) it is a queue-mode level of 35 us
+    const bool cp = !pb && nd == 1 && !use_queue && !done && nwg && v0 >= 16384ull && v0 <= (u64)(QCAP / 2) && seq < 32ull &&
+                    (((pb_mask | cp_mask) >> (u32)seq) & 1u);
+    c->compact = cp ? 1u : 0u;
+    if (cp) c->cp_at = cp_at0 | (1u << (u32)seq);
     // the next level may append its discoveries only if it is light: a push examines m_frontier
     // edges, a pull can discover at most the unvisited vertices
     const u64 unv = n_total > reached ? n_total - reached : 0;
@@ -1393,6 +1410,9 @@ struct PbArgs {
     i32* level;
     u32* parent;             // nullable
     u32 nw;
+    u32 epoch;               // of this group of launches (tags bfs_pb_list_kernel's look-back words: nobody zeroes them)
+    u32 n_hubP;
+    u32* queue_w[2];         // the queues, writable (bfs_pb_list_kernel's second job)
 };
 
 __device__ __forceinline__ bool pb_level(const BfsCtrl* c) { return !c->done && c->direction == 3; }
@@ -1419,11 +1439,14 @@ __device__ __forceinline__ u32 pb_block_scan(u32 v, u32* s_w /* >= 17 words */, 
 // hub: level 2 examines 10^5 - 10^7 edges): without this they kept the 1.1 - 1.5 ms push.
 __global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
     BfsCtrl* c = g.ctrl;
-    if (!pb_level(c) || c->use_queue) return;
+    const bool for_pb = pb_level(c) && !c->use_queue;        // the list feeds bfs_pb_prefix_kernel
+    const bool for_q = !c->done && c->compact != 0;          // ... or becomes the level's queue (a push from a sparse bitmap frontier)
+    if (!for_pb && !for_q) return;
     __shared__ u32 s_w[20];
     __shared__ u32 s_base;
     const u32 t = threadIdx.x, blk = blockIdx.x;
-    const u64* __restrict__ fr = g.bm[c->rot % 3];
+    const u32 rot = c->rot;
+    const u64* __restrict__ fr = g.bm[rot % 3];
     const u32 wpw = (g.nw + gridDim.x - 1) / gridDim.x;      // words per workgroup
     const u32 K = (wpw + PB_T - 1) / PB_T;                   // ... per thread, consecutive
     const u32 w0 = blk * wpw + t * K;
@@ -1432,14 +1455,16 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
     for (u32 k = 0; k < K; ++k) cnt += (w0 + k < wend) ? (u32)__popcll(fr[w0 + k]) : 0u;
     u32 bc;
     const u32 lc = pb_block_scan(cnt, s_w, &bc);
+    // look-back words tagged with the launch group's epoch (bit 63 | 31 bits of epoch | count): nothing has to zero them
     unsigned long long* agg = const_cast<unsigned long long*>(g.pb->agg0);
-    if (t == 0) __hip_atomic_store(&agg[blk], (1ull << 63) | (unsigned long long)bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long tag = (1ull << 31) | (unsigned long long)(g.epoch & 0x7FFFFFFFu);
+    if (t == 0) __hip_atomic_store(&agg[blk], (tag << 32) | (unsigned long long)bc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t < 64) {
         u32 pcn = 0;
         for (u32 k0 = 0; k0 < blk; k0 += 64) {
             unsigned long long w = 0ull;
             if (k0 + t < blk) {
-                do { w = __hip_atomic_load(&agg[k0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(w >> 63));
+                do { w = __hip_atomic_load(&agg[k0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 32) != tag);
             }
             pcn += (u32)w;
         }
@@ -1449,14 +1474,42 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
     }
     __syncthreads();
     u32 at = s_base + lc;
+    // the queue as eight segments of `sl` consecutive list positions each
+    const u64 v0 = c->n_frontier;
+    const u32 sl = (u32)((v0 + QSHARDS - 1) / QSHARDS) ? (u32)((v0 + QSHARDS - 1) / QSHARDS) : 1u;
+    u32* __restrict__ qw = g.queue_w[rot & 1];
     for (u32 k = 0; k < K; ++k) {
         if (w0 + k >= wend) break;
         u64 w = fr[w0 + k];
         while (w) {
-            if (at < PB_LMAX) g.lst0[at] = (w0 + k) * 64u + (u32)__builtin_ctzll(w);
+            const u32 vtx = (w0 + k) * 64u + (u32)__builtin_ctzll(w);
+            if (for_pb) { if (at < PB_LMAX) g.lst0[at] = vtx; }
+            else if (at / sl < QSHARDS) qw[(at / sl) * QSEG + at % sl] = vtx;
             ++at;
             w &= w - 1ull;
         }
+    }
+    if (for_q && blk == gridDim.x - 1 && t == 0) {
+        // the last workgroup has seen every count: the control block now describes a queue-listed frontier (what the control
+        // step of the previous level would have written had that level appended)
+        const u32 total = s_base + bc;
+        u32 qmx = 0;
+        for (u32 sg = 0; sg < QSHARDS; ++sg) {
+            const u32 b0 = sg * sl;
+            const u32 len = total > b0 ? (total - b0 < sl ? total - b0 : sl) : 0u;
+            c->qlen[rot & 1][sg * 16] = len;
+            qmx = len > qmx ? len : qmx;
+        }
+        c->qmax = qmx;
+        c->use_queue = (total == (u32)v0 && sl <= QSEG) ? 1u : 0u;   // (always: the frontier was counted by the level that made it)
+        c->compact = 0;
+        const u32 qchunk = c->qchunk;
+        const u64 v1 = c->m_frontier;
+        u64 items = (u64)QSHARDS * ((qmx + qchunk - 1) / qchunk) + v1 / PUSH_HUB_CHUNK + 1;
+        if (v1 >= PUSH_HUB_DEG && (u64)g.n_hubP / 1024 > items) items = (u64)g.n_hubP / 1024;
+        const u32 na = items * 2 < 64 ? 64u : (items * 2 > 60000ull ? 0u : (u32)(items * 2));
+        const unsigned long long seq = c->nact_seq >> 32;
+        c->nact_seq = (seq << 32) | (unsigned long long)(c->use_queue ? na : 0u);
     }
 }
 
@@ -1742,9 +1795,8 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_apply_kernel(PbArgs g) {
     __shared__ unsigned long long s_acc[2];
     __shared__ u32 s_hub;
     const u32 t = threadIdx.x;
-    if (blockIdx.x == 0) {                                   // (the look-back words of the list / prefix kernels, for the next such level)
+    if (blockIdx.x == 0) {                                   // (the prefix kernel's look-back words, for the next such level)
         for (u32 i = t; i < PB_LMAX / PB_T / PB_PPT; i += PB_T) g.pb->agg[i] = 0ull;
-        if (t < PB_LWG) g.pb->agg0[t] = 0ull;
     }
     const u32 shift = g.pb->shift;
     const u32 rot = c->rot;
@@ -2046,7 +2098,7 @@ __global__ void bfs_init_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at, u
 // memsets + bfs_init_kernel).  Every word is written by exactly one thread, which also applies the
 // seed value if the source falls into its word; workgroup 0 owns the control block.
 __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src, i32 max_level, u32 has_at,
-                                                             u32 force_dir, float alpha, u64 nnz_at, u64 pb_min, u32 pb_mask, u32 n_alive) {
+                                                             u32 force_dir, float alpha, u64 nnz_at, u64 pb_min, u32 pb_mask, u32 n_alive, u32 cp_mask) {
     const u32 tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
     // level[] is NOT cleared: level[v] is meaningful exactly where the visited bitmap has v set (the on-device
     // result is the pair); fgpu_bfs_fetch masks the rest to -1 on its way out (bfs_mask_levels_kernel).
@@ -2078,6 +2130,8 @@ __global__ __launch_bounds__(256) void bfs_fused_begin_kernel(BfsArgs a, u32 src
     c->pb_min = a.pb ? pb_min : 0ull;
     c->pb_mask = pb_mask;
     c->n_alive = n_alive;
+    c->cp_mask = a.pb ? cp_mask : 0u;
+    c->pull_floor = (a.pb && n_alive) ? a.n / 16u : 0u;
     a.queue[0][0] = src;
     c->qlen[0][0] = 1;
     c->qmax = 1;
@@ -2338,6 +2392,7 @@ struct fgpu_bfs_plan {
     u32 *pb_dst = nullptr, *pb_src = nullptr;
     u32 pb_maxchunks = 0, pb_mask = 0;
     u32 n_alive = 0;                         // vertices with an in-edge (0 when the plan has no transpose)
+    u32 cp_mask = 0, cp_seen = 0, pb_epoch = 0;   // the list kernel alone in front of those fused launches (frontier -> queue), learnt like pb_seen
     u32 pb_seen = 0, pb_searches = 0;        // fused launches that were such levels in this plan's searches so far; searches run
     bool dist_ready = false;
     std::vector<hipEvent_t> dist_ev;    // 3 per level: before the level kernel, after it, after the collective
@@ -3060,13 +3115,13 @@ static fgpu_info fused_begin(fgpu_bfs_plan* p, uint64_t src, int64_t max_level) 
     p->mask_visited = p->bm_block + 3 * (size_t)p->nw;
     hipLaunchKernelGGL(bfs_fused_begin_kernel, dim3(ctx->cus * 4), dim3(256), 0, ctx->stream(), a, (u32)src, ml,
                        p->At ? 1u : 0u, (u32)p->force_dir, (float)p->alpha, p->At ? p->At->nnz : 0ull,
-                       (u64)(ctx->opt.bfs_pb_min_edges > 0 ? ctx->opt.bfs_pb_min_edges : 1), p->pb ? p->pb_mask : 0u, ctx->opt.bfs_alive_rule ? p->n_alive : 0u);
+                       (u64)(ctx->opt.bfs_pb_min_edges > 0 ? ctx->opt.bfs_pb_min_edges : 1), p->pb ? p->pb_mask : 0u, ctx->opt.bfs_alive_rule ? p->n_alive : 0u, p->pb ? p->cp_mask : 0u);
     FGPU_HIP(hipGetLastError());
     return FGPU_OK;
 }
 
 // the four launches of a propagation-blocking level (each returns at once unless the control block says direction 3)
-static fgpu_info pb_launches(fgpu_bfs_plan* p) {
+static fgpu_info pb_launches(fgpu_bfs_plan* p, bool list_only = false) {
     fgpu_ctx* ctx = p->ctx;
     PbArgs g;
     g.ctrl = p->ctrl;
@@ -3090,7 +3145,16 @@ static fgpu_info pb_launches(fgpu_bfs_plan* p) {
     g.level = p->level;
     g.parent = p->want_parent ? p->parent : nullptr;
     g.nw = p->nw;
+    g.epoch = ++p->pb_epoch;
+    g.n_hubP = p->A->n_push_chunks;
+    g.queue_w[0] = p->queue_block;
+    g.queue_w[1] = p->queue_block + QCAP;
     hipStream_t st = ctx->stream();
+    if (list_only) {
+        hipLaunchKernelGGL(bfs_pb_list_kernel, dim3(PB_LWG), dim3(PB_T), 0, st, g);
+        FGPU_HIP(hipGetLastError());
+        return FGPU_OK;
+    }
     const size_t lds_count = ((size_t)2 * (PB_C + 2) + PB_BINS) * sizeof(u32);
     const size_t lds_scat = ((size_t)2 * (PB_C + 2) + 4 * PB_BINS) * sizeof(u32);
     u32 shift = 6;
@@ -3132,6 +3196,7 @@ static fgpu_info tiny_levels(fgpu_bfs_plan* p) {
 static fgpu_info fused_level(fgpu_bfs_plan* p) {
     BfsArgs a = make_args(p, true);
     if (p->pb && p->fused_idx < 32 && ((p->pb_mask >> p->fused_idx) & 1u)) FGPU_TRY(pb_launches(p));
+    else if (p->pb && p->fused_idx < 32 && ((p->cp_mask >> p->fused_idx) & 1u)) FGPU_TRY(pb_launches(p, true));
     const u32 grid = p->fgrid | (p->fused_idx++ & 1u);   // launch k carries its parity in the grid size (see the head of bfs_fused_kernel)
     if (p->want_parent)
         hipLaunchKernelGGL((bfs_fused_kernel<true, 0>), dim3(grid), dim3(256), 0, p->ctx->stream(), a);
@@ -3197,6 +3262,7 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     BfsArgs a = make_args(p, true);
     FGPU_HIP(hipEventRecord(p->ev0, ctx->stream()));
     if (dir == 3) FGPU_TRY(pb_launches(p));              // (the profiled pass knows the direction: pb_mask is all ones there)
+    else if (p->h_ctrl->compact) FGPU_TRY(pb_launches(p, true));
     const u32 pgrid = p->fgrid | (p->fused_idx++ & 1u);
     // The events bracket the SAME instantiation the blind (timed) level loop launches, <.., 0>; only under
     // "bfs_prof_split" (rocprofv3 PMC passes, which can tell launches apart by kernel name alone) does the pass
@@ -3243,6 +3309,9 @@ fgpu_info fgpu_bfs_run_async(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, 
         // R-MAT-26 search — only those launches are armed, and every eighth search looks at all three again)
         u32 m = (p->pb_seen && (p->pb_searches & 7u) != 7u) ? (p->pb_seen & 0xEu) : 0xEu;
         p->pb_mask = (p->pb && !deep) ? m : 0u;
+        // the list kernel alone in front of launches 4 .. 6 (the push after the last pull), narrowed the same way
+        const u32 cm = (p->cp_seen && (p->pb_searches & 7u) != 7u) ? (p->cp_seen & 0x7Eu) : 0x70u;
+        p->cp_mask = (p->pb && !deep) ? (cm & ~p->pb_mask) : 0u;
         p->pb_searches++;
     }
     FGPU_TRY(fused_begin(p, src, max_level));
@@ -3303,6 +3372,7 @@ fgpu_info fgpu_bfs_wait(fgpu_bfs_plan* p) {
         }
         if (*flag & 0x80000000u) {
             p->pb_seen |= ((volatile u32*)p->h_done)[1];
+            p->cp_seen |= ((volatile u32*)p->h_done)[2];
             p->last_levels = (int)(*flag & 0xFFFFFFu);
             p->last_heavy = (int)((*flag >> 24) & 0x7Fu);
             p->last_wait_us = waited_us();
@@ -3331,6 +3401,7 @@ fgpu_info fgpu_bfs_run(fgpu_bfs_plan* p, uint64_t src, int64_t max_level, int wa
     if (p->profile) {
         p->want_parent = want_parent != 0;
         p->pb_mask = p->pb ? 0xFFFFFFFFu : 0u;
+        p->cp_mask = 0;
         FGPU_TRY(fused_begin(p, src, max_level));
         for (;;) {
             FGPU_TRY(profiled_level(p));
