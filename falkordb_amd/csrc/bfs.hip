@@ -128,7 +128,7 @@ struct BfsCtrl {
 constexpr u32 PB_BINS = 256;
 constexpr u32 PB_C = 8192;          // edges per chunk: 8 per thread of a 1024-thread workgroup
 constexpr u32 PB_T = 1024;
-struct PbPart { u64 count, mf; u32 hub; u32 pad[11]; };   // a window's share of the level statistics (one 64-byte line)
+struct PbPart { u64 count, mf, scanned; u32 hub; u32 pad[9]; };   // a window's / workgroup's share of the level statistics (one 64-byte line)
 struct BfsPb {
     u32 nlist, nchunks, total, shift;   // rows of the compacted frontier, chunks, edges of the level; log2(vertices per window)
     u32 pad[28];
@@ -1038,7 +1038,7 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
     }
     if (t != 0) return;
     // ---- lane 0: register arithmetic, then stores only -----------------------------------------------------------------
-    if (dir0 != 2) { c->scanned_push = sp0 + v3; c->push_levels = pl0 + 1; }   // (3 = a push by propagation blocking)
+    if (dir0 != 2 && dir0 != 4) { c->scanned_push = sp0 + v3; c->push_levels = pl0 + 1; }   // (3 = a push by propagation blocking, 4 = a pull of listed candidates)
     else { c->scanned_pull = spl0 + v3; c->pull_levels = pll0 + 1; }
     const i32 level = level0 + 1;
     c->level = level;
@@ -1131,6 +1131,13 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
     // a push from a sparse bitmap frontier (the level after the last pull: 10^5 vertices over 2^26) walks every 1024-vertex item
     // that holds a frontier vertex — a chain of ~5 round trips and barriers each, 43 a workgroup, 150 us for 2 x 10^5 edges; listed
     // into the queue first (bfs_pb_list_kernel, armed like the launches above) it is a queue-mode level of 35 us
+    // a pull with few rows left to discover (the level after the heavy pulls: 10^6 of 2^26) still reads every bitmap word and every
+    // unvisited row's head — 214 us at RMAT-26 for 4 x 10^5 discoveries.  Where the list kernel is armed the candidates (unvisited
+    // AND with an in-edge) are listed and bfs_lp_kernel pulls a lane per candidate: direction 4
+    const u64 alive_unv = n_alive ? ((u64)n_alive + 1ull > reached ? (u64)n_alive + 1ull - reached : 0ull) : ~0ull;
+    const bool lp = nd == 2 && !done && nwg && alive_unv <= (n_total >> 5) && alive_unv <= (u64)PB_LMAX && seq < 32ull &&
+                    ((cp_mask >> (u32)seq) & 1u);
+    if (lp) { nd = 4; c->direction = 4; c->cp_at = cp_at0 | (1u << (u32)seq); }
     const bool cp = !pb && nd == 1 && !use_queue && !done && nwg && v0 >= 16384ull && v0 <= (u64)(QCAP / 2) && seq < 32ull &&
                     (((pb_mask | cp_mask) >> (u32)seq) & 1u);
     c->compact = cp ? 1u : 0u;
@@ -1138,7 +1145,8 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
     // the next level may append its discoveries only if it is light: a push examines m_frontier
     // edges, a pull can discover at most the unvisited vertices
     const u64 unv = n_total > reached ? n_total - reached : 0;
-    c->q_open = (!pb && (nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u;
+    c->q_open = nd == 4 ? (alive_unv <= (u64)(QCAP / 2) ? 1u : 0u)              // (bfs_lp_kernel appends a workgroup at a time)
+                        : ((!pb && (nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u);
     // workgroups the next launch needs: twice its work items (queue chunks + one per 1024 hub-row edges), at least 64 — and, when
     // the frontier may hold a hub row (>= PUSH_HUB_DEG edges to examine), enough to screen the static hub chunk list in two
     // rounds of 256 items a workgroup (3 x 10^5 items at RMAT-26: 64 workgroups took 18 rounds, 53 us for a level of 11 K edges)
@@ -1214,16 +1222,17 @@ __global__ FUSED_BOUNDS void bfs_fused_kernel(BfsArgs a) {
         g_bfs_dbg[blockIdx.x * 8 + 7] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
     }
 #endif
-    if (dir == 3) {
-        // the level was run by the bfs_pb_* launches in front of this one: the windows' statistics go through this launch's
-        // ticket like any level's
+    if (dir >= 3) {
+        // the level was run by the launches in front of this one (3: bfs_pb_*, the blocked push; 4: bfs_lp_kernel, the pull of a
+        // listed candidate set): their shares of the statistics go through this launch's ticket like any level's
         if (threadIdx.x == 0) {
             for (u32 b = blockIdx.x; b < PB_BINS; b += nwg) {
                 acc.count += a.pb->part[b].count;
                 acc.mf += a.pb->part[b].mf;
+                acc.scanned += a.pb->part[b].scanned;
                 acc.hub |= a.pb->part[b].hub;
             }
-            if (blockIdx.x == 0) acc.scanned += a.pb->total;
+            if (blockIdx.x == 0 && dir == 3) acc.scanned += a.pb->total;
         }
     } else if (dir == 1)
         push_fused<PARENT>(a, cur, use_q ? a.queue[rot & 1] : nullptr, &c->qlen[rot & 1][0], qmax, qchunk, hubs_present,
@@ -1413,6 +1422,9 @@ struct PbArgs {
     u32 epoch;               // of this group of launches (tags bfs_pb_list_kernel's look-back words: nobody zeroes them)
     u32 n_hubP;
     u32* queue_w[2];         // the queues, writable (bfs_pb_list_kernel's second job)
+    const u64* alive;        // bit v: vertex v has an in-edge (plan constant; nullable)
+    CsrView At;              // the pull direction's rows (hub-first column order when the plan has it)
+    const headv* head;
 };
 
 __device__ __forceinline__ bool pb_level(const BfsCtrl* c) { return !c->done && c->direction == 3; }
@@ -1441,7 +1453,8 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
     BfsCtrl* c = g.ctrl;
     const bool for_pb = pb_level(c) && !c->use_queue;        // the list feeds bfs_pb_prefix_kernel
     const bool for_q = !c->done && c->compact != 0;          // ... or becomes the level's queue (a push from a sparse bitmap frontier)
-    if (!for_pb && !for_q) return;
+    const bool for_lp = !c->done && c->direction == 4;       // ... or is the candidate set of bfs_lp_kernel: unvisited AND with an in-edge
+    if (!for_pb && !for_q && !for_lp) return;
     __shared__ u32 s_w[20];
     __shared__ u32 s_base;
     const u32 t = threadIdx.x, blk = blockIdx.x;
@@ -1451,8 +1464,9 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
     const u32 K = (wpw + PB_T - 1) / PB_T;                   // ... per thread, consecutive
     const u32 w0 = blk * wpw + t * K;
     const u32 wend = (blk + 1) * wpw < g.nw ? (blk + 1) * wpw : g.nw;
+    auto word_at = [&](u32 w) -> u64 { return for_lp ? (~g.visited[w] & g.alive[w]) : fr[w]; };
     u32 cnt = 0;
-    for (u32 k = 0; k < K; ++k) cnt += (w0 + k < wend) ? (u32)__popcll(fr[w0 + k]) : 0u;
+    for (u32 k = 0; k < K; ++k) cnt += (w0 + k < wend) ? (u32)__popcll(word_at(w0 + k)) : 0u;
     u32 bc;
     const u32 lc = pb_block_scan(cnt, s_w, &bc);
     // look-back words tagged with the launch group's epoch (bit 63 | 31 bits of epoch | count): nothing has to zero them
@@ -1480,15 +1494,16 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
     u32* __restrict__ qw = g.queue_w[rot & 1];
     for (u32 k = 0; k < K; ++k) {
         if (w0 + k >= wend) break;
-        u64 w = fr[w0 + k];
+        u64 w = word_at(w0 + k);
         while (w) {
             const u32 vtx = (w0 + k) * 64u + (u32)__builtin_ctzll(w);
-            if (for_pb) { if (at < PB_LMAX) g.lst0[at] = vtx; }
+            if (for_pb || for_lp) { if (at < PB_LMAX) g.lst0[at] = vtx; }
             else if (at / sl < QSHARDS) qw[(at / sl) * QSEG + at % sl] = vtx;
             ++at;
             w &= w - 1ull;
         }
     }
+    if (for_lp && blk == gridDim.x - 1 && t == 0) g.pb->nlist = s_base + bc < PB_LMAX ? s_base + bc : PB_LMAX;
     if (for_q && blk == gridDim.x - 1 && t == 0) {
         // the last workgroup has seen every count: the control block now describes a queue-listed frontier (what the control
         // step of the previous level would have written had that level appended)
@@ -1511,6 +1526,91 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_list_kernel(PbArgs g) {
         const unsigned long long seq = c->nact_seq >> 32;
         c->nact_seq = (seq << 32) | (unsigned long long)(c->use_queue ? na : 0u);
     }
+}
+
+// Direction 4: the pull of a listed candidate set.  A lane per candidate (an unvisited vertex with an in-edge): the row's head
+// entry first, then the row until an in-neighbour is in the frontier — the rows left at this stage of a search are short.  A
+// discovery sets its visited / next-frontier bits with atomics (a few 10^5 per level), stores level / parent, and — when the level
+// appends — goes to the next queue a WORKGROUP at a time (one returning add per workgroup and round on its segment's counter).
+// PB_BINS workgroups: their statistics leave through BfsPb::part like the blocked push's.
+template <bool PARENT>
+__global__ __launch_bounds__(PB_T) void bfs_lp_kernel(PbArgs g) {
+    BfsCtrl* c = g.ctrl;
+    if (c->done || c->direction != 4) return;
+    __shared__ unsigned long long s_acc[3];
+    __shared__ u32 s_hub, s_cnt, s_qbase;
+    const u32 t = threadIdx.x, blk = blockIdx.x;
+    const u32 rot = c->rot;
+    const i32 newlevel = c->level + 1;
+    const u32 nlist = g.pb->nlist;
+    const u32* __restrict__ f32 = (const u32*)g.bm[rot % 3];
+    u32* __restrict__ nxt32 = (u32*)g.bm[(rot + 1) % 3];
+    u32* __restrict__ vis32 = (u32*)g.visited;
+    const u32* __restrict__ col = g.At.colidx;
+    const bool q_open = c->q_open != 0;
+    u32* __restrict__ qseg = g.queue_w[(rot + 1) & 1] + (blk % QSHARDS) * QSEG;
+    u32* qlen = &c->qlen[(rot + 1) & 1][(blk % QSHARDS) * 16];
+    if (t < 3) s_acc[t] = 0ull;
+    if (t == 0) s_hub = 0;
+    u64 n_new = 0, mf = 0, scanned = 0;
+    u32 hub = 0;
+    for (u32 i0 = blk * PB_T; i0 < nlist; i0 += gridDim.x * PB_T) {       // (block-uniform trip count)
+        if (t == 0) s_cnt = 0;
+        __syncthreads();
+        const u32 i = i0 + t;
+        const bool on = i < nlist;
+        const u32 v = g.lst0[on ? i : nlist - 1u];
+        const u32 h = g.head[v][0];
+        bool found = on && h < HEAD_HUB && ((f32[h >> 5] >> (h & 31u)) & 1u);
+        u32 par = h;
+        if (on && !found) {
+            const u32 rb = g.At.rowptr[v], re = g.At.rowptr[v + 1];
+            u32 e = rb + (h < HEAD_HUB ? 1u : 0u);                         // (the head is the row's first entry)
+            scanned += (h < HEAD_HUB && h != 0xFFFFFFFFu) ? 1u : 0u;
+            for (; e < re; ++e) {
+                const u32 x = col[e];
+                ++scanned;
+                if ((f32[x >> 5] >> (x & 31u)) & 1u) { found = true; par = x; break; }
+            }
+        } else if (on) {
+            scanned += 1;
+        }
+        u32 rank = 0;
+        if (found) {
+            const u32 bit = 1u << (v & 31u);
+            atomicOr(&vis32[v >> 5], bit);
+            atomicOr(&nxt32[v >> 5], bit);
+            g.level[v] = newlevel;
+            if (PARENT) g.parent[v] = par;
+            const u32 d = g.deg[v];
+            n_new += 1;
+            mf += d;
+            hub |= d >= PUSH_HUB_DEG ? 1u : 0u;
+            if (q_open) rank = atomicAdd(&s_cnt, 1u);
+        }
+        if (q_open) {
+            __syncthreads();
+            if (t == 0) s_qbase = s_cnt ? atomicAdd(qlen, s_cnt) : 0u;
+            __syncthreads();
+            if (found && s_qbase + rank < QSEG) qseg[s_qbase + rank] = v;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        n_new += __shfl_xor(n_new, dd, 64);
+        mf += __shfl_xor(mf, dd, 64);
+        scanned += __shfl_xor(scanned, dd, 64);
+    }
+    __syncthreads();
+    if (__ballot(hub != 0) != 0ull && lane_id() == 0) s_hub = 1;
+    if (lane_id() == 0) {
+        atomicAdd(&s_acc[0], (unsigned long long)n_new);
+        atomicAdd(&s_acc[1], (unsigned long long)mf);
+        atomicAdd(&s_acc[2], (unsigned long long)scanned);
+    }
+    __syncthreads();
+    if (t == 0) { g.pb->part[blk].count = s_acc[0]; g.pb->part[blk].mf = s_acc[1]; g.pb->part[blk].scanned = s_acc[2]; g.pb->part[blk].hub = s_hub; }
 }
 
 // PB_LMAX / PB_T / PB_PPT = 256 workgroups, PB_PPT frontier positions per thread: ONE workgroup doing the ~3 x 10^4 random reads of a frontier's degrees
@@ -1812,7 +1912,7 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_apply_kernel(PbArgs g) {
         if (t == 0) s_hub = 0;
         if (cnt == 0 || w0 >= g.nw) {                        // (block-uniform)
             __syncthreads();
-            if (t == 0) { g.pb->part[b].count = 0; g.pb->part[b].mf = 0; g.pb->part[b].hub = 0; }
+            if (t == 0) { g.pb->part[b].count = 0; g.pb->part[b].mf = 0; g.pb->part[b].scanned = 0; g.pb->part[b].hub = 0; }
             __syncthreads();
             continue;
         }
@@ -1912,7 +2012,7 @@ __global__ __launch_bounds__(PB_T) void bfs_pb_apply_kernel(PbArgs g) {
             atomicAdd(&s_acc[1], (unsigned long long)mf);
         }
         __syncthreads();
-        if (t == 0) { g.pb->part[b].count = s_acc[0]; g.pb->part[b].mf = s_acc[1]; g.pb->part[b].hub = s_hub; }
+        if (t == 0) { g.pb->part[b].count = s_acc[0]; g.pb->part[b].mf = s_acc[1]; g.pb->part[b].scanned = 0; g.pb->part[b].hub = s_hub; }
         __syncthreads();
     }
 }
@@ -2278,6 +2378,16 @@ __global__ __launch_bounds__(256) void bfs_count_alive_kernel(const u32* __restr
     for (int d = 32; d >= 1; d >>= 1) c += (u32)__shfl_xor((int)c, d, 64);
     if (lane_id() == 0 && c) atomicAdd(out, c);
 }
+// bit v of alive: vertex v has an in-edge (a wavefront per 64 vertices)
+__global__ __launch_bounds__(256) void bfs_alive_bits_kernel(const u32* __restrict__ rowptr, u32 n, u32 nw, u64* __restrict__ alive) {
+    const u32 lane = lane_id();
+    const u32 wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    for (u32 w = wave; w < nw; w += nwaves) {
+        const u32 v = w * 64 + lane;
+        const u64 m = __ballot(v < n && rowptr[v < n ? v + 1 : n] != rowptr[v < n ? v : n]);
+        if (lane == 0) alive[w] = m;
+    }
+}
 __global__ void pull_head_kernel(const u32* __restrict__ rowptr, const u32* __restrict__ col, u32 n, u32 n_pad,
                                  headv* __restrict__ head) {
     for (u32 v = blockIdx.x * 256 + threadIdx.x; v < n_pad; v += gridDim.x * 256) {
@@ -2392,6 +2502,7 @@ struct fgpu_bfs_plan {
     u32 *pb_dst = nullptr, *pb_src = nullptr;
     u32 pb_maxchunks = 0, pb_mask = 0;
     u32 n_alive = 0;                         // vertices with an in-edge (0 when the plan has no transpose)
+    u64* alive = nullptr;                    // ... as a bitmap (plans with the propagation-blocking launches: bfs_lp_kernel's candidates)
     u32 cp_mask = 0, cp_seen = 0, pb_epoch = 0;   // the list kernel alone in front of those fused launches (frontier -> queue), learnt like pb_seen
     u32 pb_seen = 0, pb_searches = 0;        // fused launches that were such levels in this plan's searches so far; searches run
     bool dist_ready = false;
@@ -2472,6 +2583,7 @@ fgpu_info fgpu_bfs_plan_free(fgpu_bfs_plan* p) {
     c->dev_free(p->slab_ring[2]);
     c->dev_free(p->dist_deg);
     c->dev_free(p->own_deg);
+    c->dev_free(p->alive);
     c->dev_free(p->pb);
     c->dev_free(p->pb_small);
     c->dev_free(p->pb_dst);
@@ -2622,7 +2734,15 @@ static fgpu_info plan_create(fgpu_ctx* ctx, fgpu_bfs_plan** out, const fgpu_mat*
                 hipStreamSynchronize(ctx->stream()) != hipSuccess)
                 pi = FGPU_DEVICE;
         }
+        if (pi == FGPU_OK && At) {
+            pi = ctx->dev_alloc((void**)&p->alive, (size_t)p->nw * sizeof(u64));
+            if (pi == FGPU_OK) {
+                hipLaunchKernelGGL(bfs_alive_bits_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream(), (const u32*)At->rowptr, p->n, p->nw, p->alive);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream()) != hipSuccess) pi = FGPU_DEVICE;
+            }
+        }
         if (pi != FGPU_OK) {
+            ctx->dev_free(p->alive); p->alive = nullptr;
             ctx->dev_free(p->pb); ctx->dev_free(p->pb_small); ctx->dev_free(p->pb_dst); ctx->dev_free(p->pb_src);
             p->pb = nullptr; p->pb_small = nullptr; p->pb_dst = nullptr; p->pb_src = nullptr;
             (void)hipGetLastError();
@@ -3150,8 +3270,16 @@ static fgpu_info pb_launches(fgpu_bfs_plan* p, bool list_only = false) {
     g.queue_w[0] = p->queue_block;
     g.queue_w[1] = p->queue_block + QCAP;
     hipStream_t st = ctx->stream();
-    if (list_only) {
+    g.alive = p->alive;
+    if (p->At) { g.At = view_of(p->At); if (p->pull_colidx) g.At.colidx = p->pull_colidx; }
+    else { g.At.rowptr = nullptr; g.At.colidx = nullptr; g.At.hrows = nullptr; g.At.nvec = 0; g.At.nrows = 0; }
+    g.head = p->pull_head;
+    if (list_only) {   // the list kernel for a sparse frontier -> queue or a candidate set, and the pull of the latter
         hipLaunchKernelGGL(bfs_pb_list_kernel, dim3(PB_LWG), dim3(PB_T), 0, st, g);
+        if (p->alive) {
+            if (p->want_parent) hipLaunchKernelGGL(bfs_lp_kernel<true>, dim3(PB_BINS), dim3(PB_T), 0, st, g);
+            else hipLaunchKernelGGL(bfs_lp_kernel<false>, dim3(PB_BINS), dim3(PB_T), 0, st, g);
+        }
         FGPU_HIP(hipGetLastError());
         return FGPU_OK;
     }
@@ -3262,7 +3390,7 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     BfsArgs a = make_args(p, true);
     FGPU_HIP(hipEventRecord(p->ev0, ctx->stream()));
     if (dir == 3) FGPU_TRY(pb_launches(p));              // (the profiled pass knows the direction: pb_mask is all ones there)
-    else if (p->h_ctrl->compact) FGPU_TRY(pb_launches(p, true));
+    else if (p->h_ctrl->compact || dir == 4) FGPU_TRY(pb_launches(p, true));
     const u32 pgrid = p->fgrid | (p->fused_idx++ & 1u);
     // The events bracket the SAME instantiation the blind (timed) level loop launches, <.., 0>; only under
     // "bfs_prof_split" (rocprofv3 PMC passes, which can tell launches apart by kernel name alone) does the pass
@@ -3280,16 +3408,16 @@ static fgpu_info profiled_level(fgpu_bfs_plan* p) {
     FGPU_HIP(hipEventRecord(p->ev1, ctx->stream()));
     FGPU_HIP(hipEventSynchronize(p->ev1));
     FGPU_HIP(hipEventElapsedTime(&ms, p->ev0, p->ev1));
-    ProfSlot& s = p->prof[dir != 2 ? 0 : 1];
+    ProfSlot& s = p->prof[(dir != 2 && dir != 4) ? 0 : 1];
     s.ms += ms; s.launches += 1;
     FGPU_TRY(fetch_ctrl(p));
     // algorithmic bytes of the level (bitmap form): colidx actually examined,
     // rowptr pairs of the rows touched, the bitmaps streamed, level (+ out-degree) of new vertices
-    const u64 scanned = dir != 2 ? (p->h_ctrl->scanned_push - sp0) : (p->h_ctrl->scanned_pull - sl0);
+    const u64 scanned = (dir != 2 && dir != 4) ? (p->h_ctrl->scanned_push - sp0) : (p->h_ctrl->scanned_pull - sl0);
     const u64 newf = p->h_ctrl->n_frontier;
     const u64 unvisited = p->n > reached0 ? p->n - reached0 : 0;
     u64 bytes;
-    if (dir != 2) bytes = 4 * scanned + 8 * nf + (u64)p->nw * 8 * 2 + 12 * newf;
+    if (dir != 2 && dir != 4) bytes = 4 * scanned + 8 * nf + (u64)p->nw * 8 * 2 + 12 * newf;
     else bytes = 4 * scanned + 8 * unvisited + (u64)p->nw * 8 * 2 + 12 * newf;
     s.alg_bytes += bytes;
     return FGPU_OK;
