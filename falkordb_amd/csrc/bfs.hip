@@ -3580,6 +3580,7 @@ fgpu_info fgpu_bfs_stats(fgpu_bfs_plan* p, uint64_t stats[8]) {
     stats[5] = c->scanned_push;
     stats[6] = c->scanned_pull;
     stats[7] = c->n_frontier;
+    p->ctx->bfs_cp_last.store(c->cp_at, std::memory_order_relaxed);       // ("bfs_cp_last_mask": its launches behind the list kernel — queue fill / direction 4)
     p->ctx->bfs_pb_last.store(c->pb_levels, std::memory_order_relaxed);   // ("bfs_pb_last_levels": levels of that search run by propagation blocking)
     return FGPU_OK;
 }

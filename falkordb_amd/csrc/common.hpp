@@ -181,6 +181,7 @@ struct fgpu_ctx {
     int comm_rank = 0, comm_nranks = 1;
     std::atomic<uint64_t> dist_self_calls{0};   // forced self collectives issued (dist_force_self)
     std::atomic<int> scan_active{0};            // lanes of whole-frontier calls running now (expand_count_scan)
+    std::atomic<uint32_t> bfs_cp_last{0};   // ... and the fused launches of that search that ran behind bfs_pb_list_kernel ("bfs_cp_last_mask")
     std::atomic<uint32_t> bfs_pb_last{0};   // levels the search fgpu_bfs_stats last read ran by propagation blocking ("bfs_pb_last_levels")
     std::atomic<uint32_t> scan_last_live{0}, scan_last_passes{0};   // the last such call: live source rows, passes ("expand_scan_*")
     std::atomic<uint64_t> expand_launches{0};   // kernels launched by fgpu_expand* (fgpu_get_option "expand_kernel_launches")

@@ -804,6 +804,7 @@ fgpu_info fgpu_get_option(fgpu_ctx* ctx, const char* name, int64_t* value) {
     else if (!strcmp(name, "expand_nt")) *value = ctx->opt.expand_nt;
     else if (!strcmp(name, "bfs_pb")) *value = ctx->opt.bfs_pb;
     else if (!strcmp(name, "bfs_pb_min_edges")) *value = ctx->opt.bfs_pb_min_edges;
+    else if (!strcmp(name, "bfs_cp_last_mask")) *value = ctx->bfs_cp_last.load(std::memory_order_relaxed);
     else if (!strcmp(name, "bfs_pb_last_levels")) *value = ctx->bfs_pb_last.load(std::memory_order_relaxed);
     else if (!strcmp(name, "expand_scan_last_live")) *value = ctx->scan_last_live.load(std::memory_order_relaxed);
     else if (!strcmp(name, "expand_scan_last_passes")) *value = ctx->scan_last_passes.load(std::memory_order_relaxed);

@@ -119,7 +119,8 @@ fgpu_info fgpu_set_option(fgpu_ctx* ctx, const char* name, int64_t value);
  * grouped self ncclSend / ncclRecv, ncclBroadcast and ncclAllReduce of a multi-rank exchange — tests/test_gpu_dist.py),
  * "dist_self_calls" (how many such calls ran), "expand_kernel_launches" (kernels launched by fgpu_expand* on this context so
  * far: the launch count of a batch is a difference of two reads), "bfs_pb_last_levels" (levels the search fgpu_bfs_stats last
- * read ran by propagation blocking), "expand_scan_last_live" / "expand_scan_last_passes" (live source rows and passes of the
+ * read ran by propagation blocking), "bfs_cp_last_mask" (bit k: fused launch k of that search ran behind the list kernel — a
+ * sparse frontier listed into the queue, or a pull of listed candidates), "expand_scan_last_live" / "expand_scan_last_passes" (live source rows and passes of the
  * last whole-frontier fgpu_expand_count).  Unknown names return FGPU_INVALID. */
 fgpu_info fgpu_get_option(fgpu_ctx* ctx, const char* name, int64_t* value);
 /* name[256]; returns CU count, wave size, LDS bytes per block, total HBM bytes. */

@@ -489,6 +489,43 @@ def test_bfs_heavy_push_levels_by_propagation_blocking(ctx, scale, min_edges, fo
         ctx.set_option("bfs_pb_min_edges", 2 << 20)
 
 
+def test_bfs_listed_frontiers_and_listed_candidate_pulls(ctx):
+    """The two other jobs of bfs_pb_list_kernel (plans with the propagation-blocking launches; forced on here): a push level
+    whose frontier is a sparse bitmap is listed into the queue first, and a pull level with few rows left to discover runs as
+    a pull of listed candidates (direction 4, bfs_lp_kernel) — every search against the oracle's levels, parents valid, and
+    `bfs_cp_last_mask` says that some of the searches took those paths."""
+    took = 0
+    try:
+        ctx.set_option("bfs_pb", 2)
+        ctx.set_option("bfs_pb_min_edges", 1 << 40)            # (no blocked push here: the other two paths alone)
+        for scale, ef in ((16, 16), (18, 8), (19, 4)):
+            a = oracle.rmat_csr(scale, ef)
+            A = up(ctx, a)
+            At = A.transpose()
+            deg = np.diff(a.rowptr)
+            roots = np.nonzero(deg > 0)[0]
+            roots = [int(roots[i]) for i in (0, len(roots) // 3, len(roots) // 2, len(roots) - 1)] + [int(np.argmax(deg))]
+            plan = engine.BfsPlan(ctx, A, At)
+            for rep in range(2):                                # (the second round runs with the launches the first one learnt)
+                for src in roots:
+                    ref_level, _, ref_edges = oracle.bfs(a, src, -1)
+                    want_parent = (src + rep) % 2 == 0
+                    plan.run(src, -1, want_parent=want_parent)
+                    level, parent = plan.fetch(want_parent=want_parent)
+                    check_bfs(a, level, parent, src, ref_level)
+                    st = plan.stats()
+                    assert st["edges_traversed"] == ref_edges
+                    assert st["reached"] == int(np.count_nonzero(ref_level >= 0))
+                    took += 1 if ctx.get_option("bfs_cp_last_mask") else 0
+            plan.free()
+            At.free()
+            A.free()
+        assert took > 0, "no search listed a frontier or a candidate set"
+    finally:
+        ctx.set_option("bfs_pb", 1)
+        ctx.set_option("bfs_pb_min_edges", 2 << 20)
+
+
 @pytest.mark.parametrize("max_level", [0, 1, 2, 3])
 def test_bfs_max_level(ctx, max_level):
     a = oracle.rmat_csr(12)
