@@ -44,6 +44,7 @@ constexpr unsigned QSEG = QCAP / QSHARDS;
 // discoveries through eight shard counters went 217 -> 965 us — same-address atomics, 5.6 ns each — and RMAT-22 0.198 -> 0.267
 // ms.  Appending is for light levels only.)
 constexpr unsigned long long QGATE = 1ull << 17;
+constexpr unsigned long long PULL_QGATE = 1ull << 12;   // a pull level appends when at most this many vertices with an in-edge are still unvisited
 constexpr unsigned PB_LMAX = 1u << 22;   // propagation blocking: frontiers of at most this many vertices (bfs_pb_prefix_kernel: 256 workgroups x 1024 threads x 16)
 constexpr unsigned PB_PPT = 16;          // ... positions per thread, strided by the grid (a small frontier spreads over the workgroups)
 constexpr unsigned PB_LWG = 256;         // workgroups of bfs_pb_list_kernel (a frontier that is not queue-listed: bitmap -> list)
@@ -1145,8 +1146,12 @@ __device__ void fused_ctrl(BfsCtrl* c, u32* host_done, bool slab, u32 nwg, u32 n
     // the next level may append its discoveries only if it is light: a push examines m_frontier
     // edges, a pull can discover at most the unvisited vertices
     const u64 unv = n_total > reached ? n_total - reached : 0;
+    // ... counted over the vertices that HAVE an in-edge where the plan knows them (60 % of an R-MAT graph's vertices have none and
+    // stay unvisited for ever: no pull of a large graph ever appended, and the one or two levels after the last pull walked the
+    // bitmap with the whole grid, 14-19 us each at RMAT-22, where a queue-mode level of a few hundred edges is 8).  The bound is
+    // small: a pull's appends are one returning add per discovery on eight counters (4 x 10^5 of them cost 750 us, NOTES_r06 section 15)
     c->q_open = nd == 4 ? (alive_unv <= (u64)(QCAP / 2) ? 1u : 0u)              // (bfs_lp_kernel appends a workgroup at a time)
-                        : ((!pb && (nd == 1 ? v1 : unv) <= QGATE) ? 1u : 0u);
+                        : ((!pb && ((nd == 1 ? v1 : unv) <= QGATE || (nd == 2 && alive_unv <= PULL_QGATE))) ? 1u : 0u);
     // workgroups the next launch needs: twice its work items (queue chunks + one per 1024 hub-row edges), at least 64 — and, when
     // the frontier may hold a hub row (>= PUSH_HUB_DEG edges to examine), enough to screen the static hub chunk list in two
     // rounds of 256 items a workgroup (3 x 10^5 items at RMAT-26: 64 workgroups took 18 rounds, 53 us for a level of 11 K edges)
